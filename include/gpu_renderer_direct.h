@@ -1,0 +1,70 @@
+/*
+ * gpu_renderer_direct.h -- C-ABI of libGPURendererDirect.so (MI355X / gfx950).
+ *
+ * Drop-in boundary for the reference's GPURendererDirect DLL.  The first four entry points are
+ * exactly what the reference's ctypes binding binds
+ * (SuperresolutionNetwork/inference/renderer.py:78-110); everything below "additive" is new and
+ * optional.  Plain pointers and sizes only -- no torch types cross this boundary.
+ *
+ * Semantics: the *values* written by render() follow the reference's CPU renderer
+ * (CPURenderer/IsoVolumeRayTracer.h, CPURenderer.cpp:468-567,726-737); the *layout* and the
+ * call protocol follow GPURendererDirect (render_kernel.cu:254-265).  See DESIGN.md section 2.
+ */
+#ifndef GPU_RENDERER_DIRECT_H
+#define GPU_RENDERER_DIRECT_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- the reference's four exports -------------------------------------------------------- */
+
+/* Replaces GPURendererDirect/GPURendererDirect.cpp:228-246.  Creates the process-global renderer
+ * state on the current HIP device.  Returns 0 (or -1 if no HIP device is usable). */
+int initGVDB(void);
+
+/* Replaces GPURendererDirect.cpp:248-285.  Loads a GVDB .vbx volume: 0 ok, -1 if the name does
+ * not end in ".vbx", -2 if loading fails.  Clears the previous volume and resets the "last
+ * camera" used for the flow channels (GPURendererDirect.cpp:280-281). */
+int loadGrid(const char* filename);
+
+/* Replaces GPURendererDirect.cpp:393-428.  Commands: fov|cameraFoV (1 double),
+ * cameraOrigin|cameraLookAt|cameraUp (3 doubles), resolution (2 ints), isovalue (1 double),
+ * unshaded (1 int, parsed and ignored as in the reference), aosamples (1 int), aoradius (1 float),
+ * viewport (4 ints minX,minY,maxX,maxY).  Values are comma separated decimals.
+ * Returns 0, or -1 for an unknown command or (unlike the reference, which lets a C++ exception
+ * escape) for a value of the wrong arity.
+ * Additive commands: ambient|diffuse|specular (3 doubles), exponent (1 int),
+ * light ("camera" or 3 doubles). */
+int setParameter(const char* cmd, const char* value);
+
+/* Replaces GPURendererDirect.cpp:430-446.  Synchronous.  Writes resolutionY*resolutionX*12 fp32
+ * (HWC; channels r,g,b,mask,nx,ny,nz,depth,flowx,flowy,ao,shadow) to caller-owned DEVICE memory
+ * and then stores the current camera as "last".  Returns seconds (launch + sync) or -1. */
+float render(unsigned long long devicePtr);
+
+/* ---- additive exports -------------------------------------------------------------------- */
+
+/* Load a dense fp32 volume ([z][y][x], value 0 = empty) from host or device memory.
+ * Same post-conditions as loadGrid.  0 ok, -2 on failure (empty volume, dims > 4096, no memory). */
+int isoLoadDenseHost(const float* hostData, int nx, int ny, int nz);
+int isoLoadDenseDevice(unsigned long long devicePtr, int nx, int ny, int nz);
+
+/* Launch the frame on `stream` (a hipStream_t, may be NULL) without synchronising; the "last
+ * camera" bookkeeping is identical to render().  Returns 0 or -1. */
+int isoRenderAsync(unsigned long long devicePtr, void* stream);
+
+/* info: [0..2] volume dims, [3] stored bricks, [4] leaf bricks, [5..7] node bbox min,
+ * [8..10] node bbox max, [11] bytes of brick storage (MiB), out_max = grid max value. */
+int isoGetVolumeInfo(int info[12], float* out_max);
+
+/* Kernel variant: 0 = per-ray global-memory gather, 1 = wave-cooperative LDS brick cache. */
+int isoSetKernelVariant(int variant);
+
+/* Release all device memory held by the renderer. */
+void isoShutdown(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,50 @@
+"""Locates, builds and loads the in-tree HIP shared libraries.
+
+The libraries are plain C-ABI (see ``include/*.h``) and are bound with ctypes.  They live in
+``isosurfacesuperresolution_amd/lib`` so that they travel with the source tree; nothing is
+installed into site-packages.  There is no CPU fallback: if a library is missing and cannot be
+built, loading raises.
+"""
+import ctypes
+import os
+import subprocess
+
+_PKG = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(_PKG, "csrc")
+LIBDIR = os.path.join(_PKG, "lib")
+RENDERER_LIB = os.path.join(LIBDIR, "libGPURendererDirect.so")
+SR_LIB = os.path.join(LIBDIR, "libisr_sr.so")
+
+_cache = {}
+
+
+def build(force=False, verbose=False):
+    """Compile every HIP extension for gfx950 (hipcc cross-compiles without a GPU)."""
+    cmd = ["make", "-C", CSRC, "all"]
+    if force:
+        cmd.insert(1, "-B")
+    out = None if verbose else subprocess.DEVNULL
+    subprocess.check_call(cmd, stdout=out)
+    return [RENDERER_LIB, SR_LIB]
+
+
+def _preload_hip_runtime():
+    # When torch is in the process its bundled libamdhip64 (SONAME libamdhip64.so.7) must be the
+    # one our libraries bind to, otherwise two HIP runtimes would own separate contexts.
+    try:
+        import torch  # noqa: F401  (import order is the point)
+    except ImportError:
+        pass
+
+
+def load(path):
+    if path in _cache:
+        return _cache[path]
+    if not os.path.exists(path):
+        build()
+    if not os.path.exists(path):
+        raise RuntimeError("native library %s is missing and could not be built" % path)
+    _preload_hip_runtime()
+    lib = ctypes.CDLL(path)
+    _cache[path] = lib
+    return lib

@@ -1,0 +1,470 @@
+// Host side of libGPURendererDirect.so: process-global renderer state, the reference's
+// string-keyed parameter protocol, volume upload (dense -> 9^3 apron bricks + occupancy
+// hierarchy, built on the GPU), camera/matrix set-up in fp64, launch and timing.
+//
+// Replaces GPURendererDirect/GPURendererDirect.cpp:34-446 (exports at :228-246, :248-285,
+// :393-428, :430-446).  Camera mathematics follow the CPU renderer, whose values this library
+// reproduces: TP/openvdb/tools/RayTracer.h:404-531, TP/openvdb/math/Mat.h:758-774,
+// TP/openvdb/math/Mat4.h:531-672, CPURenderer/CPURenderer.cpp:448-458,484-507.
+// Compiled with -ffp-contract=off (bit-exact camera constants vs. the CPU restatement).
+#include <hip/hip_runtime.h>
+
+#include <chrono>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/gpu_renderer_direct.h"
+#include "iso_params.h"
+#include "vbx_reader.h"
+
+namespace {
+
+struct Args {   // GPURendererDirect.cpp:103-128
+    int resolutionX = 512, resolutionY = 512;
+    double cameraFov = 45;
+    double cameraOrigin[3] = { 0, 0, -1 };
+    double cameraLookAt[3] = { 0, 0, 0 };
+    double cameraUp[3] = { 0, 1, 0 };
+    int noShading = 0;
+    int viewport[4] = { 0, 0, 512, 512 };
+    double isovalue = 0.0;
+    double materialDiffuse[3] = { 0.7, 0.7, 0.7 };
+    double materialSpecular[3] = { 1, 1, 1 };
+    double materialAmbient[3] = { 0.1, 0.1, 0.1 };
+    int materialSpecularExponent = 32;
+    bool cameraLight = true;
+    double lightDirection[3] = { 0, 0, 0 };
+    int aoSamples = 32;
+    float aoRadius = 0.01f;
+};
+
+struct Volume {
+    bool loaded = false;
+    int nx = 0, ny = 0, nz = 0, nbx = 0, nby = 0, nbz = 0, n1x = 0, n1y = 0, n1z = 0;
+    int nslots = 0, nleaf = 0;
+    int bbmin[3] = { 0, 0, 0 }, bbmax[3] = { 0, 0, 0 };
+    float maxValue = 0.f;
+    double s = 1, sinv = 1, t[3] = { 0, 0, 0 };
+    float* bricks = nullptr;
+    int32_t* slot = nullptr;
+    uint8_t* leaf = nullptr;
+    uint8_t* node1 = nullptr;
+};
+
+struct State {
+    bool initialised = false;
+    Args args;
+    double lastOrigin[3] = { 0, 0, -1 }, lastLookAt[3] = { 0, 0, 0 };
+    Volume vol;
+    int variant = 0;
+};
+State g;
+
+#define HIP_OK(expr)                                                                         \
+    do {                                                                                     \
+        hipError_t e_ = (expr);                                                              \
+        if (e_ != hipSuccess) {                                                              \
+            std::fprintf(stderr, "GPURendererDirect: HIP error '%s' in %s (%s:%d)\n",        \
+                         hipGetErrorString(e_), #expr, __FILE__, __LINE__);                  \
+            return false;                                                                    \
+        }                                                                                    \
+    } while (0)
+
+void freeVolume(Volume& v)
+{
+    if (v.bricks) (void)hipFree(v.bricks);
+    if (v.slot) (void)hipFree(v.slot);
+    if (v.leaf) (void)hipFree(v.leaf);
+    if (v.node1) (void)hipFree(v.node1);
+    v = Volume();
+}
+
+// ---- "a,b,c" parsing (GPURendererDirect.cpp:60-85); strict arity, no exceptions ------------
+bool splitNumbers(const char* s, int n, double* out)
+{
+    const char* p = s;
+    for (int k = 0; k < n; ++k) {
+        char* end = nullptr;
+        out[k] = std::strtod(p, &end);
+        if (end == p) return false;
+        while (*end == ' ' || *end == '\t') ++end;
+        if (k + 1 < n) {
+            if (*end != ',') return false;
+            p = end + 1;
+        } else if (*end != '\0' && *end != '\n' && *end != '\r') {
+            return false;
+        }
+    }
+    return true;
+}
+
+// ---- fp64 vector helpers with OpenVDB's operation order ------------------------------------
+inline double len3(const double a[3]) { return std::sqrt(a[0] * a[0] + a[1] * a[1] + a[2] * a[2]); }
+inline void unit3(const double a[3], double o[3])
+{
+    const double l = len3(a);
+    o[0] = a[0] / l; o[1] = a[1] / l; o[2] = a[2] / l;
+}
+inline void cross3(const double a[3], const double b[3], double o[3])
+{
+    o[0] = a[1] * b[2] - a[2] * b[1];
+    o[1] = a[2] * b[0] - a[0] * b[2];
+    o[2] = a[0] * b[1] - a[1] * b[0];
+}
+inline void normalize3(double a[3])
+{
+    const double d = len3(a);
+    if (!(std::fabs(d - 0.0) > 1.0e-7)) return;
+    const double r = 1.0 / d;
+    a[0] *= r; a[1] *= r; a[2] *= r;
+}
+
+void buildCamera(IsoCamera& c, const double origin[3], const double lookAt[3], const double up[3],
+                 double fov, int W, int H)
+{
+    const double aperture = 0.01;
+    const double focal = aperture / (2.0 * (std::tan(fov * M_PI / 360.0)));
+    c.sw = 0.5 * aperture / focal;
+    c.sh = c.sw * double(H) / double(W);
+    const double dir[3] = { origin[0] - lookAt[0], origin[1] - lookAt[1], origin[2] - lookAt[2] };
+    double fwd[3], upn[3], hor[3], upv[3], tmp[3];
+    unit3(dir, fwd);
+    unit3(up, upn);
+    cross3(upn, fwd, tmp); unit3(tmp, hor);
+    cross3(fwd, hor, tmp); unit3(tmp, upv);
+    for (int k = 0; k < 3; ++k) {
+        c.J[0][k] = hor[k]; c.J[1][k] = upv[k]; c.J[2][k] = fwd[k];
+        c.org[k] = origin[k];
+        c.d0[k] = 0.0 * hor[k] + 0.0 * upv[k] + (-1.0) * fwd[k];
+    }
+    const double (*m)[3] = c.J;
+    const double m0011 = m[0][0] * m[1][1], m0012 = m[0][0] * m[1][2], m0110 = m[0][1] * m[1][0];
+    const double m0210 = m[0][2] * m[1][0], m0120 = m[0][1] * m[2][0], m0220 = m[0][2] * m[2][0];
+    double detA = m0011 * m[2][2] - m0012 * m[2][1] - m0110 * m[2][2]
+                + m0210 * m[2][1] + m0120 * m[1][2] - m0220 * m[1][1];
+    detA = 1.0 / detA;
+    double (*inv)[4] = c.V;
+    inv[0][0] = detA * ( m[1][1] * m[2][2] - m[1][2] * m[2][1]);
+    inv[0][1] = detA * (-m[0][1] * m[2][2] + m[0][2] * m[2][1]);
+    inv[0][2] = detA * ( m[0][1] * m[1][2] - m[0][2] * m[1][1]);
+    inv[1][0] = detA * (-m[1][0] * m[2][2] + m[1][2] * m[2][0]);
+    inv[1][1] = detA * ( m[0][0] * m[2][2] - m0220);
+    inv[1][2] = detA * ( m0210 - m0012);
+    inv[2][0] = detA * ( m[1][0] * m[2][1] - m[1][1] * m[2][0]);
+    inv[2][1] = detA * ( m0120 - m[0][0] * m[2][1]);
+    inv[2][2] = detA * ( m0011 - m0110);
+    const double* o = c.org;
+    inv[3][0] = -(o[0] * inv[0][0] + o[1] * inv[1][0] + o[2] * inv[2][0]);
+    inv[3][1] = -(o[0] * inv[0][1] + o[1] * inv[1][1] + o[2] * inv[2][1]);
+    inv[3][2] = -(o[0] * inv[0][2] + o[1] * inv[1][2] + o[2] * inv[2][2]);
+    inv[0][3] = 0.0; inv[1][3] = 0.0; inv[2][3] = 0.0; inv[3][3] = 1.0;
+}
+
+float orderBitsToFloat(unsigned int u)
+{
+    u = (u & 0x80000000u) ? (u & 0x7fffffffu) : ~u;
+    float f;
+    std::memcpy(&f, &u, 4);
+    return f;
+}
+
+// Dense device volume -> bricks, occupancy hierarchy, bbox, max, world map.
+bool uploadFromDevice(const float* dense, int nx, int ny, int nz)
+{
+    if (nx <= 0 || ny <= 0 || nz <= 0 || nx > 4096 || ny > 4096 || nz > 4096) return false;
+    Volume v;
+    v.nx = nx; v.ny = ny; v.nz = nz;
+    v.nbx = (nx + 7) / 8; v.nby = (ny + 7) / 8; v.nbz = (nz + 7) / 8;
+    v.n1x = (nx + 127) / 128; v.n1y = (ny + 127) / 128; v.n1z = (nz + 127) / 128;
+    const size_t nb = size_t(v.nbx) * v.nby * v.nbz;
+    uint8_t *dFlag9 = nullptr;
+    int* dBBox = nullptr;
+    unsigned int* dMax = nullptr;
+    HIP_OK(hipMalloc(&dFlag9, nb));
+    HIP_OK(hipMalloc(&v.leaf, nb));
+    HIP_OK(hipMalloc(&dBBox, 6 * sizeof(int)));
+    HIP_OK(hipMalloc(&dMax, sizeof(unsigned int)));
+    const int bboxInit[6] = { INT32_MAX, INT32_MAX, INT32_MAX, INT32_MIN, INT32_MIN, INT32_MIN };
+    const unsigned int zero = 0;
+    HIP_OK(hipMemcpy(dBBox, bboxInit, sizeof(bboxInit), hipMemcpyHostToDevice));
+    HIP_OK(hipMemcpy(dMax, &zero, sizeof(zero), hipMemcpyHostToDevice));
+    iso_launch_brick_flags(dense, nx, ny, nz, v.nbx, v.nby, v.nbz, dFlag9, v.leaf, dBBox, dMax, nullptr);
+    HIP_OK(hipGetLastError());
+    std::vector<uint8_t> flag9(nb), leaf(nb);
+    int bbox[6];
+    unsigned int maxbits = 0;
+    HIP_OK(hipMemcpy(flag9.data(), dFlag9, nb, hipMemcpyDeviceToHost));
+    HIP_OK(hipMemcpy(leaf.data(), v.leaf, nb, hipMemcpyDeviceToHost));
+    HIP_OK(hipMemcpy(bbox, dBBox, sizeof(bbox), hipMemcpyDeviceToHost));
+    HIP_OK(hipMemcpy(&maxbits, dMax, sizeof(maxbits), hipMemcpyDeviceToHost));
+    (void)hipFree(dFlag9); (void)hipFree(dBBox); (void)hipFree(dMax);
+
+    // slot table (exclusive scan of flag9), leaf-level bbox, 128^3 node occupancy
+    std::vector<int32_t> slot(nb);
+    std::vector<uint8_t> node1(size_t(v.n1x) * v.n1y * v.n1z, 0);
+    int lmin[3] = { INT32_MAX, INT32_MAX, INT32_MAX }, lmax[3] = { INT32_MIN, INT32_MIN, INT32_MIN };
+    int nslots = 0, nleaf = 0;
+    for (int z = 0; z < v.nbz; ++z)
+        for (int y = 0; y < v.nby; ++y)
+            for (int x = 0; x < v.nbx; ++x) {
+                const size_t b = (size_t(z) * v.nby + y) * v.nbx + x;
+                slot[b] = flag9[b] ? nslots++ : -1;
+                if (leaf[b]) {
+                    ++nleaf;
+                    node1[(size_t(z >> 4) * v.n1y + (y >> 4)) * v.n1x + (x >> 4)] = 1;
+                    if (x < lmin[0]) lmin[0] = x; if (x > lmax[0]) lmax[0] = x;
+                    if (y < lmin[1]) lmin[1] = y; if (y > lmax[1]) lmax[1] = y;
+                    if (z < lmin[2]) lmin[2] = z; if (z > lmax[2]) lmax[2] = z;
+                }
+            }
+    if (nleaf == 0) {   // the reference throws on empty grids (IsoVolumeRayTracer.h:188-190)
+        freeVolume(v);
+        return false;
+    }
+    v.nslots = nslots; v.nleaf = nleaf;
+    for (int k = 0; k < 3; ++k) {   // IsoVolumeRayTracer.h:195-197
+        v.bbmin[k] = lmin[k] * 8;
+        v.bbmax[k] = lmax[k] * 8 + 7 + 1;
+    }
+    v.maxValue = orderBitsToFloat(maxbits);
+    // CPURenderer.cpp:448-458 with unit voxels: scale longest active-bbox edge to 1, centre at 0
+    double ext[3], cen[3];
+    for (int k = 0; k < 3; ++k) {
+        const double lo = double(bbox[k]), hi = double(bbox[3 + k]);
+        ext[k] = hi - lo;
+        cen[k] = (lo + hi) * 0.5;
+    }
+    double m = ext[0];
+    if (ext[1] > m) m = ext[1];
+    if (ext[2] > m) m = ext[2];
+    if (!(m > 0)) { freeVolume(v); return false; }
+    const double scale = 1.0 / m;
+    v.s = 1.0 * scale;
+    v.sinv = 1.0 / v.s;
+    for (int k = 0; k < 3; ++k) v.t[k] = (-cen[k]) * scale;
+
+    HIP_OK(hipMalloc(&v.slot, nb * sizeof(int32_t)));
+    HIP_OK(hipMalloc(&v.node1, node1.size()));
+    HIP_OK(hipMalloc(&v.bricks, size_t(nslots) * ISO_BRICK_STRIDE * sizeof(float)));
+    HIP_OK(hipMemcpy(v.slot, slot.data(), nb * sizeof(int32_t), hipMemcpyHostToDevice));
+    HIP_OK(hipMemcpy(v.node1, node1.data(), node1.size(), hipMemcpyHostToDevice));
+    iso_launch_brick_fill(dense, nx, ny, nz, v.nbx, v.nby, v.nbz, v.slot, v.bricks, nullptr);
+    HIP_OK(hipGetLastError());
+    HIP_OK(hipDeviceSynchronize());
+    v.loaded = true;
+    freeVolume(g.vol);
+    g.vol = v;
+    // GPURendererDirect.cpp:280-281
+    for (int k = 0; k < 3; ++k) { g.lastOrigin[k] = g.args.cameraOrigin[k]; g.lastLookAt[k] = g.args.cameraLookAt[k]; }
+    return true;
+}
+
+bool launchFrame(float* out, hipStream_t stream)
+{
+    const Args& a = g.args;
+    const Volume& v = g.vol;
+    if (!g.initialised || !v.loaded || !out || a.resolutionX <= 0 || a.resolutionY <= 0) return false;
+    IsoRenderParams p;
+    std::memset(&p, 0, sizeof(p));
+    IsoCamera last;
+    buildCamera(p.cam, a.cameraOrigin, a.cameraLookAt, a.cameraUp, a.cameraFov, a.resolutionX, a.resolutionY);
+    buildCamera(last, g.lastOrigin, g.lastLookAt, a.cameraUp, a.cameraFov, a.resolutionX, a.resolutionY);
+    std::memcpy(p.Vlast, last.V, sizeof(p.Vlast));
+    p.s = v.s; p.sinv = v.sinv;
+    for (int k = 0; k < 3; ++k) p.t[k] = v.t[k];
+    // CPURenderer.cpp:501-503,515-516: relative isovalue, narrowed through float
+    p.iso = double(float(a.isovalue * double(v.maxValue)));
+    double light[3];
+    for (int k = 0; k < 3; ++k) light[k] = a.cameraLight ? (a.cameraLookAt[k] - a.cameraOrigin[k]) : a.lightDirection[k];
+    normalize3(light);
+    for (int k = 0; k < 3; ++k) {
+        p.light[k] = light[k];
+        p.ambient[k] = a.materialAmbient[k];
+        p.diffuse[k] = a.materialDiffuse[k];
+        p.specular[k] = a.materialSpecular[k];
+        p.bbmin[k] = v.bbmin[k]; p.bbmax[k] = v.bbmax[k];
+    }
+    p.exponent = a.materialSpecularExponent;
+    p.spec_c1 = (a.materialSpecularExponent + 2) / (2 * M_PI);
+    p.W = a.resolutionX; p.H = a.resolutionY;
+    for (int k = 0; k < 4; ++k) p.vp[k] = a.viewport[k];
+    p.nx = v.nx; p.ny = v.ny; p.nz = v.nz;
+    p.nbx = v.nbx; p.nby = v.nby; p.nbz = v.nbz;
+    p.n1x = v.n1x; p.n1y = v.n1y; p.n1z = v.n1z;
+    p.any_leaf = v.nleaf > 0;
+    p.bricks = v.bricks; p.slot = v.slot; p.leaf = v.leaf; p.node1 = v.node1;
+    p.out = out;
+    iso_launch_render(p, g.variant, stream);
+    if (hipGetLastError() != hipSuccess) return false;
+    // GPURendererDirect.cpp:440-442: the camera just rendered becomes the flow reference
+    for (int k = 0; k < 3; ++k) { g.lastOrigin[k] = a.cameraOrigin[k]; g.lastLookAt[k] = a.cameraLookAt[k]; }
+    return true;
+}
+
+bool endsWith(const std::string& s, const char* suffix)
+{
+    const size_t n = std::strlen(suffix);
+    return s.size() >= n && s.compare(s.size() - n, n, suffix) == 0;
+}
+
+}  // namespace
+
+extern "C" {
+
+int initGVDB(void)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) {
+        std::fprintf(stderr, "GPURendererDirect: no HIP device available\n");
+        return -1;
+    }
+    if (hipFree(nullptr) != hipSuccess) return -1;   // create the context on the current device
+    if (!g.initialised) {
+        g.args = Args();
+        g.initialised = true;
+    }
+    return 0;
+}
+
+int loadGrid(const char* filename)
+{
+    if (!filename) return -1;
+    const std::string name(filename);
+    if (!endsWith(name, ".vbx")) {
+        std::printf("Error: Input must end in .vbx\n");
+        return -1;
+    }
+    if (!g.initialised) return -2;
+    std::vector<float> dense;
+    int nx = 0, ny = 0, nz = 0;
+    std::string err;
+    if (!vbx_read_dense(name.c_str(), dense, nx, ny, nz, err)) {
+        std::printf("Unable to load VBX file: %s\n", err.c_str());
+        return -2;
+    }
+    return isoLoadDenseHost(dense.data(), nx, ny, nz);
+}
+
+int setParameter(const char* cmd_, const char* value)
+{
+    if (!cmd_ || !value) return -1;
+    const std::string cmd(cmd_);
+    Args& a = g.args;
+    double d[4];
+    if (cmd == "fov" || cmd == "cameraFoV") {
+        if (!splitNumbers(value, 1, d)) return -1;
+        a.cameraFov = d[0];
+    } else if (cmd == "cameraOrigin") {
+        if (!splitNumbers(value, 3, d)) return -1;
+        for (int k = 0; k < 3; ++k) a.cameraOrigin[k] = d[k];
+    } else if (cmd == "cameraLookAt") {
+        if (!splitNumbers(value, 3, d)) return -1;
+        for (int k = 0; k < 3; ++k) a.cameraLookAt[k] = d[k];
+    } else if (cmd == "cameraUp") {
+        if (!splitNumbers(value, 3, d)) return -1;
+        for (int k = 0; k < 3; ++k) a.cameraUp[k] = d[k];
+    } else if (cmd == "resolution") {
+        if (!splitNumbers(value, 2, d)) return -1;
+        a.resolutionX = int(d[0]); a.resolutionY = int(d[1]);
+    } else if (cmd == "isovalue") {
+        if (!splitNumbers(value, 1, d)) return -1;
+        a.isovalue = d[0];
+    } else if (cmd == "unshaded") {
+        if (!splitNumbers(value, 1, d)) return -1;
+        a.noShading = int(d[0]);
+    } else if (cmd == "aosamples") {
+        if (!splitNumbers(value, 1, d)) return -1;
+        a.aoSamples = int(d[0]);
+    } else if (cmd == "aoradius") {
+        if (!splitNumbers(value, 1, d)) return -1;
+        a.aoRadius = float(d[0]);
+    } else if (cmd == "viewport") {
+        if (!splitNumbers(value, 4, d)) return -1;
+        for (int k = 0; k < 4; ++k) a.viewport[k] = int(d[k]);
+    } else if (cmd == "ambient" || cmd == "diffuse" || cmd == "specular") {   // additive
+        if (!splitNumbers(value, 3, d)) return -1;
+        double* dst = cmd == "ambient" ? a.materialAmbient : (cmd == "diffuse" ? a.materialDiffuse : a.materialSpecular);
+        for (int k = 0; k < 3; ++k) dst[k] = d[k];
+    } else if (cmd == "exponent") {                                            // additive
+        if (!splitNumbers(value, 1, d)) return -1;
+        a.materialSpecularExponent = int(d[0]);
+    } else if (cmd == "light") {                                               // additive
+        if (std::strcmp(value, "camera") == 0) a.cameraLight = true;
+        else {
+            if (!splitNumbers(value, 3, d)) return -1;
+            a.cameraLight = false;
+            for (int k = 0; k < 3; ++k) a.lightDirection[k] = d[k];
+        }
+    } else {
+        std::printf("Unknown command: '%s', exit\n", cmd_);
+        return -1;
+    }
+    return 0;
+}
+
+float render(unsigned long long devicePtr)
+{
+    if (hipDeviceSynchronize() != hipSuccess) return -1.f;
+    const auto start = std::chrono::high_resolution_clock::now();
+    if (!launchFrame(reinterpret_cast<float*>(devicePtr), nullptr)) return -1.f;
+    if (hipDeviceSynchronize() != hipSuccess) {
+        std::fprintf(stderr, "GPURendererDirect: kernel failed: %s\n", hipGetErrorString(hipGetLastError()));
+        return -1.f;
+    }
+    const auto finish = std::chrono::high_resolution_clock::now();
+    return float(std::chrono::duration<double>(finish - start).count());
+}
+
+int isoRenderAsync(unsigned long long devicePtr, void* stream)
+{
+    return launchFrame(reinterpret_cast<float*>(devicePtr), static_cast<hipStream_t>(stream)) ? 0 : -1;
+}
+
+int isoLoadDenseDevice(unsigned long long devicePtr, int nx, int ny, int nz)
+{
+    if (!g.initialised || !devicePtr) return -2;
+    return uploadFromDevice(reinterpret_cast<const float*>(devicePtr), nx, ny, nz) ? 0 : -2;
+}
+
+int isoLoadDenseHost(const float* hostData, int nx, int ny, int nz)
+{
+    if (!g.initialised || !hostData || nx <= 0 || ny <= 0 || nz <= 0) return -2;
+    float* dense = nullptr;
+    const size_t bytes = size_t(nx) * ny * nz * sizeof(float);
+    if (hipMalloc(&dense, bytes) != hipSuccess) return -2;
+    if (hipMemcpy(dense, hostData, bytes, hipMemcpyHostToDevice) != hipSuccess) { (void)hipFree(dense); return -2; }
+    const bool ok = uploadFromDevice(dense, nx, ny, nz);
+    (void)hipFree(dense);
+    return ok ? 0 : -2;
+}
+
+int isoGetVolumeInfo(int info[12], float* out_max)
+{
+    const Volume& v = g.vol;
+    if (!v.loaded) return -1;
+    info[0] = v.nx; info[1] = v.ny; info[2] = v.nz;
+    info[3] = v.nslots; info[4] = v.nleaf;
+    for (int k = 0; k < 3; ++k) { info[5 + k] = v.bbmin[k]; info[8 + k] = v.bbmax[k]; }
+    info[11] = int((size_t(v.nslots) * ISO_BRICK_STRIDE * sizeof(float)) >> 20);
+    if (out_max) *out_max = v.maxValue;
+    return 0;
+}
+
+int isoSetKernelVariant(int variant)
+{
+    if (variant < 0 || variant > 1) return -1;
+    g.variant = variant;
+    return 0;
+}
+
+void isoShutdown(void)
+{
+    freeVolume(g.vol);
+    g.initialised = false;
+}
+
+}  // extern "C"

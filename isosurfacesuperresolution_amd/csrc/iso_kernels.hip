@@ -1,0 +1,447 @@
+// Isosurface ray-march kernels for MI355X (gfx950, wave64).
+//
+// What is computed (values): the reference's CPU tracer -- hierarchical DDA over 4096/128/8-voxel
+// nodes, voxel DDA with zero-crossing test and 5 bisection steps, node-centred trilinear
+// interpolation, +-1 voxel central-difference normal, two-sided Phong, camera-space flow
+// (CPURenderer/IsoVolumeRayTracer.h:37-46,81-114,274-309,502-551; PhongShader.h:27-38;
+//  CPURenderer.cpp:726-737).  Layout of the result: GPURendererDirect's interleaved HWC
+// 12-channel buffer (GPURendererDirect/render_kernel.cu:254-265).
+//
+// How (MI355X-native, nothing in common with the CUDA/GVDB kernel): the volume lives in HBM as
+// 9^3 "apron bricks" (8^3 voxels + the +1 layer trilinear needs), one wave64 owns one 8x8 pixel
+// tile, ray state is fp64 (78 TF/s vector fp64 on CDNA4 makes the reference's double DDA
+// affordable), samples are fp32.  This TU is compiled with -ffp-contract=off: the hit mask must be
+// bit-identical to the IEEE CPU restatement, so no FMA contraction is allowed here.
+//
+// Variant 0: every lane gathers its 8 corners from the brick in global memory (L2/MALL resident).
+// Variant 1: the wave cooperatively stages the brick most lanes need into LDS (ballot vote),
+//            lanes whose ray is inside that brick march out of LDS; see iso_render_lds below.
+#include <hip/hip_runtime.h>
+#include <float.h>
+#include <stdint.h>
+
+#include "iso_params.h"
+
+namespace {
+
+struct Ray {
+    double ex, ey, ez, dx, dy, dz, ix, iy, iz, t0, t1;
+};
+
+struct DDA {
+    double t0, t1, nx, ny, nz, dx, dy, dz;
+    int vx, vy, vz, sx, sy, sz;
+};
+
+__device__ __forceinline__ void ray_at(const Ray& r, double t, double& px, double& py, double& pz)
+{
+    px = r.ex + r.dx * t;
+    py = r.ey + r.dy * t;
+    pz = r.ez + r.dz * t;
+}
+
+// TP/openvdb/math/DDA.h:79-103
+template <int LOG2DIM>
+__device__ __forceinline__ void dda_init(DDA& d, const Ray& r)
+{
+    constexpr int DIM = 1 << LOG2DIM;
+    d.t0 = r.t0;
+    d.t1 = r.t1;
+    double px, py, pz;
+    ray_at(r, d.t0, px, py, pz);
+    d.vx = ((int)floor(px)) & (~(DIM - 1));
+    d.vy = ((int)floor(py)) & (~(DIM - 1));
+    d.vz = ((int)floor(pz)) & (~(DIM - 1));
+#define ISO_AXIS(V, S, N, D, P, DIR, INV)                                   \
+    if (DIR == 0.0) { S = 0; N = DBL_MAX; D = DBL_MAX; }                      \
+    else if (INV > 0) { S = DIM; N = d.t0 + ((double)(V + DIM) - P) * INV; D = (double)S * INV; } \
+    else { S = -DIM; N = d.t0 + ((double)V - P) * INV; D = (double)S * INV; }
+    ISO_AXIS(d.vx, d.sx, d.nx, d.dx, px, r.dx, r.ix)
+    ISO_AXIS(d.vy, d.sy, d.ny, d.dy, py, r.dy, r.iy)
+    ISO_AXIS(d.vz, d.sz, d.nz, d.dz, pz, r.dz, r.iz)
+#undef ISO_AXIS
+}
+
+// TP/openvdb/math/DDA.h:139 with Math.h:623-626
+__device__ __forceinline__ double dda_next(const DDA& d)
+{
+    double a = d.t1 < d.nx ? d.t1 : d.nx;
+    double b = d.ny < d.nz ? d.ny : d.nz;
+    return b < a ? b : a;
+}
+
+// TP/openvdb/math/DDA.h:111-117 with the MinIndex tie table of Math.h:893-902
+__device__ __forceinline__ bool dda_step(DDA& d)
+{
+    const int key = ((d.nx < d.ny) << 2) + ((d.nx < d.nz) << 1) + (d.ny < d.nz);
+    if (key >= 6) { d.t0 = d.nx; d.nx += d.dx; d.vx += d.sx; }
+    else if (key == 1 || key == 3) { d.t0 = d.ny; d.ny += d.dy; d.vy += d.sy; }
+    else { d.t0 = d.nz; d.nz += d.dz; d.vz += d.sz; }
+    return d.t0 <= d.t1;
+}
+
+// ---- volume access -------------------------------------------------------------------------
+
+__device__ __forceinline__ float voxel_value(const IsoRenderParams& P, int x, int y, int z)
+{
+    if ((unsigned)x >= (unsigned)P.nx || (unsigned)y >= (unsigned)P.ny || (unsigned)z >= (unsigned)P.nz) return 0.0f;
+    const int s = P.slot[((z >> 3) * P.nby + (y >> 3)) * P.nbx + (x >> 3)];
+    if (s < 0) return 0.0f;
+    return P.bricks[(size_t)s * ISO_BRICK_STRIDE + ((z & 7) * 9 + (y & 7)) * 9 + (x & 7)];
+}
+
+// TP/openvdb/math/Stencils.h:335-354 -- nested lerps z, then y, then x, all in float
+__device__ __forceinline__ float trilerp(float V000, float V001, float V010, float V011,
+                                         float V100, float V101, float V110, float V111,
+                                         float u, float v, float w)
+{
+    float A = V000 + (V001 - V000) * w;
+    float B = V010 + (V011 - V010) * w;
+    float C = A + (B - A) * v;
+    A = V100 + (V101 - V100) * w;
+    B = V110 + (V111 - V110) * w;
+    float D = A + (B - A) * v;
+    return C + (D - C) * u;
+}
+
+__device__ __forceinline__ float interp_from_brick(const float* __restrict__ b, int lx, int ly, int lz, float u, float v, float w)
+{
+    const float* q = b + (lz * 9 + ly) * 9 + lx;
+    return trilerp(q[0], q[81], q[9], q[90], q[1], q[82], q[10], q[91], u, v, w);
+}
+
+// Trilinear sample at index-space position (px,py,pz); Stencils.h:110-114 (cell = floor of the
+// double position, fractions from the float-narrowed position).
+__device__ __forceinline__ float interp_global(const IsoRenderParams& P, double px, double py, double pz)
+{
+    const int cx = (int)floor(px), cy = (int)floor(py), cz = (int)floor(pz);
+    const float u = (float)px - (float)cx;
+    const float v = (float)py - (float)cy;
+    const float w = (float)pz - (float)cz;
+    if ((unsigned)cx < (unsigned)P.nx && (unsigned)cy < (unsigned)P.ny && (unsigned)cz < (unsigned)P.nz) {
+        const int s = P.slot[((cz >> 3) * P.nby + (cy >> 3)) * P.nbx + (cx >> 3)];
+        if (s < 0) return 0.0f;   // all 27 candidate corners are zero: 0 + (0-0)*w ... == +0
+        return interp_from_brick(P.bricks + (size_t)s * ISO_BRICK_STRIDE, cx & 7, cy & 7, cz & 7, u, v, w);
+    }
+    // cell on or outside the low/high border of the grid: per-corner fetch (background 0 outside)
+    return trilerp(voxel_value(P, cx, cy, cz), voxel_value(P, cx, cy, cz + 1),
+                   voxel_value(P, cx, cy + 1, cz), voxel_value(P, cx, cy + 1, cz + 1),
+                   voxel_value(P, cx + 1, cy, cz), voxel_value(P, cx + 1, cy, cz + 1),
+                   voxel_value(P, cx + 1, cy + 1, cz), voxel_value(P, cx + 1, cy + 1, cz + 1), u, v, w);
+}
+
+// IsoVolumeRayTracer.h:66-71 (float - double -> double -> float)
+__device__ __forceinline__ float interp_value(const IsoRenderParams& P, const Ray& r, double t)
+{
+    double px, py, pz;
+    ray_at(r, t, px, py, pz);
+    return (float)((double)interp_global(P, px, py, pz) - P.iso);
+}
+
+__device__ __forceinline__ bool has_leaf(const IsoRenderParams& P, int x, int y, int z)
+{
+    if ((unsigned)x >= (unsigned)P.nx || (unsigned)y >= (unsigned)P.ny || (unsigned)z >= (unsigned)P.nz) return false;
+    return P.leaf[((z >> 3) * P.nby + (y >> 3)) * P.nbx + (x >> 3)] != 0;
+}
+__device__ __forceinline__ bool has_node1(const IsoRenderParams& P, int x, int y, int z)
+{
+    if ((unsigned)x >= (unsigned)P.nx || (unsigned)y >= (unsigned)P.ny || (unsigned)z >= (unsigned)P.nz) return false;
+    return P.node1[((z >> 7) * P.n1y + (y >> 7)) * P.n1x + (x >> 7)] != 0;
+}
+__device__ __forceinline__ bool has_node2(const IsoRenderParams& P, int x, int y, int z)
+{
+    return P.any_leaf && x == 0 && y == 0 && z == 0;
+}
+
+// IsoVolumeRayTracer.h:81-114
+__device__ __forceinline__ bool hits_voxel(const IsoRenderParams& P, const Ray& ray, double& time)
+{
+    DDA d;
+    dda_init<0>(d, ray);
+    double t0 = d.t0;
+    float v0 = interp_value(P, ray, t0);
+    do {
+        double t1 = dda_next(d);
+        float v1 = interp_value(P, ray, t1);
+        if (v0 * v1 <= 0.0f) {
+            double t = 0.5 * (t0 + t1);
+            for (int i = 0; i < 5; ++i) {
+                float v2 = interp_value(P, ray, t);
+                if (v0 * v2 <= 0.0f) t1 = t;
+                else { t0 = t; v0 = v2; }
+                t = 0.5 * (t0 + t1);
+            }
+            time = t;
+            return true;
+        }
+        t0 = t1;
+        v0 = v1;
+    } while (dda_step(d));
+    return false;
+}
+
+// IsoVolumeRayTracer.h:37-46 for node sizes 4096, 128, 8
+__device__ bool hits_hierarchy(const IsoRenderParams& P, Ray& ray, double& time)
+{
+    DDA d2;
+    dda_init<12>(d2, ray);
+    do {
+        if (has_node2(P, d2.vx, d2.vy, d2.vz)) {
+            ray.t0 = d2.t0; ray.t1 = dda_next(d2);
+            DDA d1;
+            dda_init<7>(d1, ray);
+            do {
+                if (has_node1(P, d1.vx, d1.vy, d1.vz)) {
+                    ray.t0 = d1.t0; ray.t1 = dda_next(d1);
+                    DDA d0;
+                    dda_init<3>(d0, ray);
+                    do {
+                        if (has_leaf(P, d0.vx, d0.vy, d0.vz)) {
+                            ray.t0 = d0.t0; ray.t1 = dda_next(d0);
+                            if (hits_voxel(P, ray, time)) return true;
+                        }
+                    } while (dda_step(d0));
+                }
+            } while (dda_step(d1));
+        }
+    } while (dda_step(d2));
+    return false;
+}
+
+__device__ __forceinline__ double len3(double x, double y, double z) { return sqrt(x * x + y * y + z * z); }
+
+// Vec3::normalize(eps = 1e-7), TP/openvdb/math/Vec3.h:377-385
+__device__ __forceinline__ void normalize3(double& x, double& y, double& z)
+{
+    const double d = len3(x, y, z);
+    if (!(fabs(d - 0.0) > 1.0e-7)) return;
+    const double r = 1.0 / d;
+    x *= r; y *= r; z *= r;
+}
+
+// PerspectiveCamera::getRay + Ray::worldToIndex + Ray::clip
+// (TP/openvdb/tools/RayTracer.h:444-448,507-516; TP/openvdb/math/Ray.h:177-185,260-293)
+__device__ __forceinline__ bool make_ray(const IsoRenderParams& P, int i, int j, Ray& r, double& wdx, double& wdy, double& wdz)
+{
+    const IsoCamera& c = P.cam;
+    const double ds0 = (2 * ((double)i + 0.5) / (double)P.W - 1) * c.sw;
+    const double ds1 = (1 - 2 * ((double)j + 0.5) / (double)P.H) * c.sh;
+    const double ds2 = -1.0;
+    double dx = ds0 * c.J[0][0] + ds1 * c.J[1][0] + ds2 * c.J[2][0];
+    double dy = ds0 * c.J[0][1] + ds1 * c.J[1][1] + ds2 * c.J[2][1];
+    double dz = ds0 * c.J[0][2] + ds1 * c.J[1][2] + ds2 * c.J[2][2];
+    normalize3(dx, dy, dz);
+    wdx = dx; wdy = dy; wdz = dz;
+    const double sc = 1.0 / (dx * c.d0[0] + dy * c.d0[1] + dz * c.d0[2]);
+    const double wt0 = 1e-3 * sc, wt1 = DBL_MAX * sc;
+    r.ex = (c.org[0] - P.t[0]) * P.sinv;
+    r.ey = (c.org[1] - P.t[1]) * P.sinv;
+    r.ez = (c.org[2] - P.t[2]) * P.sinv;
+    const double ix = dx * P.sinv, iy = dy * P.sinv, iz = dz * P.sinv;
+    const double len = len3(ix, iy, iz);
+    r.dx = ix / len; r.dy = iy / len; r.dz = iz / len;
+    r.ix = 1.0 / r.dx; r.iy = 1.0 / r.dy; r.iz = 1.0 / r.dz;
+    double t0 = len * wt0, t1 = len * wt1;
+#define ISO_SLAB(MIN, MAX, E, INV)                                 \
+    {                                                              \
+        double a = ((double)(MIN) - E) * INV;                      \
+        double b = ((double)(MAX) - E) * INV;                      \
+        if (a > b) { double s_ = a; a = b; b = s_; }               \
+        if (a > t0) t0 = a;                                        \
+        if (b < t1) t1 = b;                                        \
+        if (t0 > t1) return false;                                 \
+    }
+    ISO_SLAB(P.bbmin[0], P.bbmax[0], r.ex, r.ix)
+    ISO_SLAB(P.bbmin[1], P.bbmax[1], r.ey, r.iy)
+    ISO_SLAB(P.bbmin[2], P.bbmax[2], r.ez, r.iz)
+#undef ISO_SLAB
+    r.t0 = t0; r.t1 = t1;
+    return true;
+}
+
+// Everything after the hit time is known: position, normal, Phong, depth, flow
+// (IsoVolumeRayTracer.h:274-292,300-307,519-548; PhongShader.h:27-38; CPURenderer.cpp:726-737)
+__device__ __forceinline__ void shade_hit(const IsoRenderParams& P, const Ray& r, double it,
+                                          double wdx, double wdy, double wdz, float o[12])
+{
+    double ipx, ipy, ipz;
+    ray_at(r, it, ipx, ipy, ipz);
+    const double wx = ipx * P.s + P.t[0], wy = ipy * P.s + P.t[1], wz = ipz * P.s + P.t[2];
+    double nx = (double)interp_global(P, ipx + 1.0, ipy + 0.0, ipz + 0.0);
+    nx -= (double)interp_global(P, ipx - 1.0, ipy - 0.0, ipz - 0.0);
+    double ny = (double)interp_global(P, ipx + 0.0, ipy + 1.0, ipz + 0.0);
+    ny -= (double)interp_global(P, ipx - 0.0, ipy - 1.0, ipz - 0.0);
+    double nz = (double)interp_global(P, ipx + 0.0, ipy + 0.0, ipz + 1.0);
+    nz -= (double)interp_global(P, ipx - 0.0, ipy - 0.0, ipz - 1.0);
+    normalize3(nx, ny, nz);
+    const double wtime = it * len3(r.dx * P.s, r.dy * P.s, r.dz * P.s);
+
+    const double ndl = nx * P.light[0] + ny * P.light[1] + nz * P.light[2];
+    const double andl = fabs(ndl);
+    double c0 = P.ambient[0], c1 = P.ambient[1], c2 = P.ambient[2];
+    c0 += P.diffuse[0] * andl; c1 += P.diffuse[1] * andl; c2 += P.diffuse[2] * andl;
+    const double two = 2 * ndl;
+    const double rx = two * nx - P.light[0], ry = two * ny - P.light[1], rz = two * nz - P.light[2];
+    const double rd = rx * wdx + ry * wdy + rz * wdz;
+    double x = rd > 0.0 ? rd : 0.0;
+    double pw = 1.0;
+    int e = P.exponent;
+    if (e < 0) { e = -e; x = 1.0 / x; }
+    while (e--) pw *= x;
+    c0 += (P.specular[0] * P.spec_c1) * pw;
+    c1 += (P.specular[1] * P.spec_c1) * pw;
+    c2 += (P.specular[2] * P.spec_c1) * pw;
+    o[0] = (float)c0; o[1] = (float)c1; o[2] = (float)c2;
+    o[3] = (wtime == 0) ? 0.0f : 1.0f;
+    if (wtime > 0) {
+        const double (*V)[4] = P.cam.V;
+        double n0 = nx * V[0][0] + ny * V[1][0] + nz * V[2][0];
+        double n1 = nx * V[0][1] + ny * V[1][1] + nz * V[2][1];
+        double n2 = nx * V[0][2] + ny * V[1][2] + nz * V[2][2];
+        if (n2 < 0) { n0 = -n0; n1 = -n1; n2 = -n2; }
+        o[4] = (float)n0; o[5] = (float)n1; o[6] = (float)n2; o[7] = (float)wtime;
+        const double (*L)[4] = P.Vlast;
+        const double cx = wx * V[0][0] + wy * V[1][0] + wz * V[2][0] + 1.0 * V[3][0];
+        const double cy = wx * V[0][1] + wy * V[1][1] + wz * V[2][1] + 1.0 * V[3][1];
+        const double cw = wx * V[0][3] + wy * V[1][3] + wz * V[2][3] + 1.0 * V[3][3];
+        const double lx = wx * L[0][0] + wy * L[1][0] + wz * L[2][0] + 1.0 * L[3][0];
+        const double ly = wx * L[0][1] + wy * L[1][1] + wz * L[2][1] + 1.0 * L[3][1];
+        const double lw = wx * L[0][3] + wy * L[1][3] + wz * L[2][3] + 1.0 * L[3][3];
+        o[8] = -(float)(lx / lw - cx / cw);
+        o[9] = -(float)(ly / lw - cy / cw);
+    }
+}
+
+__device__ __forceinline__ void store_pixel(const IsoRenderParams& P, int i, int j, const float o[12])
+{
+    float4* dst = reinterpret_cast<float4*>(P.out + ((size_t)j * P.W + i) * 12);
+    dst[0] = make_float4(o[0], o[1], o[2], o[3]);
+    dst[1] = make_float4(o[4], o[5], o[6], o[7]);
+    dst[2] = make_float4(o[8], o[9], o[10], o[11]);
+}
+
+// XCD-aware tile order: blocks b and b+8 share an XCD/L2, so give each XCD a contiguous run of
+// tiles (neighbouring pixel tiles walk the same bricks).  Bijective for any tile count.
+__device__ __forceinline__ int xcd_remap(int bid, int nwg)
+{
+    const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
+    return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+}
+
+// ---- variant 0: per-lane gather ------------------------------------------------------------
+__global__ __launch_bounds__(64) void iso_render_gather(const IsoRenderParams P)
+{
+    const int tiles_x = (P.W + 7) >> 3, tiles_y = (P.H + 7) >> 3;
+    const int tile = xcd_remap(blockIdx.x, tiles_x * tiles_y);
+    const int lane = threadIdx.x;
+    const int i = (tile % tiles_x) * 8 + (lane & 7);
+    const int j = (tile / tiles_x) * 8 + (lane >> 3);
+    if (i >= P.W || j >= P.H) return;
+    float o[12] = { 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 1.0f, 0.f };
+    const bool inside = i >= P.vp[0] && j >= P.vp[1] && i < P.vp[2] && j < P.vp[3];
+    if (inside) {
+        o[8] = -0.0f; o[9] = -0.0f;
+        Ray r;
+        double wdx, wdy, wdz, it;
+        if (make_ray(P, i, j, r, wdx, wdy, wdz) && hits_hierarchy(P, r, it))
+            shade_hit(P, r, it, wdx, wdy, wdz, o);
+    }
+    store_pixel(P, i, j, o);
+}
+
+// ---- brick builder -------------------------------------------------------------------------
+// One 64-lane workgroup per 8^3 brick position.  flag9: any non-zero among the 9^3 apron values
+// (brick must be stored); leaf: any non-zero among the 8^3 own voxels (OpenVDB leaf exists);
+// bbox6 / maxbits: active-voxel bbox and maximum (grid->evalMinMax, CPURenderer.cpp:501-502).
+__device__ __forceinline__ unsigned int float_order_bits(float f)
+{
+    unsigned int u = __float_as_uint(f);
+    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+
+__global__ __launch_bounds__(64) void iso_brick_flags(const float* __restrict__ dense, int nx, int ny, int nz,
+                                                     int nbx, int nby, int nbz,
+                                                     uint8_t* flag9, uint8_t* leaf, int* bbox6, unsigned int* maxbits)
+{
+    const int b = blockIdx.x;
+    const int bx = b % nbx, by = (b / nbx) % nby, bz = b / (nbx * nby);
+    const int lane = threadIdx.x;
+    bool any9 = false, any8 = false;
+    int mnx = INT32_MAX, mny = INT32_MAX, mnz = INT32_MAX, mxx = INT32_MIN, mxy = INT32_MIN, mxz = INT32_MIN;
+    unsigned int mb = 0;
+    for (int k = lane; k < ISO_BRICK_VALUES; k += 64) {
+        const int lx = k % 9, ly = (k / 9) % 9, lz = k / 81;
+        const int x = bx * 8 + lx, y = by * 8 + ly, z = bz * 8 + lz;
+        float f = 0.0f;
+        if (x < nx && y < ny && z < nz) f = dense[((size_t)z * ny + y) * nx + x];
+        if (f != 0.0f) {
+            any9 = true;
+            if (lx < 8 && ly < 8 && lz < 8) {
+                any8 = true;
+                mnx = min(mnx, x); mny = min(mny, y); mnz = min(mnz, z);
+                mxx = max(mxx, x); mxy = max(mxy, y); mxz = max(mxz, z);
+                mb = max(mb, float_order_bits(f));
+            }
+        }
+    }
+    const unsigned long long m9 = __ballot(any9), m8 = __ballot(any8);
+    if (m8) {
+        for (int off = 32; off > 0; off >>= 1) {
+            mnx = min(mnx, __shfl_xor(mnx, off)); mny = min(mny, __shfl_xor(mny, off)); mnz = min(mnz, __shfl_xor(mnz, off));
+            mxx = max(mxx, __shfl_xor(mxx, off)); mxy = max(mxy, __shfl_xor(mxy, off)); mxz = max(mxz, __shfl_xor(mxz, off));
+            mb = max(mb, (unsigned int)__shfl_xor((int)mb, off));
+        }
+    }
+    if (lane == 0) {
+        flag9[b] = m9 ? 1 : 0;
+        leaf[b] = m8 ? 1 : 0;
+        if (m8) {
+            atomicMin(&bbox6[0], mnx); atomicMin(&bbox6[1], mny); atomicMin(&bbox6[2], mnz);
+            atomicMax(&bbox6[3], mxx); atomicMax(&bbox6[4], mxy); atomicMax(&bbox6[5], mxz);
+            atomicMax(maxbits, mb);
+        }
+    }
+}
+
+__global__ __launch_bounds__(64) void iso_brick_fill(const float* __restrict__ dense, int nx, int ny, int nz,
+                                                    int nbx, int nby, int nbz,
+                                                    const int32_t* __restrict__ slot, float* __restrict__ bricks)
+{
+    const int b = blockIdx.x;
+    const int s = slot[b];
+    if (s < 0) return;
+    const int bx = b % nbx, by = (b / nbx) % nby, bz = b / (nbx * nby);
+    float* dst = bricks + (size_t)s * ISO_BRICK_STRIDE;
+    for (int k = threadIdx.x; k < ISO_BRICK_STRIDE; k += 64) {
+        float f = 0.0f;
+        if (k < ISO_BRICK_VALUES) {
+            const int lx = k % 9, ly = (k / 9) % 9, lz = k / 81;
+            const int x = bx * 8 + lx, y = by * 8 + ly, z = bz * 8 + lz;
+            if (x < nx && y < ny && z < nz) f = dense[((size_t)z * ny + y) * nx + x];
+        }
+        dst[k] = f;
+    }
+}
+
+}  // namespace
+
+void iso_launch_render(const IsoRenderParams& p, int variant, void* stream)
+{
+    const int tiles = ((p.W + 7) >> 3) * ((p.H + 7) >> 3);
+    (void)variant;
+    hipLaunchKernelGGL(iso_render_gather, dim3(tiles), dim3(64), 0, (hipStream_t)stream, p);
+}
+
+void iso_launch_brick_flags(const float* dense, int nx, int ny, int nz, int nbx, int nby, int nbz,
+                            uint8_t* flag9, uint8_t* leaf, int* bbox6, unsigned int* maxbits, void* stream)
+{
+    hipLaunchKernelGGL(iso_brick_flags, dim3(nbx * nby * nbz), dim3(64), 0, (hipStream_t)stream,
+                       dense, nx, ny, nz, nbx, nby, nbz, flag9, leaf, bbox6, maxbits);
+}
+
+void iso_launch_brick_fill(const float* dense, int nx, int ny, int nz, int nbx, int nby, int nbz,
+                           const int32_t* slot, float* bricks, void* stream)
+{
+    hipLaunchKernelGGL(iso_brick_fill, dim3(nbx * nby * nbz), dim3(64), 0, (hipStream_t)stream,
+                       dense, nx, ny, nz, nbx, nby, nbz, slot, bricks);
+}

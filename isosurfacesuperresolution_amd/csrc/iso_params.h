@@ -1,0 +1,46 @@
+// Parameter block shared by the renderer host code and the ray-march kernels.
+#pragma once
+#include <stdint.h>
+
+#define ISO_BRICK 8
+#define ISO_APRON_DIM 9                 // 8 voxels + 1 apron voxel on the high side
+#define ISO_BRICK_VALUES 729            // 9^3
+#define ISO_BRICK_STRIDE 736            // floats per stored brick (2944 B, 16-B aligned)
+
+struct IsoCamera {
+    double J[3][3];   // rows: horizontal, up, forward (TP/openvdb/math/Mat.h:758-774)
+    double org[3];
+    double d0[3];     // base ray direction (0,0,-1)*J
+    double sw, sh;    // half frame width / height (TP/openvdb/tools/RayTracer.h:411,498)
+    double V[4][4];   // inverse camera matrix, row-vector convention
+};
+
+struct IsoRenderParams {
+    IsoCamera cam;
+    double Vlast[4][4];          // inverse matrix of the previously rendered camera (flow)
+    double s, sinv, t[3];        // index -> world: w = i*s + t
+    double iso;                  // absolute isovalue, already narrowed through float
+    double light[3];
+    double ambient[3], diffuse[3], specular[3];
+    double spec_c1;              // (e+2)/(2*pi)
+    int exponent;
+    int W, H;
+    int vp[4];
+    int nx, ny, nz;              // voxel dims
+    int nbx, nby, nbz;           // 8^3 brick grid
+    int n1x, n1y, n1z;           // 128^3 node grid
+    int bbmin[3], bbmax[3];      // node-level bbox (max already +1)
+    int any_leaf;
+    const float* bricks;         // [slot][ISO_BRICK_STRIDE], local index (z*9+y)*9+x
+    const int32_t* slot;         // [nbz][nby][nbx] -> slot or -1 (all 9^3 values zero)
+    const uint8_t* leaf;         // [nbz][nby][nbx] leaf node exists
+    const uint8_t* node1;        // [n1z][n1y][n1x]
+    float* out;                  // [H][W][12]
+};
+
+// launchers (iso_kernels.hip)
+void iso_launch_render(const IsoRenderParams& p, int variant, void* stream);
+void iso_launch_brick_flags(const float* dense, int nx, int ny, int nz, int nbx, int nby, int nbz,
+                            uint8_t* flag9, uint8_t* leaf, int* bbox6, unsigned int* maxbits, void* stream);
+void iso_launch_brick_fill(const float* dense, int nx, int ny, int nz, int nbx, int nby, int nbz,
+                           const int32_t* slot, float* bricks, void* stream);

@@ -1,0 +1,117 @@
+"""ctypes binding of libGPURendererDirect.so.
+
+Mirrors ``SuperresolutionNetwork/inference/renderer.py:78-117`` (class ``DirectRenderer``:
+``load``, ``send_command``, ``render_direct``, ``get_time``, ``close``) and ``Material``
+(``:9-15``).  Additive: ``load_dense`` (dense numpy / device tensor volumes), ``render_async``,
+return codes are surfaced instead of being dropped.
+"""
+import ctypes
+import os
+
+from .. import _native
+
+
+class Material:
+    """inference/renderer.py:9-15"""
+
+    def __init__(self, iso):
+        self.isovalue = iso
+        self.diffuseColor = [0.7, 0.2, 0.2]
+        self.specularColor = [0.1, 0.1, 0.1]
+        self.specularExponent = 16
+        self.light = 'camera'
+
+
+class DirectRenderer:
+    def __init__(self, renderer=None):
+        """``renderer``: path of libGPURendererDirect.so (default: the in-tree build)."""
+        if renderer is None:
+            renderer = _native.RENDERER_LIB
+        assert isinstance(renderer, str)
+        if renderer == _native.RENDERER_LIB:
+            self.lib = _native.load(renderer)
+        else:
+            assert os.path.exists(renderer)
+            _native._preload_hip_runtime()
+            self.lib = ctypes.cdll.LoadLibrary(renderer)
+        self.time = 0
+        lib = self.lib
+        lib.initGVDB.argtypes = []
+        lib.initGVDB.restype = ctypes.c_int
+        lib.loadGrid.argtypes = [ctypes.c_char_p]
+        lib.loadGrid.restype = ctypes.c_int
+        lib.setParameter.argtypes = [ctypes.c_char_p, ctypes.c_char_p]
+        lib.setParameter.restype = ctypes.c_int
+        lib.render.argtypes = [ctypes.c_ulonglong]
+        lib.render.restype = ctypes.c_float
+        lib.isoLoadDenseHost.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int]
+        lib.isoLoadDenseHost.restype = ctypes.c_int
+        lib.isoLoadDenseDevice.argtypes = [ctypes.c_ulonglong, ctypes.c_int, ctypes.c_int, ctypes.c_int]
+        lib.isoLoadDenseDevice.restype = ctypes.c_int
+        lib.isoRenderAsync.argtypes = [ctypes.c_ulonglong, ctypes.c_void_p]
+        lib.isoRenderAsync.restype = ctypes.c_int
+        lib.isoGetVolumeInfo.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
+        lib.isoGetVolumeInfo.restype = ctypes.c_int
+        lib.isoSetKernelVariant.argtypes = [ctypes.c_int]
+        lib.isoSetKernelVariant.restype = ctypes.c_int
+        lib.isoShutdown.argtypes = []
+        lib.isoShutdown.restype = None
+        if lib.initGVDB() != 0:
+            raise RuntimeError("initGVDB failed: no usable HIP device")
+
+    def load(self, filename: str):
+        return self.lib.loadGrid(ctypes.c_char_p(filename.encode("ascii")))
+
+    def load_dense(self, volume):
+        """Additive: dense fp32 volume [z][y][x] as a numpy array or a device tensor."""
+        if hasattr(volume, "data_ptr"):
+            assert volume.is_cuda and volume.is_contiguous() and volume.dim() == 3
+            nz, ny, nx = volume.shape
+            import torch
+            torch.cuda.synchronize()
+            rc = self.lib.isoLoadDenseDevice(ctypes.c_ulonglong(volume.data_ptr()), nx, ny, nz)
+        else:
+            import numpy as np
+            volume = np.ascontiguousarray(volume, dtype=np.float32)
+            nz, ny, nx = volume.shape
+            rc = self.lib.isoLoadDenseHost(volume.ctypes.data, nx, ny, nz)
+        if rc != 0:
+            raise RuntimeError("loading the dense volume failed (rc=%d)" % rc)
+        return rc
+
+    def send_command(self, cmd, value):
+        assert isinstance(cmd, str)
+        assert isinstance(value, str)
+        return self.lib.setParameter(ctypes.c_char_p(cmd.encode("ascii")),
+                                     ctypes.c_char_p(value.encode("ascii")))
+
+    def render_direct(self, tensor):
+        time = self.lib.render(ctypes.c_ulonglong(tensor.data_ptr()))
+        self.time = float(time)
+        return self.time
+
+    def render_async(self, tensor, stream=None):
+        """Additive: enqueue the frame on ``stream`` (a torch.cuda.Stream or None) without syncing."""
+        handle = ctypes.c_void_p(stream.cuda_stream) if stream is not None else None
+        rc = self.lib.isoRenderAsync(ctypes.c_ulonglong(tensor.data_ptr()), handle)
+        if rc != 0:
+            raise RuntimeError("isoRenderAsync failed")
+
+    def volume_info(self):
+        info = (ctypes.c_int * 12)()
+        mx = ctypes.c_float()
+        if self.lib.isoGetVolumeInfo(info, ctypes.byref(mx)) != 0:
+            return None
+        return {"dims": list(info[0:3]), "bricks": info[3], "leaves": info[4],
+                "node_bbox_min": list(info[5:8]), "node_bbox_max": list(info[8:11]),
+                "brick_mib": info[11], "max_value": mx.value}
+
+    def set_kernel_variant(self, variant):
+        return self.lib.isoSetKernelVariant(int(variant))
+
+    def get_time(self):
+        """Returns the time of the last render pass in seconds"""
+        return self.time
+
+    def close(self):
+        pass  # No-op, as in the reference

@@ -1,0 +1,114 @@
+"""Synthetic stand-in volumes and camera paths.
+
+The reference ships no volumes (README.md:68 points at a release download), so every
+benchmark/test volume is generated here, deterministically.  All volumes are fp32 in [0,1],
+C-order ``[z][y][x]``, with values < 0.02 set to exactly 0 so that empty space is sparse
+(mirrors ``ExternalImporter.cpp:154`` + ``copyFromDense(..., 0.001f)`` at ``:181``).
+"""
+import math
+
+import numpy as np
+
+SPARSITY_THRESHOLD = 0.02
+
+
+def _sparsify(v):
+    v[v < SPARSITY_THRESHOLD] = 0.0
+    return v
+
+
+def sphere64():
+    """V64-sphere (BASELINE config #1): soft sphere of radius 20 voxels, iso 0.5."""
+    z, y, x = np.meshgrid(np.arange(64, dtype=np.float32), np.arange(64, dtype=np.float32),
+                          np.arange(64, dtype=np.float32), indexing="ij")
+    r = np.sqrt((x - 31.5) ** 2 + (y - 31.5) ** 2 + (z - 31.5) ** 2)
+    v = np.clip((20.0 - r) / 4.0 + 0.5, 0.0, 1.0).astype(np.float32)
+    return _sparsify(v)
+
+
+def _upsample_axis(a, n, axis):
+    """Linear resampling of ``a`` along ``axis`` to ``n`` samples, endpoints aligned."""
+    m = a.shape[axis]
+    pos = np.arange(n, dtype=np.float64) * ((m - 1) / (n - 1))
+    i0 = np.minimum(np.floor(pos).astype(np.int64), m - 2)
+    w = (pos - i0).astype(np.float32)
+    shape = [1] * a.ndim
+    shape[axis] = n
+    w = w.reshape(shape)
+    lo = np.take(a, i0, axis=axis)
+    hi = np.take(a, i0 + 1, axis=axis)
+    return lo + (hi - lo) * w
+
+
+def _value_noise(rng, lattices, n, zrange=None):
+    """Sum of trilinearly upsampled uniform lattices, weights 1, 1/2, 1/4, ..., normalised."""
+    total = None
+    wsum = 0.0
+    for o, l in enumerate(lattices):
+        lat = rng.random((l, l, l), dtype=np.float32)
+        wgt = 0.5 ** o
+        a = _upsample_axis(lat, n, 0)
+        if zrange is not None:
+            a = a[zrange[0]:zrange[1]]
+        a = _upsample_axis(a, n, 1)
+        a = _upsample_axis(a, n, 2)
+        a *= np.float32(wgt)
+        total = a if total is None else total + a
+        wsum += wgt
+    total /= np.float32(wsum)
+    return total
+
+
+def _radius(n, zrange=None):
+    c = (np.arange(n, dtype=np.float32) + 0.5) / n - 0.5
+    cz = c if zrange is None else c[zrange[0]:zrange[1]]
+    return np.sqrt(cz[:, None, None] ** 2 + c[None, :, None] ** 2 + c[None, None, :] ** 2)
+
+
+def ejecta(n=256, seed=272):
+    """V256-ejecta (BASELINE config #2): value noise x spherical shell, iso 0.34."""
+    rng = np.random.default_rng(seed)
+    lattices = [8, 16, 32] if n >= 64 else [4, 8, 16]
+    v = _value_noise(rng, lattices, n)
+    r = _radius(n)
+    v *= np.exp(-((r - 0.30) / 0.12) ** 2).astype(np.float32)
+    v /= v.max()
+    return _sparsify(v.astype(np.float32))
+
+
+def cloud(n=512, seed=49):
+    """V512-cloud (BASELINE config #4): 5-octave value noise x gaussian blob, iso 0.30."""
+    rng = np.random.default_rng(seed)
+    lattices = [4, 8, 16, 32, 64]
+    v = _value_noise(rng, lattices, n)
+    r = _radius(n)
+    v *= np.exp(-(r / 0.35) ** 2).astype(np.float32)
+    v /= v.max()
+    return _sparsify(v.astype(np.float32))
+
+
+VOLUMES = {
+    "sphere64": (sphere64, 0.5),
+    "ejecta256": (lambda: ejecta(256), 0.34),
+    "ejecta128": (lambda: ejecta(128), 0.34),
+    "cloud512": (lambda: cloud(512), 0.30),
+}
+
+
+def orbit_camera(k, K=64, distance=2.0, pitch=0.38):
+    """Camera origin on the orbit of SURVEY.md 8(d): distance 2.0, pitch 0.38 rad, yaw 2*pi*k/K.
+    Follows the spherical convention of ``inference/camera.py:61-66`` (orientation Yp)."""
+    yaw = 2.0 * math.pi * k / K
+    return [math.cos(pitch) * math.cos(yaw) * distance,
+            math.sin(pitch) * distance,
+            math.cos(pitch) * math.sin(yaw) * distance]
+
+
+def fmt3(v):
+    """Format a 3-vector exactly as the reference's callers do (``mainGUI.py:667-671``)."""
+    return "%5.3f,%5.3f,%5.3f" % (v[0], v[1], v[2])
+
+
+def quantize3(v):
+    """Value a renderer sees after the caller's %5.3f formatting."""
+    return [float(s) for s in fmt3(v).split(",")]

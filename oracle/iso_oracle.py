@@ -1,0 +1,120 @@
+"""ctypes wrapper around oracle/libiso_oracle.so -- TEST INFRASTRUCTURE ONLY.
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this
+(see oracle/iso_oracle.h for the "parity unpinned" statement).
+"""
+import ctypes
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+
+
+class IsoParams(ctypes.Structure):
+    _fields_ = [
+        ("width", ctypes.c_int), ("height", ctypes.c_int),
+        ("fov_deg", ctypes.c_double),
+        ("origin", ctypes.c_double * 3), ("lookat", ctypes.c_double * 3), ("up", ctypes.c_double * 3),
+        ("last_origin", ctypes.c_double * 3), ("last_lookat", ctypes.c_double * 3),
+        ("isovalue", ctypes.c_double),
+        ("ambient", ctypes.c_double * 3), ("diffuse", ctypes.c_double * 3), ("specular", ctypes.c_double * 3),
+        ("specular_exponent", ctypes.c_int),
+        ("light_from_camera", ctypes.c_int),
+        ("light_dir", ctypes.c_double * 3),
+        ("viewport", ctypes.c_int * 4),
+    ]
+
+
+def build(force=False):
+    so = os.path.join(_HERE, "libiso_oracle.so")
+    src = os.path.join(_HERE, "iso_oracle.c")
+    if force or not os.path.exists(so) or os.path.getmtime(so) < os.path.getmtime(src):
+        subprocess.check_call(["make", "-C", _HERE, "-B", "libiso_oracle.so"], stdout=subprocess.DEVNULL)
+    return so
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        so = os.path.join(_HERE, "libiso_oracle.so")
+        if not os.path.exists(so):
+            build()
+        L = ctypes.CDLL(so)
+        L.iso_volume_create.restype = ctypes.c_void_p
+        L.iso_volume_create.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int]
+        L.iso_volume_free.argtypes = [ctypes.c_void_p]
+        L.iso_volume_info.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]
+        L.iso_params_default.argtypes = [ctypes.POINTER(IsoParams)]
+        L.iso_render.restype = ctypes.c_int
+        L.iso_render.argtypes = [ctypes.c_void_p, ctypes.POINTER(IsoParams), ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int]
+        L.iso_num_threads.restype = ctypes.c_int
+        _LIB = L
+    return _LIB
+
+
+class OracleVolume:
+    def __init__(self, dense):
+        dense = np.ascontiguousarray(dense, dtype=np.float32)
+        assert dense.ndim == 3
+        nz, ny, nx = dense.shape
+        self._h = lib().iso_volume_create(dense.ctypes.data, nx, ny, nz)
+        if not self._h:
+            raise ValueError("oracle: empty or oversized volume")
+        self.shape = dense.shape
+
+    def info(self):
+        info = (ctypes.c_int * 13)()
+        st = (ctypes.c_double * 4)()
+        mx = ctypes.c_float()
+        lib().iso_volume_info(self._h, info, st, ctypes.byref(mx))
+        return {"node_bbox_min": list(info[0:3]), "node_bbox_max": list(info[3:6]),
+                "active_bbox_min": list(info[6:9]), "active_bbox_max": list(info[9:12]),
+                "num_leaves": info[12], "scale": st[0], "translation": list(st[1:4]), "max_value": mx.value}
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            lib().iso_volume_free(self._h)
+            self._h = None
+
+
+def default_params():
+    p = IsoParams()
+    lib().iso_params_default(ctypes.byref(p))
+    return p
+
+
+def make_params(width, height, origin, lookat=(0, 0, 0), up=(0, 1, 0), fov=45.0, isovalue=0.5,
+                last_origin=None, last_lookat=None, viewport=None, **material):
+    p = default_params()
+    p.width, p.height = int(width), int(height)
+    p.fov_deg = float(fov)
+    for k in range(3):
+        p.origin[k] = float(origin[k]); p.lookat[k] = float(lookat[k]); p.up[k] = float(up[k])
+        p.last_origin[k] = float((last_origin if last_origin is not None else origin)[k])
+        p.last_lookat[k] = float((last_lookat if last_lookat is not None else lookat)[k])
+    p.isovalue = float(isovalue)
+    vp = viewport if viewport is not None else (0, 0, width, height)
+    for k in range(4):
+        p.viewport[k] = int(vp[k])
+    for name in ("ambient", "diffuse", "specular"):
+        if name in material:
+            for k in range(3):
+                getattr(p, name)[k] = float(material[name][k])
+    if "specular_exponent" in material:
+        p.specular_exponent = int(material["specular_exponent"])
+    return p
+
+
+def render(volume, params, threads=0, with_stats=True):
+    """Returns (image[H,W,12] float32, stats dict)."""
+    out = np.empty((params.height, params.width, 12), dtype=np.float32)
+    stats = (ctypes.c_longlong * 4)()
+    lib().iso_render(volume._h, ctypes.byref(params), out.ctypes.data, stats if with_stats else None, int(threads))
+    return out, {"hits": stats[0], "samples": stats[1], "bricks_touched": stats[2], "steps": stats[3]}
+
+
+def num_threads():
+    return lib().iso_num_threads()
