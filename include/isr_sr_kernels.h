@@ -1,0 +1,57 @@
+/*
+ * isr_sr_kernels.h -- C-ABI of libisr_sr.so: the hand-written gfx950 kernels behind the
+ * super-resolution network (EnhanceNet) of the reference.
+ *
+ * The reference has no native interface on this path: its convolutions are `nn.Conv2d`
+ * modules dispatched to cuDNN through PyTorch (SuperresolutionNetwork/models/enhancenet.py:92-125,
+ * forward :136-144).  These entry points are what a maintainer binds in place of those library
+ * calls: plain device pointers, sizes and a hipStream_t -- no torch types.
+ *
+ * All tensors are fp32, NCHW, contiguous, resident on the current HIP device.
+ * Every function returns 0 on success, a negative value on invalid arguments or launch failure.
+ */
+#ifndef ISR_SR_KERNELS_H
+#define ISR_SR_KERNELS_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* activation codes */
+#define ISR_ACT_NONE 0
+#define ISR_ACT_RELU 1
+#define ISR_ACT_LEAKY 2   /* LeakyReLU / single-parameter PReLU with slope `slope` */
+
+/* Padded sizes of the kernel-side weight layout [9][cinPad][coutPad]. */
+int isrConvCinPad(int Cin);
+int isrConvCoutPad(int Cout);
+
+/* Re-lays PyTorch conv weights w[Cout][Cin][3][3] into wprep[9][cinPad][coutPad] (zero padded).
+ * transpose_flip = 0: forward weights,  tap = ky*3+kx, wprep[tap][ci][co] = w[co][ci][ky][kx].
+ * transpose_flip = 1: data-gradient weights (the roles of Cin/Cout swap and the taps flip):
+ *   wprep[tap][co][ci] = w[co][ci][2-ky][2-kx], sized [9][isrConvCinPad(Cout)][isrConvCoutPad(Cin)]. */
+int isrConvPrepareWeights(const float* w, float* wprep, int Cout, int Cin, int transpose_flip, void* stream);
+
+/* Fused 3x3 convolution, stride 1, zero padding 1 (replaces nn.Conv2d(...,3,padding=1) + nn.ReLU
+ * (+ the residual add of enhancenet.py:141, + the preceding nn.Upsample(x2, bilinear) of :116,:119)):
+ *     y = act(conv3x3(U(x), w) + bias) + residual
+ * x: [N][Cin][H/u][W/u] with u = 2 if upsample2x (bilinear, align_corners=False) else 1;
+ * wprep: from isrConvPrepareWeights(.., 0); bias: [Cout] or NULL; residual: [N][Cout][H][W] or NULL;
+ * y: [N][Cout][H][W].  H, W are the OUTPUT sizes. */
+int isrConv3x3Forward(const float* x, const float* wprep, const float* bias, const float* residual, float* y,
+                      int N, int Cin, int H, int W, int Cout, int act, float slope, int upsample2x, void* stream);
+
+/* Weight gradient of the same convolution: dw[Cout][Cin][3][3] = sum_{n,y,x} gz[n][co][y][x] * x[n][ci][y+ky-1][x+kx-1]
+ * and db[Cout] = sum gz.  x: [N][Cin][H][W], gz: [N][Cout][H][W] (gradient w.r.t. the pre-activation).
+ * workspace: at least isrConvWeightGradWorkspace(...) bytes of device memory. dw/db are overwritten. */
+long long isrConvWeightGradWorkspace(int N, int Cin, int H, int W, int Cout);
+int isrConv3x3WeightGrad(const float* x, const float* gz, float* dw, float* db, void* workspace,
+                         int N, int Cin, int H, int W, int Cout, void* stream);
+
+/* gz = gy * act'(y) for the activations above (y is the post-activation output, before the residual add). */
+int isrActBackward(const float* gy, const float* y, float* gz, long long count, int act, float slope, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

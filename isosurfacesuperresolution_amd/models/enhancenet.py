@@ -1,0 +1,103 @@
+"""EnhanceNet generator (Sajjadi et al.) as used by the reference's unshaded video pipeline.
+
+Same constructor, attributes, sub-module names and ``state_dict`` keys as
+``SuperresolutionNetwork/models/enhancenet.py`` (``preblock.0``, ``blocks.{0..9}.{0,2}``,
+``postblock.{1,4,6,8}``), so reference checkpoints load; the forward pass is written against
+``ops.conv3x3`` so that on an MI355X every 3x3 convolution runs the fused HIP/MFMA kernel
+(bias + ReLU + residual add + optional x2 bilinear upsample of the input in one launch) instead
+of conv -> activation -> add as separate library calls.
+
+Architecture (enhancenet.py:92-125): pre: conv(Cin->64)+ReLU; 10 x [conv+ReLU, conv] with
+skip; post: up x2, conv+ReLU, up x2, conv+ReLU, conv+ReLU, conv(64->Cout).  Reconstruction
+(``:51-90``): with ``reconType='residual'`` the first ``len(channel_mask)`` output channels get
+the bilinearly resized first ``len(channel_mask)`` input channels added (sliced, not gathered).
+Initialisation (``:127-133``): orthogonal with gain sqrt(2) for the convs inside ``blocks`` only.
+"""
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from .. import ops
+
+
+class EnhanceNet(nn.Module):
+    def __init__(self, upscale_factor, input_channels, channel_mask, output_channels, opt):
+        super().__init__()
+        assert upscale_factor == 4
+        self.upscale_factor = upscale_factor
+        self.upsample = opt.upsample
+        self.recon_type = opt.reconType
+        self.use_bn = opt.useBN
+        self.channel_mask = channel_mask
+        self.input_channels = input_channels
+        self.output_channels = output_channels
+        self._build(input_channels, output_channels)
+        self._initialize_weights()
+
+    def _upsample(self, factor):
+        if self.upsample in ('nearest', 'bilinear', 'bicubic'):
+            return nn.Upsample(scale_factor=factor, mode=self.upsample)
+        # the reference's pixel-shuffle branch references a missing attribute (enhancenet.py:48)
+        raise ValueError("unsupported upsample mode '%s'" % self.upsample)
+
+    def _build(self, cin, cout):
+        def conv(i, o):
+            return nn.Conv2d(i, o, 3, padding=1)
+
+        self.preblock = nn.Sequential(conv(cin, 64), nn.ReLU())
+        blocks = []
+        for _ in range(10):   # hard-coded as in the reference (enhancenet.py:98)
+            if self.use_bn:
+                blocks.append(nn.Sequential(conv(64, 64), nn.BatchNorm2d(64), nn.ReLU(),
+                                            conv(64, 64), nn.BatchNorm2d(64)))
+            else:
+                blocks.append(nn.Sequential(conv(64, 64), nn.ReLU(), conv(64, 64)))
+        self.blocks = nn.ModuleList(blocks)
+        self.postblock = nn.Sequential(
+            self._upsample(2), conv(64, 64), nn.ReLU(),
+            self._upsample(2), conv(64, 64), nn.ReLU(),
+            conv(64, 64), nn.ReLU(),
+            conv(64, cout))
+
+    def _initialize_weights(self):
+        gain = nn.init.calculate_gain('relu')
+        for block in self.blocks:
+            for m in block.modules():
+                if isinstance(m, nn.Conv2d):
+                    nn.init.orthogonal_(m.weight, gain)
+
+    # ------------------------------------------------------------------ forward
+    def _recon_image(self, inputs, outputs):
+        k = len(self.channel_mask)
+        if self.recon_type != 'residual':
+            return outputs, outputs
+        if k > self.output_channels:
+            raise ValueError("number of output channels must be at least the number of masked input channels")
+        resized = F.interpolate(inputs[:, 0:k], size=[outputs.shape[2], outputs.shape[3]], mode=self.upsample,
+                                **({'align_corners': False} if self.upsample in ('bilinear', 'bicubic') else {}))
+        if k == self.output_channels:
+            return resized + outputs, outputs
+        return torch.cat([resized + outputs[:, 0:k], outputs[:, k:]], dim=1), outputs
+
+    def _fused_ok(self):
+        return (not self.use_bn) and self.upsample == 'bilinear'
+
+    def forward(self, inputs):
+        if not self._fused_ok():
+            features = self.preblock(inputs)
+            for block in self.blocks:
+                features = features + block(features)
+            outputs = self.postblock(features)
+            return self._recon_image(inputs, outputs)
+        c = ops.conv3x3
+        pre = self.preblock[0]
+        f = c(inputs, pre.weight, pre.bias, act='relu')
+        for block in self.blocks:
+            t = c(f, block[0].weight, block[0].bias, act='relu')
+            f = c(t, block[2].weight, block[2].bias, residual=f)
+        p = self.postblock
+        f = c(f, p[1].weight, p[1].bias, act='relu', upsample2x=True)
+        f = c(f, p[4].weight, p[4].bias, act='relu', upsample2x=True)
+        f = c(f, p[6].weight, p[6].bias, act='relu')
+        outputs = c(f, p[8].weight, p[8].bias)
+        return self._recon_image(inputs, outputs)

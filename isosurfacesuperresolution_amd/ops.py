@@ -1,0 +1,177 @@
+"""Functional bridge between the PyTorch modules and the hand-written HIP kernels.
+
+``conv3x3`` is the one hot op of the super-resolution network (23 of the 24 weight layers and
+99.9 % of its FLOPs):
+
+    y = act(conv3x3(U(x), w, padding=1) + bias) + residual         U = optional bilinear x2
+
+* CUDA/HIP tensors: one launch of ``isrConv3x3Forward`` from libisr_sr.so (fp32 MFMA) through the
+  C-ABI of ``include/isr_sr_kernels.h``.  Autograd is provided by hand-written kernels as well:
+  the data gradient re-uses the forward kernel with flipped/transposed weights, the weight
+  gradient is ``isrConv3x3WeightGrad``.  There is no fallback: if the library is missing this raises.
+* CPU tensors: the reference's own CPU path, i.e. plain PyTorch ops (BASELINE config #1).
+"""
+import ctypes
+
+import torch
+import torch.nn.functional as F
+
+from . import _native
+
+ACT_CODES = {'none': 0, 'relu': 1, 'leaky': 2}
+_lib = None
+
+
+def _sr():
+    global _lib
+    if _lib is None:
+        lib = _native.load(_native.SR_LIB)
+        vp, ci, cf, ll = ctypes.c_void_p, ctypes.c_int, ctypes.c_float, ctypes.c_longlong
+        lib.isrConvCinPad.argtypes = [ci]; lib.isrConvCinPad.restype = ci
+        lib.isrConvCoutPad.argtypes = [ci]; lib.isrConvCoutPad.restype = ci
+        lib.isrConvPrepareWeights.argtypes = [vp, vp, ci, ci, ci, vp]; lib.isrConvPrepareWeights.restype = ci
+        lib.isrConv3x3Forward.argtypes = [vp, vp, vp, vp, vp, ci, ci, ci, ci, ci, ci, cf, ci, vp]
+        lib.isrConv3x3Forward.restype = ci
+        lib.isrConvWeightGradWorkspace.argtypes = [ci, ci, ci, ci, ci]; lib.isrConvWeightGradWorkspace.restype = ll
+        lib.isrConv3x3WeightGrad.argtypes = [vp, vp, vp, vp, vp, ci, ci, ci, ci, ci, vp]; lib.isrConv3x3WeightGrad.restype = ci
+        lib.isrActBackward.argtypes = [vp, vp, vp, ll, ci, cf, vp]; lib.isrActBackward.restype = ci
+        _lib = lib
+    return _lib
+
+
+def _stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _ptr(t):
+    return ctypes.c_void_p(t.data_ptr()) if t is not None else None
+
+
+# Inference re-uses the re-laid-out weights until the parameter is modified in place or replaced.
+_wcache = {}
+
+
+def prepare_weights(weight, transpose_flip=False):
+    """PyTorch [Cout,Cin,3,3] -> kernel layout [9][cinPad][coutPad] (device tensor)."""
+    lib = _sr()
+    cout, cin = weight.shape[0], weight.shape[1]
+    key = (weight.data_ptr(), weight._version, tuple(weight.shape), bool(transpose_flip), weight.device.index)
+    hit = _wcache.get(key)
+    if hit is not None:
+        return hit
+    w = weight.detach().contiguous()
+    if transpose_flip:
+        cin_pad, cout_pad = lib.isrConvCinPad(cout), lib.isrConvCoutPad(cin)
+    else:
+        cin_pad, cout_pad = lib.isrConvCinPad(cin), lib.isrConvCoutPad(cout)
+    wp = torch.empty(9 * cin_pad * cout_pad, dtype=torch.float32, device=weight.device)
+    rc = lib.isrConvPrepareWeights(_ptr(w), _ptr(wp), cout, cin, 1 if transpose_flip else 0, _stream())
+    if rc != 0:
+        raise RuntimeError("isrConvPrepareWeights failed (%d)" % rc)
+    if len(_wcache) > 256:
+        _wcache.clear()
+    _wcache[key] = wp
+    return wp
+
+
+def _launch_forward(x, wprep, bias, residual, cin, cout, act, slope, upsample2x):
+    lib = _sr()
+    n, _, hin, win = x.shape
+    h, w = (hin * 2, win * 2) if upsample2x else (hin, win)
+    y = torch.empty((n, cout, h, w), dtype=torch.float32, device=x.device)
+    rc = lib.isrConv3x3Forward(_ptr(x), _ptr(wprep), _ptr(bias), _ptr(residual), _ptr(y),
+                               n, cin, h, w, cout, ACT_CODES[act], float(slope), 1 if upsample2x else 0, _stream())
+    if rc != 0:
+        raise RuntimeError("isrConv3x3Forward failed (%d)" % rc)
+    return y
+
+
+_workspace = {}
+
+
+def _wgrad_workspace(device, nbytes):
+    ws = _workspace.get(device)
+    if ws is None or ws.numel() < nbytes:
+        ws = torch.empty(nbytes, dtype=torch.uint8, device=device)
+        _workspace[device] = ws
+    return ws
+
+
+class _Conv3x3Function(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, weight, bias, residual, act, slope):
+        x = x.contiguous()
+        res = residual.contiguous() if residual is not None else None
+        b = bias.contiguous() if bias is not None else None
+        cout, cin = weight.shape[0], weight.shape[1]
+        y = _launch_forward(x, prepare_weights(weight), b, res, cin, cout, act, slope, False)
+        ctx.act, ctx.slope = act, slope
+        ctx.has_bias, ctx.has_res = bias is not None, residual is not None
+        if act != 'none' and residual is not None:
+            raise RuntimeError("conv3x3: activation together with a fused residual is inference-only")
+        ctx.save_for_backward(x, weight, y if act != 'none' else None)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        lib = _sr()
+        x, weight, y = ctx.saved_tensors
+        gy = gy.contiguous()
+        cout, cin = weight.shape[0], weight.shape[1]
+        n, _, h, w = x.shape
+        if ctx.act != 'none':
+            gz = torch.empty_like(gy)
+            rc = lib.isrActBackward(_ptr(gy), _ptr(y), _ptr(gz), gy.numel(), ACT_CODES[ctx.act], float(ctx.slope), _stream())
+            if rc != 0:
+                raise RuntimeError("isrActBackward failed (%d)" % rc)
+        else:
+            gz = gy
+        gx = gw = gb = gres = None
+        if ctx.needs_input_grad[0]:
+            # data gradient = the same fused kernel on flipped / transposed weights
+            gx = _launch_forward(gz, prepare_weights(weight, transpose_flip=True), None, None, cout, cin, 'none', 0.0, False)
+        if ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2]):
+            gw = torch.empty_like(weight, memory_format=torch.contiguous_format)
+            gb = torch.empty(cout, dtype=torch.float32, device=x.device) if ctx.has_bias else None
+            ws = _wgrad_workspace(x.device, lib.isrConvWeightGradWorkspace(n, cin, h, w, cout))
+            rc = lib.isrConv3x3WeightGrad(_ptr(x), _ptr(gz), _ptr(gw), _ptr(gb), _ptr(ws), n, cin, h, w, cout, _stream())
+            if rc != 0:
+                raise RuntimeError("isrConv3x3WeightGrad failed (%d)" % rc)
+        if ctx.has_res and ctx.needs_input_grad[3]:
+            gres = gy
+        return gx, gw, gb, gres, None, None
+
+
+def _act_cpu(z, act, slope):
+    if act == 'relu':
+        return F.relu(z)
+    if act == 'leaky':
+        return F.leaky_relu(z, slope)
+    return z
+
+
+def conv3x3(x, weight, bias=None, act='none', slope=0.01, residual=None, upsample2x=False):
+    """See module docstring.  x [N,Cin,h,w], weight [Cout,Cin,3,3] -> [N,Cout,H,W]."""
+    if act not in ACT_CODES:
+        raise ValueError("unknown activation %r" % (act,))
+    if not x.is_cuda:
+        if upsample2x:
+            x = F.interpolate(x, scale_factor=2, mode='bilinear', align_corners=False)
+        y = _act_cpu(F.conv2d(x, weight, bias, padding=1), act, slope)
+        return y + residual if residual is not None else y
+    if x.dtype != torch.float32 or weight.dtype != torch.float32:
+        raise TypeError("conv3x3 (HIP) computes in fp32")
+    needs_grad = torch.is_grad_enabled() and (x.requires_grad or weight.requires_grad or
+                                              (bias is not None and bias.requires_grad) or
+                                              (residual is not None and residual.requires_grad))
+    if not needs_grad:
+        cout, cin = weight.shape[0], weight.shape[1]
+        return _launch_forward(x.contiguous(), prepare_weights(weight),
+                               bias.contiguous() if bias is not None else None,
+                               residual.contiguous() if residual is not None else None,
+                               cin, cout, act, slope, upsample2x)
+    if upsample2x:   # training: keep the resize as its own differentiable op
+        x = F.interpolate(x, scale_factor=2, mode='bilinear', align_corners=False)
+    if residual is not None and act != 'none':
+        return _Conv3x3Function.apply(x, weight, bias, None, act, slope) + residual
+    return _Conv3x3Function.apply(x, weight, bias, residual, act, slope)
