@@ -45,7 +45,8 @@ struct ConvParams {
     float* y;
     int N, Cin, H, W, Cout;  // H, W: output size
     int Hin, Win;            // input size (H/2, W/2 when upsampling)
-    int cinPad, coutPad;
+    int cinPad, coutPad;     // padded channel counts of the weight layout
+    int co0;                 // first output channel handled by this launch (multiple of 64)
     int tilesX, tilesY;
     int act;
     float slope;
@@ -116,14 +117,16 @@ __global__ __launch_bounds__(NTHREADS, 1) void conv3x3_fwd_kernel(const ConvPara
         const int col = rem - r * PW;
         return load_input<UPS>(p, n, chunk * CK + c, oy0 + r - 1, ox0 + col - 1);
     };
-    auto weight_slice = [&](int chunk, int tap) -> const float4* {
-        return reinterpret_cast<const float4*>(p.w + ((size_t)tap * p.cinPad + chunk * CK) * CP);
+    // float4 `q` of the [CK][CP] weight slice of (chunk, tap): row = input channel, CP couts from co0
+    auto weight_slice = [&](int chunk, int tap, int q) -> float4 {
+        const int row = q / (CP / 4), c4 = q - row * (CP / 4);
+        return *reinterpret_cast<const float4*>(p.w + ((size_t)tap * p.cinPad + chunk * CK + row) * p.coutPad + p.co0 + c4 * 4);
     };
 
     // prologue: chunk 0 in full
     for (int e = tid; e < CHUNK; e += NTHREADS) patch0[e] = patch_value(0, e);
     for (int tap = 0; tap < 9; ++tap)
-        if (tid < WSLICE4) reinterpret_cast<float4*>(wlds0 + tap * CK * CP)[tid] = weight_slice(0, tap)[tid];
+        if (tid < WSLICE4) reinterpret_cast<float4*>(wlds0 + tap * CK * CP)[tid] = weight_slice(0, tap, tid);
     __syncthreads();
 
     const int j = lane & 31;       // pixel column inside the tile / cout inside the M tile
@@ -148,7 +151,7 @@ __global__ __launch_bounds__(NTHREADS, 1) void conv3x3_fwd_kernel(const ConvPara
                     const int e = tid + (tap * STAGE_PER_TAP + i) * NTHREADS;
                     sv[i] = e < CHUNK ? patch_value(chunk + 1, e) : 0.0f;
                 }
-                if (tid < WSLICE4) wv = weight_slice(chunk + 1, tap)[tid];
+                if (tid < WSLICE4) wv = weight_slice(chunk + 1, tap, tid);
             }
             const int dy = tap / 3, dx = tap - dy * 3;
             const float* pt = pb + dy * PW + dx;
@@ -189,7 +192,7 @@ __global__ __launch_bounds__(NTHREADS, 1) void conv3x3_fwd_kernel(const ConvPara
             for (int m = 0; m < MT; ++m) {
 #pragma unroll
                 for (int i = 0; i < 16; ++i) {
-                    const int co = m * 32 + (i & 3) + 8 * (i >> 2) + 4 * kh;
+                    const int co = p.co0 + m * 32 + (i & 3) + 8 * (i >> 2) + 4 * kh;
                     if (co < p.Cout) {
                         float v = acc[m][r][i];
                         if (p.bias) v += p.bias[co];
@@ -397,7 +400,6 @@ int isrConv3x3Forward(const float* x, const float* wprep, const float* bias, con
                       int N, int Cin, int H, int W, int Cout, int act, float slope, int upsample2x, void* stream)
 {
     if (!x || !wprep || !y || N <= 0 || Cin <= 0 || Cout <= 0 || H <= 0 || W <= 0) return -1;
-    if (Cout > 64) return -1;                       // M tiles per wave: 1 or 2
     if (upsample2x && ((H & 1) || (W & 1))) return -1;
     if (act < ISR_ACT_NONE || act > ISR_ACT_LEAKY) return -1;
     ConvParams p;
@@ -419,12 +421,16 @@ int isrConv3x3Forward(const float* x, const float* wprep, const float* bias, con
         (void)hipFuncSetAttribute((const void*)conv3x3_fwd_kernel<2, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)conv_fwd_lds_bytes<2>());
         attr_done = true;
     }
-    if (p.coutPad == 32) {
-        if (upsample2x) hipLaunchKernelGGL((conv3x3_fwd_kernel<1, true>), grid, block, conv_fwd_lds_bytes<1>(), s, p);
-        else hipLaunchKernelGGL((conv3x3_fwd_kernel<1, false>), grid, block, conv_fwd_lds_bytes<1>(), s, p);
-    } else {
-        if (upsample2x) hipLaunchKernelGGL((conv3x3_fwd_kernel<2, true>), grid, block, conv_fwd_lds_bytes<2>(), s, p);
-        else hipLaunchKernelGGL((conv3x3_fwd_kernel<2, false>), grid, block, conv_fwd_lds_bytes<2>(), s, p);
+    // one launch per group of up to 64 output channels (2 M tiles per wave)
+    for (int co0 = 0; co0 < p.coutPad; co0 += 64) {
+        p.co0 = co0;
+        if (p.coutPad - co0 == 32) {
+            if (upsample2x) hipLaunchKernelGGL((conv3x3_fwd_kernel<1, true>), grid, block, conv_fwd_lds_bytes<1>(), s, p);
+            else hipLaunchKernelGGL((conv3x3_fwd_kernel<1, false>), grid, block, conv_fwd_lds_bytes<1>(), s, p);
+        } else {
+            if (upsample2x) hipLaunchKernelGGL((conv3x3_fwd_kernel<2, true>), grid, block, conv_fwd_lds_bytes<2>(), s, p);
+            else hipLaunchKernelGGL((conv3x3_fwd_kernel<2, false>), grid, block, conv_fwd_lds_bytes<2>(), s, p);
+        }
     }
     return hipGetLastError() == hipSuccess ? 0 : -2;
 }

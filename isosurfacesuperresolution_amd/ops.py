@@ -12,6 +12,7 @@
 * CPU tensors: the reference's own CPU path, i.e. plain PyTorch ops (BASELINE config #1).
 """
 import ctypes
+import weakref
 
 import torch
 import torch.nn.functional as F
@@ -47,7 +48,8 @@ def _ptr(t):
     return ctypes.c_void_p(t.data_ptr()) if t is not None else None
 
 
-# Inference re-uses the re-laid-out weights until the parameter is modified in place or replaced.
+# Inference re-uses the re-laid-out weights for as long as the very same tensor object is alive and
+# unmodified (a data_ptr alone is not an identity: the caching allocator recycles addresses).
 _wcache = {}
 
 
@@ -55,10 +57,12 @@ def prepare_weights(weight, transpose_flip=False):
     """PyTorch [Cout,Cin,3,3] -> kernel layout [9][cinPad][coutPad] (device tensor)."""
     lib = _sr()
     cout, cin = weight.shape[0], weight.shape[1]
-    key = (weight.data_ptr(), weight._version, tuple(weight.shape), bool(transpose_flip), weight.device.index)
+    key = (id(weight), bool(transpose_flip))
     hit = _wcache.get(key)
     if hit is not None:
-        return hit
+        ref, version, ptr, wp = hit
+        if ref() is weight and version == weight._version and ptr == weight.data_ptr():
+            return wp
     w = weight.detach().contiguous()
     if transpose_flip:
         cin_pad, cout_pad = lib.isrConvCinPad(cout), lib.isrConvCoutPad(cin)
@@ -68,9 +72,10 @@ def prepare_weights(weight, transpose_flip=False):
     rc = lib.isrConvPrepareWeights(_ptr(w), _ptr(wp), cout, cin, 1 if transpose_flip else 0, _stream())
     if rc != 0:
         raise RuntimeError("isrConvPrepareWeights failed (%d)" % rc)
-    if len(_wcache) > 256:
-        _wcache.clear()
-    _wcache[key] = wp
+    if len(_wcache) > 512:
+        for k in [k for k, v in _wcache.items() if v[0]() is None]:
+            del _wcache[k]
+    _wcache[key] = (weakref.ref(weight), weight._version, weight.data_ptr(), wp)
     return wp
 
 
