@@ -1,0 +1,206 @@
+#!/usr/bin/env python
+"""Headline benchmark: frames/s of (ray-march low-res G-buffer + 4x EnhanceNet SR + screen-space
+shading) at a 256^3 volume, 480x270 -> 1920x1080 (BASELINE.json configs[1]).
+
+    python bench.py --gpus N --steps K --warmup W
+
+A "step" is one frame of the orbit camera path of SURVEY.md 8(d) on synthetic data (V256-ejecta
+stand-in volume, seeded random-init EnhanceNet weights).  With N > 1 (launched by
+torch.distributed.run, one rank per GPU) every rank renders its own contiguous chunk of the
+sequence, started with ``initialImage``: weak scaling, no data-path collective.
+Rank 0 prints ONE JSON line.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+MFMA_F32_PEAK_TFLOPS = 157.3      # /opt/skills/guides/MI355X_MICROARCH.md, chip-level parameters
+HBM_PEAK_GBS = 8000.0
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=30)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--volume", default="ejecta256", choices=["ejecta256", "ejecta128", "sphere64"])
+    ap.add_argument("--low", default="480x270")
+    ap.add_argument("--no-temporal", action="store_true")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--raymarch-variant", type=int, default=0)
+    return ap.parse_args()
+
+
+def main():
+    args = parse()
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+    from isosurfacesuperresolution_amd import models, ops, volumes as V
+    from isosurfacesuperresolution_amd.inference import DirectRenderer, LoadedModel
+    from isosurfacesuperresolution_amd.pipeline import SuperResolutionPipeline, default_shading
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    assert torch.cuda.is_available(), "bench.py needs an MI355X"
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    assert args.gpus == world, "--gpus must equal the number of launched ranks"
+
+    low_w, low_h = (int(v) for v in args.low.split("x"))
+    iso = {"ejecta256": 0.34, "ejecta128": 0.34, "sphere64": 0.5}[args.volume]
+    vol = V.VOLUMES[args.volume][0]()
+    renderer = DirectRenderer()
+    renderer.set_kernel_variant(args.raymarch_variant)
+    renderer.load_dense(vol)
+    opt = argparse.Namespace(upsample='bilinear', reconType='residual', useBN=False, numResidualLayers=10)
+    torch.manual_seed(0)
+    net = models.createNetwork('EnhanceNet', 4, 101, [0, 1, 2, 3, 4], 6, opt)
+    model = LoadedModel.from_model(net, "cuda", parameters={"initialImage": "zero"})
+    pipe = SuperResolutionPipeline(renderer, model, default_shading("cuda", 30.0), (low_w, low_h),
+                                   temporal=not args.no_temporal)
+    pipe.set_static(fov=30.0, isovalue=iso)
+
+    K, Wm = args.steps, args.warmup
+    first = rank * K                      # this rank's contiguous chunk of the orbit
+    origins = [V.orbit_camera(first + k - Wm, K=max(64, world * K)) for k in range(Wm + K)]
+
+    def sync():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    for k in range(Wm):
+        pipe.frame(origins[k])
+    pipe.reset()
+    sink = []
+    ops.set_profile_sink(sink)
+    rm_events = []
+    sync()
+    t0 = time.perf_counter()
+    for k in range(K):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        with torch.no_grad():
+            e0.record()
+            low = pipe.render_low(origins[Wm + k])
+            e1.record()
+            raw = pipe.superresolve(low)
+            rgb = pipe.shading(raw)
+        rm_events.append((e0, e1))
+    sync()
+    elapsed = time.perf_counter() - t0
+    ops.set_profile_sink(None)
+    if world > 1:
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        elapsed = tmax.item()
+
+    # ---- per-kernel numbers from HIP events recorded on the launch stream inside the timed region
+    per = {}
+    for name, flops, groups, ev0, ev1 in sink:
+        d = per.setdefault(name, [0.0, 0.0, 0])
+        d[0] += flops
+        d[1] += ev0.elapsed_time(ev1) * 1e-3
+        d[2] += groups
+    dominant = max(per.items(), key=lambda kv: kv[1][1])
+    dom_name, (dom_flops, dom_time, dom_launches) = dominant
+    achieved = dom_flops / dom_time / 1e12
+    rm_time = sum(a.elapsed_time(b) for a, b in rm_events) * 1e-3 / K
+
+    result = {
+        "metric": "frames/sec (render+4x SR) at 256^3 -> 1080p",
+        "value": world * K / elapsed,
+        "unit": "frames/s",
+        "n_gpus": world, "steps": K, "warmup": Wm,
+        "ms_per_step": elapsed / K * 1e3,
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": "f32",
+        "data": "synthetic (V256-ejecta stand-in volume, seeded random-init EnhanceNet weights)",
+        "config": {"workload": "%s volume, %dx%d -> %dx%d 4x SR inference, orbit camera, temporal=%s" % (
+            args.volume, low_w, low_h, 4 * low_w, 4 * low_h, "off" if args.no_temporal else "on"),
+            "frames_per_rank": K, "sharding": "contiguous frame chunks per rank, no collective"},
+        "roofline": {"kernel": dom_name, "bound": "mfma", "achieved": achieved, "peak": MFMA_F32_PEAK_TFLOPS,
+                     "unit": "TFLOP/s", "frac": achieved / MFMA_F32_PEAK_TFLOPS, "traffic": None,
+                     "avg_launch_ms": dom_time / dom_launches * 1e3, "launches_per_frame": dom_launches / K,
+                     "flops_per_launch": dom_flops / dom_launches},
+        "kernels": {n: {"tflops": v[0] / v[1] / 1e12, "ms_per_frame": v[1] / K * 1e3, "launches_per_frame": v[2] / K}
+                    for n, v in per.items()},
+        "raymarch": {"kernel": "iso_render_gather", "ms_per_frame": rm_time * 1e3},
+    }
+
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        result.update(cpu_reference_leg(args, vol, iso, net, pipe, origins[Wm], low_w, low_h, result, rm_time))
+    if rank == 0:
+        print(json.dumps(result))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+def cpu_reference_leg(args, vol, iso, net, pipe, origin, low_w, low_h, result, rm_time):
+    """CPU baseline (the oracle = a port of the reference's CPU path, timed on this box's host
+    cores on a bounded sample: one frame) and PSNR of the GPU frame against it."""
+    import numpy as np
+    import torch
+    from isosurfacesuperresolution_amd import models, volumes as V, utils
+    from isosurfacesuperresolution_amd.inference import LoadedModel
+    from isosurfacesuperresolution_amd.pipeline import default_shading
+    from oracle import iso_oracle
+
+    cores = os.cpu_count()
+    torch.set_num_threads(cores)
+    ov = iso_oracle.OracleVolume(vol)
+    q = V.quantize3(origin)
+    p = iso_oracle.make_params(low_w, low_h, origin=q, fov=30.0, isovalue=float("%5.3f" % iso))
+    t0 = time.perf_counter()
+    ref, stats = iso_oracle.render(ov, p, threads=0)
+    t_render = time.perf_counter() - t0
+    opt = argparse.Namespace(upsample='bilinear', reconType='residual', useBN=False, numResidualLayers=10)
+    cpu_net = models.createNetwork('EnhanceNet', 4, 101, [0, 1, 2, 3, 4], 6, opt)
+    cpu_net.load_state_dict({k: v.cpu() for k, v in net.state_dict().items()})
+    cpu_model = LoadedModel.from_model(cpu_net.eval(), "cpu", parameters={"initialImage": "zero"})
+    low = torch.from_numpy(ref).permute(2, 0, 1).unsqueeze(0)
+    t0 = time.perf_counter()
+    raw = cpu_model.inference(low, None)
+    raw = torch.cat([raw[:, 0:1].clamp(-1, 1), utils.ScreenSpaceShading.normalize(raw[:, 1:4], dim=1),
+                     raw[:, 4:].clamp(0, 1)], dim=1)
+    rgb_cpu = default_shading("cpu", 30.0)(raw)
+    t_sr = time.perf_counter() - t0
+    # same frame on the GPU (fresh sequence) for PSNR and mask parity
+    pipe.reset()
+    rgb_gpu, raw_gpu = pipe.frame(origin)
+    torch.cuda.synchronize()
+    gbuf = pipe.gbuffer.cpu().numpy()
+    mse = torch.mean((rgb_gpu.cpu() - rgb_cpu) ** 2).item()
+    psnr = 10 * np.log10(1 / max(1e-10, mse))      # mainVideoUnshaded.py:693
+    bytes_alg = stats["bricks_touched"] * 2048 + low_w * low_h * 48
+    out = {
+        "cpu_baseline": {"value": 1.0 / (t_render + t_sr), "unit": "frames/s", "cores": cores, "kind": "port",
+                         "sample": "1 frame: oracle ray-march %dx%d (%.3f s, OpenMP %d threads) + PyTorch CPU EnhanceNet+shading (%.3f s, %d threads)" % (
+                             low_w, low_h, t_render, iso_oracle.num_threads(), t_sr, cores)},
+        "parity": {"mask_mismatches": int((gbuf[..., 3] != ref[..., 3]).sum()),
+                   "gbuffer_max_abs_err_excl_flow": float(np.abs(np.delete(gbuf, [8, 9], axis=2) - np.delete(ref, [8, 9], axis=2)).max()),
+                   "sr_raw_max_abs_err": float((raw_gpu.cpu() - raw).abs().max().item()),
+                   "psnr_rgb_vs_cpu_db": float(psnr)},
+    }
+    result["raymarch"].update({
+        "bricks_touched": stats["bricks_touched"], "samples": stats["samples"], "hit_pixels": stats["hits"],
+        "algorithmic_bytes": bytes_alg, "achieved_GBps": bytes_alg / rm_time / 1e9,
+        "frac_of_8TBps": bytes_alg / rm_time / 1e9 / HBM_PEAK_GBS, "samples_per_s": stats["samples"] / rm_time})
+    return out
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,2 @@
+from .lossbuilder import LossBuilder
+from .lossnet_unshaded import LossNetUnshaded

@@ -1,0 +1,146 @@
+"""``LossNetUnshaded``: training loss on the unshaded G-buffer (mask, normal, depth, AO).
+
+Public surface of ``SuperresolutionNetwork/losses/lossnet_unshaded.py`` (constructor arguments,
+``forward(gt, pred, input, prev_input_warped, prev_pred_warped) -> (loss, {key: float})``,
+static ``pad``) for the l1 / mse(l2) / temp-l2 terms of the README recipe
+``l1:mask:1,l1:ao:1,l1:normal:10,l1:depth:10,temp-l2:color:0.1``:
+
+* spec mini-language ``name:target[:weight]`` (``:30,45-107``); ``('mse','color')`` with weight 0 is
+  always evaluated because PSNR is derived from it (``:37-38``);
+* a border of ``padding`` pixels of gt / pred / prev is zeroed first (``pad``, ``:171-185`` -- note the
+  reference crops both axes with the *height*, so only square inputs are meaningful there; here
+  each axis uses its own size, identical for squares);
+* normals are re-normalised, the gt mask ``clamp(m/2+1/2, 0, 1)`` gates normal / ao / depth terms
+  (``:236-256``); colours come from an internal shader with fov 30, light (0,0,1), white material,
+  specular off, strengths from ``opt.lossAmbient / lossDiffuse / lossSpecular / lossAO`` (``:116-126``);
+* ``temp-l2`` compares against the warped previous prediction (``:357-388``).
+
+Parity note: this module is checked against hand-derived values only -- importing the reference's
+``losses`` package needs torchvision, which this image lacks (parity unpinned for S7).
+"""
+import numpy as np
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from ..utils import ScreenSpaceShading
+from .lossbuilder import LossBuilder
+
+_TARGETS = ('mask', 'normal', 'color', 'ao', 'depth', 'all')
+
+
+class LossNetUnshaded(nn.Module):
+    def __init__(self, device, input_channels, output_channels, high_res, padding, opt):
+        super().__init__()
+        self.padding = padding
+        self.upsample = opt.upsample
+        assert input_channels == 5
+        assert output_channels == 6
+        self.loss_list = [s.split(':') for s in opt.losses.split(',')]
+        builder = LossBuilder(device)
+        loss_dict = {'mse': builder.mse()}
+        self.weight_dict = {('mse', 'color'): 0.0}
+        self.has_discriminator = False
+        self.has_style_or_content_loss = False
+        self.has_temporal_l2_loss = False
+        for entry in self.loss_list:
+            if len(entry) < 2:
+                raise ValueError("illegal format for loss list: " + ':'.join(entry))
+            name, target = entry[0], entry[1]
+            weight = float(entry[2]) if len(entry) > 2 else 1.0
+            if target not in _TARGETS:
+                raise ValueError("Unknown target: " + target)
+            if name in ('mse', 'l2', 'l2_loss'):
+                self.weight_dict[('mse', target)] = weight
+            elif name in ('l1', 'l1_loss'):
+                loss_dict['l1'] = builder.l1_loss()
+                self.weight_dict[('l1', target)] = weight
+            elif name in ('tl2', 'temp-l2'):
+                loss_dict['temp-l2'] = builder.mse()
+                self.weight_dict[('temp-l2', target)] = weight
+                self.has_temporal_l2_loss = True
+            elif name in ('l2-ds', 'l1-ds', 'perceptual', 'texture', 'adv', 'gan', 'tgan', 'sgan'):
+                raise NotImplementedError("loss '%s' is outside the accelerated hot path" % name)
+            else:
+                raise ValueError('unknown loss %s' % name)
+        self.loss_dict = nn.ModuleDict(loss_dict)
+        print('Loss weights:', self.weight_dict)
+
+        sh = ScreenSpaceShading(device)
+        sh.fov(30)
+        sh.ambient_light_color(np.array([opt.lossAmbient] * 3))
+        sh.diffuse_light_color(np.array([opt.lossDiffuse] * 3))
+        sh.specular_light_color(np.array([getattr(opt, 'lossSpecular', 0.0)] * 3))
+        sh.specular_exponent(16)
+        sh.enable_specular = False
+        sh.light_direction(np.array([0.0, 0.0, 1.0]))
+        sh.material_color(np.array([1.0, 1.0, 1.0]))
+        sh.ambient_occlusion(opt.lossAO)
+        self.shading = sh
+        print('LossNet: ambient occlusion strength:', opt.lossAO)
+
+    def get_discr_parameters(self):
+        return []
+
+    @staticmethod
+    def pad(img, border):
+        """Overwrites a ``border``-pixel frame of ``img`` with zeros (size unchanged)."""
+        if border == 0:
+            return img
+        b, c, h, w = img.shape
+        inner = img[:, :, border:h - border, border:w - border]
+        out = F.pad(inner, (border, border, border, border), 'constant', 0)
+        assert out.shape[2] == h and out.shape[3] == w
+        return out
+
+    def forward(self, gt, pred, input, prev_input_warped, prev_pred_warped):
+        B, Cout, Hh, Wh = gt.shape
+        assert Cout == 6
+        assert gt.shape == pred.shape
+        gt = LossNetUnshaded.pad(gt, self.padding)
+        pred = LossNetUnshaded.pad(pred, self.padding)
+        if prev_pred_warped is not None:
+            prev_pred_warped = LossNetUnshaded.pad(prev_pred_warped, self.padding)
+
+        norm = ScreenSpaceShading.normalize
+        gt_mask, pred_mask = gt[:, 0:1], pred[:, 0:1]
+        gate = torch.clamp(gt_mask * 0.5 + 0.5, 0, 1)
+        fields = {
+            'mask': (gt_mask, pred_mask),
+            'normal': (norm(gt[:, 1:4], dim=1) * gate, norm(pred[:, 1:4], dim=1) * gate),
+            'ao': (gt[:, 5:6] * gate, pred[:, 5:6] * gate),
+            'depth': (gt[:, 4:5] * gate, pred[:, 4:5] * gate),
+        }
+        gt_color = self.shading(gt)
+        pred_color = self.shading(pred)
+        fields['color'] = (gt_color, pred_color)
+
+        total = 0.0
+        values = {}
+        for name in ('mse', 'l1'):
+            for target in ('mask', 'normal', 'ao', 'depth', 'color'):
+                key = (name, target)
+                if key in self.weight_dict:
+                    a, b = fields[target]
+                    loss = self.loss_dict[name](a, b)
+                    values[key] = loss.item()
+                    total = total + self.weight_dict[key] * loss
+
+        if self.has_temporal_l2_loss:
+            crit = self.loss_dict['temp-l2']
+            prev = prev_pred_warped
+            tfields = {
+                'mask': lambda: (pred_mask, prev[:, 0:1]),
+                'normal': lambda: (fields['normal'][1], norm(prev[:, 1:4], dim=1) * gate),
+                'ao': lambda: (fields['ao'][1], prev[:, 5:6] * gate),
+                'depth': lambda: (fields['depth'][1], prev[:, 4:5] * gate),
+                'color': lambda: (pred_color, self.shading(prev)),
+            }
+            for target in ('mask', 'normal', 'ao', 'depth', 'color'):
+                key = ('temp-l2', target)
+                if key in self.weight_dict:
+                    a, b = tfields[target]()
+                    loss = crit(a, b)
+                    values[key] = loss.item()
+                    total = total + self.weight_dict[key] * loss
+        return total, values

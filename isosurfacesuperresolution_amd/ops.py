@@ -79,15 +79,34 @@ def prepare_weights(weight, transpose_flip=False):
     return wp
 
 
+# Optional per-launch timing hook for bench.py: a list that receives
+# (kernel_name, algorithmic_flops, start_event, end_event) for every forward launch.
+_profile_sink = None
+
+
+def set_profile_sink(sink):
+    global _profile_sink
+    _profile_sink = sink
+
+
 def _launch_forward(x, wprep, bias, residual, cin, cout, act, slope, upsample2x):
     lib = _sr()
     n, _, hin, win = x.shape
     h, w = (hin * 2, win * 2) if upsample2x else (hin, win)
     y = torch.empty((n, cout, h, w), dtype=torch.float32, device=x.device)
+    sink = _profile_sink
+    if sink is not None:
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        ev0.record()
     rc = lib.isrConv3x3Forward(_ptr(x), _ptr(wprep), _ptr(bias), _ptr(residual), _ptr(y),
                                n, cin, h, w, cout, ACT_CODES[act], float(slope), 1 if upsample2x else 0, _stream())
     if rc != 0:
         raise RuntimeError("isrConv3x3Forward failed (%d)" % rc)
+    if sink is not None:
+        ev1.record()
+        name = "conv3x3_fwd_kernel<%d,%s>" % (1 if cout <= 32 else 2, "true" if upsample2x else "false")
+        groups = (cout + 63) // 64
+        sink.append((name, 2.0 * 9 * cin * cout * n * h * w, groups, ev0, ev1))
     return y
 
 
