@@ -149,6 +149,19 @@ def main():
         dist.destroy_process_group()
 
 
+def host_cores():
+    """CPU cores this process may actually use (cgroup quota, then affinity, then cpu_count)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as f:
+            quota, period = f.read().split()
+        if quota != "max":
+            n = min(n, max(1, int(float(quota) / float(period) + 0.5)))
+    except (OSError, ValueError):
+        pass
+    return min(n, int(os.environ.get("BENCH_CPU_THREADS", "16")))
+
+
 def cpu_reference_leg(args, vol, iso, net, pipe, origin, low_w, low_h, result, rm_time):
     """CPU baseline (the oracle = a port of the reference's CPU path, timed on this box's host
     cores on a bounded sample: one frame) and PSNR of the GPU frame against it."""
@@ -159,13 +172,13 @@ def cpu_reference_leg(args, vol, iso, net, pipe, origin, low_w, low_h, result, r
     from isosurfacesuperresolution_amd.pipeline import default_shading
     from oracle import iso_oracle
 
-    cores = os.cpu_count()
+    cores = host_cores()
     torch.set_num_threads(cores)
     ov = iso_oracle.OracleVolume(vol)
     q = V.quantize3(origin)
     p = iso_oracle.make_params(low_w, low_h, origin=q, fov=30.0, isovalue=float("%5.3f" % iso))
     t0 = time.perf_counter()
-    ref, stats = iso_oracle.render(ov, p, threads=0)
+    ref, stats = iso_oracle.render(ov, p, threads=cores)
     t_render = time.perf_counter() - t0
     opt = argparse.Namespace(upsample='bilinear', reconType='residual', useBN=False, numResidualLayers=10)
     cpu_net = models.createNetwork('EnhanceNet', 4, 101, [0, 1, 2, 3, 4], 6, opt)
@@ -189,7 +202,7 @@ def cpu_reference_leg(args, vol, iso, net, pipe, origin, low_w, low_h, result, r
     out = {
         "cpu_baseline": {"value": 1.0 / (t_render + t_sr), "unit": "frames/s", "cores": cores, "kind": "port",
                          "sample": "1 frame: oracle ray-march %dx%d (%.3f s, OpenMP %d threads) + PyTorch CPU EnhanceNet+shading (%.3f s, %d threads)" % (
-                             low_w, low_h, t_render, iso_oracle.num_threads(), t_sr, cores)},
+                             low_w, low_h, t_render, cores, t_sr, cores)},
         "parity": {"mask_mismatches": int((gbuf[..., 3] != ref[..., 3]).sum()),
                    "gbuffer_max_abs_err_excl_flow": float(np.abs(np.delete(gbuf, [8, 9], axis=2) - np.delete(ref, [8, 9], axis=2)).max()),
                    "sr_raw_max_abs_err": float((raw_gpu.cpu() - raw).abs().max().item()),
