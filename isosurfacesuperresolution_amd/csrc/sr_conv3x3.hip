@@ -58,23 +58,37 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg)
     return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
 }
 
-// One patch element (hi-res coordinates gy, gx; channel ch) of the conv input.
+// One patch element (hi-res coordinates gy, gx; channel ch) of the conv input, fetched through a
+// buffer descriptor of image n: an out-of-range byte offset makes the hardware return 0, which is
+// exactly the conv's zero padding (and the channel padding), so there is no branch and no select
+// between the load and the ds_write that parks the value in LDS.
 template <bool UPS>
-__device__ __forceinline__ float load_input(const ConvParams& p, int n, int ch, int gy, int gx)
+__device__ __forceinline__ float load_input(const ConvParams& p, __amdgpu_buffer_rsrc_t rsrc, int ch, int gy, int gx)
 {
-    if (ch >= p.Cin || (unsigned)gy >= (unsigned)p.H || (unsigned)gx >= (unsigned)p.W) return 0.0f;
-    const float* img = p.x + ((size_t)n * p.Cin + ch) * p.Hin * p.Win;
-    if (!UPS) return img[(size_t)gy * p.Win + gx];
-    // bilinear x2, align_corners=False: src = (dst + .5) * .5 - .5 clamped at 0 (ATen upsample_bilinear2d)
-    float sy = ((float)gy + 0.5f) * 0.5f - 0.5f; sy = sy < 0.f ? 0.f : sy;
-    float sx = ((float)gx + 0.5f) * 0.5f - 0.5f; sx = sx < 0.f ? 0.f : sx;
-    const int y0 = (int)sy, x0 = (int)sx;
-    const int y1 = y0 + (y0 < p.Hin - 1 ? 1 : 0), x1 = x0 + (x0 < p.Win - 1 ? 1 : 0);
-    const float ly = sy - (float)y0, lx = sx - (float)x0;
-    const float hy = 1.0f - ly, hx = 1.0f - lx;
-    const float v00 = img[(size_t)y0 * p.Win + x0], v01 = img[(size_t)y0 * p.Win + x1];
-    const float v10 = img[(size_t)y1 * p.Win + x0], v11 = img[(size_t)y1 * p.Win + x1];
-    return hy * (hx * v00 + lx * v01) + ly * (hx * v10 + lx * v11);
+    const bool ok = ch < p.Cin && (unsigned)gy < (unsigned)p.H && (unsigned)gx < (unsigned)p.W;
+    const unsigned bad = 0xFFFFFFF0u;
+    if (!UPS) {
+        const unsigned off = ok ? (unsigned)(((ch * p.Hin + gy) * p.Win + gx) * 4) : bad;
+        return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, off, 0, 0));
+    } else {
+        // bilinear x2, align_corners=False: src = (dst + .5) * .5 - .5 clamped at 0 (ATen upsample_bilinear2d)
+        float sy = ((float)gy + 0.5f) * 0.5f - 0.5f; sy = sy < 0.f ? 0.f : sy;
+        float sx = ((float)gx + 0.5f) * 0.5f - 0.5f; sx = sx < 0.f ? 0.f : sx;
+        const int y0 = (int)sy, x0 = (int)sx;
+        const int y1 = y0 + (y0 < p.Hin - 1 ? 1 : 0), x1 = x0 + (x0 < p.Win - 1 ? 1 : 0);
+        const float ly = sy - (float)y0, lx = sx - (float)x0;
+        const float hy = 1.0f - ly, hx = 1.0f - lx;
+        const int rowbase = ch * p.Hin;
+        const unsigned o00 = ok ? (unsigned)(((rowbase + y0) * p.Win + x0) * 4) : bad;
+        const unsigned o01 = ok ? (unsigned)(((rowbase + y0) * p.Win + x1) * 4) : bad;
+        const unsigned o10 = ok ? (unsigned)(((rowbase + y1) * p.Win + x0) * 4) : bad;
+        const unsigned o11 = ok ? (unsigned)(((rowbase + y1) * p.Win + x1) * 4) : bad;
+        const float v00 = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, o00, 0, 0));
+        const float v01 = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, o01, 0, 0));
+        const float v10 = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, o10, 0, 0));
+        const float v11 = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, o11, 0, 0));
+        return hy * (hx * v00 + lx * v01) + ly * (hx * v10 + lx * v11);
+    }
 }
 
 constexpr int STAGE_PER_TAP = (STAGE_REGS + 8) / 9;             // 5 patch elements per thread per tap
@@ -109,14 +123,23 @@ __global__ __launch_bounds__(NTHREADS, 1) void conv3x3_fwd_kernel(const ConvPara
 
     const int nchunks = p.cinPad / CK;
 
-    // patch element e of chunk `chunk` (e in [0, CHUNK))
-    auto patch_value = [&](int chunk, int e) -> float {
-        const int c = e / PLANE;
-        const int rem = e - c * PLANE;
-        const int r = rem / PW;
-        const int col = rem - r * PW;
-        return load_input<UPS>(p, n, chunk * CK + c, oy0 + r - 1, ox0 + col - 1);
+    // image n of the input as a buffer resource (per image < 4 GiB)
+    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(p.x + (size_t)n * p.Cin * p.Hin * p.Win), 0, p.Cin * p.Hin * p.Win * 4, 0x00020000);
+    // patch element (c, r, col) of chunk `chunk`
+    auto patch_value = [&](int chunk, int c, int r, int col) -> float {
+        return load_input<UPS>(p, rsrc, c < CK ? chunk * CK + c : p.Cin, oy0 + r - 1, ox0 + col - 1);
     };
+    // element index e -> (c, r, col); advancing e by NTHREADS = 7 rows + 18 cols
+    static_assert(NTHREADS == 7 * PW + 18, "stride decomposition");
+    auto advance = [&](int& c, int& r, int& col) {
+        col += 18; r += 7;                      // branch-free carries (selects, not jumps)
+        const int wc = col >= PW ? 1 : 0;
+        col -= wc * PW; r += wc;
+        const int wr = r >= PH ? 1 : 0;
+        r -= wr * PH; c += wr;
+    };
+    const int c_first = tid / PLANE, r_first = (tid - c_first * PLANE) / PW, col_first = tid - c_first * PLANE - r_first * PW;
     // float4 `q` of the [CK][CP] weight slice of (chunk, tap): row = input channel, CP couts from co0
     auto weight_slice = [&](int chunk, int tap, int q) -> float4 {
         const int row = q / (CP / 4), c4 = q - row * (CP / 4);
@@ -124,7 +147,26 @@ __global__ __launch_bounds__(NTHREADS, 1) void conv3x3_fwd_kernel(const ConvPara
     };
 
     // prologue: chunk 0 in full
-    for (int e = tid; e < CHUNK; e += NTHREADS) patch0[e] = patch_value(0, e);
+    {   // batches of 13 loads in flight, then 13 LDS writes (a load->write loop would serialise
+        // 39 memory round trips per thread in front of the first MFMA)
+        constexpr int PB = 13;
+        static_assert(STAGE_REGS == 3 * PB, "prologue batching");
+        int c = c_first, r = r_first, col = col_first;
+#pragma unroll 1
+        for (int b = 0; b < 3; ++b) {
+            float v[PB];
+#pragma unroll
+            for (int i = 0; i < PB; ++i) {
+                v[i] = patch_value(0, c, r, col);
+                advance(c, r, col);
+            }
+#pragma unroll
+            for (int i = 0; i < PB; ++i) {
+                const int e = tid + (b * PB + i) * NTHREADS;
+                if (e < CHUNK) patch0[e] = v[i];
+            }
+        }
+    }
     for (int tap = 0; tap < 9; ++tap)
         if (tid < WSLICE4) reinterpret_cast<float4*>(wlds0 + tap * CK * CP)[tid] = weight_slice(0, tap, tid);
     __syncthreads();
@@ -139,6 +181,7 @@ __global__ __launch_bounds__(NTHREADS, 1) void conv3x3_fwd_kernel(const ConvPara
         const float* wb = wlds0 + buf * WCHUNK + kh * CP + j;
         float* pnext = patch0 + (buf ^ 1) * CHUNK;
         float* wnext = wlds0 + (buf ^ 1) * WCHUNK;
+        int sc = c_first, sr = r_first, scol = col_first;      // staging cursor of this thread
 #pragma unroll 1
         for (int tap = 0; tap < 9; ++tap) {
             // 1/9 of the next chunk is fetched now and parked in LDS after this tap's MFMAs; the
@@ -148,14 +191,17 @@ __global__ __launch_bounds__(NTHREADS, 1) void conv3x3_fwd_kernel(const ConvPara
             if (more) {
 #pragma unroll
                 for (int i = 0; i < STAGE_PER_TAP; ++i) {
-                    const int e = tid + (tap * STAGE_PER_TAP + i) * NTHREADS;
-                    sv[i] = e < CHUNK ? patch_value(chunk + 1, e) : 0.0f;
+                    sv[i] = patch_value(chunk + 1, sc, sr, scol);
+                    advance(sc, sr, scol);
                 }
-                if (tid < WSLICE4) wv = weight_slice(chunk + 1, tap, tid);
+                wv = weight_slice(chunk + 1, tap, min(tid, WSLICE4 - 1));
             }
             const int dy = tap / 3, dx = tap - dy * 3;
             const float* pt = pb + dy * PW + dx;
             const float* wt = wb + tap * CK * CP;
+            // Pin the memory order only (ALU may interleave with the MFMAs): the staging loads stay
+            // in front of the MFMA block, their ds_writes (and so their vmcnt wait) behind it.
+            __builtin_amdgcn_sched_barrier(0x78F);   // everything but VMEM may cross
 #pragma unroll
             for (int kk = 0; kk < CK / 2; ++kk) {
                 float a[MT], b[4];
@@ -169,6 +215,7 @@ __global__ __launch_bounds__(NTHREADS, 1) void conv3x3_fwd_kernel(const ConvPara
                     for (int r = 0; r < 4; ++r)
                         acc[m][r] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[m], b[r], acc[m][r], 0, 0, 0);
             }
+            __builtin_amdgcn_sched_barrier(0x57F);   // everything but DS writes may cross
             if (more) {
 #pragma unroll
                 for (int i = 0; i < STAGE_PER_TAP; ++i) {
@@ -181,28 +228,47 @@ __global__ __launch_bounds__(NTHREADS, 1) void conv3x3_fwd_kernel(const ConvPara
         __syncthreads();
     }
 
-    // epilogue: D row (cout) = (reg&3) + 8*(reg>>2) + 4*(lane>>5), D col (pixel) = lane&31
+    // epilogue: D row (cout) = (reg&3) + 8*(reg>>2) + 4*(lane>>5), D col (pixel) = lane&31.
+    // Bias and residual are fetched in batches from clamped addresses (no branch per element, one
+    // wait per batch); only the stores are predicated.
     const int ox = ox0 + j;
-    if (ox < p.W) {
+    const int oxc = min(ox, p.W - 1);
+    float bv[MT][16];
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int oy = oy0 + wave * 4 + r;
-            if (oy >= p.H) continue;
+    for (int m = 0; m < MT; ++m)
 #pragma unroll
-            for (int m = 0; m < MT; ++m) {
+        for (int i = 0; i < 16; ++i)
+            bv[m][i] = p.bias[min(p.co0 + m * 32 + (i & 3) + 8 * (i >> 2) + 4 * kh, p.Cout - 1)];
+    const size_t plane = (size_t)p.H * p.W;
 #pragma unroll
-                for (int i = 0; i < 16; ++i) {
-                    const int co = p.co0 + m * 32 + (i & 3) + 8 * (i >> 2) + 4 * kh;
-                    if (co < p.Cout) {
-                        float v = acc[m][r][i];
-                        if (p.bias) v += p.bias[co];
-                        if (p.act == ISR_ACT_RELU) v = v > 0.f ? v : 0.f;
-                        else if (p.act == ISR_ACT_LEAKY) v = v > 0.f ? v : v * p.slope;
-                        const size_t idx = (((size_t)n * p.Cout + co) * p.H + oy) * p.W + ox;
-                        if (p.residual) v += p.residual[idx];
-                        p.y[idx] = v;
-                    }
-                }
+    for (int r = 0; r < 4; ++r) {
+        const int oy = oy0 + wave * 4 + r;
+        const int oyc = min(oy, p.H - 1);
+        const bool pix_ok = ox < p.W && oy < p.H;
+#pragma unroll
+        for (int m = 0; m < MT; ++m) {
+            float rv[16];
+            size_t idx[16];
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const int co = min(p.co0 + m * 32 + (i & 3) + 8 * (i >> 2) + 4 * kh, p.Cout - 1);
+                idx[i] = ((size_t)n * p.Cout + co) * plane + (size_t)oyc * p.W + oxc;
+            }
+            if (p.residual) {
+#pragma unroll
+                for (int i = 0; i < 16; ++i) rv[i] = p.residual[idx[i]];
+            } else {
+#pragma unroll
+                for (int i = 0; i < 16; ++i) rv[i] = 0.0f;
+            }
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const int co = p.co0 + m * 32 + (i & 3) + 8 * (i >> 2) + 4 * kh;
+                float v = acc[m][r][i] + bv[m][i];
+                if (p.act == ISR_ACT_RELU) v = v > 0.f ? v : 0.f;
+                else if (p.act == ISR_ACT_LEAKY) v = v > 0.f ? v : v * p.slope;
+                v += rv[i];
+                if (pix_ok && co < p.Cout) p.y[idx[i]] = v;
             }
         }
     }
@@ -413,6 +479,15 @@ int isrConv3x3Forward(const float* x, const float* wprep, const float* bias, con
     if (nwg > 0x7fffffffLL) return -1;
     const dim3 grid((unsigned)nwg), block(NTHREADS);
     hipStream_t s = (hipStream_t)stream;
+    static float* zero_bias = nullptr;   // bias == NULL -> a device buffer of zeros (keeps the epilogue branch-free)
+    if (!bias) {
+        if (!zero_bias) {
+            if (hipMalloc(&zero_bias, 4096 * sizeof(float)) != hipSuccess) return -2;
+            if (hipMemset(zero_bias, 0, 4096 * sizeof(float)) != hipSuccess) return -2;
+        }
+        if (Cout > 4096) return -1;
+        p.bias = zero_bias;
+    }
     static bool attr_done = false;
     if (!attr_done) {   // > 64 KiB of dynamic LDS needs an explicit opt-in
         (void)hipFuncSetAttribute((const void*)conv3x3_fwd_kernel<1, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)conv_fwd_lds_bytes<1>());
