@@ -50,6 +50,8 @@ struct ConvParams {
     int tilesX, tilesY;
     int act;
     float slope;
+    int dbg;                 // ablation bits for tools/bench_conv.py (0 in production)
+    unsigned long long* stamps;   // dbg & 8: per-workgroup s_memtime stamps (diagnostic builds only)
 };
 
 __device__ __forceinline__ int xcd_remap(int bid, int nwg)
@@ -58,47 +60,68 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg)
     return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
 }
 
-// One patch element (hi-res coordinates gy, gx; channel ch) of the conv input, fetched through a
-// buffer descriptor of image n: an out-of-range byte offset makes the hardware return 0, which is
-// exactly the conv's zero padding (and the channel padding), so there is no branch and no select
-// between the load and the ds_write that parks the value in LDS.
-template <bool UPS>
-__device__ __forceinline__ float load_input(const ConvParams& p, __amdgpu_buffer_rsrc_t rsrc, int ch, int gy, int gx)
+constexpr int STAGE_PER_TAP = (STAGE_REGS + 8) / 9;             // 5 patch elements per thread per tap
+constexpr unsigned BAD_OFFSET = 0x80000000u;                    // beyond any buffer (< 2 GiB per image)
+
+typedef __amdgpu_buffer_rsrc_t rsrc_t;
+
+__device__ __forceinline__ float buf_load(rsrc_t r, unsigned voff)
 {
-    const bool ok = ch < p.Cin && (unsigned)gy < (unsigned)p.H && (unsigned)gx < (unsigned)p.W;
-    const unsigned bad = 0xFFFFFFF0u;
+    return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, (int)voff, 0, 0));
+}
+
+// Staging plan of one thread: element i (i < 45) of a chunk is patch position e = tid + 256*i,
+// i.e. channel c = e / 612 of the chunk, patch row/col (r, col).  The byte offset of that element
+// inside the chunk's 16 input planes does not depend on the chunk, so it is computed once per
+// workgroup; out-of-image positions get BAD_OFFSET (the buffer hardware then returns 0 = the
+// conv's zero padding) and channels beyond Cin fall behind the descriptor's num_records.
+// With the x2-upsampling loader the offset is that of the top-left bilinear tap and `code` packs
+// the other three taps and the two lerp weights: bit0: x1 = x0+1, bit1: y1 = y0+1,
+// bits 2-3: lx in {0, .25, .75}, bits 4-5: ly likewise.
+template <bool UPS>
+__device__ __forceinline__ void plan_element(const ConvParams& p, int e, int oy0, int ox0, unsigned& voff, int& code)
+{
+    const int c = e / PLANE;
+    const int rem = e - c * PLANE;
+    const int r = rem / PW;
+    const int col = rem - r * PW;
+    const int gy = oy0 + r - 1, gx = ox0 + col - 1;
+    const bool ok = e < CHUNK && (unsigned)gy < (unsigned)p.H && (unsigned)gx < (unsigned)p.W;
+    code = 0;
     if (!UPS) {
-        const unsigned off = ok ? (unsigned)(((ch * p.Hin + gy) * p.Win + gx) * 4) : bad;
-        return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, off, 0, 0));
+        voff = ok ? (unsigned)(((c * p.Hin + gy) * p.Win + gx) * 4) : BAD_OFFSET;
     } else {
-        // bilinear x2, align_corners=False: src = (dst + .5) * .5 - .5 clamped at 0 (ATen upsample_bilinear2d)
+        // bilinear x2, align_corners=False (ATen upsample_bilinear2d): src = (dst+.5)*.5-.5, clamped at 0
         float sy = ((float)gy + 0.5f) * 0.5f - 0.5f; sy = sy < 0.f ? 0.f : sy;
         float sx = ((float)gx + 0.5f) * 0.5f - 0.5f; sx = sx < 0.f ? 0.f : sx;
         const int y0 = (int)sy, x0 = (int)sx;
-        const int y1 = y0 + (y0 < p.Hin - 1 ? 1 : 0), x1 = x0 + (x0 < p.Win - 1 ? 1 : 0);
-        const float ly = sy - (float)y0, lx = sx - (float)x0;
-        const float hy = 1.0f - ly, hx = 1.0f - lx;
-        const int rowbase = ch * p.Hin;
-        const unsigned o00 = ok ? (unsigned)(((rowbase + y0) * p.Win + x0) * 4) : bad;
-        const unsigned o01 = ok ? (unsigned)(((rowbase + y0) * p.Win + x1) * 4) : bad;
-        const unsigned o10 = ok ? (unsigned)(((rowbase + y1) * p.Win + x0) * 4) : bad;
-        const unsigned o11 = ok ? (unsigned)(((rowbase + y1) * p.Win + x1) * 4) : bad;
-        const float v00 = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, o00, 0, 0));
-        const float v01 = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, o01, 0, 0));
-        const float v10 = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, o10, 0, 0));
-        const float v11 = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, o11, 0, 0));
-        return hy * (hx * v00 + lx * v01) + ly * (hx * v10 + lx * v11);
+        const float ly = sy - (float)y0, lx = sx - (float)x0;          // exactly 0, .25 or .75
+        const int cx = lx == 0.f ? 0 : (lx < 0.5f ? 1 : 2), cy = ly == 0.f ? 0 : (ly < 0.5f ? 1 : 2);
+        code = (x0 < p.Win - 1 ? 1 : 0) | (y0 < p.Hin - 1 ? 2 : 0) | (cx << 2) | (cy << 4);
+        voff = ok ? (unsigned)(((c * p.Hin + y0) * p.Win + x0) * 4) : BAD_OFFSET;
     }
 }
 
-constexpr int STAGE_PER_TAP = (STAGE_REGS + 8) / 9;             // 5 patch elements per thread per tap
+template <bool UPS>
+__device__ __forceinline__ float fetch_element(rsrc_t rs, unsigned voff, int code, unsigned rowBytes)
+{
+    if (!UPS) return buf_load(rs, voff);
+    const unsigned dx = (code & 1) ? 4u : 0u, dy = (code & 2) ? rowBytes : 0u;
+    const float v00 = buf_load(rs, voff), v01 = buf_load(rs, voff + dx);
+    const float v10 = buf_load(rs, voff + dy), v11 = buf_load(rs, voff + dy + dx);
+    const float lx = (code & 4) ? 0.25f : ((code & 8) ? 0.75f : 0.f);
+    const float ly = (code & 16) ? 0.25f : ((code & 32) ? 0.75f : 0.f);
+    const float hx = 1.0f - lx, hy = 1.0f - ly;
+    return hy * (hx * v00 + lx * v01) + ly * (hx * v10 + lx * v11);
+}
 
 template <int MT, bool UPS>
 __global__ __launch_bounds__(NTHREADS, 1) void conv3x3_fwd_kernel(const ConvParams p)
 {
-    constexpr int CP = MT * 32;                 // padded couts
+    constexpr int CP = MT * 32;                 // padded couts handled by this launch
     constexpr int WCHUNK = 9 * CK * CP;         // weight floats per chunk
     constexpr int WSLICE4 = CK * CP / 4;        // float4 per tap slice (256 or 128)
+    constexpr int NSTAGE = STAGE_PER_TAP * 9;   // 45 planned elements per thread (39 real)
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* patch0 = smem;                       // [2][CHUNK]
     float* wlds0 = smem + 2 * CHUNK;            // [2][WCHUNK]
@@ -113,6 +136,8 @@ __global__ __launch_bounds__(NTHREADS, 1) void conv3x3_fwd_kernel(const ConvPara
     const int ty = t / p.tilesX, tx = t - ty * p.tilesX;
     const int oy0 = ty * TH, ox0 = tx * TW;
 
+    unsigned long long st0 = 0, st1 = 0, st2 = 0;
+    if (p.dbg & 8) st0 = __builtin_amdgcn_s_memtime();
     f32x16 acc[MT][4];
 #pragma unroll
     for (int m = 0; m < MT; ++m)
@@ -122,67 +147,86 @@ __global__ __launch_bounds__(NTHREADS, 1) void conv3x3_fwd_kernel(const ConvPara
             for (int i = 0; i < 16; ++i) acc[m][r][i] = 0.0f;
 
     const int nchunks = p.cinPad / CK;
-
-    // image n of the input as a buffer resource (per image < 4 GiB)
-    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<float*>(p.x + (size_t)n * p.Cin * p.Hin * p.Win), 0, p.Cin * p.Hin * p.Win * 4, 0x00020000);
-    // patch element (c, r, col) of chunk `chunk`
-    auto patch_value = [&](int chunk, int c, int r, int col) -> float {
-        return load_input<UPS>(p, rsrc, c < CK ? chunk * CK + c : p.Cin, oy0 + r - 1, ox0 + col - 1);
-    };
-    // element index e -> (c, r, col); advancing e by NTHREADS = 7 rows + 18 cols
-    static_assert(NTHREADS == 7 * PW + 18, "stride decomposition");
-    auto advance = [&](int& c, int& r, int& col) {
-        col += 18; r += 7;                      // branch-free carries (selects, not jumps)
-        const int wc = col >= PW ? 1 : 0;
-        col -= wc * PW; r += wc;
-        const int wr = r >= PH ? 1 : 0;
-        r -= wr * PH; c += wr;
-    };
-    const int c_first = tid / PLANE, r_first = (tid - c_first * PLANE) / PW, col_first = tid - c_first * PLANE - r_first * PW;
-    // float4 `q` of the [CK][CP] weight slice of (chunk, tap): row = input channel, CP couts from co0
-    auto weight_slice = [&](int chunk, int tap, int q) -> float4 {
-        const int row = q / (CP / 4), c4 = q - row * (CP / 4);
-        return *reinterpret_cast<const float4*>(p.w + ((size_t)tap * p.cinPad + chunk * CK + row) * p.coutPad + p.co0 + c4 * 4);
+    const int planeIn = p.Hin * p.Win;
+    const float* ximg = p.x + (size_t)n * p.Cin * planeIn;
+    const unsigned rowBytes = (unsigned)p.Win * 4u;
+    // descriptor of the 16 input planes of `chunk` (channels >= Cin are out of range -> 0)
+    auto chunk_rsrc = [&](int chunk) -> rsrc_t {
+        const int left = p.Cin - chunk * CK;
+        return __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(ximg + (size_t)chunk * CK * planeIn), 0,
+                                                 left > 0 ? left * planeIn * 4 : 0, 0x00020000);
     };
 
-    // prologue: chunk 0 in full
-    {   // batches of 13 loads in flight, then 13 LDS writes (a load->write loop would serialise
-        // 39 memory round trips per thread in front of the first MFMA)
-        constexpr int PB = 13;
-        static_assert(STAGE_REGS == 3 * PB, "prologue batching");
-        int c = c_first, r = r_first, col = col_first;
-#pragma unroll 1
+    unsigned voff[NSTAGE];
+    int code[UPS ? NSTAGE : 1];
+#pragma unroll
+    for (int i = 0; i < NSTAGE; ++i) {
+        int cd;
+        plan_element<UPS>(p, tid + i * NTHREADS, oy0, ox0, voff[i], cd);
+        if (UPS) code[UPS ? i : 0] = cd;
+    }
+    // weights: float4 `tid` of the [CK][CP] slice of (chunk, tap); rows are input channels
+    const int wrow = min(tid, WSLICE4 - 1) / (CP / 4), wc4 = min(tid, WSLICE4 - 1) - wrow * (CP / 4);
+    const float* wthread = p.w + (size_t)wrow * p.coutPad + p.co0 + wc4 * 4;
+    auto weight_slice = [&](int chunk, int tap) -> float4 {
+        return *reinterpret_cast<const float4*>(wthread + ((size_t)tap * p.cinPad + chunk * CK) * p.coutPad);
+    };
+
+    // prologue: chunk 0 in full, in batches of 13 loads in flight
+    {
+        const rsrc_t rs = chunk_rsrc(0);
+#pragma unroll
         for (int b = 0; b < 3; ++b) {
-            float v[PB];
+            float v[13];
 #pragma unroll
-            for (int i = 0; i < PB; ++i) {
-                v[i] = patch_value(0, c, r, col);
-                advance(c, r, col);
-            }
+            for (int i = 0; i < 13; ++i) v[i] = fetch_element<UPS>(rs, voff[b * 13 + i], UPS ? code[UPS ? b * 13 + i : 0] : 0, rowBytes);
 #pragma unroll
-            for (int i = 0; i < PB; ++i) {
-                const int e = tid + (b * PB + i) * NTHREADS;
+            for (int i = 0; i < 13; ++i) {
+                const int e = tid + (b * 13 + i) * NTHREADS;
                 if (e < CHUNK) patch0[e] = v[i];
             }
         }
+        float4 wv[9];
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) wv[tap] = weight_slice(0, tap);
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap)
+            if (tid < WSLICE4) reinterpret_cast<float4*>(wlds0 + tap * CK * CP)[tid] = wv[tap];
     }
-    for (int tap = 0; tap < 9; ++tap)
-        if (tid < WSLICE4) reinterpret_cast<float4*>(wlds0 + tap * CK * CP)[tid] = weight_slice(0, tap, tid);
     __syncthreads();
+    if (p.dbg & 8) st1 = __builtin_amdgcn_s_memtime();
 
     const int j = lane & 31;       // pixel column inside the tile / cout inside the M tile
     const int kh = lane >> 5;      // which of the 2 k values of the 32x32x2 MFMA this lane feeds
 
+    auto load_ops = [&](float (&a)[MT], float (&b)[4], const float* w_, const float* p_, int kk) {
+#pragma unroll
+        for (int m = 0; m < MT; ++m) a[m] = w_[(2 * kk) * CP + m * 32];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) b[r] = p_[(2 * kk) * PLANE + r * PW];
+    };
+    auto mfma_step = [&](const float (&a)[MT], const float (&b)[4]) {
+#pragma unroll
+        for (int m = 0; m < MT; ++m)
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                acc[m][r] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[m], b[r], acc[m][r], 0, 0, 0);
+    };
+
     for (int chunk = 0; chunk < nchunks; ++chunk) {
         const int buf = chunk & 1;
-        const bool more = chunk + 1 < nchunks;
+        const bool more = chunk + 1 < nchunks && !(p.dbg & 1);
         const float* pb = patch0 + buf * CHUNK + kh * PLANE + (wave * 4) * PW + j;
         const float* wb = wlds0 + buf * WCHUNK + kh * CP + j;
-        float* pnext = patch0 + (buf ^ 1) * CHUNK;
+        float* pnext = patch0 + (buf ^ 1) * CHUNK + tid;
         float* wnext = wlds0 + (buf ^ 1) * WCHUNK;
-        int sc = c_first, sr = r_first, scol = col_first;      // staging cursor of this thread
-#pragma unroll 1
+        const rsrc_t rsn = chunk_rsrc(chunk + 1);
+        // Operand registers are double buffered by hand: the LDS reads of k-step kk+1 are issued
+        // before the 8 MFMAs of k-step kk (512 cycles of cover); the taps are fully unrolled so
+        // that every LDS address is base + immediate and the staging plan is indexed statically.
+        float a0[MT], b0[4], a1[MT], b1[4];
+        load_ops(a0, b0, wb, pb, 0);
+#pragma unroll
         for (int tap = 0; tap < 9; ++tap) {
             // 1/9 of the next chunk is fetched now and parked in LDS after this tap's MFMAs; the
             // other buffer is idle (every wave passed the barrier that ended its last use).
@@ -191,36 +235,39 @@ __global__ __launch_bounds__(NTHREADS, 1) void conv3x3_fwd_kernel(const ConvPara
             if (more) {
 #pragma unroll
                 for (int i = 0; i < STAGE_PER_TAP; ++i) {
-                    sv[i] = patch_value(chunk + 1, sc, sr, scol);
-                    advance(sc, sr, scol);
+                    const int q = tap * STAGE_PER_TAP + i;
+                    if (q < STAGE_REGS) sv[i] = fetch_element<UPS>(rsn, voff[q], UPS ? code[UPS ? q : 0] : 0, rowBytes);
                 }
-                wv = weight_slice(chunk + 1, tap, min(tid, WSLICE4 - 1));
+                wv = weight_slice(chunk + 1, tap);
             }
             const int dy = tap / 3, dx = tap - dy * 3;
+            const int tn = tap + 1, dyn = tn / 3, dxn = tn - dyn * 3;
             const float* pt = pb + dy * PW + dx;
             const float* wt = wb + tap * CK * CP;
-            // Pin the memory order only (ALU may interleave with the MFMAs): the staging loads stay
-            // in front of the MFMA block, their ds_writes (and so their vmcnt wait) behind it.
-            __builtin_amdgcn_sched_barrier(0x78F);   // everything but VMEM may cross
+            const float* ptn = pb + dyn * PW + dxn;
+            const float* wtn = wb + tn * CK * CP;
+            // full scheduling fences: left alone, hipcc sinks each ds_read to just in front of its
+            // consumer (fewer live registers), which re-exposes the LDS latency every k-step, and
+            // hoists the staging ds_writes (with their vmcnt wait) in front of the MFMAs
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int kk = 0; kk < CK / 2; ++kk) {
-                float a[MT], b[4];
-#pragma unroll
-                for (int m = 0; m < MT; ++m) a[m] = wt[(2 * kk) * CP + m * 32];
-#pragma unroll
-                for (int r = 0; r < 4; ++r) b[r] = pt[(2 * kk) * PLANE + r * PW];
-#pragma unroll
-                for (int m = 0; m < MT; ++m)
-#pragma unroll
-                    for (int r = 0; r < 4; ++r)
-                        acc[m][r] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[m], b[r], acc[m][r], 0, 0, 0);
+            for (int kk = 0; kk < CK / 2; kk += 2) {
+                load_ops(a1, b1, wt, pt, kk + 1);
+                __builtin_amdgcn_sched_barrier(0);
+                mfma_step(a0, b0);
+                __builtin_amdgcn_sched_barrier(0);
+                if (kk + 2 < CK / 2) load_ops(a0, b0, wt, pt, kk + 2);
+                else if (tap < 8) load_ops(a0, b0, wtn, ptn, 0);
+                __builtin_amdgcn_sched_barrier(0);
+                mfma_step(a1, b1);
+                __builtin_amdgcn_sched_barrier(0);
             }
-            __builtin_amdgcn_sched_barrier(0x57F);   // everything but DS writes may cross
             if (more) {
 #pragma unroll
                 for (int i = 0; i < STAGE_PER_TAP; ++i) {
-                    const int e = tid + (tap * STAGE_PER_TAP + i) * NTHREADS;
-                    if (e < CHUNK) pnext[e] = sv[i];
+                    const int q = tap * STAGE_PER_TAP + i;
+                    if (q < STAGE_REGS - 1) pnext[q * NTHREADS] = sv[i];
+                    else if (q == STAGE_REGS - 1) { if (tid < CHUNK - (STAGE_REGS - 1) * NTHREADS) pnext[q * NTHREADS] = sv[i]; }
                 }
                 if (tid < WSLICE4) reinterpret_cast<float4*>(wnext + tap * CK * CP)[tid] = wv;
             }
@@ -228,49 +275,54 @@ __global__ __launch_bounds__(NTHREADS, 1) void conv3x3_fwd_kernel(const ConvPara
         __syncthreads();
     }
 
+    if (p.dbg & 8) st2 = __builtin_amdgcn_s_memtime();
     // epilogue: D row (cout) = (reg&3) + 8*(reg>>2) + 4*(lane>>5), D col (pixel) = lane&31.
-    // Bias and residual are fetched in batches from clamped addresses (no branch per element, one
-    // wait per batch); only the stores are predicated.
+    // Output / residual go through buffer descriptors of image n: per-lane byte offset of the pixel
+    // (BAD_OFFSET outside the image), per-register scalar offset of the channel plane; channels
+    // >= Cout fall behind num_records and are dropped by the hardware.  No per-element branches.
     const int ox = ox0 + j;
-    const int oxc = min(ox, p.W - 1);
+    const size_t plane = (size_t)p.H * p.W;
+    const int outBytes = (int)((size_t)p.Cout * plane * 4);
+    const rsrc_t yrs = __builtin_amdgcn_make_buffer_rsrc(p.y + (size_t)n * p.Cout * plane, 0, outBytes, 0x00020000);
+    const rsrc_t rrs = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(p.residual ? p.residual + (size_t)n * p.Cout * plane : p.y), 0, p.residual ? outBytes : 0, 0x00020000);
     float bv[MT][16];
 #pragma unroll
     for (int m = 0; m < MT; ++m)
 #pragma unroll
         for (int i = 0; i < 16; ++i)
             bv[m][i] = p.bias[min(p.co0 + m * 32 + (i & 3) + 8 * (i >> 2) + 4 * kh, p.Cout - 1)];
-    const size_t plane = (size_t)p.H * p.W;
+    const int planeBytes = (int)(plane * 4);
+    const unsigned khoff = (unsigned)(4 * kh) * (unsigned)planeBytes;
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
         const int oy = oy0 + wave * 4 + r;
-        const int oyc = min(oy, p.H - 1);
-        const bool pix_ok = ox < p.W && oy < p.H;
+        const bool pix_ok = ox < p.W && oy < p.H && !(p.dbg & 2);
+        const unsigned pix = pix_ok ? (unsigned)((oy * p.W + ox) * 4) + khoff : BAD_OFFSET;
 #pragma unroll
         for (int m = 0; m < MT; ++m) {
             float rv[16];
-            size_t idx[16];
 #pragma unroll
             for (int i = 0; i < 16; ++i) {
-                const int co = min(p.co0 + m * 32 + (i & 3) + 8 * (i >> 2) + 4 * kh, p.Cout - 1);
-                idx[i] = ((size_t)n * p.Cout + co) * plane + (size_t)oyc * p.W + oxc;
-            }
-            if (p.residual) {
-#pragma unroll
-                for (int i = 0; i < 16; ++i) rv[i] = p.residual[idx[i]];
-            } else {
-#pragma unroll
-                for (int i = 0; i < 16; ++i) rv[i] = 0.0f;
+                const int soff = (p.co0 + m * 32 + (i & 3) + 8 * (i >> 2)) * planeBytes;
+                rv[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rrs, (int)pix, soff, 0));
             }
 #pragma unroll
             for (int i = 0; i < 16; ++i) {
-                const int co = p.co0 + m * 32 + (i & 3) + 8 * (i >> 2) + 4 * kh;
+                const int soff = (p.co0 + m * 32 + (i & 3) + 8 * (i >> 2)) * planeBytes;
                 float v = acc[m][r][i] + bv[m][i];
                 if (p.act == ISR_ACT_RELU) v = v > 0.f ? v : 0.f;
                 else if (p.act == ISR_ACT_LEAKY) v = v > 0.f ? v : v * p.slope;
                 v += rv[i];
-                if (pix_ok && co < p.Cout) p.y[idx[i]] = v;
+                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), yrs, (int)pix, soff, 0);
             }
         }
+    }
+    if ((p.dbg & 8) && tid == 0 && p.stamps) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const unsigned long long st3 = __builtin_amdgcn_s_memtime();
+        unsigned long long* o = p.stamps + (size_t)blockIdx.x * 4;
+        o[0] = st0; o[1] = st1; o[2] = st2; o[3] = st3;
     }
 }
 
@@ -445,7 +497,13 @@ constexpr int WGRAD_MAX_SLABS = 512;
 
 }  // namespace
 
+static int g_conv_dbg = 0;
+static unsigned long long* g_conv_stamps = nullptr;
+
 extern "C" {
+
+void isrDebugSetAblation(int bits) { g_conv_dbg = bits; }   // not part of the public header
+void isrDebugSetStampBuffer(void* p) { g_conv_stamps = (unsigned long long*)p; }
 
 int isrConvCinPad(int Cin) { return ((Cin + CK - 1) / CK) * CK; }
 int isrConvCoutPad(int Cout) { return ((Cout + 31) / 32) * 32; }
@@ -475,6 +533,8 @@ int isrConv3x3Forward(const float* x, const float* wprep, const float* bias, con
     p.cinPad = isrConvCinPad(Cin); p.coutPad = isrConvCoutPad(Cout);
     p.tilesX = (W + TW - 1) / TW; p.tilesY = (H + TH - 1) / TH;
     p.act = act; p.slope = slope;
+    p.dbg = g_conv_dbg;
+    p.stamps = g_conv_stamps;
     const long long nwg = (long long)N * p.tilesX * p.tilesY;
     if (nwg > 0x7fffffffLL) return -1;
     const dim3 grid((unsigned)nwg), block(NTHREADS);
