@@ -61,6 +61,11 @@ int isoGetVolumeInfo(int info[12], float* out_max);
 /* Kernel variant: 0 = per-ray global-memory gather, 1 = wave-cooperative LDS brick cache. */
 int isoSetKernelVariant(int variant);
 
+/* Host-only helpers around the .vbx reader (no GPU needed): volume dims [x,y,z] of the dense box
+ * spanned by the stored bricks, and the dense fp32 data [z][y][x] itself. 0 ok, -2 on failure. */
+int isoVbxInfo(const char* path, int dims[3]);
+int isoVbxReadDense(const char* path, float* hostOut);
+
 /* Release all device memory held by the renderer. */
 void isoShutdown(void);
 

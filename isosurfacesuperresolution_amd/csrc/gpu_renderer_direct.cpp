@@ -461,6 +461,26 @@ int isoSetKernelVariant(int variant)
     return 0;
 }
 
+int isoVbxInfo(const char* path, int dims[3])
+{
+    std::vector<float> dense;
+    std::string err;
+    int nx, ny, nz;
+    if (!path || !vbx_read_dense(path, dense, nx, ny, nz, err)) return -2;
+    dims[0] = nx; dims[1] = ny; dims[2] = nz;
+    return 0;
+}
+
+int isoVbxReadDense(const char* path, float* hostOut)
+{
+    std::vector<float> dense;
+    std::string err;
+    int nx, ny, nz;
+    if (!path || !hostOut || !vbx_read_dense(path, dense, nx, ny, nz, err)) return -2;
+    std::memcpy(hostOut, dense.data(), dense.size() * sizeof(float));
+    return 0;
+}
+
 void isoShutdown(void)
 {
     freeVolume(g.vol);

@@ -1,0 +1,127 @@
+"""Training step of the unshaded temporal network, and its data-parallel form.
+
+Restates ``trainNormal`` of ``SuperresolutionNetwork/mainVideoUnshaded.py:397-473`` (optimizer and
+scheduler of ``:287-300``: Adam(lr 1e-4), ``StepLR(lrStep, 0.5)`` stepped at epoch start; seeds of
+``:170-171``):
+
+    for each clip [B, T, ...]:   loss = 0, previous_output = None
+      for j in range(T):
+        j == 0: previous_warped = initialImage(input[:,0], 6, mode);  previous_warped_loss = target[:,0]
+        j  > 0: previous_warped = warp_upscale(previous_output, flow[:,j-1], 4, special_mask=True)
+        prediction = model(cat(input[:,j], flatten_high(previous_warped, 4)))
+        loss += criterion(target[:,j], prediction, up(input[:,j]), previous_input, previous_warped_loss)
+        previous_output = cat(clamp(mask), normalize(normal), clamp(depth), clamp(ao))   # NOT detached
+      loss.backward(); optimizer.step()
+
+The reference has nothing distributed.  ``DataParallelTrainer`` adds the
+MI355X form: one process per GPU, the global batch split over ranks, identical initial weights
+(rank 0 broadcast), and after ``backward`` ONE all-reduce of a single flat 3.64 MB gradient bucket
+(911 046 fp32; RCCL over xGMI is latency bound at this size, so per-layer buckets would only add
+launches), averaged, then a local Adam step.  Loss terms are batch means, so averaged gradients
+equal the single-process gradients of the global batch.
+"""
+import torch
+import torch.distributed as dist
+import torch.nn.functional as F
+
+from .models import VideoTools
+from .utils import ScreenSpaceShading, initialImage
+
+
+def clip_loss(model, criterion, input, flow, target, initial_image="zero", upscale=4, upsample="bilinear",
+              disable_temporal=False):
+    """input [B,T,5,h,w], flow [B,T,2,h,w], target [B,T,6,4h,4w] -> (loss tensor, sum of per-frame floats)."""
+    B, T, Cout, Hh, Wh = target.shape
+    previous_output = None
+    loss = 0
+    loss_sum = 0.0
+    kw = dict(mode=upsample, **({"align_corners": False} if upsample in ("bilinear", "bicubic") else {}))
+    for j in range(T):
+        if j == 0 or disable_temporal:
+            previous_warped = initialImage(input[:, 0], Cout, initial_image, False, upscale)
+            previous_warped_loss = target[:, 0]
+            previous_input = F.interpolate(input[:, 0], size=(Hh, Wh), **kw)
+        else:
+            previous_warped = VideoTools.warp_upscale(previous_output, flow[:, j - 1], upscale, special_mask=True)
+            previous_warped_loss = previous_warped
+            previous_input = F.interpolate(input[:, j - 1], size=(Hh, Wh), **kw)
+            previous_input = VideoTools.warp_upscale(previous_input, flow[:, j - 1], upscale, special_mask=True)
+        single_input = torch.cat((input[:, j], VideoTools.flatten_high(previous_warped, upscale)), dim=1)
+        prediction, _ = model(single_input)
+        input_high = F.interpolate(input[:, j], size=(Hh, Wh), **kw)
+        loss0, _ = criterion(target[:, j], prediction, input_high, previous_input, previous_warped_loss)
+        loss = loss + loss0
+        loss_sum += float(loss0.item())
+        previous_output = torch.cat([
+            torch.clamp(prediction[:, 0:1], -1, +1),
+            ScreenSpaceShading.normalize(prediction[:, 1:4], dim=1),
+            torch.clamp(prediction[:, 4:5], 0, +1),
+            torch.clamp(prediction[:, 5:6], 0, +1)], dim=1)
+    return loss, loss_sum
+
+
+def make_optimizer(model, lr=1e-4, lr_step=500, lr_gamma=0.5):
+    opt = torch.optim.Adam(model.parameters(), lr=lr)
+    sched = torch.optim.lr_scheduler.StepLR(opt, lr_step, lr_gamma)
+    return opt, sched
+
+
+def train_step(model, criterion, optimizer, batch, **kw):
+    """One optimisation step on a clip batch (single process)."""
+    input, flow, target = batch
+    optimizer.zero_grad()
+    loss, loss_sum = clip_loss(model, criterion, input, flow, target, **kw)
+    loss.backward()
+    optimizer.step()
+    return loss_sum / target.shape[1]
+
+
+class DataParallelTrainer:
+    """Data-parallel ``train_step``: one process per GPU, one flat gradient all-reduce per step."""
+
+    def __init__(self, model, criterion, optimizer, process_group=None):
+        self.model, self.criterion, self.optimizer = model, criterion, optimizer
+        self.group = process_group
+        self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
+        self.params = [p for p in model.parameters() if p.requires_grad]
+        self.numel = sum(p.numel() for p in self.params)
+        first = self.params[0]
+        self.bucket = torch.zeros(self.numel, dtype=first.dtype, device=first.device)
+        if self.world > 1:
+            for p in self.params:          # identical start on every rank
+                dist.broadcast(p.data, src=0, group=process_group)
+
+    def shard(self, batch):
+        """Rank's slice of a global clip batch (B must divide evenly)."""
+        if self.world == 1:
+            return batch
+        rank = dist.get_rank(self.group)
+        B = batch[0].shape[0]
+        assert B % self.world == 0, "global batch must be divisible by the number of ranks"
+        per = B // self.world
+        return tuple(t[rank * per:(rank + 1) * per] for t in batch)
+
+    def _allreduce_gradients(self):
+        off = 0
+        for p in self.params:
+            n = p.numel()
+            g = p.grad if p.grad is not None else torch.zeros_like(p)
+            self.bucket[off:off + n].copy_(g.reshape(-1))
+            off += n
+        dist.all_reduce(self.bucket, op=dist.ReduceOp.SUM, group=self.group)
+        self.bucket.div_(self.world)
+        off = 0
+        for p in self.params:
+            n = p.numel()
+            p.grad = self.bucket[off:off + n].view_as(p).clone() if p.grad is None else p.grad.copy_(self.bucket[off:off + n].view_as(p))
+            off += n
+
+    def step(self, local_batch, **kw):
+        input, flow, target = local_batch
+        self.optimizer.zero_grad()
+        loss, loss_sum = clip_loss(self.model, self.criterion, input, flow, target, **kw)
+        loss.backward()
+        if self.world > 1:
+            self._allreduce_gradients()
+        self.optimizer.step()
+        return loss_sum / target.shape[1]
