@@ -61,6 +61,12 @@ int isoGetVolumeInfo(int info[12], float* out_max);
 /* Kernel variant: 0 = per-ray global-memory gather, 1 = wave-cooperative LDS brick cache. */
 int isoSetKernelVariant(int variant);
 
+/* Optional per-frame kernel timing for benchmarks: while enabled, each ray-march dispatch carries a
+ * start/stop event pair on its own packet.  isoProfileGet(i, &ms) after synchronising. */
+int isoProfileEnable(int on);
+int isoProfileCount(void);
+int isoProfileGet(int i, float* ms);
+
 /* Host-only helpers around the .vbx reader (no GPU needed): volume dims [x,y,z] of the dense box
  * spanned by the stored bricks, and the dense fp32 data [z][y][x] itself. 0 ok, -2 on failure. */
 int isoVbxInfo(const char* path, int dims[3]);

@@ -51,6 +51,15 @@ int isrConv3x3WeightGrad(const float* x, const float* gz, float* dw, float* db, 
 /* gz = gy * act'(y) for the activations above (y is the post-activation output, before the residual add). */
 int isrActBackward(const float* gy, const float* y, float* gz, long long count, int act, float slope, void* stream);
 
+/* Optional per-dispatch timing of isrConv3x3Forward for benchmarks: while enabled, every forward
+ * dispatch carries a start/stop event pair on its own packet (no extra stream operations).
+ * isrProfileEnable(1) clears the records and starts recording, (0) stops.  After synchronising the
+ * stream, record i gives variant = 2*MT + upsample (MT = 1|2 M tiles of 32 output channels), the
+ * algorithmic FLOPs 2*9*Cin*Cout*N*H*W of the dispatch and its duration in ms. */
+int isrProfileEnable(int on);
+int isrProfileCount(void);
+int isrProfileGet(int i, int* variant, double* flops, float* ms);
+
 #ifdef __cplusplus
 }
 #endif

@@ -15,6 +15,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <string>
+#include <utility>
 #include <vector>
 
 #include "../../include/gpu_renderer_direct.h"
@@ -61,6 +62,8 @@ struct State {
     double lastOrigin[3] = { 0, 0, -1 }, lastLookAt[3] = { 0, 0, 0 };
     Volume vol;
     int variant = 0;
+    bool profile = false;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> events;   // one pair per profiled frame
 };
 State g;
 
@@ -298,7 +301,12 @@ bool launchFrame(float* out, hipStream_t stream)
     p.any_leaf = v.nleaf > 0;
     p.bricks = v.bricks; p.slot = v.slot; p.leaf = v.leaf; p.node1 = v.node1;
     p.out = out;
-    iso_launch_render(p, g.variant, stream);
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    if (g.profile) {
+        if (hipEventCreate(&e0) == hipSuccess && hipEventCreate(&e1) == hipSuccess) g.events.emplace_back(e0, e1);
+        else e0 = e1 = nullptr;
+    }
+    iso_launch_render(p, g.variant, stream, e0, e1);
     if (hipGetLastError() != hipSuccess) return false;
     // GPURendererDirect.cpp:440-442: the camera just rendered becomes the flow reference
     for (int k = 0; k < 3; ++k) { g.lastOrigin[k] = a.cameraOrigin[k]; g.lastLookAt[k] = a.cameraLookAt[k]; }
@@ -459,6 +467,22 @@ int isoSetKernelVariant(int variant)
     if (variant < 0 || variant > 1) return -1;
     g.variant = variant;
     return 0;
+}
+
+int isoProfileEnable(int on)
+{
+    for (auto& e : g.events) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
+    g.events.clear();
+    g.profile = on != 0;
+    return 0;
+}
+
+int isoProfileCount(void) { return (int)g.events.size(); }
+
+int isoProfileGet(int i, float* ms)
+{
+    if (i < 0 || i >= (int)g.events.size() || !ms) return -1;
+    return hipEventElapsedTime(ms, g.events[i].first, g.events[i].second) == hipSuccess ? 0 : -2;
 }
 
 int isoVbxInfo(const char* path, int dims[3])

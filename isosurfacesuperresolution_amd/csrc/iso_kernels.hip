@@ -17,6 +17,7 @@
 // Variant 1: the wave cooperatively stages the brick most lanes need into LDS (ballot vote),
 //            lanes whose ray is inside that brick march out of LDS; see iso_render_lds below.
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 #include <float.h>
 #include <stdint.h>
 
@@ -425,11 +426,12 @@ __global__ __launch_bounds__(64) void iso_brick_fill(const float* __restrict__ d
 
 }  // namespace
 
-void iso_launch_render(const IsoRenderParams& p, int variant, void* stream)
+void iso_launch_render(const IsoRenderParams& p, int variant, void* stream, void* startEvent, void* stopEvent)
 {
     const int tiles = ((p.W + 7) >> 3) * ((p.H + 7) >> 3);
     (void)variant;
-    hipLaunchKernelGGL(iso_render_gather, dim3(tiles), dim3(64), 0, (hipStream_t)stream, p);
+    hipExtLaunchKernelGGL(iso_render_gather, dim3(tiles), dim3(64), 0, (hipStream_t)stream,
+                          (hipEvent_t)startEvent, (hipEvent_t)stopEvent, 0, p);
 }
 
 void iso_launch_brick_flags(const float* dense, int nx, int ny, int nz, int nbx, int nby, int nbz,

@@ -39,7 +39,7 @@ struct IsoRenderParams {
 };
 
 // launchers (iso_kernels.hip)
-void iso_launch_render(const IsoRenderParams& p, int variant, void* stream);
+void iso_launch_render(const IsoRenderParams& p, int variant, void* stream, void* startEvent, void* stopEvent);
 void iso_launch_brick_flags(const float* dense, int nx, int ny, int nz, int nbx, int nby, int nbz,
                             uint8_t* flag9, uint8_t* leaf, int* bbox6, unsigned int* maxbits, void* stream);
 void iso_launch_brick_fill(const float* dense, int nx, int ny, int nz, int nbx, int nby, int nbz,

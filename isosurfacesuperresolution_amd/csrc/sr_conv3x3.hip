@@ -19,7 +19,10 @@
 // [tap][cin][cout] layout (256 B per k-step and M tile; fp32 MFMA is so slow -- 64 cycles per
 // instruction -- that this is ~4 B/clk/CU).
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 #include <stdint.h>
+
+#include <vector>
 
 #include "../../include/isr_sr_kernels.h"
 
@@ -497,10 +500,48 @@ constexpr int WGRAD_MAX_SLABS = 512;
 
 }  // namespace
 
+// ---- optional per-dispatch timing (bench.py): start/stop events ride on the dispatch packet itself
+// (hipExtLaunchKernelGGL), so no extra barrier packets or cache flushes perturb the stream.
+struct ProfileRecord { int variant; double flops; hipEvent_t e0, e1; };
+static bool g_profile = false;
+static std::vector<ProfileRecord> g_records;
+static std::vector<hipEvent_t> g_event_pool;
+static size_t g_pool_used = 0;
+static hipEvent_t pool_event()
+{
+    if (g_pool_used == g_event_pool.size()) {
+        hipEvent_t e;
+        if (hipEventCreate(&e) != hipSuccess) return nullptr;
+        g_event_pool.push_back(e);
+    }
+    return g_event_pool[g_pool_used++];
+}
+
 static int g_conv_dbg = 0;
 static unsigned long long* g_conv_stamps = nullptr;
 
 extern "C" {
+
+// Per-dispatch profiling of isrConv3x3Forward (see include/isr_sr_kernels.h)
+int isrProfileEnable(int on)
+{
+    g_profile = on != 0;
+    g_records.clear();
+    g_pool_used = 0;
+    return 0;
+}
+
+int isrProfileCount(void) { return (int)g_records.size(); }
+
+int isrProfileGet(int i, int* variant, double* flops, float* ms)
+{
+    if (i < 0 || i >= (int)g_records.size()) return -1;
+    const ProfileRecord& r = g_records[i];
+    float t = 0.f;
+    if (!r.e0 || !r.e1 || hipEventElapsedTime(&t, r.e0, r.e1) != hipSuccess) return -2;
+    *variant = r.variant; *flops = r.flops; *ms = t;
+    return 0;
+}
 
 void isrDebugSetAblation(int bits) { g_conv_dbg = bits; }   // not part of the public header
 void isrDebugSetStampBuffer(void* p) { g_conv_stamps = (unsigned long long*)p; }
@@ -559,12 +600,20 @@ int isrConv3x3Forward(const float* x, const float* wprep, const float* bias, con
     // one launch per group of up to 64 output channels (2 M tiles per wave)
     for (int co0 = 0; co0 < p.coutPad; co0 += 64) {
         p.co0 = co0;
-        if (p.coutPad - co0 == 32) {
-            if (upsample2x) hipLaunchKernelGGL((conv3x3_fwd_kernel<1, true>), grid, block, conv_fwd_lds_bytes<1>(), s, p);
-            else hipLaunchKernelGGL((conv3x3_fwd_kernel<1, false>), grid, block, conv_fwd_lds_bytes<1>(), s, p);
+        const int mt = (p.coutPad - co0 == 32) ? 1 : 2;
+        hipEvent_t e0 = nullptr, e1 = nullptr;
+        if (g_profile) {
+            e0 = pool_event(); e1 = pool_event();
+            const int cg = Cout - co0 < 64 ? Cout - co0 : 64;
+            g_records.push_back({ mt * 2 + (upsample2x ? 1 : 0), 2.0 * 9 * Cin * cg * (double)N * H * W, e0, e1 });
+        }
+        const size_t lds = mt == 1 ? conv_fwd_lds_bytes<1>() : conv_fwd_lds_bytes<2>();
+        if (mt == 1) {
+            if (upsample2x) hipExtLaunchKernelGGL((conv3x3_fwd_kernel<1, true>), grid, block, lds, s, e0, e1, 0, p);
+            else hipExtLaunchKernelGGL((conv3x3_fwd_kernel<1, false>), grid, block, lds, s, e0, e1, 0, p);
         } else {
-            if (upsample2x) hipLaunchKernelGGL((conv3x3_fwd_kernel<2, true>), grid, block, conv_fwd_lds_bytes<2>(), s, p);
-            else hipLaunchKernelGGL((conv3x3_fwd_kernel<2, false>), grid, block, conv_fwd_lds_bytes<2>(), s, p);
+            if (upsample2x) hipExtLaunchKernelGGL((conv3x3_fwd_kernel<2, true>), grid, block, lds, s, e0, e1, 0, p);
+            else hipExtLaunchKernelGGL((conv3x3_fwd_kernel<2, false>), grid, block, lds, s, e0, e1, 0, p);
         }
     }
     return hipGetLastError() == hipSuccess ? 0 : -2;

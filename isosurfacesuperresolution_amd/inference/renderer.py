@@ -54,6 +54,12 @@ class DirectRenderer:
         lib.isoGetVolumeInfo.restype = ctypes.c_int
         lib.isoSetKernelVariant.argtypes = [ctypes.c_int]
         lib.isoSetKernelVariant.restype = ctypes.c_int
+        lib.isoProfileEnable.argtypes = [ctypes.c_int]
+        lib.isoProfileEnable.restype = ctypes.c_int
+        lib.isoProfileCount.argtypes = []
+        lib.isoProfileCount.restype = ctypes.c_int
+        lib.isoProfileGet.argtypes = [ctypes.c_int, ctypes.c_void_p]
+        lib.isoProfileGet.restype = ctypes.c_int
         lib.isoShutdown.argtypes = []
         lib.isoShutdown.restype = None
         if lib.initGVDB() != 0:
@@ -105,6 +111,19 @@ class DirectRenderer:
         return {"dims": list(info[0:3]), "bricks": info[3], "leaves": info[4],
                 "node_bbox_min": list(info[5:8]), "node_bbox_max": list(info[8:11]),
                 "brick_mib": info[11], "max_value": mx.value}
+
+    def profile_enable(self, on):
+        """Additive: per-frame kernel timing carried on the dispatch packets (no extra stream ops)."""
+        self.lib.isoProfileEnable(1 if on else 0)
+
+    def profile_times_ms(self):
+        ms = ctypes.c_float()
+        out = []
+        for i in range(self.lib.isoProfileCount()):
+            if self.lib.isoProfileGet(i, ctypes.byref(ms)) != 0:
+                raise RuntimeError("isoProfileGet failed")
+            out.append(ms.value)
+        return out
 
     def set_kernel_variant(self, variant):
         return self.lib.isoSetKernelVariant(int(variant))

@@ -36,6 +36,9 @@ def _sr():
         lib.isrConvWeightGradWorkspace.argtypes = [ci, ci, ci, ci, ci]; lib.isrConvWeightGradWorkspace.restype = ll
         lib.isrConv3x3WeightGrad.argtypes = [vp, vp, vp, vp, vp, ci, ci, ci, ci, ci, vp]; lib.isrConv3x3WeightGrad.restype = ci
         lib.isrActBackward.argtypes = [vp, vp, vp, ll, ci, cf, vp]; lib.isrActBackward.restype = ci
+        lib.isrProfileEnable.argtypes = [ci]; lib.isrProfileEnable.restype = ci
+        lib.isrProfileCount.argtypes = []; lib.isrProfileCount.restype = ci
+        lib.isrProfileGet.argtypes = [ci, vp, vp, vp]; lib.isrProfileGet.restype = ci
         _lib = lib
     return _lib
 
@@ -79,14 +82,27 @@ def prepare_weights(weight, transpose_flip=False):
     return wp
 
 
-# Optional per-launch timing hook for bench.py: a list that receives
-# (kernel_name, algorithmic_flops, start_event, end_event) for every forward launch.
-_profile_sink = None
+# Optional per-dispatch timing for bench.py: the library attaches start/stop events to the
+# dispatch packets themselves (isrProfile*), which does not add stream operations.
+VARIANT_NAMES = {2: "conv3x3_fwd_kernel<1,false>", 3: "conv3x3_fwd_kernel<1,true>",
+                 4: "conv3x3_fwd_kernel<2,false>", 5: "conv3x3_fwd_kernel<2,true>"}
 
 
-def set_profile_sink(sink):
-    global _profile_sink
-    _profile_sink = sink
+def profile_enable(on):
+    _sr().isrProfileEnable(1 if on else 0)
+
+
+def profile_records():
+    """[(kernel_name, algorithmic_flops, milliseconds)] of every forward dispatch since profile_enable(True);
+    call after synchronising."""
+    lib = _sr()
+    out = []
+    v, f, ms = ctypes.c_int(), ctypes.c_double(), ctypes.c_float()
+    for i in range(lib.isrProfileCount()):
+        if lib.isrProfileGet(i, ctypes.byref(v), ctypes.byref(f), ctypes.byref(ms)) != 0:
+            raise RuntimeError("isrProfileGet failed")
+        out.append((VARIANT_NAMES[v.value], f.value, ms.value))
+    return out
 
 
 def _launch_forward(x, wprep, bias, residual, cin, cout, act, slope, upsample2x):
@@ -94,19 +110,10 @@ def _launch_forward(x, wprep, bias, residual, cin, cout, act, slope, upsample2x)
     n, _, hin, win = x.shape
     h, w = (hin * 2, win * 2) if upsample2x else (hin, win)
     y = torch.empty((n, cout, h, w), dtype=torch.float32, device=x.device)
-    sink = _profile_sink
-    if sink is not None:
-        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        ev0.record()
     rc = lib.isrConv3x3Forward(_ptr(x), _ptr(wprep), _ptr(bias), _ptr(residual), _ptr(y),
                                n, cin, h, w, cout, ACT_CODES[act], float(slope), 1 if upsample2x else 0, _stream())
     if rc != 0:
         raise RuntimeError("isrConv3x3Forward failed (%d)" % rc)
-    if sink is not None:
-        ev1.record()
-        name = "conv3x3_fwd_kernel<%d,%s>" % (1 if cout <= 32 else 2, "true" if upsample2x else "false")
-        groups = (cout + 63) // 64
-        sink.append((name, 2.0 * 9 * cin * cout * n * h * w, groups, ev0, ev1))
     return y
 
 
