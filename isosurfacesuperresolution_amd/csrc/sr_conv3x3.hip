@@ -67,6 +67,7 @@ constexpr int STAGE_PER_TAP = (STAGE_REGS + 8) / 9;             // 5 patch eleme
 constexpr unsigned BAD_OFFSET = 0x80000000u;                    // beyond any buffer (< 2 GiB per image)
 
 typedef __amdgpu_buffer_rsrc_t rsrc_t;
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
 __device__ __forceinline__ float buf_load(rsrc_t r, unsigned voff)
 {
@@ -178,14 +179,17 @@ __global__ __launch_bounds__(NTHREADS, 1) void conv3x3_fwd_kernel(const ConvPara
     // prologue: chunk 0 in full, in batches of 13 loads in flight
     {
         const rsrc_t rs = chunk_rsrc(0);
+        constexpr int NB = UPS ? 3 : 1;            // batches: 39 (or 3 x 13 x 4 taps) loads in flight
+        constexpr int PB = STAGE_REGS / NB;
+        static_assert(PB * NB == STAGE_REGS, "prologue batching");
 #pragma unroll
-        for (int b = 0; b < 3; ++b) {
-            float v[13];
+        for (int b = 0; b < NB; ++b) {
+            float v[PB];
 #pragma unroll
-            for (int i = 0; i < 13; ++i) v[i] = fetch_element<UPS>(rs, voff[b * 13 + i], UPS ? code[UPS ? b * 13 + i : 0] : 0, rowBytes);
+            for (int i = 0; i < PB; ++i) v[i] = fetch_element<UPS>(rs, voff[b * PB + i], UPS ? code[UPS ? b * PB + i : 0] : 0, rowBytes);
 #pragma unroll
-            for (int i = 0; i < 13; ++i) {
-                const int e = tid + (b * 13 + i) * NTHREADS;
+            for (int i = 0; i < PB; ++i) {
+                const int e = tid + (b * PB + i) * NTHREADS;
                 if (e < CHUNK) patch0[e] = v[i];
             }
         }
@@ -296,6 +300,45 @@ __global__ __launch_bounds__(NTHREADS, 1) void conv3x3_fwd_kernel(const ConvPara
         for (int i = 0; i < 16; ++i)
             bv[m][i] = p.bias[min(p.co0 + m * 32 + (i & 3) + 8 * (i >> 2) + 4 * kh, p.Cout - 1)];
     const int planeBytes = (int)(plane * 4);
+    if ((p.W & 3) == 0) {
+        // Wide path: each wave transposes one output row (64 couts x 32 pixels) through its own 8 KB
+        // of the now idle LDS, so that a lane owns 4 consecutive pixels of one channel and the
+        // global traffic is dwordx4 (4x fewer store instructions; the dword epilogue is store-issue
+        // bound at ~7 B/clk/CU).  Bias/activation are applied on the way in, the residual on the way out.
+        float* tr = smem + wave * (64 * 32);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int oy = oy0 + wave * 4 + r;
+#pragma unroll
+            for (int m = 0; m < MT; ++m)
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    float v = acc[m][r][i] + bv[m][i];
+                    if (p.act == ISR_ACT_RELU) v = v > 0.f ? v : 0.f;
+                    else if (p.act == ISR_ACT_LEAKY) v = v > 0.f ? v : v * p.slope;
+                    tr[(m * 32 + (i & 3) + 8 * (i >> 2) + 4 * kh) * 32 + j] = v;
+                }
+            // same-wave hand-off: LDS operations of one wave complete in order
+            __builtin_amdgcn_s_waitcnt(0xC07F);   // lgkmcnt(0)
+#pragma unroll
+            for (int t = 0; t < MT * 4; ++t) {
+                const int q = lane + 64 * t;                     // float4 index: cout = q/8, pixel group = q%8
+                const int co = q >> 3, px = ox0 + (q & 7) * 4;
+                const bool ok = oy < p.H && px < p.W && !(p.dbg & 2);
+                const unsigned off = ok ? (unsigned)((oy * p.W + px) * 4) : BAD_OFFSET;
+                const int soff = (p.co0 + co) * planeBytes;      // per lane -> goes into the vector offset
+                float4 v = reinterpret_cast<const float4*>(tr)[q];
+                const unsigned voffs = ok ? off + (unsigned)soff : BAD_OFFSET;
+                if (p.residual) {
+                    const u32x4 rr = __builtin_amdgcn_raw_buffer_load_b128(rrs, (int)voffs, 0, 0);
+                    const float4 rf = __builtin_bit_cast(float4, rr);
+                    v.x += rf.x; v.y += rf.y; v.z += rf.z; v.w += rf.w;
+                }
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), yrs, (int)voffs, 0, 0);
+            }
+            __builtin_amdgcn_s_waitcnt(0xC07F);   // reads done before the next row overwrites the slab
+        }
+    } else {
     const unsigned khoff = (unsigned)(4 * kh) * (unsigned)planeBytes;
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
@@ -320,6 +363,7 @@ __global__ __launch_bounds__(NTHREADS, 1) void conv3x3_fwd_kernel(const ConvPara
                 __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), yrs, (int)pix, soff, 0);
             }
         }
+    }
     }
     if ((p.dbg & 8) && tid == 0 && p.stamps) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");

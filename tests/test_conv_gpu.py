@@ -37,6 +37,9 @@ CASES = [
     (3, 5, 7, 9, 11, 'leaky', False, False, False),
     (1, 6, 64, 8, 8, 'none', False, False, False),        # shape of the data gradient of the final layer
     (1, 64, 64, 1, 1, 'relu', True, False, False),
+    (1, 64, 64, 24, 36, 'none', True, True, False),       # fused skip on the dwordx4 (W % 4 == 0) epilogue
+    (2, 64, 6, 20, 64, 'relu', True, True, False),
+    (1, 64, 64, 8, 8, 'relu', True, False, True),         # tiny upsampled tile
 ]
 
 
