@@ -22,6 +22,7 @@
 #include <hip/hip_ext.h>
 #include <stdint.h>
 
+#include <type_traits>
 #include <vector>
 
 #include "../../include/isr_sr_kernels.h"
@@ -77,13 +78,19 @@ __device__ __forceinline__ float buf_load(rsrc_t r, unsigned voff)
 // Staging plan of one thread: element i (i < 45) of a chunk is patch position e = tid + 256*i,
 // i.e. channel c = e / 612 of the chunk, patch row/col (r, col).  The byte offset of that element
 // inside the chunk's 16 input planes does not depend on the chunk, so it is computed once per
-// workgroup; out-of-image positions get BAD_OFFSET (the buffer hardware then returns 0 = the
-// conv's zero padding) and channels beyond Cin fall behind the descriptor's num_records.
-// With the x2-upsampling loader the offset is that of the top-left bilinear tap and `code` packs
-// the other three taps and the two lerp weights: bit0: x1 = x0+1, bit1: y1 = y0+1,
-// bits 2-3: lx in {0, .25, .75}, bits 4-5: ly likewise.
+// workgroup and kept in ONE register per element; out-of-image positions get PLAN_BAD (the
+// buffer hardware then returns 0 = the conv's zero padding) and channels beyond Cin fall behind
+// the descriptor's num_records.
+// With the x2-upsampling loader (bilinear, align_corners=False: src = (dst+.5)/2-.5 clamped at 0)
+// the word holds the offset of the top-left tap plus 4 flag bits: bits 0/1 = parity of the
+// hi-res x/y (odd -> weight .25 on the +1 neighbour, even -> .75), bits 29/30 = "+1 neighbour
+// exists" in x/y.  At the image borders (dst 0 and dst max) the neighbour flag is cleared, which
+// makes both taps the same texel, so the border cases need no weight of their own.
+constexpr unsigned PLAN_BAD = 0x80000000u;
+constexpr unsigned PLAN_DX = 1u << 29, PLAN_DY = 1u << 30, PLAN_OFF = 0x1FFFFFFCu;
+
 template <bool UPS>
-__device__ __forceinline__ void plan_element(const ConvParams& p, int e, int oy0, int ox0, unsigned& voff, int& code)
+__device__ __forceinline__ unsigned plan_element(const ConvParams& p, int e, int oy0, int ox0)
 {
     const int c = e / PLANE;
     const int rem = e - c * PLANE;
@@ -91,32 +98,37 @@ __device__ __forceinline__ void plan_element(const ConvParams& p, int e, int oy0
     const int col = rem - r * PW;
     const int gy = oy0 + r - 1, gx = ox0 + col - 1;
     const bool ok = e < CHUNK && (unsigned)gy < (unsigned)p.H && (unsigned)gx < (unsigned)p.W;
-    code = 0;
+    if (!ok) return PLAN_BAD;
+    if (!UPS) return (unsigned)(((c * p.Hin + gy) * p.Win + gx) * 4);
+    const int x0 = gx > 0 ? (gx - 1) >> 1 : 0, y0 = gy > 0 ? (gy - 1) >> 1 : 0;
+    unsigned w = (unsigned)(((c * p.Hin + y0) * p.Win + x0) * 4) | (unsigned)(gx & 1) | ((unsigned)(gy & 1) << 1);
+    if (gx > 0 && x0 < p.Win - 1) w |= PLAN_DX;
+    if (gy > 0 && y0 < p.Hin - 1) w |= PLAN_DY;
+    return w;
+}
+
+// phase 1: issue the loads of one element (1 or 4 dwords)
+template <bool UPS>
+__device__ __forceinline__ void issue_element(rsrc_t rs, unsigned w, unsigned rowBytes, float (&raw)[UPS ? 4 : 1])
+{
     if (!UPS) {
-        voff = ok ? (unsigned)(((c * p.Hin + gy) * p.Win + gx) * 4) : BAD_OFFSET;
+        raw[0] = buf_load(rs, w);
     } else {
-        // bilinear x2, align_corners=False (ATen upsample_bilinear2d): src = (dst+.5)*.5-.5, clamped at 0
-        float sy = ((float)gy + 0.5f) * 0.5f - 0.5f; sy = sy < 0.f ? 0.f : sy;
-        float sx = ((float)gx + 0.5f) * 0.5f - 0.5f; sx = sx < 0.f ? 0.f : sx;
-        const int y0 = (int)sy, x0 = (int)sx;
-        const float ly = sy - (float)y0, lx = sx - (float)x0;          // exactly 0, .25 or .75
-        const int cx = lx == 0.f ? 0 : (lx < 0.5f ? 1 : 2), cy = ly == 0.f ? 0 : (ly < 0.5f ? 1 : 2);
-        code = (x0 < p.Win - 1 ? 1 : 0) | (y0 < p.Hin - 1 ? 2 : 0) | (cx << 2) | (cy << 4);
-        voff = ok ? (unsigned)(((c * p.Hin + y0) * p.Win + x0) * 4) : BAD_OFFSET;
+        const unsigned off = (w & PLAN_BAD) ? PLAN_BAD : (w & PLAN_OFF);
+        const unsigned dx = (w & PLAN_DX) ? 4u : 0u, dy = (w & PLAN_DY) ? rowBytes : 0u;
+        raw[0] = buf_load(rs, off); raw[1] = buf_load(rs, off + dx);
+        raw[2] = buf_load(rs, off + dy); raw[3] = buf_load(rs, off + dy + dx);
     }
 }
 
+// phase 2: the value that goes to LDS
 template <bool UPS>
-__device__ __forceinline__ float fetch_element(rsrc_t rs, unsigned voff, int code, unsigned rowBytes)
+__device__ __forceinline__ float finish_element(unsigned w, const float (&raw)[UPS ? 4 : 1])
 {
-    if (!UPS) return buf_load(rs, voff);
-    const unsigned dx = (code & 1) ? 4u : 0u, dy = (code & 2) ? rowBytes : 0u;
-    const float v00 = buf_load(rs, voff), v01 = buf_load(rs, voff + dx);
-    const float v10 = buf_load(rs, voff + dy), v11 = buf_load(rs, voff + dy + dx);
-    const float lx = (code & 4) ? 0.25f : ((code & 8) ? 0.75f : 0.f);
-    const float ly = (code & 16) ? 0.25f : ((code & 32) ? 0.75f : 0.f);
+    if (!UPS) return raw[0];
+    const float lx = (w & 1u) ? 0.25f : 0.75f, ly = (w & 2u) ? 0.25f : 0.75f;
     const float hx = 1.0f - lx, hy = 1.0f - ly;
-    return hy * (hx * v00 + lx * v01) + ly * (hx * v10 + lx * v11);
+    return hy * (hx * raw[0] + lx * raw[1]) + ly * (hx * raw[2] + lx * raw[3]);
 }
 
 template <int MT, bool UPS>
@@ -129,6 +141,7 @@ __global__ __launch_bounds__(NTHREADS, 1) void conv3x3_fwd_kernel(const ConvPara
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* patch0 = smem;                       // [2][CHUNK]
     float* wlds0 = smem + 2 * CHUNK;            // [2][WCHUNK]
+    float* dump = wlds0 + 2 * WCHUNK;           // [4*NTHREADS] write-only sink for masked-off staging lanes
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -161,14 +174,9 @@ __global__ __launch_bounds__(NTHREADS, 1) void conv3x3_fwd_kernel(const ConvPara
                                                  left > 0 ? left * planeIn * 4 : 0, 0x00020000);
     };
 
-    unsigned voff[NSTAGE];
-    int code[UPS ? NSTAGE : 1];
+    unsigned plan[NSTAGE];
 #pragma unroll
-    for (int i = 0; i < NSTAGE; ++i) {
-        int cd;
-        plan_element<UPS>(p, tid + i * NTHREADS, oy0, ox0, voff[i], cd);
-        if (UPS) code[UPS ? i : 0] = cd;
-    }
+    for (int i = 0; i < NSTAGE; ++i) plan[i] = plan_element<UPS>(p, tid + i * NTHREADS, oy0, ox0);
     // weights: float4 `tid` of the [CK][CP] slice of (chunk, tap); rows are input channels
     const int wrow = min(tid, WSLICE4 - 1) / (CP / 4), wc4 = min(tid, WSLICE4 - 1) - wrow * (CP / 4);
     const float* wthread = p.w + (size_t)wrow * p.coutPad + p.co0 + wc4 * 4;
@@ -184,13 +192,13 @@ __global__ __launch_bounds__(NTHREADS, 1) void conv3x3_fwd_kernel(const ConvPara
         static_assert(PB * NB == STAGE_REGS, "prologue batching");
 #pragma unroll
         for (int b = 0; b < NB; ++b) {
-            float v[PB];
+            float raw[PB][UPS ? 4 : 1];
 #pragma unroll
-            for (int i = 0; i < PB; ++i) v[i] = fetch_element<UPS>(rs, voff[b * PB + i], UPS ? code[UPS ? b * PB + i : 0] : 0, rowBytes);
+            for (int i = 0; i < PB; ++i) issue_element<UPS>(rs, plan[b * PB + i], rowBytes, raw[i]);
 #pragma unroll
             for (int i = 0; i < PB; ++i) {
                 const int e = tid + (b * PB + i) * NTHREADS;
-                if (e < CHUNK) patch0[e] = v[i];
+                if (e < CHUNK) patch0[e] = finish_element<UPS>(plan[b * PB + i], raw[i]);
             }
         }
         float4 wv[9];
@@ -231,54 +239,80 @@ __global__ __launch_bounds__(NTHREADS, 1) void conv3x3_fwd_kernel(const ConvPara
         // Operand registers are double buffered by hand: the LDS reads of k-step kk+1 are issued
         // before the 8 MFMAs of k-step kk (512 cycles of cover); the taps are fully unrolled so
         // that every LDS address is base + immediate and the staging plan is indexed statically.
+        //
+        // Staging of the next chunk rides inside the MFMA regions, software pipelined over taps:
+        // k-step i (< 6) of tap t issues the loads of element 6t+i (taps 0..6 cover the 39
+        // elements) and, first, parks the element issued TWO taps earlier (128 MFMAs, ~3.4 us of
+        // cover for an HBM miss) in the idle LDS buffer.  The weight slices go two per tap in
+        // k-steps 6 and 7 of taps 0..4 with the same distance.  So every park happens inside the
+        // tap loop, and the address / lerp VALU work sits in the shadow of the MFMAs.
+        constexpr int EPT = 6;                      // elements issued per tap
+        static_assert(EPT * 7 >= STAGE_REGS, "taps 0..6 must cover the chunk");
         float a0[MT], b0[4], a1[MT], b1[4];
+        float raw[2][EPT][UPS ? 4 : 1];
+        float4 wraw[2][2];
         load_ops(a0, b0, wb, pb, 0);
+        // The plan words are loop invariant; without the opaque copy hipcc hoists the decoded
+        // offsets / weights of all 39 elements out of the chunk loop (+150 live registers, spills).
+        auto plan_word = [&](int q) -> unsigned {
+            unsigned w = plan[q];
+            asm volatile("" : "+v"(w));
+            return w;
+        };
+        // No branch around any staging access (a branch makes hipcc's waitcnt pass fall back to
+        // vmcnt(0) in front of every ds_write): lanes without an element write to the `dump` area.
+        float* const plast = (tid < CHUNK - (STAGE_REGS - 1) * NTHREADS) ? pnext + (STAGE_REGS - 1) * NTHREADS : dump + tid;
+        auto park = [&](int q, const float (&rw)[UPS ? 4 : 1]) {           // element q (static) -> LDS
+            const float v = finish_element<UPS>(plan_word(q), rw);
+            if (q < STAGE_REGS - 1) pnext[q * NTHREADS] = v;
+            else if (q == STAGE_REGS - 1) *plast = v;
+        };
+        float4* const wdst = (WSLICE4 >= NTHREADS || tid < WSLICE4) ? reinterpret_cast<float4*>(wnext) + tid
+                                                                    : reinterpret_cast<float4*>(dump) + tid;
+        const int wstep = (WSLICE4 >= NTHREADS || tid < WSLICE4) ? CK * CP / 4 : 0;   // float4 per tap slice
+        auto stage_work = [&](int tap, int kk) {  // called inside the MFMA region of k-step kk
+            if (kk < EPT) {
+                if (tap >= 2 && (tap - 2) * EPT + kk < STAGE_REGS) park((tap - 2) * EPT + kk, raw[tap & 1][kk]);
+                const int q = tap * EPT + kk;
+                if (tap <= 6 && q < STAGE_REGS) issue_element<UPS>(rsn, plan_word(q), rowBytes, raw[tap & 1][kk]);
+            } else {
+                const int h = kk - EPT;                                   // 0 or 1
+                const int sp = (tap - 2) * 2 + h, si = tap * 2 + h;       // weight slices parked / issued
+                if (tap >= 2 && sp < 9) wdst[sp * wstep] = wraw[tap & 1][h];
+                if (si < 9) wraw[tap & 1][h] = weight_slice(chunk + 1, si);
+            }
+        };
+        // `more` is hoisted out of the tap loop (two copies of the loop) for the same reason.
+        auto run_taps = [&](auto MORE) {
 #pragma unroll
         for (int tap = 0; tap < 9; ++tap) {
-            // 1/9 of the next chunk is fetched now and parked in LDS after this tap's MFMAs; the
-            // other buffer is idle (every wave passed the barrier that ended its last use).
-            float sv[STAGE_PER_TAP];
-            float4 wv;
-            if (more) {
-#pragma unroll
-                for (int i = 0; i < STAGE_PER_TAP; ++i) {
-                    const int q = tap * STAGE_PER_TAP + i;
-                    if (q < STAGE_REGS) sv[i] = fetch_element<UPS>(rsn, voff[q], UPS ? code[UPS ? q : 0] : 0, rowBytes);
-                }
-                wv = weight_slice(chunk + 1, tap);
-            }
             const int dy = tap / 3, dx = tap - dy * 3;
             const int tn = tap + 1, dyn = tn / 3, dxn = tn - dyn * 3;
             const float* pt = pb + dy * PW + dx;
             const float* wt = wb + tap * CK * CP;
             const float* ptn = pb + dyn * PW + dxn;
             const float* wtn = wb + tn * CK * CP;
-            // full scheduling fences: left alone, hipcc sinks each ds_read to just in front of its
-            // consumer (fewer live registers), which re-exposes the LDS latency every k-step, and
-            // hoists the staging ds_writes (with their vmcnt wait) in front of the MFMAs
+            // full scheduling fences between the LDS-read groups and the MFMA groups: left alone,
+            // hipcc sinks each ds_read to just in front of its consumer (fewer live registers),
+            // which re-exposes the LDS latency every k-step
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int kk = 0; kk < CK / 2; kk += 2) {
                 load_ops(a1, b1, wt, pt, kk + 1);
                 __builtin_amdgcn_sched_barrier(0);
                 mfma_step(a0, b0);
+                if (decltype(MORE)::value) stage_work(tap, kk);
                 __builtin_amdgcn_sched_barrier(0);
                 if (kk + 2 < CK / 2) load_ops(a0, b0, wt, pt, kk + 2);
                 else if (tap < 8) load_ops(a0, b0, wtn, ptn, 0);
                 __builtin_amdgcn_sched_barrier(0);
                 mfma_step(a1, b1);
+                if (decltype(MORE)::value) stage_work(tap, kk + 1);
                 __builtin_amdgcn_sched_barrier(0);
             }
-            if (more) {
-#pragma unroll
-                for (int i = 0; i < STAGE_PER_TAP; ++i) {
-                    const int q = tap * STAGE_PER_TAP + i;
-                    if (q < STAGE_REGS - 1) pnext[q * NTHREADS] = sv[i];
-                    else if (q == STAGE_REGS - 1) { if (tid < CHUNK - (STAGE_REGS - 1) * NTHREADS) pnext[q * NTHREADS] = sv[i]; }
-                }
-                if (tid < WSLICE4) reinterpret_cast<float4*>(wnext + tap * CK * CP)[tid] = wv;
-            }
         }
+        };
+        if (more) run_taps(std::true_type{}); else run_taps(std::false_type{});
         __syncthreads();
     }
 
@@ -374,7 +408,7 @@ __global__ __launch_bounds__(NTHREADS, 1) void conv3x3_fwd_kernel(const ConvPara
 }
 
 template <int MT>
-constexpr size_t conv_fwd_lds_bytes() { return (size_t)(2 * CHUNK + 2 * 9 * CK * MT * 32) * sizeof(float); }
+constexpr size_t conv_fwd_lds_bytes() { return (size_t)(2 * CHUNK + 2 * 9 * CK * MT * 32 + 4 * NTHREADS) * sizeof(float); }
 
 // ---- weight re-layout ------------------------------------------------------------------------
 __global__ void prepare_weights_kernel(const float* __restrict__ w, float* __restrict__ wp,
