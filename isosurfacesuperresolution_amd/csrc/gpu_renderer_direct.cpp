@@ -62,6 +62,8 @@ struct State {
     double lastOrigin[3] = { 0, 0, -1 }, lastLookAt[3] = { 0, 0, 0 };
     Volume vol;
     int variant = 0;
+    float* aoHemi = nullptr;     // device copies of the AO tables
+    float* aoRot = nullptr;
     bool profile = false;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> events;   // one pair per profiled frame
 };
@@ -165,6 +167,41 @@ void buildCamera(IsoCamera& c, const double origin[3], const double lookAt[3], c
     inv[3][1] = -(o[0] * inv[0][1] + o[1] * inv[1][1] + o[2] * inv[2][1]);
     inv[3][2] = -(o[0] * inv[0][2] + o[1] * inv[1][2] + o[2] * inv[2][2]);
     inv[0][3] = 0.0; inv[1][3] = 0.0; inv[2][3] = 0.0; inv[3][3] = 1.0;
+}
+
+// AO tables of GPURendererDirect.cpp:146-189, generated with an explicit minstd_rand0 (seed 1): the
+// reference's unseeded std::default_random_engine is implementation defined.
+unsigned lcgNext(unsigned& st)
+{
+    st = unsigned((static_cast<unsigned long long>(st) * 16807ULL) % 2147483647ULL);
+    return st;
+}
+float lcgUniform(unsigned& st) { return float(lcgNext(st) - 1u) * (1.0f / 2147483646.0f); }
+
+bool uploadAoTables()
+{
+    std::vector<float> hemi(512 * 4), rot(16 * 4);
+    unsigned st = 1u;
+    for (int i = 0; i < 512; ++i) {
+        const float u1 = lcgUniform(st), u2 = lcgUniform(st);
+        const float r = sqrtf(u1);
+        const float theta = float(2 * M_PI * u2);
+        const float x = r * cosf(theta), y = r * sinf(theta);
+        float scale = lcgUniform(st);
+        scale = float(0.1 + 0.9 * scale * scale);
+        hemi[4 * i + 0] = x * scale; hemi[4 * i + 1] = y * scale;
+        hemi[4 * i + 2] = sqrtf(1 - u1) * scale; hemi[4 * i + 3] = 0.f;
+    }
+    for (int i = 0; i < 16; ++i) {
+        const float x = lcgUniform(st) * 2 - 1, y = lcgUniform(st) * 2 - 1;
+        const float linv = 1.0f / sqrtf(x * x + y * y);
+        rot[4 * i + 0] = x * linv; rot[4 * i + 1] = y * linv; rot[4 * i + 2] = 0.f; rot[4 * i + 3] = 0.f;
+    }
+    HIP_OK(hipMalloc(&g.aoHemi, hemi.size() * sizeof(float)));
+    HIP_OK(hipMalloc(&g.aoRot, rot.size() * sizeof(float)));
+    HIP_OK(hipMemcpy(g.aoHemi, hemi.data(), hemi.size() * sizeof(float), hipMemcpyHostToDevice));
+    HIP_OK(hipMemcpy(g.aoRot, rot.data(), rot.size() * sizeof(float), hipMemcpyHostToDevice));
+    return true;
 }
 
 float orderBitsToFloat(unsigned int u)
@@ -301,6 +338,9 @@ bool launchFrame(float* out, hipStream_t stream)
     p.any_leaf = v.nleaf > 0;
     p.bricks = v.bricks; p.slot = v.slot; p.leaf = v.leaf; p.node1 = v.node1;
     p.out = out;
+    p.aoSamples = a.aoSamples < 0 ? 0 : (a.aoSamples > 512 ? 512 : a.aoSamples);   // GPURendererDirect.cpp:350
+    p.aoRadius = double(a.aoRadius);
+    p.aoHemi = g.aoHemi; p.aoRot = g.aoRot;
     hipEvent_t e0 = nullptr, e1 = nullptr;
     if (g.profile) {
         if (hipEventCreate(&e0) == hipSuccess && hipEventCreate(&e1) == hipSuccess) g.events.emplace_back(e0, e1);
@@ -333,6 +373,7 @@ int initGVDB(void)
     if (hipFree(nullptr) != hipSuccess) return -1;   // create the context on the current device
     if (!g.initialised) {
         g.args = Args();
+        if (!uploadAoTables()) return -1;
         g.initialised = true;
     }
     return 0;
@@ -508,6 +549,9 @@ int isoVbxReadDense(const char* path, float* hostOut)
 void isoShutdown(void)
 {
     freeVolume(g.vol);
+    if (g.aoHemi) (void)hipFree(g.aoHemi);
+    if (g.aoRot) (void)hipFree(g.aoRot);
+    g.aoHemi = g.aoRot = nullptr;
     g.initialised = false;
 }
 

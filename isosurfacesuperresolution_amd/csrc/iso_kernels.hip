@@ -260,10 +260,76 @@ __device__ __forceinline__ bool make_ray(const IsoRenderParams& P, int i, int j,
     return true;
 }
 
+// ---- ambient occlusion ---------------------------------------------------------------------
+// render_kernel.cu:109-146 (mode 1: ray sampling) with the secondary rays cast by the same
+// double-precision hierarchy as the primary ray; tables of GPURendererDirect.cpp:146-189.
+__device__ bool cast_world(const IsoRenderParams& P, double ox, double oy, double oz, double dx, double dy, double dz,
+                           double& hx, double& hy, double& hz)
+{
+    Ray r;
+    r.ex = (ox - P.t[0]) * P.sinv; r.ey = (oy - P.t[1]) * P.sinv; r.ez = (oz - P.t[2]) * P.sinv;
+    const double ix = dx * P.sinv, iy = dy * P.sinv, iz = dz * P.sinv;
+    const double len = len3(ix, iy, iz);
+    r.dx = ix / len; r.dy = iy / len; r.dz = iz / len;
+    r.ix = 1.0 / r.dx; r.iy = 1.0 / r.dy; r.iz = 1.0 / r.dz;
+    double t0 = len * 1e-9, t1 = len * DBL_MAX;
+#define ISO_SLAB(MIN, MAX, E, INV)                                 \
+    {                                                              \
+        double a = ((double)(MIN) - E) * INV;                      \
+        double b = ((double)(MAX) - E) * INV;                      \
+        if (a > b) { double s_ = a; a = b; b = s_; }               \
+        if (a > t0) t0 = a;                                        \
+        if (b < t1) t1 = b;                                        \
+        if (t0 > t1) return false;                                 \
+    }
+    ISO_SLAB(P.bbmin[0], P.bbmax[0], r.ex, r.ix)
+    ISO_SLAB(P.bbmin[1], P.bbmax[1], r.ey, r.iy)
+    ISO_SLAB(P.bbmin[2], P.bbmax[2], r.ez, r.iz)
+#undef ISO_SLAB
+    r.t0 = t0; r.t1 = t1;
+    double it;
+    if (!hits_hierarchy(P, r, it)) return false;
+    double px, py, pz;
+    ray_at(r, it, px, py, pz);
+    hx = px * P.s + P.t[0]; hy = py * P.s + P.t[1]; hz = pz * P.s + P.t[2];
+    return true;
+}
+
+__device__ double ambient_occlusion(const IsoRenderParams& P, double px, double py, double pz,
+                                    double nx, double ny, double nz, int x, int y)
+{
+    const float* rot = P.aoRot + 4 * ((x % 4) + 4 * (y % 4));
+    const double qx = rot[0], qy = rot[1], qz = rot[2];
+    const double dn = qx * nx + qy * ny + qz * nz;
+    double tx = qx - nx * dn, ty = qy - ny * dn, tz = qz - nz * dn;
+    normalize3(tx, ty, tz);
+    const double bx = ny * tz - nz * ty, by = nz * tx - nx * tz, bz = nx * ty - ny * tx;
+    double ao = 0.0;
+    const int n = P.aoSamples > 512 ? 512 : P.aoSamples;
+    for (int i = 0; i < n; ++i) {
+        double sx = P.aoHemi[4 * i], sy = P.aoHemi[4 * i + 1], sz = P.aoHemi[4 * i + 2];
+        normalize3(sx, sy, sz);
+        double wx = tx * sx + bx * sy + nx * sz;
+        double wy = ty * sx + by * sy + ny * sz;
+        double wz = tz * sx + bz * sy + nz * sz;
+        normalize3(wx, wy, wz);
+        double hx, hy, hz;
+        double value = 1.0;
+        if (cast_world(P, px, py, pz, wx, wy, wz, hx, hy, hz)) {
+            const double dist = len3(px - hx, py - hy, pz - hz);
+            double yv = 1.0 - P.aoRadius / dist;                 // smoothstep(1, 0, r/d)
+            yv = yv < 0.0 ? 0.0 : (yv > 1.0 ? 1.0 : yv);
+            value = yv * yv * (3.0 - (2.0 * yv));
+        }
+        ao += value;
+    }
+    return ao / n;
+}
+
 // Everything after the hit time is known: position, normal, Phong, depth, flow
 // (IsoVolumeRayTracer.h:274-292,300-307,519-548; PhongShader.h:27-38; CPURenderer.cpp:726-737)
 __device__ __forceinline__ void shade_hit(const IsoRenderParams& P, const Ray& r, double it,
-                                          double wdx, double wdy, double wdz, float o[12])
+                                          double wdx, double wdy, double wdz, int px_, int py_, float o[12])
 {
     double ipx, ipy, ipz;
     ray_at(r, it, ipx, ipy, ipz);
@@ -310,6 +376,12 @@ __device__ __forceinline__ void shade_hit(const IsoRenderParams& P, const Ray& r
         const double lw = wx * L[0][3] + wy * L[1][3] + wz * L[2][3] + 1.0 * L[3][3];
         o[8] = -(float)(lx / lw - cx / cw);
         o[9] = -(float)(ly / lw - cy / cw);
+        if (P.aoSamples > 0) {
+            // hemisphere around the normal that faces the viewer, origin pulled back by aoBias = 1e-3
+            double ax = nx, ay = ny, az = nz;
+            if (nx * wdx + ny * wdy + nz * wdz > 0) { ax = -ax; ay = -ay; az = -az; }
+            o[10] = (float)ambient_occlusion(P, wx - 1e-3 * wdx, wy - 1e-3 * wdy, wz - 1e-3 * wdz, ax, ay, az, px_, py_);
+        }
     }
 }
 
@@ -345,7 +417,7 @@ __global__ __launch_bounds__(64) void iso_render_gather(const IsoRenderParams P)
         Ray r;
         double wdx, wdy, wdz, it;
         if (make_ray(P, i, j, r, wdx, wdy, wdz) && hits_hierarchy(P, r, it))
-            shade_hit(P, r, it, wdx, wdy, wdz, o);
+            shade_hit(P, r, it, wdx, wdy, wdz, i, j, o);
     }
     store_pixel(P, i, j, o);
 }

@@ -36,6 +36,10 @@ struct IsoRenderParams {
     const uint8_t* leaf;         // [nbz][nby][nbx] leaf node exists
     const uint8_t* node1;        // [n1z][n1y][n1x]
     float* out;                  // [H][W][12]
+    int aoSamples;               // 0 -> AO channel == 1
+    double aoRadius;             // world units
+    const float* aoHemi;         // [512][4] cosine-hemisphere table
+    const float* aoRot;          // [16][4] per-pixel (x%4, y%4) rotation vectors
 };
 
 // launchers (iso_kernels.hip)

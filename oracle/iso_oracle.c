@@ -147,6 +147,7 @@ void iso_params_default(iso_params* p)
     p->specular_exponent = 32;
     p->light_from_camera = 1;
     p->viewport[2] = 512; p->viewport[3] = 512;
+    p->ao_samples = 0; p->ao_radius = 0.01;
 }
 
 /* ------------------------------------------------------------------ small vector helpers
@@ -431,12 +432,100 @@ static int hits_node2(const iso_volume* v, ray_t* ray, double iso, double* time,
     return 0;
 }
 
+/* ------------------------------------------------------------------ ambient occlusion
+ * GPURendererDirect.cpp:146-189 (tables) and render_kernel.cu:109-146 (mode 1, ray sampling),
+ * with the secondary rays cast by the CPU tracer's own hierarchy (doubles) instead of GVDB's.
+ * The reference has no CPU implementation of this (CPURenderer.cpp:736 writes 1), so this
+ * restatement is the only oracle the HIP kernel's AO has. */
+
+static unsigned lcg_next(unsigned* st)     /* minstd_rand0: x <- 16807 x mod (2^31 - 1) */
+{
+    *st = (unsigned)(((unsigned long long)*st * 16807ULL) % 2147483647ULL);
+    return *st;
+}
+static float lcg_uniform(unsigned* st)     /* [0,1) */
+{
+    return (float)(lcg_next(st) - 1u) * (1.0f / 2147483646.0f);
+}
+
+void iso_ao_tables(float* hemi, float* rot)
+{
+    unsigned st = 1u;
+    for (int i = 0; i < 512; ++i) {
+        float u1 = lcg_uniform(&st), u2 = lcg_uniform(&st);
+        float r = sqrtf(u1);
+        float theta = (float)(2 * M_PI * u2);
+        float x = r * cosf(theta), y = r * sinf(theta);
+        float scale = lcg_uniform(&st);
+        scale = (float)(0.1 + 0.9 * scale * scale);
+        hemi[4 * i + 0] = x * scale; hemi[4 * i + 1] = y * scale;
+        hemi[4 * i + 2] = sqrtf(1 - u1) * scale; hemi[4 * i + 3] = 0.f;
+    }
+    for (int i = 0; i < 16; ++i) {
+        float x = lcg_uniform(&st) * 2 - 1, y = lcg_uniform(&st) * 2 - 1;
+        float linv = 1.0f / sqrtf(x * x + y * y);
+        rot[4 * i + 0] = x * linv; rot[4 * i + 1] = y * linv; rot[4 * i + 2] = 0.f; rot[4 * i + 3] = 0.f;
+    }
+}
+
+/* world-space ray (origin o, unit direction d) -> first hit position; returns 0 on a miss */
+static int cast_world(const iso_volume* v, const double o[3], const double d[3], double iso, double hitw[3], counters_t* cn)
+{
+    ray_t r;
+    double di[3];
+    for (int k = 0; k < 3; ++k) { r.eye[k] = (o[k] - v->t[k]) * v->sinv; di[k] = d[k] * v->sinv; }
+    double len = v3_len(di);
+    for (int k = 0; k < 3; ++k) { r.dir[k] = di[k] / len; r.inv[k] = 1.0 / r.dir[k]; }
+    r.t0 = len * 1e-9; r.t1 = len * DBL_MAX;       /* Ray's default time span, Ray.h:83-84 */
+    if (!ray_clip(&r, v->nbox_min, v->nbox_max)) return 0;
+    double it;
+    if (!hits_node2(v, &r, iso, &it, cn)) return 0;
+    double ip[3];
+    ray_at(&r, it, ip);
+    for (int k = 0; k < 3; ++k) hitw[k] = ip[k] * v->s + v->t[k];
+    return 1;
+}
+
+static double ambient_occlusion(const iso_volume* v, const iso_params* p, const float* hemi, const float* rot,
+                                const double pos[3], const double nrm[3], int x, int y, double iso, counters_t* cn)
+{
+    if (p->ao_samples <= 0) return 1.0;
+    const float* nz = rot + 4 * ((x % 4) + 4 * (y % 4));
+    double noise[3] = { nz[0], nz[1], nz[2] };
+    double dn = v3_dot(noise, nrm);
+    double tan_[3] = { noise[0] - nrm[0] * dn, noise[1] - nrm[1] * dn, noise[2] - nrm[2] * dn };
+    v3_normalize(tan_);
+    double bit[3];
+    v3_cross(nrm, tan_, bit);
+    double ao = 0.0;
+    int n = p->ao_samples > 512 ? 512 : p->ao_samples;
+    for (int i = 0; i < n; ++i) {
+        double st[3] = { hemi[4 * i], hemi[4 * i + 1], hemi[4 * i + 2] };
+        v3_normalize(st);
+        double sw[3];
+        for (int k = 0; k < 3; ++k) sw[k] = tan_[k] * st[0] + bit[k] * st[1] + nrm[k] * st[2];
+        v3_normalize(sw);
+        double h[3];
+        double value = 1.0;
+        if (cast_world(v, pos, sw, iso, h, cn)) {
+            double dd[3] = { pos[0] - h[0], pos[1] - h[1], pos[2] - h[2] };
+            double dist = v3_len(dd);
+            double yv = 1.0 - p->ao_radius / dist;            /* smoothstep(1, 0, r/d), cuda_math.cuh:1507-1511 */
+            yv = yv < 0.0 ? 0.0 : (yv > 1.0 ? 1.0 : yv);
+            value = yv * yv * (3.0 - (2.0 * yv));
+        }
+        ao += value;
+    }
+    return ao / n;
+}
+
 /* ------------------------------------------------------------------ per-pixel driver
  * IsoVolumeRayTracer.h:294-309 (intersectsWS), :274-292 (gradient), :502-551 (operator()),
  * PhongShader.h:27-38, CPURenderer.cpp:726-737 (channel packing) */
 
 static void render_pixel(const iso_volume* v, const iso_params* p, const camera_t* cam, const camera_t* nxt,
-                         double iso, const double light[3], int i, int j, float* o, counters_t* cn, long long* hits)
+                         double iso, const double light[3], const float* hemi, const float* rot,
+                         int i, int j, float* o, counters_t* cn, long long* hits)
 {
     for (int k = 0; k < 12; ++k) o[k] = 0.0f;
     o[8] = -0.0f; o[9] = -0.0f;          /* -static_cast<float>(0) , CPURenderer.cpp:734-735 */
@@ -517,6 +606,14 @@ static void render_pixel(const iso_volume* v, const iso_params* p, const camera_
         double nx_ = sn4[0] / sn4[3], ny_ = sn4[1] / sn4[3];
         o[8] = -(float)(nx_ - cx);
         o[9] = -(float)(ny_ - cy);
+        if (p->ao_samples > 0) {
+            /* hemisphere around the normal that faces the viewer; start 1e-3 world units back along
+             * the primary ray (aoBias, render_kernel.cu:38,251) */
+            double na[3] = { n[0], n[1], n[2] };
+            if (v3_dot(n, dir) > 0) { na[0] = -na[0]; na[1] = -na[1]; na[2] = -na[2]; }
+            double pos[3] = { world[0] - 1e-3 * dir[0], world[1] - 1e-3 * dir[1], world[2] - 1e-3 * dir[2] };
+            o[10] = (float)ambient_occlusion(v, p, hemi, rot, pos, na, i, j, iso, cn);
+        }
     }
 }
 
@@ -541,6 +638,9 @@ int iso_render(const iso_volume* v, const iso_params* p, float* out, long long s
     if (p->light_from_camera) for (int k = 0; k < 3; ++k) light[k] = p->lookat[k] - p->origin[k];
     else for (int k = 0; k < 3; ++k) light[k] = p->light_dir[k];
     v3_normalize(light);
+    static float hemi[512 * 4], rot[16 * 4];
+    static int tables_ready = 0;
+    if (!tables_ready) { iso_ao_tables(hemi, rot); tables_ready = 1; }
     memset(v->touched, 0, (size_t)v->bx * v->by * v->bz);
     long long hits = 0, samples = 0, steps = 0;
     const int W = p->width, H = p->height;
@@ -552,7 +652,7 @@ int iso_render(const iso_volume* v, const iso_params* p, float* out, long long s
         counters_t cn = { 0, 0 };
         long long h = 0;
         for (int i = 0; i < W; ++i)
-            render_pixel(v, p, &cam, &nxt, iso, light, i, j, out + ((size_t)j * W + i) * 12, stats ? &cn : NULL, &h);
+            render_pixel(v, p, &cam, &nxt, iso, light, hemi, rot, i, j, out + ((size_t)j * W + i) * 12, stats ? &cn : NULL, &h);
         hits += h; samples += cn.samples; steps += cn.steps;
     }
     if (stats) {

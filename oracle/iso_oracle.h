@@ -43,7 +43,14 @@ typedef struct {
     int light_from_camera;                  /* CPURenderer.cpp:504-507 */
     double light_dir[3];
     int viewport[4];                        /* minX,minY,maxX,maxY (render_kernel.cu:222) */
+    int ao_samples;                         /* 0 -> AO == 1 (CPURenderer.cpp:736); else ray-cast AO, render_kernel.cu:109-146 */
+    double ao_radius;                       /* world units of the unit-cube normalisation */
 } iso_params;
+
+/* The 512-entry cosine-hemisphere table and the 4x4 rotation table of
+ * GPURendererDirect.cpp:146-189, generated with an explicit minstd_rand0 (seed 1) instead of the
+ * reference's unseeded std::default_random_engine (implementation defined). hemi: [512][4], rot: [16][4]. */
+void iso_ao_tables(float* hemi, float* rot);
 
 void iso_params_default(iso_params* p);
 

@@ -25,6 +25,8 @@ class IsoParams(ctypes.Structure):
         ("light_from_camera", ctypes.c_int),
         ("light_dir", ctypes.c_double * 3),
         ("viewport", ctypes.c_int * 4),
+        ("ao_samples", ctypes.c_int),
+        ("ao_radius", ctypes.c_double),
     ]
 
 
@@ -51,6 +53,7 @@ def lib():
         L.iso_render.restype = ctypes.c_int
         L.iso_render.argtypes = [ctypes.c_void_p, ctypes.POINTER(IsoParams), ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int]
         L.iso_num_threads.restype = ctypes.c_int
+        L.iso_ao_tables.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
         _LIB = L
     return _LIB
 
@@ -87,7 +90,7 @@ def default_params():
 
 
 def make_params(width, height, origin, lookat=(0, 0, 0), up=(0, 1, 0), fov=45.0, isovalue=0.5,
-                last_origin=None, last_lookat=None, viewport=None, **material):
+                last_origin=None, last_lookat=None, viewport=None, ao_samples=0, ao_radius=0.01, **material):
     p = default_params()
     p.width, p.height = int(width), int(height)
     p.fov_deg = float(fov)
@@ -96,6 +99,8 @@ def make_params(width, height, origin, lookat=(0, 0, 0), up=(0, 1, 0), fov=45.0,
         p.last_origin[k] = float((last_origin if last_origin is not None else origin)[k])
         p.last_lookat[k] = float((last_lookat if last_lookat is not None else lookat)[k])
     p.isovalue = float(isovalue)
+    p.ao_samples = int(ao_samples)
+    p.ao_radius = float(ao_radius)
     vp = viewport if viewport is not None else (0, 0, width, height)
     for k in range(4):
         p.viewport[k] = int(vp[k])
@@ -118,3 +123,10 @@ def render(volume, params, threads=0, with_stats=True):
 
 def num_threads():
     return lib().iso_num_threads()
+
+
+def ao_tables():
+    hemi = np.zeros((512, 4), np.float32)
+    rot = np.zeros((16, 4), np.float32)
+    lib().iso_ao_tables(hemi.ctypes.data, rot.ctypes.data)
+    return hemi, rot

@@ -20,7 +20,8 @@ def renderer():
     return DirectRenderer()
 
 
-def _render_gpu(renderer, W, H, origin, fov, iso, lookat=(0, 0, 0), up=(0, 1, 0), viewport=None):
+def _render_gpu(renderer, W, H, origin, fov, iso, lookat=(0, 0, 0), up=(0, 1, 0), viewport=None,
+                ao_samples=0, ao_radius=0.01):
     import torch
     r = renderer
     assert r.send_command("cameraOrigin", V.fmt3(origin)) == 0
@@ -31,8 +32,8 @@ def _render_gpu(renderer, W, H, origin, fov, iso, lookat=(0, 0, 0), up=(0, 1, 0)
     assert r.send_command("resolution", "%d,%d" % (W, H)) == 0
     vp = viewport or (0, 0, W, H)
     assert r.send_command("viewport", "%d,%d,%d,%d" % tuple(vp)) == 0
-    assert r.send_command("aoradius", "0.01") == 0
-    assert r.send_command("aosamples", "0") == 0
+    assert r.send_command("aoradius", "%5.3f" % ao_radius) == 0
+    assert r.send_command("aosamples", "%d" % ao_samples) == 0
     out = torch.full((H, W, 12), 7.0, dtype=torch.float32, device="cuda")
     t = r.render_direct(out)
     assert t >= 0
@@ -80,6 +81,27 @@ def test_parity_with_oracle(renderer, oracle, case, variant):
         _compare(gpu, ref)
         assert ref[..., 3].sum() > 0
         last = origin
+
+
+def test_ambient_occlusion_matches_restatement(renderer, oracle):
+    """Ray-cast AO (render_kernel.cu:109-146 restated on the CPU tracer's hierarchy).  The reference's
+    CPU renderer has no AO, so the oracle here is this project's own restatement (parity unpinned)."""
+    vol = V.ejecta(64)
+    renderer.set_kernel_variant(0)
+    renderer.load_dense(vol)
+    ov = oracle.OracleVolume(vol)
+    origin = V.quantize3(V.orbit_camera(9))
+    W, H = 96, 54
+    _render_gpu(renderer, W, H, origin, 30.0, 0.34)
+    gpu = _render_gpu(renderer, W, H, origin, 30.0, 0.34, ao_samples=12, ao_radius=0.05)
+    p = oracle.make_params(W, H, origin=origin, fov=30.0, isovalue=0.34, ao_samples=12, ao_radius=0.05)
+    ref, _ = oracle.render(ov, p)
+    assert np.array_equal(gpu[..., 3], ref[..., 3])
+    hit = ref[..., 3] == 1
+    assert ref[..., 10][hit].min() < 0.9 and ref[..., 10][~hit].min() == 1.0     # occlusion exists; misses stay 1
+    assert np.abs(gpu[..., 10] - ref[..., 10]).max() <= TOL
+    gpu[..., 10] = ref[..., 10]
+    _compare(gpu, ref)
 
 
 def test_viewport_and_ragged_resolution(renderer, oracle):
