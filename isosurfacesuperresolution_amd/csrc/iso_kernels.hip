@@ -328,6 +328,7 @@ __device__ double ambient_occlusion(const IsoRenderParams& P, double px, double 
 
 // Everything after the hit time is known: position, normal, Phong, depth, flow
 // (IsoVolumeRayTracer.h:274-292,300-307,519-548; PhongShader.h:27-38; CPURenderer.cpp:726-737)
+template <bool AO>
 __device__ __forceinline__ void shade_hit(const IsoRenderParams& P, const Ray& r, double it,
                                           double wdx, double wdy, double wdz, int px_, int py_, float o[12])
 {
@@ -376,7 +377,7 @@ __device__ __forceinline__ void shade_hit(const IsoRenderParams& P, const Ray& r
         const double lw = wx * L[0][3] + wy * L[1][3] + wz * L[2][3] + 1.0 * L[3][3];
         o[8] = -(float)(lx / lw - cx / cw);
         o[9] = -(float)(ly / lw - cy / cw);
-        if (P.aoSamples > 0) {
+        if (AO && P.aoSamples > 0) {
             // hemisphere around the normal that faces the viewer, origin pulled back by aoBias = 1e-3
             double ax = nx, ay = ny, az = nz;
             if (nx * wdx + ny * wdy + nz * wdz > 0) { ax = -ax; ay = -ay; az = -az; }
@@ -402,6 +403,7 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg)
 }
 
 // ---- variant 0: per-lane gather ------------------------------------------------------------
+template <bool AO>
 __global__ __launch_bounds__(64) void iso_render_gather(const IsoRenderParams P)
 {
     const int tiles_x = (P.W + 7) >> 3, tiles_y = (P.H + 7) >> 3;
@@ -417,9 +419,163 @@ __global__ __launch_bounds__(64) void iso_render_gather(const IsoRenderParams P)
         Ray r;
         double wdx, wdy, wdz, it;
         if (make_ray(P, i, j, r, wdx, wdy, wdz) && hits_hierarchy(P, r, it))
-            shade_hit(P, r, it, wdx, wdy, wdz, i, j, o);
+            shade_hit<AO>(P, r, it, wdx, wdy, wdz, i, j, o);
     }
     store_pixel(P, i, j, o);
+}
+
+// ---- variant 1: wave-cooperative LDS brick cache --------------------------------------------
+// The hierarchy walk of hits_hierarchy() as a resumable per-lane state machine, so that the wave
+// can meet between leaves: every lane walks its node/leaf DDAs to its next occupied leaf, the wave
+// votes (ballot) for the leaf of its first waiting lane, stages that 9^3 apron brick into LDS with
+// coalesced 16-byte loads, and the lanes inside that leaf run the voxel DDA on LDS; samples whose
+// cell falls outside the staged brick (entry / exit faces) fall back to the global gather, so the
+// arithmetic -- and therefore the hit mask -- is identical to variant 0 and to the CPU restatement.
+struct Walk {
+    DDA d2, d1, d0;
+    int lvl;          // 2, 1, 0: level whose current cell has not been examined yet
+};
+
+// advance to the next occupied leaf; returns false when the ray has left the volume.
+// On success ray.t0/t1 hold the leaf's span (IsoVolumeRayTracer.h:42) and (lx,ly,lz) its brick index.
+__device__ __forceinline__ bool walk_next_leaf(const IsoRenderParams& P, Walk& w, Ray& ray, int& brick)
+{
+    for (;;) {
+        if (w.lvl == 2) {
+            if (has_node2(P, w.d2.vx, w.d2.vy, w.d2.vz)) {
+                ray.t0 = w.d2.t0; ray.t1 = dda_next(w.d2);
+                dda_init<7>(w.d1, ray);
+                w.lvl = 1;
+            } else if (!dda_step(w.d2)) return false;
+        } else if (w.lvl == 1) {
+            if (has_node1(P, w.d1.vx, w.d1.vy, w.d1.vz)) {
+                ray.t0 = w.d1.t0; ray.t1 = dda_next(w.d1);
+                dda_init<3>(w.d0, ray);
+                w.lvl = 0;
+            } else if (!dda_step(w.d1)) {
+                if (!dda_step(w.d2)) return false;
+                w.lvl = 2;
+            }
+        } else {
+            if (has_leaf(P, w.d0.vx, w.d0.vy, w.d0.vz)) {
+                ray.t0 = w.d0.t0; ray.t1 = dda_next(w.d0);
+                brick = ((w.d0.vz >> 3) * P.nby + (w.d0.vy >> 3)) * P.nbx + (w.d0.vx >> 3);
+                return true;
+            }
+            if (!dda_step(w.d0)) {
+                if (!dda_step(w.d1)) {
+                    if (!dda_step(w.d2)) return false;
+                    w.lvl = 2;
+                } else w.lvl = 1;
+            }
+        }
+    }
+}
+
+// the leaf just visited produced no hit: `while (mDDA.step())` of each enclosing level
+__device__ __forceinline__ bool walk_leave_leaf(Walk& w)
+{
+    if (dda_step(w.d0)) { w.lvl = 0; return true; }
+    if (dda_step(w.d1)) { w.lvl = 1; return true; }
+    if (dda_step(w.d2)) { w.lvl = 2; return true; }
+    return false;
+}
+
+__device__ __forceinline__ float interp_cached(const IsoRenderParams& P, const float* __restrict__ lds, int cachedBrick,
+                                               double px, double py, double pz)
+{
+    const int cx = (int)floor(px), cy = (int)floor(py), cz = (int)floor(pz);
+    if ((unsigned)cx < (unsigned)P.nx && (unsigned)cy < (unsigned)P.ny && (unsigned)cz < (unsigned)P.nz &&
+        ((cz >> 3) * P.nby + (cy >> 3)) * P.nbx + (cx >> 3) == cachedBrick) {
+        const float u = (float)px - (float)cx;
+        const float v = (float)py - (float)cy;
+        const float w = (float)pz - (float)cz;
+        return interp_from_brick(lds, cx & 7, cy & 7, cz & 7, u, v, w);
+    }
+    return interp_global(P, px, py, pz);
+}
+
+__device__ __forceinline__ bool hits_voxel_cached(const IsoRenderParams& P, const float* lds, int cachedBrick,
+                                                  const Ray& ray, double& time)
+{
+    auto value = [&](double t) -> float {
+        double px, py, pz;
+        ray_at(ray, t, px, py, pz);
+        return (float)((double)interp_cached(P, lds, cachedBrick, px, py, pz) - P.iso);
+    };
+    DDA d;
+    dda_init<0>(d, ray);
+    double t0 = d.t0;
+    float v0 = value(t0);
+    do {
+        double t1 = dda_next(d);
+        float v1 = value(t1);
+        if (v0 * v1 <= 0.0f) {
+            double t = 0.5 * (t0 + t1);
+            for (int i = 0; i < 5; ++i) {
+                float v2 = value(t);
+                if (v0 * v2 <= 0.0f) t1 = t;
+                else { t0 = t; v0 = v2; }
+                t = 0.5 * (t0 + t1);
+            }
+            time = t;
+            return true;
+        }
+        t0 = t1;
+        v0 = v1;
+    } while (dda_step(d));
+    return false;
+}
+
+template <bool AO>
+__global__ __launch_bounds__(64) void iso_render_lds(const IsoRenderParams P)
+{
+    __shared__ __attribute__((aligned(16))) float brickLds[ISO_BRICK_STRIDE];
+    const int tiles_x = (P.W + 7) >> 3, tiles_y = (P.H + 7) >> 3;
+    const int tile = xcd_remap(blockIdx.x, tiles_x * tiles_y);
+    const int lane = threadIdx.x;
+    const int i = (tile % tiles_x) * 8 + (lane & 7);
+    const int j = (tile / tiles_x) * 8 + (lane >> 3);
+    const bool in_image = i < P.W && j < P.H;
+    float o[12] = { 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 1.0f, 0.f };
+    const bool inside = in_image && i >= P.vp[0] && j >= P.vp[1] && i < P.vp[2] && j < P.vp[3];
+    Ray r;
+    Walk w;
+    double wdx = 0, wdy = 0, wdz = 0, it = 0;
+    int brick = -1;
+    bool hit = false;
+    // state: 0 = walking to the next leaf, 1 = waiting at a leaf, 2 = finished
+    int state = 2;
+    if (inside) {
+        o[8] = -0.0f; o[9] = -0.0f;
+        if (make_ray(P, i, j, r, wdx, wdy, wdz)) {
+            dda_init<12>(w.d2, r);
+            w.lvl = 2;
+            state = 0;
+        }
+    }
+    for (;;) {
+        if (state == 0) state = walk_next_leaf(P, w, r, brick) ? 1 : 2;
+        const unsigned long long waiting = __ballot(state == 1);
+        if (!waiting) break;                                   // ballot-based early out of the tile
+        const int leader = __ffsll((long long)waiting) - 1;
+        const int chosen = __shfl(brick, leader);
+        const int slot = P.slot[chosen];                       // wave-uniform; a leaf always has a slot
+        const float4* src = reinterpret_cast<const float4*>(P.bricks + (size_t)slot * ISO_BRICK_STRIDE);
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            const int q = lane + 64 * k;
+            if (q < ISO_BRICK_STRIDE / 4) reinterpret_cast<float4*>(brickLds)[q] = src[q];
+        }
+        __syncthreads();
+        if (state == 1 && brick == chosen) {
+            if (hits_voxel_cached(P, brickLds, chosen, r, it)) { hit = true; state = 2; }
+            else state = walk_leave_leaf(w) ? 0 : 2;
+        }
+        __syncthreads();                                       // everyone done reading before the next stage
+    }
+    if (hit) shade_hit<AO>(P, r, it, wdx, wdy, wdz, i, j, o);
+    if (in_image) store_pixel(P, i, j, o);
 }
 
 // ---- brick builder -------------------------------------------------------------------------
@@ -501,9 +657,17 @@ __global__ __launch_bounds__(64) void iso_brick_fill(const float* __restrict__ d
 void iso_launch_render(const IsoRenderParams& p, int variant, void* stream, void* startEvent, void* stopEvent)
 {
     const int tiles = ((p.W + 7) >> 3) * ((p.H + 7) >> 3);
-    (void)variant;
-    hipExtLaunchKernelGGL(iso_render_gather, dim3(tiles), dim3(64), 0, (hipStream_t)stream,
-                          (hipEvent_t)startEvent, (hipEvent_t)stopEvent, 0, p);
+    const dim3 grid(tiles), block(64);
+    hipStream_t st = (hipStream_t)stream;
+    hipEvent_t e0 = (hipEvent_t)startEvent, e1 = (hipEvent_t)stopEvent;
+    // the AO loop is a separate instantiation: it costs registers the SR-mode render (aosamples=0) should not pay
+    if (variant == 1) {
+        if (p.aoSamples > 0) hipExtLaunchKernelGGL(iso_render_lds<true>, grid, block, 0, st, e0, e1, 0, p);
+        else hipExtLaunchKernelGGL(iso_render_lds<false>, grid, block, 0, st, e0, e1, 0, p);
+    } else {
+        if (p.aoSamples > 0) hipExtLaunchKernelGGL(iso_render_gather<true>, grid, block, 0, st, e0, e1, 0, p);
+        else hipExtLaunchKernelGGL(iso_render_gather<false>, grid, block, 0, st, e0, e1, 0, p);
+    }
 }
 
 void iso_launch_brick_flags(const float* dense, int nx, int ny, int nz, int nbx, int nby, int nbz,
