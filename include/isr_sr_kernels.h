@@ -51,6 +51,23 @@ int isrConv3x3WeightGrad(const float* x, const float* gz, float* dw, float* db, 
 /* gz = gy * act'(y) for the activations above (y is the post-activation output, before the residual add). */
 int isrActBackward(const float* gy, const float* y, float* gz, long long count, int act, float slope, void* stream);
 
+/* Input assembly of one inference frame (replaces inference/loadedmodel.py:84-118,
+ * models/videotools.py:8-25,51-87 and utils/initial_image.py:5-54 as ~60 PyTorch launches):
+ * net_input[101][h][w] = cat(mask*2-1, normal, depth  from the renderer's HWC G-buffer,
+ *                           flatten_high(warp_upscale(prev_high, flow, 4, special_mask=True), 4)).
+ * flow_filled: [2][h][w] hole-filled flow; prev_high: [6][4h][4w] or NULL, in which case init_mode
+ * selects initialImage: 0 "zero", 1 "unshaded", 2 "input". */
+int isrAssembleInput(const float* gbuffer_hwc12, const float* flow_filled, const float* prev_high, float* net_input,
+                     int h, int w, int init_mode, int ao_inverted, void* stream);
+
+/* End of one inference frame: raw[6][4h][4w] (EnhanceNet output before its residual reconstruction)
+ * -> next_prev = cat(clamp(mask +- 1), normalize(normal), clamp(depth, ao in [0,1])) after
+ * out[:5] += bilinear x4 of net_input[:5] (models/enhancenet.py:65-78, mainGUI.py:594-599), and
+ * rgb[3][4h][4w] = ScreenSpaceShading(next_prev) (utils/shading.py:148-191; rgb may be NULL).
+ * shading24: ambient[3], diffuse[3], specular[3], light(normalised)[3], material[3], background[3] (host). */
+int isrFinishFrame(const float* raw, const float* net_input, float* next_prev, float* rgb, int h, int w,
+                   const float* shading24, int exponent, float ao_strength, int inverse_ao, int enable_specular, void* stream);
+
 /* Optional per-dispatch timing of isrConv3x3Forward for benchmarks: while enabled, every forward
  * dispatch carries a start/stop event pair on its own packet (no extra stream operations).
  * isrProfileEnable(1) clears the records and starts recording, (0) stops.  After synchronising the

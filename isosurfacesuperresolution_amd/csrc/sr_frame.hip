@@ -1,0 +1,238 @@
+// Frame-assembly kernels around the EnhanceNet convolutions (inference path): everything the
+// reference does with ~100 small PyTorch launches per frame between the renderer and the first
+// convolution, and between the last convolution and the displayed image, in two passes over memory.
+//
+//  isrAssembleInput  = LoadedModel.inference's input assembly (inference/loadedmodel.py:84-118):
+//                      (mask*2-1, normal, depth) from the HWC G-buffer, VideoTools.warp_upscale of
+//                      the previous high-res frame by the (hole-filled) low-res flow
+//                      (models/videotools.py:51-87) and VideoTools.flatten_high (:8-25).
+//  isrFinishFrame    = EnhanceNet._recon_image's residual (models/enhancenet.py:51-90), the
+//                      clamp / normalise of mainGUI.py:594-599 and ScreenSpaceShading.forward
+//                      (utils/shading.py:148-191).
+//
+// Both are HBM-streaming kernels (each ~100-125 MB of traffic at 1080p).
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/isr_sr_kernels.h"
+
+namespace {
+
+// bilinear source coordinate, align_corners=False (ATen area_pixel_compute_source_index)
+__device__ __forceinline__ void src_index(int dst, float scale, int in_size, int& i0, int& i1, float& l1)
+{
+    float s = ((float)dst + 0.5f) * scale - 0.5f;
+    s = s < 0.f ? 0.f : s;
+    i0 = (int)s;
+    i1 = i0 + (i0 < in_size - 1 ? 1 : 0);
+    l1 = s - (float)i0;
+}
+
+struct AssembleParams {
+    const float* gbuf;      // [h][w][12]
+    const float* flow;      // [2][h][w] hole-filled low-res flow (may be NULL when prev == NULL)
+    const float* prev;      // [6][4h][4w] previous output or NULL
+    float* out;             // [101][h][w]
+    int h, w;
+    int init_mode;          // prev == NULL: 0 zero, 1 unshaded constants, 2 upsampled input (+ones)
+    int ao_inverted;
+};
+
+// one thread per low-res pixel; loops over the 4x4 hi-res positions and the 6 channels
+__global__ __launch_bounds__(256) void assemble_input_kernel(const AssembleParams p)
+{
+    const int x = blockIdx.x * blockDim.x + threadIdx.x;
+    const int y = blockIdx.y;
+    if (x >= p.w) return;
+    const size_t plane = (size_t)p.h * p.w;
+    const size_t pix = (size_t)y * p.w + x;
+    const float* g = p.gbuf + pix * 12;
+    const float4 g0 = *reinterpret_cast<const float4*>(g);        // r g b mask
+    const float4 g1 = *reinterpret_cast<const float4*>(g + 4);    // nx ny nz depth
+    p.out[0 * plane + pix] = g0.w * 2.0f - 1.0f;
+    p.out[1 * plane + pix] = g1.x;
+    p.out[2 * plane + pix] = g1.y;
+    p.out[3 * plane + pix] = g1.z;
+    p.out[4 * plane + pix] = g1.w;
+    const int H = 4 * p.h, W = 4 * p.w;
+    const size_t hplane = (size_t)H * W;
+    float* o = p.out + 5 * plane + pix;
+    if (!p.prev) {
+        if (p.init_mode == 0) {
+#pragma unroll 4
+            for (int c = 0; c < 96; ++c) o[(size_t)c * plane] = 0.0f;
+        } else if (p.init_mode == 1) {
+            const float defaults[6] = { -1.f, 0.f, 0.f, 1.f, 0.5f, p.ao_inverted ? 0.f : 1.f };
+            for (int c = 0; c < 6; ++c)
+                for (int k = 0; k < 16; ++k) o[(size_t)(c * 16 + k) * plane] = defaults[c];
+        } else {
+            // "input": bilinear x4 of (mask*2-1, normal, depth), remaining channel = 1
+            for (int dy = 0; dy < 4; ++dy)
+                for (int dx = 0; dx < 4; ++dx) {
+                    int y0, y1, x0, x1; float ly, lx;
+                    src_index(4 * y + dy, 0.25f, p.h, y0, y1, ly);
+                    src_index(4 * x + dx, 0.25f, p.w, x0, x1, lx);
+                    const float hy = 1.f - ly, hx = 1.f - lx;
+                    const float* a = p.gbuf + ((size_t)y0 * p.w + x0) * 12;
+                    const float* b = p.gbuf + ((size_t)y0 * p.w + x1) * 12;
+                    const float* c_ = p.gbuf + ((size_t)y1 * p.w + x0) * 12;
+                    const float* d = p.gbuf + ((size_t)y1 * p.w + x1) * 12;
+                    for (int c = 0; c < 5; ++c) {
+                        const int ch = 3 + c;
+                        float va = a[ch], vb = b[ch], vc = c_[ch], vd = d[ch];
+                        if (c == 0) { va = va * 2.f - 1.f; vb = vb * 2.f - 1.f; vc = vc * 2.f - 1.f; vd = vd * 2.f - 1.f; }
+                        o[(size_t)(c * 16 + dy * 4 + dx) * plane] = hy * (hx * va + lx * vb) + ly * (hx * vc + lx * vd);
+                    }
+                    o[(size_t)(5 * 16 + dy * 4 + dx) * plane] = 1.0f;
+                }
+        }
+        return;
+    }
+    const float* fx = p.flow;
+    const float* fy = p.flow + plane;
+    const float sx_scale = 0.5f * (float)(W - 1), sy_scale = 0.5f * (float)(H - 1);
+    for (int dy = 0; dy < 4; ++dy) {
+        const int Y = 4 * y + dy;
+        int y0, y1; float ly;
+        src_index(Y, 0.25f, p.h, y0, y1, ly);
+        for (int dx = 0; dx < 4; ++dx) {
+            const int X = 4 * x + dx;
+            int x0, x1; float lx;
+            src_index(X, 0.25f, p.w, x0, x1, lx);
+            const float hy = 1.f - ly, hx = 1.f - lx;
+            // flow scaled by (-2, +2) then bilinearly upsampled (videotools.py:65-70)
+            const float f00x = fx[y0 * p.w + x0] * -2.0f, f01x = fx[y0 * p.w + x1] * -2.0f;
+            const float f10x = fx[y1 * p.w + x0] * -2.0f, f11x = fx[y1 * p.w + x1] * -2.0f;
+            const float f00y = fy[y0 * p.w + x0] * 2.0f, f01y = fy[y0 * p.w + x1] * 2.0f;
+            const float f10y = fy[y1 * p.w + x0] * 2.0f, f11y = fy[y1 * p.w + x1] * 2.0f;
+            const float flx = hy * (hx * f00x + lx * f01x) + ly * (hx * f10x + lx * f11x);
+            const float fly = hy * (hx * f00y + lx * f01y) + ly * (hx * f10y + lx * f11y);
+            // grid = linspace(-1, 1)[X] + flow ; sample position with align_corners=True
+            const float gx = (-1.0f + 2.0f * (float)X / (float)(W - 1)) + flx;
+            const float gy = (-1.0f + 2.0f * (float)Y / (float)(H - 1)) + fly;
+            const float sx = (gx + 1.0f) * sx_scale, sy = (gy + 1.0f) * sy_scale;
+            const float fx0 = floorf(sx), fy0 = floorf(sy);
+            const int ix0 = (int)fx0, iy0 = (int)fy0;
+            const float wx1 = sx - fx0, wy1 = sy - fy0, wx0 = 1.f - wx1, wy0 = 1.f - wy1;
+            const bool vx0 = (unsigned)ix0 < (unsigned)W, vx1 = (unsigned)(ix0 + 1) < (unsigned)W;
+            const bool vy0 = (unsigned)iy0 < (unsigned)H, vy1 = (unsigned)(iy0 + 1) < (unsigned)H;
+            const float w00 = wx0 * wy0, w01 = wx1 * wy0, w10 = wx0 * wy1, w11 = wx1 * wy1;
+            const size_t b00 = (size_t)iy0 * W + ix0;
+#pragma unroll
+            for (int c = 0; c < 6; ++c) {
+                const float* q = p.prev + (size_t)c * hplane;
+                float v00 = (vy0 && vx0) ? q[b00] : 0.f, v01 = (vy0 && vx1) ? q[b00 + 1] : 0.f;
+                float v10 = (vy1 && vx0) ? q[b00 + W] : 0.f, v11 = (vy1 && vx1) ? q[b00 + W + 1] : 0.f;
+                float r;
+                if (c == 0) {   // special mask: [-1,1] -> [0,1] before sampling, back after (zero padding == -1)
+                    v00 = (vy0 && vx0) ? v00 * 0.5f + 0.5f : 0.f; v01 = (vy0 && vx1) ? v01 * 0.5f + 0.5f : 0.f;
+                    v10 = (vy1 && vx0) ? v10 * 0.5f + 0.5f : 0.f; v11 = (vy1 && vx1) ? v11 * 0.5f + 0.5f : 0.f;
+                    r = (v00 * w00 + v01 * w01 + v10 * w10 + v11 * w11) * 2.0f - 1.0f;
+                } else {
+                    r = v00 * w00 + v01 * w01 + v10 * w10 + v11 * w11;
+                }
+                o[(size_t)(c * 16 + dy * 4 + dx) * plane] = r;
+            }
+        }
+    }
+}
+
+struct FinishParams {
+    const float* raw;       // [6][H][W] network output before the residual reconstruction
+    const float* net_in;    // [Cin][h][w] network input (first 5 channels are used)
+    float* next_prev;       // [6][H][W] clamped / normalised frame (next frame's "previous")
+    float* rgb;             // [3][H][W] shaded colour (may be NULL)
+    int h, w;
+    float ambient[3], diffuse[3], specular[3], light[3], material[3], background[3];
+    int exponent;
+    float ao_strength;
+    int inverse_ao, enable_specular;
+};
+
+__global__ __launch_bounds__(256) void finish_frame_kernel(const FinishParams p)
+{
+    const int X = blockIdx.x * blockDim.x + threadIdx.x;
+    const int Y = blockIdx.y;
+    const int H = 4 * p.h, W = 4 * p.w;
+    if (X >= W) return;
+    const size_t hplane = (size_t)H * W, lplane = (size_t)p.h * p.w;
+    const size_t pix = (size_t)Y * W + X;
+    int y0, y1, x0, x1; float ly, lx;
+    src_index(Y, 0.25f, p.h, y0, y1, ly);
+    src_index(X, 0.25f, p.w, x0, x1, lx);
+    const float hy = 1.f - ly, hx = 1.f - lx;
+    float v[6];
+#pragma unroll
+    for (int c = 0; c < 6; ++c) v[c] = p.raw[(size_t)c * hplane + pix];
+#pragma unroll
+    for (int c = 0; c < 5; ++c) {       // out[:, :5] += bilinear_resize(x[:, :5])   (enhancenet.py:65-78)
+        const float* q = p.net_in + (size_t)c * lplane;
+        v[c] += hy * (hx * q[y0 * p.w + x0] + lx * q[y0 * p.w + x1]) + ly * (hx * q[y1 * p.w + x0] + lx * q[y1 * p.w + x1]);
+    }
+    // mainGUI.py:594-599
+    const float mask = fminf(fmaxf(v[0], -1.f), 1.f);
+    const float nlen = fmaxf(sqrtf(v[1] * v[1] + v[2] * v[2] + v[3] * v[3]), 1e-7f);
+    const float nx = v[1] / nlen, ny = v[2] / nlen, nz = v[3] / nlen;
+    const float depth = fminf(fmaxf(v[4], 0.f), 1.f);
+    const float ao = fminf(fmaxf(v[5], 0.f), 1.f);
+    p.next_prev[0 * hplane + pix] = mask;
+    p.next_prev[1 * hplane + pix] = nx;
+    p.next_prev[2 * hplane + pix] = ny;
+    p.next_prev[3 * hplane + pix] = nz;
+    p.next_prev[4 * hplane + pix] = depth;
+    p.next_prev[5 * hplane + pix] = ao;
+    if (!p.rgb) return;
+    // utils/shading.py:148-191
+    const float a = p.inverse_ao ? 1.0f - ao : ao;
+    const float aof = p.ao_strength * fminf(fmaxf(a, 0.f), 1.f) + (1.0f - p.ao_strength);
+    const float ndl = p.light[0] * nx + p.light[1] * ny + p.light[2] * nz;
+    float spec = 0.f;
+    if (p.enable_specular) {
+        const float rz = 2.f * ndl * nz - p.light[2];           // eye direction is (0,0,1) everywhere
+        const float base = fminf(fmaxf(rz, 0.f), 1.f);
+        float pw = 1.f;
+        for (int e = 0; e < p.exponent; ++e) pw *= base;
+        spec = ((float)(p.exponent + 2) / (2.0f * 3.14159265358979323846f)) * pw;
+    }
+    const float t = fminf(fmaxf(mask * 0.5f + 0.5f, 0.f), 1.f);
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        float col = p.ambient[k] * p.material[k] + (p.diffuse[k] * p.material[k]) * fabsf(ndl) + spec * p.specular[k];
+        col *= aof;
+        col = p.background[k] + t * (col - p.background[k]);
+        p.rgb[(size_t)k * hplane + pix] = fminf(fmaxf(col, 0.f), 1.f);
+    }
+}
+
+}  // namespace
+
+extern "C" {
+
+int isrAssembleInput(const float* gbuffer_hwc12, const float* flow_filled, const float* prev_high, float* net_input,
+                     int h, int w, int init_mode, int ao_inverted, void* stream)
+{
+    if (!gbuffer_hwc12 || !net_input || h <= 0 || w <= 0) return -1;
+    if (prev_high && !flow_filled) return -1;
+    if (init_mode < 0 || init_mode > 2) return -1;
+    AssembleParams p = { gbuffer_hwc12, flow_filled, prev_high, net_input, h, w, init_mode, ao_inverted };
+    hipLaunchKernelGGL(assemble_input_kernel, dim3((w + 255) / 256, h), dim3(256), 0, (hipStream_t)stream, p);
+    return hipGetLastError() == hipSuccess ? 0 : -2;
+}
+
+int isrFinishFrame(const float* raw, const float* net_input, float* next_prev, float* rgb, int h, int w,
+                   const float* shading24, int exponent, float ao_strength, int inverse_ao, int enable_specular, void* stream)
+{
+    if (!raw || !net_input || !next_prev || h <= 0 || w <= 0 || (rgb && !shading24)) return -1;
+    FinishParams p;
+    p.raw = raw; p.net_in = net_input; p.next_prev = next_prev; p.rgb = rgb; p.h = h; p.w = w;
+    for (int k = 0; k < 3; ++k) {
+        p.ambient[k] = rgb ? shading24[k] : 0.f; p.diffuse[k] = rgb ? shading24[3 + k] : 0.f;
+        p.specular[k] = rgb ? shading24[6 + k] : 0.f; p.light[k] = rgb ? shading24[9 + k] : 0.f;
+        p.material[k] = rgb ? shading24[12 + k] : 0.f; p.background[k] = rgb ? shading24[15 + k] : 0.f;
+    }
+    p.exponent = exponent; p.ao_strength = ao_strength; p.inverse_ao = inverse_ao; p.enable_specular = enable_specular;
+    hipLaunchKernelGGL(finish_frame_kernel, dim3((4 * w + 255) / 256, 4 * h), dim3(256), 0, (hipStream_t)stream, p);
+    return hipGetLastError() == hipSuccess ? 0 : -2;
+}
+
+}  // extern "C"

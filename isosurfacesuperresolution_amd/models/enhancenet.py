@@ -82,13 +82,10 @@ class EnhanceNet(nn.Module):
     def _fused_ok(self):
         return (not self.use_bn) and self.upsample == 'bilinear'
 
-    def forward(self, inputs):
-        if not self._fused_ok():
-            features = self.preblock(inputs)
-            for block in self.blocks:
-                features = features + block(features)
-            outputs = self.postblock(features)
-            return self._recon_image(inputs, outputs)
+    def forward_features(self, inputs):
+        """The convolutional trunk only: the tensor ``_recon_image`` receives (used by the fused
+        frame pipeline, which folds the reconstruction into its finishing kernel)."""
+        assert self._fused_ok()
         c = ops.conv3x3
         pre = self.preblock[0]
         f = c(inputs, pre.weight, pre.bias, act='relu')
@@ -99,5 +96,13 @@ class EnhanceNet(nn.Module):
         f = c(f, p[1].weight, p[1].bias, act='relu', upsample2x=True)
         f = c(f, p[4].weight, p[4].bias, act='relu', upsample2x=True)
         f = c(f, p[6].weight, p[6].bias, act='relu')
-        outputs = c(f, p[8].weight, p[8].bias)
-        return self._recon_image(inputs, outputs)
+        return c(f, p[8].weight, p[8].bias)
+
+    def forward(self, inputs):
+        if not self._fused_ok():
+            features = self.preblock(inputs)
+            for block in self.blocks:
+                features = features + block(features)
+            outputs = self.postblock(features)
+            return self._recon_image(inputs, outputs)
+        return self._recon_image(inputs, self.forward_features(inputs))

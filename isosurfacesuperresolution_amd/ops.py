@@ -36,6 +36,8 @@ def _sr():
         lib.isrConvWeightGradWorkspace.argtypes = [ci, ci, ci, ci, ci]; lib.isrConvWeightGradWorkspace.restype = ll
         lib.isrConv3x3WeightGrad.argtypes = [vp, vp, vp, vp, vp, ci, ci, ci, ci, ci, vp]; lib.isrConv3x3WeightGrad.restype = ci
         lib.isrActBackward.argtypes = [vp, vp, vp, ll, ci, cf, vp]; lib.isrActBackward.restype = ci
+        lib.isrAssembleInput.argtypes = [vp, vp, vp, vp, ci, ci, ci, ci, vp]; lib.isrAssembleInput.restype = ci
+        lib.isrFinishFrame.argtypes = [vp, vp, vp, vp, ci, ci, vp, ci, cf, ci, ci, vp]; lib.isrFinishFrame.restype = ci
         lib.isrProfileEnable.argtypes = [ci]; lib.isrProfileEnable.restype = ci
         lib.isrProfileCount.argtypes = []; lib.isrProfileCount.restype = ci
         lib.isrProfileGet.argtypes = [ci, vp, vp, vp]; lib.isrProfileGet.restype = ci
@@ -206,3 +208,48 @@ def conv3x3(x, weight, bias=None, act='none', slope=0.01, residual=None, upsampl
     if residual is not None and act != 'none':
         return _Conv3x3Function.apply(x, weight, bias, None, act, slope) + residual
     return _Conv3x3Function.apply(x, weight, bias, residual, act, slope)
+
+
+# ---- fused frame assembly (inference) ---------------------------------------------------------
+INIT_MODES = {"zero": 0, "unshaded": 1, "input": 2}
+
+
+def assemble_input(gbuffer_hwc, flow_filled, prev_high, initial_image="zero", ao_inverted=False, out=None):
+    """Renderer G-buffer [h,w,12] (+ hole-filled flow [1,2,h,w], previous frame [1,6,4h,4w] or None)
+    -> network input [1,101,h,w] in one launch (``isrAssembleInput``)."""
+    assert gbuffer_hwc.is_cuda and gbuffer_hwc.is_contiguous() and gbuffer_hwc.shape[-1] == 12
+    h, w = gbuffer_hwc.shape[0], gbuffer_hwc.shape[1]
+    if out is None:
+        out = torch.empty((1, 101, h, w), dtype=torch.float32, device=gbuffer_hwc.device)
+    if prev_high is not None:
+        prev_high = prev_high.contiguous()
+        flow_filled = flow_filled.contiguous()
+        assert prev_high.shape == (1, 6, 4 * h, 4 * w) and flow_filled.shape == (1, 2, h, w)
+    rc = _sr().isrAssembleInput(_ptr(gbuffer_hwc), _ptr(flow_filled) if prev_high is not None else None,
+                                _ptr(prev_high), _ptr(out), h, w, INIT_MODES[initial_image], 1 if ao_inverted else 0, _stream())
+    if rc != 0:
+        raise RuntimeError("isrAssembleInput failed (%d)" % rc)
+    return out
+
+
+def finish_frame(raw, net_input, shading=None):
+    """Conv output before reconstruction [1,6,4h,4w] + network input [1,>=5,h,w] -> (next_prev [1,6,4h,4w],
+    rgb [1,3,4h,4w] or None) in one launch (``isrFinishFrame``).  ``shading``: a utils.ScreenSpaceShading."""
+    raw = raw.contiguous()
+    net_input = net_input.contiguous()
+    _, _, H, W = raw.shape
+    h, w = H // 4, W // 4
+    nxt = torch.empty_like(raw)
+    rgb = None
+    params = None
+    exponent, ao, inv, spec = 1, 0.0, 0, 0
+    if shading is not None:
+        rgb = torch.empty((1, 3, H, W), dtype=torch.float32, device=raw.device)
+        vals = shading.packed_parameters()
+        params = (ctypes.c_float * 18)(*vals)
+        exponent, ao = int(shading._specular_exponent), float(shading._ao)
+        inv, spec = int(bool(shading.inverse_ao)), int(bool(shading.enable_specular))
+    rc = _sr().isrFinishFrame(_ptr(raw), _ptr(net_input), _ptr(nxt), _ptr(rgb), h, w, params, exponent, ao, inv, spec, _stream())
+    if rc != 0:
+        raise RuntimeError("isrFinishFrame failed (%d)" % rc)
+    return nxt, rgb

@@ -10,6 +10,8 @@ stages enqueued on one HIP stream and no host synchronisation inside the frame.
 import numpy as np
 import torch
 
+from . import ops
+from .inference.flowfill import fill_flow
 from .utils import ScreenSpaceShading
 from .volumes import fmt3
 
@@ -30,7 +32,7 @@ def default_shading(device, fov=30.0):
 
 
 class SuperResolutionPipeline:
-    def __init__(self, renderer, model, shading, low_res, upscale=4, temporal=True, device="cuda"):
+    def __init__(self, renderer, model, shading, low_res, upscale=4, temporal=True, device="cuda", fused=True):
         self.renderer = renderer
         self.model = model            # inference.LoadedModel
         self.shading = shading
@@ -40,6 +42,10 @@ class SuperResolutionPipeline:
         self.device = device
         self.gbuffer = torch.empty((self.low_h, self.low_w, 12), dtype=torch.float32, device=device)
         self.previous = None
+        # fused=True: input assembly and frame finishing run as two HIP kernels (ops.assemble_input /
+        # ops.finish_frame); fused=False: the module-level PyTorch path (LoadedModel.inference etc.)
+        self.fused = fused and upscale == 4 and getattr(model.model, 'recon_type', None) == 'residual' \
+            and getattr(model.model, 'channel_mask', None) is not None and len(model.model.channel_mask) == 5
         self.set_static(fov=shading.get_fov(), isovalue=0.5)
 
     def set_static(self, fov, isovalue, lookat=(0.0, 0.0, 0.0), up=(0.0, 1.0, 0.0)):
@@ -70,8 +76,26 @@ class SuperResolutionPipeline:
         self.previous = raw
         return raw
 
+    def frame_fused(self, origin):
+        with torch.no_grad():
+            self.render_low(origin)
+            g = self.gbuffer
+            prev = self.previous if self.temporal else None
+            flow = None
+            if prev is not None:
+                low = g.permute(2, 0, 1).unsqueeze(0)
+                flow = fill_flow(low[:, 8:10], low[:, 3:4] != 0)
+            x = ops.assemble_input(g, flow, prev, self.model.initial_image_mode, self.model.inverse_ao)
+            feat = self.model.model.forward_features(x)
+            self.shading.inverse_ao = self.model.inverse_ao
+            raw, rgb = ops.finish_frame(feat, x, self.shading)
+            self.previous = raw
+        return rgb, raw
+
     def frame(self, origin):
         """origin: camera position. Returns (rgb [1,3,4h,4w], raw [1,6,4h,4w]) on the device."""
+        if self.fused:
+            return self.frame_fused(origin)
         with torch.no_grad():
             low = self.render_low(origin)
             raw = self.superresolve(low)

@@ -77,6 +77,14 @@ class ScreenSpaceShading(nn.Module):
         self._background = self._vec(color)
         return self
 
+    def packed_parameters(self):
+        """18 floats for the fused HIP finish kernel: ambient, diffuse, specular, light, material, background."""
+        vals = []
+        for t in (self._ambient_light_color, self._diffuse_light_color, self._specular_light_color,
+                  self._light_direction, self._material_color, self._background):
+            vals += [float(v) for v in t.reshape(-1).tolist()]
+        return vals
+
     def _get_eyedir(self, h, w):
         key = (h, w)
         if key not in self._eyedirs:

@@ -142,3 +142,37 @@ def test_enhancenet_gpu_train_step_matches_cpu():
         errs.append((pc.grad - pg.grad.cpu().double()).norm().item() / pc.grad.norm().item())
     assert max(errs) <= 1e-2, max(errs)
     assert sum(e <= 1e-5 for e in errs) >= 0.8 * len(errs), sorted(errs)[-12:]
+
+
+def test_fused_frame_kernels_match_module_path():
+    """isrAssembleInput / isrFinishFrame (one launch each) vs. the module-level PyTorch path
+    (LoadedModel.inference + clamp/normalise + ScreenSpaceShading), over a short temporal sequence."""
+    from isosurfacesuperresolution_amd import models, ops
+    from isosurfacesuperresolution_amd.inference import LoadedModel, fill_flow
+    from isosurfacesuperresolution_amd.pipeline import default_shading
+    from isosurfacesuperresolution_amd.utils import ScreenSpaceShading
+    opt = argparse.Namespace(upsample='bilinear', reconType='residual', useBN=False, numResidualLayers=10)
+    torch.manual_seed(7)
+    net = models.createNetwork('EnhanceNet', 4, 101, [0, 1, 2, 3, 4], 6, opt).cuda().eval()
+    for mode in ("zero", "input", "unshaded"):
+        lm = LoadedModel.from_model(net, "cuda", parameters={"initialImage": mode})
+        sh = default_shading("cuda", 30.0)
+        h, w = 23, 37
+        prev_a = prev_b = None
+        for step in range(3):
+            g = torch.rand(h, w, 12, device="cuda")
+            g[..., 3] = (g[..., 3] > 0.4).float()
+            g[..., 8:10] = (g[..., 8:10] - 0.5) * 0.05
+            low = g.permute(2, 0, 1).unsqueeze(0)
+            with torch.no_grad():
+                raw_a = lm.inference(low, prev_a)
+                raw_a = torch.cat([raw_a[:, 0:1].clamp(-1, 1), ScreenSpaceShading.normalize(raw_a[:, 1:4], dim=1),
+                                   raw_a[:, 4:].clamp(0, 1)], dim=1)
+                rgb_a = sh(raw_a)
+                flow = fill_flow(low[:, 8:10], low[:, 3:4] != 0) if prev_b is not None else None
+                x = ops.assemble_input(g, flow, prev_b, mode, False)
+                feat = net.forward_features(x)
+                raw_b, rgb_b = ops.finish_frame(feat, x, sh)
+            assert (raw_a - raw_b).abs().max().item() <= 1e-4, (mode, step)
+            assert (rgb_a - rgb_b).abs().max().item() <= 1e-4, (mode, step)
+            prev_a, prev_b = raw_a, raw_b
