@@ -60,6 +60,12 @@ int isrActBackward(const float* gy, const float* y, float* gz, long long count, 
 int isrAssembleInput(const float* gbuffer_hwc12, const float* flow_filled, const float* prev_high, float* net_input,
                      int h, int w, int init_mode, int ao_inverted, void* stream);
 
+/* Hole filling of the low-res flow (channels 8,9 of the HWC G-buffer) where the mask (channel 3) is 0:
+ * mask-weighted push-pull pyramid, the on-device replacement of the reference's CPU OpenCV
+ * cv.inpaint call (inference/loadedmodel.py:77-82).  flow_out: [2][h][w].  Three launches. */
+long long isrFlowFillWorkspace(int h, int w);
+int isrFlowFill(const float* gbuffer_hwc12, float* flow_out, void* workspace, int h, int w, void* stream);
+
 /* End of one inference frame: raw[6][4h][4w] (EnhanceNet output before its residual reconstruction)
  * -> next_prev = cat(clamp(mask +- 1), normalize(normal), clamp(depth, ao in [0,1])) after
  * out[:5] += bilinear x4 of net_input[:5] (models/enhancenet.py:65-78, mainGUI.py:594-599), and

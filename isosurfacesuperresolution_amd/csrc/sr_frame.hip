@@ -204,6 +204,104 @@ __global__ __launch_bounds__(256) void finish_frame_kernel(const FinishParams p)
     }
 }
 
+
+// ---- flow hole filling: push-pull pyramid in ONE launch -----------------------------------------
+// Same arithmetic as inference/flowfill.py (mask-weighted 2x2 pulls down to 1x1, bilinear pushes
+// back up, known pixels kept), which the PyTorch version spends ~150 tiny launches on.  The whole
+// pyramid of a 480x270 frame is 1.4 MB and L2 resident, so a single 1024-thread workgroup walks
+// it level by level with __syncthreads() in between -- no inter-kernel gaps, no grid sync.
+struct FillLevel { int h, w; size_t off; };     // v: [2][h][w] at off, m: [h][w] at off + 2*h*w
+
+// mode 0: pull level 0 -> 1 over the whole grid; mode 1: one workgroup pulls levels 2..n and pushes
+// back down to level 1; mode 2: push level 1 -> 0 over the whole grid (the two big levels are
+// bandwidth work for every CU, the small ones latency work for one).
+__global__ __launch_bounds__(1024) void flow_fill_kernel(const float* __restrict__ gbuf, float* __restrict__ out,
+                                                          float* __restrict__ ws, int h, int w, int mode)
+{
+    __shared__ FillLevel lv[20];
+    __shared__ int nlev;
+    const int tid = threadIdx.x;
+    const int gtid = blockIdx.x * 1024 + tid, gstride = gridDim.x * 1024;
+    if (tid == 0) {
+        int ch = h, cw = w, n = 0;
+        size_t off = 0;
+        lv[0].h = h; lv[0].w = w; lv[0].off = 0;      // level 0 lives in gbuf / out, not in ws
+        while (!(ch <= 1 && cw <= 1) && n < 18) {
+            ch = (ch + 1) / 2; cw = (cw + 1) / 2;
+            ++n;
+            lv[n].h = ch; lv[n].w = cw; lv[n].off = off;
+            off += (size_t)3 * ch * cw;
+        }
+        nlev = n;
+    }
+    __syncthreads();
+    // pull
+    const int pull_lo = mode == 0 ? 1 : 2, pull_hi = mode == 0 ? 1 : (mode == 1 ? nlev : 0);
+    for (int l = pull_lo; l <= pull_hi; ++l) {
+        const int ph = lv[l - 1].h, pw = lv[l - 1].w, ch = lv[l].h, cw = lv[l].w;
+        float* v = ws + lv[l].off;
+        float* m = v + (size_t)2 * ch * cw;
+        const float* pv = ws + lv[l - 1].off;
+        const float* pm = pv + (size_t)2 * ph * pw;
+        for (int e = gtid; e < ch * cw; e += gstride) {
+            const int y = e / cw, x = e - y * cw;
+            float sm = 0.f, sx = 0.f, sy = 0.f;
+#pragma unroll
+            for (int dy = 0; dy < 2; ++dy)
+#pragma unroll
+                for (int dx = 0; dx < 2; ++dx) {
+                    const int yy = 2 * y + dy, xx = 2 * x + dx;
+                    if (yy < ph && xx < pw) {
+                        if (l == 1) {
+                            const float* g = gbuf + ((size_t)yy * pw + xx) * 12;
+                            const float valid = g[3] != 0.f ? 1.f : 0.f;
+                            sm += valid; sx += g[8] * valid; sy += g[9] * valid;
+                        } else {
+                            sm += pm[yy * pw + xx]; sx += pv[yy * pw + xx]; sy += pv[ph * pw + yy * pw + xx];
+                        }
+                    }
+                }
+            const float ms = sm * 0.25f, vx = sx * 0.25f, vy = sy * 0.25f;     // avg_pool2d over the zero-padded 2x2
+            const float den = ms > 1e-12f ? ms : 1e-12f;
+            v[e] = ms > 0.f ? vx / den : 0.f;
+            v[ch * cw + e] = ms > 0.f ? vy / den : 0.f;
+            m[e] = ms > 0.f ? 1.f : 0.f;
+        }
+        __syncthreads();
+    }
+    // push: the coarsest level is complete; every finer level keeps its known pixels
+    const int push_hi = mode == 1 ? nlev - 1 : (mode == 2 ? 0 : -1), push_lo = mode == 1 ? 1 : 0;
+    for (int l = push_hi; l >= push_lo; --l) {
+        const int fh = lv[l].h, fw = lv[l].w, ch = lv[l + 1].h, cw = lv[l + 1].w;
+        const float* cv = ws + lv[l + 1].off;
+        float* fv = l == 0 ? out : ws + lv[l].off;
+        const float* fm = l == 0 ? nullptr : fv + (size_t)2 * fh * fw;
+        const float sy_ = (float)ch / (float)fh, sx_ = (float)cw / (float)fw;
+        for (int e = gtid; e < fh * fw; e += gstride) {
+            const int y = e / fw, x = e - y * fw;
+            bool known; float kx = 0.f, ky = 0.f;
+            if (l == 0) {
+                const float* g = gbuf + (size_t)e * 12;
+                known = g[3] != 0.f; kx = g[8]; ky = g[9];
+            } else {
+                known = fm[e] > 0.f; kx = fv[e]; ky = fv[fh * fw + e];
+            }
+            float ox = kx, oy = ky;
+            if (!known) {
+                int y0, y1, x0, x1; float ly, lx;
+                src_index(y, sy_, ch, y0, y1, ly);
+                src_index(x, sx_, cw, x0, x1, lx);
+                const float hy = 1.f - ly, hx = 1.f - lx;
+                ox = hy * (hx * cv[y0 * cw + x0] + lx * cv[y0 * cw + x1]) + ly * (hx * cv[y1 * cw + x0] + lx * cv[y1 * cw + x1]);
+                const float* c2 = cv + ch * cw;
+                oy = hy * (hx * c2[y0 * cw + x0] + lx * c2[y0 * cw + x1]) + ly * (hx * c2[y1 * cw + x0] + lx * c2[y1 * cw + x1]);
+            }
+            fv[e] = ox; fv[fh * fw + e] = oy;
+        }
+        __syncthreads();
+    }
+}
+
 }  // namespace
 
 extern "C" {
@@ -216,6 +314,24 @@ int isrAssembleInput(const float* gbuffer_hwc12, const float* flow_filled, const
     if (init_mode < 0 || init_mode > 2) return -1;
     AssembleParams p = { gbuffer_hwc12, flow_filled, prev_high, net_input, h, w, init_mode, ao_inverted };
     hipLaunchKernelGGL(assemble_input_kernel, dim3((w + 255) / 256, h), dim3(256), 0, (hipStream_t)stream, p);
+    return hipGetLastError() == hipSuccess ? 0 : -2;
+}
+
+long long isrFlowFillWorkspace(int h, int w)
+{
+    long long floats = 0;
+    while (!(h <= 1 && w <= 1)) { h = (h + 1) / 2; w = (w + 1) / 2; floats += 3LL * h * w; }
+    return (floats + 16) * (long long)sizeof(float);
+}
+
+int isrFlowFill(const float* gbuffer_hwc12, float* flow_out, void* workspace, int h, int w, void* stream)
+{
+    if (!gbuffer_hwc12 || !flow_out || !workspace || h <= 0 || w <= 0) return -1;
+    const int big = (h * w + 4 * 1024 - 1) / (4 * 1024);
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(flow_fill_kernel, dim3(big > 0 ? big : 1), dim3(1024), 0, st, gbuffer_hwc12, flow_out, (float*)workspace, h, w, 0);
+    hipLaunchKernelGGL(flow_fill_kernel, dim3(1), dim3(1024), 0, st, gbuffer_hwc12, flow_out, (float*)workspace, h, w, 1);
+    hipLaunchKernelGGL(flow_fill_kernel, dim3(4 * big > 0 ? 4 * big : 1), dim3(1024), 0, st, gbuffer_hwc12, flow_out, (float*)workspace, h, w, 2);
     return hipGetLastError() == hipSuccess ? 0 : -2;
 }
 

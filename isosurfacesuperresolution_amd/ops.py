@@ -37,6 +37,8 @@ def _sr():
         lib.isrConv3x3WeightGrad.argtypes = [vp, vp, vp, vp, vp, ci, ci, ci, ci, ci, vp]; lib.isrConv3x3WeightGrad.restype = ci
         lib.isrActBackward.argtypes = [vp, vp, vp, ll, ci, cf, vp]; lib.isrActBackward.restype = ci
         lib.isrAssembleInput.argtypes = [vp, vp, vp, vp, ci, ci, ci, ci, vp]; lib.isrAssembleInput.restype = ci
+        lib.isrFlowFillWorkspace.argtypes = [ci, ci]; lib.isrFlowFillWorkspace.restype = ll
+        lib.isrFlowFill.argtypes = [vp, vp, vp, ci, ci, vp]; lib.isrFlowFill.restype = ci
         lib.isrFinishFrame.argtypes = [vp, vp, vp, vp, ci, ci, vp, ci, cf, ci, ci, vp]; lib.isrFinishFrame.restype = ci
         lib.isrProfileEnable.argtypes = [ci]; lib.isrProfileEnable.restype = ci
         lib.isrProfileCount.argtypes = []; lib.isrProfileCount.restype = ci
@@ -229,6 +231,25 @@ def assemble_input(gbuffer_hwc, flow_filled, prev_high, initial_image="zero", ao
                                 _ptr(prev_high), _ptr(out), h, w, INIT_MODES[initial_image], 1 if ao_inverted else 0, _stream())
     if rc != 0:
         raise RuntimeError("isrAssembleInput failed (%d)" % rc)
+    return out
+
+
+_fill_ws = {}
+
+
+def fill_flow_gbuffer(gbuffer_hwc):
+    """Hole-filled flow [1,2,h,w] straight from the renderer's G-buffer [h,w,12] (``isrFlowFill``)."""
+    lib = _sr()
+    h, w = gbuffer_hwc.shape[0], gbuffer_hwc.shape[1]
+    key = (gbuffer_hwc.device, h, w)
+    ws = _fill_ws.get(key)
+    if ws is None:
+        ws = torch.empty(lib.isrFlowFillWorkspace(h, w), dtype=torch.uint8, device=gbuffer_hwc.device)
+        _fill_ws[key] = ws
+    out = torch.empty((1, 2, h, w), dtype=torch.float32, device=gbuffer_hwc.device)
+    rc = lib.isrFlowFill(_ptr(gbuffer_hwc), _ptr(out), _ptr(ws), h, w, _stream())
+    if rc != 0:
+        raise RuntimeError("isrFlowFill failed (%d)" % rc)
     return out
 
 

@@ -83,8 +83,7 @@ class SuperResolutionPipeline:
             prev = self.previous if self.temporal else None
             flow = None
             if prev is not None:
-                low = g.permute(2, 0, 1).unsqueeze(0)
-                flow = fill_flow(low[:, 8:10], low[:, 3:4] != 0)
+                flow = ops.fill_flow_gbuffer(g)
             x = ops.assemble_input(g, flow, prev, self.model.initial_image_mode, self.model.inverse_ao)
             feat = self.model.model.forward_features(x)
             self.shading.inverse_ao = self.model.inverse_ao

@@ -169,7 +169,9 @@ def test_fused_frame_kernels_match_module_path():
                 raw_a = torch.cat([raw_a[:, 0:1].clamp(-1, 1), ScreenSpaceShading.normalize(raw_a[:, 1:4], dim=1),
                                    raw_a[:, 4:].clamp(0, 1)], dim=1)
                 rgb_a = sh(raw_a)
-                flow = fill_flow(low[:, 8:10], low[:, 3:4] != 0) if prev_b is not None else None
+                flow = ops.fill_flow_gbuffer(g) if prev_b is not None else None
+                if flow is not None:
+                    assert (flow - fill_flow(low[:, 8:10], low[:, 3:4] != 0)).abs().max().item() <= 1e-5
                 x = ops.assemble_input(g, flow, prev_b, mode, False)
                 feat = net.forward_features(x)
                 raw_b, rgb_b = ops.finish_frame(feat, x, sh)
