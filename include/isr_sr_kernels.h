@@ -41,6 +41,14 @@ int isrConvPrepareWeights(const float* w, float* wprep, int Cout, int Cin, int t
 int isrConv3x3Forward(const float* x, const float* wprep, const float* bias, const float* residual, float* y,
                       int N, int Cin, int H, int W, int Cout, int act, float slope, int upsample2x, void* stream);
 
+/* The same fused convolution for Cout <= 8 (EnhanceNet's final 64 -> 6 layer, enhancenet.py:124) on the
+ * vector ALU instead of the 32-row MFMA tile.  isrConvSmallPrepare re-lays w[Cout][Cin][3][3] into
+ * w8[9][isrConvSmallCinPad(Cin)][8] and bias into bias8[8] (zero padded); no upsampling variant. */
+int isrConvSmallCinPad(int Cin);
+int isrConvSmallPrepare(const float* w, const float* bias, float* w8, float* bias8, int Cout, int Cin, void* stream);
+int isrConv3x3SmallCout(const float* x, const float* w8, const float* bias8, const float* residual, float* y,
+                        int N, int Cin, int H, int W, int Cout, int act, float slope, void* stream);
+
 /* Weight gradient of the same convolution: dw[Cout][Cin][3][3] = sum_{n,y,x} gz[n][co][y][x] * x[n][ci][y+ky-1][x+kx-1]
  * and db[Cout] = sum gz.  x: [N][Cin][H][W], gz: [N][Cout][H][W] (gradient w.r.t. the pre-activation).
  * workspace: at least isrConvWeightGradWorkspace(...) bytes of device memory. dw/db are overwritten. */

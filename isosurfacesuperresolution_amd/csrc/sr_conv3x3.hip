@@ -739,3 +739,206 @@ int isrConv3x3WeightGrad(const float* x, const float* gz, float* dw, float* db, 
 }
 
 }  // extern "C"
+
+// ---- small-Cout direct convolution on the vector ALU --------------------------------------------
+// The last layer of EnhanceNet maps 64 -> 6 channels (enhancenet.py:124).  On the 32-row MFMA tile
+// that wastes 26/32 of the matrix pipe (19 TFLOP/s algorithmic).  With <= 8 output channels the
+// weights of one (cin, tap) fit an s_load_dwordx8, so the conv is a plain FMA loop with the weight as
+// the scalar operand: each thread owns 4 consecutive pixels x 8 channels (32 accumulators), the
+// haloed input rows come from LDS as one ds_read_b128 + ds_read_b64 per (cin, dy), i.e. 72 FMAs per
+// two LDS reads.  Same fused epilogue semantics as the MFMA kernel (bias, activation, residual).
+namespace {
+
+constexpr int SC_TH = 16, SC_TW = 64;          // output tile
+constexpr int SC_PH = SC_TH + 2;
+constexpr int SC_PWS = 66;                     // LDS row stride = patch width: element e of a stage lives at e (8-B aligned rows)
+constexpr int SC_CK = 8;                       // input channels per LDS stage
+constexpr int SC_PLANE = SC_PH * SC_PWS;       // 1224 floats
+constexpr int SC_STAGE = 38 * 256;             // 9728 floats >= 8*18*66 = 9504 (one slot per thread per pass)
+
+struct SmallConvParams {
+    const float* x; const float* w8;           // w8: [9][cinPad8][8] (cout padded to 8, cin to a multiple of 8, zero filled)
+    const float* bias8; const float* residual; float* y;
+    int N, Cin, H, W, Cout;
+    int tilesX, tilesY;
+    int act; float slope;
+};
+
+__global__ __launch_bounds__(256, 2) void conv3x3_small_cout_kernel(const SmallConvParams p)
+{
+    __shared__ __attribute__((aligned(16))) float patch[2][SC_STAGE];
+    const int tid = threadIdx.x;
+    const int tilesPerImage = p.tilesX * p.tilesY;
+    const int bid = xcd_remap(blockIdx.x, gridDim.x);
+    const int n = bid / tilesPerImage;
+    const int t = bid - n * tilesPerImage;
+    const int ty = t / p.tilesX, tx = t - ty * p.tilesX;
+    const int oy0 = ty * SC_TH, ox0 = tx * SC_TW;
+    const int ly = tid >> 4, lx4 = (tid & 15) * 4;          // this thread: row ly, pixels lx4..lx4+3
+
+    const size_t planeIn = (size_t)p.H * p.W;
+    const float* ximg = p.x + (size_t)n * p.Cin * planeIn;
+    const int nstages = (p.Cin + SC_CK - 1) / SC_CK;
+
+    // staging: 66 x 18 positions x 8 channels = 9504 elements / 256 threads -> 38 slots per thread,
+    // spread 5 per channel iteration: issued before the iteration's 216 FMAs, parked after the next one's
+    constexpr int NSLOT = (SC_CK * SC_PH * 66 + 255) / 256;        // 38
+    constexpr int SPC = (NSLOT + SC_CK - 1) / SC_CK;               // 5
+    const int cinPad = nstages * SC_CK;
+    unsigned plan[NSLOT];                                            // byte offsets inside a stage's 8 planes
+#pragma unroll
+    for (int i = 0; i < NSLOT; ++i) {
+        const int e = tid + i * 256;
+        const int c = e / (SC_PH * 66), rem = e - c * (SC_PH * 66);
+        const int r = rem / 66, col = rem - r * 66;
+        const int gy = oy0 + r - 1, gx = ox0 + col - 1;
+        const bool ok = e < SC_CK * SC_PH * 66 && (unsigned)gy < (unsigned)p.H && (unsigned)gx < (unsigned)p.W;
+        plan[i] = ok ? (unsigned)(((c * p.H + gy) * p.W + gx) * 4) : BAD_OFFSET;
+    }
+    auto stage_rsrc = [&](int stage) -> rsrc_t {
+        const int left = p.Cin - stage * SC_CK;
+        return __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(ximg + (size_t)stage * SC_CK * planeIn), 0,
+                                                 left > 0 ? (int)(left * planeIn * 4) : 0, 0x00020000);
+    };
+
+    float acc[4][8];
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+#pragma unroll
+        for (int co = 0; co < 8; ++co) acc[q][co] = 0.f;
+
+    {   // prologue: stage 0, in two batches
+        const rsrc_t rs = stage_rsrc(0);
+#pragma unroll
+        for (int b = 0; b < 2; ++b) {
+            float v[NSLOT / 2];
+#pragma unroll
+            for (int i = 0; i < NSLOT / 2; ++i) v[i] = buf_load(rs, plan[b * (NSLOT / 2) + i]);
+#pragma unroll
+            for (int i = 0; i < NSLOT / 2; ++i) patch[0][tid + (b * (NSLOT / 2) + i) * 256] = v[i];
+        }
+    }
+    __syncthreads();
+    for (int stage = 0; stage < nstages; ++stage) {
+        const int buf = stage & 1;
+        const bool more = stage + 1 < nstages;
+        const rsrc_t rsn = stage_rsrc(stage + 1);
+        const float* pb = &patch[buf][ly * SC_PWS + lx4];
+        float* pn = patch[buf ^ 1] + tid;
+        const int cbase = stage * SC_CK;
+        float sv[2][SPC];
+#pragma unroll
+        for (int c = 0; c < SC_CK; ++c) {
+            if (more) {
+#pragma unroll
+                for (int i = 0; i < SPC; ++i)
+                    if (c * SPC + i < NSLOT) sv[c & 1][i] = buf_load(rsn, plan[c * SPC + i]);
+            }
+            const int ci = cbase + c;
+#pragma unroll
+            for (int dy = 0; dy < 3; ++dy) {
+                const float* row = pb + c * SC_PLANE + dy * SC_PWS;
+                const float2 a = *reinterpret_cast<const float2*>(row);
+                const float2 b = *reinterpret_cast<const float2*>(row + 2);
+                const float2 d = *reinterpret_cast<const float2*>(row + 4);
+                const float in[6] = { a.x, a.y, b.x, b.y, d.x, d.y };
+#pragma unroll
+                for (int dx = 0; dx < 3; ++dx) {
+                    const float* wk = p.w8 + ((size_t)(dy * 3 + dx) * cinPad + ci) * 8;   // uniform -> scalar loads
+#pragma unroll
+                    for (int co = 0; co < 8; ++co) {
+                        const float wv = wk[co];
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) acc[q][co] = fmaf(in[q + dx], wv, acc[q][co]);
+                    }
+                }
+            }
+            if (more && c >= 1) {
+#pragma unroll
+                for (int i = 0; i < SPC; ++i)
+                    if ((c - 1) * SPC + i < NSLOT) pn[((c - 1) * SPC + i) * 256] = sv[(c - 1) & 1][i];
+            }
+        }
+        if (more) {
+#pragma unroll
+            for (int i = 0; i < SPC; ++i)
+                if ((SC_CK - 1) * SPC + i < NSLOT) pn[((SC_CK - 1) * SPC + i) * 256] = sv[(SC_CK - 1) & 1][i];
+        }
+        __syncthreads();
+    }
+    const int oy = oy0 + ly, ox = ox0 + lx4;
+    if (oy < p.H) {
+        const size_t plane = (size_t)p.H * p.W;
+#pragma unroll
+        for (int co = 0; co < 8; ++co) {
+            if (co >= p.Cout) break;
+            const size_t base = ((size_t)n * p.Cout + co) * plane + (size_t)oy * p.W + ox;
+            float v[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                float r = acc[q][co] + p.bias8[co];
+                if (p.act == ISR_ACT_RELU) r = r > 0.f ? r : 0.f;
+                else if (p.act == ISR_ACT_LEAKY) r = r > 0.f ? r : r * p.slope;
+                v[q] = r;
+            }
+            if (ox + 3 < p.W && (p.W & 3) == 0) {
+                float4 o = make_float4(v[0], v[1], v[2], v[3]);
+                if (p.residual) { const float4 rr = *reinterpret_cast<const float4*>(p.residual + base); o.x += rr.x; o.y += rr.y; o.z += rr.z; o.w += rr.w; }
+                *reinterpret_cast<float4*>(p.y + base) = o;
+            } else {
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+                    if (ox + q < p.W) p.y[base + q] = v[q] + (p.residual ? p.residual[base + q] : 0.f);
+            }
+        }
+    }
+}
+
+__global__ void prepare_weights8_kernel(const float* __restrict__ w, const float* __restrict__ bias, float* __restrict__ w8,
+                                        float* __restrict__ bias8, int Cout, int Cin)
+{
+    const int cinPad = ((Cin + SC_CK - 1) / SC_CK) * SC_CK;
+    const int total = 9 * cinPad * 8;
+    for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < total; e += gridDim.x * blockDim.x) {
+        const int co = e & 7, ci = (e >> 3) % cinPad, tap = e / (8 * cinPad);
+        w8[e] = (co < Cout && ci < Cin) ? w[((co * Cin + ci) * 3 + tap / 3) * 3 + tap % 3] : 0.f;
+    }
+    if (blockIdx.x == 0 && threadIdx.x < 8) bias8[threadIdx.x] = (bias && (int)threadIdx.x < Cout) ? bias[threadIdx.x] : 0.f;
+}
+
+}  // namespace
+
+extern "C" {
+
+int isrConvSmallCinPad(int Cin) { return ((Cin + SC_CK - 1) / SC_CK) * SC_CK; }
+
+int isrConvSmallPrepare(const float* w, const float* bias, float* w8, float* bias8, int Cout, int Cin, void* stream)
+{
+    if (!w || !w8 || !bias8 || Cout <= 0 || Cout > 8 || Cin <= 0) return -1;
+    const int total = 9 * (((Cin + SC_CK - 1) / SC_CK) * SC_CK) * 8;
+    hipLaunchKernelGGL(prepare_weights8_kernel, dim3((total + 255) / 256), dim3(256), 0, (hipStream_t)stream, w, bias, w8, bias8, Cout, Cin);
+    return hipGetLastError() == hipSuccess ? 0 : -2;
+}
+
+int isrConv3x3SmallCout(const float* x, const float* w8, const float* bias8, const float* residual, float* y,
+                        int N, int Cin, int H, int W, int Cout, int act, float slope, void* stream)
+{
+    if (!x || !w8 || !bias8 || !y || N <= 0 || Cin <= 0 || Cout <= 0 || Cout > 8 || H <= 0 || W <= 0) return -1;
+    if ((long long)Cin * H * W * 4 >= (1LL << 31)) return -1;
+    SmallConvParams p;
+    p.x = x; p.w8 = w8; p.bias8 = bias8; p.residual = residual; p.y = y;
+    p.N = N; p.Cin = Cin; p.H = H; p.W = W; p.Cout = Cout;
+    p.tilesX = (W + SC_TW - 1) / SC_TW; p.tilesY = (H + SC_TH - 1) / SC_TH;
+    p.act = act; p.slope = slope;
+    const long long nwg = (long long)N * p.tilesX * p.tilesY;
+    if (nwg > 0x7fffffffLL) return -1;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    if (g_profile) {
+        e0 = pool_event(); e1 = pool_event();
+        g_records.push_back({ 6, 2.0 * 9 * Cin * Cout * (double)N * H * W, e0, e1 });
+    }
+    hipExtLaunchKernelGGL(conv3x3_small_cout_kernel, dim3((unsigned)nwg), dim3(256), 0, (hipStream_t)stream, e0, e1, 0, p);
+    return hipGetLastError() == hipSuccess ? 0 : -2;
+}
+
+}  // extern "C"

@@ -37,6 +37,9 @@ def _sr():
         lib.isrConv3x3WeightGrad.argtypes = [vp, vp, vp, vp, vp, ci, ci, ci, ci, ci, vp]; lib.isrConv3x3WeightGrad.restype = ci
         lib.isrActBackward.argtypes = [vp, vp, vp, ll, ci, cf, vp]; lib.isrActBackward.restype = ci
         lib.isrAssembleInput.argtypes = [vp, vp, vp, vp, ci, ci, ci, ci, vp]; lib.isrAssembleInput.restype = ci
+        lib.isrConvSmallCinPad.argtypes = [ci]; lib.isrConvSmallCinPad.restype = ci
+        lib.isrConvSmallPrepare.argtypes = [vp, vp, vp, vp, ci, ci, vp]; lib.isrConvSmallPrepare.restype = ci
+        lib.isrConv3x3SmallCout.argtypes = [vp, vp, vp, vp, vp, ci, ci, ci, ci, ci, ci, cf, vp]; lib.isrConv3x3SmallCout.restype = ci
         lib.isrFlowFillWorkspace.argtypes = [ci, ci]; lib.isrFlowFillWorkspace.restype = ll
         lib.isrFlowFill.argtypes = [vp, vp, vp, ci, ci, vp]; lib.isrFlowFill.restype = ci
         lib.isrFinishFrame.argtypes = [vp, vp, vp, vp, ci, ci, vp, ci, cf, ci, ci, vp]; lib.isrFinishFrame.restype = ci
@@ -88,7 +91,7 @@ def prepare_weights(weight, transpose_flip=False):
 
 # Optional per-dispatch timing for bench.py: the library attaches start/stop events to the
 # dispatch packets themselves (isrProfile*), which does not add stream operations.
-VARIANT_NAMES = {2: "conv3x3_fwd_kernel<1,false>", 3: "conv3x3_fwd_kernel<1,true>",
+VARIANT_NAMES = {6: "conv3x3_small_cout_kernel", 2: "conv3x3_fwd_kernel<1,false>", 3: "conv3x3_fwd_kernel<1,true>",
                  4: "conv3x3_fwd_kernel<2,false>", 5: "conv3x3_fwd_kernel<2,true>"}
 
 
@@ -107,6 +110,46 @@ def profile_records():
             raise RuntimeError("isrProfileGet failed")
         out.append((VARIANT_NAMES[v.value], f.value, ms.value))
     return out
+
+
+_small_cache = {}
+
+
+def _prepare_small(weight, bias):
+    """(w8, bias8) device tensors for the Cout <= 8 vector-ALU kernel, cached like prepare_weights."""
+    lib = _sr()
+    key = id(weight)
+    hit = _small_cache.get(key)
+    bptr = bias.data_ptr() if bias is not None else 0
+    bver = bias._version if bias is not None else 0
+    if hit is not None:
+        ref, ver, ptr, bp, bv, w8, b8 = hit
+        if ref() is weight and ver == weight._version and ptr == weight.data_ptr() and bp == bptr and bv == bver:
+            return w8, b8
+    cout, cin = weight.shape[0], weight.shape[1]
+    w8 = torch.empty(9 * lib.isrConvSmallCinPad(cin) * 8, dtype=torch.float32, device=weight.device)
+    b8 = torch.empty(8, dtype=torch.float32, device=weight.device)
+    rc = lib.isrConvSmallPrepare(_ptr(weight.detach().contiguous()), _ptr(bias.detach().contiguous()) if bias is not None else None,
+                                 _ptr(w8), _ptr(b8), cout, cin, _stream())
+    if rc != 0:
+        raise RuntimeError("isrConvSmallPrepare failed (%d)" % rc)
+    if len(_small_cache) > 64:
+        _small_cache.clear()
+    _small_cache[key] = (weakref.ref(weight), weight._version, weight.data_ptr(), bptr, bver, w8, b8)
+    return w8, b8
+
+
+def _launch_small(x, weight, bias, residual, act, slope):
+    lib = _sr()
+    n, cin, h, w = x.shape
+    cout = weight.shape[0]
+    w8, b8 = _prepare_small(weight, bias)
+    y = torch.empty((n, cout, h, w), dtype=torch.float32, device=x.device)
+    rc = lib.isrConv3x3SmallCout(_ptr(x), _ptr(w8), _ptr(b8), _ptr(residual), _ptr(y), n, cin, h, w, cout,
+                                 ACT_CODES[act], float(slope), _stream())
+    if rc != 0:
+        raise RuntimeError("isrConv3x3SmallCout failed (%d)" % rc)
+    return y
 
 
 def _launch_forward(x, wprep, bias, residual, cin, cout, act, slope, upsample2x):
@@ -201,6 +244,8 @@ def conv3x3(x, weight, bias=None, act='none', slope=0.01, residual=None, upsampl
                                               (residual is not None and residual.requires_grad))
     if not needs_grad:
         cout, cin = weight.shape[0], weight.shape[1]
+        if cout <= 8 and not upsample2x and cin * x.shape[2] * x.shape[3] * 4 < 2 ** 31:
+            return _launch_small(x.contiguous(), weight, bias, residual.contiguous() if residual is not None else None, act, slope)
         return _launch_forward(x.contiguous(), prepare_weights(weight),
                                bias.contiguous() if bias is not None else None,
                                residual.contiguous() if residual is not None else None,
