@@ -801,11 +801,12 @@ __global__ __launch_bounds__(256, 2) void conv3x3_small_cout_kernel(const SmallC
                                                  left > 0 ? (int)(left * planeIn * 4) : 0, 0x00020000);
     };
 
-    float acc[4][8];
+    typedef float f32x2 __attribute__((ext_vector_type(2)));
+    f32x2 acc[2][8];          // [pixel pair][cout]: packed so that the FMAs are v_pk_fma_f32 (2 lanes x 2 FMA / 4 clk)
 #pragma unroll
-    for (int q = 0; q < 4; ++q)
+    for (int q = 0; q < 2; ++q)
 #pragma unroll
-        for (int co = 0; co < 8; ++co) acc[q][co] = 0.f;
+        for (int co = 0; co < 8; ++co) acc[q][co] = (f32x2){ 0.f, 0.f };
 
     {   // prologue: stage 0, in two batches
         const rsrc_t rs = stage_rsrc(0);
@@ -845,11 +846,12 @@ __global__ __launch_bounds__(256, 2) void conv3x3_small_cout_kernel(const SmallC
 #pragma unroll
                 for (int dx = 0; dx < 3; ++dx) {
                     const float* wk = p.w8 + ((size_t)(dy * 3 + dx) * cinPad + ci) * 8;   // uniform -> scalar loads
+                    const f32x2 i01 = { in[dx], in[dx + 1] }, i23 = { in[dx + 2], in[dx + 3] };
 #pragma unroll
                     for (int co = 0; co < 8; ++co) {
-                        const float wv = wk[co];
-#pragma unroll
-                        for (int q = 0; q < 4; ++q) acc[q][co] = fmaf(in[q + dx], wv, acc[q][co]);
+                        const f32x2 wv = { wk[co], wk[co] };
+                        acc[0][co] = __builtin_elementwise_fma(i01, wv, acc[0][co]);
+                        acc[1][co] = __builtin_elementwise_fma(i23, wv, acc[1][co]);
                     }
                 }
             }
@@ -876,7 +878,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_small_cout_kernel(const SmallC
             float v[4];
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
-                float r = acc[q][co] + p.bias8[co];
+                float r = acc[q >> 1][co][q & 1] + p.bias8[co];
                 if (p.act == ISR_ACT_RELU) r = r > 0.f ? r : 0.f;
                 else if (p.act == ISR_ACT_LEAKY) r = r > 0.f ? r : r * p.slope;
                 v[q] = r;
