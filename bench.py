@@ -115,6 +115,15 @@ def main():
     achieved = dom_flops / dom_time / 1e12
     rm_time = sum(rm_ms) * 1e-3 / max(1, len(rm_ms))
 
+    # HBM traffic of the dominant kernel: PMC counters cannot be read from inside this process; the
+    # committed rocprofv3 --pmc passes of this same command (profiles/r01_pmc_summary.md) provide it.
+    traffic = None
+    try:
+        with open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")) as f:
+            traffic = json.load(f)[dom_name]["traffic_bytes_per_launch"]
+    except (OSError, KeyError, ValueError):
+        pass
+
     result = {
         "metric": "frames/sec (render+4x SR) at 256^3 -> 1080p",
         "value": world * K / elapsed,
@@ -130,7 +139,8 @@ def main():
             args.volume, low_w, low_h, 4 * low_w, 4 * low_h, "off" if args.no_temporal else "on"),
             "frames_per_rank": K, "sharding": "contiguous frame chunks per rank, no collective"},
         "roofline": {"kernel": dom_name, "bound": "mfma", "achieved": achieved, "peak": MFMA_F32_PEAK_TFLOPS,
-                     "unit": "TFLOP/s", "frac": achieved / MFMA_F32_PEAK_TFLOPS, "traffic": None,
+                     "unit": "TFLOP/s", "frac": achieved / MFMA_F32_PEAK_TFLOPS, "traffic": traffic,
+                     "traffic_source": "profiles/r01_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, bytes per launch)" if traffic else None,
                      "avg_launch_ms": dom_time / dom_launches * 1e3, "launches_per_frame": dom_launches / K,
                      "flops_per_launch": dom_flops / dom_launches},
         "kernels": {n: {"tflops": v[0] / v[1] / 1e12, "ms_per_frame": v[1] / K * 1e3, "launches_per_frame": v[2] / K}
