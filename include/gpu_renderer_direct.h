@@ -50,6 +50,14 @@ float render(unsigned long long devicePtr);
 int isoLoadDenseHost(const float* hostData, int nx, int ny, int nz);
 int isoLoadDenseDevice(unsigned long long devicePtr, int nx, int ny, int nz);
 
+/* Load one tile of a larger volume (multi-GPU object-space decomposition): the dense
+ * data are the tile plus its halo, `origin` is the global index of local voxel (0,0,0), the world
+ * normalisation and the isovalue scale come from the GLOBAL active bbox / maximum, and rays are clipped
+ * to the region [clipLo, clipHi) (global index coordinates) this tile owns. An all-zero tile is valid. */
+int isoLoadDenseTileHost(const float* hostData, int nx, int ny, int nz, const int origin[3],
+                         const int globalActiveMin[3], const int globalActiveMax[3], float globalMax,
+                         const int clipLo[3], const int clipHi[3]);
+
 /* Launch the frame on `stream` (a hipStream_t, may be NULL) without synchronising; the "last
  * camera" bookkeeping is identical to render().  Returns 0 or -1. */
 int isoRenderAsync(unsigned long long devicePtr, void* stream);

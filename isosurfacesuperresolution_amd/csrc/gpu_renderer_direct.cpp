@@ -212,8 +212,17 @@ float orderBitsToFloat(unsigned int u)
     return f;
 }
 
+// Placement of a tile inside a larger (multi-GPU) volume: the world map and the isovalue scale come
+// from the GLOBAL volume, rays are clipped to the tile's own region.
+struct TileInfo {
+    int origin[3];                 // global index of local voxel (0,0,0)
+    int gmin[3], gmax[3];          // global active-voxel bbox
+    float globalMax;
+    int clipLo[3], clipHi[3];      // region owned by this tile, global index coordinates, [lo, hi)
+};
+
 // Dense device volume -> bricks, occupancy hierarchy, bbox, max, world map.
-bool uploadFromDevice(const float* dense, int nx, int ny, int nz)
+bool uploadFromDevice(const float* dense, int nx, int ny, int nz, const TileInfo* tile = nullptr)
 {
     if (nx <= 0 || ny <= 0 || nz <= 0 || nx > 4096 || ny > 4096 || nz > 4096) return false;
     Volume v;
@@ -261,9 +270,12 @@ bool uploadFromDevice(const float* dense, int nx, int ny, int nz)
                     if (z < lmin[2]) lmin[2] = z; if (z > lmax[2]) lmax[2] = z;
                 }
             }
-    if (nleaf == 0) {   // the reference throws on empty grids (IsoVolumeRayTracer.h:188-190)
+    if (nleaf == 0 && !tile) {   // the reference throws on empty grids (IsoVolumeRayTracer.h:188-190)
         freeVolume(v);
         return false;
+    }
+    if (nleaf == 0) {            // an empty tile of a larger volume renders nothing
+        for (int k = 0; k < 3; ++k) { lmin[k] = 0; lmax[k] = -1; }
     }
     v.nslots = nslots; v.nleaf = nleaf;
     for (int k = 0; k < 3; ++k) {   // IsoVolumeRayTracer.h:195-197
@@ -273,6 +285,10 @@ bool uploadFromDevice(const float* dense, int nx, int ny, int nz)
     v.maxValue = orderBitsToFloat(maxbits);
     // CPURenderer.cpp:448-458 with unit voxels: scale longest active-bbox edge to 1, centre at 0
     double ext[3], cen[3];
+    if (tile) {
+        for (int k = 0; k < 3; ++k) { bbox[k] = tile->gmin[k]; bbox[3 + k] = tile->gmax[k]; }
+        v.maxValue = tile->globalMax;
+    }
     for (int k = 0; k < 3; ++k) {
         const double lo = double(bbox[k]), hi = double(bbox[3 + k]);
         ext[k] = hi - lo;
@@ -286,6 +302,15 @@ bool uploadFromDevice(const float* dense, int nx, int ny, int nz)
     v.s = 1.0 * scale;
     v.sinv = 1.0 / v.s;
     for (int k = 0; k < 3; ++k) v.t[k] = (-cen[k]) * scale;
+    if (tile) {
+        // local index = global index - origin  =>  world = local*s + (t + origin*s); rays see only [clipLo, clipHi)
+        for (int k = 0; k < 3; ++k) {
+            v.t[k] = v.t[k] + double(tile->origin[k]) * v.s;
+            const int lo = tile->clipLo[k] - tile->origin[k], hi = tile->clipHi[k] - tile->origin[k];
+            if (lo > v.bbmin[k]) v.bbmin[k] = lo;
+            if (hi < v.bbmax[k]) v.bbmax[k] = hi;
+        }
+    }
 
     HIP_OK(hipMalloc(&v.slot, nb * sizeof(int32_t)));
     HIP_OK(hipMalloc(&v.node1, node1.size()));
@@ -487,6 +512,26 @@ int isoLoadDenseHost(const float* hostData, int nx, int ny, int nz)
     if (hipMalloc(&dense, bytes) != hipSuccess) return -2;
     if (hipMemcpy(dense, hostData, bytes, hipMemcpyHostToDevice) != hipSuccess) { (void)hipFree(dense); return -2; }
     const bool ok = uploadFromDevice(dense, nx, ny, nz);
+    (void)hipFree(dense);
+    return ok ? 0 : -2;
+}
+
+int isoLoadDenseTileHost(const float* hostData, int nx, int ny, int nz, const int origin[3],
+                         const int globalActiveMin[3], const int globalActiveMax[3], float globalMax,
+                         const int clipLo[3], const int clipHi[3])
+{
+    if (!g.initialised || !hostData || nx <= 0 || ny <= 0 || nz <= 0 || !origin || !globalActiveMin || !globalActiveMax || !clipLo || !clipHi) return -2;
+    TileInfo t;
+    for (int k = 0; k < 3; ++k) {
+        t.origin[k] = origin[k]; t.gmin[k] = globalActiveMin[k]; t.gmax[k] = globalActiveMax[k];
+        t.clipLo[k] = clipLo[k]; t.clipHi[k] = clipHi[k];
+    }
+    t.globalMax = globalMax;
+    float* dense = nullptr;
+    const size_t bytes = size_t(nx) * ny * nz * sizeof(float);
+    if (hipMalloc(&dense, bytes) != hipSuccess) return -2;
+    if (hipMemcpy(dense, hostData, bytes, hipMemcpyHostToDevice) != hipSuccess) { (void)hipFree(dense); return -2; }
+    const bool ok = uploadFromDevice(dense, nx, ny, nz, &t);
     (void)hipFree(dense);
     return ok ? 0 : -2;
 }

@@ -48,6 +48,8 @@ class DirectRenderer:
         lib.isoLoadDenseHost.restype = ctypes.c_int
         lib.isoLoadDenseDevice.argtypes = [ctypes.c_ulonglong, ctypes.c_int, ctypes.c_int, ctypes.c_int]
         lib.isoLoadDenseDevice.restype = ctypes.c_int
+        lib.isoLoadDenseTileHost.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int] + [ctypes.c_void_p] * 3 + [ctypes.c_float] + [ctypes.c_void_p] * 2
+        lib.isoLoadDenseTileHost.restype = ctypes.c_int
         lib.isoRenderAsync.argtypes = [ctypes.c_ulonglong, ctypes.c_void_p]
         lib.isoRenderAsync.restype = ctypes.c_int
         lib.isoGetVolumeInfo.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
@@ -83,6 +85,18 @@ class DirectRenderer:
             rc = self.lib.isoLoadDenseHost(volume.ctypes.data, nx, ny, nz)
         if rc != 0:
             raise RuntimeError("loading the dense volume failed (rc=%d)" % rc)
+        return rc
+
+    def load_tile(self, tile):
+        """Additive: one tile of a larger volume (see ``parallel_render.partition_volume``)."""
+        import numpy as np
+        data = np.ascontiguousarray(tile['data'], dtype=np.float32)
+        nz, ny, nx = data.shape
+        i3 = lambda v: (ctypes.c_int * 3)(*[int(a) for a in v])
+        rc = self.lib.isoLoadDenseTileHost(data.ctypes.data, nx, ny, nz, i3(tile['origin']), i3(tile['gmin']), i3(tile['gmax']),
+                                           ctypes.c_float(tile['gmaxval']), i3(tile['clip_lo']), i3(tile['clip_hi']))
+        if rc != 0:
+            raise RuntimeError("loading the volume tile failed (rc=%d)" % rc)
         return rc
 
     def send_command(self, cmd, value):

@@ -1,0 +1,89 @@
+"""Object-space tiled rendering of volumes that are split over the GPUs of a node
+(BASELINE config #5: 1024^3 as 2x2x2 tiles of 512^3).
+
+The reference has nothing like this (single device).  Every rank ray-marches the FULL low-res image
+against its own tile (loaded with ``DirectRenderer.load_tile``: world map and isovalue scale of the
+global volume, rays clipped to the tile's region), then the 12-channel G-buffers are exchanged with
+ONE all-gather (RCCL over xGMI: 24.9 MB per GPU at 960x540) and composited per pixel by nearest hit
+-- valid because the first isosurface hit along a ray is the minimum over the disjoint convex tiles.
+"""
+import numpy as np
+import torch
+import torch.distributed as dist
+
+HALO = 8      # multiples of the 8^3 leaf keep the tile's leaf grid aligned with the global one
+
+
+def global_stats(volume):
+    """Active-voxel bbox (x,y,z order) and maximum of a dense [z][y][x] volume."""
+    nzv = np.argwhere(volume != 0)
+    lo, hi = nzv.min(0)[::-1], nzv.max(0)[::-1]
+    return [int(v) for v in lo], [int(v) for v in hi], float(volume.max())
+
+
+def tile_boxes(shape, splits):
+    """[(lo(x,y,z), hi(x,y,z))] of an (sz, sy, sx) split of a [z][y][x] volume, z-major rank order."""
+    nz, ny, nx = shape
+    sz, sy, sx = splits
+    edges = lambda n, s: [round(i * n / s) for i in range(s + 1)]
+    ex, ey, ez = edges(nx, sx), edges(ny, sy), edges(nz, sz)
+    boxes = []
+    for k in range(sz):
+        for j in range(sy):
+            for i in range(sx):
+                boxes.append(((ex[i], ey[j], ez[k]), (ex[i + 1], ey[j + 1], ez[k + 1])))
+    return boxes
+
+
+def make_tile(volume_slice_fn, shape, box, gmin, gmax, gmaxval):
+    """Tile descriptor for ``DirectRenderer.load_tile``.  ``volume_slice_fn(z0,z1,y0,y1,x0,x1)`` returns the
+    dense data of that index range (so a rank can generate or read only what it owns)."""
+    nz, ny, nx = shape
+    (x0, y0, z0), (x1, y1, z1) = box
+    ox, oy, oz = max(0, x0 - HALO), max(0, y0 - HALO), max(0, z0 - HALO)
+    ex, ey, ez = min(nx, x1 + HALO), min(ny, y1 + HALO), min(nz, z1 + HALO)
+    return {"data": volume_slice_fn(oz, ez, oy, ey, ox, ex), "origin": (ox, oy, oz), "gmin": gmin, "gmax": gmax,
+            "gmaxval": gmaxval, "clip_lo": (x0, y0, z0), "clip_hi": (x1, y1, z1)}
+
+
+def partition_volume(volume, splits=(2, 2, 2)):
+    """All tiles of an in-memory volume (tests / single-process use)."""
+    gmin, gmax, gmaxval = global_stats(volume)
+    fn = lambda z0, z1, y0, y1, x0, x1: volume[z0:z1, y0:y1, x0:x1]
+    return [make_tile(fn, volume.shape, box, gmin, gmax, gmaxval) for box in tile_boxes(volume.shape, splits)]
+
+
+def composite(gbuffers):
+    """Nearest-hit composite of per-tile G-buffers [T, H, W, 12] -> [H, W, 12] (mask ch 3, depth ch 7)."""
+    mask = gbuffers[..., 3] > 0
+    depth = torch.where(mask, gbuffers[..., 7], torch.full_like(gbuffers[..., 7], float("inf")))
+    win = depth.argmin(dim=0)                                        # [H, W]
+    idx = win.unsqueeze(0).unsqueeze(-1).expand(1, *gbuffers.shape[1:])
+    out = torch.gather(gbuffers, 0, idx)[0]
+    return out
+
+
+class TiledRenderer:
+    """One rank of the tiled render: local ray-march, all-gather, composite (identical on all ranks)."""
+
+    def __init__(self, renderer, tile, process_group=None, render_fn=None):
+        """``render_fn(tensor[H,W,12])`` overrides the local render (CPU tests drive the exchange and the
+        composite over gloo with the oracle as the local renderer)."""
+        self.renderer = renderer
+        self.group = process_group
+        self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
+        self.render_fn = render_fn
+        if renderer is not None:
+            renderer.load_tile(tile)
+
+    def render(self, width, height, device="cuda"):
+        local = torch.empty((height, width, 12), dtype=torch.float32, device=device)
+        if self.render_fn is not None:
+            self.render_fn(local)
+        else:
+            self.renderer.render_direct(local)
+        if self.world == 1:
+            return local
+        gathered = torch.empty((self.world, height, width, 12), dtype=torch.float32, device=device)
+        dist.all_gather_into_tensor(gathered, local, group=self.group)
+        return composite(gathered)

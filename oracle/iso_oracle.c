@@ -118,6 +118,47 @@ iso_volume* iso_volume_create(const float* dense, int nx, int ny, int nz)
     return v;
 }
 
+/* Tile of a larger volume (tests of the multi-GPU tiled render): same placement rules as the
+ * product's isoLoadDenseTileHost -- world map and isovalue scale from the GLOBAL volume, rays clipped
+ * to the tile's own region.  An all-zero tile is allowed (renders nothing). */
+iso_volume* iso_volume_create_tile(const float* dense, int nx, int ny, int nz, const int origin[3],
+                                   const int gmin[3], const int gmax[3], float global_max,
+                                   const int clip_lo[3], const int clip_hi[3])
+{
+    size_t n = (size_t)nx * ny * nz;
+    int any = 0;
+    for (size_t i = 0; i < n && !any; ++i) any = dense[i] != 0.0f;
+    iso_volume* v;
+    if (any) v = iso_volume_create(dense, nx, ny, nz);
+    else {
+        float* tmp = (float*)malloc(n * sizeof(float));
+        memcpy(tmp, dense, n * sizeof(float));
+        tmp[0] = 1.0f;                       /* build the containers, then forget the dummy voxel */
+        v = iso_volume_create(tmp, nx, ny, nz);
+        free(tmp);
+        if (v) { v->data[0] = 0.0f; memset(v->leaf, 0, (size_t)v->bx * v->by * v->bz); memset(v->node1, 0, (size_t)v->mx * v->my * v->mz);
+                 v->any_leaf = 0; v->nleaf = 0; for (int k = 0; k < 3; ++k) { v->nbox_min[k] = 0; v->nbox_max[k] = 0; } }
+    }
+    if (!v) return NULL;
+    double ext[3], cen[3];
+    for (int k = 0; k < 3; ++k) { double lo = (double)gmin[k], hi = (double)gmax[k]; ext[k] = hi - lo; cen[k] = (lo + hi) * 0.5; }
+    double m = ext[0];
+    if (ext[1] > m) m = ext[1];
+    if (ext[2] > m) m = ext[2];
+    double scale = 1.0 / m;
+    v->s = 1.0 * scale;
+    v->sinv = 1.0 / v->s;
+    v->max_value = global_max;
+    for (int k = 0; k < 3; ++k) {
+        v->t[k] = (-cen[k]) * scale;
+        v->t[k] = v->t[k] + (double)origin[k] * v->s;
+        int lo = clip_lo[k] - origin[k], hi = clip_hi[k] - origin[k];
+        if (lo > v->nbox_min[k]) v->nbox_min[k] = lo;
+        if (hi < v->nbox_max[k]) v->nbox_max[k] = hi;
+    }
+    return v;
+}
+
 void iso_volume_free(iso_volume* v)
 {
     if (!v) return;

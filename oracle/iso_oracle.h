@@ -26,6 +26,9 @@ typedef struct iso_volume iso_volume;
  * normalised as CPURenderer.cpp:448-458 does.  Dimensions must be <= 4096 per axis
  * (one level-2 node of the 5-4-3 tree).  The data are copied. Returns NULL on error. */
 iso_volume* iso_volume_create(const float* dense, int nx, int ny, int nz);
+iso_volume* iso_volume_create_tile(const float* dense, int nx, int ny, int nz, const int origin[3],
+                                   const int gmin[3], const int gmax[3], float global_max,
+                                   const int clip_lo[3], const int clip_hi[3]);
 void iso_volume_free(iso_volume* v);
 
 /* info[0..2] node-level bbox min, [3..5] node-level bbox max (IsoVolumeRayTracer.h:195-197),

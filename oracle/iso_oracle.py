@@ -47,6 +47,8 @@ def lib():
         L = ctypes.CDLL(so)
         L.iso_volume_create.restype = ctypes.c_void_p
         L.iso_volume_create.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int]
+        L.iso_volume_create_tile.restype = ctypes.c_void_p
+        L.iso_volume_create_tile.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int] + [ctypes.c_void_p] * 3 + [ctypes.c_float] + [ctypes.c_void_p] * 2
         L.iso_volume_free.argtypes = [ctypes.c_void_p]
         L.iso_volume_info.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]
         L.iso_params_default.argtypes = [ctypes.POINTER(IsoParams)]
@@ -59,11 +61,17 @@ def lib():
 
 
 class OracleVolume:
-    def __init__(self, dense):
+    def __init__(self, dense, tile=None):
+        """tile: dict(origin, gmin, gmax, gmaxval, clip_lo, clip_hi) in (x,y,z) order for a tile of a larger volume."""
         dense = np.ascontiguousarray(dense, dtype=np.float32)
         assert dense.ndim == 3
         nz, ny, nx = dense.shape
-        self._h = lib().iso_volume_create(dense.ctypes.data, nx, ny, nz)
+        if tile is not None:
+            i3 = lambda v: (ctypes.c_int * 3)(*[int(a) for a in v])
+            self._h = lib().iso_volume_create_tile(dense.ctypes.data, nx, ny, nz, i3(tile['origin']), i3(tile['gmin']), i3(tile['gmax']),
+                                                   ctypes.c_float(tile['gmaxval']), i3(tile['clip_lo']), i3(tile['clip_hi']))
+        else:
+            self._h = lib().iso_volume_create(dense.ctypes.data, nx, ny, nz)
         if not self._h:
             raise ValueError("oracle: empty or oversized volume")
         self.shape = dense.shape
@@ -78,8 +86,11 @@ class OracleVolume:
                 "num_leaves": info[12], "scale": st[0], "translation": list(st[1:4]), "max_value": mx.value}
 
     def __del__(self):
-        if getattr(self, "_h", None):
-            lib().iso_volume_free(self._h)
+        if getattr(self, "_h", None) and _LIB is not None:
+            try:
+                _LIB.iso_volume_free(self._h)
+            except Exception:
+                pass
             self._h = None
 
 

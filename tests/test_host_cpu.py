@@ -209,3 +209,43 @@ dist.destroy_process_group()
     assert upd_single.abs().max() > 1e-4
     rel = (upd_single - upd_ddp).norm() / upd_single.norm()
     assert rel < 1e-2, rel
+
+
+def test_tiled_render_two_rank_gloo_composite(tmp_path, oracle):
+    """Object-space split over 2 ranks: local render of each tile (oracle, CPU), ONE all-gather over
+    gloo, nearest-hit composite == the single-volume render (SURVEY.md 8(e), config #5)."""
+    script = tmp_path / "tiled.py"
+    script.write_text('''
+import os, sys, numpy as np, torch, torch.distributed as dist
+sys.path.insert(0, %r)
+from oracle import iso_oracle as O
+from isosurfacesuperresolution_amd import volumes as V, parallel_render as PR
+dist.init_process_group("gloo")
+rank = dist.get_rank()
+vol = V.ejecta(64)
+gmin, gmax, gmaxval = PR.global_stats(vol)
+box = PR.tile_boxes(vol.shape, (2, 1, 1))[rank]
+tile = PR.make_tile(lambda z0, z1, y0, y1, x0, x1: vol[z0:z1, y0:y1, x0:x1], vol.shape, box, gmin, gmax, gmaxval)
+tv = O.OracleVolume(tile["data"], tile=tile)
+p = O.make_params(80, 48, origin=V.quantize3(V.orbit_camera(21)), fov=30.0, isovalue=0.34)
+def local_render(t):
+    img, _ = O.render(tv, p, threads=2)
+    t.copy_(torch.from_numpy(img))
+tr = PR.TiledRenderer(None, tile, render_fn=local_render)
+out = tr.render(80, 48, device="cpu")
+if rank == 0:
+    np.save(%r, out.numpy())
+dist.destroy_process_group()
+''' % (ROOT, str(tmp_path / "tiled.npy")))
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="2")
+    subprocess.check_call([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
+                           "--master-addr", "127.0.0.1", "--master-port", "29617", str(script)],
+                          env=env, stdout=subprocess.DEVNULL, timeout=300)
+    comp = np.load(tmp_path / "tiled.npy")
+    vol = V.ejecta(64)
+    p = oracle.make_params(80, 48, origin=V.quantize3(V.orbit_camera(21)), fov=30.0, isovalue=0.34)
+    full, _ = oracle.render(oracle.OracleVolume(vol), p)
+    assert full[..., 3].sum() > 100
+    assert int((comp[..., 3] != full[..., 3]).sum()) <= 2           # tile-entry rounding may move a silhouette pixel
+    both = (comp[..., 3] == 1) & (full[..., 3] == 1)
+    assert np.abs(comp - full)[both].max() <= 1e-4
