@@ -84,6 +84,6 @@ class TiledRenderer:
             self.renderer.render_direct(local)
         if self.world == 1:
             return local
-        gathered = torch.empty((self.world, height, width, 12), dtype=torch.float32, device=device)
-        dist.all_gather_into_tensor(gathered, local, group=self.group)
-        return composite(gathered)
+        gathered = torch.empty((self.world * height, width, 12), dtype=torch.float32, device=device)
+        dist.all_gather_into_tensor(gathered, local, group=self.group)       # concatenated along dim 0
+        return composite(gathered.view(self.world, height, width, 12))
