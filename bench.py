@@ -52,9 +52,16 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     assert torch.cuda.is_available(), "bench.py needs an MI355X"
+    # BENCH_DIST_BACKEND=gloo + BENCH_SHARE_DEVICE=1 rehearse the multi-rank path on a one-GPU box
+    backend = os.environ.get("BENCH_DIST_BACKEND", "nccl")
+    if os.environ.get("BENCH_SHARE_DEVICE") == "1":
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     if world > 1:
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend)
     assert args.gpus == world, "--gpus must equal the number of launched ranks"
 
     low_w, low_h = (int(v) for v in args.low.split("x"))
@@ -100,7 +107,7 @@ def main():
     ops.profile_enable(False)
     renderer.profile_enable(False)
     if world > 1:
-        tmax = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = tmax.item()
 
