@@ -33,6 +33,7 @@ def parse():
     ap.add_argument("--no-temporal", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--raymarch-variant", type=int, default=0)
+    ap.add_argument("--no-overlap", action="store_true", help="render frame t and super-resolve it back to back on one stream")
     return ap.parse_args()
 
 
@@ -68,7 +69,6 @@ def main():
     iso = {"ejecta256": 0.34, "ejecta128": 0.34, "sphere64": 0.5}[args.volume]
     vol = V.VOLUMES[args.volume][0]()
     renderer = DirectRenderer()
-    renderer.set_kernel_variant(args.raymarch_variant)
     renderer.load_dense(vol)
     opt = argparse.Namespace(upsample='bilinear', reconType='residual', useBN=False, numResidualLayers=10)
     torch.manual_seed(0)
@@ -77,6 +77,9 @@ def main():
     pipe = SuperResolutionPipeline(renderer, model, default_shading("cuda", 30.0), (low_w, low_h),
                                    temporal=not args.no_temporal)
     pipe.set_static(fov=30.0, isovalue=iso)
+    pipe.foreground_variant = args.raymarch_variant
+    renderer.set_kernel_variant(args.raymarch_variant)
+    overlap = not args.no_overlap
 
     K, Wm = args.steps, args.warmup
     first = rank * K                      # this rank's contiguous chunk of the orbit
@@ -89,7 +92,8 @@ def main():
             torch.cuda.synchronize()
 
     for k in range(Wm):
-        pipe.frame(origins[k])
+        pipe.frame(origins[k], origins[k + 1] if overlap else None)
+    torch.cuda.synchronize()
     pipe.reset()
     # Per-kernel durations come from start/stop events carried on the dispatch packets themselves
     # (hipExtLaunchKernelGGL inside the libraries, on the stream the kernels run on): unlike
@@ -99,7 +103,8 @@ def main():
     sync()
     t0 = time.perf_counter()
     for k in range(K):
-        pipe.frame(origins[Wm + k])
+        # the next frame's ray-march is enqueued on a side stream and overlaps this frame's network
+        pipe.frame(origins[Wm + k], origins[Wm + k + 1] if overlap and k + 1 < K else None)
     sync()
     elapsed = time.perf_counter() - t0
     records = ops.profile_records()
@@ -144,7 +149,8 @@ def main():
         "data": "synthetic (V256-ejecta stand-in volume, seeded random-init EnhanceNet weights)",
         "config": {"workload": "%s volume, %dx%d -> %dx%d 4x SR inference, orbit camera, temporal=%s" % (
             args.volume, low_w, low_h, 4 * low_w, 4 * low_h, "off" if args.no_temporal else "on"),
-            "frames_per_rank": K, "sharding": "contiguous frame chunks per rank, no collective"},
+            "frames_per_rank": K, "sharding": "contiguous frame chunks per rank, no collective",
+            "overlap": ("render(t+1) on a side HIP stream || SR(t), %d ray-march waves" % pipe.side_waves) if overlap else "off"},
         "roofline": {"kernel": dom_name, "bound": "mfma", "achieved": achieved, "peak": MFMA_F32_PEAK_TFLOPS,
                      "unit": "TFLOP/s", "frac": achieved / MFMA_F32_PEAK_TFLOPS, "traffic": traffic,
                      "traffic_source": "profiles/r01_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, bytes per launch)" if traffic else None,
@@ -152,7 +158,8 @@ def main():
                      "flops_per_launch": dom_flops / dom_launches},
         "kernels": {n: {"tflops": v[0] / v[1] / 1e12, "ms_per_frame": v[1] / K * 1e3, "launches_per_frame": v[2] / K}
                     for n, v in per.items()},
-        "raymarch": {"kernel": "iso_render_gather", "ms_per_frame": rm_time * 1e3},
+        "raymarch": {"kernel": "iso_render_gather_slim (under the network)" if overlap else "iso_render_gather",
+                     "ms_per_frame": rm_time * 1e3},
     }
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline:

@@ -75,6 +75,12 @@ int isoProfileEnable(int on);
 int isoProfileCount(void);
 int isoProfileGet(int i, float* ms);
 
+/* Variant 2 only: launch at most `waves` one-wave workgroups, each striding over the 8x8 pixel tiles
+ * (0 = one per tile, the default).  4 x the CU count keeps one ray-march wave per SIMD, which is what
+ * lets the next SR conv workgroup land on every CU while a frame renders on a side stream.
+ * Returns 0, or -1 for a negative cap. */
+int isoSetWaveCap(int waves);
+
 /* Host-only helpers around the .vbx reader (no GPU needed): volume dims [x,y,z] of the dense box
  * spanned by the stored bricks, and the dense fp32 data [z][y][x] itself. 0 ok, -2 on failure. */
 int isoVbxInfo(const char* path, int dims[3]);

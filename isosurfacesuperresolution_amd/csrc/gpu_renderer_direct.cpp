@@ -62,6 +62,7 @@ struct State {
     double lastOrigin[3] = { 0, 0, -1 }, lastLookAt[3] = { 0, 0, 0 };
     Volume vol;
     int variant = 0;
+    int waveCap = 0;             // see isoSetWaveCap
     float* aoHemi = nullptr;     // device copies of the AO tables
     float* aoRot = nullptr;
     bool profile = false;
@@ -371,7 +372,7 @@ bool launchFrame(float* out, hipStream_t stream)
         if (hipEventCreate(&e0) == hipSuccess && hipEventCreate(&e1) == hipSuccess) g.events.emplace_back(e0, e1);
         else e0 = e1 = nullptr;
     }
-    iso_launch_render(p, g.variant, stream, e0, e1);
+    iso_launch_render(p, g.variant, stream, e0, e1, g.waveCap);
     if (hipGetLastError() != hipSuccess) return false;
     // GPURendererDirect.cpp:440-442: the camera just rendered becomes the flow reference
     for (int k = 0; k < 3; ++k) { g.lastOrigin[k] = a.cameraOrigin[k]; g.lastLookAt[k] = a.cameraLookAt[k]; }
@@ -548,9 +549,16 @@ int isoGetVolumeInfo(int info[12], float* out_max)
     return 0;
 }
 
+int isoSetWaveCap(int waves)
+{
+    if (waves < 0) return -1;
+    g.waveCap = waves;
+    return 0;
+}
+
 int isoSetKernelVariant(int variant)
 {
-    if (variant < 0 || variant > 1) return -1;
+    if (variant < 0 || variant > 2) return -1;
     g.variant = variant;
     return 0;
 }

@@ -404,10 +404,9 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg)
 
 // ---- variant 0: per-lane gather ------------------------------------------------------------
 template <bool AO>
-__global__ __launch_bounds__(64) void iso_render_gather(const IsoRenderParams P)
+__device__ __forceinline__ void render_gather_tile(const IsoRenderParams& P, int vb, int tiles_x, int ntiles)
 {
-    const int tiles_x = (P.W + 7) >> 3, tiles_y = (P.H + 7) >> 3;
-    const int tile = xcd_remap(blockIdx.x, tiles_x * tiles_y);
+    const int tile = xcd_remap(vb, ntiles);
     const int lane = threadIdx.x;
     const int i = (tile % tiles_x) * 8 + (lane & 7);
     const int j = (tile / tiles_x) * 8 + (lane >> 3);
@@ -422,6 +421,36 @@ __global__ __launch_bounds__(64) void iso_render_gather(const IsoRenderParams P)
             shade_hit<AO>(P, r, it, wdx, wdy, wdz, i, j, o);
     }
     store_pixel(P, i, j, o);
+}
+
+template <bool AO>
+__device__ __forceinline__ void render_gather_pixel(const IsoRenderParams& P)
+{
+    const int tiles_x = (P.W + 7) >> 3, ntiles = tiles_x * ((P.H + 7) >> 3);
+    render_gather_tile<AO>(P, blockIdx.x, tiles_x, ntiles);
+}
+
+template <bool AO>
+__global__ __launch_bounds__(64) void iso_render_gather(const IsoRenderParams P)
+{
+    render_gather_pixel<AO>(P);
+}
+
+// ---- variant 2: the same code in a 128-register budget ----------------------------------------
+// For rendering frame t+1 on a side stream under the SR network of frame t: the fused conv holds
+// 226 VGPR + 128 AGPR = 360 of a SIMD's 512 registers, so a 168-register ray-march wave can never
+// sit beside it and the two kernels only time-slice CUs.  At <= 128 registers (a few cold values
+// spilled to scratch) one ray-march wave fits beside each conv wave and fills its stall slots --
+// provided there is never a second one on the same SIMD (2 x 128 + 360 > 512 would keep the next
+// conv workgroup off that CU), hence the wave cap: 4 x #CUs waves, striding over the tiles.
+// Same instructions on the same values: results are bit-identical to variant 0.
+template <bool AO>
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void iso_render_gather_slim(const IsoRenderParams P)
+{
+    // the grid may be capped (a multiple of 8, so a wave's tiles stay on its XCD's share of the image):
+    // every wave then strides over the tiles, which bounds how many ray-march waves exist at any time
+    const int tiles_x = (P.W + 7) >> 3, ntiles = tiles_x * ((P.H + 7) >> 3);
+    for (int vb = blockIdx.x; vb < ntiles; vb += gridDim.x) render_gather_tile<AO>(P, vb, tiles_x, ntiles);
 }
 
 // ---- variant 1: wave-cooperative LDS brick cache --------------------------------------------
@@ -654,7 +683,7 @@ __global__ __launch_bounds__(64) void iso_brick_fill(const float* __restrict__ d
 
 }  // namespace
 
-void iso_launch_render(const IsoRenderParams& p, int variant, void* stream, void* startEvent, void* stopEvent)
+void iso_launch_render(const IsoRenderParams& p, int variant, void* stream, void* startEvent, void* stopEvent, int waveCap)
 {
     const int tiles = ((p.W + 7) >> 3) * ((p.H + 7) >> 3);
     const dim3 grid(tiles), block(64);
@@ -664,6 +693,10 @@ void iso_launch_render(const IsoRenderParams& p, int variant, void* stream, void
     if (variant == 1) {
         if (p.aoSamples > 0) hipExtLaunchKernelGGL(iso_render_lds<true>, grid, block, 0, st, e0, e1, 0, p);
         else hipExtLaunchKernelGGL(iso_render_lds<false>, grid, block, 0, st, e0, e1, 0, p);
+    } else if (variant == 2) {
+        const dim3 capped(waveCap > 0 && waveCap < tiles ? (waveCap + 7) & ~7 : tiles);   // 0 = one wave per tile
+        if (p.aoSamples > 0) hipExtLaunchKernelGGL(iso_render_gather_slim<true>, capped, block, 0, st, e0, e1, 0, p);
+        else hipExtLaunchKernelGGL(iso_render_gather_slim<false>, capped, block, 0, st, e0, e1, 0, p);
     } else {
         if (p.aoSamples > 0) hipExtLaunchKernelGGL(iso_render_gather<true>, grid, block, 0, st, e0, e1, 0, p);
         else hipExtLaunchKernelGGL(iso_render_gather<false>, grid, block, 0, st, e0, e1, 0, p);

@@ -43,7 +43,8 @@ struct IsoRenderParams {
 };
 
 // launchers (iso_kernels.hip)
-void iso_launch_render(const IsoRenderParams& p, int variant, void* stream, void* startEvent, void* stopEvent);
+// waveCap: variant 2 only -- launch at most this many one-wave workgroups (0 = one per 8x8 tile)
+void iso_launch_render(const IsoRenderParams& p, int variant, void* stream, void* startEvent, void* stopEvent, int waveCap);
 void iso_launch_brick_flags(const float* dense, int nx, int ny, int nz, int nbx, int nby, int nbz,
                             uint8_t* flag9, uint8_t* leaf, int* bbox6, unsigned int* maxbits, void* stream);
 void iso_launch_brick_fill(const float* dense, int nx, int ny, int nz, int nbx, int nby, int nbz,

@@ -56,6 +56,8 @@ class DirectRenderer:
         lib.isoGetVolumeInfo.restype = ctypes.c_int
         lib.isoSetKernelVariant.argtypes = [ctypes.c_int]
         lib.isoSetKernelVariant.restype = ctypes.c_int
+        lib.isoSetWaveCap.argtypes = [ctypes.c_int]
+        lib.isoSetWaveCap.restype = ctypes.c_int
         lib.isoProfileEnable.argtypes = [ctypes.c_int]
         lib.isoProfileEnable.restype = ctypes.c_int
         lib.isoProfileCount.argtypes = []
@@ -138,6 +140,10 @@ class DirectRenderer:
                 raise RuntimeError("isoProfileGet failed")
             out.append(ms.value)
         return out
+
+    def set_wave_cap(self, waves):
+        """Additive: see isoSetWaveCap (variant 2, side-stream rendering under the SR network)."""
+        return self.lib.isoSetWaveCap(int(waves))
 
     def set_kernel_variant(self, variant):
         return self.lib.isoSetKernelVariant(int(variant))

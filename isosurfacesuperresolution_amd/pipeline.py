@@ -41,7 +41,20 @@ class SuperResolutionPipeline:
         self.temporal = temporal
         self.device = device
         self.gbuffer = torch.empty((self.low_h, self.low_w, 12), dtype=torch.float32, device=device)
+        # render(t+1) || SR(t): the ray-marcher of the NEXT frame runs on a side stream while the
+        # MFMA-bound network of the current one owns the main stream (the renderer does not depend on
+        # the network's output).  Two G-buffers, two events per buffer.
+        self._gbuffers = [self.gbuffer, torch.empty_like(self.gbuffer)]
+        self._render_stream = torch.cuda.Stream(device=device) if str(device).startswith("cuda") else None
+        self._ready = [torch.cuda.Event(), torch.cuda.Event()] if self._render_stream else None
+        self._consumed = [torch.cuda.Event(), torch.cuda.Event()] if self._render_stream else None
+        self._slot = 0
+        self._prefetched = None           # (origin tuple, slot) of a render already in flight
+        # a prefetched frame is rendered by the 128-register ray-marcher (kernel variant 2) with one wave per
+        # SIMD, so that it sits beside the conv waves instead of displacing them (csrc/iso_kernels.hip)
+        self.side_waves = 4 * torch.cuda.get_device_properties(device).multi_processor_count if self._render_stream else 0
         self.previous = None
+        self.foreground_variant = 0       # kernel variant of frames rendered on the main stream
         # fused=True: input assembly and frame finishing run as two HIP kernels (ops.assemble_input /
         # ops.finish_frame); fused=False: the module-level PyTorch path (LoadedModel.inference etc.)
         self.fused = fused and upscale == 4 and getattr(model.model, 'recon_type', None) == 'residual' \
@@ -61,6 +74,35 @@ class SuperResolutionPipeline:
 
     def reset(self):
         self.previous = None
+        self._prefetched = None
+
+    def prefetch(self, origin):
+        """Start rendering the G-buffer of ``origin`` on the side stream (used by ``frame(..., next_origin=)``)."""
+        slot = self._slot ^ 1
+        rs = self._render_stream
+        rs.wait_event(self._consumed[slot])              # the network has finished reading that buffer
+        self.renderer.send_command("cameraOrigin", fmt3(origin))
+        self.renderer.set_kernel_variant(2)
+        self.renderer.set_wave_cap(self.side_waves)
+        self.renderer.render_async(self._gbuffers[slot], rs)
+        self.renderer.set_kernel_variant(self.foreground_variant)
+        self._ready[slot].record(rs)
+        self._prefetched = (tuple(origin), slot)
+
+    def _acquire_gbuffer(self, origin):
+        """G-buffer of ``origin`` on the current stream: the prefetched one if it matches, else rendered now."""
+        cur = torch.cuda.current_stream()
+        if self._prefetched is not None and self._prefetched[0] == tuple(origin):
+            slot = self._prefetched[1]
+            cur.wait_event(self._ready[slot])
+            self._prefetched = None
+        else:
+            slot = self._slot
+            self.renderer.send_command("cameraOrigin", fmt3(origin))
+            self.renderer.render_async(self._gbuffers[slot], cur)
+        self._slot = slot
+        self.gbuffer = self._gbuffers[slot]
+        return self.gbuffer
 
     def render_low(self, origin):
         self.renderer.send_command("cameraOrigin", fmt3(origin))
@@ -76,25 +118,28 @@ class SuperResolutionPipeline:
         self.previous = raw
         return raw
 
-    def frame_fused(self, origin):
+    def frame_fused(self, origin, next_origin=None):
         with torch.no_grad():
-            self.render_low(origin)
-            g = self.gbuffer
+            g = self._acquire_gbuffer(origin)
             prev = self.previous if self.temporal else None
             flow = None
             if prev is not None:
                 flow = ops.fill_flow_gbuffer(g)
             x = ops.assemble_input(g, flow, prev, self.model.initial_image_mode, self.model.inverse_ao)
+            self._consumed[self._slot].record(torch.cuda.current_stream())   # G-buffer no longer needed
+            if next_origin is not None:
+                self.prefetch(next_origin)
             feat = self.model.model.forward_features(x)
             self.shading.inverse_ao = self.model.inverse_ao
             raw, rgb = ops.finish_frame(feat, x, self.shading)
             self.previous = raw
         return rgb, raw
 
-    def frame(self, origin):
-        """origin: camera position. Returns (rgb [1,3,4h,4w], raw [1,6,4h,4w]) on the device."""
+    def frame(self, origin, next_origin=None):
+        """origin: camera position; ``next_origin`` (optional) starts the next frame's ray-march on a side
+        stream so that it overlaps this frame's network.  Returns (rgb [1,3,4h,4w], raw [1,6,4h,4w])."""
         if self.fused:
-            return self.frame_fused(origin)
+            return self.frame_fused(origin, next_origin)
         with torch.no_grad():
             low = self.render_low(origin)
             raw = self.superresolve(low)

@@ -178,3 +178,36 @@ def test_fused_frame_kernels_match_module_path():
             assert (raw_a - raw_b).abs().max().item() <= 1e-4, (mode, step)
             assert (rgb_a - rgb_b).abs().max().item() <= 1e-4, (mode, step)
             prev_a, prev_b = raw_a, raw_b
+
+
+def test_pipeline_overlap_matches_back_to_back():
+    """frame(origin, next_origin) renders frame t+1 on a side stream under the network of frame t
+    (pipeline.py); the frames must be the ones the single-stream sequence produces, bit for bit."""
+    from isosurfacesuperresolution_amd import models, volumes as V
+    from isosurfacesuperresolution_amd.inference import DirectRenderer, LoadedModel
+    from isosurfacesuperresolution_amd.pipeline import SuperResolutionPipeline, default_shading
+    opt = argparse.Namespace(upsample='bilinear', reconType='residual', useBN=False, numResidualLayers=10)
+    torch.manual_seed(3)
+    net = models.createNetwork('EnhanceNet', 4, 101, [0, 1, 2, 3, 4], 6, opt)
+    lm = LoadedModel.from_model(net, "cuda", parameters={"initialImage": "zero"})
+    renderer = DirectRenderer()
+    renderer.load_dense(V.ejecta(64))
+    origins = [V.orbit_camera(k) for k in range(5)]
+    outs = []
+    for overlap in (False, True):
+        pipe = SuperResolutionPipeline(renderer, lm, default_shading("cuda", 30.0), (96, 56))
+        pipe.set_static(fov=30.0, isovalue=0.34)
+        pipe.frame(origins[0])          # settle the renderer's "last camera" identically for both passes
+        pipe.reset()
+        seq = []
+        for k, o in enumerate(origins):
+            nxt = origins[k + 1] if overlap and k + 1 < len(origins) else None
+            rgb, raw = pipe.frame(o, nxt)
+            seq.append((rgb.clone(), raw.clone(), pipe.gbuffer.clone()))
+        torch.cuda.synchronize()
+        outs.append(seq)
+    for (rgb_a, raw_a, g_a), (rgb_b, raw_b, g_b) in zip(*outs):
+        assert torch.equal(g_a, g_b)
+        assert torch.equal(raw_a, raw_b)
+        assert torch.equal(rgb_a, rgb_b)
+    assert outs[0][-1][2][..., 3].sum().item() > 0

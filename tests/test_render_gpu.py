@@ -48,7 +48,7 @@ def _compare(gpu, ref):
         assert err <= TOL, "%s differs by %g" % (name, err)
 
 
-@pytest.mark.parametrize("variant", [0, 1])
+@pytest.mark.parametrize("variant", [0, 1, 2])
 @pytest.mark.parametrize("case", [
     dict(vol="sphere64", W=128, H=128, fov=45.0, iso=0.5, frames=(0, 7, 19)),
     dict(vol="ejecta64", W=160, H=90, fov=30.0, iso=0.34, frames=(3, 40)),
@@ -155,3 +155,23 @@ def test_tiled_render_composite_matches_full_volume(renderer, oracle):
     g = _render_gpu(renderer, W, H, origin, 30.0, 0.34)
     ref, _ = oracle.render(oracle.OracleVolume(tile["data"], tile=tile), oracle.make_params(W, H, origin=origin, fov=30.0, isovalue=0.34))
     _compare(g, ref)
+
+
+@pytest.mark.parametrize("cap", [8, 200, 1024])
+def test_capped_side_stream_variant_is_bit_identical(renderer, cap):
+    """Variant 2 (128-register build, waves striding over the tiles) must reproduce variant 0 bit for bit,
+    whatever the wave cap (510 tiles here, so every cap below strides)."""
+    vol = V.ejecta(64)
+    renderer.load_dense(vol)
+    origin = V.quantize3(V.orbit_camera(5))
+    renderer.set_kernel_variant(0)
+    _render_gpu(renderer, 240, 135, origin, 30.0, 0.34)
+    a = _render_gpu(renderer, 240, 135, origin, 30.0, 0.34)
+    renderer.set_kernel_variant(2)
+    assert renderer.set_wave_cap(cap) == 0
+    b = _render_gpu(renderer, 240, 135, origin, 30.0, 0.34)
+    renderer.set_wave_cap(0)
+    renderer.set_kernel_variant(0)
+    assert renderer.set_wave_cap(-1) == -1
+    assert a[..., 3].sum() > 0
+    assert np.array_equal(a.view(np.uint32), b.view(np.uint32))
