@@ -51,6 +51,7 @@ struct ConvParams {
     int Hin, Win;            // input size (H/2, W/2 when upsampling)
     int cinPad, coutPad;     // padded channel counts of the weight layout
     int co0;                 // first output channel handled by this launch (multiple of 64)
+    int cgroups;             // conv3x3_fwd2_kernel: 32-channel groups covered by the grid (co0 + 32 g)
     int tilesX, tilesY;
     int act;
     float slope;
@@ -89,7 +90,7 @@ __device__ __forceinline__ float buf_load(rsrc_t r, unsigned voff)
 constexpr unsigned PLAN_BAD = 0x80000000u;
 constexpr unsigned PLAN_DX = 1u << 29, PLAN_DY = 1u << 30, PLAN_OFF = 0x1FFFFFFCu;
 
-template <bool UPS>
+template <bool UPS, int CHUNK_ = CHUNK>
 __device__ __forceinline__ unsigned plan_element(const ConvParams& p, int e, int oy0, int ox0)
 {
     const int c = e / PLANE;
@@ -97,7 +98,7 @@ __device__ __forceinline__ unsigned plan_element(const ConvParams& p, int e, int
     const int r = rem / PW;
     const int col = rem - r * PW;
     const int gy = oy0 + r - 1, gx = ox0 + col - 1;
-    const bool ok = e < CHUNK && (unsigned)gy < (unsigned)p.H && (unsigned)gx < (unsigned)p.W;
+    const bool ok = e < CHUNK_ && (unsigned)gy < (unsigned)p.H && (unsigned)gx < (unsigned)p.W;
     if (!ok) return PLAN_BAD;
     if (!UPS) return (unsigned)(((c * p.Hin + gy) * p.Win + gx) * 4);
     const int x0 = gx > 0 ? (gx - 1) >> 1 : 0, y0 = gy > 0 ? (gy - 1) >> 1 : 0;
@@ -130,6 +131,10 @@ __device__ __forceinline__ float finish_element(unsigned w, const float (&raw)[U
     const float hx = 1.0f - lx, hy = 1.0f - ly;
     return hy * (hx * raw[0] + lx * raw[1]) + ly * (hx * raw[2] + lx * raw[3]);
 }
+
+template <int MT>
+__device__ __forceinline__ void conv_epilogue(const ConvParams& p, f32x16 (&acc)[MT][4], float* smem, int n, int oy0, int ox0,
+                                              int co0, int wave, int lane);
 
 template <int MT, bool UPS>
 __global__ __launch_bounds__(NTHREADS, 1) void conv3x3_fwd_kernel(const ConvParams p)
@@ -317,6 +322,21 @@ __global__ __launch_bounds__(NTHREADS, 1) void conv3x3_fwd_kernel(const ConvPara
     }
 
     if (p.dbg & 8) st2 = __builtin_amdgcn_s_memtime();
+    conv_epilogue<MT>(p, acc, smem, n, oy0, ox0, p.co0, wave, lane);
+    if ((p.dbg & 8) && tid == 0 && p.stamps) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const unsigned long long st3 = __builtin_amdgcn_s_memtime();
+        unsigned long long* o = p.stamps + (size_t)blockIdx.x * 4;
+        o[0] = st0; o[1] = st1; o[2] = st2; o[3] = st3;
+    }
+}
+
+
+template <int MT>
+__device__ __forceinline__ void conv_epilogue(const ConvParams& p, f32x16 (&acc)[MT][4], float* smem, int n, int oy0, int ox0,
+                                              int co0, int wave, int lane)
+{
+    const int j = lane & 31, kh = lane >> 5;
     // epilogue: D row (cout) = (reg&3) + 8*(reg>>2) + 4*(lane>>5), D col (pixel) = lane&31.
     // Output / residual go through buffer descriptors of image n: per-lane byte offset of the pixel
     // (BAD_OFFSET outside the image), per-register scalar offset of the channel plane; channels
@@ -332,7 +352,7 @@ __global__ __launch_bounds__(NTHREADS, 1) void conv3x3_fwd_kernel(const ConvPara
     for (int m = 0; m < MT; ++m)
 #pragma unroll
         for (int i = 0; i < 16; ++i)
-            bv[m][i] = p.bias[min(p.co0 + m * 32 + (i & 3) + 8 * (i >> 2) + 4 * kh, p.Cout - 1)];
+            bv[m][i] = p.bias[min(co0 + m * 32 + (i & 3) + 8 * (i >> 2) + 4 * kh, p.Cout - 1)];
     const int planeBytes = (int)(plane * 4);
     if ((p.W & 3) == 0) {
         // Wide path: each wave transposes one output row (64 couts x 32 pixels) through its own 8 KB
@@ -360,7 +380,7 @@ __global__ __launch_bounds__(NTHREADS, 1) void conv3x3_fwd_kernel(const ConvPara
                 const int co = q >> 3, px = ox0 + (q & 7) * 4;
                 const bool ok = oy < p.H && px < p.W && !(p.dbg & 2);
                 const unsigned off = ok ? (unsigned)((oy * p.W + px) * 4) : BAD_OFFSET;
-                const int soff = (p.co0 + co) * planeBytes;      // per lane -> goes into the vector offset
+                const int soff = (co0 + co) * planeBytes;      // per lane -> goes into the vector offset
                 float4 v = reinterpret_cast<const float4*>(tr)[q];
                 const unsigned voffs = ok ? off + (unsigned)soff : BAD_OFFSET;
                 if (p.residual) {
@@ -384,12 +404,12 @@ __global__ __launch_bounds__(NTHREADS, 1) void conv3x3_fwd_kernel(const ConvPara
             float rv[16];
 #pragma unroll
             for (int i = 0; i < 16; ++i) {
-                const int soff = (p.co0 + m * 32 + (i & 3) + 8 * (i >> 2)) * planeBytes;
+                const int soff = (co0 + m * 32 + (i & 3) + 8 * (i >> 2)) * planeBytes;
                 rv[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rrs, (int)pix, soff, 0));
             }
 #pragma unroll
             for (int i = 0; i < 16; ++i) {
-                const int soff = (p.co0 + m * 32 + (i & 3) + 8 * (i >> 2)) * planeBytes;
+                const int soff = (co0 + m * 32 + (i & 3) + 8 * (i >> 2)) * planeBytes;
                 float v = acc[m][r][i] + bv[m][i];
                 if (p.act == ISR_ACT_RELU) v = v > 0.f ? v : 0.f;
                 else if (p.act == ISR_ACT_LEAKY) v = v > 0.f ? v : v * p.slope;
@@ -399,12 +419,189 @@ __global__ __launch_bounds__(NTHREADS, 1) void conv3x3_fwd_kernel(const ConvPara
         }
     }
     }
-    if ((p.dbg & 8) && tid == 0 && p.stamps) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        const unsigned long long st3 = __builtin_amdgcn_s_memtime();
-        unsigned long long* o = p.stamps + (size_t)blockIdx.x * 4;
-        o[0] = st0; o[1] = st1; o[2] = st2; o[3] = st3;
+}
+
+// ---- forward, two workgroups per CU ------------------------------------------------------------
+// Same implicit GEMM, re-budgeted so that TWO workgroups share a CU: one M tile (32 output channels)
+// per workgroup and 8-channel chunks -> 61 KB of LDS and < 256 registers per wave.  The point is not
+// the MFMA loop (it is the same 8 x 32x32x2 per k-step pair) but everything around it: with one
+// workgroup per CU the prologue (first chunk from HBM), the per-chunk barriers and the epilogue
+// (bias/act/residual/store) leave the matrix pipe idle ~15 % of a workgroup's life; with two, the
+// other workgroup's waves issue MFMAs in those holes.  The price is that a tile's input patch is staged
+// once per 32-channel group (both groups of a tile are adjacent workgroups on one XCD, so the second
+// read is an L2 hit).
+constexpr int CK2 = 8;
+constexpr int CHUNK2 = CK2 * PLANE;                                  // 4896 floats
+constexpr int NEL2 = (CHUNK2 + NTHREADS - 1) / NTHREADS;             // 20 patch elements per thread and chunk
+constexpr int WCH2 = 9 * CK2 * 32;                                   // 2304 weight floats per chunk
+constexpr int NW42 = WCH2 / 4;                                       // 576 float4
+constexpr int NWI2 = (NW42 + NTHREADS - 1) / NTHREADS;               // 3 per thread
+constexpr int NITEMS2 = NEL2 + NWI2;                                 // 23 staging items per thread and chunk
+constexpr int KSTEPS2 = CK2 / 2;                                     // 4 k-steps per tap
+constexpr int NSLOTS2 = 9 * KSTEPS2;                                 // 36 k-steps per chunk = staging slots
+constexpr int DIST2 = 13;                                            // slots between issue and park
+static_assert(NITEMS2 + DIST2 <= NSLOTS2, "every item must be parked inside its chunk");
+constexpr size_t conv_fwd2_lds_bytes() { return (size_t)(2 * CHUNK2 + 2 * WCH2 + 4 * NTHREADS) * sizeof(float); }
+
+template <bool UPS>
+__global__ __launch_bounds__(NTHREADS, 2) void conv3x3_fwd2_kernel(const ConvParams p)
+{
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* patch0 = smem;                       // [2][CHUNK2]
+    float* wlds0 = smem + 2 * CHUNK2;           // [2][9][CK2][32]
+    float* dump = wlds0 + 2 * WCH2;             // [4*NTHREADS] sink for masked-off staging lanes
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int tilesPerImage = p.tilesX * p.tilesY;
+    const int lid = xcd_remap(blockIdx.x, gridDim.x);
+    const int grp = lid % p.cgroups;            // the channel groups of one tile are neighbours on one XCD
+    const int bid = lid / p.cgroups;
+    const int n = bid / tilesPerImage;
+    const int t = bid - n * tilesPerImage;
+    const int ty = t / p.tilesX, tx = t - ty * p.tilesX;
+    const int oy0 = ty * TH, ox0 = tx * TW;
+    const int co0 = p.co0 + grp * 32;
+
+    f32x16 acc[1][4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[0][r][i] = 0.0f;
+
+    const int nchunks = (p.Cin + CK2 - 1) / CK2;     // weight rows >= Cin are zero, input planes >= Cin read as 0
+    const int planeIn = p.Hin * p.Win;
+    const float* ximg = p.x + (size_t)n * p.Cin * planeIn;
+    const unsigned rowBytes = (unsigned)p.Win * 4u;
+    auto chunk_rsrc = [&](int chunk) -> rsrc_t {
+        const int left = p.Cin - chunk * CK2;
+        return __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(ximg + (size_t)chunk * CK2 * planeIn), 0,
+                                                 left > 0 ? left * planeIn * 4 : 0, 0x00020000);
+    };
+
+    unsigned plan[NEL2];
+#pragma unroll
+    for (int i = 0; i < NEL2; ++i) plan[i] = plan_element<UPS, CHUNK2>(p, tid + i * NTHREADS, oy0, ox0);
+    // weights: float4 f = tid + 256 i of the chunk's [9][CK2][32] block; f = tap*64 + k*8 + c4
+    unsigned woff[NWI2];
+#pragma unroll
+    for (int i = 0; i < NWI2; ++i) {
+        const int f = min(tid + i * NTHREADS, NW42 - 1);
+        const int tap = f >> 6, k = (f >> 3) & 7, c4 = f & 7;
+        woff[i] = (unsigned)((tap * p.cinPad + k) * p.coutPad + co0 + c4 * 4);
     }
+    const float* wchunk = p.w;
+    const size_t wchunkStep = (size_t)CK2 * p.coutPad;
+    auto weight_item = [&](const float* base, int i) -> float4 { return *reinterpret_cast<const float4*>(base + woff[i]); };
+
+    // prologue: chunk 0 in full
+    {
+        const rsrc_t rs = chunk_rsrc(0);
+        constexpr int NB = UPS ? 2 : 1;
+        constexpr int PB = NEL2 / NB;
+        static_assert(PB * NB == NEL2, "prologue batching");
+        float4 wv[NWI2];
+#pragma unroll
+        for (int i = 0; i < NWI2; ++i) wv[i] = weight_item(wchunk, i);
+#pragma unroll
+        for (int b = 0; b < NB; ++b) {
+            float raw[PB][UPS ? 4 : 1];
+#pragma unroll
+            for (int i = 0; i < PB; ++i) issue_element<UPS>(rs, plan[b * PB + i], rowBytes, raw[i]);
+#pragma unroll
+            for (int i = 0; i < PB; ++i) {
+                const int e = tid + (b * PB + i) * NTHREADS;
+                if (e < CHUNK2) patch0[e] = finish_element<UPS>(plan[b * PB + i], raw[i]);
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < NWI2; ++i)
+            if (tid + i * NTHREADS < NW42) reinterpret_cast<float4*>(wlds0)[tid + i * NTHREADS] = wv[i];
+    }
+    __syncthreads();
+
+    const int j = lane & 31;
+    const int kh = lane >> 5;
+    auto load_ops = [&](float& a, float (&b)[4], const float* w_, const float* p_, int kk) {
+        a = w_[(2 * kk) * 32];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) b[r] = p_[(2 * kk) * PLANE + r * PW];
+    };
+    auto mfma_step = [&](float a, const float (&b)[4]) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc[0][r] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b[r], acc[0][r], 0, 0, 0);
+    };
+
+    for (int chunk = 0; chunk < nchunks; ++chunk) {
+        const int buf = chunk & 1;
+        const bool more = chunk + 1 < nchunks;
+        const float* pb = patch0 + buf * CHUNK2 + kh * PLANE + (wave * 4) * PW + j;
+        const float* wb = wlds0 + buf * WCH2 + kh * 32 + j;
+        float* pnext = patch0 + (buf ^ 1) * CHUNK2 + tid;
+        float4* wnext = reinterpret_cast<float4*>(wlds0 + (buf ^ 1) * WCH2) + tid;
+        const rsrc_t rsn = chunk_rsrc(chunk + 1);
+        wchunk += wchunkStep;                       // now the next chunk's weight rows (only read when `more`)
+        float a0, b0[4], a1, b1[4];
+        float raw[DIST2][UPS ? 4 : 1];
+        float4 wraw[NWI2];
+        load_ops(a0, b0, wb, pb, 0);
+        auto plan_word = [&](int q) -> unsigned {   // opaque copy: keeps hipcc from hoisting the decode of all elements
+            unsigned w = plan[q];
+            asm volatile("" : "+v"(w));
+            return w;
+        };
+        float* const plast = (tid < CHUNK2 - (NEL2 - 1) * NTHREADS) ? pnext + (NEL2 - 1) * NTHREADS : dump + tid;
+        float4* const wlast = (tid < NW42 - (NWI2 - 1) * NTHREADS) ? wnext + (NWI2 - 1) * NTHREADS
+                                                                   : reinterpret_cast<float4*>(dump) + tid;
+        // slot s = k-step s of the chunk: park item s - DIST2, then issue item s (items: 20 patch
+        // elements, then 3 weight float4).  No branches around the memory operations (see above).
+        auto slot = [&](int s) {
+            const int qp = s - DIST2;
+            if (qp >= 0 && qp < NITEMS2) {
+                if (qp < NEL2) {
+                    const float v = finish_element<UPS>(plan_word(qp), raw[qp % DIST2]);
+                    if (qp < NEL2 - 1) pnext[qp * NTHREADS] = v; else *plast = v;
+                } else {
+                    const int i = qp - NEL2;
+                    if (i < NWI2 - 1) wnext[i * NTHREADS] = wraw[i]; else *wlast = wraw[i];
+                }
+            }
+            if (s < NITEMS2) {
+                if (s < NEL2) issue_element<UPS>(rsn, plan_word(s), rowBytes, raw[s % DIST2]);
+                else wraw[s - NEL2] = weight_item(wchunk, s - NEL2);
+            }
+        };
+        auto run_taps = [&](auto MORE) {
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) {
+            const int dy = tap / 3, dx = tap - dy * 3;
+            const int tn = tap + 1, dyn = tn / 3, dxn = tn - dyn * 3;
+            const float* pt = pb + dy * PW + dx;
+            const float* wt = wb + tap * CK2 * 32;
+            const float* ptn = pb + dyn * PW + dxn;
+            const float* wtn = wb + tn * CK2 * 32;
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int kk = 0; kk < KSTEPS2; kk += 2) {
+                load_ops(a1, b1, wt, pt, kk + 1);
+                __builtin_amdgcn_sched_barrier(0);
+                mfma_step(a0, b0);
+                if (decltype(MORE)::value) slot(tap * KSTEPS2 + kk);
+                __builtin_amdgcn_sched_barrier(0);
+                if (kk + 2 < KSTEPS2) load_ops(a0, b0, wt, pt, kk + 2);
+                else if (tap < 8) load_ops(a0, b0, wtn, ptn, 0);
+                __builtin_amdgcn_sched_barrier(0);
+                mfma_step(a1, b1);
+                if (decltype(MORE)::value) slot(tap * KSTEPS2 + kk + 1);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        };
+        if (more) run_taps(std::true_type{}); else run_taps(std::false_type{});
+        __syncthreads();
+    }
+    conv_epilogue<1>(p, acc, smem, n, oy0, ox0, co0, wave, lane);
 }
 
 template <int MT>
@@ -596,6 +793,7 @@ static hipEvent_t pool_event()
 }
 
 static int g_conv_dbg = 0;
+static int g_conv_algo = 1;   // 0: one workgroup per CU (64 channels), 1: two per CU (32 channels each)
 static unsigned long long* g_conv_stamps = nullptr;
 
 extern "C" {
@@ -621,7 +819,8 @@ int isrProfileGet(int i, int* variant, double* flops, float* ms)
     return 0;
 }
 
-void isrDebugSetAblation(int bits) { g_conv_dbg = bits; }   // not part of the public header
+void isrDebugSetAblation(int bits) { g_conv_dbg = bits; }
+void isrDebugSetForwardAlgo(int a) { g_conv_algo = a; }   // not part of the public header
 void isrDebugSetStampBuffer(void* p) { g_conv_stamps = (unsigned long long*)p; }
 
 int isrConvCinPad(int Cin) { return ((Cin + CK - 1) / CK) * CK; }
@@ -674,6 +873,28 @@ int isrConv3x3Forward(const float* x, const float* wprep, const float* bias, con
         (void)hipFuncSetAttribute((const void*)conv3x3_fwd_kernel<2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)conv_fwd_lds_bytes<2>());
         (void)hipFuncSetAttribute((const void*)conv3x3_fwd_kernel<2, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)conv_fwd_lds_bytes<2>());
         attr_done = true;
+    }
+    p.cgroups = 1;
+    if (g_conv_algo == 1) {
+        // two workgroups per CU, one 32-channel group each; the grid covers all groups of all tiles
+        static bool attr2_done = false;
+        if (!attr2_done) {
+            (void)hipFuncSetAttribute((const void*)conv3x3_fwd2_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)conv_fwd2_lds_bytes());
+            (void)hipFuncSetAttribute((const void*)conv3x3_fwd2_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)conv_fwd2_lds_bytes());
+            attr2_done = true;
+        }
+        p.co0 = 0;
+        p.cgroups = p.coutPad / 32;
+        if (nwg * p.cgroups > 0x7fffffffLL) return -1;
+        hipEvent_t e0 = nullptr, e1 = nullptr;
+        if (g_profile) {
+            e0 = pool_event(); e1 = pool_event();
+            g_records.push_back({ 8 + (upsample2x ? 1 : 0), 2.0 * 9 * Cin * Cout * (double)N * H * W, e0, e1 });
+        }
+        const dim3 grid2((unsigned)(nwg * p.cgroups));
+        if (upsample2x) hipExtLaunchKernelGGL((conv3x3_fwd2_kernel<true>), grid2, block, conv_fwd2_lds_bytes(), s, e0, e1, 0, p);
+        else hipExtLaunchKernelGGL((conv3x3_fwd2_kernel<false>), grid2, block, conv_fwd2_lds_bytes(), s, e0, e1, 0, p);
+        return hipGetLastError() == hipSuccess ? 0 : -2;
     }
     // one launch per group of up to 64 output channels (2 M tiles per wave)
     for (int co0 = 0; co0 < p.coutPad; co0 += 64) {
