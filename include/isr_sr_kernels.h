@@ -41,6 +41,15 @@ int isrConvPrepareWeights(const float* w, float* wprep, int Cout, int Cin, int t
 int isrConv3x3Forward(const float* x, const float* wprep, const float* bias, const float* residual, float* y,
                       int N, int Cin, int H, int W, int Cout, int act, float slope, int upsample2x, void* stream);
 
+/* The same convolution on tensors whose channel planes are not packed: x / y / residual are addressed as
+ * base + n * image + c * plane + row * cols + col (strides in floats; plane >= rows * cols; one image must
+ * stay below 2 GiB).  Lets a caller pad the plane size of the 1080p activations: with a plane of exactly
+ * 1920 x 1080 x 4 B the 64 planes alias in the memory system and the conv loses ~15 %. */
+int isrConv3x3ForwardStrided(const float* x, const float* wprep, const float* bias, const float* residual, float* y,
+                             int N, int Cin, int H, int W, int Cout, int act, float slope, int upsample2x,
+                             long long xPlane, long long xImage, long long yPlane, long long yImage,
+                             long long rPlane, long long rImage, void* stream);
+
 /* The same fused convolution for Cout <= 8 (EnhanceNet's final 64 -> 6 layer, enhancenet.py:124) on the
  * vector ALU instead of the 32-row MFMA tile.  isrConvSmallPrepare re-lays w[Cout][Cin][3][3] into
  * w8[9][isrConvSmallCinPad(Cin)][8] and bias into bias8[8] (zero padded); no upsampling variant. */
@@ -48,6 +57,10 @@ int isrConvSmallCinPad(int Cin);
 int isrConvSmallPrepare(const float* w, const float* bias, float* w8, float* bias8, int Cout, int Cin, void* stream);
 int isrConv3x3SmallCout(const float* x, const float* w8, const float* bias8, const float* residual, float* y,
                         int N, int Cin, int H, int W, int Cout, int act, float slope, void* stream);
+/* ... with a strided input (see isrConv3x3ForwardStrided); y and residual are packed. */
+int isrConv3x3SmallCoutStrided(const float* x, const float* w8, const float* bias8, const float* residual, float* y,
+                               int N, int Cin, int H, int W, int Cout, int act, float slope,
+                               long long xPlane, long long xImage, void* stream);
 
 /* Weight gradient of the same convolution: dw[Cout][Cin][3][3] = sum_{n,y,x} gz[n][co][y][x] * x[n][ci][y+ky-1][x+kx-1]
  * and db[Cout] = sum gz.  x: [N][Cin][H][W], gz: [N][Cout][H][W] (gradient w.r.t. the pre-activation).

@@ -49,6 +49,8 @@ struct ConvParams {
     float* y;
     int N, Cin, H, W, Cout;  // H, W: output size
     int Hin, Win;            // input size (H/2, W/2 when upsampling)
+    int xPlane, yPlane, rPlane;          // channel strides of x / y / residual in floats (>= rows * cols)
+    long long xImage, yImage, rImage;    // batch strides in floats
     int cinPad, coutPad;     // padded channel counts of the weight layout
     int co0;                 // first output channel handled by this launch (multiple of 64)
     int cgroups;             // conv3x3_fwd2_kernel: 32-channel groups covered by the grid (co0 + 32 g)
@@ -100,9 +102,9 @@ __device__ __forceinline__ unsigned plan_element(const ConvParams& p, int e, int
     const int gy = oy0 + r - 1, gx = ox0 + col - 1;
     const bool ok = e < CHUNK_ && (unsigned)gy < (unsigned)p.H && (unsigned)gx < (unsigned)p.W;
     if (!ok) return PLAN_BAD;
-    if (!UPS) return (unsigned)(((c * p.Hin + gy) * p.Win + gx) * 4);
+    if (!UPS) return (unsigned)((c * p.xPlane + gy * p.Win + gx) * 4);
     const int x0 = gx > 0 ? (gx - 1) >> 1 : 0, y0 = gy > 0 ? (gy - 1) >> 1 : 0;
-    unsigned w = (unsigned)(((c * p.Hin + y0) * p.Win + x0) * 4) | (unsigned)(gx & 1) | ((unsigned)(gy & 1) << 1);
+    unsigned w = (unsigned)((c * p.xPlane + y0 * p.Win + x0) * 4) | (unsigned)(gx & 1) | ((unsigned)(gy & 1) << 1);
     if (gx > 0 && x0 < p.Win - 1) w |= PLAN_DX;
     if (gy > 0 && y0 < p.Hin - 1) w |= PLAN_DY;
     return w;
@@ -169,8 +171,8 @@ __global__ __launch_bounds__(NTHREADS, 1) void conv3x3_fwd_kernel(const ConvPara
             for (int i = 0; i < 16; ++i) acc[m][r][i] = 0.0f;
 
     const int nchunks = p.cinPad / CK;
-    const int planeIn = p.Hin * p.Win;
-    const float* ximg = p.x + (size_t)n * p.Cin * planeIn;
+    const int planeIn = p.xPlane;
+    const float* ximg = p.x + (size_t)n * p.xImage;
     const unsigned rowBytes = (unsigned)p.Win * 4u;
     // descriptor of the 16 input planes of `chunk` (channels >= Cin are out of range -> 0)
     auto chunk_rsrc = [&](int chunk) -> rsrc_t {
@@ -342,19 +344,21 @@ __device__ __forceinline__ void conv_epilogue(const ConvParams& p, f32x16 (&acc)
     // (BAD_OFFSET outside the image), per-register scalar offset of the channel plane; channels
     // >= Cout fall behind num_records and are dropped by the hardware.  No per-element branches.
     const int ox = ox0 + j;
-    const size_t plane = (size_t)p.H * p.W;
-    const int outBytes = (int)((size_t)p.Cout * plane * 4);
-    const rsrc_t yrs = __builtin_amdgcn_make_buffer_rsrc(p.y + (size_t)n * p.Cout * plane, 0, outBytes, 0x00020000);
+    // y and the residual may have different channel strides: the per-lane offset is built from the pixel part
+    // and the channel part separately for each of them
+    const int outBytes = (int)((size_t)p.Cout * p.yPlane * 4);
+    const rsrc_t yrs = __builtin_amdgcn_make_buffer_rsrc(p.y + (size_t)n * p.yImage, 0, outBytes, 0x00020000);
     const rsrc_t rrs = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<float*>(p.residual ? p.residual + (size_t)n * p.Cout * plane : p.y), 0, p.residual ? outBytes : 0, 0x00020000);
+        const_cast<float*>(p.residual ? p.residual + (size_t)n * p.rImage : p.y), 0,
+        p.residual ? (int)((size_t)p.Cout * p.rPlane * 4) : 0, 0x00020000);
     float bv[MT][16];
 #pragma unroll
     for (int m = 0; m < MT; ++m)
 #pragma unroll
         for (int i = 0; i < 16; ++i)
             bv[m][i] = p.bias[min(co0 + m * 32 + (i & 3) + 8 * (i >> 2) + 4 * kh, p.Cout - 1)];
-    const int planeBytes = (int)(plane * 4);
-    if ((p.W & 3) == 0) {
+    const int planeBytes = p.yPlane * 4, rplaneBytes = p.rPlane * 4;
+    if (((p.W | p.yPlane | p.rPlane) & 3) == 0) {
         // Wide path: each wave transposes one output row (64 couts x 32 pixels) through its own 8 KB
         // of the now idle LDS, so that a lane owns 4 consecutive pixels of one channel and the
         // global traffic is dwordx4 (4x fewer store instructions; the dword epilogue is store-issue
@@ -384,7 +388,8 @@ __device__ __forceinline__ void conv_epilogue(const ConvParams& p, f32x16 (&acc)
                 float4 v = reinterpret_cast<const float4*>(tr)[q];
                 const unsigned voffs = ok ? off + (unsigned)soff : BAD_OFFSET;
                 if (p.residual) {
-                    const u32x4 rr = __builtin_amdgcn_raw_buffer_load_b128(rrs, (int)voffs, 0, 0);
+                    const unsigned roffs = ok ? off + (unsigned)((co0 + co) * rplaneBytes) : BAD_OFFSET;
+                    const u32x4 rr = __builtin_amdgcn_raw_buffer_load_b128(rrs, (int)roffs, 0, 0);
                     const float4 rf = __builtin_bit_cast(float4, rr);
                     v.x += rf.x; v.y += rf.y; v.z += rf.z; v.w += rf.w;
                 }
@@ -393,19 +398,20 @@ __device__ __forceinline__ void conv_epilogue(const ConvParams& p, f32x16 (&acc)
             __builtin_amdgcn_s_waitcnt(0xC07F);   // reads done before the next row overwrites the slab
         }
     } else {
-    const unsigned khoff = (unsigned)(4 * kh) * (unsigned)planeBytes;
+    const unsigned khoff = (unsigned)(4 * kh) * (unsigned)planeBytes, rkhoff = (unsigned)(4 * kh) * (unsigned)rplaneBytes;
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
         const int oy = oy0 + wave * 4 + r;
         const bool pix_ok = ox < p.W && oy < p.H && !(p.dbg & 2);
         const unsigned pix = pix_ok ? (unsigned)((oy * p.W + ox) * 4) + khoff : BAD_OFFSET;
+        const unsigned rpix = pix_ok ? (unsigned)((oy * p.W + ox) * 4) + rkhoff : BAD_OFFSET;
 #pragma unroll
         for (int m = 0; m < MT; ++m) {
             float rv[16];
 #pragma unroll
             for (int i = 0; i < 16; ++i) {
-                const int soff = (co0 + m * 32 + (i & 3) + 8 * (i >> 2)) * planeBytes;
-                rv[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rrs, (int)pix, soff, 0));
+                const int soff = (co0 + m * 32 + (i & 3) + 8 * (i >> 2)) * rplaneBytes;
+                rv[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rrs, (int)rpix, soff, 0));
             }
 #pragma unroll
             for (int i = 0; i < 16; ++i) {
@@ -460,10 +466,17 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv3x3_fwd2_kernel(const ConvPar
     const int bid = lid / p.cgroups;
     const int n = bid / tilesPerImage;
     const int t = bid - n * tilesPerImage;
-    const int ty = t / p.tilesX, tx = t - ty * p.tilesX;
+    int ty = t / p.tilesX, tx = t - ty * p.tilesX;
+    if (p.dbg & 16) {   // experiment: column strips of 15 tiles
+        const int S = 15, per = S * p.tilesY, strip = t / per, within = t - strip * per;
+        const int sw = min(S, p.tilesX - strip * S);
+        ty = within / sw; tx = strip * S + within - ty * sw;
+    }
     const int oy0 = ty * TH, ox0 = tx * TW;
     const int co0 = p.co0 + grp * 32;
 
+    unsigned long long st0 = 0, st1 = 0, st2 = 0;
+    if (p.dbg & 8) st0 = __builtin_amdgcn_s_memtime();
     f32x16 acc[1][4];
 #pragma unroll
     for (int r = 0; r < 4; ++r)
@@ -471,8 +484,8 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv3x3_fwd2_kernel(const ConvPar
         for (int i = 0; i < 16; ++i) acc[0][r][i] = 0.0f;
 
     const int nchunks = (p.Cin + CK2 - 1) / CK2;     // weight rows >= Cin are zero, input planes >= Cin read as 0
-    const int planeIn = p.Hin * p.Win;
-    const float* ximg = p.x + (size_t)n * p.Cin * planeIn;
+    const int planeIn = p.xPlane;
+    const float* ximg = p.x + (size_t)n * p.xImage;
     const unsigned rowBytes = (unsigned)p.Win * 4u;
     auto chunk_rsrc = [&](int chunk) -> rsrc_t {
         const int left = p.Cin - chunk * CK2;
@@ -520,6 +533,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv3x3_fwd2_kernel(const ConvPar
             if (tid + i * NTHREADS < NW42) reinterpret_cast<float4*>(wlds0)[tid + i * NTHREADS] = wv[i];
     }
     __syncthreads();
+    if (p.dbg & 8) st1 = __builtin_amdgcn_s_memtime();
 
     const int j = lane & 31;
     const int kh = lane >> 5;
@@ -535,7 +549,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv3x3_fwd2_kernel(const ConvPar
 
     for (int chunk = 0; chunk < nchunks; ++chunk) {
         const int buf = chunk & 1;
-        const bool more = chunk + 1 < nchunks;
+        const bool more = chunk + 1 < nchunks && !(p.dbg & 1);
         const float* pb = patch0 + buf * CHUNK2 + kh * PLANE + (wave * 4) * PW + j;
         const float* wb = wlds0 + buf * WCH2 + kh * 32 + j;
         float* pnext = patch0 + (buf ^ 1) * CHUNK2 + tid;
@@ -543,7 +557,8 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv3x3_fwd2_kernel(const ConvPar
         const rsrc_t rsn = chunk_rsrc(chunk + 1);
         wchunk += wchunkStep;                       // now the next chunk's weight rows (only read when `more`)
         float a0, b0[4], a1, b1[4];
-        float raw[DIST2][UPS ? 4 : 1];
+        constexpr int RING2 = UPS ? DIST2 : NEL2;
+        float raw[RING2][UPS ? 4 : 1];
         float4 wraw[NWI2];
         load_ops(a0, b0, wb, pb, 0);
         auto plan_word = [&](int q) -> unsigned {   // opaque copy: keeps hipcc from hoisting the decode of all elements
@@ -554,22 +569,43 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv3x3_fwd2_kernel(const ConvPar
         float* const plast = (tid < CHUNK2 - (NEL2 - 1) * NTHREADS) ? pnext + (NEL2 - 1) * NTHREADS : dump + tid;
         float4* const wlast = (tid < NW42 - (NWI2 - 1) * NTHREADS) ? wnext + (NWI2 - 1) * NTHREADS
                                                                    : reinterpret_cast<float4*>(dump) + tid;
-        // slot s = k-step s of the chunk: park item s - DIST2, then issue item s (items: 20 patch
-        // elements, then 3 weight float4).  No branches around the memory operations (see above).
-        auto slot = [&](int s) {
-            const int qp = s - DIST2;
-            if (qp >= 0 && qp < NITEMS2) {
-                if (qp < NEL2) {
-                    const float v = finish_element<UPS>(plan_word(qp), raw[qp % DIST2]);
-                    if (qp < NEL2 - 1) pnext[qp * NTHREADS] = v; else *plast = v;
-                } else {
-                    const int i = qp - NEL2;
-                    if (i < NWI2 - 1) wnext[i * NTHREADS] = wraw[i]; else *wlast = wraw[i];
-                }
+        // slot s = k-step s of the chunk.  Items: 20 patch elements, then 3 weight float4.
+        // UPS (4 loads per element): park item s - DIST2, then issue item s -- 13 elements in flight.
+        // Plain: everything is issued two per slot in slots 0..11 and parked two per slot in slots
+        // 24..35, i.e. every load has 24 k-steps (>= 6000 cycles) to come back from HBM; the 1080p
+        // layers lost ~10 % to s_waitcnt vmcnt stalls with a 13-slot distance.
+        // No branches around the memory operations (see above).
+        auto park_item = [&](int qp, int ring) {
+            if (qp < NEL2) {
+                const float v = finish_element<UPS>(plan_word(qp), raw[ring]);
+                if (qp < NEL2 - 1) pnext[qp * NTHREADS] = v; else *plast = v;
+            } else {
+                const int i = qp - NEL2;
+                if (i < NWI2 - 1) wnext[i * NTHREADS] = wraw[i]; else *wlast = wraw[i];
             }
-            if (s < NITEMS2) {
-                if (s < NEL2) issue_element<UPS>(rsn, plan_word(s), rowBytes, raw[s % DIST2]);
-                else wraw[s - NEL2] = weight_item(wchunk, s - NEL2);
+        };
+        auto issue_item = [&](int q, int ring) {
+            if (q < NEL2) issue_element<UPS>(rsn, plan_word(q), rowBytes, raw[ring]);
+            else wraw[q - NEL2] = weight_item(wchunk, q - NEL2);
+        };
+        auto slot = [&](int s) {
+            if (UPS) {
+                const int qp = s - DIST2;
+                if (qp >= 0 && qp < NITEMS2) park_item(qp, qp % RING2);
+                if (s < NITEMS2) issue_item(s, s % RING2);
+            } else {
+                constexpr int PARK0 = NSLOTS2 - (NITEMS2 + 1) / 2;     // 24
+                static_assert(PARK0 >= (NITEMS2 + 1) / 2, "issue phase must end before the park phase starts");
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    const int qp = (s - PARK0) * 2 + h;
+                    if (s >= PARK0 && qp < NITEMS2) park_item(qp, qp);
+                }
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    const int q = s * 2 + h;
+                    if (q < NITEMS2) issue_item(q, q);
+                }
             }
         };
         auto run_taps = [&](auto MORE) {
@@ -601,7 +637,14 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv3x3_fwd2_kernel(const ConvPar
         if (more) run_taps(std::true_type{}); else run_taps(std::false_type{});
         __syncthreads();
     }
+    if (p.dbg & 8) st2 = __builtin_amdgcn_s_memtime();
     conv_epilogue<1>(p, acc, smem, n, oy0, ox0, co0, wave, lane);
+    if ((p.dbg & 8) && tid == 0 && p.stamps) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const unsigned long long st3 = __builtin_amdgcn_s_memtime();
+        unsigned long long* o = p.stamps + (size_t)blockIdx.x * 4;
+        o[0] = st0; o[1] = st1; o[2] = st2; o[3] = st3;
+    }
 }
 
 template <int MT>
@@ -841,13 +884,32 @@ int isrConvPrepareWeights(const float* w, float* wprep, int Cout, int Cin, int t
 int isrConv3x3Forward(const float* x, const float* wprep, const float* bias, const float* residual, float* y,
                       int N, int Cin, int H, int W, int Cout, int act, float slope, int upsample2x, void* stream)
 {
+    if (N <= 0 || Cin <= 0 || Cout <= 0 || H <= 0 || W <= 0) return -1;
+    const long long xp = upsample2x ? (long long)(H / 2) * (W / 2) : (long long)H * W, yp = (long long)H * W;
+    return isrConv3x3ForwardStrided(x, wprep, bias, residual, y, N, Cin, H, W, Cout, act, slope, upsample2x,
+                                    xp, xp * Cin, yp, yp * Cout, yp, yp * Cout, stream);
+}
+
+int isrConv3x3ForwardStrided(const float* x, const float* wprep, const float* bias, const float* residual, float* y,
+                             int N, int Cin, int H, int W, int Cout, int act, float slope, int upsample2x,
+                             long long xPlane, long long xImage, long long yPlane, long long yImage,
+                             long long rPlane, long long rImage, void* stream)
+{
     if (!x || !wprep || !y || N <= 0 || Cin <= 0 || Cout <= 0 || H <= 0 || W <= 0) return -1;
     if (upsample2x && ((H & 1) || (W & 1))) return -1;
     if (act < ISR_ACT_NONE || act > ISR_ACT_LEAKY) return -1;
+    {
+        const long long rowsIn = (long long)(upsample2x ? H / 2 : H) * (upsample2x ? W / 2 : W);
+        if (xPlane < rowsIn || yPlane < (long long)H * W || (residual && rPlane < (long long)H * W)) return -1;
+        // buffer descriptors address one image with 32-bit byte offsets
+        if (xPlane * Cin * 4 > 0x7fffffffLL || yPlane * Cout * 4 > 0x7fffffffLL || (residual && rPlane * Cout * 4 > 0x7fffffffLL)) return -1;
+    }
     ConvParams p;
     p.x = x; p.w = wprep; p.bias = bias; p.residual = residual; p.y = y;
     p.N = N; p.Cin = Cin; p.H = H; p.W = W; p.Cout = Cout;
     p.Hin = upsample2x ? H / 2 : H; p.Win = upsample2x ? W / 2 : W;
+    p.xPlane = (int)xPlane; p.yPlane = (int)yPlane; p.rPlane = (int)(residual ? rPlane : yPlane);
+    p.xImage = xImage; p.yImage = yImage; p.rImage = rImage;
     p.cinPad = isrConvCinPad(Cin); p.coutPad = isrConvCoutPad(Cout);
     p.tilesX = (W + TW - 1) / TW; p.tilesY = (H + TH - 1) / TH;
     p.act = act; p.slope = slope;
@@ -983,6 +1045,7 @@ struct SmallConvParams {
     int N, Cin, H, W, Cout;
     int tilesX, tilesY;
     int act; float slope;
+    long long xPlane, xImage;                  // channel / batch strides of x in floats (y and residual are packed)
 };
 
 __global__ __launch_bounds__(256, 2) void conv3x3_small_cout_kernel(const SmallConvParams p)
@@ -997,8 +1060,8 @@ __global__ __launch_bounds__(256, 2) void conv3x3_small_cout_kernel(const SmallC
     const int oy0 = ty * SC_TH, ox0 = tx * SC_TW;
     const int ly = tid >> 4, lx4 = (tid & 15) * 4;          // this thread: row ly, pixels lx4..lx4+3
 
-    const size_t planeIn = (size_t)p.H * p.W;
-    const float* ximg = p.x + (size_t)n * p.Cin * planeIn;
+    const size_t planeIn = (size_t)p.xPlane;
+    const float* ximg = p.x + (size_t)n * p.xImage;
     const int nstages = (p.Cin + SC_CK - 1) / SC_CK;
 
     // staging: 66 x 18 positions x 8 channels = 9504 elements / 256 threads -> 38 slots per thread,
@@ -1014,7 +1077,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_small_cout_kernel(const SmallC
         const int r = rem / 66, col = rem - r * 66;
         const int gy = oy0 + r - 1, gx = ox0 + col - 1;
         const bool ok = e < SC_CK * SC_PH * 66 && (unsigned)gy < (unsigned)p.H && (unsigned)gx < (unsigned)p.W;
-        plan[i] = ok ? (unsigned)(((c * p.H + gy) * p.W + gx) * 4) : BAD_OFFSET;
+        plan[i] = ok ? (unsigned)((c * (int)p.xPlane + gy * p.W + gx) * 4) : BAD_OFFSET;
     }
     auto stage_rsrc = [&](int stage) -> rsrc_t {
         const int left = p.Cin - stage * SC_CK;
@@ -1146,13 +1209,22 @@ int isrConvSmallPrepare(const float* w, const float* bias, float* w8, float* bia
 int isrConv3x3SmallCout(const float* x, const float* w8, const float* bias8, const float* residual, float* y,
                         int N, int Cin, int H, int W, int Cout, int act, float slope, void* stream)
 {
+    return isrConv3x3SmallCoutStrided(x, w8, bias8, residual, y, N, Cin, H, W, Cout, act, slope,
+                                      (long long)H * W, (long long)Cin * H * W, stream);
+}
+
+int isrConv3x3SmallCoutStrided(const float* x, const float* w8, const float* bias8, const float* residual, float* y,
+                               int N, int Cin, int H, int W, int Cout, int act, float slope,
+                               long long xPlane, long long xImage, void* stream)
+{
     if (!x || !w8 || !bias8 || !y || N <= 0 || Cin <= 0 || Cout <= 0 || Cout > 8 || H <= 0 || W <= 0) return -1;
-    if ((long long)Cin * H * W * 4 >= (1LL << 31)) return -1;
+    if (xPlane < (long long)H * W || (long long)Cin * xPlane * 4 >= (1LL << 31)) return -1;
     SmallConvParams p;
     p.x = x; p.w8 = w8; p.bias8 = bias8; p.residual = residual; p.y = y;
     p.N = N; p.Cin = Cin; p.H = H; p.W = W; p.Cout = Cout;
     p.tilesX = (W + SC_TW - 1) / SC_TW; p.tilesY = (H + SC_TH - 1) / SC_TH;
     p.act = act; p.slope = slope;
+    p.xPlane = xPlane; p.xImage = xImage;
     const long long nwg = (long long)N * p.tilesX * p.tilesY;
     if (nwg > 0x7fffffffLL) return -1;
     hipEvent_t e0 = nullptr, e1 = nullptr;

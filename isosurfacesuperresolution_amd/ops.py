@@ -33,6 +33,8 @@ def _sr():
         lib.isrConvPrepareWeights.argtypes = [vp, vp, ci, ci, ci, vp]; lib.isrConvPrepareWeights.restype = ci
         lib.isrConv3x3Forward.argtypes = [vp, vp, vp, vp, vp, ci, ci, ci, ci, ci, ci, cf, ci, vp]
         lib.isrConv3x3Forward.restype = ci
+        lib.isrConv3x3ForwardStrided.argtypes = [vp, vp, vp, vp, vp, ci, ci, ci, ci, ci, ci, cf, ci, ll, ll, ll, ll, ll, ll, vp]
+        lib.isrConv3x3ForwardStrided.restype = ci
         lib.isrConvWeightGradWorkspace.argtypes = [ci, ci, ci, ci, ci]; lib.isrConvWeightGradWorkspace.restype = ll
         lib.isrConv3x3WeightGrad.argtypes = [vp, vp, vp, vp, vp, ci, ci, ci, ci, ci, vp]; lib.isrConv3x3WeightGrad.restype = ci
         lib.isrActBackward.argtypes = [vp, vp, vp, ll, ci, cf, vp]; lib.isrActBackward.restype = ci
@@ -40,6 +42,8 @@ def _sr():
         lib.isrConvSmallCinPad.argtypes = [ci]; lib.isrConvSmallCinPad.restype = ci
         lib.isrConvSmallPrepare.argtypes = [vp, vp, vp, vp, ci, ci, vp]; lib.isrConvSmallPrepare.restype = ci
         lib.isrConv3x3SmallCout.argtypes = [vp, vp, vp, vp, vp, ci, ci, ci, ci, ci, ci, cf, vp]; lib.isrConv3x3SmallCout.restype = ci
+        lib.isrConv3x3SmallCoutStrided.argtypes = [vp, vp, vp, vp, vp, ci, ci, ci, ci, ci, ci, cf, ll, ll, vp]
+        lib.isrConv3x3SmallCoutStrided.restype = ci
         lib.isrFlowFillWorkspace.argtypes = [ci, ci]; lib.isrFlowFillWorkspace.restype = ll
         lib.isrFlowFill.argtypes = [vp, vp, vp, ci, ci, vp]; lib.isrFlowFill.restype = ci
         lib.isrFinishFrame.argtypes = [vp, vp, vp, vp, ci, ci, vp, ci, cf, ci, ci, vp]; lib.isrFinishFrame.restype = ci
@@ -145,23 +149,61 @@ def _launch_small(x, weight, bias, residual, act, slope):
     n, cin, h, w = x.shape
     cout = weight.shape[0]
     w8, b8 = _prepare_small(weight, bias)
+    x, xp, xi = _plane_strides(x)
     y = torch.empty((n, cout, h, w), dtype=torch.float32, device=x.device)
-    rc = lib.isrConv3x3SmallCout(_ptr(x), _ptr(w8), _ptr(b8), _ptr(residual), _ptr(y), n, cin, h, w, cout,
-                                 ACT_CODES[act], float(slope), _stream())
+    rc = lib.isrConv3x3SmallCoutStrided(_ptr(x), _ptr(w8), _ptr(b8), _ptr(residual), _ptr(y), n, cin, h, w, cout,
+                                        ACT_CODES[act], float(slope), xp, xi, _stream())
     if rc != 0:
         raise RuntimeError("isrConv3x3SmallCout failed (%d)" % rc)
     return y
+
+
+# Channel-plane padding of large activations.  A [64][1080][1920] fp32 tensor has planes of exactly
+# 2025 x 4 KiB; when the 1080p conv reads 64 such planes and writes 64 more (same rows of every plane at the
+# same time) the accesses alias in the memory system and the layer drops from 125 to 105 TFLOP/s
+# (tools/bench_conv_pad.py: any padding >= 16 floats on BOTH tensors cures it, padding one of them does not).
+# Activations the conv kernels allocate themselves therefore get one extra row between channel planes once a
+# plane reaches PLANE_PAD_MIN_BYTES; every consumer in this package takes the strides from the tensor
+# (`_plane_strides`), anything else sees an ordinary strided view.
+PLANE_PAD_MIN_BYTES = 4 << 20
+PLANE_PAD_ROWS = 1
+
+
+def plane_pad(h, w):
+    return PLANE_PAD_ROWS * ((w + 3) // 4) * 4 if h * w * 4 >= PLANE_PAD_MIN_BYTES else 0
+
+
+def empty_planes(n, c, h, w, device):
+    """[n, c, h, w] fp32 tensor with packed rows and (possibly) padded channel planes."""
+    plane = h * w + plane_pad(h, w)
+    if plane == h * w:
+        return torch.empty((n, c, h, w), dtype=torch.float32, device=device)
+    return torch.empty(n * c * plane, dtype=torch.float32, device=device).as_strided((n, c, h, w), (c * plane, plane, w, 1))
+
+
+def _plane_strides(t):
+    """(tensor, plane stride, image stride) with packed rows; copies only if the rows are not packed."""
+    n, c, h, w = t.shape
+    if t.stride(3) == 1 and t.stride(2) == w and t.stride(1) >= h * w and (n == 1 or t.stride(0) >= c * t.stride(1)):
+        return t, t.stride(1), t.stride(0) if n > 1 else c * t.stride(1)
+    t = t.contiguous()
+    return t, h * w, c * h * w
 
 
 def _launch_forward(x, wprep, bias, residual, cin, cout, act, slope, upsample2x):
     lib = _sr()
     n, _, hin, win = x.shape
     h, w = (hin * 2, win * 2) if upsample2x else (hin, win)
-    y = torch.empty((n, cout, h, w), dtype=torch.float32, device=x.device)
-    rc = lib.isrConv3x3Forward(_ptr(x), _ptr(wprep), _ptr(bias), _ptr(residual), _ptr(y),
-                               n, cin, h, w, cout, ACT_CODES[act], float(slope), 1 if upsample2x else 0, _stream())
+    x, xp, xi = _plane_strides(x)
+    rp = ri = 0
+    if residual is not None:
+        residual, rp, ri = _plane_strides(residual)
+    y = empty_planes(n, cout, h, w, x.device)
+    rc = lib.isrConv3x3ForwardStrided(_ptr(x), _ptr(wprep), _ptr(bias), _ptr(residual), _ptr(y),
+                                      n, cin, h, w, cout, ACT_CODES[act], float(slope), 1 if upsample2x else 0,
+                                      xp, xi, y.stride(1), cout * y.stride(1), rp, ri, _stream())
     if rc != 0:
-        raise RuntimeError("isrConv3x3Forward failed (%d)" % rc)
+        raise RuntimeError("isrConv3x3ForwardStrided failed (%d)" % rc)
     return y
 
 
@@ -246,10 +288,10 @@ def conv3x3(x, weight, bias=None, act='none', slope=0.01, residual=None, upsampl
     if not needs_grad:
         cout, cin = weight.shape[0], weight.shape[1]
         if cout <= 8 and not upsample2x and cin * x.shape[2] * x.shape[3] * 4 < 2 ** 31:
-            return _launch_small(x.contiguous(), weight, bias, residual.contiguous() if residual is not None else None, act, slope)
-        return _launch_forward(x.contiguous(), prepare_weights(weight),
+            return _launch_small(x, weight, bias, residual.contiguous() if residual is not None else None, act, slope)
+        return _launch_forward(x, prepare_weights(weight),
                                bias.contiguous() if bias is not None else None,
-                               residual.contiguous() if residual is not None else None,
+                               residual,
                                cin, cout, act, slope, upsample2x)
     if upsample2x:   # training: keep the resize as its own differentiable op
         x = F.interpolate(x, scale_factor=2, mode='bilinear', align_corners=False)
