@@ -429,33 +429,47 @@ __device__ __forceinline__ void conv_epilogue(const ConvParams& p, f32x16 (&acc)
 
 // ---- forward, two workgroups per CU ------------------------------------------------------------
 // Same implicit GEMM, re-budgeted so that TWO workgroups share a CU: one M tile (32 output channels)
-// per workgroup and 8-channel chunks -> 61 KB of LDS and < 256 registers per wave.  The point is not
+// per workgroup and 8-channel chunks -> 66 KB of LDS and < 256 registers per wave.  The point is not
 // the MFMA loop (it is the same 8 x 32x32x2 per k-step pair) but everything around it: with one
 // workgroup per CU the prologue (first chunk from HBM), the per-chunk barriers and the epilogue
 // (bias/act/residual/store) leave the matrix pipe idle ~15 % of a workgroup's life; with two, the
 // other workgroup's waves issue MFMAs in those holes.  The price is that a tile's input patch is staged
 // once per 32-channel group (both groups of a tile are adjacent workgroups on one XCD, so the second
 // read is an L2 hit).
+//
+// x2-upsampling loader: the 18x34 hi-res patch is 9x17 "quads" of 2x2 pixels (rows 2a-1, 2a; columns
+// 2b-1, 2b relative to the tile) that interpolate the SAME four source texels (bilinear,
+// align_corners=False: odd pixels weigh the pair .75/.25, even pixels .25/.75; clamping the source
+// coordinates to the image reproduces the border rule).  One thread does a whole quad: 4 loads and 16
+// FMAs for 4 patch elements instead of 16 loads and 28 FMAs, two ds_write_b64.
 constexpr int CK2 = 8;
 constexpr int CHUNK2 = CK2 * PLANE;                                  // 4896 floats
 constexpr int NEL2 = (CHUNK2 + NTHREADS - 1) / NTHREADS;             // 20 patch elements per thread and chunk
+constexpr int QUADS2 = 9 * 17;                                       // per channel
+constexpr int NQ2 = QUADS2 * CK2;                                    // 1224 quads per chunk
+constexpr int NQT2 = (NQ2 + NTHREADS - 1) / NTHREADS;                // 5 per thread
 constexpr int WCH2 = 9 * CK2 * 32;                                   // 2304 weight floats per chunk
 constexpr int NW42 = WCH2 / 4;                                       // 576 float4
 constexpr int NWI2 = (NW42 + NTHREADS - 1) / NTHREADS;               // 3 per thread
-constexpr int NITEMS2 = NEL2 + NWI2;                                 // 23 staging items per thread and chunk
 constexpr int KSTEPS2 = CK2 / 2;                                     // 4 k-steps per tap
 constexpr int NSLOTS2 = 9 * KSTEPS2;                                 // 36 k-steps per chunk = staging slots
-constexpr int DIST2 = 13;                                            // slots between issue and park
-static_assert(NITEMS2 + DIST2 <= NSLOTS2, "every item must be parked inside its chunk");
-constexpr size_t conv_fwd2_lds_bytes() { return (size_t)(2 * CHUNK2 + 2 * WCH2 + 4 * NTHREADS) * sizeof(float); }
+constexpr int DUMP2 = 4 * NTHREADS;                                  // write-only sink behind each patch buffer
+constexpr int PSTRIDE2 = CHUNK2 + DUMP2;                             // patch buffer + its sink
+// LDS: [2][WCH2] weights, then 2 x ([CHUNK2] patch, [DUMP2] sink): a masked-off staging lane keeps its
+// offset and lands in the sink of whichever buffer is being filled.
+constexpr size_t conv_fwd2_lds_bytes() { return (size_t)(2 * WCH2 + 2 * PSTRIDE2) * sizeof(float); }
+
+constexpr unsigned Q_DX = 1u, Q_DY = 2u, Q_VX0 = 4u, Q_VX1 = 8u, Q_VY0 = 16u, Q_VY1 = 32u;   // aux bits; LDS float offset << 8
 
 template <bool UPS>
 __global__ __launch_bounds__(NTHREADS, 2) void conv3x3_fwd2_kernel(const ConvParams p)
 {
+    constexpr int NEL = UPS ? NQT2 : NEL2;      // patch staging items per thread and chunk
+    constexpr int NLD = UPS ? 4 : 1;            // loads per item
+    constexpr int NITEMS = NEL + NWI2;
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    float* patch0 = smem;                       // [2][CHUNK2]
-    float* wlds0 = smem + 2 * CHUNK2;           // [2][9][CK2][32]
-    float* dump = wlds0 + 2 * WCH2;             // [4*NTHREADS] sink for masked-off staging lanes
+    float* wlds0 = smem;                        // [2][9][CK2][32]
+    float* patch0 = smem + 2 * WCH2;            // 2 x (patch, sink)
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -466,12 +480,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv3x3_fwd2_kernel(const ConvPar
     const int bid = lid / p.cgroups;
     const int n = bid / tilesPerImage;
     const int t = bid - n * tilesPerImage;
-    int ty = t / p.tilesX, tx = t - ty * p.tilesX;
-    if (p.dbg & 16) {   // experiment: column strips of 15 tiles
-        const int S = 15, per = S * p.tilesY, strip = t / per, within = t - strip * per;
-        const int sw = min(S, p.tilesX - strip * S);
-        ty = within / sw; tx = strip * S + within - ty * sw;
-    }
+    const int ty = t / p.tilesX, tx = t - ty * p.tilesX;
     const int oy0 = ty * TH, ox0 = tx * TW;
     const int co0 = p.co0 + grp * 32;
 
@@ -493,9 +502,38 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv3x3_fwd2_kernel(const ConvPar
                                                  left > 0 ? left * planeIn * 4 : 0, 0x00020000);
     };
 
-    unsigned plan[NEL2];
+    // Staging plan, one or two words per item, chunk invariant.
+    //  plain: plan = byte offset of the element in the chunk's planes (PLAN_BAD outside the image);
+    //         item i is patch element tid + 256 i and goes to that float of the patch buffer.
+    //  UPS:   plan = byte offset of the quad's top-left source texel (clamped into the image),
+    //         aux  = Q_* flags | (float offset of the quad's first element in the patch buffer) << 8.
+    unsigned plan[NEL], aux[UPS ? NEL : 1];
+    if (UPS) {
+        const int m0 = (oy0 >> 1) - 1, q0 = (ox0 >> 1) - 1;
 #pragma unroll
-    for (int i = 0; i < NEL2; ++i) plan[i] = plan_element<UPS, CHUNK2>(p, tid + i * NTHREADS, oy0, ox0);
+        for (int i = 0; i < NEL; ++i) {
+            const int qi = tid + i * NTHREADS;
+            const int c = qi / QUADS2, rem = qi - c * QUADS2;
+            const int a = rem / 17, b = rem - a * 17;
+            const int m = m0 + a, q = q0 + b;                          // source row / column of the top-left texel
+            const int r0 = min(max(m, 0), p.Hin - 1), r1 = min(max(m + 1, 0), p.Hin - 1);
+            const int c0 = min(max(q, 0), p.Win - 1), c1 = min(max(q + 1, 0), p.Win - 1);
+            const int gy = oy0 - 1 + 2 * a, gx = ox0 - 1 + 2 * b;      // hi-res coordinates of the quad's first pixel
+            unsigned f = 0;
+            if (c1 != c0) f |= Q_DX;
+            if (r1 != r0) f |= Q_DY;
+            if ((unsigned)gx < (unsigned)p.W) f |= Q_VX0;
+            if ((unsigned)(gx + 1) < (unsigned)p.W) f |= Q_VX1;
+            if ((unsigned)gy < (unsigned)p.H) f |= Q_VY0;
+            if ((unsigned)(gy + 1) < (unsigned)p.H) f |= Q_VY1;
+            const bool exists = qi < NQ2;
+            plan[i] = exists ? (unsigned)((c * p.xPlane + r0 * p.Win + c0) * 4) : PLAN_BAD;
+            aux[i] = f | (unsigned)(exists ? c * PLANE + (2 * a) * PW + 2 * b : CHUNK2 + 2 * tid) << 8;
+        }
+    } else {
+#pragma unroll
+        for (int i = 0; i < NEL; ++i) plan[i] = plan_element<false, CHUNK2>(p, tid + i * NTHREADS, oy0, ox0);
+    }
     // weights: float4 f = tid + 256 i of the chunk's [9][CK2][32] block; f = tap*64 + k*8 + c4
     unsigned woff[NWI2];
 #pragma unroll
@@ -508,25 +546,46 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv3x3_fwd2_kernel(const ConvPar
     const size_t wchunkStep = (size_t)CK2 * p.coutPad;
     auto weight_item = [&](const float* base, int i) -> float4 { return *reinterpret_cast<const float4*>(base + woff[i]); };
 
+    auto issue_patch = [&](rsrc_t rs, unsigned w, unsigned a, float (&raw)[NLD]) {
+        if (UPS) {
+            const unsigned dx = (a & Q_DX) ? 4u : 0u, dy = (a & Q_DY) ? rowBytes : 0u;
+            raw[0] = buf_load(rs, w); raw[UPS ? 1 : 0] = buf_load(rs, w + dx);
+            raw[UPS ? 2 : 0] = buf_load(rs, w + dy); raw[UPS ? 3 : 0] = buf_load(rs, w + dy + dx);
+        } else {
+            raw[0] = buf_load(rs, w);
+        }
+    };
+    // UPS: the four pixels of a quad from its four texels, zeroed outside the image (the conv's padding)
+    auto park_quad = [&](float* pbuf, unsigned a, const float (&raw)[NLD]) {
+        const float t00 = raw[0], t01 = raw[UPS ? 1 : 0], t10 = raw[UPS ? 2 : 0], t11 = raw[UPS ? 3 : 0];
+        const float top0 = __builtin_fmaf(0.25f, t01, 0.75f * t00), top1 = __builtin_fmaf(0.75f, t01, 0.25f * t00);
+        const float bot0 = __builtin_fmaf(0.25f, t11, 0.75f * t10), bot1 = __builtin_fmaf(0.75f, t11, 0.25f * t10);
+        float v00 = __builtin_fmaf(0.25f, bot0, 0.75f * top0), v01 = __builtin_fmaf(0.25f, bot1, 0.75f * top1);
+        float v10 = __builtin_fmaf(0.75f, bot0, 0.25f * top0), v11 = __builtin_fmaf(0.75f, bot1, 0.25f * top1);
+        const int ia = (int)a;
+        const unsigned mx0 = (unsigned)__builtin_amdgcn_sbfe(ia, 2, 1), mx1 = (unsigned)__builtin_amdgcn_sbfe(ia, 3, 1);
+        const unsigned my0 = (unsigned)__builtin_amdgcn_sbfe(ia, 4, 1), my1 = (unsigned)__builtin_amdgcn_sbfe(ia, 5, 1);
+        auto masked = [](float v, unsigned m) { return __builtin_bit_cast(float, __builtin_bit_cast(unsigned, v) & m); };
+        v00 = masked(v00, mx0 & my0); v01 = masked(v01, mx1 & my0);
+        v10 = masked(v10, mx0 & my1); v11 = masked(v11, mx1 & my1);
+        float* d = pbuf + (a >> 8);
+        *reinterpret_cast<float2*>(d) = make_float2(v00, v01);
+        *reinterpret_cast<float2*>(d + PW) = make_float2(v10, v11);
+    };
+
     // prologue: chunk 0 in full
     {
         const rsrc_t rs = chunk_rsrc(0);
-        constexpr int NB = UPS ? 2 : 1;
-        constexpr int PB = NEL2 / NB;
-        static_assert(PB * NB == NEL2, "prologue batching");
         float4 wv[NWI2];
 #pragma unroll
         for (int i = 0; i < NWI2; ++i) wv[i] = weight_item(wchunk, i);
+        float raw[NEL][NLD];
 #pragma unroll
-        for (int b = 0; b < NB; ++b) {
-            float raw[PB][UPS ? 4 : 1];
+        for (int i = 0; i < NEL; ++i) issue_patch(rs, plan[i], UPS ? aux[UPS ? i : 0] : 0u, raw[i]);
 #pragma unroll
-            for (int i = 0; i < PB; ++i) issue_element<UPS>(rs, plan[b * PB + i], rowBytes, raw[i]);
-#pragma unroll
-            for (int i = 0; i < PB; ++i) {
-                const int e = tid + (b * PB + i) * NTHREADS;
-                if (e < CHUNK2) patch0[e] = finish_element<UPS>(plan[b * PB + i], raw[i]);
-            }
+        for (int i = 0; i < NEL; ++i) {
+            if (UPS) park_quad(patch0, aux[UPS ? i : 0], raw[i]);
+            else if (tid + i * NTHREADS < CHUNK2) patch0[tid + i * NTHREADS] = raw[i][0];
         }
 #pragma unroll
         for (int i = 0; i < NWI2; ++i)
@@ -550,64 +609,66 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv3x3_fwd2_kernel(const ConvPar
     for (int chunk = 0; chunk < nchunks; ++chunk) {
         const int buf = chunk & 1;
         const bool more = chunk + 1 < nchunks && !(p.dbg & 1);
-        const float* pb = patch0 + buf * CHUNK2 + kh * PLANE + (wave * 4) * PW + j;
+        const float* pb = patch0 + buf * PSTRIDE2 + kh * PLANE + (wave * 4) * PW + j;
         const float* wb = wlds0 + buf * WCH2 + kh * 32 + j;
-        float* pnext = patch0 + (buf ^ 1) * CHUNK2 + tid;
-        float4* wnext = reinterpret_cast<float4*>(wlds0 + (buf ^ 1) * WCH2) + tid;
+        float* const pfill = patch0 + (buf ^ 1) * PSTRIDE2;          // buffer being filled (+ its sink)
+        float* const pnext = pfill + tid;
+        float4* const wnext = reinterpret_cast<float4*>(wlds0 + (buf ^ 1) * WCH2) + tid;
         const rsrc_t rsn = chunk_rsrc(chunk + 1);
         wchunk += wchunkStep;                       // now the next chunk's weight rows (only read when `more`)
         float a0, b0[4], a1, b1[4];
-        constexpr int RING2 = UPS ? DIST2 : NEL2;
-        float raw[RING2][UPS ? 4 : 1];
+        float raw[NEL][NLD];
         float4 wraw[NWI2];
         load_ops(a0, b0, wb, pb, 0);
-        auto plan_word = [&](int q) -> unsigned {   // opaque copy: keeps hipcc from hoisting the decode of all elements
-            unsigned w = plan[q];
+        auto opaque = [&](unsigned w) -> unsigned {   // keeps hipcc from hoisting the decode of every item out of the loop
             asm volatile("" : "+v"(w));
             return w;
         };
-        float* const plast = (tid < CHUNK2 - (NEL2 - 1) * NTHREADS) ? pnext + (NEL2 - 1) * NTHREADS : dump + tid;
+        float* const plast = (tid < CHUNK2 - (NEL2 - 1) * NTHREADS) ? pnext + (NEL2 - 1) * NTHREADS : pfill + CHUNK2 + tid;
         float4* const wlast = (tid < NW42 - (NWI2 - 1) * NTHREADS) ? wnext + (NWI2 - 1) * NTHREADS
-                                                                   : reinterpret_cast<float4*>(dump) + tid;
-        // slot s = k-step s of the chunk.  Items: 20 patch elements, then 3 weight float4.
-        // UPS (4 loads per element): park item s - DIST2, then issue item s -- 13 elements in flight.
-        // Plain: everything is issued two per slot in slots 0..11 and parked two per slot in slots
-        // 24..35, i.e. every load has 24 k-steps (>= 6000 cycles) to come back from HBM; the 1080p
-        // layers lost ~10 % to s_waitcnt vmcnt stalls with a 13-slot distance.
-        // No branches around the memory operations (see above).
-        auto park_item = [&](int qp, int ring) {
-            if (qp < NEL2) {
-                const float v = finish_element<UPS>(plan_word(qp), raw[ring]);
-                if (qp < NEL2 - 1) pnext[qp * NTHREADS] = v; else *plast = v;
+                                                                   : reinterpret_cast<float4*>(pfill + CHUNK2) + tid;
+        // Staging of the next chunk rides in the MFMA slots (slot s = k-step s of the chunk, 36 per
+        // chunk), all loads early and all LDS writes late so that every load has >= 20 k-steps
+        // (>= 5000 cycles) to come back.  No branches around the memory operations: a branch makes
+        // hipcc's waitcnt pass fall back to vmcnt(0).
+        //   plain: items issued two per slot in slots 0..11, parked two per slot in slots 24..35
+        //   UPS:   quad i issued in slot 2i, weights in slots 10..12; quad i parked in slot 20+3i, weights 33..35
+        auto park_item = [&](int q) {
+            if (q < NEL) {
+                if (UPS) park_quad(pfill, opaque(aux[UPS ? q : 0]), raw[q]);
+                else if (q < NEL - 1) pnext[q * NTHREADS] = raw[q][0];
+                else *plast = raw[q][0];
             } else {
-                const int i = qp - NEL2;
+                const int i = q - NEL;
                 if (i < NWI2 - 1) wnext[i * NTHREADS] = wraw[i]; else *wlast = wraw[i];
             }
         };
-        auto issue_item = [&](int q, int ring) {
-            if (q < NEL2) issue_element<UPS>(rsn, plan_word(q), rowBytes, raw[ring]);
-            else wraw[q - NEL2] = weight_item(wchunk, q - NEL2);
+        auto issue_item = [&](int q) {
+            if (q < NEL) issue_patch(rsn, opaque(plan[q]), UPS ? opaque(aux[UPS ? q : 0]) : 0u, raw[q]);
+            else wraw[q - NEL] = weight_item(wchunk, q - NEL);
         };
         auto slot = [&](int s) {
             if (UPS) {
-                const int qp = s - DIST2;
-                if (qp >= 0 && qp < NITEMS2) park_item(qp, qp % RING2);
-                if (s < NITEMS2) issue_item(s, s % RING2);
+                if (s >= 20 && s < 20 + 3 * NEL && (s - 20) % 3 == 0) park_item((s - 20) / 3);
+                if (s >= NSLOTS2 - NWI2) park_item(NEL + s - (NSLOTS2 - NWI2));
+                if (s < 2 * NEL && s % 2 == 0) issue_item(s / 2);
+                if (s >= 2 * NEL && s < 2 * NEL + NWI2) issue_item(NEL + s - 2 * NEL);
             } else {
-                constexpr int PARK0 = NSLOTS2 - (NITEMS2 + 1) / 2;     // 24
-                static_assert(PARK0 >= (NITEMS2 + 1) / 2, "issue phase must end before the park phase starts");
+                constexpr int PARK0 = NSLOTS2 - (NITEMS + 1) / 2;     // 24
+                static_assert(UPS || PARK0 >= (NITEMS + 1) / 2, "issue phase must end before the park phase starts");
 #pragma unroll
                 for (int h = 0; h < 2; ++h) {
                     const int qp = (s - PARK0) * 2 + h;
-                    if (s >= PARK0 && qp < NITEMS2) park_item(qp, qp);
+                    if (s >= PARK0 && qp < NITEMS) park_item(qp);
                 }
 #pragma unroll
                 for (int h = 0; h < 2; ++h) {
                     const int q = s * 2 + h;
-                    if (q < NITEMS2) issue_item(q, q);
+                    if (q < NITEMS) issue_item(q);
                 }
             }
         };
+        static_assert(20 + 3 * (NQT2 - 1) < NSLOTS2 - NWI2 && 2 * NQT2 + NWI2 <= 20, "UPS staging schedule");
         auto run_taps = [&](auto MORE) {
 #pragma unroll
         for (int tap = 0; tap < 9; ++tap) {
