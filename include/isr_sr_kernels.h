@@ -50,10 +50,13 @@ int isrConv3x3ForwardStrided(const float* x, const float* wprep, const float* bi
                              long long xPlane, long long xImage, long long yPlane, long long yImage,
                              long long rPlane, long long rImage, void* stream);
 
-/* The same fused convolution for Cout <= 8 (EnhanceNet's final 64 -> 6 layer, enhancenet.py:124) on the
- * vector ALU instead of the 32-row MFMA tile.  isrConvSmallPrepare re-lays w[Cout][Cin][3][3] into
- * w8[9][isrConvSmallCinPad(Cin)][8] and bias into bias8[8] (zero padded); no upsampling variant. */
+/* The same fused convolution for Cout <= 8 (EnhanceNet's final 64 -> 6 layer, enhancenet.py:124) on
+ * 4x4x1 MFMA blocks (4 channels x 64 pixels per instruction) instead of the 32-row MFMA tile.
+ * isrConvSmallPrepare re-lays w[Cout][Cin][3][3] into w8 (isrConvSmallWeightFloats(Cin) floats, a layout
+ * private to the kernel) and bias into bias8[8] (zero padded); no upsampling variant.
+ * isrConvSmallCinPad is kept for callers that sized buffers with it (Cin rounded up to 8). */
 int isrConvSmallCinPad(int Cin);
+long long isrConvSmallWeightFloats(int Cin);
 int isrConvSmallPrepare(const float* w, const float* bias, float* w8, float* bias8, int Cout, int Cin, void* stream);
 int isrConv3x3SmallCout(const float* x, const float* w8, const float* bias8, const float* residual, float* y,
                         int N, int Cin, int H, int W, int Cout, int act, float slope, void* stream);

@@ -1084,24 +1084,39 @@ int isrConv3x3WeightGrad(const float* x, const float* gz, float* dw, float* db, 
 
 }  // extern "C"
 
-// ---- small-Cout direct convolution on the vector ALU --------------------------------------------
+// ---- small-Cout convolution on 4x4x1 MFMA blocks ---------------------------------------------------
 // The last layer of EnhanceNet maps 64 -> 6 channels (enhancenet.py:124).  On the 32-row MFMA tile
-// that wastes 26/32 of the matrix pipe (19 TFLOP/s algorithmic).  With <= 8 output channels the
-// weights of one (cin, tap) fit an s_load_dwordx8, so the conv is a plain FMA loop with the weight as
-// the scalar operand: each thread owns 4 consecutive pixels x 8 channels (32 accumulators), the
-// haloed input rows come from LDS as one ds_read_b128 + ds_read_b64 per (cin, dy), i.e. 72 FMAs per
-// two LDS reads.  Same fused epilogue semantics as the MFMA kernel (bias, activation, residual).
+// that wastes 26/32 of the matrix pipe.  v_mfma_f32_4x4x1_16B_f32 instead multiplies sixteen
+// independent (4 x 1) x (1 x 4) blocks: with A = the weights of 4 output channels (the same in every
+// block: lane l holds channel l % 4) and B = 64 consecutive pixels of one input row (lane l = pixel l),
+// one instruction is D[ch][pixel] += w[ch] * x[pixel] for 4 channels x 64 pixels -- the conv's
+// natural layout, no padding beyond 6 -> 8 channels, and the result registers are already
+// [channel][64 contiguous pixels].  Same rate as every other f32 MFMA (512 flops / 8 cycles).
+//
+// Workgroup = 4 waves = 16 x 64 output pixels, wave w owns rows 4w..4w+3 and both channel groups
+// (8 accumulators of 4 registers).  Input: 4-channel chunks of the haloed 18 x 66 patch, double
+// buffered in LDS, the B operand is a plain ds_read_b32 of 64 consecutive floats (row rr, column
+// lane + dx); each of those registers feeds every (dy, r) with dy + r = rr and both channel groups
+// (2..6 MFMAs).  A operands: per input channel 18 values per lane, kept in LDS as
+// [chunk][c][lane % 4][(dx, dy, group)] and read with ds_read_b128 (4 distinct addresses per wave).
+// Same fused epilogue semantics as the big kernel (bias, activation, residual).
 namespace {
 
-constexpr int SC_TH = 16, SC_TW = 64;          // output tile
-constexpr int SC_PH = SC_TH + 2;
-constexpr int SC_PWS = 66;                     // LDS row stride = patch width: element e of a stage lives at e (8-B aligned rows)
-constexpr int SC_CK = 8;                       // input channels per LDS stage
-constexpr int SC_PLANE = SC_PH * SC_PWS;       // 1224 floats
-constexpr int SC_STAGE = 38 * 256;             // 9728 floats >= 8*18*66 = 9504 (one slot per thread per pass)
+constexpr int SM_TH = 16, SM_TW = 64;          // output tile
+constexpr int SM_PH = SM_TH + 2, SM_PW = SM_TW + 2;
+constexpr int SM_CK = 4;                       // input channels per LDS chunk
+constexpr int SM_PLANE = SM_PH * SM_PW;        // 1188 floats
+constexpr int SM_CHUNK = SM_CK * SM_PLANE;     // 4752
+constexpr int SM_NEL = (SM_CHUNK + 255) / 256; // 19 elements per thread and chunk
+constexpr int SM_PBUF = SM_NEL * 256;          // 4864: patch buffer, the tail is a sink for masked-off lanes
+constexpr int SM_WQ = 20;                      // floats per (c, lane % 4): 18 weights [dx][dy][group] + 2 pad (16-byte rows)
+constexpr int SM_WCH = SM_CK * 4 * SM_WQ;      // 320 weight floats per chunk = 80 float4
+constexpr int SM_WBUF = 4 * 256;               // every thread writes one float4 (80 real ones)
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 struct SmallConvParams {
-    const float* x; const float* w8;           // w8: [9][cinPad8][8] (cout padded to 8, cin to a multiple of 8, zero filled)
+    const float* x; const float* wq;           // wq: [chunks][4][4][20], see prepare_weights_small_kernel
     const float* bias8; const float* residual; float* y;
     int N, Cin, H, W, Cout;
     int tilesX, tilesY;
@@ -1111,144 +1126,138 @@ struct SmallConvParams {
 
 __global__ __launch_bounds__(256, 2) void conv3x3_small_cout_kernel(const SmallConvParams p)
 {
-    __shared__ __attribute__((aligned(16))) float patch[2][SC_STAGE];
+    __shared__ __attribute__((aligned(16))) float patch[2][SM_PBUF];
+    __shared__ __attribute__((aligned(16))) float wl[2][SM_WBUF];
     const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
     const int tilesPerImage = p.tilesX * p.tilesY;
     const int bid = xcd_remap(blockIdx.x, gridDim.x);
     const int n = bid / tilesPerImage;
     const int t = bid - n * tilesPerImage;
     const int ty = t / p.tilesX, tx = t - ty * p.tilesX;
-    const int oy0 = ty * SC_TH, ox0 = tx * SC_TW;
-    const int ly = tid >> 4, lx4 = (tid & 15) * 4;          // this thread: row ly, pixels lx4..lx4+3
+    const int oy0 = ty * SM_TH, ox0 = tx * SM_TW;
 
-    const size_t planeIn = (size_t)p.xPlane;
+    const int planeIn = (int)p.xPlane;
     const float* ximg = p.x + (size_t)n * p.xImage;
-    const int nstages = (p.Cin + SC_CK - 1) / SC_CK;
+    const int nchunks = (p.Cin + SM_CK - 1) / SM_CK;
 
-    // staging: 66 x 18 positions x 8 channels = 9504 elements / 256 threads -> 38 slots per thread,
-    // spread 5 per channel iteration: issued before the iteration's 216 FMAs, parked after the next one's
-    constexpr int NSLOT = (SC_CK * SC_PH * 66 + 255) / 256;        // 38
-    constexpr int SPC = (NSLOT + SC_CK - 1) / SC_CK;               // 5
-    const int cinPad = nstages * SC_CK;
-    unsigned plan[NSLOT];                                            // byte offsets inside a stage's 8 planes
+    unsigned plan[SM_NEL];                     // byte offsets inside a chunk's 4 planes (BAD_OFFSET -> 0)
 #pragma unroll
-    for (int i = 0; i < NSLOT; ++i) {
+    for (int i = 0; i < SM_NEL; ++i) {
         const int e = tid + i * 256;
-        const int c = e / (SC_PH * 66), rem = e - c * (SC_PH * 66);
-        const int r = rem / 66, col = rem - r * 66;
+        const int c = e / SM_PLANE, rem = e - c * SM_PLANE;
+        const int r = rem / SM_PW, col = rem - r * SM_PW;
         const int gy = oy0 + r - 1, gx = ox0 + col - 1;
-        const bool ok = e < SC_CK * SC_PH * 66 && (unsigned)gy < (unsigned)p.H && (unsigned)gx < (unsigned)p.W;
-        plan[i] = ok ? (unsigned)((c * (int)p.xPlane + gy * p.W + gx) * 4) : BAD_OFFSET;
+        const bool ok = e < SM_CHUNK && (unsigned)gy < (unsigned)p.H && (unsigned)gx < (unsigned)p.W;
+        plan[i] = ok ? (unsigned)((c * planeIn + gy * p.W + gx) * 4) : BAD_OFFSET;
     }
-    auto stage_rsrc = [&](int stage) -> rsrc_t {
-        const int left = p.Cin - stage * SC_CK;
-        return __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(ximg + (size_t)stage * SC_CK * planeIn), 0,
-                                                 left > 0 ? (int)(left * planeIn * 4) : 0, 0x00020000);
+    auto chunk_rsrc = [&](int chunk) -> rsrc_t {
+        const int left = p.Cin - chunk * SM_CK;
+        return __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(ximg + (size_t)chunk * SM_CK * planeIn), 0,
+                                                 left > 0 ? left * planeIn * 4 : 0, 0x00020000);
     };
+    const float4* wq4 = reinterpret_cast<const float4*>(p.wq) + min(tid, SM_WCH / 4 - 1);
 
-    typedef float f32x2 __attribute__((ext_vector_type(2)));
-    f32x2 acc[2][8];          // [pixel pair][cout]: packed so that the FMAs are v_pk_fma_f32 (2 lanes x 2 FMA / 4 clk)
+    f32x4 acc[2][4];
 #pragma unroll
-    for (int q = 0; q < 2; ++q)
+    for (int g = 0; g < 2; ++g)
 #pragma unroll
-        for (int co = 0; co < 8; ++co) acc[q][co] = (f32x2){ 0.f, 0.f };
+        for (int r = 0; r < 4; ++r) acc[g][r] = (f32x4){ 0.f, 0.f, 0.f, 0.f };
 
-    {   // prologue: stage 0, in two batches
-        const rsrc_t rs = stage_rsrc(0);
+    {   // prologue: chunk 0
+        const rsrc_t rs = chunk_rsrc(0);
+        float v[SM_NEL];
+        const float4 wv = wq4[0];
 #pragma unroll
-        for (int b = 0; b < 2; ++b) {
-            float v[NSLOT / 2];
+        for (int i = 0; i < SM_NEL; ++i) v[i] = buf_load(rs, plan[i]);
 #pragma unroll
-            for (int i = 0; i < NSLOT / 2; ++i) v[i] = buf_load(rs, plan[b * (NSLOT / 2) + i]);
-#pragma unroll
-            for (int i = 0; i < NSLOT / 2; ++i) patch[0][tid + (b * (NSLOT / 2) + i) * 256] = v[i];
-        }
+        for (int i = 0; i < SM_NEL; ++i) patch[0][tid + i * 256] = v[i];
+        reinterpret_cast<float4*>(wl[0])[tid] = wv;
     }
     __syncthreads();
-    for (int stage = 0; stage < nstages; ++stage) {
-        const int buf = stage & 1;
-        const bool more = stage + 1 < nstages;
-        const rsrc_t rsn = stage_rsrc(stage + 1);
-        const float* pb = &patch[buf][ly * SC_PWS + lx4];
-        float* pn = patch[buf ^ 1] + tid;
-        const int cbase = stage * SC_CK;
-        float sv[2][SPC];
+
+    for (int chunk = 0; chunk < nchunks; ++chunk) {
+        const int buf = chunk & 1;
+        const bool more = chunk + 1 < nchunks;
+        float sv[SM_NEL];
+        float4 wv;
+        if (more) {
+            const rsrc_t rsn = chunk_rsrc(chunk + 1);
 #pragma unroll
-        for (int c = 0; c < SC_CK; ++c) {
-            if (more) {
+            for (int i = 0; i < SM_NEL; ++i) sv[i] = buf_load(rsn, plan[i]);
+            wv = wq4[(chunk + 1) * (SM_WCH / 4)];
+        }
+        __builtin_amdgcn_sched_barrier(0);       // keep the loads above the MFMA block (hipcc would sink them to the stores)
+        const float* pw = patch[buf] + (4 * wave) * SM_PW + lane;
+        const float* aw = wl[buf] + (lane & 3) * SM_WQ;
 #pragma unroll
-                for (int i = 0; i < SPC; ++i)
-                    if (c * SPC + i < NSLOT) sv[c & 1][i] = buf_load(rsn, plan[c * SPC + i]);
+        for (int c = 0; c < SM_CK; ++c) {
+            float a[SM_WQ];
+#pragma unroll
+            for (int q = 0; q < SM_WQ / 4; ++q) {
+                const float4 a4 = *reinterpret_cast<const float4*>(aw + c * 4 * SM_WQ + 4 * q);
+                a[4 * q] = a4.x; a[4 * q + 1] = a4.y; a[4 * q + 2] = a4.z; a[4 * q + 3] = a4.w;
             }
-            const int ci = cbase + c;
 #pragma unroll
-            for (int dy = 0; dy < 3; ++dy) {
-                const float* row = pb + c * SC_PLANE + dy * SC_PWS;
-                const float2 a = *reinterpret_cast<const float2*>(row);
-                const float2 b = *reinterpret_cast<const float2*>(row + 2);
-                const float2 d = *reinterpret_cast<const float2*>(row + 4);
-                const float in[6] = { a.x, a.y, b.x, b.y, d.x, d.y };
+            for (int dx = 0; dx < 3; ++dx) {
+                float b[6];
 #pragma unroll
-                for (int dx = 0; dx < 3; ++dx) {
-                    const float* wk = p.w8 + ((size_t)(dy * 3 + dx) * cinPad + ci) * 8;   // uniform -> scalar loads
-                    const f32x2 i01 = { in[dx], in[dx + 1] }, i23 = { in[dx + 2], in[dx + 3] };
+                for (int rr = 0; rr < 6; ++rr) b[rr] = pw[c * SM_PLANE + rr * SM_PW + dx];
 #pragma unroll
-                    for (int co = 0; co < 8; ++co) {
-                        const f32x2 wv = { wk[co], wk[co] };
-                        acc[0][co] = __builtin_elementwise_fma(i01, wv, acc[0][co]);
-                        acc[1][co] = __builtin_elementwise_fma(i23, wv, acc[1][co]);
-                    }
-                }
-            }
-            if (more && c >= 1) {
+                for (int dy = 0; dy < 3; ++dy)
 #pragma unroll
-                for (int i = 0; i < SPC; ++i)
-                    if ((c - 1) * SPC + i < NSLOT) pn[((c - 1) * SPC + i) * 256] = sv[(c - 1) & 1][i];
+                    for (int r = 0; r < 4; ++r)
+#pragma unroll
+                        for (int g = 0; g < 2; ++g)
+                            acc[g][r] = __builtin_amdgcn_mfma_f32_4x4x1f32(a[(dx * 3 + dy) * 2 + g], b[dy + r], acc[g][r], 0, 0, 0);
             }
         }
         if (more) {
 #pragma unroll
-            for (int i = 0; i < SPC; ++i)
-                if ((SC_CK - 1) * SPC + i < NSLOT) pn[((SC_CK - 1) * SPC + i) * 256] = sv[(SC_CK - 1) & 1][i];
+            for (int i = 0; i < SM_NEL; ++i) patch[buf ^ 1][tid + i * 256] = sv[i];
+            reinterpret_cast<float4*>(wl[buf ^ 1])[tid] = wv;
         }
         __syncthreads();
     }
-    const int oy = oy0 + ly, ox = ox0 + lx4;
-    if (oy < p.H) {
-        const size_t plane = (size_t)p.H * p.W;
+
+    // D register i of group g = channel 4g + i, lane = pixel column
+    const int ox = ox0 + lane;
+    const size_t plane = (size_t)p.H * p.W;
+    if (ox < p.W) {
 #pragma unroll
-        for (int co = 0; co < 8; ++co) {
-            if (co >= p.Cout) break;
-            const size_t base = ((size_t)n * p.Cout + co) * plane + (size_t)oy * p.W + ox;
-            float v[4];
+        for (int g = 0; g < 2; ++g)
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                float r = acc[q >> 1][co][q & 1] + p.bias8[co];
-                if (p.act == ISR_ACT_RELU) r = r > 0.f ? r : 0.f;
-                else if (p.act == ISR_ACT_LEAKY) r = r > 0.f ? r : r * p.slope;
-                v[q] = r;
+            for (int i = 0; i < 4; ++i) {
+                const int co = 4 * g + i;
+                if (co >= p.Cout) break;
+                const float bias = p.bias8[co];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int oy = oy0 + 4 * wave + r;
+                    if (oy >= p.H) break;
+                    float v = acc[g][r][i] + bias;
+                    if (p.act == ISR_ACT_RELU) v = v > 0.f ? v : 0.f;
+                    else if (p.act == ISR_ACT_LEAKY) v = v > 0.f ? v : v * p.slope;
+                    const size_t o = ((size_t)n * p.Cout + co) * plane + (size_t)oy * p.W + ox;
+                    if (p.residual) v += p.residual[o];
+                    p.y[o] = v;
+                }
             }
-            if (ox + 3 < p.W && (p.W & 3) == 0) {
-                float4 o = make_float4(v[0], v[1], v[2], v[3]);
-                if (p.residual) { const float4 rr = *reinterpret_cast<const float4*>(p.residual + base); o.x += rr.x; o.y += rr.y; o.z += rr.z; o.w += rr.w; }
-                *reinterpret_cast<float4*>(p.y + base) = o;
-            } else {
-#pragma unroll
-                for (int q = 0; q < 4; ++q)
-                    if (ox + q < p.W) p.y[base + q] = v[q] + (p.residual ? p.residual[base + q] : 0.f);
-            }
-        }
     }
 }
 
-__global__ void prepare_weights8_kernel(const float* __restrict__ w, const float* __restrict__ bias, float* __restrict__ w8,
-                                        float* __restrict__ bias8, int Cout, int Cin)
+// wq[chunk][c][q][k]: k = (dx*3 + dy)*2 + g < 18 -> w[4g + q][chunk*4 + c][dy][dx], zero padded
+__global__ void prepare_weights_small_kernel(const float* __restrict__ w, const float* __restrict__ bias, float* __restrict__ wq,
+                                             float* __restrict__ bias8, int Cout, int Cin)
 {
-    const int cinPad = ((Cin + SC_CK - 1) / SC_CK) * SC_CK;
-    const int total = 9 * cinPad * 8;
+    const int nchunks = (Cin + SM_CK - 1) / SM_CK;
+    const int total = nchunks * SM_WCH;
     for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < total; e += gridDim.x * blockDim.x) {
-        const int co = e & 7, ci = (e >> 3) % cinPad, tap = e / (8 * cinPad);
-        w8[e] = (co < Cout && ci < Cin) ? w[((co * Cin + ci) * 3 + tap / 3) * 3 + tap % 3] : 0.f;
+        const int chunk = e / SM_WCH, rem = e - chunk * SM_WCH;
+        const int c = rem / (4 * SM_WQ), q = (rem / SM_WQ) & 3, k = rem % SM_WQ;
+        const int dx = k / 6, dy = (k % 6) >> 1, g = k & 1;
+        const int co = 4 * g + q, ci = chunk * SM_CK + c;
+        wq[e] = (k < 18 && co < Cout && ci < Cin) ? w[((co * Cin + ci) * 3 + dy) * 3 + dx] : 0.f;
     }
     if (blockIdx.x == 0 && threadIdx.x < 8) bias8[threadIdx.x] = (bias && (int)threadIdx.x < Cout) ? bias[threadIdx.x] : 0.f;
 }
@@ -1257,13 +1266,15 @@ __global__ void prepare_weights8_kernel(const float* __restrict__ w, const float
 
 extern "C" {
 
-int isrConvSmallCinPad(int Cin) { return ((Cin + SC_CK - 1) / SC_CK) * SC_CK; }
+int isrConvSmallCinPad(int Cin) { return ((Cin + 7) / 8) * 8; }
+
+long long isrConvSmallWeightFloats(int Cin) { return (long long)((Cin + SM_CK - 1) / SM_CK) * SM_WCH; }
 
 int isrConvSmallPrepare(const float* w, const float* bias, float* w8, float* bias8, int Cout, int Cin, void* stream)
 {
     if (!w || !w8 || !bias8 || Cout <= 0 || Cout > 8 || Cin <= 0) return -1;
-    const int total = 9 * (((Cin + SC_CK - 1) / SC_CK) * SC_CK) * 8;
-    hipLaunchKernelGGL(prepare_weights8_kernel, dim3((total + 255) / 256), dim3(256), 0, (hipStream_t)stream, w, bias, w8, bias8, Cout, Cin);
+    const int total = (int)isrConvSmallWeightFloats(Cin);
+    hipLaunchKernelGGL(prepare_weights_small_kernel, dim3((total + 255) / 256), dim3(256), 0, (hipStream_t)stream, w, bias, w8, bias8, Cout, Cin);
     return hipGetLastError() == hipSuccess ? 0 : -2;
 }
 
@@ -1281,9 +1292,9 @@ int isrConv3x3SmallCoutStrided(const float* x, const float* w8, const float* bia
     if (!x || !w8 || !bias8 || !y || N <= 0 || Cin <= 0 || Cout <= 0 || Cout > 8 || H <= 0 || W <= 0) return -1;
     if (xPlane < (long long)H * W || (long long)Cin * xPlane * 4 >= (1LL << 31)) return -1;
     SmallConvParams p;
-    p.x = x; p.w8 = w8; p.bias8 = bias8; p.residual = residual; p.y = y;
+    p.x = x; p.wq = w8; p.bias8 = bias8; p.residual = residual; p.y = y;
     p.N = N; p.Cin = Cin; p.H = H; p.W = W; p.Cout = Cout;
-    p.tilesX = (W + SC_TW - 1) / SC_TW; p.tilesY = (H + SC_TH - 1) / SC_TH;
+    p.tilesX = (W + SM_TW - 1) / SM_TW; p.tilesY = (H + SM_TH - 1) / SM_TH;
     p.act = act; p.slope = slope;
     p.xPlane = xPlane; p.xImage = xImage;
     const long long nwg = (long long)N * p.tilesX * p.tilesY;

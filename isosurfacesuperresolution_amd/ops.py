@@ -40,6 +40,7 @@ def _sr():
         lib.isrActBackward.argtypes = [vp, vp, vp, ll, ci, cf, vp]; lib.isrActBackward.restype = ci
         lib.isrAssembleInput.argtypes = [vp, vp, vp, vp, ci, ci, ci, ci, vp]; lib.isrAssembleInput.restype = ci
         lib.isrConvSmallCinPad.argtypes = [ci]; lib.isrConvSmallCinPad.restype = ci
+        lib.isrConvSmallWeightFloats.argtypes = [ci]; lib.isrConvSmallWeightFloats.restype = ll
         lib.isrConvSmallPrepare.argtypes = [vp, vp, vp, vp, ci, ci, vp]; lib.isrConvSmallPrepare.restype = ci
         lib.isrConv3x3SmallCout.argtypes = [vp, vp, vp, vp, vp, ci, ci, ci, ci, ci, ci, cf, vp]; lib.isrConv3x3SmallCout.restype = ci
         lib.isrConv3x3SmallCoutStrided.argtypes = [vp, vp, vp, vp, vp, ci, ci, ci, ci, ci, ci, cf, ll, ll, vp]
@@ -121,7 +122,7 @@ _small_cache = {}
 
 
 def _prepare_small(weight, bias):
-    """(w8, bias8) device tensors for the Cout <= 8 vector-ALU kernel, cached like prepare_weights."""
+    """(w8, bias8) device tensors for the Cout <= 8 kernel, cached like prepare_weights."""
     lib = _sr()
     key = id(weight)
     hit = _small_cache.get(key)
@@ -132,7 +133,7 @@ def _prepare_small(weight, bias):
         if ref() is weight and ver == weight._version and ptr == weight.data_ptr() and bp == bptr and bv == bver:
             return w8, b8
     cout, cin = weight.shape[0], weight.shape[1]
-    w8 = torch.empty(9 * lib.isrConvSmallCinPad(cin) * 8, dtype=torch.float32, device=weight.device)
+    w8 = torch.empty(lib.isrConvSmallWeightFloats(cin), dtype=torch.float32, device=weight.device)
     b8 = torch.empty(8, dtype=torch.float32, device=weight.device)
     rc = lib.isrConvSmallPrepare(_ptr(weight.detach().contiguous()), _ptr(bias.detach().contiguous()) if bias is not None else None,
                                  _ptr(w8), _ptr(b8), cout, cin, _stream())

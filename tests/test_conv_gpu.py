@@ -40,6 +40,9 @@ CASES = [
     (1, 64, 64, 24, 36, 'none', True, True, False),       # fused skip on the dwordx4 (W % 4 == 0) epilogue
     (2, 64, 6, 20, 64, 'relu', True, True, False),
     (1, 64, 64, 8, 8, 'relu', True, False, True),         # tiny upsampled tile
+    (1, 101, 8, 33, 70, 'leaky', True, True, False),      # small-Cout kernel: ragged tiles, Cin % 4 != 0, all 8 channels
+    (2, 3, 1, 17, 130, 'none', False, False, False),      # small-Cout kernel: one channel, one partial chunk
+    (1, 64, 64, 34, 38, 'relu', True, True, True),        # upsampled, ragged, fused skip
 ]
 
 
@@ -61,6 +64,32 @@ def test_conv3x3_forward(case):
     assert y.shape == ref.shape
     err = (y.cpu().double() - ref).abs().max().item()
     assert err <= 1e-4, err
+
+
+def test_conv3x3_padded_channel_planes():
+    """Tensors with padded channel planes (ops.empty_planes) go through the strided C entry points unchanged."""
+    from isosurfacesuperresolution_amd import ops
+    g = torch.Generator().manual_seed(11)
+    x = torch.rand(2, 64, 20, 36, generator=g) * 2 - 1
+    w1 = (torch.rand(64, 64, 3, 3, generator=g) * 2 - 1) / 24.0
+    w2 = (torch.rand(6, 64, 3, 3, generator=g) * 2 - 1) / 24.0
+    b1, b2 = torch.rand(64, generator=g), torch.rand(6, generator=g)
+    res = torch.rand(2, 64, 40, 72, generator=g)
+    ref1 = _ref(x, w1, b1, 'relu', 0.1, res, True)
+    ref2 = _ref(ref1.float(), w2, b2, 'none', 0.1, None, False)
+    old = ops.plane_pad
+    ops.plane_pad = lambda h, w: 52        # force padding at every size (a multiple of 4 floats)
+    try:
+        with torch.no_grad():
+            xp = ops.empty_planes(2, 64, 20, 36, 'cuda'); xp.copy_(x)
+            rp = ops.empty_planes(2, 64, 40, 72, 'cuda'); rp.copy_(res)
+            y1 = ops.conv3x3(xp, w1.cuda(), b1.cuda(), act='relu', residual=rp, upsample2x=True)
+            assert y1.stride(1) == 40 * 72 + 52 and not y1.is_contiguous()
+            y2 = ops.conv3x3(y1, w2.cuda(), b2.cuda())
+    finally:
+        ops.plane_pad = old
+    assert (y1.cpu().double() - ref1).abs().max().item() <= 1e-4
+    assert (y2.cpu().double() - ref2).abs().max().item() <= 1e-4
 
 
 def test_conv3x3_is_exact_fma_chain_on_integers():
