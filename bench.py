@@ -11,6 +11,7 @@ sequence, started with ``initialImage``: weak scaling, no data-
 Rank 0 prints ONE JSON line.
 """
 import argparse
+import contextlib
 import json
 import os
 import sys
@@ -72,7 +73,8 @@ def main():
     renderer.load_dense(vol)
     opt = argparse.Namespace(upsample='bilinear', reconType='residual', useBN=False, numResidualLayers=10)
     torch.manual_seed(0)
-    net = models.createNetwork('EnhanceNet', 4, 101, [0, 1, 2, 3, 4], 6, opt)
+    with contextlib.redirect_stdout(sys.stderr):      # createNetwork prints its configuration like the reference does
+        net = models.createNetwork('EnhanceNet', 4, 101, [0, 1, 2, 3, 4], 6, opt)
     model = LoadedModel.from_model(net, "cuda", parameters={"initialImage": "zero"})
     pipe = SuperResolutionPipeline(renderer, model, default_shading("cuda", 30.0), (low_w, low_h),
                                    temporal=not args.no_temporal)
@@ -202,7 +204,8 @@ def cpu_reference_leg(args, vol, iso, net, pipe, origin, low_w, low_h, result, r
     ref, stats = iso_oracle.render(ov, p, threads=cores)
     t_render = time.perf_counter() - t0
     opt = argparse.Namespace(upsample='bilinear', reconType='residual', useBN=False, numResidualLayers=10)
-    cpu_net = models.createNetwork('EnhanceNet', 4, 101, [0, 1, 2, 3, 4], 6, opt)
+    with contextlib.redirect_stdout(sys.stderr):
+        cpu_net = models.createNetwork('EnhanceNet', 4, 101, [0, 1, 2, 3, 4], 6, opt)
     cpu_net.load_state_dict({k: v.cpu() for k, v in net.state_dict().items()})
     cpu_model = LoadedModel.from_model(cpu_net.eval(), "cpu", parameters={"initialImage": "zero"})
     low = torch.from_numpy(ref).permute(2, 0, 1).unsqueeze(0)
