@@ -251,6 +251,74 @@ dist.destroy_process_group()
     assert np.abs(comp - full)[both].max() <= 1e-4
 
 
+def _strip_sequence(seed=5, frames=3, h=70, w=40):
+    """A short synthetic low-resolution G-buffer sequence [frames][h][w][12] with holes in mask and flow."""
+    g = torch.Generator().manual_seed(seed)
+    seq = []
+    for _ in range(frames):
+        t = torch.rand(h, w, 12, generator=g)
+        t[..., 3] = (t[..., 3] > 0.35).float()
+        t[..., 4:7] = t[..., 4:7] * 2 - 1
+        t[..., 8:10] = (t[..., 8:10] - 0.5) * 0.08
+        seq.append(t)
+    return seq
+
+
+def test_strip_super_resolution_three_rank_gloo_matches_single_process(tmp_path):
+    """One frame's SR split over 3 ranks by screen strips with a 24-px halo + ONE all-gather per frame
+     == the single-process temporal sequence (uneven strips: 70 rows over 3 ranks)."""
+    script = tmp_path / "strips.py"
+    script.write_text('''
+import os, sys, torch, torch.distributed as dist
+sys.path.insert(0, %r)
+sys.path.insert(0, os.path.join(%r, "tests"))
+from isosurfacesuperresolution_amd import models, parallel_sr
+from isosurfacesuperresolution_amd.inference import LoadedModel
+from isosurfacesuperresolution_amd.pipeline import default_shading
+from test_host_cpu import OPT, _strip_sequence
+dist.init_process_group("gloo")
+torch.manual_seed(77)
+net = models.createNetwork('EnhanceNet', 4, 101, [0, 1, 2, 3, 4], 6, OPT).eval()
+lm = LoadedModel.from_model(net, "cpu", parameters={"initialImage": "zero"})
+sr = parallel_sr.StripSuperResolution(lm, default_shading("cpu", 30.0))
+outs = [sr.frame(g) for g in _strip_sequence()]
+if dist.get_rank() == 2:                       # any rank holds the full frames
+    torch.save([(rgb, raw) for rgb, raw in outs], %r)
+dist.destroy_process_group()
+''' % (ROOT, ROOT, str(tmp_path / "strips.pt")))
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="2")
+    subprocess.check_call([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=3",
+                           "--master-addr", "127.0.0.1", "--master-port", "29621", str(script)],
+                          env=env, stdout=subprocess.DEVNULL, timeout=300)
+    from isosurfacesuperresolution_amd import parallel_sr
+    from isosurfacesuperresolution_amd.pipeline import default_shading
+    split = torch.load(tmp_path / "strips.pt")
+    torch.manual_seed(77)
+    net = models.createNetwork('EnhanceNet', 4, 101, [0, 1, 2, 3, 4], 6, OPT).eval()
+    lm = inference.LoadedModel.from_model(net, "cpu", parameters={"initialImage": "zero"})
+    single = parallel_sr.StripSuperResolution(lm, default_shading("cpu", 30.0))     # world == 1: the whole frame
+    for g, (rgb_s, raw_s) in zip(_strip_sequence(), split):
+        rgb, raw = single.frame(g)
+        assert raw.shape == raw_s.shape == (1, 6, 280, 160)
+        assert (raw - raw_s).abs().max().item() <= 1e-5
+        assert (rgb - rgb_s).abs().max().item() <= 1e-5
+    # and the single-rank strip path is the reference module path (LoadedModel.inference + clamp/normalise)
+    ref_prev = None
+    single.reset()
+    for g in _strip_sequence():
+        low = g.permute(2, 0, 1).unsqueeze(0)
+        ref = lm.inference(low, ref_prev)
+        ref = torch.cat([ref[:, 0:1].clamp(-1, 1), inference_normalize(ref[:, 1:4]), ref[:, 4:].clamp(0, 1)], dim=1)
+        _, raw = single.frame(g)
+        assert (raw - ref).abs().max().item() <= 1e-5
+        ref_prev = ref
+
+
+def inference_normalize(v):
+    from isosurfacesuperresolution_amd.utils import ScreenSpaceShading
+    return ScreenSpaceShading.normalize(v, dim=1)
+
+
 def test_ssim_matches_reference_fixture():
     from isosurfacesuperresolution_amd import utils
     G = np.load(os.path.join(ROOT, "tests", "golden", "sr_reference.npz"))

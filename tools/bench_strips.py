@@ -1,0 +1,35 @@
+"""Per-rank critical path of parallel_sr at 960x540 -> 3840x2160 (BASELINE config #5's SR half) on ONE GPU:
+replicated input assembly + the strip of rank world//2 (a middle strip has both halos), for world = 1, 2, 4, 8."""
+import sys
+sys.path.insert(0, '.')
+import argparse
+import torch
+from isosurfacesuperresolution_amd import models, parallel_sr
+from isosurfacesuperresolution_amd.inference import LoadedModel
+from isosurfacesuperresolution_amd.pipeline import default_shading
+opt = argparse.Namespace(upsample='bilinear', reconType='residual', useBN=False, numResidualLayers=10)
+torch.manual_seed(0)
+net = models.createNetwork('EnhanceNet', 4, 101, [0, 1, 2, 3, 4], 6, opt)
+lm = LoadedModel.from_model(net, "cuda", parameters={"initialImage": "zero"})
+sr = parallel_sr.StripSuperResolution(lm, default_shading("cuda", 30.0))
+h, w = (int(v) for v in (sys.argv[1] if len(sys.argv) > 1 else "540x960").split("x"))
+g = torch.rand(h, w, 12, device="cuda")
+g[..., 3] = (g[..., 3] > 0.4).float()
+g[..., 8:10] = (g[..., 8:10] - 0.5) * 0.02
+with torch.no_grad():
+    sr.previous = torch.rand(1, 6, 4 * h, 4 * w, device="cuda")
+    for world in (1, 2, 4, 8):
+        rank = world // 2
+        for it in range(3):
+            if it == 1:
+                torch.cuda.synchronize()
+                e0, e1, e2 = (torch.cuda.Event(enable_timing=True) for _ in range(3))
+                e0.record()
+            x = sr.network_input(g)
+            if it >= 1 and it == 1: e1.record()
+            raw, rgb = sr.compute_strip(x, rank, world)
+            if it == 1: e2.record()
+        torch.cuda.synchronize()
+        y0, y1 = parallel_sr.strip_bounds(h, world, rank)
+        print("world %d: rows %d + halo -> assembly %.2f ms + strip %.2f ms = %.2f ms; all-gather payload %.1f MB per rank" % (
+            world, y1 - y0, e0.elapsed_time(e1), e1.elapsed_time(e2), e0.elapsed_time(e2), 9 * (y1 - y0) * 4 * w * 4 * 4 / 1e6), flush=True)
