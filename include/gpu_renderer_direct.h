@@ -35,7 +35,16 @@ int loadGrid(const char* filename);
  * Returns 0, or -1 for an unknown command or (unlike the reference, which lets a C++ exception
  * escape) for a value of the wrong arity.
  * Additive commands: ambient|diffuse|specular (3 doubles), exponent (1 int),
- * light ("camera" or 3 doubles). */
+ * light ("camera" or 3 doubles), and
+ *   semantics ("cpu" | "gvdb"): which of the reference's two renderers the numbers follow.
+ *     "cpu"  (default): CPURenderer -- node-centred sampling, voxel DDA + 5 bisections, isovalue relative to the
+ *            grid maximum, world = longest edge 1.0, depth = distance, camera-space normal flipped to z >= 0,
+ *            flow = camera-space delta, AO only when aosamples > 0, shadow 0.
+ *     "gvdb": GPURendererDirect's CUDA kernel -- cell-centred sampling, 0.05-voxel march + 10 bisections,
+ *            ABSOLUTE isovalue, world = longest edge 0.5, GVDB camera (half-width tangent tan(fov/2)/2),
+ *            depth = NDC z, outward view-space normal, flow = 0.5 * delta NDC, ray-cast AO, shadow 1: the
+ *            G-buffer statistics the released networks were trained on (computed in IEEE float; the texture
+ *            unit's filtering is not bit-reproducible). */
 int setParameter(const char* cmd, const char* value);
 
 /* Replaces GPURendererDirect.cpp:430-446.  Synchronous.  Writes resolutionY*resolutionX*12 fp32

@@ -63,6 +63,7 @@ struct State {
     Volume vol;
     int variant = 0;
     int waveCap = 0;             // see isoSetWaveCap
+    int semantics = 0;           // 0: reference CPU renderer (default), 1: reference CUDA renderer (setParameter("semantics", "gvdb"))
     float* aoHemi = nullptr;     // device copies of the AO tables
     float* aoRot = nullptr;
     bool profile = false;
@@ -329,6 +330,84 @@ bool uploadFromDevice(const float* dense, int nx, int ny, int nz, const TileInfo
     return true;
 }
 
+// ---- semantics=gvdb: the CUDA renderer's camera / transform, as constants of one frame --------------------------
+// gvdb_camera.cpp:431-441 (gluLookAt basis)
+void gvdbBasis(const double origin[3], const double lookat[3], const double up[3], double side[3], double upv[3], double back[3])
+{
+    double d[3] = { lookat[0] - origin[0], lookat[1] - origin[1], lookat[2] - origin[2] };
+    double l = std::sqrt(d[0] * d[0] + d[1] * d[1] + d[2] * d[2]);
+    for (int k = 0; k < 3; ++k) d[k] /= l;
+    side[0] = d[1] * up[2] - d[2] * up[1]; side[1] = d[2] * up[0] - d[0] * up[2]; side[2] = d[0] * up[1] - d[1] * up[0];
+    l = std::sqrt(side[0] * side[0] + side[1] * side[1] + side[2] * side[2]);
+    for (int k = 0; k < 3; ++k) side[k] /= l;
+    upv[0] = side[1] * d[2] - side[2] * d[1]; upv[1] = side[2] * d[0] - side[0] * d[2]; upv[2] = side[0] * d[1] - side[1] * d[0];
+    l = std::sqrt(upv[0] * upv[0] + upv[1] * upv[1] + upv[2] * upv[2]);
+    for (int k = 0; k < 3; ++k) { upv[k] /= l; back[k] = -d[k]; }
+}
+
+// proj * view, row-major; P00 = 2 near / (tan(fov/2) near), near .1, far 5000 (gvdb_camera.cpp:59-60,447-455)
+void gvdbViewProj(const double origin[3], const double lookat[3], const double up[3], double fovDeg, double aspect, float out[16])
+{
+    double s[3], u[3], b[3];
+    gvdbBasis(origin, lookat, up, s, u, b);
+    const double nr = 0.1, fr = 5000.0;
+    const double sx = std::tan(fovDeg * (M_PI / 180.0) / 2.0) * nr, sy = sx / aspect;
+    const double P[4][4] = { { 2.0 * nr / sx, 0, 0, 0 }, { 0, 2.0 * nr / sy, 0, 0 },
+                             { 0, 0, -(fr + nr) / (fr - nr), -(2.0 * fr * nr) / (fr - nr) }, { 0, 0, -1.0, 0 } };
+    const double V[4][4] = { { s[0], s[1], s[2], -(s[0] * origin[0] + s[1] * origin[1] + s[2] * origin[2]) },
+                             { u[0], u[1], u[2], -(u[0] * origin[0] + u[1] * origin[1] + u[2] * origin[2]) },
+                             { b[0], b[1], b[2], -(b[0] * origin[0] + b[1] * origin[1] + b[2] * origin[2]) },
+                             { 0, 0, 0, 1 } };
+    for (int i = 0; i < 4; ++i)
+        for (int j = 0; j < 4; ++j) {
+            double a = 0;
+            for (int k = 0; k < 4; ++k) a += P[i][k] * V[k][j];
+            out[4 * i + j] = float(a);
+        }
+}
+
+void buildGvdbFrame(IsoGvdbFrame& f, const Args& a, const Volume& v, const double lastOrigin[3], const double lastLookAt[3])
+{
+    // loadGrid: SetTransform(-centre, 0.5 / longest edge) of the object bounds (GPURendererDirect.cpp:266-278)
+    double ext = 0, cen[3];
+    for (int k = 0; k < 3; ++k) {
+        const double lo = v.bbmin[k], hi = v.bbmax[k];
+        if (hi - lo > ext) ext = hi - lo;
+        cen[k] = (lo + hi) * 0.5;
+    }
+    const double scale = 0.5 / ext;
+    f.scale = float(scale);
+    for (int k = 0; k < 3; ++k) {
+        f.tr[k] = float(-cen[k] * scale);
+        f.rpos[k] = float(a.cameraOrigin[k] / scale + cen[k]);       // campos * invxform
+    }
+    const double aspect = double(a.resolutionX) / double(a.resolutionY);
+    gvdbViewProj(a.cameraOrigin, a.cameraLookAt, a.cameraUp, a.cameraFov, aspect, f.cur);
+    gvdbViewProj(lastOrigin, lastLookAt, a.cameraUp, a.cameraFov, aspect, f.nxt);
+    double s[3], u[3], b[3];
+    gvdbBasis(a.cameraOrigin, a.cameraLookAt, a.cameraUp, s, u, b);
+    for (int k = 0; k < 3; ++k) { f.vrot[k] = float(s[k]); f.vrot[3 + k] = float(u[k]); f.vrot[6 + k] = float(b[k]); }
+    // corner rays tl / tr / bl (gvdb_camera.cpp:598-601,654-665): view-space directions (x / P00, y / P11, -1)
+    const double hx = std::tan(a.cameraFov * (M_PI / 180.0) / 2.0) / 2.0, hy = hx / aspect;
+    for (int k = 0; k < 3; ++k) {
+        const double tl = -hx * s[k] + hy * u[k] - b[k];
+        const double tr = hx * s[k] + hy * u[k] - b[k];
+        const double bl = -hx * s[k] - hy * u[k] - b[k];
+        f.cams[k] = float(tl); f.camu[k] = float(tr - tl); f.camv[k] = float(bl - tl);
+    }
+    double L[3];
+    for (int k = 0; k < 3; ++k) L[k] = a.cameraLight ? (a.cameraLookAt[k] - a.cameraOrigin[k]) : a.lightDirection[k];
+    const double ll = std::sqrt(L[0] * L[0] + L[1] * L[1] + L[2] * L[2]);
+    for (int k = 0; k < 3; ++k) {
+        f.light[k] = float(L[k] / ll);
+        f.ambient[k] = float(a.materialAmbient[k]); f.diffuse[k] = float(a.materialDiffuse[k]); f.specular[k] = float(a.materialSpecular[k]);
+    }
+    f.iso = float(a.isovalue);                                       // absolute (GPURendererDirect.cpp:364)
+    f.exponent = a.materialSpecularExponent;
+    f.spec_c = float(a.materialSpecularExponent + 2) / (2.0f * 3.41f);   // render_kernel.cu:236
+    f.aoRadius = a.aoRadius;
+}
+
 bool launchFrame(float* out, hipStream_t stream)
 {
     const Args& a = g.args;
@@ -372,7 +451,13 @@ bool launchFrame(float* out, hipStream_t stream)
         if (hipEventCreate(&e0) == hipSuccess && hipEventCreate(&e1) == hipSuccess) g.events.emplace_back(e0, e1);
         else e0 = e1 = nullptr;
     }
-    iso_launch_render(p, g.variant, stream, e0, e1, g.waveCap);
+    if (g.semantics == 1) {
+        IsoGvdbFrame f;
+        buildGvdbFrame(f, a, v, g.lastOrigin, g.lastLookAt);
+        iso_launch_render_gvdb(p, f, stream, e0, e1);
+    } else {
+        iso_launch_render(p, g.variant, stream, e0, e1, g.waveCap);
+    }
     if (hipGetLastError() != hipSuccess) return false;
     // GPURendererDirect.cpp:440-442: the camera just rendered becomes the flow reference
     for (int k = 0; k < 3; ++k) { g.lastOrigin[k] = a.cameraOrigin[k]; g.lastLookAt[k] = a.cameraLookAt[k]; }
@@ -474,6 +559,10 @@ int setParameter(const char* cmd_, const char* value)
             a.cameraLight = false;
             for (int k = 0; k < 3; ++k) a.lightDirection[k] = d[k];
         }
+    } else if (cmd == "semantics") {                                           // additive, see include/gpu_renderer_direct.h
+        if (std::strcmp(value, "cpu") == 0) g.semantics = 0;
+        else if (std::strcmp(value, "gvdb") == 0) g.semantics = 1;
+        else return -1;
     } else {
         std::printf("Unknown command: '%s', exit\n", cmd_);
         return -1;

@@ -42,9 +42,25 @@ struct IsoRenderParams {
     const float* aoRot;          // [16][4] per-pixel (x%4, y%4) rotation vectors
 };
 
-// launchers (iso_kernels.hip)
+// Per-frame constants of the `semantics=gvdb` kernel (iso_gvdb.hip), prepared in double and narrowed to float
+struct IsoGvdbFrame {
+    float rpos[3];               // camera position in grid-local (voxel) coordinates
+    float cams[3], camu[3], camv[3];   // corner-ray basis (cuda_gvdb_geom.cuh:66-74)
+    float cur[16], nxt[16];      // proj * view of the current / previously rendered camera, row-major
+    float vrot[9];               // rotation rows of the view matrix (side, up, -dir)
+    float scale, tr[3];          // grid-local -> world: w = scale * p + tr
+    float light[3];
+    float iso;                   // absolute
+    float ambient[3], diffuse[3], specular[3];
+    float spec_c;                // (e + 2) / (2 * 3.41)
+    int exponent;
+    float aoRadius;
+};
+
+// launchers (iso_kernels.hip, iso_gvdb.hip)
 // waveCap: variant 2 only -- launch at most this many one-wave workgroups (0 = one per 8x8 tile)
 void iso_launch_render(const IsoRenderParams& p, int variant, void* stream, void* startEvent, void* stopEvent, int waveCap);
+void iso_launch_render_gvdb(const IsoRenderParams& p, const IsoGvdbFrame& f, void* stream, void* startEvent, void* stopEvent);
 void iso_launch_brick_flags(const float* dense, int nx, int ny, int nz, int nbx, int nby, int nbz,
                             uint8_t* flag9, uint8_t* leaf, int* bbox6, unsigned int* maxbits, void* stream);
 void iso_launch_brick_fill(const float* dense, int nx, int ny, int nz, int nbx, int nby, int nbz,

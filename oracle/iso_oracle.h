@@ -65,6 +65,10 @@ void iso_params_default(iso_params* p);
  * tbb::parallel_for over rows, IsoVolumeRayTracer.h:494-498).  Returns 0. */
 int iso_render(const iso_volume* v, const iso_params* p, float* out_hwc, long long stats[4], int threads);
 
+/* The same frame with the arithmetic of the reference's CUDA renderer (right column): see
+ * iso_oracle_gvdb.c.  isovalue is ABSOLUTE here; stats are not collected.  Returns 0. */
+int iso_render_gvdb(const iso_volume* v, const iso_params* p, float* out_hwc, int threads);
+
 int iso_num_threads(void);
 
 #ifdef __cplusplus

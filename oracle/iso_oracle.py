@@ -32,8 +32,8 @@ class IsoParams(ctypes.Structure):
 
 def build(force=False):
     so = os.path.join(_HERE, "libiso_oracle.so")
-    src = os.path.join(_HERE, "iso_oracle.c")
-    if force or not os.path.exists(so) or os.path.getmtime(so) < os.path.getmtime(src):
+    srcs = [os.path.join(_HERE, f) for f in ("iso_oracle.c", "iso_oracle_gvdb.c", "iso_oracle.h", "iso_oracle_priv.h")]
+    if force or not os.path.exists(so) or os.path.getmtime(so) < max(os.path.getmtime(f) for f in srcs):
         subprocess.check_call(["make", "-C", _HERE, "-B", "libiso_oracle.so"], stdout=subprocess.DEVNULL)
     return so
 
@@ -55,6 +55,8 @@ def lib():
         L.iso_render.restype = ctypes.c_int
         L.iso_render.argtypes = [ctypes.c_void_p, ctypes.POINTER(IsoParams), ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int]
         L.iso_num_threads.restype = ctypes.c_int
+        L.iso_render_gvdb.restype = ctypes.c_int
+        L.iso_render_gvdb.argtypes = [ctypes.c_void_p, ctypes.POINTER(IsoParams), ctypes.c_void_p, ctypes.c_int]
         L.iso_ao_tables.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
         _LIB = L
     return _LIB
@@ -130,6 +132,13 @@ def render(volume, params, threads=0, with_stats=True):
     stats = (ctypes.c_longlong * 4)()
     lib().iso_render(volume._h, ctypes.byref(params), out.ctypes.data, stats if with_stats else None, int(threads))
     return out, {"hits": stats[0], "samples": stats[1], "bricks_touched": stats[2], "steps": stats[3]}
+
+
+def render_gvdb(volume, params, threads=0):
+    """The frame with the CUDA renderer's arithmetic (iso_oracle_gvdb.c); params.isovalue is absolute.  [H,W,12]."""
+    out = np.empty((params.height, params.width, 12), dtype=np.float32)
+    lib().iso_render_gvdb(volume._h, ctypes.byref(params), out.ctypes.data, int(threads))
+    return out
 
 
 def num_threads():

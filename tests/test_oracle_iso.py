@@ -104,3 +104,69 @@ def test_thread_count_invariance(oracle):
 def test_empty_volume_rejected(oracle):
     with pytest.raises(ValueError):
         oracle.OracleVolume(np.zeros((16, 16, 16), np.float32))
+
+
+# ---- the CUDA renderer's arithmetic (oracle/iso_oracle_gvdb.c), pinned by analytic answers as well --------------
+
+def _gvdb_sphere(oracle, res=96, origin=(0.0, 0.0, 1.0), **kw):
+    vol = V.sphere64()
+    ov = oracle.OracleVolume(vol)
+    p = oracle.make_params(res, res, origin=origin, fov=45.0, isovalue=0.5, **kw)
+    return ov, p
+
+
+def test_gvdb_semantics_sphere_analytic(oracle):
+    """(Even resolution: a ray with an exactly zero direction component turns the DDA's 0 * inf into NaN, in the
+    reference's macros as much as here.)  Cell-centred sampling puts the sphere centre at voxel 32.0 = the centre of the brick bounding box [8,56),
+    longest edge (48 voxels) -> 0.5 world units: world radius 20 * 0.5/48 around the origin."""
+    ov, p = _gvdb_sphere(oracle, ambient=(0.1, 0.2, 0.3), diffuse=(0.5, 0.4, 0.3), specular=(0.25, 0.5, 1.0), specular_exponent=4)
+    img = oracle.render_gvdb(ov, p, threads=2)
+    R = 20.0 * 0.5 / 48.0
+    c = 96 // 2
+    px = img[c, c]
+    assert px[3] == 1.0 and px[11] == 1.0 and px[10] == 1.0            # mask, shadow == 1, ao == 1 without samples
+    near, far = 0.1, 5000.0
+    ndc = lambda d: (far + near) / (far - near) - 2 * far * near / ((far - near) * d)
+    assert abs(px[7] - ndc(1.0 - R)) < 2e-3                            # depth is NDC z (render_kernel.cu:247)
+    assert px[6] > 0.999 and abs(px[4]) < 3e-2 and abs(px[5]) < 3e-2    # outward normal, view space, no flip
+    assert px[8] == 0.0 and px[9] == 0.0                               # static camera
+    # Phong with light = view direction: |n.l| = 1, R.eye = 1 -> a + d + s (e + 2) / (2 * 3.41)
+    expect = np.array([0.1, 0.2, 0.3]) + np.array([0.5, 0.4, 0.3]) + np.array([0.25, 0.5, 1.0]) * 6.0 / 6.82
+    assert np.allclose(px[0:3], expect, atol=2e-3)
+    # silhouette: image half-width tangent is tan(fov/2)/2 (SURVEY R7)
+    hx = math.tan(math.radians(22.5)) / 2.0
+    j, i = np.mgrid[0:96, 0:96]
+    tx, ty = (2 * (i + 0.5) / 96 - 1) * hx, (1 - 2 * (j + 0.5) / 96) * hx
+    tan_angle = np.sqrt(tx * tx + ty * ty)
+    limit = R / math.sqrt(1 - R * R)
+    assert (img[..., 3][tan_angle < 0.97 * limit] == 1).all()
+    assert (img[..., 3][tan_angle > 1.03 * limit] == 0).all()
+    hit = img[..., 3] == 1
+    assert np.allclose(np.linalg.norm(img[..., 4:7][hit], axis=-1), 1.0, atol=1e-5)
+    assert (img[..., 0:3][~hit] == 0).all() and (img[..., 10][~hit] == 1).all()
+    # absolute isovalue: a larger threshold is a smaller sphere
+    p2 = oracle.make_params(96, 96, origin=(0.0, 0.0, 1.0), fov=45.0, isovalue=0.75)
+    assert oracle.render_gvdb(ov, p2, threads=2)[..., 3].sum() < hit.sum()
+
+
+def test_gvdb_semantics_flow_depth_viewport_and_ao(oracle):
+    ov, p = _gvdb_sphere(oracle, res=64, origin=(0.3, 0.1, 1.0), last_origin=(0.25, 0.1, 1.0))
+    img = oracle.render_gvdb(ov, p, threads=2)
+    hit = img[..., 3] == 1
+    assert hit.sum() > 500
+    # the camera orbited towards +x since the last frame: the near side of the object moves to -x on screen,
+    # flow = 0.5 (cur - last) < 0 there (points behind the look-at centre would move the other way)
+    assert img[..., 8][hit].mean() < -0.005 and np.abs(img[..., 9][hit]).mean() < 0.3 * np.abs(img[..., 8][hit]).mean()
+    assert img[..., 7][hit].min() > 0.5 and img[..., 7][hit].max() < 1.0
+    # viewport
+    pv = oracle.make_params(64, 64, origin=(0.3, 0.1, 1.0), fov=45.0, isovalue=0.5, viewport=(16, 8, 40, 56))
+    iv = oracle.render_gvdb(ov, pv, threads=2)
+    inside = np.zeros((64, 64), bool); inside[8:56, 16:40] = True
+    assert (iv[..., 3][~inside] == 0).all() and np.array_equal(iv[..., 3][inside], img[..., 3][inside])
+    # ray-cast AO: inside (0, 1], 1 on a convex sphere for most rays but not identically
+    pa = oracle.make_params(48, 48, origin=(0.0, 0.0, 1.0), fov=45.0, isovalue=0.5, ao_samples=8, ao_radius=0.1)
+    ia = oracle.render_gvdb(ov, pa, threads=2)
+    ha = ia[..., 3] == 1
+    assert (ia[..., 10][ha] > 0).all() and (ia[..., 10][ha] <= 1).all()
+    # thread count does not change a single bit
+    assert np.array_equal(oracle.render_gvdb(ov, p, threads=1).view(np.uint32), img.view(np.uint32))

@@ -21,3 +21,15 @@ for W, H in res:
         torch.cuda.synchronize()
         ms = r.profile_times_ms(); r.profile_enable(False)
         print("%dx%d variant %d: %.3f ms/frame (min %.3f max %.3f) checksum %.6f" % (W, H, variant, sum(ms) / len(ms), min(ms), max(ms), out[..., 3].sum().item()))
+    # semantics=gvdb (the CUDA renderer's arithmetic): camera distance 1.0 because the world is half the size
+    r.set_kernel_variant(0)
+    r.send_command("semantics", "gvdb"); r.send_command("isovalue", "0.250")
+    for k in range(3):
+        r.send_command("cameraOrigin", V.fmt3(V.orbit_camera(k, distance=1.0))); r.render_direct(out)
+    r.profile_enable(True)
+    for k in range(10):
+        r.send_command("cameraOrigin", V.fmt3(V.orbit_camera(5 + k, distance=1.0))); r.render_async(out, torch.cuda.current_stream())
+    torch.cuda.synchronize()
+    ms = r.profile_times_ms(); r.profile_enable(False)
+    print("%dx%d semantics=gvdb: %.3f ms/frame (min %.3f max %.3f) hit pixels %.0f" % (W, H, sum(ms) / len(ms), min(ms), max(ms), out[..., 3].sum().item()))
+    r.send_command("semantics", "cpu"); r.send_command("isovalue", "0.340")
