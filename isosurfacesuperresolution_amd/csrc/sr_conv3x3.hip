@@ -850,23 +850,43 @@ __global__ void wgrad_reduce_kernel(const float* __restrict__ slabs, int G, floa
     if (e >= 9 * 64 * 64) return;
     const int ci = e & 63, co = (e >> 6) & 63, tap = e >> 12;
     if (co0 + co >= Cout || ci0 + ci >= Cin) return;
-    float s = 0.0f;
-    for (int g = 0; g < G; ++g) s += slabs[(size_t)g * 9 * 64 * 64 + e];
-    dw[((size_t)(co0 + co) * Cin + (ci0 + ci)) * 9 + tap] = s;
+    // eight interleaved partial sums (slab g goes to sum g % 8) keep eight loads in flight; the order is fixed,
+    // so the result is bitwise reproducible run to run
+    float s[8] = { 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f };
+    const float* src = slabs + e;
+    int g = 0;
+    for (; g + 8 <= G; g += 8) {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) s[k] += src[(size_t)(g + k) * 9 * 64 * 64];
+    }
+    for (int k = 0; g < G; ++g, ++k) s[k] += src[(size_t)g * 9 * 64 * 64];
+    dw[((size_t)(co0 + co) * Cin + (ci0 + ci)) * 9 + tap] = ((s[0] + s[1]) + (s[2] + s[3])) + ((s[4] + s[5]) + (s[6] + s[7]));
 }
 
-// db[c] = sum over n,y,x of gz[n][c][y][x]; one workgroup per channel, fixed reduction order.
+// db[c] = sum over n,y,x of gz[n][c][y][x]; one workgroup per channel, fixed reduction order
+// (four interleaved partial sums per thread, float4 loads when the planes allow it).
 __global__ __launch_bounds__(256) void bias_grad_kernel(const float* __restrict__ gz, float* __restrict__ db,
                                                          int N, int C, long long HW)
 {
     __shared__ float red[256];
     const int c = blockIdx.x;
-    float s = 0.0f;
-    for (int n = 0; n < N; ++n) {
-        const float* src = gz + ((size_t)n * C + c) * HW;
-        for (long long i = threadIdx.x; i < HW; i += 256) s += src[i];
+    float s0 = 0.0f, s1 = 0.0f, s2 = 0.0f, s3 = 0.0f;
+    if ((HW & 3) == 0) {
+        const long long q = HW >> 2;
+        for (int n = 0; n < N; ++n) {
+            const float4* src = reinterpret_cast<const float4*>(gz + ((size_t)n * C + c) * HW);
+            for (long long i = threadIdx.x; i < q; i += 256) {
+                const float4 v = src[i];
+                s0 += v.x; s1 += v.y; s2 += v.z; s3 += v.w;
+            }
+        }
+    } else {
+        for (int n = 0; n < N; ++n) {
+            const float* src = gz + ((size_t)n * C + c) * HW;
+            for (long long i = threadIdx.x; i < HW; i += 256) s0 += src[i];
+        }
     }
-    red[threadIdx.x] = s;
+    red[threadIdx.x] = (s0 + s1) + (s2 + s3);
     __syncthreads();
     for (int off = 128; off > 0; off >>= 1) {
         if ((int)threadIdx.x < off) red[threadIdx.x] += red[threadIdx.x + off];
