@@ -35,6 +35,7 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--raymarch-variant", type=int, default=0)
     ap.add_argument("--no-overlap", action="store_true", help="render frame t and super-resolve it back to back on one stream")
+    ap.add_argument("--side-waves", type=int, default=0, help="wave cap of the overlapped ray-march (0 = 4 per CU)")
     return ap.parse_args()
 
 
@@ -82,6 +83,8 @@ def main():
     pipe.foreground_variant = args.raymarch_variant
     renderer.set_kernel_variant(args.raymarch_variant)
     overlap = not args.no_overlap
+    if args.side_waves > 0:
+        pipe.side_waves = args.side_waves
 
     K, Wm = args.steps, args.warmup
     first = rank * K                      # this rank's contiguous chunk of the orbit

@@ -84,7 +84,7 @@ int isoProfileEnable(int on);
 int isoProfileCount(void);
 int isoProfileGet(int i, float* ms);
 
-/* Variant 2 only: launch at most `waves` one-wave workgroups, each striding over the 8x8 pixel tiles
+/* Variant 2 only: launch at most `waves` one-wave workgroups, which pull the 8x8 pixel tiles from per-XCD queues
  * (0 = one per tile, the default).  4 x the CU count keeps one ray-march wave per SIMD, which is what
  * lets the next SR conv workgroup land on every CU while a frame renders on a side stream.
  * Returns 0, or -1 for a negative cap. */

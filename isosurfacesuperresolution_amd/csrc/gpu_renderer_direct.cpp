@@ -66,6 +66,7 @@ struct State {
     int semantics = 0;           // 0: reference CPU renderer (default), 1: reference CUDA renderer (setParameter("semantics", "gvdb"))
     float* aoHemi = nullptr;     // device copies of the AO tables
     float* aoRot = nullptr;
+    unsigned* tileQueue = nullptr;   // 8 per-XCD work counters of kernel variant 2
     bool profile = false;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> events;   // one pair per profiled frame
 };
@@ -201,6 +202,7 @@ bool uploadAoTables()
     }
     HIP_OK(hipMalloc(&g.aoHemi, hemi.size() * sizeof(float)));
     HIP_OK(hipMalloc(&g.aoRot, rot.size() * sizeof(float)));
+    if (!g.tileQueue) HIP_OK(hipMalloc(&g.tileQueue, 8 * sizeof(unsigned)));
     HIP_OK(hipMemcpy(g.aoHemi, hemi.data(), hemi.size() * sizeof(float), hipMemcpyHostToDevice));
     HIP_OK(hipMemcpy(g.aoRot, rot.data(), rot.size() * sizeof(float), hipMemcpyHostToDevice));
     return true;
@@ -446,6 +448,7 @@ bool launchFrame(float* out, hipStream_t stream)
     p.aoSamples = a.aoSamples < 0 ? 0 : (a.aoSamples > 512 ? 512 : a.aoSamples);   // GPURendererDirect.cpp:350
     p.aoRadius = double(a.aoRadius);
     p.aoHemi = g.aoHemi; p.aoRot = g.aoRot;
+    p.tileQueue = g.tileQueue;
     hipEvent_t e0 = nullptr, e1 = nullptr;
     if (g.profile) {
         if (hipEventCreate(&e0) == hipSuccess && hipEventCreate(&e1) == hipSuccess) g.events.emplace_back(e0, e1);
@@ -693,6 +696,8 @@ void isoShutdown(void)
     freeVolume(g.vol);
     if (g.aoHemi) (void)hipFree(g.aoHemi);
     if (g.aoRot) (void)hipFree(g.aoRot);
+    if (g.tileQueue) (void)hipFree(g.tileQueue);
+    g.tileQueue = nullptr;
     g.aoHemi = g.aoRot = nullptr;
     g.initialised = false;
 }

@@ -447,10 +447,23 @@ __global__ __launch_bounds__(64) void iso_render_gather(const IsoRenderParams P)
 template <bool AO>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void iso_render_gather_slim(const IsoRenderParams P)
 {
-    // the grid may be capped (a multiple of 8, so a wave's tiles stay on its XCD's share of the image):
-    // every wave then strides over the tiles, which bounds how many ray-march waves exist at any time
+    // The grid is capped and the waves PULL tiles: tile costs differ by several x (background vs. deep volume),
+    // and with a fixed stride the frame waits for the unluckiest wave.  One queue per XCD (its contiguous share
+    // of the image, as in xcd_remap, so neighbouring tiles keep sharing an L2); a wave whose own queue is empty
+    // steals from the next XCD's.  Every wave ends after 8 failed fetches: the grid always drains.
     const int tiles_x = (P.W + 7) >> 3, ntiles = tiles_x * ((P.H + 7) >> 3);
-    for (int vb = blockIdx.x; vb < ntiles; vb += gridDim.x) render_gather_tile<AO>(P, vb, tiles_x, ntiles);
+    const int q = ntiles >> 3, r = ntiles & 7, xcd = blockIdx.x & 7;
+    for (int s = 0; s < 8; ++s) {
+        const int k = (xcd + s) & 7;
+        const unsigned cnt = (unsigned)(q + (k < r ? 1 : 0));
+        for (;;) {
+            unsigned i = 0;
+            if (threadIdx.x == 0) i = atomicAdd(&P.tileQueue[k], 1u);
+            i = (unsigned)__builtin_amdgcn_readfirstlane((int)i);
+            if (i >= cnt) break;
+            render_gather_tile<AO>(P, (int)i * 8 + k, tiles_x, ntiles);
+        }
+    }
 }
 
 // ---- variant 1: wave-cooperative LDS brick cache --------------------------------------------
@@ -695,6 +708,7 @@ void iso_launch_render(const IsoRenderParams& p, int variant, void* stream, void
         else hipExtLaunchKernelGGL(iso_render_lds<false>, grid, block, 0, st, e0, e1, 0, p);
     } else if (variant == 2) {
         const dim3 capped(waveCap > 0 && waveCap < tiles ? (waveCap + 7) & ~7 : tiles);   // 0 = one wave per tile
+        (void)hipMemsetAsync(p.tileQueue, 0, 8 * sizeof(unsigned), st);
         if (p.aoSamples > 0) hipExtLaunchKernelGGL(iso_render_gather_slim<true>, capped, block, 0, st, e0, e1, 0, p);
         else hipExtLaunchKernelGGL(iso_render_gather_slim<false>, capped, block, 0, st, e0, e1, 0, p);
     } else {

@@ -40,6 +40,7 @@ struct IsoRenderParams {
     double aoRadius;             // world units
     const float* aoHemi;         // [512][4] cosine-hemisphere table
     const float* aoRot;          // [16][4] per-pixel (x%4, y%4) rotation vectors
+    unsigned* tileQueue;         // variant 2: 8 per-XCD tile counters, zeroed before the launch
 };
 
 // Per-frame constants of the `semantics=gvdb` kernel (iso_gvdb.hip), prepared in double and narrowed to float
