@@ -48,6 +48,7 @@ class SuperResolutionPipeline:
         self._render_stream = torch.cuda.Stream(device=device) if str(device).startswith("cuda") else None
         self._ready = [torch.cuda.Event(), torch.cuda.Event()] if self._render_stream else None
         self._consumed = [torch.cuda.Event(), torch.cuda.Event()] if self._render_stream else None
+        self._frame_start = torch.cuda.Event() if self._render_stream else None
         self._slot = 0
         self._prefetched = None           # (origin tuple, slot) of a render already in flight
         # a prefetched frame is rendered by the 128-register ray-marcher (kernel variant 2) with one wave per
@@ -80,7 +81,9 @@ class SuperResolutionPipeline:
         """Start rendering the G-buffer of ``origin`` on the side stream (used by ``frame(..., next_origin=)``)."""
         slot = self._slot ^ 1
         rs = self._render_stream
-        rs.wait_event(self._consumed[slot])              # the network has finished reading that buffer
+        rs.wait_event(self._consumed[slot])              # the network has finished reading that buffer ...
+        rs.wait_event(self._frame_start)                 # ... and so has anything the caller enqueued before this frame()
+                                                         # (``pipe.gbuffer`` stays valid until the next frame() call)
         self.renderer.send_command("cameraOrigin", fmt3(origin))
         self.renderer.set_kernel_variant(2)
         self.renderer.set_wave_cap(self.side_waves)
@@ -120,6 +123,8 @@ class SuperResolutionPipeline:
 
     def frame_fused(self, origin, next_origin=None):
         with torch.no_grad():
+            if next_origin is not None:
+                self._frame_start.record(torch.cuda.current_stream())
             g = self._acquire_gbuffer(origin)
             prev = self.previous if self.temporal else None
             flow = None

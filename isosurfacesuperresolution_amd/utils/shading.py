@@ -23,12 +23,18 @@ class ScreenSpaceShading(nn.Module):
         self._device = device
         self.enable_specular = True
         self.inverse_ao = False
+        self._host_vectors = {}
         self._background = self._vec(np.array([0.0, 0.0, 0.0]))
         self._eyedirs = dict()
 
     def _vec(self, a):
         assert isinstance(a, np.ndarray) and a.shape == (3,)
-        return torch.from_numpy(np.asarray(a, dtype=np.float64)).to(device=self._device, dtype=torch.float32).view(1, 3, 1, 1)
+        t = torch.from_numpy(np.asarray(a, dtype=np.float64)).to(dtype=torch.float32)
+        dev = t.to(device=self._device).view(1, 3, 1, 1)
+        # host copy of the float32 values for packed_parameters(): reading them back from the device tensor
+        # would synchronise the stream once per vector and frame
+        self._host_vectors[id(dev)] = (dev, [float(v) for v in t.tolist()])
+        return dev
 
     def fov(self, fov):
         assert isinstance(fov, (float, int))
@@ -82,7 +88,12 @@ class ScreenSpaceShading(nn.Module):
         vals = []
         for t in (self._ambient_light_color, self._diffuse_light_color, self._specular_light_color,
                   self._light_direction, self._material_color, self._background):
-            vals += [float(v) for v in t.reshape(-1).tolist()]
+            hit = self._host_vectors.get(id(t))
+            vals += hit[1] if hit is not None and hit[0] is t else [float(v) for v in t.reshape(-1).tolist()]
+        if len(self._host_vectors) > 64:      # setters called many times: drop copies of replaced vectors
+            live = {id(t) for t in (self._ambient_light_color, self._diffuse_light_color, self._specular_light_color,
+                                    self._light_direction, self._material_color, self._background)}
+            self._host_vectors = {k: v for k, v in self._host_vectors.items() if k in live}
         return vals
 
     def _get_eyedir(self, h, w):
