@@ -38,10 +38,12 @@ struct AssembleParams {
     int ao_inverted;
 };
 
-// one thread per low-res pixel; loops over the 4x4 hi-res positions and the 6 channels
+// one thread per (low-res pixel, dx): neighbouring lanes read neighbouring hi-res columns (the gathers of the
+// previous frame coalesce; one thread per low-res pixel read 4x its algorithmic bytes); loops over dy and 6 channels
 __global__ __launch_bounds__(256) void assemble_input_kernel(const AssembleParams p)
 {
-    const int x = blockIdx.x * blockDim.x + threadIdx.x;
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    const int x = t >> 2, dx = t & 3;
     const int y = blockIdx.y;
     if (x >= p.w) return;
     const size_t plane = (size_t)p.h * p.w;
@@ -49,26 +51,27 @@ __global__ __launch_bounds__(256) void assemble_input_kernel(const AssembleParam
     const float* g = p.gbuf + pix * 12;
     const float4 g0 = *reinterpret_cast<const float4*>(g);        // r g b mask
     const float4 g1 = *reinterpret_cast<const float4*>(g + 4);    // nx ny nz depth
-    p.out[0 * plane + pix] = g0.w * 2.0f - 1.0f;
-    p.out[1 * plane + pix] = g1.x;
-    p.out[2 * plane + pix] = g1.y;
-    p.out[3 * plane + pix] = g1.z;
-    p.out[4 * plane + pix] = g1.w;
+    if (dx == 0) {
+        p.out[0 * plane + pix] = g0.w * 2.0f - 1.0f;
+        p.out[1 * plane + pix] = g1.x;
+        p.out[2 * plane + pix] = g1.y;
+        p.out[3 * plane + pix] = g1.z;
+        p.out[4 * plane + pix] = g1.w;
+    }
     const int H = 4 * p.h, W = 4 * p.w;
     const size_t hplane = (size_t)H * W;
     float* o = p.out + 5 * plane + pix;
     if (!p.prev) {
         if (p.init_mode == 0) {
-#pragma unroll 4
-            for (int c = 0; c < 96; ++c) o[(size_t)c * plane] = 0.0f;
+            for (int c = 0; c < 6; ++c)
+                for (int dy = 0; dy < 4; ++dy) o[(size_t)(c * 16 + dy * 4 + dx) * plane] = 0.0f;
         } else if (p.init_mode == 1) {
             const float defaults[6] = { -1.f, 0.f, 0.f, 1.f, 0.5f, p.ao_inverted ? 0.f : 1.f };
             for (int c = 0; c < 6; ++c)
-                for (int k = 0; k < 16; ++k) o[(size_t)(c * 16 + k) * plane] = defaults[c];
+                for (int dy = 0; dy < 4; ++dy) o[(size_t)(c * 16 + dy * 4 + dx) * plane] = defaults[c];
         } else {
             // "input": bilinear x4 of (mask*2-1, normal, depth), remaining channel = 1
-            for (int dy = 0; dy < 4; ++dy)
-                for (int dx = 0; dx < 4; ++dx) {
+            for (int dy = 0; dy < 4; ++dy) {
                     int y0, y1, x0, x1; float ly, lx;
                     src_index(4 * y + dy, 0.25f, p.h, y0, y1, ly);
                     src_index(4 * x + dx, 0.25f, p.w, x0, x1, lx);
@@ -95,7 +98,7 @@ __global__ __launch_bounds__(256) void assemble_input_kernel(const AssembleParam
         const int Y = 4 * y + dy;
         int y0, y1; float ly;
         src_index(Y, 0.25f, p.h, y0, y1, ly);
-        for (int dx = 0; dx < 4; ++dx) {
+        {
             const int X = 4 * x + dx;
             int x0, x1; float lx;
             src_index(X, 0.25f, p.w, x0, x1, lx);
@@ -313,7 +316,7 @@ int isrAssembleInput(const float* gbuffer_hwc12, const float* flow_filled, const
     if (prev_high && !flow_filled) return -1;
     if (init_mode < 0 || init_mode > 2) return -1;
     AssembleParams p = { gbuffer_hwc12, flow_filled, prev_high, net_input, h, w, init_mode, ao_inverted };
-    hipLaunchKernelGGL(assemble_input_kernel, dim3((w + 255) / 256, h), dim3(256), 0, (hipStream_t)stream, p);
+    hipLaunchKernelGGL(assemble_input_kernel, dim3((4 * w + 255) / 256, h), dim3(256), 0, (hipStream_t)stream, p);
     return hipGetLastError() == hipSuccess ? 0 : -2;
 }
 
