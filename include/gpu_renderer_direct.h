@@ -90,6 +90,12 @@ int isoProfileGet(int i, float* ms);
  * Returns 0, or -1 for a negative cap. */
 int isoSetWaveCap(int waves);
 
+/* Enqueues a one-wave kernel on `stream` that returns once every wave of the most recently launched variant-2
+ * render has started (or after `timeoutUs`).  Put on the stream of the SR network right after the render was
+ * enqueued on its side stream, it makes the ray-march waves land on an idle GPU -- one per SIMD -- instead of racing
+ * the network's next kernel for slots.  Returns 0, -1 before initGVDB. */
+int isoGateResident(void* stream, int timeoutUs);
+
 /* Host-only helpers around the .vbx reader (no GPU needed): volume dims [x,y,z] of the dense box
  * spanned by the stored bricks, and the dense fp32 data [z][y][x] itself. 0 ok, -2 on failure. */
 int isoVbxInfo(const char* path, int dims[3]);

@@ -66,7 +66,8 @@ struct State {
     int semantics = 0;           // 0: reference CPU renderer (default), 1: reference CUDA renderer (setParameter("semantics", "gvdb"))
     float* aoHemi = nullptr;     // device copies of the AO tables
     float* aoRot = nullptr;
-    unsigned* tileQueue = nullptr;   // 8 per-XCD work counters of kernel variant 2
+    unsigned* tileQueue = nullptr;   // 8 per-XCD work counters of kernel variant 2 (+ 1 resident-wave counter)
+    unsigned residentTarget = 0;     // waves launched by all variant-2 renders so far (what the counter will reach)
     bool profile = false;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> events;   // one pair per profiled frame
 };
@@ -202,7 +203,11 @@ bool uploadAoTables()
     }
     HIP_OK(hipMalloc(&g.aoHemi, hemi.size() * sizeof(float)));
     HIP_OK(hipMalloc(&g.aoRot, rot.size() * sizeof(float)));
-    if (!g.tileQueue) HIP_OK(hipMalloc(&g.tileQueue, 8 * sizeof(unsigned)));
+    if (!g.tileQueue) {
+        HIP_OK(hipMalloc(&g.tileQueue, 16 * sizeof(unsigned)));
+        HIP_OK(hipMemset(g.tileQueue, 0, 16 * sizeof(unsigned)));
+        g.residentTarget = 0;
+    }
     HIP_OK(hipMemcpy(g.aoHemi, hemi.data(), hemi.size() * sizeof(float), hipMemcpyHostToDevice));
     HIP_OK(hipMemcpy(g.aoRot, rot.data(), rot.size() * sizeof(float), hipMemcpyHostToDevice));
     return true;
@@ -449,6 +454,7 @@ bool launchFrame(float* out, hipStream_t stream)
     p.aoRadius = double(a.aoRadius);
     p.aoHemi = g.aoHemi; p.aoRot = g.aoRot;
     p.tileQueue = g.tileQueue;
+    p.resident = g.tileQueue + 8;
     hipEvent_t e0 = nullptr, e1 = nullptr;
     if (g.profile) {
         if (hipEventCreate(&e0) == hipSuccess && hipEventCreate(&e1) == hipSuccess) g.events.emplace_back(e0, e1);
@@ -460,6 +466,10 @@ bool launchFrame(float* out, hipStream_t stream)
         iso_launch_render_gvdb(p, f, stream, e0, e1);
     } else {
         iso_launch_render(p, g.variant, stream, e0, e1, g.waveCap);
+        if (g.variant == 2) {
+            const int tiles = ((p.W + 7) >> 3) * ((p.H + 7) >> 3);
+            g.residentTarget += unsigned(g.waveCap > 0 && g.waveCap < tiles ? (g.waveCap + 7) & ~7 : tiles);
+        }
     }
     if (hipGetLastError() != hipSuccess) return false;
     // GPURendererDirect.cpp:440-442: the camera just rendered becomes the flow reference
@@ -646,6 +656,13 @@ int isoSetWaveCap(int waves)
     if (waves < 0) return -1;
     g.waveCap = waves;
     return 0;
+}
+
+int isoGateResident(void* stream, int timeoutUs)
+{
+    if (!g.initialised || !g.tileQueue || timeoutUs < 0) return -1;
+    iso_launch_gate(g.tileQueue + 8, g.residentTarget, timeoutUs, stream);
+    return hipGetLastError() == hipSuccess ? 0 : -1;
 }
 
 int isoSetKernelVariant(int variant)

@@ -451,6 +451,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
     // and with a fixed stride the frame waits for the unluckiest wave.  One queue per XCD (its contiguous share
     // of the image, as in xcd_remap, so neighbouring tiles keep sharing an L2); a wave whose own queue is empty
     // steals from the next XCD's.  Every wave ends after 8 failed fetches: the grid always drains.
+    if (threadIdx.x == 0) atomicAdd(P.resident, 1u);      // "this wave has a slot" -- see iso_gate_kernel
     const int tiles_x = (P.W + 7) >> 3, ntiles = tiles_x * ((P.H + 7) >> 3);
     const int q = ntiles >> 3, r = ntiles & 7, xcd = blockIdx.x & 7;
     for (int s = 0; s < 8; ++s) {
@@ -463,6 +464,24 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
             if (i >= cnt) break;
             render_gather_tile<AO>(P, (int)i * 8 + k, tiles_x, ntiles);
         }
+    }
+}
+
+// WHERE the capped ray-march waves land decides what the overlap costs: dispatched into an idle GPU they spread
+// one per SIMD; dispatched while another kernel is ramping up they pile onto the CUs that happen to be free, and
+// every CU with two of them on a SIMD is lost to the conv workgroups for the whole render (measured: the 480x270
+// conv layers 84 -> 130-200 us).  The frame pipeline therefore puts this one-wave kernel on the MAIN stream right
+// after it has enqueued the render on the side stream: it holds the main stream back until all ray-march waves have
+// reported in (or a timeout passes -- it must never wait for a render that is not coming).
+__global__ __launch_bounds__(64) void iso_gate_kernel(const unsigned* resident, unsigned target, long long timeoutTicks)
+{
+    if (threadIdx.x != 0) return;
+    const long long t0 = (long long)__builtin_amdgcn_s_memrealtime();      // 100 MHz
+    for (;;) {
+        const unsigned seen = __atomic_load_n(resident, __ATOMIC_RELAXED);
+        if ((int)(seen - target) >= 0) break;
+        if ((long long)__builtin_amdgcn_s_memrealtime() - t0 > timeoutTicks) break;
+        __builtin_amdgcn_s_sleep(8);
     }
 }
 
@@ -715,6 +734,11 @@ void iso_launch_render(const IsoRenderParams& p, int variant, void* stream, void
         if (p.aoSamples > 0) hipExtLaunchKernelGGL(iso_render_gather<true>, grid, block, 0, st, e0, e1, 0, p);
         else hipExtLaunchKernelGGL(iso_render_gather<false>, grid, block, 0, st, e0, e1, 0, p);
     }
+}
+
+void iso_launch_gate(const unsigned* resident, unsigned target, int timeoutUs, void* stream)
+{
+    hipLaunchKernelGGL(iso_gate_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, resident, target, (long long)timeoutUs * 100);
 }
 
 void iso_launch_brick_flags(const float* dense, int nx, int ny, int nz, int nbx, int nby, int nbz,

@@ -41,6 +41,7 @@ struct IsoRenderParams {
     const float* aoHemi;         // [512][4] cosine-hemisphere table
     const float* aoRot;          // [16][4] per-pixel (x%4, y%4) rotation vectors
     unsigned* tileQueue;         // variant 2: 8 per-XCD tile counters, zeroed before the launch
+    unsigned* resident;          // variant 2: every wave adds 1 when it starts (never reset; see iso_launch_gate)
 };
 
 // Per-frame constants of the `semantics=gvdb` kernel (iso_gvdb.hip), prepared in double and narrowed to float
@@ -62,6 +63,8 @@ struct IsoGvdbFrame {
 // waveCap: variant 2 only -- launch at most this many one-wave workgroups (0 = one per 8x8 tile)
 void iso_launch_render(const IsoRenderParams& p, int variant, void* stream, void* startEvent, void* stopEvent, int waveCap);
 void iso_launch_render_gvdb(const IsoRenderParams& p, const IsoGvdbFrame& f, void* stream, void* startEvent, void* stopEvent);
+// One wave on `stream` that spins until *resident has reached `target` (wrap-safe) or `timeoutUs` have passed.
+void iso_launch_gate(const unsigned* resident, unsigned target, int timeoutUs, void* stream);
 void iso_launch_brick_flags(const float* dense, int nx, int ny, int nz, int nbx, int nby, int nbz,
                             uint8_t* flag9, uint8_t* leaf, int* bbox6, unsigned int* maxbits, void* stream);
 void iso_launch_brick_fill(const float* dense, int nx, int ny, int nz, int nbx, int nby, int nbz,

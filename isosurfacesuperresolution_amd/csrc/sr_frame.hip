@@ -224,7 +224,7 @@ __global__ __launch_bounds__(1024) void flow_fill_kernel(const float* __restrict
     __shared__ FillLevel lv[20];
     __shared__ int nlev;
     const int tid = threadIdx.x;
-    const int gtid = blockIdx.x * 1024 + tid, gstride = gridDim.x * 1024;
+    const int gtid = blockIdx.x * blockDim.x + tid, gstride = gridDim.x * blockDim.x;
     if (tid == 0) {
         int ch = h, cw = w, n = 0;
         size_t off = 0;
@@ -329,12 +329,19 @@ long long isrFlowFillWorkspace(int h, int w)
 
 int isrFlowFill(const float* gbuffer_hwc12, float* flow_out, void* workspace, int h, int w, void* stream)
 {
+    return isrFlowFillEx(gbuffer_hwc12, flow_out, workspace, h, w, 1024, stream);
+}
+
+int isrFlowFillEx(const float* gbuffer_hwc12, float* flow_out, void* workspace, int h, int w, int threads, void* stream)
+{
     if (!gbuffer_hwc12 || !flow_out || !workspace || h <= 0 || w <= 0) return -1;
-    const int big = (h * w + 4 * 1024 - 1) / (4 * 1024);
+    if (threads != 64 && threads != 128 && threads != 256 && threads != 512 && threads != 1024) return -1;
+    const int per = 4 * threads;
+    const int big = (h * w + per - 1) / per;
     hipStream_t st = (hipStream_t)stream;
-    hipLaunchKernelGGL(flow_fill_kernel, dim3(big > 0 ? big : 1), dim3(1024), 0, st, gbuffer_hwc12, flow_out, (float*)workspace, h, w, 0);
-    hipLaunchKernelGGL(flow_fill_kernel, dim3(1), dim3(1024), 0, st, gbuffer_hwc12, flow_out, (float*)workspace, h, w, 1);
-    hipLaunchKernelGGL(flow_fill_kernel, dim3(4 * big > 0 ? 4 * big : 1), dim3(1024), 0, st, gbuffer_hwc12, flow_out, (float*)workspace, h, w, 2);
+    hipLaunchKernelGGL(flow_fill_kernel, dim3(big > 0 ? big : 1), dim3(threads), 0, st, gbuffer_hwc12, flow_out, (float*)workspace, h, w, 0);
+    hipLaunchKernelGGL(flow_fill_kernel, dim3(1), dim3(threads), 0, st, gbuffer_hwc12, flow_out, (float*)workspace, h, w, 1);
+    hipLaunchKernelGGL(flow_fill_kernel, dim3(4 * big > 0 ? 4 * big : 1), dim3(threads), 0, st, gbuffer_hwc12, flow_out, (float*)workspace, h, w, 2);
     return hipGetLastError() == hipSuccess ? 0 : -2;
 }
 

@@ -56,6 +56,8 @@ class DirectRenderer:
         lib.isoGetVolumeInfo.restype = ctypes.c_int
         lib.isoSetKernelVariant.argtypes = [ctypes.c_int]
         lib.isoSetKernelVariant.restype = ctypes.c_int
+        lib.isoGateResident.argtypes = [ctypes.c_void_p, ctypes.c_int]
+        lib.isoGateResident.restype = ctypes.c_int
         lib.isoSetWaveCap.argtypes = [ctypes.c_int]
         lib.isoSetWaveCap.restype = ctypes.c_int
         lib.isoProfileEnable.argtypes = [ctypes.c_int]
@@ -140,6 +142,10 @@ class DirectRenderer:
                 raise RuntimeError("isoProfileGet failed")
             out.append(ms.value)
         return out
+
+    def gate_resident(self, stream, timeout_us=100):
+        """Additive: see isoGateResident.  ``stream``: a torch.cuda.Stream."""
+        return self.lib.isoGateResident(ctypes.c_void_p(stream.cuda_stream), int(timeout_us))
 
     def set_wave_cap(self, waves):
         """Additive: see isoSetWaveCap (variant 2, side-stream rendering under the SR network)."""

@@ -47,6 +47,7 @@ def _sr():
         lib.isrConv3x3SmallCoutStrided.restype = ci
         lib.isrFlowFillWorkspace.argtypes = [ci, ci]; lib.isrFlowFillWorkspace.restype = ll
         lib.isrFlowFill.argtypes = [vp, vp, vp, ci, ci, vp]; lib.isrFlowFill.restype = ci
+        lib.isrFlowFillEx.argtypes = [vp, vp, vp, ci, ci, ci, vp]; lib.isrFlowFillEx.restype = ci
         lib.isrFinishFrame.argtypes = [vp, vp, vp, vp, ci, ci, vp, ci, cf, ci, ci, vp]; lib.isrFinishFrame.restype = ci
         lib.isrProfileEnable.argtypes = [ci]; lib.isrProfileEnable.restype = ci
         lib.isrProfileCount.argtypes = []; lib.isrProfileCount.restype = ci
@@ -326,17 +327,22 @@ def assemble_input(gbuffer_hwc, flow_filled, prev_high, initial_image="zero", ao
 _fill_ws = {}
 
 
-def fill_flow_gbuffer(gbuffer_hwc):
-    """Hole-filled flow [1,2,h,w] straight from the renderer's G-buffer [h,w,12] (``isrFlowFill``)."""
+def fill_flow_gbuffer(gbuffer_hwc, out=None, stream=None, threads=1024):
+    """Hole-filled flow [1,2,h,w] straight from the renderer's G-buffer [h,w,12] (``isrFlowFill``).
+    ``out`` / ``stream``: caller-owned result tensor and HIP stream (the frame pipeline fills the flow of the next
+    frame on its render stream, with 256-thread workgroups that fit beside the conv kernels); the pyramid workspace
+    is per (device, size, stream)."""
     lib = _sr()
     h, w = gbuffer_hwc.shape[0], gbuffer_hwc.shape[1]
-    key = (gbuffer_hwc.device, h, w)
+    st = torch.cuda.current_stream() if stream is None else stream
+    key = (gbuffer_hwc.device, h, w, st.cuda_stream)
     ws = _fill_ws.get(key)
     if ws is None:
         ws = torch.empty(lib.isrFlowFillWorkspace(h, w), dtype=torch.uint8, device=gbuffer_hwc.device)
         _fill_ws[key] = ws
-    out = torch.empty((1, 2, h, w), dtype=torch.float32, device=gbuffer_hwc.device)
-    rc = lib.isrFlowFill(_ptr(gbuffer_hwc), _ptr(out), _ptr(ws), h, w, _stream())
+    if out is None:
+        out = torch.empty((1, 2, h, w), dtype=torch.float32, device=gbuffer_hwc.device)
+    rc = lib.isrFlowFillEx(_ptr(gbuffer_hwc), _ptr(out), _ptr(ws), h, w, int(threads), ctypes.c_void_p(st.cuda_stream))
     if rc != 0:
         raise RuntimeError("isrFlowFill failed (%d)" % rc)
     return out

@@ -45,6 +45,9 @@ class SuperResolutionPipeline:
         # MFMA-bound network of the current one owns the main stream (the renderer does not depend on
         # the network's output).  Two G-buffers, two events per buffer.
         self._gbuffers = [self.gbuffer, torch.empty_like(self.gbuffer)]
+        # the hole-filled flow of a prefetched frame is computed on the render stream as well (it only needs the G-buffer)
+        self._flows = [torch.empty((1, 2, self.low_h, self.low_w), dtype=torch.float32, device=device) for _ in range(2)]
+        self._flow_ready = [False, False]
         self._render_stream = torch.cuda.Stream(device=device) if str(device).startswith("cuda") else None
         self._ready = [torch.cuda.Event(), torch.cuda.Event()] if self._render_stream else None
         self._consumed = [torch.cuda.Event(), torch.cuda.Event()] if self._render_stream else None
@@ -89,6 +92,9 @@ class SuperResolutionPipeline:
         self.renderer.set_wave_cap(self.side_waves)
         self.renderer.render_async(self._gbuffers[slot], rs)
         self.renderer.set_kernel_variant(self.foreground_variant)
+        self._flow_ready[slot] = self.fused and self.temporal
+        if self._flow_ready[slot]:
+            ops.fill_flow_gbuffer(self._gbuffers[slot], out=self._flows[slot], stream=rs, threads=256)
         self._ready[slot].record(rs)
         self._prefetched = (tuple(origin), slot)
 
@@ -101,6 +107,7 @@ class SuperResolutionPipeline:
             self._prefetched = None
         else:
             slot = self._slot
+            self._flow_ready[slot] = False
             self.renderer.send_command("cameraOrigin", fmt3(origin))
             self.renderer.render_async(self._gbuffers[slot], cur)
         self._slot = slot
@@ -126,14 +133,17 @@ class SuperResolutionPipeline:
             if next_origin is not None:
                 self._frame_start.record(torch.cuda.current_stream())
             g = self._acquire_gbuffer(origin)
+            if next_origin is not None:
+                # the next frame's render goes first, and this stream waits until its waves sit one per SIMD on the
+                # (momentarily idle) GPU; launched later they would race the network's kernels for slots
+                self.prefetch(next_origin)
+                self.renderer.gate_resident(torch.cuda.current_stream())
             prev = self.previous if self.temporal else None
             flow = None
             if prev is not None:
-                flow = ops.fill_flow_gbuffer(g)
+                flow = self._flows[self._slot] if self._flow_ready[self._slot] else ops.fill_flow_gbuffer(g)
             x = ops.assemble_input(g, flow, prev, self.model.initial_image_mode, self.model.inverse_ao)
             self._consumed[self._slot].record(torch.cuda.current_stream())   # G-buffer no longer needed
-            if next_origin is not None:
-                self.prefetch(next_origin)
             feat = self.model.model.forward_features(x)
             self.shading.inverse_ao = self.model.inverse_ao
             raw, rgb = ops.finish_frame(feat, x, self.shading)
