@@ -214,3 +214,25 @@ def test_gvdb_semantics_parity_with_restatement(renderer, oracle, case):
             last = origin
     finally:
         assert renderer.send_command("semantics", "cpu") == 0
+
+
+def test_residency_gate_returns(renderer):
+    """isoGateResident: a one-wave kernel that waits for the waves of the last variant-2 render; with that render
+    already finished (or none launched at all) it must return at once, never block the stream."""
+    import time
+    import torch
+    vol = V.ejecta(64)
+    renderer.load_dense(vol)
+    s = torch.cuda.current_stream()
+    assert renderer.gate_resident(s, 100) == 0                  # nothing launched yet
+    renderer.set_kernel_variant(2)
+    renderer.set_wave_cap(64)
+    _render_gpu(renderer, 160, 90, V.quantize3(V.orbit_camera(3)), 30.0, 0.34)
+    renderer.set_kernel_variant(0)
+    renderer.set_wave_cap(0)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    assert renderer.gate_resident(s, 100000) == 0               # 0.1 s timeout must not be needed
+    torch.cuda.synchronize()
+    assert time.perf_counter() - t0 < 0.05
+    assert renderer.gate_resident(s, -1) == -1
