@@ -92,11 +92,11 @@ __device__ __forceinline__ float buf_load(rsrc_t r, unsigned voff)
 constexpr unsigned PLAN_BAD = 0x80000000u;
 constexpr unsigned PLAN_DX = 1u << 29, PLAN_DY = 1u << 30, PLAN_OFF = 0x1FFFFFFCu;
 
-template <bool UPS, int CHUNK_ = CHUNK>
+template <bool UPS, int CHUNK_ = CHUNK, int PLANE_ = PLANE>
 __device__ __forceinline__ unsigned plan_element(const ConvParams& p, int e, int oy0, int ox0)
 {
-    const int c = e / PLANE;
-    const int rem = e - c * PLANE;
+    const int c = e / PLANE_;
+    const int rem = e - c * PLANE_;
     const int r = rem / PW;
     const int col = rem - r * PW;
     const int gy = oy0 + r - 1, gx = ox0 + col - 1;
@@ -134,8 +134,8 @@ __device__ __forceinline__ float finish_element(unsigned w, const float (&raw)[U
     return hy * (hx * raw[0] + lx * raw[1]) + ly * (hx * raw[2] + lx * raw[3]);
 }
 
-template <int MT>
-__device__ __forceinline__ void conv_epilogue(const ConvParams& p, f32x16 (&acc)[MT][4], float* smem, int n, int oy0, int ox0,
+template <int MT, int R = 4>
+__device__ __forceinline__ void conv_epilogue(const ConvParams& p, f32x16 (&acc)[MT][R], float* smem, int n, int oy0, int ox0,
                                               int co0, int wave, int lane);
 
 template <int MT, bool UPS>
@@ -334,8 +334,8 @@ __global__ __launch_bounds__(NTHREADS, 1) void conv3x3_fwd_kernel(const ConvPara
 }
 
 
-template <int MT>
-__device__ __forceinline__ void conv_epilogue(const ConvParams& p, f32x16 (&acc)[MT][4], float* smem, int n, int oy0, int ox0,
+template <int MT, int R>
+__device__ __forceinline__ void conv_epilogue(const ConvParams& p, f32x16 (&acc)[MT][R], float* smem, int n, int oy0, int ox0,
                                               int co0, int wave, int lane)
 {
     const int j = lane & 31, kh = lane >> 5;
@@ -365,8 +365,8 @@ __device__ __forceinline__ void conv_epilogue(const ConvParams& p, f32x16 (&acc)
         // bound at ~7 B/clk/CU).  Bias/activation are applied on the way in, the residual on the way out.
         float* tr = smem + wave * (64 * 32);
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int oy = oy0 + wave * 4 + r;
+        for (int r = 0; r < R; ++r) {
+            const int oy = oy0 + wave * R + r;
 #pragma unroll
             for (int m = 0; m < MT; ++m)
 #pragma unroll
@@ -400,8 +400,8 @@ __device__ __forceinline__ void conv_epilogue(const ConvParams& p, f32x16 (&acc)
     } else {
     const unsigned khoff = (unsigned)(4 * kh) * (unsigned)planeBytes, rkhoff = (unsigned)(4 * kh) * (unsigned)rplaneBytes;
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-        const int oy = oy0 + wave * 4 + r;
+    for (int r = 0; r < R; ++r) {
+        const int oy = oy0 + wave * R + r;
         const bool pix_ok = ox < p.W && oy < p.H && !(p.dbg & 2);
         const unsigned pix = pix_ok ? (unsigned)((oy * p.W + ox) * 4) + khoff : BAD_OFFSET;
         const unsigned rpix = pix_ok ? (unsigned)((oy * p.W + ox) * 4) + rkhoff : BAD_OFFSET;
@@ -442,28 +442,43 @@ __device__ __forceinline__ void conv_epilogue(const ConvParams& p, f32x16 (&acc)
 // align_corners=False: odd pixels weigh the pair .75/.25, even pixels .25/.75; clamping the source
 // coordinates to the image reproduces the border rule).  One thread does a whole quad: 4 loads and 16
 // FMAs for 4 patch elements instead of 16 loads and 28 FMAs, two ds_write_b64.
+//
+// R = output rows per wave: 4 (tile 16x32) or 1 (tile 4x32).  The small tile is for small problems (the 32x32
+// training crops, 128x128 previews): a 64->64 layer on 16 crops is 64 workgroups of the big tile for 512 slots,
+// 256 of the small one; per workgroup it stages the same weights for a quarter of the MFMAs, which only pays when
+// the GPU would otherwise idle.
 constexpr int CK2 = 8;
-constexpr int CHUNK2 = CK2 * PLANE;                                  // 4896 floats
-constexpr int NEL2 = (CHUNK2 + NTHREADS - 1) / NTHREADS;             // 20 patch elements per thread and chunk
-constexpr int QUADS2 = 9 * 17;                                       // per channel
-constexpr int NQ2 = QUADS2 * CK2;                                    // 1224 quads per chunk
-constexpr int NQT2 = (NQ2 + NTHREADS - 1) / NTHREADS;                // 5 per thread
+template <int R> struct Geo2 {
+    static constexpr int TH_ = 4 * R;                                    // tile rows
+    static constexpr int PH_ = TH_ + 2;                                  // patch rows
+    static constexpr int PLANE_ = PH_ * PW;                              // floats per channel plane (612 / 204)
+    static constexpr int CHUNK_ = CK2 * PLANE_;                          // 4896 / 1632 floats
+    static constexpr int NEL_ = (CHUNK_ + NTHREADS - 1) / NTHREADS;      // 20 / 7 patch elements per thread and chunk
+    static constexpr int QUADS_ = (PH_ / 2) * 17;                        // 2x2 quads per channel (x2 loader)
+    static constexpr int NQ_ = QUADS_ * CK2;                             // 1224 / 408 quads per chunk
+    static constexpr int NQT_ = (NQ_ + NTHREADS - 1) / NTHREADS;         // 5 / 2 per thread
+    static constexpr int PSTRIDE_ = CHUNK_ + 4 * NTHREADS;               // patch buffer + its sink
+};
 constexpr int WCH2 = 9 * CK2 * 32;                                   // 2304 weight floats per chunk
 constexpr int NW42 = WCH2 / 4;                                       // 576 float4
 constexpr int NWI2 = (NW42 + NTHREADS - 1) / NTHREADS;               // 3 per thread
 constexpr int KSTEPS2 = CK2 / 2;                                     // 4 k-steps per tap
 constexpr int NSLOTS2 = 9 * KSTEPS2;                                 // 36 k-steps per chunk = staging slots
 constexpr int DUMP2 = 4 * NTHREADS;                                  // write-only sink behind each patch buffer
-constexpr int PSTRIDE2 = CHUNK2 + DUMP2;                             // patch buffer + its sink
-// LDS: [2][WCH2] weights, then 2 x ([CHUNK2] patch, [DUMP2] sink): a masked-off staging lane keeps its
-// offset and lands in the sink of whichever buffer is being filled.
-constexpr size_t conv_fwd2_lds_bytes() { return (size_t)(2 * WCH2 + 2 * PSTRIDE2) * sizeof(float); }
+// LDS: [2][WCH2] weights, then 2 x ([CHUNK_] patch, [DUMP2] sink): a masked-off staging lane keeps its
+// offset and lands in the sink of whichever buffer is being filled.  (The epilogue transposes through the first
+// 4 x 8 KB of it.)
+template <int R>
+constexpr size_t conv_fwd2_lds_bytes() { return (size_t)(2 * WCH2 + 2 * Geo2<R>::PSTRIDE_) * sizeof(float); }
+static_assert(conv_fwd2_lds_bytes<1>() >= 4 * 64 * 32 * sizeof(float), "epilogue slab");
 
 constexpr unsigned Q_DX = 1u, Q_DY = 2u, Q_VX0 = 4u, Q_VX1 = 8u, Q_VY0 = 16u, Q_VY1 = 32u;   // aux bits; LDS float offset << 8
 
-template <bool UPS>
+template <bool UPS, int R>
 __global__ __launch_bounds__(NTHREADS, 2) void conv3x3_fwd2_kernel(const ConvParams p)
 {
+    typedef Geo2<R> G;
+    constexpr int PLANE_ = G::PLANE_, CHUNK2 = G::CHUNK_, NEL2 = G::NEL_, QUADS2 = G::QUADS_, NQ2 = G::NQ_, NQT2 = G::NQT_, PSTRIDE2 = G::PSTRIDE_;
     constexpr int NEL = UPS ? NQT2 : NEL2;      // patch staging items per thread and chunk
     constexpr int NLD = UPS ? 4 : 1;            // loads per item
     constexpr int NITEMS = NEL + NWI2;
@@ -481,14 +496,14 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv3x3_fwd2_kernel(const ConvPar
     const int n = bid / tilesPerImage;
     const int t = bid - n * tilesPerImage;
     const int ty = t / p.tilesX, tx = t - ty * p.tilesX;
-    const int oy0 = ty * TH, ox0 = tx * TW;
+    const int oy0 = ty * G::TH_, ox0 = tx * TW;
     const int co0 = p.co0 + grp * 32;
 
     unsigned long long st0 = 0, st1 = 0, st2 = 0;
     if (p.dbg & 8) st0 = __builtin_amdgcn_s_memtime();
-    f32x16 acc[1][4];
+    f32x16 acc[1][R];
 #pragma unroll
-    for (int r = 0; r < 4; ++r)
+    for (int r = 0; r < R; ++r)
 #pragma unroll
         for (int i = 0; i < 16; ++i) acc[0][r][i] = 0.0f;
 
@@ -528,11 +543,11 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv3x3_fwd2_kernel(const ConvPar
             if ((unsigned)(gy + 1) < (unsigned)p.H) f |= Q_VY1;
             const bool exists = qi < NQ2;
             plan[i] = exists ? (unsigned)((c * p.xPlane + r0 * p.Win + c0) * 4) : PLAN_BAD;
-            aux[i] = f | (unsigned)(exists ? c * PLANE + (2 * a) * PW + 2 * b : CHUNK2 + 2 * tid) << 8;
+            aux[i] = f | (unsigned)(exists ? c * PLANE_ + (2 * a) * PW + 2 * b : CHUNK2 + 2 * tid) << 8;
         }
     } else {
 #pragma unroll
-        for (int i = 0; i < NEL; ++i) plan[i] = plan_element<false, CHUNK2>(p, tid + i * NTHREADS, oy0, ox0);
+        for (int i = 0; i < NEL; ++i) plan[i] = plan_element<false, CHUNK2, PLANE_>(p, tid + i * NTHREADS, oy0, ox0);
     }
     // weights: float4 f = tid + 256 i of the chunk's [9][CK2][32] block; f = tap*64 + k*8 + c4
     unsigned woff[NWI2];
@@ -596,27 +611,27 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv3x3_fwd2_kernel(const ConvPar
 
     const int j = lane & 31;
     const int kh = lane >> 5;
-    auto load_ops = [&](float& a, float (&b)[4], const float* w_, const float* p_, int kk) {
+    auto load_ops = [&](float& a, float (&b)[R], const float* w_, const float* p_, int kk) {
         a = w_[(2 * kk) * 32];
 #pragma unroll
-        for (int r = 0; r < 4; ++r) b[r] = p_[(2 * kk) * PLANE + r * PW];
+        for (int r = 0; r < R; ++r) b[r] = p_[(2 * kk) * PLANE_ + r * PW];
     };
-    auto mfma_step = [&](float a, const float (&b)[4]) {
+    auto mfma_step = [&](float a, const float (&b)[R]) {
 #pragma unroll
-        for (int r = 0; r < 4; ++r) acc[0][r] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b[r], acc[0][r], 0, 0, 0);
+        for (int r = 0; r < R; ++r) acc[0][r] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b[r], acc[0][r], 0, 0, 0);
     };
 
     for (int chunk = 0; chunk < nchunks; ++chunk) {
         const int buf = chunk & 1;
         const bool more = chunk + 1 < nchunks && !(p.dbg & 1);
-        const float* pb = patch0 + buf * PSTRIDE2 + kh * PLANE + (wave * 4) * PW + j;
+        const float* pb = patch0 + buf * PSTRIDE2 + kh * PLANE_ + (wave * R) * PW + j;
         const float* wb = wlds0 + buf * WCH2 + kh * 32 + j;
         float* const pfill = patch0 + (buf ^ 1) * PSTRIDE2;          // buffer being filled (+ its sink)
         float* const pnext = pfill + tid;
         float4* const wnext = reinterpret_cast<float4*>(wlds0 + (buf ^ 1) * WCH2) + tid;
         const rsrc_t rsn = chunk_rsrc(chunk + 1);
         wchunk += wchunkStep;                       // now the next chunk's weight rows (only read when `more`)
-        float a0, b0[4], a1, b1[4];
+        float a0, b0[R], a1, b1[R];
         float raw[NEL][NLD];
         float4 wraw[NWI2];
         load_ops(a0, b0, wb, pb, 0);
@@ -669,6 +684,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv3x3_fwd2_kernel(const ConvPar
             }
         };
         static_assert(20 + 3 * (NQT2 - 1) < NSLOTS2 - NWI2 && 2 * NQT2 + NWI2 <= 20, "UPS staging schedule");
+        static_assert(CHUNK2 + 2 * NTHREADS + PW + 2 <= PSTRIDE2, "the quad sink must stay inside the buffer's sink");
         auto run_taps = [&](auto MORE) {
 #pragma unroll
         for (int tap = 0; tap < 9; ++tap) {
@@ -699,7 +715,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv3x3_fwd2_kernel(const ConvPar
         __syncthreads();
     }
     if (p.dbg & 8) st2 = __builtin_amdgcn_s_memtime();
-    conv_epilogue<1>(p, acc, smem, n, oy0, ox0, co0, wave, lane);
+    conv_epilogue<1, R>(p, acc, smem, n, oy0, ox0, co0, wave, lane);
     if ((p.dbg & 8) && tid == 0 && p.stamps) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         const unsigned long long st3 = __builtin_amdgcn_s_memtime();
@@ -917,6 +933,7 @@ static hipEvent_t pool_event()
 }
 
 static int g_conv_dbg = 0;
+static int g_conv_tile = 0;   // 0: automatic, 1: always 4x32 tiles, 2: always 16x32 tiles (tools / tests)
 static int g_conv_algo = 1;   // 0: one workgroup per CU (64 channels), 1: two per CU (32 channels each)
 static unsigned long long* g_conv_stamps = nullptr;
 
@@ -944,7 +961,8 @@ int isrProfileGet(int i, int* variant, double* flops, float* ms)
 }
 
 void isrDebugSetAblation(int bits) { g_conv_dbg = bits; }
-void isrDebugSetForwardAlgo(int a) { g_conv_algo = a; }   // not part of the public header
+void isrDebugSetForwardAlgo(int a) { g_conv_algo = a; }
+void isrDebugSetForwardTile(int t) { g_conv_tile = t; }   // not part of the public header
 void isrDebugSetStampBuffer(void* p) { g_conv_stamps = (unsigned long long*)p; }
 
 int isrConvCinPad(int Cin) { return ((Cin + CK - 1) / CK) * CK; }
@@ -1022,21 +1040,36 @@ int isrConv3x3ForwardStrided(const float* x, const float* wprep, const float* bi
         // two workgroups per CU, one 32-channel group each; the grid covers all groups of all tiles
         static bool attr2_done = false;
         if (!attr2_done) {
-            (void)hipFuncSetAttribute((const void*)conv3x3_fwd2_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)conv_fwd2_lds_bytes());
-            (void)hipFuncSetAttribute((const void*)conv3x3_fwd2_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)conv_fwd2_lds_bytes());
+            (void)hipFuncSetAttribute((const void*)conv3x3_fwd2_kernel<true, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)conv_fwd2_lds_bytes<4>());
+            (void)hipFuncSetAttribute((const void*)conv3x3_fwd2_kernel<false, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)conv_fwd2_lds_bytes<4>());
             attr2_done = true;
         }
         p.co0 = 0;
         p.cgroups = p.coutPad / 32;
         if (nwg * p.cgroups > 0x7fffffffLL) return -1;
+        // small problems: 4x32 tiles (one row per wave) when the 16x32 tiling would leave most of the 2 x #CU slots empty
+        const long long tilesY4 = (H + 3) / 4, nwgSmall = (long long)N * p.tilesX * tilesY4 * p.cgroups;
+        const bool small = (g_conv_tile == 1) || (g_conv_tile == 0 && nwg * p.cgroups < 384 && nwgSmall <= 0x7fffffffLL);
+        if (small) {
+            p.tilesY = (int)tilesY4;
+            hipEvent_t e0 = nullptr, e1 = nullptr;
+            if (g_profile) {
+                e0 = pool_event(); e1 = pool_event();
+                g_records.push_back({ 10 + (upsample2x ? 1 : 0), 2.0 * 9 * Cin * Cout * (double)N * H * W, e0, e1 });
+            }
+            const dim3 grid1((unsigned)nwgSmall);
+            if (upsample2x) hipExtLaunchKernelGGL((conv3x3_fwd2_kernel<true, 1>), grid1, block, conv_fwd2_lds_bytes<1>(), s, e0, e1, 0, p);
+            else hipExtLaunchKernelGGL((conv3x3_fwd2_kernel<false, 1>), grid1, block, conv_fwd2_lds_bytes<1>(), s, e0, e1, 0, p);
+            return hipGetLastError() == hipSuccess ? 0 : -2;
+        }
         hipEvent_t e0 = nullptr, e1 = nullptr;
         if (g_profile) {
             e0 = pool_event(); e1 = pool_event();
             g_records.push_back({ 8 + (upsample2x ? 1 : 0), 2.0 * 9 * Cin * Cout * (double)N * H * W, e0, e1 });
         }
         const dim3 grid2((unsigned)(nwg * p.cgroups));
-        if (upsample2x) hipExtLaunchKernelGGL((conv3x3_fwd2_kernel<true>), grid2, block, conv_fwd2_lds_bytes(), s, e0, e1, 0, p);
-        else hipExtLaunchKernelGGL((conv3x3_fwd2_kernel<false>), grid2, block, conv_fwd2_lds_bytes(), s, e0, e1, 0, p);
+        if (upsample2x) hipExtLaunchKernelGGL((conv3x3_fwd2_kernel<true, 4>), grid2, block, conv_fwd2_lds_bytes<4>(), s, e0, e1, 0, p);
+        else hipExtLaunchKernelGGL((conv3x3_fwd2_kernel<false, 4>), grid2, block, conv_fwd2_lds_bytes<4>(), s, e0, e1, 0, p);
         return hipGetLastError() == hipSuccess ? 0 : -2;
     }
     // one launch per group of up to 64 output channels (2 M tiles per wave)

@@ -66,6 +66,20 @@ def test_conv3x3_forward(case):
     assert err <= 1e-4, err
 
 
+@pytest.mark.parametrize("tile", [1, 2])
+@pytest.mark.parametrize("case", [c for c in CASES if c[2] > 8 or c[8]])
+def test_conv3x3_forward_both_tilings(case, tile):
+    """The forward kernel has a 16x32 and a 4x32 tiling (picked by problem size); both must give the reference
+    result on every case, whatever the heuristic would choose."""
+    from isosurfacesuperresolution_amd import ops
+    lib = ops._sr()
+    lib.isrDebugSetForwardTile(tile)
+    try:
+        test_conv3x3_forward(case)
+    finally:
+        lib.isrDebugSetForwardTile(0)
+
+
 def test_conv3x3_padded_channel_planes():
     """Tensors with padded channel planes (ops.empty_planes) go through the strided C entry points unchanged."""
     from isosurfacesuperresolution_amd import ops
