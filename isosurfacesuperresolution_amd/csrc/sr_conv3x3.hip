@@ -793,45 +793,91 @@ struct WGradParams {
     int tilesX, tilesY, ntiles;
 };
 
+// Staging is branch-free and software pipelined: the next tile's 8 + 51 elements per thread are fetched through
+// buffer descriptors (out-of-image / out-of-range channels read 0) into registers BEFORE the tile's MFMA block and
+// parked in LDS after it.  TAPS = 9: one workgroup accumulates all taps (144 accumulator registers per wave);
+// TAPS = 3: three workgroups share a tile set, one row of the 3x3 each -- three times the workgroups for small
+// problems (the 32x32 training crops are 128 tiles for 256 CUs).
+template <int TAPS>
 __global__ __launch_bounds__(NTHREADS, 1) void conv3x3_wgrad_kernel(const WGradParams p)
 {
     __shared__ float gzs[64 * GZ_STRIDE];
     __shared__ float xps[64 * XP_PLANE];
+    constexpr int TG = 9 / TAPS;                       // workgroups per slab
+    constexpr int NGZ = 64 * WG_PX / NTHREADS;         // 32 gz elements per thread and tile
+    constexpr int NXE = (64 * (WG_TH + 2) * XP_W + NTHREADS - 1) / NTHREADS;   // 51 x elements
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int m = wave >> 1, nn = wave & 1;
     const int j = lane & 31, kh = lane >> 5;
+    const int g = blockIdx.x / TG, tap0 = (blockIdx.x - g * TG) * TAPS, nslab = gridDim.x / TG;
 
-    f32x16 acc[9];
+    f32x16 acc[TAPS];
 #pragma unroll
-    for (int t = 0; t < 9; ++t)
+    for (int t = 0; t < TAPS; ++t)
 #pragma unroll
         for (int i = 0; i < 16; ++i) acc[t][i] = 0.0f;
 
+    // per-thread element descriptors, tile invariant: gz element i = (channel c, pixel px) -> LDS slot + (ry, rx);
+    // x element i = (channel c, patch row r, patch column col)
+    unsigned xdesc[NXE];
+#pragma unroll
+    for (int i = 0; i < NXE; ++i) {
+        const int e = tid + i * NTHREADS;
+        const int c = e / ((WG_TH + 2) * XP_W), rem = e - c * ((WG_TH + 2) * XP_W);
+        const int r = rem / XP_W, col = rem - r * XP_W;
+        xdesc[i] = e < 64 * (WG_TH + 2) * XP_W ? (unsigned)(c | (r << 8) | (col << 16)) : 0xFFFFFFFFu;
+    }
+    const size_t planeBytes = (size_t)p.H * p.W * 4;
     const int tilesPerImage = p.tilesX * p.tilesY;
-    for (int tile = blockIdx.x; tile < p.ntiles; tile += gridDim.x) {
+    float gv[NGZ], xv[NXE];
+
+    auto fetch = [&](int tile) {
         const int n = tile / tilesPerImage;
         const int t2 = tile - n * tilesPerImage;
         const int ty = t2 / p.tilesX, tx = t2 - ty * p.tilesX;
         const int oy0 = ty * WG_TH, ox0 = tx * WG_TW;
-        __syncthreads();   // previous tile fully consumed
-        for (int e = tid; e < 64 * WG_PX; e += NTHREADS) {
-            const int c = e / WG_PX, px = e - c * WG_PX;
-            const int ry = px / WG_TW, rx = px - ry * WG_TW;
-            const int co = p.co0 + c, gy = oy0 + ry, gx = ox0 + rx;
-            float v = 0.0f;
-            if (co < p.Cout && gy < p.H && gx < p.W) v = p.gz[(((size_t)n * p.Cout + co) * p.H + gy) * p.W + gx];
-            gzs[c * GZ_STRIDE + px] = v;
+        const int gzc = p.Cout - p.co0, xc = p.Cin - p.ci0;
+        const rsrc_t grs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.gz + ((size_t)n * p.Cout + p.co0) * p.H * p.W), 0,
+                                                             (int)((gzc < 64 ? gzc : 64) * planeBytes), 0x00020000);
+        const rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.x + ((size_t)n * p.Cin + p.ci0) * p.H * p.W), 0,
+                                                             (int)((xc < 64 ? xc : 64) * planeBytes), 0x00020000);
+#pragma unroll
+        for (int i = 0; i < NGZ; ++i) {
+            const int e = tid + i * NTHREADS;
+            const int c = e >> 7, px = e & 127, ry = px >> 5, rx = px & 31;
+            const int gy = oy0 + ry, gx = ox0 + rx;
+            const bool ok = gy < p.H && gx < p.W;
+            gv[i] = buf_load(grs, ok ? (unsigned)((c * p.H + gy) * p.W + gx) * 4u : BAD_OFFSET);
         }
-        for (int e = tid; e < 64 * (WG_TH + 2) * XP_W; e += NTHREADS) {
-            const int c = e / ((WG_TH + 2) * XP_W), rem = e - c * ((WG_TH + 2) * XP_W);
-            const int r = rem / XP_W, col = rem - r * XP_W;
-            const int ci = p.ci0 + c, gy = oy0 + r - 1, gx = ox0 + col - 1;
-            float v = 0.0f;
-            if (ci < p.Cin && (unsigned)gy < (unsigned)p.H && (unsigned)gx < (unsigned)p.W)
-                v = p.x[(((size_t)n * p.Cin + ci) * p.H + gy) * p.W + gx];
-            xps[c * XP_PLANE + r * XP_W + col] = v;
+#pragma unroll
+        for (int i = 0; i < NXE; ++i) {
+            const unsigned d = xdesc[i];
+            const int c = d & 255, r = (d >> 8) & 255, col = (d >> 16) & 255;
+            const int gy = oy0 + r - 1, gx = ox0 + col - 1;
+            const bool ok = d != 0xFFFFFFFFu && (unsigned)gy < (unsigned)p.H && (unsigned)gx < (unsigned)p.W;
+            xv[i] = buf_load(xrs, ok ? (unsigned)((c * p.H + gy) * p.W + gx) * 4u : BAD_OFFSET);
         }
-        __syncthreads();
+    };
+    auto park = [&]() {
+#pragma unroll
+        for (int i = 0; i < NGZ; ++i) {
+            const int e = tid + i * NTHREADS;
+            gzs[(e >> 7) * GZ_STRIDE + (e & 127)] = gv[i];
+        }
+#pragma unroll
+        for (int i = 0; i < NXE; ++i) {
+            const unsigned d = xdesc[i];
+            if (d != 0xFFFFFFFFu) xps[(d & 255) * XP_PLANE + ((d >> 8) & 255) * XP_W + ((d >> 16) & 255)] = xv[i];
+        }
+    };
+
+    int tile = g;
+    if (tile < p.ntiles) { fetch(tile); park(); }
+    __syncthreads();
+    for (; tile < p.ntiles; tile += nslab) {
+        const bool more = tile + nslab < p.ntiles;
+        if (more) fetch(tile + nslab);
+        __builtin_amdgcn_sched_barrier(0);               // the loads stay above the MFMA block
         const float* ga = &gzs[(m * 32 + j) * GZ_STRIDE + kh];
         const float* xb = &xps[(nn * 32 + j) * XP_PLANE + kh];
 #pragma unroll
@@ -840,22 +886,26 @@ __global__ __launch_bounds__(NTHREADS, 1) void conv3x3_wgrad_kernel(const WGradP
             for (int rx = 0; rx < WG_TW; rx += 2) {
                 const float a = ga[ry * WG_TW + rx];
 #pragma unroll
-                for (int tap = 0; tap < 9; ++tap) {
-                    const int dy = tap / 3, dx = tap - dy * 3;
-                    const float b = xb[(ry + dy) * XP_W + rx + dx];
-                    acc[tap] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[tap], 0, 0, 0);
+                for (int t = 0; t < TAPS; ++t) {
+                    const int tap = TAPS == 9 ? t : -1;
+                    const int dy = TAPS == 9 ? tap / 3 : 0, dx = TAPS == 9 ? tap - dy * 3 : t;
+                    const float b = xb[(ry + (TAPS == 9 ? dy : tap0 / 3)) * XP_W + rx + dx];
+                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[t], 0, 0, 0);
                 }
             }
         }
+        __syncthreads();                                 // everyone has finished reading this tile
+        if (more) park();
+        __syncthreads();
     }
     // slab[g][tap][co(64)][ci(64)]
-    float* slab = p.slabs + (size_t)blockIdx.x * 9 * 64 * 64;
+    float* slab = p.slabs + (size_t)g * 9 * 64 * 64;
 #pragma unroll
-    for (int tap = 0; tap < 9; ++tap)
+    for (int t = 0; t < TAPS; ++t)
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
             const int co = m * 32 + (i & 3) + 8 * (i >> 2) + 4 * kh;
-            slab[((size_t)tap * 64 + co) * 64 + nn * 32 + j] = acc[tap][i];
+            slab[((size_t)(tap0 + t) * 64 + co) * 64 + nn * 32 + j] = acc[t][i];
         }
 }
 
@@ -1123,11 +1173,14 @@ int isrConv3x3WeightGrad(const float* x, const float* gz, float* dw, float* db, 
     const long long nt = (long long)N * p.tilesX * p.tilesY;
     if (nt > 0x7fffffffLL) return -1;
     p.ntiles = (int)nt;
+    if ((long long)(Cin < 64 ? Cin : 64) * H * W * 4 > 0x7fffffffLL || (long long)(Cout < 64 ? Cout : 64) * H * W * 4 > 0x7fffffffLL) return -1;
     const int G = p.ntiles < WGRAD_MAX_SLABS ? p.ntiles : WGRAD_MAX_SLABS;
+    const bool split = G <= 192;        // few tiles: one workgroup per row of the 3x3 instead of one per tile set
     for (int co0 = 0; co0 < Cout; co0 += 64)
         for (int ci0 = 0; ci0 < Cin; ci0 += 64) {
             p.co0 = co0; p.ci0 = ci0;
-            hipLaunchKernelGGL(conv3x3_wgrad_kernel, dim3(G), dim3(NTHREADS), 0, s, p);
+            if (split) hipLaunchKernelGGL(conv3x3_wgrad_kernel<3>, dim3(3 * G), dim3(NTHREADS), 0, s, p);
+            else hipLaunchKernelGGL(conv3x3_wgrad_kernel<9>, dim3(G), dim3(NTHREADS), 0, s, p);
             hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((9 * 64 * 64 + 255) / 256), dim3(256), 0, s,
                                p.slabs, G, dw, Cout, Cin, co0, ci0);
         }
