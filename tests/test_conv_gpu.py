@@ -283,3 +283,31 @@ def test_strip_super_resolution_is_bit_identical_on_gpu():
                 assert torch.equal(torch.cat([p[0] for p in parts], dim=2), full_raw), (step, world)
                 assert torch.equal(torch.cat([p[1] for p in parts], dim=2), full_rgb), (step, world)
         prev = full_raw
+
+
+def test_config4_clips_rendered_here_train_with_temporal_loss():
+    """BASELINE config #4 in miniature (tools/config4_cloud.py runs the 512^3 version): a cloud volume, clips of 3
+    frames rendered by this package's ray-marcher (low + 4x ground truth with ray-cast AO), 32^2 crops, EnhanceNet
+    training steps with the temp-l2 loss and the warped previous-frame recurrence; the loss must fall."""
+    from isosurfacesuperresolution_amd import models, losses, train, volumes as V
+    from isosurfacesuperresolution_amd.dataset_video import render_clip
+    from isosurfacesuperresolution_amd.inference import DirectRenderer
+    r = DirectRenderer()
+    r.load_dense(V.cloud(64))
+    clips = [render_clip(r, [V.orbit_camera(8 * c + k, K=64, distance=1.8, pitch=0.3) for k in range(3)], (64, 40),
+                         isovalue=0.30, ao_samples=4, ao_radius=0.05) for c in range(2)]
+    lo = torch.from_numpy(np.stack([c[1][:, :, 4:36, 16:48] for c in clips])).cuda()
+    fl = torch.from_numpy(np.stack([c[2][:, :, 4:36, 16:48] for c in clips])).cuda()
+    hi = torch.from_numpy(np.stack([c[0][:, :, 16:144, 64:192] for c in clips])).cuda()
+    assert lo.shape == (2, 3, 5, 32, 32) and hi.shape == (2, 3, 6, 128, 128) and fl.shape == (2, 3, 2, 32, 32)
+    assert float((lo[:, :, 0] > 0).float().mean()) > 0.3                       # the crops see the cloud
+    assert float(hi[:, :, 5].min()) >= 0 and float(hi[:, :, 5].max()) <= 1      # AO target channel
+    opt = argparse.Namespace(upsample='bilinear', reconType='residual', useBN=False, numResidualLayers=10,
+                             losses="l1:mask:1,l1:ao:1,l1:normal:10,l1:depth:10,temp-l2:color:0.1",
+                             lossAO=0.0, lossAmbient=0.1, lossDiffuse=0.9, lossSpecular=0.0)
+    torch.manual_seed(124)
+    net = models.createNetwork('EnhanceNet', 4, 101, [0, 1, 2, 3, 4], 6, opt).cuda()
+    crit = losses.LossNetUnshaded('cuda', 5, 6, 128, 16, opt).cuda()
+    optim, _ = train.make_optimizer(net)
+    hist = [train.train_step(net, crit, optim, (lo, fl, hi), initial_image="zero") for _ in range(5)]
+    assert all(np.isfinite(hist)) and hist[-1] < hist[0], hist
