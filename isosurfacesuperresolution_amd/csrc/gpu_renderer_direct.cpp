@@ -468,7 +468,7 @@ bool launchFrame(float* out, hipStream_t stream)
         iso_launch_render(p, g.variant, stream, e0, e1, g.waveCap);
         if (g.variant == 2) {
             const int tiles = ((p.W + 7) >> 3) * ((p.H + 7) >> 3);
-            g.residentTarget += unsigned(g.waveCap > 0 && g.waveCap < tiles ? (g.waveCap + 7) & ~7 : tiles);
+            g.residentTarget += unsigned(g.waveCap > 0 && g.waveCap < tiles ? (g.waveCap + 7) & ~7 : (tiles + 7) & ~7);
         }
     }
     if (hipGetLastError() != hipSuccess) return false;

@@ -404,10 +404,9 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg)
 
 // ---- variant 0: per-lane gather ------------------------------------------------------------
 template <bool AO>
-__device__ __forceinline__ void render_gather_tile(const IsoRenderParams& P, int vb, int tiles_x, int ntiles)
+__device__ __forceinline__ void render_gather_tile(const IsoRenderParams& P, int vb, int tiles_x, int ntiles, int lane)
 {
     const int tile = xcd_remap(vb, ntiles);
-    const int lane = threadIdx.x;
     const int i = (tile % tiles_x) * 8 + (lane & 7);
     const int j = (tile / tiles_x) * 8 + (lane >> 3);
     if (i >= P.W || j >= P.H) return;
@@ -427,7 +426,7 @@ template <bool AO>
 __device__ __forceinline__ void render_gather_pixel(const IsoRenderParams& P)
 {
     const int tiles_x = (P.W + 7) >> 3, ntiles = tiles_x * ((P.H + 7) >> 3);
-    render_gather_tile<AO>(P, blockIdx.x, tiles_x, ntiles);
+    render_gather_tile<AO>(P, blockIdx.x, tiles_x, ntiles, threadIdx.x);
 }
 
 template <bool AO>
@@ -445,13 +444,16 @@ __global__ __launch_bounds__(64) void iso_render_gather(const IsoRenderParams P)
 // conv workgroup off that CU), hence the wave cap: 4 x #CUs waves, striding over the tiles.
 // Same instructions on the same values: results are bit-identical to variant 0.
 template <bool AO>
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void iso_render_gather_slim(const IsoRenderParams P)
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) void iso_render_gather_slim(const IsoRenderParams P)
 {
+    // workgroups of FOUR independent waves: the hardware spreads the waves of a workgroup over the four SIMDs of its
+    // CU, so 'one workgroup per CU' is 'one wave per SIMD', and 256 workgroups dispatch 4x faster than 1024
+    const int lane = threadIdx.x & 63;
     // The grid is capped and the waves PULL tiles: tile costs differ by several x (background vs. deep volume),
     // and with a fixed stride the frame waits for the unluckiest wave.  One queue per XCD (its contiguous share
     // of the image, as in xcd_remap, so neighbouring tiles keep sharing an L2); a wave whose own queue is empty
     // steals from the next XCD's.  Every wave ends after 8 failed fetches: the grid always drains.
-    if (threadIdx.x == 0) atomicAdd(P.resident, 1u);      // "this wave has a slot" -- see iso_gate_kernel
+    if (lane == 0) atomicAdd(P.resident, 1u);             // "this wave has a slot" -- see iso_gate_kernel
     const int tiles_x = (P.W + 7) >> 3, ntiles = tiles_x * ((P.H + 7) >> 3);
     const int q = ntiles >> 3, r = ntiles & 7, xcd = blockIdx.x & 7;
     for (int s = 0; s < 8; ++s) {
@@ -459,10 +461,10 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
         const unsigned cnt = (unsigned)(q + (k < r ? 1 : 0));
         for (;;) {
             unsigned i = 0;
-            if (threadIdx.x == 0) i = atomicAdd(&P.tileQueue[k], 1u);
+            if (lane == 0) i = atomicAdd(&P.tileQueue[k], 1u);
             i = (unsigned)__builtin_amdgcn_readfirstlane((int)i);
             if (i >= cnt) break;
-            render_gather_tile<AO>(P, (int)i * 8 + k, tiles_x, ntiles);
+            render_gather_tile<AO>(P, (int)i * 8 + k, tiles_x, ntiles, lane);
         }
     }
 }
@@ -726,10 +728,11 @@ void iso_launch_render(const IsoRenderParams& p, int variant, void* stream, void
         if (p.aoSamples > 0) hipExtLaunchKernelGGL(iso_render_lds<true>, grid, block, 0, st, e0, e1, 0, p);
         else hipExtLaunchKernelGGL(iso_render_lds<false>, grid, block, 0, st, e0, e1, 0, p);
     } else if (variant == 2) {
-        const dim3 capped(waveCap > 0 && waveCap < tiles ? (waveCap + 7) & ~7 : tiles);   // 0 = one wave per tile
+        const int waves = waveCap > 0 && waveCap < tiles ? (waveCap + 7) & ~7 : (tiles + 7) & ~7;   // 0 = one wave per tile
+        const dim3 capped(waves / 4), block4(256);                                                  // 4 waves per workgroup
         (void)hipMemsetAsync(p.tileQueue, 0, 8 * sizeof(unsigned), st);
-        if (p.aoSamples > 0) hipExtLaunchKernelGGL(iso_render_gather_slim<true>, capped, block, 0, st, e0, e1, 0, p);
-        else hipExtLaunchKernelGGL(iso_render_gather_slim<false>, capped, block, 0, st, e0, e1, 0, p);
+        if (p.aoSamples > 0) hipExtLaunchKernelGGL(iso_render_gather_slim<true>, capped, block4, 0, st, e0, e1, 0, p);
+        else hipExtLaunchKernelGGL(iso_render_gather_slim<false>, capped, block4, 0, st, e0, e1, 0, p);
     } else {
         if (p.aoSamples > 0) hipExtLaunchKernelGGL(iso_render_gather<true>, grid, block, 0, st, e0, e1, 0, p);
         else hipExtLaunchKernelGGL(iso_render_gather<false>, grid, block, 0, st, e0, e1, 0, p);
