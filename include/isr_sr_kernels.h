@@ -89,7 +89,8 @@ int isrAssembleInput(const float* gbuffer_hwc12, const float* flow_filled, const
  * cv.inpaint call (inference/loadedmodel.py:77-82).  flow_out: [2][h][w].  Three launches. */
 long long isrFlowFillWorkspace(int h, int w);
 int isrFlowFill(const float* gbuffer_hwc12, float* flow_out, void* workspace, int h, int w, void* stream);
-/* ... with `threads` (64..1024, a power of two) per workgroup instead of 1024.  256 = one wave per SIMD: the three
+/* ... with `threads` (64..1024, a power of two) per workgroup of the two grid-wide launches instead of 1024 (the
+ * single-workgroup pyramid pass in between always uses 1024).  256 = one wave per SIMD: the three
  * launches then fit beside the SR network's conv workgroups when the fill of the NEXT frame runs on a side stream
  * (1024-thread workgroups evict conv workgroups from their CU and cost the network more than the fill takes). */
 int isrFlowFillEx(const float* gbuffer_hwc12, float* flow_out, void* workspace, int h, int w, int threads, void* stream);

@@ -448,6 +448,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvParams& p, f32x16 (&acc)
 // 256 of the small one; per workgroup it stages the same weights for a quarter of the MFMAs, which only pays when
 // the GPU would otherwise idle.
 constexpr int CK2 = 8;
+constexpr int DUMP2 = 4 * NTHREADS;                                  // write-only sink behind each patch buffer
 template <int R> struct Geo2 {
     static constexpr int TH_ = 4 * R;                                    // tile rows
     static constexpr int PH_ = TH_ + 2;                                  // patch rows
@@ -457,14 +458,13 @@ template <int R> struct Geo2 {
     static constexpr int QUADS_ = (PH_ / 2) * 17;                        // 2x2 quads per channel (x2 loader)
     static constexpr int NQ_ = QUADS_ * CK2;                             // 1224 / 408 quads per chunk
     static constexpr int NQT_ = (NQ_ + NTHREADS - 1) / NTHREADS;         // 5 / 2 per thread
-    static constexpr int PSTRIDE_ = CHUNK_ + 4 * NTHREADS;               // patch buffer + its sink
+    static constexpr int PSTRIDE_ = CHUNK_ + DUMP2;                      // patch buffer + its sink
 };
 constexpr int WCH2 = 9 * CK2 * 32;                                   // 2304 weight floats per chunk
 constexpr int NW42 = WCH2 / 4;                                       // 576 float4
 constexpr int NWI2 = (NW42 + NTHREADS - 1) / NTHREADS;               // 3 per thread
 constexpr int KSTEPS2 = CK2 / 2;                                     // 4 k-steps per tap
 constexpr int NSLOTS2 = 9 * KSTEPS2;                                 // 36 k-steps per chunk = staging slots
-constexpr int DUMP2 = 4 * NTHREADS;                                  // write-only sink behind each patch buffer
 // LDS: [2][WCH2] weights, then 2 x ([CHUNK_] patch, [DUMP2] sink): a masked-off staging lane keeps its
 // offset and lands in the sink of whichever buffer is being filled.  (The epilogue transposes through the first
 // 4 x 8 KB of it.)

