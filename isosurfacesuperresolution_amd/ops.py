@@ -99,7 +99,7 @@ def prepare_weights(weight, transpose_flip=False):
 # dispatch packets themselves (isrProfile*), which does not add stream operations.
 VARIANT_NAMES = {6: "conv3x3_small_cout_kernel", 2: "conv3x3_fwd_kernel<1,false>", 3: "conv3x3_fwd_kernel<1,true>",
                  4: "conv3x3_fwd_kernel<2,false>", 5: "conv3x3_fwd_kernel<2,true>",
-                 8: "conv3x3_fwd2_kernel<false>", 9: "conv3x3_fwd2_kernel<true>",
+                 8: "conv3x3_fwd2_kernel<false,4>", 9: "conv3x3_fwd2_kernel<true,4>",
                  10: "conv3x3_fwd2_kernel<false,1>", 11: "conv3x3_fwd2_kernel<true,1>"}
 
 
