@@ -103,6 +103,13 @@ int isrFlowFillEx(const float* gbuffer_hwc12, float* flow_out, void* workspace, 
 int isrFinishFrame(const float* raw, const float* net_input, float* next_prev, float* rgb, int h, int w,
                    const float* shading24, int exponent, float ao_strength, int inverse_ao, int enable_specular, void* stream);
 
+/* The frame's last layer and isrFinishFrame in ONE launch: conv3x3(x [Cin][4h][4w], 64 -> 6) + bias feeds the per-pixel
+ * finishing code directly (no [6][4h][4w] round trip through memory).  w8 / bias8 from isrConvSmallPrepare for Cout = 6;
+ * x may have padded channel planes (xPlane floats apart); the other arguments are those of isrFinishFrame. */
+int isrConvSmallFinishFrame(const float* x, const float* w8, const float* bias8, const float* net_input, float* next_prev, float* rgb,
+                            int Cin, int h, int w, long long xPlane, const float* shading24, int exponent, float ao_strength,
+                            int inverse_ao, int enable_specular, void* stream);
+
 /* Optional per-dispatch timing of isrConv3x3Forward for benchmarks: while enabled, every forward
  * dispatch carries a start/stop event pair on its own packet (no extra stream operations).
  * isrProfileEnable(1) clears the records and starts recording, (0) stops.  After synchronising the

@@ -26,6 +26,7 @@
 #include <vector>
 
 #include "../../include/isr_sr_kernels.h"
+#include "sr_finish.h"
 
 namespace {
 
@@ -1228,6 +1229,8 @@ struct SmallConvParams {
     int tilesX, tilesY;
     int act; float slope;
     long long xPlane, xImage;                  // channel / batch strides of x in floats (y and residual are packed)
+    int finish;                                // 1: instead of storing y, finish the frame per pixel (fin; N == 1, Cout == 6)
+    FinishParams fin;
 };
 
 __global__ __launch_bounds__(256, 2) void conv3x3_small_cout_kernel(const SmallConvParams p)
@@ -1329,6 +1332,22 @@ __global__ __launch_bounds__(256, 2) void conv3x3_small_cout_kernel(const SmallC
     // D register i of group g = channel 4g + i, lane = pixel column
     const int ox = ox0 + lane;
     const size_t plane = (size_t)p.H * p.W;
+    if (p.finish) {
+        // the frame's last layer: clamp / normalise / shade right here instead of a 50 MB round trip through memory
+        // and another launch (isrFinishFrame); the six channels of a pixel sit in this lane's accumulators
+        if (ox < p.W) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int oy = oy0 + 4 * wave + r;
+                if (oy >= p.H) break;
+                float v[6];
+#pragma unroll
+                for (int co = 0; co < 6; ++co) v[co] = acc[co >> 2][r][co & 3] + p.bias8[co];
+                isr_finish_pixel(p.fin, ox, oy, v);
+            }
+        }
+        return;
+    }
     if (ox < p.W) {
 #pragma unroll
         for (int g = 0; g < 2; ++g)
@@ -1403,6 +1422,7 @@ int isrConv3x3SmallCoutStrided(const float* x, const float* w8, const float* bia
     p.tilesX = (W + SM_TW - 1) / SM_TW; p.tilesY = (H + SM_TH - 1) / SM_TH;
     p.act = act; p.slope = slope;
     p.xPlane = xPlane; p.xImage = xImage;
+    p.finish = 0;
     const long long nwg = (long long)N * p.tilesX * p.tilesY;
     if (nwg > 0x7fffffffLL) return -1;
     hipEvent_t e0 = nullptr, e1 = nullptr;
@@ -1411,6 +1431,30 @@ int isrConv3x3SmallCoutStrided(const float* x, const float* w8, const float* bia
         g_records.push_back({ 6, 2.0 * 9 * Cin * Cout * (double)N * H * W, e0, e1 });
     }
     hipExtLaunchKernelGGL(conv3x3_small_cout_kernel, dim3((unsigned)nwg), dim3(256), 0, (hipStream_t)stream, e0, e1, 0, p);
+    return hipGetLastError() == hipSuccess ? 0 : -2;
+}
+
+int isrConvSmallFinishFrame(const float* x, const float* w8, const float* bias8, const float* net_input, float* next_prev, float* rgb,
+                            int Cin, int h, int w, long long xPlane, const float* shading24, int exponent, float ao_strength,
+                            int inverse_ao, int enable_specular, void* stream)
+{
+    if (!x || !w8 || !bias8 || !net_input || !next_prev || Cin <= 0 || h <= 0 || w <= 0 || (rgb && !shading24)) return -1;
+    const int H = 4 * h, W = 4 * w;
+    if (xPlane < (long long)H * W || (long long)Cin * xPlane * 4 >= (1LL << 31)) return -1;
+    SmallConvParams p;
+    p.x = x; p.wq = w8; p.bias8 = bias8; p.residual = nullptr; p.y = nullptr;
+    p.N = 1; p.Cin = Cin; p.H = H; p.W = W; p.Cout = 6;
+    p.tilesX = (W + SM_TW - 1) / SM_TW; p.tilesY = (H + SM_TH - 1) / SM_TH;
+    p.act = ISR_ACT_NONE; p.slope = 0.f;
+    p.xPlane = xPlane; p.xImage = (long long)Cin * xPlane;
+    p.finish = 1;
+    isr_fill_finish_params(p.fin, nullptr, net_input, next_prev, rgb, h, w, shading24, exponent, ao_strength, inverse_ao, enable_specular);
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    if (g_profile) {
+        e0 = pool_event(); e1 = pool_event();
+        g_records.push_back({ 6, 2.0 * 9 * Cin * 6 * (double)H * W, e0, e1 });
+    }
+    hipExtLaunchKernelGGL(conv3x3_small_cout_kernel, dim3((unsigned)(p.tilesX * p.tilesY)), dim3(256), 0, (hipStream_t)stream, e0, e1, 0, p);
     return hipGetLastError() == hipSuccess ? 0 : -2;
 }
 

@@ -49,6 +49,8 @@ def _sr():
         lib.isrFlowFill.argtypes = [vp, vp, vp, ci, ci, vp]; lib.isrFlowFill.restype = ci
         lib.isrFlowFillEx.argtypes = [vp, vp, vp, ci, ci, ci, vp]; lib.isrFlowFillEx.restype = ci
         lib.isrFinishFrame.argtypes = [vp, vp, vp, vp, ci, ci, vp, ci, cf, ci, ci, vp]; lib.isrFinishFrame.restype = ci
+        lib.isrConvSmallFinishFrame.argtypes = [vp, vp, vp, vp, vp, vp, ci, ci, ci, ll, vp, ci, cf, ci, ci, vp]
+        lib.isrConvSmallFinishFrame.restype = ci
         lib.isrProfileEnable.argtypes = [ci]; lib.isrProfileEnable.restype = ci
         lib.isrProfileCount.argtypes = []; lib.isrProfileCount.restype = ci
         lib.isrProfileGet.argtypes = [ci, vp, vp, vp]; lib.isrProfileGet.restype = ci
@@ -347,6 +349,32 @@ def fill_flow_gbuffer(gbuffer_hwc, out=None, stream=None, threads=1024):
     if rc != 0:
         raise RuntimeError("isrFlowFill failed (%d)" % rc)
     return out
+
+
+def final_conv_finish(features, weight, bias, net_input, shading=None):
+    """The network's last layer (64 -> 6, no activation) and ``finish_frame`` in one launch
+    (``isrConvSmallFinishFrame``): features [1,Cin,4h,4w] (channel planes may be padded), net_input [1,>=5,h,w]
+    -> (next_prev [1,6,4h,4w], rgb [1,3,4h,4w] or None)."""
+    assert features.is_cuda and features.shape[0] == 1 and weight.shape[0] == 6
+    lib = _sr()
+    w8, b8 = _prepare_small(weight, bias)
+    features, xp, _ = _plane_strides(features)
+    net_input = net_input.contiguous()
+    _, cin, H, W = features.shape
+    h, w = H // 4, W // 4
+    nxt = torch.empty((1, 6, H, W), dtype=torch.float32, device=features.device)
+    rgb, params = None, None
+    exponent, ao, inv, spec = 1, 0.0, 0, 0
+    if shading is not None:
+        rgb = torch.empty((1, 3, H, W), dtype=torch.float32, device=features.device)
+        params = (ctypes.c_float * 18)(*shading.packed_parameters())
+        exponent, ao = int(shading._specular_exponent), float(shading._ao)
+        inv, spec = int(bool(shading.inverse_ao)), int(bool(shading.enable_specular))
+    rc = lib.isrConvSmallFinishFrame(_ptr(features), _ptr(w8), _ptr(b8), _ptr(net_input), _ptr(nxt), _ptr(rgb), cin, h, w, xp,
+                                     params, exponent, ao, inv, spec, _stream())
+    if rc != 0:
+        raise RuntimeError("isrConvSmallFinishFrame failed (%d)" % rc)
+    return nxt, rgb
 
 
 def finish_frame(raw, net_input, shading=None):

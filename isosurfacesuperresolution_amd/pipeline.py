@@ -144,9 +144,14 @@ class SuperResolutionPipeline:
                 flow = self._flows[self._slot] if self._flow_ready[self._slot] else ops.fill_flow_gbuffer(g)
             x = ops.assemble_input(g, flow, prev, self.model.initial_image_mode, self.model.inverse_ao)
             self._consumed[self._slot].record(torch.cuda.current_stream())   # G-buffer no longer needed
-            feat = self.model.model.forward_features(x)
+            net = self.model.model
             self.shading.inverse_ao = self.model.inverse_ao
-            raw, rgb = ops.finish_frame(feat, x, self.shading)
+            last = net.postblock[8]
+            if last.weight.shape[0] == 6:
+                # the last layer's epilogue finishes the frame (one launch, no [6,4h,4w] round trip)
+                raw, rgb = ops.final_conv_finish(net.forward_features(x, last_layer=False), last.weight, last.bias, x, self.shading)
+            else:
+                raw, rgb = ops.finish_frame(net.forward_features(x), x, self.shading)
             self.previous = raw
         return rgb, raw
 

@@ -220,6 +220,12 @@ def test_fused_frame_kernels_match_module_path():
                 raw_b, rgb_b = ops.finish_frame(feat, x, sh)
             assert (raw_a - raw_b).abs().max().item() <= 1e-4, (mode, step)
             assert (rgb_a - rgb_b).abs().max().item() <= 1e-4, (mode, step)
+            # ... and the last layer fused with the finishing (isrConvSmallFinishFrame) gives the same frame (the shading
+            # arithmetic is inlined into another kernel, where the compiler may contract different multiply-adds)
+            with torch.no_grad():
+                last = net.postblock[8]
+                raw_c, rgb_c = ops.final_conv_finish(net.forward_features(x, last_layer=False), last.weight, last.bias, x, sh)
+            assert torch.equal(raw_c, raw_b) and (rgb_c - rgb_b).abs().max().item() <= 1e-6, (mode, step)
             prev_a, prev_b = raw_a, raw_b
 
 
