@@ -317,3 +317,31 @@ def test_config4_clips_rendered_here_train_with_temporal_loss():
     optim, _ = train.make_optimizer(net)
     hist = [train.train_step(net, crit, optim, (lo, fl, hi), initial_image="zero") for _ in range(5)]
     assert all(np.isfinite(hist)) and hist[-1] < hist[0], hist
+
+
+@pytest.mark.parametrize("low", [(61, 35), (97, 3), (33, 64)])
+def test_pipeline_ragged_sizes_fused_vs_module_path(low):
+    """The fused frame path (side-stream render + gate, fused assembly, HIP convs with both tilings, last layer +
+    finishing in one launch) against the module-level path at sizes that are multiples of nothing."""
+    from isosurfacesuperresolution_amd import models, volumes as V
+    from isosurfacesuperresolution_amd.inference import DirectRenderer, LoadedModel
+    from isosurfacesuperresolution_amd.pipeline import SuperResolutionPipeline, default_shading
+    opt = argparse.Namespace(upsample='bilinear', reconType='residual', useBN=False, numResidualLayers=10)
+    torch.manual_seed(3)
+    net = models.createNetwork('EnhanceNet', 4, 101, [0, 1, 2, 3, 4], 6, opt)
+    lm = LoadedModel.from_model(net, "cuda", parameters={"initialImage": "zero"})
+    r = DirectRenderer()
+    r.load_dense(V.ejecta(64))
+    outs = []
+    for fused in (True, False):
+        pipe = SuperResolutionPipeline(r, lm, default_shading("cuda", 30.0), low, fused=fused)
+        pipe.set_static(fov=30.0, isovalue=0.34)
+        seq = []
+        for k in range(3):
+            rgb, raw = pipe.frame(V.orbit_camera(k), V.orbit_camera(k + 1) if fused else None)
+            seq.append((rgb.clone(), raw.clone()))
+        torch.cuda.synchronize()
+        outs.append(seq)
+    for (rgb_a, raw_a), (rgb_b, raw_b) in zip(*outs):
+        assert rgb_a.shape == (1, 3, 4 * low[1], 4 * low[0])
+        assert (raw_a - raw_b).abs().max().item() <= 1e-4 and (rgb_a - rgb_b).abs().max().item() <= 1e-4
