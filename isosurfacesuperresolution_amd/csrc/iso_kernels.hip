@@ -453,7 +453,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
     // and with a fixed stride the frame waits for the unluckiest wave.  One queue per XCD (its contiguous share
     // of the image, as in xcd_remap, so neighbouring tiles keep sharing an L2); a wave whose own queue is empty
     // steals from the next XCD's.  Every wave ends after 8 failed fetches: the grid always drains.
-    if (lane == 0) atomicAdd(P.resident, 1u);             // "this wave has a slot" -- see iso_gate_kernel
+    if (threadIdx.x == 0) atomicAdd(P.resident, 4u);      // "this workgroup's four waves have their slots" -- see
+                                                          // iso_gate_kernel; one atomic per workgroup: 1024 on one address serialise
     const int tiles_x = (P.W + 7) >> 3, ntiles = tiles_x * ((P.H + 7) >> 3);
     const int q = ntiles >> 3, r = ntiles & 7, xcd = blockIdx.x & 7;
     for (int s = 0; s < 8; ++s) {
