@@ -345,3 +345,18 @@ def test_pipeline_ragged_sizes_fused_vs_module_path(low):
     for (rgb_a, raw_a), (rgb_b, raw_b) in zip(*outs):
         assert rgb_a.shape == (1, 3, 4 * low[1], 4 * low[0])
         assert (raw_a - raw_b).abs().max().item() <= 1e-4 and (rgb_a - rgb_b).abs().max().item() <= 1e-4
+
+
+def test_reference_checkpoint_on_the_hip_kernels(tmp_path):
+    """The reference-format checkpoint fixture (tests/golden/make_checkpoint_fixture.py) loaded onto the GPU: the HIP
+    convolutions reproduce the reference network's own CPU output within 1e-4."""
+    import zipfile
+    from isosurfacesuperresolution_amd import inference
+    here = os.path.join(os.path.dirname(__file__), "golden")
+    with zipfile.ZipFile(os.path.join(here, "ref_checkpoint.zip")) as z:
+        z.extractall(tmp_path)
+    io = np.load(os.path.join(here, "ref_checkpoint_io.npz"))
+    lm = inference.LoadedModel(str(tmp_path / "model_epoch_12.pth"), "cuda", 4)
+    with torch.no_grad():
+        y, raw = lm.model(torch.from_numpy(io["x"]).cuda())
+    assert np.abs(y.cpu().numpy() - io["y"]).max() <= 1e-4 and np.abs(raw.cpu().numpy() - io["raw"]).max() <= 1e-4
