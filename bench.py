@@ -132,6 +132,20 @@ def main():
     dom_name, (dom_flops, dom_time, dom_launches) = dominant
     achieved = dom_flops / dom_time / 1e12
     rm_time = sum(rm_ms) * 1e-3 / max(1, len(rm_ms))
+    # the ray-marcher on its own (outside the timed region): the kernel's own figure, next to the one it has as a
+    # one-wave-per-SIMD guest under the network
+    rm_alone = rm_time
+    if overlap:
+        gb = torch.empty((low_h, low_w, 12), dtype=torch.float32, device="cuda")
+        renderer.set_kernel_variant(args.raymarch_variant)
+        renderer.profile_enable(True)
+        for k in range(6):
+            renderer.send_command("cameraOrigin", V.fmt3(origins[Wm + (k % K)]))
+            renderer.render_async(gb, torch.cuda.current_stream())
+        torch.cuda.synchronize()
+        alone = renderer.profile_times_ms()[1:]
+        renderer.profile_enable(False)
+        rm_alone = sum(alone) * 1e-3 / max(1, len(alone))
 
     # HBM traffic of the dominant kernel: PMC counters cannot be read from inside this process; the
     # committed rocprofv3 --pmc passes of this same command (profiles/r01_pmc_summary.md) provide it.
@@ -165,11 +179,11 @@ def main():
         "kernels": {n: {"tflops": v[0] / v[1] / 1e12, "ms_per_frame": v[1] / K * 1e3, "launches_per_frame": v[2] / K}
                     for n, v in per.items()},
         "raymarch": {"kernel": "iso_render_gather_slim (under the network)" if overlap else "iso_render_gather",
-                     "ms_per_frame": rm_time * 1e3},
+                     "ms_per_frame": rm_time * 1e3, "alone_ms_per_frame": rm_alone * 1e3},
     }
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        result.update(cpu_reference_leg(args, vol, iso, net, pipe, origins[Wm], low_w, low_h, result, rm_time))
+        result.update(cpu_reference_leg(args, vol, iso, net, pipe, origins[Wm], low_w, low_h, result, rm_alone))
     if rank == 0:
         print(json.dumps(result))
     if world > 1:
