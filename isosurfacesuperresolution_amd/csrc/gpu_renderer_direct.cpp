@@ -53,6 +53,7 @@ struct Volume {
     float* bricks = nullptr;
     int32_t* slot = nullptr;
     uint8_t* leaf = nullptr;
+    float* leafRange = nullptr;  // (min, max) per brick position, see iso_kernels.hip: leaf_may_cross
     uint8_t* node1 = nullptr;
 };
 
@@ -88,6 +89,7 @@ void freeVolume(Volume& v)
     if (v.bricks) (void)hipFree(v.bricks);
     if (v.slot) (void)hipFree(v.slot);
     if (v.leaf) (void)hipFree(v.leaf);
+    if (v.leafRange) (void)hipFree(v.leafRange);
     if (v.node1) (void)hipFree(v.node1);
     v = Volume();
 }
@@ -327,6 +329,8 @@ bool uploadFromDevice(const float* dense, int nx, int ny, int nz, const TileInfo
     HIP_OK(hipMemcpy(v.slot, slot.data(), nb * sizeof(int32_t), hipMemcpyHostToDevice));
     HIP_OK(hipMemcpy(v.node1, node1.data(), node1.size(), hipMemcpyHostToDevice));
     iso_launch_brick_fill(dense, nx, ny, nz, v.nbx, v.nby, v.nbz, v.slot, v.bricks, nullptr);
+    HIP_OK(hipMalloc(&v.leafRange, nb * 2 * sizeof(float)));
+    iso_launch_leaf_range(dense, nx, ny, nz, v.nbx, v.nby, v.nbz, v.leafRange, nullptr);
     HIP_OK(hipGetLastError());
     HIP_OK(hipDeviceSynchronize());
     v.loaded = true;
@@ -448,7 +452,7 @@ bool launchFrame(float* out, hipStream_t stream)
     p.nbx = v.nbx; p.nby = v.nby; p.nbz = v.nbz;
     p.n1x = v.n1x; p.n1y = v.n1y; p.n1z = v.n1z;
     p.any_leaf = v.nleaf > 0;
-    p.bricks = v.bricks; p.slot = v.slot; p.leaf = v.leaf; p.node1 = v.node1;
+    p.bricks = v.bricks; p.slot = v.slot; p.leaf = v.leaf; p.leafRange = v.leafRange; p.node1 = v.node1;
     p.out = out;
     p.aoSamples = a.aoSamples < 0 ? 0 : (a.aoSamples > 512 ? 512 : a.aoSamples);   // GPURendererDirect.cpp:350
     p.aoRadius = double(a.aoRadius);

@@ -145,7 +145,10 @@ __device__ __forceinline__ bool ray_cast(const IsoRenderParams& P, float iso, f3
         const float mz = (float)((tside.z < tside.x) & (tside.z <= tside.y));
         const float ty = mx != 0.f ? tside.x : (my != 0.f ? tside.y : tside.z);
         const int bx = ox + (int)p.x, by = oy + (int)p.y, bz = oz + (int)p.z;
-        if (P.leaf[((size_t)bz * P.nby + by) * P.nbx + bx]) {
+        const size_t bi = ((size_t)bz * P.nby + by) * P.nbx + bx;
+        // max skipping, exact: a march through this brick reads voxels of [8b-1, 8b+9]^3 only; if their maximum (plus the
+        // rounding allowance of the float lerps) is below the isovalue no sample can reach it and the march finds nothing
+        if (P.leaf[bi] && !(iso > P.leafRange[2 * bi + 1] + 4e-6f * fmaxf(fabsf(P.leafRange[2 * bi]), fabsf(P.leafRange[2 * bi + 1])))) {
             const f3 vmin = mk((float)(bx * 8), (float)(by * 8), (float)(bz * 8));
             if (march_brick<CUSTOM>(P, iso, vmin, tx + GV_EPS, pos, dir, hit, grad)) return true;
         }

@@ -144,6 +144,20 @@ __device__ __forceinline__ bool has_leaf(const IsoRenderParams& P, int x, int y,
     if ((unsigned)x >= (unsigned)P.nx || (unsigned)y >= (unsigned)P.ny || (unsigned)z >= (unsigned)P.nz) return false;
     return P.leaf[((z >> 3) * P.nby + (y >> 3)) * P.nbx + (x >> 3)] != 0;
 }
+// Min/max skipping, exact: every sample the voxel DDA of a leaf can take reads voxels of [8b-1, 8b+9]^3 only (cells
+// 8b-1 .. 8b+8: a position may sit a rounding error outside the leaf's faces), and a trilinear value stays inside the
+// range of its 8 corners up to ~11 ulp of the seven float lerps.  If the isovalue lies outside [min, max] of that
+// neighbourhood by more than the pad, (value - iso) has one strict sign along the whole march, the reference's
+// `v0 * v1 <= 0` never fires, and stepping over the leaf is the same computation.  Long rays that cross the thin
+// low-density fringe or the dense core without meeting the surface were the tail the whole frame waited for.
+__device__ __forceinline__ bool leaf_may_cross(const IsoRenderParams& P, int x, int y, int z)
+{
+    const float* mm = P.leafRange + 2 * (size_t)(((z >> 3) * P.nby + (y >> 3)) * P.nbx + (x >> 3));
+    const double lo = (double)mm[0], hi = (double)mm[1];
+    const double pad = 4e-6 * fmax(fabs(lo), fabs(hi));
+    return !(P.iso < lo - pad || P.iso > hi + pad);
+}
+
 __device__ __forceinline__ bool has_node1(const IsoRenderParams& P, int x, int y, int z)
 {
     if ((unsigned)x >= (unsigned)P.nx || (unsigned)y >= (unsigned)P.ny || (unsigned)z >= (unsigned)P.nz) return false;
@@ -197,7 +211,7 @@ __device__ bool hits_hierarchy(const IsoRenderParams& P, Ray& ray, double& time)
                     DDA d0;
                     dda_init<3>(d0, ray);
                     do {
-                        if (has_leaf(P, d0.vx, d0.vy, d0.vz)) {
+                        if (has_leaf(P, d0.vx, d0.vy, d0.vz) && leaf_may_cross(P, d0.vx, d0.vy, d0.vz)) {
                             ray.t0 = d0.t0; ray.t1 = dda_next(d0);
                             if (hits_voxel(P, ray, time)) return true;
                         }
@@ -521,7 +535,7 @@ __device__ __forceinline__ bool walk_next_leaf(const IsoRenderParams& P, Walk& w
                 w.lvl = 2;
             }
         } else {
-            if (has_leaf(P, w.d0.vx, w.d0.vy, w.d0.vz)) {
+            if (has_leaf(P, w.d0.vx, w.d0.vy, w.d0.vz) && leaf_may_cross(P, w.d0.vx, w.d0.vy, w.d0.vz)) {
                 ray.t0 = w.d0.t0; ray.t1 = dda_next(w.d0);
                 brick = ((w.d0.vz >> 3) * P.nby + (w.d0.vy >> 3)) * P.nbx + (w.d0.vx >> 3);
                 return true;
@@ -716,7 +730,34 @@ __global__ __launch_bounds__(64) void iso_brick_fill(const float* __restrict__ d
     }
 }
 
+// range[b] = (min, max) over the voxels [8b-1, 8b+9]^3 of brick position b; outside the grid counts as 0
+__global__ __launch_bounds__(64) void iso_leaf_range(const float* __restrict__ dense, int nx, int ny, int nz,
+                                                    int nbx, int nby, int nbz, float* __restrict__ range)
+{
+    const int b = blockIdx.x;
+    const int bx = b % nbx, by = (b / nbx) % nby, bz = b / (nbx * nby);
+    float lo = 3.0e38f, hi = -3.0e38f;
+    for (int k = threadIdx.x; k < 11 * 11 * 11; k += 64) {
+        const int lx = k % 11, ly = (k / 11) % 11, lz = k / 121;
+        const int x = bx * 8 - 1 + lx, y = by * 8 - 1 + ly, z = bz * 8 - 1 + lz;
+        float f = 0.0f;
+        if ((unsigned)x < (unsigned)nx && (unsigned)y < (unsigned)ny && (unsigned)z < (unsigned)nz) f = dense[((size_t)z * ny + y) * nx + x];
+        lo = fminf(lo, f); hi = fmaxf(hi, f);
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        lo = fminf(lo, __shfl_xor(lo, off));
+        hi = fmaxf(hi, __shfl_xor(hi, off));
+    }
+    if (threadIdx.x == 0) { range[2 * (size_t)b] = lo; range[2 * (size_t)b + 1] = hi; }
+}
+
 }  // namespace
+
+void iso_launch_leaf_range(const float* dense, int nx, int ny, int nz, int nbx, int nby, int nbz, float* range, void* stream)
+{
+    hipLaunchKernelGGL(iso_leaf_range, dim3(nbx * nby * nbz), dim3(64), 0, (hipStream_t)stream, dense, nx, ny, nz, nbx, nby, nbz, range);
+}
 
 void iso_launch_render(const IsoRenderParams& p, int variant, void* stream, void* startEvent, void* stopEvent, int waveCap)
 {

@@ -34,6 +34,7 @@ struct IsoRenderParams {
     const float* bricks;         // [slot][ISO_BRICK_STRIDE], local index (z*9+y)*9+x
     const int32_t* slot;         // [nbz][nby][nbx] -> slot or -1 (all 9^3 values zero)
     const uint8_t* leaf;         // [nbz][nby][nbx] leaf node exists
+    const float* leafRange;      // [nbz][nby][nbx][2] min / max of every value a march through that leaf can read
     const uint8_t* node1;        // [n1z][n1y][n1x]
     float* out;                  // [H][W][12]
     int aoSamples;               // 0 -> AO channel == 1
@@ -67,5 +68,6 @@ void iso_launch_render_gvdb(const IsoRenderParams& p, const IsoGvdbFrame& f, voi
 void iso_launch_gate(const unsigned* resident, unsigned target, int timeoutUs, void* stream);
 void iso_launch_brick_flags(const float* dense, int nx, int ny, int nz, int nbx, int nby, int nbz,
                             uint8_t* flag9, uint8_t* leaf, int* bbox6, unsigned int* maxbits, void* stream);
+void iso_launch_leaf_range(const float* dense, int nx, int ny, int nz, int nbx, int nby, int nbz, float* range, void* stream);
 void iso_launch_brick_fill(const float* dense, int nx, int ny, int nz, int nbx, int nby, int nbz,
                            const int32_t* slot, float* bricks, void* stream);
