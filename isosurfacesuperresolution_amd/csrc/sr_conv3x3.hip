@@ -28,6 +28,14 @@
 #include "../../include/isr_sr_kernels.h"
 #include "sr_finish.h"
 
+// Launch with start/stop events on the dispatch packet when profiling, as a plain launch otherwise (plain launches can be
+// captured into a HIP graph -- train.GraphedTrainStep -- the Ext form cannot be relied upon there).
+#define ISR_LAUNCH(KERNEL, GRID, BLOCK, LDS, STREAM, E0, E1, ...)                                              \
+    do {                                                                                                        \
+        if ((E0) || (E1)) hipExtLaunchKernelGGL(KERNEL, GRID, BLOCK, LDS, STREAM, E0, E1, 0, __VA_ARGS__);    \
+        else hipLaunchKernelGGL(KERNEL, GRID, BLOCK, LDS, STREAM, __VA_ARGS__);                                \
+    } while (0)
+
 namespace {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -1109,8 +1117,8 @@ int isrConv3x3ForwardStrided(const float* x, const float* wprep, const float* bi
                 g_records.push_back({ 10 + (upsample2x ? 1 : 0), 2.0 * 9 * Cin * Cout * (double)N * H * W, e0, e1 });
             }
             const dim3 grid1((unsigned)nwgSmall);
-            if (upsample2x) hipExtLaunchKernelGGL((conv3x3_fwd2_kernel<true, 1>), grid1, block, conv_fwd2_lds_bytes<1>(), s, e0, e1, 0, p);
-            else hipExtLaunchKernelGGL((conv3x3_fwd2_kernel<false, 1>), grid1, block, conv_fwd2_lds_bytes<1>(), s, e0, e1, 0, p);
+            if (upsample2x) ISR_LAUNCH((conv3x3_fwd2_kernel<true, 1>), grid1, block, conv_fwd2_lds_bytes<1>(), s, e0, e1, p);
+            else ISR_LAUNCH((conv3x3_fwd2_kernel<false, 1>), grid1, block, conv_fwd2_lds_bytes<1>(), s, e0, e1, p);
             return hipGetLastError() == hipSuccess ? 0 : -2;
         }
         hipEvent_t e0 = nullptr, e1 = nullptr;
@@ -1119,8 +1127,8 @@ int isrConv3x3ForwardStrided(const float* x, const float* wprep, const float* bi
             g_records.push_back({ 8 + (upsample2x ? 1 : 0), 2.0 * 9 * Cin * Cout * (double)N * H * W, e0, e1 });
         }
         const dim3 grid2((unsigned)(nwg * p.cgroups));
-        if (upsample2x) hipExtLaunchKernelGGL((conv3x3_fwd2_kernel<true, 4>), grid2, block, conv_fwd2_lds_bytes<4>(), s, e0, e1, 0, p);
-        else hipExtLaunchKernelGGL((conv3x3_fwd2_kernel<false, 4>), grid2, block, conv_fwd2_lds_bytes<4>(), s, e0, e1, 0, p);
+        if (upsample2x) ISR_LAUNCH((conv3x3_fwd2_kernel<true, 4>), grid2, block, conv_fwd2_lds_bytes<4>(), s, e0, e1, p);
+        else ISR_LAUNCH((conv3x3_fwd2_kernel<false, 4>), grid2, block, conv_fwd2_lds_bytes<4>(), s, e0, e1, p);
         return hipGetLastError() == hipSuccess ? 0 : -2;
     }
     // one launch per group of up to 64 output channels (2 M tiles per wave)
@@ -1135,11 +1143,11 @@ int isrConv3x3ForwardStrided(const float* x, const float* wprep, const float* bi
         }
         const size_t lds = mt == 1 ? conv_fwd_lds_bytes<1>() : conv_fwd_lds_bytes<2>();
         if (mt == 1) {
-            if (upsample2x) hipExtLaunchKernelGGL((conv3x3_fwd_kernel<1, true>), grid, block, lds, s, e0, e1, 0, p);
-            else hipExtLaunchKernelGGL((conv3x3_fwd_kernel<1, false>), grid, block, lds, s, e0, e1, 0, p);
+            if (upsample2x) ISR_LAUNCH((conv3x3_fwd_kernel<1, true>), grid, block, lds, s, e0, e1, p);
+            else ISR_LAUNCH((conv3x3_fwd_kernel<1, false>), grid, block, lds, s, e0, e1, p);
         } else {
-            if (upsample2x) hipExtLaunchKernelGGL((conv3x3_fwd_kernel<2, true>), grid, block, lds, s, e0, e1, 0, p);
-            else hipExtLaunchKernelGGL((conv3x3_fwd_kernel<2, false>), grid, block, lds, s, e0, e1, 0, p);
+            if (upsample2x) ISR_LAUNCH((conv3x3_fwd_kernel<2, true>), grid, block, lds, s, e0, e1, p);
+            else ISR_LAUNCH((conv3x3_fwd_kernel<2, false>), grid, block, lds, s, e0, e1, p);
         }
     }
     return hipGetLastError() == hipSuccess ? 0 : -2;
@@ -1430,7 +1438,7 @@ int isrConv3x3SmallCoutStrided(const float* x, const float* w8, const float* bia
         e0 = pool_event(); e1 = pool_event();
         g_records.push_back({ 6, 2.0 * 9 * Cin * Cout * (double)N * H * W, e0, e1 });
     }
-    hipExtLaunchKernelGGL(conv3x3_small_cout_kernel, dim3((unsigned)nwg), dim3(256), 0, (hipStream_t)stream, e0, e1, 0, p);
+    ISR_LAUNCH(conv3x3_small_cout_kernel, dim3((unsigned)nwg), dim3(256), 0, (hipStream_t)stream, e0, e1, p);
     return hipGetLastError() == hipSuccess ? 0 : -2;
 }
 
@@ -1454,7 +1462,7 @@ int isrConvSmallFinishFrame(const float* x, const float* w8, const float* bias8,
         e0 = pool_event(); e1 = pool_event();
         g_records.push_back({ 6, 2.0 * 9 * Cin * 6 * (double)H * W, e0, e1 });
     }
-    hipExtLaunchKernelGGL(conv3x3_small_cout_kernel, dim3((unsigned)(p.tilesX * p.tilesY)), dim3(256), 0, (hipStream_t)stream, e0, e1, 0, p);
+    ISR_LAUNCH(conv3x3_small_cout_kernel, dim3((unsigned)(p.tilesX * p.tilesY)), dim3(256), 0, (hipStream_t)stream, e0, e1, p);
     return hipGetLastError() == hipSuccess ? 0 : -2;
 }
 

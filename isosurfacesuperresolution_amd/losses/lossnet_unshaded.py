@@ -32,6 +32,9 @@ _TARGETS = ('mask', 'normal', 'color', 'ao', 'depth', 'all')
 class LossNetUnshaded(nn.Module):
     def __init__(self, device, input_channels, output_channels, high_res, padding, opt):
         super().__init__()
+        # the reference returns the per-term values as Python floats (one device synchronisation per term and frame);
+        # lazy_values = True returns detached tensors instead, so that a training step can be enqueued without stalls
+        self.lazy_values = False
         self.padding = padding
         self.upsample = opt.upsample
         assert input_channels == 5
@@ -123,7 +126,7 @@ class LossNetUnshaded(nn.Module):
                 if key in self.weight_dict:
                     a, b = fields[target]
                     loss = self.loss_dict[name](a, b)
-                    values[key] = loss.item()
+                    values[key] = loss.detach() if self.lazy_values else loss.item()
                     total = total + self.weight_dict[key] * loss
 
         if self.has_temporal_l2_loss:
@@ -141,6 +144,6 @@ class LossNetUnshaded(nn.Module):
                 if key in self.weight_dict:
                     a, b = tfields[target]()
                     loss = crit(a, b)
-                    values[key] = loss.item()
+                    values[key] = loss.detach() if self.lazy_values else loss.item()
                     total = total + self.weight_dict[key] * loss
         return total, values

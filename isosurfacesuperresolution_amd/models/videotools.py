@@ -43,7 +43,11 @@ class VideoTools:
     def warp_upscale(image_high, flow_low, upscale_factor, special_mask=False):
         B, C, H, W = flow_low.shape
         assert C == 2
-        scale = torch.tensor([-2.0, 2.0], dtype=flow_low.dtype, device=flow_low.device).view(1, 2, 1, 1)
+        key = ('scale', flow_low.dtype, str(flow_low.device))
+        scale = VideoTools._offset_cache.get(key)        # cached: building it is a host->device copy per call
+        if scale is None:
+            scale = torch.tensor([-2.0, 2.0], dtype=flow_low.dtype, device=flow_low.device).view(1, 2, 1, 1)
+            VideoTools._offset_cache[key] = scale
         flow_high = F.interpolate(flow_low * scale, scale_factor=upscale_factor, mode='bilinear',
                                   align_corners=False)
         flow_high = flow_high.permute(0, 2, 3, 1)

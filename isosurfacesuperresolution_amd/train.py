@@ -30,11 +30,16 @@ from .utils import ScreenSpaceShading, initialImage
 
 def clip_loss(model, criterion, input, flow, target, initial_image="zero", upscale=4, upsample="bilinear",
               disable_temporal=False):
-    """input [B,T,5,h,w], flow [B,T,2,h,w], target [B,T,6,4h,4w] -> (loss tensor, sum of per-frame floats)."""
+    """input [B,T,5,h,w], flow [B,T,2,h,w], target [B,T,6,4h,4w] -> (loss tensor, sum of the per-frame losses).
+    The reference reads every frame's loss back with ``.item()`` (mainVideoUnshaded.py:454); here the sum is accumulated
+    on the device and read back ONCE after the last frame, so the whole clip is enqueued without a stall."""
     B, T, Cout, Hh, Wh = target.shape
     previous_output = None
     loss = 0
-    loss_sum = 0.0
+    loss_sum = None
+    lazy_before = getattr(criterion, 'lazy_values', None)
+    if lazy_before is not None:
+        criterion.lazy_values = True
     kw = dict(mode=upsample, **({"align_corners": False} if upsample in ("bilinear", "bicubic") else {}))
     for j in range(T):
         if j == 0 or disable_temporal:
@@ -51,17 +56,19 @@ def clip_loss(model, criterion, input, flow, target, initial_image="zero", upsca
         input_high = F.interpolate(input[:, j], size=(Hh, Wh), **kw)
         loss0, _ = criterion(target[:, j], prediction, input_high, previous_input, previous_warped_loss)
         loss = loss + loss0
-        loss_sum += float(loss0.item())
+        loss_sum = loss0.detach() if loss_sum is None else loss_sum + loss0.detach()
         previous_output = torch.cat([
             torch.clamp(prediction[:, 0:1], -1, +1),
             ScreenSpaceShading.normalize(prediction[:, 1:4], dim=1),
             torch.clamp(prediction[:, 4:5], 0, +1),
             torch.clamp(prediction[:, 5:6], 0, +1)], dim=1)
+    if lazy_before is not None:
+        criterion.lazy_values = lazy_before
     return loss, loss_sum
 
 
-def make_optimizer(model, lr=1e-4, lr_step=500, lr_gamma=0.5):
-    opt = torch.optim.Adam(model.parameters(), lr=lr)
+def make_optimizer(model, lr=1e-4, lr_step=500, lr_gamma=0.5, capturable=False):
+    opt = torch.optim.Adam(model.parameters(), lr=lr, capturable=capturable)
     sched = torch.optim.lr_scheduler.StepLR(opt, lr_step, lr_gamma)
     return opt, sched
 
@@ -73,7 +80,50 @@ def train_step(model, criterion, optimizer, batch, **kw):
     loss, loss_sum = clip_loss(model, criterion, input, flow, target, **kw)
     loss.backward()
     optimizer.step()
-    return loss_sum / target.shape[1]
+    return float(loss_sum.item()) / target.shape[1]
+
+
+class GraphedTrainStep:
+    """The whole optimisation step (T frames forward with the recurrence, backward through time, Adam) captured ONCE in
+    a HIP graph and replayed: at the per-GPU batch of BASELINE config #3 (2 clips) a step is ~1500 small launches and the
+    eager loop is bound by Python, not by the GPU.  Needs a GPU, fixed batch shapes, an optimizer created with
+    ``capturable=True`` and (as everywhere in this package) no host read-back inside the step; the loss of each step is
+    returned as a device tensor.  ``all_reduce`` (optional callable) runs between backward and the optimizer step --
+    ``DataParallelTrainer`` passes its flat-bucket RCCL all-reduce, which is captured with the rest."""
+
+    def __init__(self, model, criterion, optimizer, example_batch, all_reduce=None, warmup=3, **kw):
+        self.model, self.criterion, self.optimizer, self.kw = model, criterion, optimizer, kw
+        self.all_reduce = all_reduce
+        self.static = tuple(torch.empty_like(t) for t in example_batch)
+        for dst, src in zip(self.static, example_batch):
+            dst.copy_(src)
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):                      # PyTorch's capture recipe: warm up on a side stream
+            for _ in range(warmup):
+                self._eager()
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        self.graph = torch.cuda.CUDAGraph()
+        self.optimizer.zero_grad(set_to_none=True)
+        with torch.cuda.graph(self.graph):
+            self.loss = self._eager()
+
+    def _eager(self):
+        input, flow, target = self.static
+        self.optimizer.zero_grad(set_to_none=True)
+        loss, loss_sum = clip_loss(self.model, self.criterion, input, flow, target, **self.kw)
+        loss.backward()
+        if self.all_reduce is not None:
+            self.all_reduce()
+        self.optimizer.step()
+        return loss_sum / target.shape[1]
+
+    def __call__(self, batch):
+        for dst, src in zip(self.static, batch):
+            dst.copy_(src, non_blocking=True)
+        self.graph.replay()
+        return self.loss
 
 
 class DataParallelTrainer:
@@ -116,6 +166,12 @@ class DataParallelTrainer:
             p.grad = self.bucket[off:off + n].view_as(p).clone() if p.grad is None else p.grad.copy_(self.bucket[off:off + n].view_as(p))
             off += n
 
+    def graphed(self, example_local_batch, **kw):
+        """The data-parallel step captured in a HIP graph (``GraphedTrainStep``) with the flat-bucket all-reduce inside;
+        needs the RCCL backend (gloo collectives cannot be captured) and an optimizer created with capturable=True."""
+        return GraphedTrainStep(self.model, self.criterion, self.optimizer, example_local_batch,
+                                all_reduce=self._allreduce_gradients if self.world > 1 else None, **kw)
+
     def step(self, local_batch, **kw):
         input, flow, target = local_batch
         self.optimizer.zero_grad()
@@ -124,4 +180,4 @@ class DataParallelTrainer:
         if self.world > 1:
             self._allreduce_gradients()
         self.optimizer.step()
-        return loss_sum / target.shape[1]
+        return float(loss_sum.item()) / target.shape[1]

@@ -360,3 +360,38 @@ def test_reference_checkpoint_on_the_hip_kernels(tmp_path):
     with torch.no_grad():
         y, raw = lm.model(torch.from_numpy(io["x"]).cuda())
     assert np.abs(y.cpu().numpy() - io["y"]).max() <= 1e-4 and np.abs(raw.cpu().numpy() - io["raw"]).max() <= 1e-4
+
+
+def test_graphed_train_step_matches_eager():
+    """train.GraphedTrainStep (the whole T-frame step captured in a HIP graph) against the eager train_step: same
+    start, same clip batch, warm-up + 2 steps -> the same weights (up to individual ReLUs that sit within rounding of
+    zero, cf. test_enhancenet_gpu_train_step_matches_cpu) and the same loss."""
+    from isosurfacesuperresolution_amd import models, losses, train
+    opt = argparse.Namespace(upsample='bilinear', reconType='residual', useBN=False, numResidualLayers=10,
+                             losses="l1:mask:1,l1:ao:1,l1:normal:10,l1:depth:10,temp-l2:color:0.1",
+                             lossAO=0.0, lossAmbient=0.1, lossDiffuse=0.9, lossSpecular=0.0)
+    g = torch.Generator(device='cuda').manual_seed(5)
+    inp = torch.rand(2, 3, 5, 32, 32, device='cuda', generator=g); inp[:, :, 0] = inp[:, :, 0] * 2 - 1
+    flow = (torch.rand(2, 3, 2, 32, 32, device='cuda', generator=g) - 0.5) * 0.05
+    tgt = torch.rand(2, 3, 6, 128, 128, device='cuda', generator=g); tgt[:, :, 0] = tgt[:, :, 0] * 2 - 1
+    crit = losses.LossNetUnshaded('cuda', 5, 6, 128, 16, opt).cuda()
+    nets, finals, last = [], [], []
+    for graphed in (False, True):
+        torch.manual_seed(11)
+        net = models.createNetwork('EnhanceNet', 4, 101, [0, 1, 2, 3, 4], 6, opt).cuda()
+        init = torch.cat([p.detach().reshape(-1).clone() for p in net.parameters()])
+        optim, _ = train.make_optimizer(net, lr=1e-4, capturable=graphed)
+        if graphed:
+            step = train.GraphedTrainStep(net, crit, optim, (inp, flow, tgt), warmup=3, initial_image="zero")
+            for _ in range(2):
+                l = float(step((inp, flow, tgt)))
+        else:
+            for _ in range(5):
+                l = train.train_step(net, crit, optim, (inp, flow, tgt), initial_image="zero")
+        torch.cuda.synchronize()
+        finals.append(torch.cat([p.detach().reshape(-1) for p in net.parameters()]) - init)
+        last.append(l)
+    assert finals[0].abs().max().item() > 1e-4
+    rel = ((finals[0] - finals[1]).norm() / finals[0].norm()).item()
+    assert rel < 2e-2, rel
+    assert abs(last[0] - last[1]) <= 2e-2 * abs(last[0]), last

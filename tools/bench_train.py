@@ -25,4 +25,17 @@ for _ in range(steps):
     l = train.train_step(net, crit, optim, (inp, flow, tgt), initial_image="zero")
 torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / steps
 flops = 13.4e9 * B * T
+graphed = "graph" in sys.argv
+if graphed:
+    torch.manual_seed(124)
+    net2 = models.createNetwork('EnhanceNet', 4, 101, [0, 1, 2, 3, 4], 6, opt).cuda()
+    optim2, _ = train.make_optimizer(net2, capturable=True)
+    t0 = time.perf_counter()
+    step = train.GraphedTrainStep(net2, crit, optim2, (inp, flow, tgt), initial_image="zero")
+    torch.cuda.synchronize(); t_cap = time.perf_counter() - t0
+    for _ in range(2): lg = step((inp, flow, tgt))
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    for _ in range(steps): lg = step((inp, flow, tgt))
+    torch.cuda.synchronize(); dtg = (time.perf_counter() - t0) / steps
+    print("B=%d T=%d HIP graph: %.1f ms/step, %.2f clips/s, %.1f TFLOP/s, loss %.4f (capture %.1f s)" % (B, T, dtg * 1e3, B / dtg, flops / dtg / 1e12, float(lg), t_cap))
 print("B=%d T=%d: %.1f ms/step, %.2f clips/s, %.1f TFLOP/s (conv fwd+dgrad+wgrad algorithmic), loss %.4f" % (B, T, dt * 1e3, B / dt, flops / dt / 1e12, l))
