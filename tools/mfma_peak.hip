@@ -57,13 +57,35 @@ void run(int blocks, int iters, const float* rnd, const char* name)
            (double)h[0] / (double)h[1] * 100.0, (double)h[0] / (8.0 * iters));
     hipFree(d); hipFree(c);
 }
-int main()
+// "mfma_peak <variant 0..3> <seconds>": keep one variant running so that rocm-smi can sample the package power.
+template <bool LDS>
+void soak(const float* src, double seconds)
+{
+    float* d; hipMalloc(&d, 256 * 256 * 4);
+    unsigned long long* c; hipMalloc(&c, 16);
+    hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+    double total = 0;
+    while (total < seconds * 1e3) {
+        hipEventRecord(e0);
+        for (int i = 0; i < 20; ++i) k<LDS><<<256, 256>>>(d, src, 20000, c);
+        hipEventRecord(e1); hipEventSynchronize(e1);
+        float ms; hipEventElapsedTime(&ms, e0, e1);
+        total += ms;
+    }
+}
+int main(int argc, char** argv)
 {
     std::vector<float> h(16384);
     srand(1);
     for (auto& v : h) v = (float)rand() / RAND_MAX * 2.f - 1.f;
     float* rnd; hipMalloc(&rnd, h.size() * 4); hipMemcpy(rnd, h.data(), h.size() * 4, hipMemcpyHostToDevice);
     float* zer; hipMalloc(&zer, h.size() * 4); hipMemset(zer, 0, h.size() * 4);
+    if (argc > 2) {
+        int v = atoi(argv[1]);
+        double sec = atof(argv[2]);
+        if (v & 2) soak<true>((v & 1) ? zer : rnd, sec); else soak<false>((v & 1) ? zer : rnd, sec);
+        return 0;
+    }
     run<false>(256, 20000, rnd, "registers, random data");
     run<false>(256, 20000, zer, "registers, zeros");
     run<true>(256, 20000, rnd, "LDS operands, random data");
