@@ -72,6 +72,31 @@ long long isrConvWeightGradWorkspace(int N, int Cin, int H, int W, int Cout);
 int isrConv3x3WeightGrad(const float* x, const float* gz, float* dw, float* db, void* workspace,
                          int N, int Cin, int H, int W, int Cout, void* stream);
 
+/* x2 bilinear upsampling, align_corners=False (nn.Upsample(scale_factor=2, mode='bilinear') of
+ * SuperresolutionNetwork/models/enhancenet.py:116,119 when it is not fused into the following convolution, i.e. in
+ * training) and its adjoint.  x / gx: [planes][h][w], y / gy: [planes][2h][2w], packed; w even.  The adjoint is a
+ * gather (no atomics: bitwise reproducible). */
+int isrUpsample2xForward(const float* x, float* y, long long planes, int h, int w, void* stream);
+int isrUpsample2xBackward(const float* gy, float* gx, long long planes, int h, int w, void* stream);
+
+/* LossNetUnshaded (SuperresolutionNetwork/losses/lossnet_unshaded.py:236-388) for the l1 / mse / temp-l2 terms on
+ * mask / normal / ao / depth / colour, fused: one pass forward (+ a one-workgroup reduction), one pass backward.
+ * gt, pred, prev: [N][6][H][W] (mask, normal xyz, depth, ao), W % 4 == 0; prev = warped previous prediction or NULL
+ * (then the temp-l2 terms are skipped).  A border of `pad` pixels is treated as zeroed in all three (the module's
+ * `pad`).  weights15 / enabled bit: index kind * 5 + target, kind 0 mse, 1 l1, 2 temp-l2, target 0 mask, 1 normal,
+ * 2 ao, 3 depth, 4 colour.  shading12: ambient*material, diffuse*material, light direction, background (specular
+ * is off in the loss shader, lossnet_unshaded.py:116-126).  values16 (device): the 15 term means (0 for terms that
+ * are not enabled) and [15] = sum of weight * mean.  workspace: isrLossUnshadedWorkspace() bytes.
+ * Backward: gvalues16 (device) is d L / d values16, of which only [15] is read; writes gpred (and gprev unless
+ * NULL), both [N][6][H][W]. */
+long long isrLossUnshadedWorkspace(void);
+int isrLossUnshadedForward(const float* gt, const float* pred, const float* prev, int N, int H, int W, int pad,
+                           const float* weights15, unsigned enabled, const float* shading12, float ao_strength, int inverse_ao,
+                           void* workspace, float* values16, void* stream);
+int isrLossUnshadedBackward(const float* gt, const float* pred, const float* prev, int N, int H, int W, int pad,
+                            const float* weights15, unsigned enabled, const float* shading12, float ao_strength, int inverse_ao,
+                            const float* gvalues16, float* gpred, float* gprev, void* stream);
+
 /* gz = gy * act'(y) for the activations above (y is the post-activation output, before the residual add). */
 int isrActBackward(const float* gy, const float* y, float* gz, long long count, int act, float slope, void* stream);
 

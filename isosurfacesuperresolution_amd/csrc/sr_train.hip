@@ -1,0 +1,401 @@
+// Training-side kernels of the super-resolution path that are NOT convolutions (gfx950): everything here is
+// HBM/launch bound elementwise work that the reference runs as chains of small PyTorch launches.
+//
+//  * x2 bilinear upsampling (align_corners=False) forward / backward -- nn.Upsample(scale_factor=2, 'bilinear')
+//    of SuperresolutionNetwork/models/enhancenet.py:116,119 and its autograd adjoint;
+//  * LossNetUnshaded (SuperresolutionNetwork/losses/lossnet_unshaded.py:236-388, l1 / mse / temp-l2 terms on
+//    mask / normal / ao / depth / colour): forward = ONE pass over gt / pred / prev that produces every term's
+//    sum, backward = ONE pass that writes d loss / d pred and d loss / d prev.  The module path
+//    (losses/lossnet_unshaded.py in this package) issues ~150 launches forward and ~200 backward per frame.
+#include <hip/hip_runtime.h>
+#include "../../include/isr_sr_kernels.h"
+#include "sr_finish.h"
+
+namespace {
+
+// ---------------------------------------------------------------------------------------------------------
+// x2 bilinear upsampling
+// ---------------------------------------------------------------------------------------------------------
+// y[p][Y][X] = hy*(hx*x[y0][x0] + lx*x[y0][x1]) + ly*(hx*x[y1][x0] + lx*x[y1][x1])   (ATen's association)
+__global__ __launch_bounds__(256) void upsample2x_fwd_kernel(const float* __restrict__ x, float* __restrict__ y, int h, int w, long long quads)
+{
+    const int W = 2 * w, H = 2 * h, QW = W / 4;
+    for (long long q = (long long)blockIdx.x * 256 + threadIdx.x; q < quads; q += (long long)gridDim.x * 256) {
+        const int qx = (int)(q % QW);
+        const long long r = q / QW;
+        const int Y = (int)(r % H);
+        const long long plane = r / H;
+        int y0, y1; float ly;
+        isr_src_index(Y, 0.5f, h, y0, y1, ly);
+        const float hy = 1.f - ly;
+        const float* r0 = x + (plane * h + y0) * w;
+        const float* r1 = x + (plane * h + y1) * w;
+        float o[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            int x0, x1; float lx;
+            isr_src_index(4 * qx + k, 0.5f, w, x0, x1, lx);
+            const float hx = 1.f - lx;
+            o[k] = hy * (hx * r0[x0] + lx * r0[x1]) + ly * (hx * r1[x0] + lx * r1[x1]);
+        }
+        *reinterpret_cast<float4*>(y + (plane * H + Y) * W + 4 * qx) = make_float4(o[0], o[1], o[2], o[3]);
+    }
+}
+
+// weight with which output index `o` reads input index `i` along one axis of length n (0 if it does not)
+__device__ __forceinline__ float up2_weight(int o, int i, int n)
+{
+    int i0, i1; float l1;
+    isr_src_index(o, 0.5f, n, i0, i1, l1);
+    return (i0 == i ? 1.f - l1 : 0.f) + (i1 == i ? l1 : 0.f);
+}
+
+// adjoint as a gather (deterministic, no atomics): input pixel (iy, ix) is read by output rows 2iy-1 .. 2iy+2
+__global__ __launch_bounds__(256) void upsample2x_bwd_kernel(const float* __restrict__ gy, float* __restrict__ gx, int h, int w, long long count)
+{
+    const int W = 2 * w, H = 2 * h;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < count; i += (long long)gridDim.x * 256) {
+        const int ix = (int)(i % w);
+        const long long r = i / w;
+        const int iy = (int)(r % h);
+        const long long plane = r / h;
+        float wx[4], acc = 0.f;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int X = 2 * ix - 1 + k;
+            wx[k] = (X >= 0 && X < W) ? up2_weight(X, ix, w) : 0.f;
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int Y = 2 * iy - 1 + j;
+            if (Y < 0 || Y >= H) continue;
+            const float wy = up2_weight(Y, iy, h);
+            const float* row = gy + (plane * H + Y) * W;
+            float s = 0.f;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int X = 2 * ix - 1 + k;
+                if (X >= 0 && X < W) s += wx[k] * row[X];
+            }
+            acc += wy * s;
+        }
+        gx[i] = acc;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// LossNetUnshaded
+// ---------------------------------------------------------------------------------------------------------
+constexpr int LOSS_TERMS = 15;        // kind * 5 + target;  kind: 0 mse, 1 l1, 2 temp-l2;  target: 0 mask 1 normal 2 ao 3 depth 4 colour
+constexpr int LOSS_SLOTS = 16;        // + the weighted total
+
+struct LossParams {
+    const float* gt;      // [N][6][H][W]
+    const float* pred;
+    const float* prev;    // may be NULL (no temp-l2 terms)
+    int N, H, W, pad;
+    float weight[LOSS_TERMS];
+    unsigned enabled;     // bit t: term t is evaluated
+    float ambmat[3], diffmat[3], light[3], bg[3];
+    float ao_strength;
+    int inverse_ao;
+    float* partial;       // [blocks][LOSS_SLOTS]
+    float* values;        // [LOSS_SLOTS]: per-term means, [15] = sum of weight * mean
+    int blocks;
+    const float* gout;    // backward: d / d values (only [15] is used)
+    float* gpred;
+    float* gprev;         // may be NULL
+};
+
+struct Fields {           // what the loss terms compare, and what their derivatives need
+    float m, n[3], ao, d, col[3];
+    float nh[3], len, ndl, aof, t, cb[3], colpre[3];
+    bool a_in, t_in;
+};
+
+__device__ __forceinline__ float clamp01(float v) { return fminf(fmaxf(v, 0.f), 1.f); }
+
+__device__ __forceinline__ void eval_fields(const LossParams& P, const float (&x)[6], float gate, Fields& f)
+{
+    f.m = x[0];
+    f.len = sqrtf(x[1] * x[1] + x[2] * x[2] + x[3] * x[3]);
+    const float den = fmaxf(f.len, 1e-7f);
+#pragma unroll
+    for (int k = 0; k < 3; ++k) { f.nh[k] = x[1 + k] / den; f.n[k] = f.nh[k] * gate; }
+    f.d = x[4] * gate;
+    f.ao = x[5] * gate;
+    const float a = P.inverse_ao ? 1.0f - x[5] : x[5];
+    f.a_in = a >= 0.f && a <= 1.f;
+    f.aof = P.ao_strength * clamp01(a) + (1.0f - P.ao_strength);
+    f.ndl = P.light[0] * x[1] + P.light[1] * x[2] + P.light[2] * x[3];      // the shader takes the normal as it is
+    const float tt = x[0] * 0.5f + 0.5f;
+    f.t_in = tt >= 0.f && tt <= 1.f;
+    f.t = clamp01(tt);
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        f.cb[k] = P.ambmat[k] + P.diffmat[k] * fabsf(f.ndl);
+        f.colpre[k] = P.bg[k] + f.t * (f.cb[k] * f.aof - P.bg[k]);
+        f.col[k] = clamp01(f.colpre[k]);
+    }
+}
+
+// upstream derivative w.r.t. the fields -> derivative w.r.t. the six channels
+struct FieldGrad { float m, n[3], ao, d, col[3]; };
+
+__device__ __forceinline__ void backprop_fields(const LossParams& P, const Fields& f, float gate, const FieldGrad& g, float (&gx)[6])
+{
+    gx[0] = g.m;
+    gx[4] = gate * g.d;
+    gx[5] = gate * g.ao;
+    float dn[3] = {gate * g.n[0], gate * g.n[1], gate * g.n[2]};
+    if (f.len > 1e-7f) {
+        const float dot = f.nh[0] * dn[0] + f.nh[1] * dn[1] + f.nh[2] * dn[2];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) gx[1 + k] = (dn[k] - f.nh[k] * dot) / f.len;
+    } else {
+#pragma unroll
+        for (int k = 0; k < 3; ++k) gx[1 + k] = dn[k] / 1e-7f;
+    }
+    float dt = 0.f, daof = 0.f, dabs = 0.f;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        const float gp = (f.colpre[k] >= 0.f && f.colpre[k] <= 1.f) ? g.col[k] : 0.f;
+        dt += gp * (f.cb[k] * f.aof - P.bg[k]);
+        const float dc = gp * f.t;
+        daof += dc * f.cb[k];
+        dabs += dc * f.aof * P.diffmat[k];
+    }
+    if (f.t_in) gx[0] += 0.5f * dt;
+    if (f.a_in) gx[5] += daof * P.ao_strength * (P.inverse_ao ? -1.f : 1.f);
+    const float sg = f.ndl > 0.f ? 1.f : (f.ndl < 0.f ? -1.f : 0.f);
+#pragma unroll
+    for (int k = 0; k < 3; ++k) gx[1 + k] += dabs * sg * P.light[k];
+}
+
+__device__ __forceinline__ float sgn(float v) { return v > 0.f ? 1.f : (v < 0.f ? -1.f : 0.f); }
+
+// one thread = four horizontally adjacent pixels of one image
+template <bool BACKWARD>
+__global__ __launch_bounds__(256) void loss_unshaded_kernel(LossParams P)
+{
+    const int QW = P.W / 4;
+    const long long quadsPerImage = (long long)QW * P.H;
+    const long long quads = quadsPerImage * P.N;
+    const size_t plane = (size_t)P.H * P.W;
+    float sums[LOSS_TERMS];
+#pragma unroll
+    for (int t = 0; t < LOSS_TERMS; ++t) sums[t] = 0.f;
+
+    float coef[LOSS_TERMS];      // backward: weight * d mean / d sum, times the upstream gradient
+    if (BACKWARD) {
+        const float go = P.gout[LOSS_TERMS];
+        const float n1 = (float)((double)P.N * P.H * P.W), n3 = 3.0f * n1;
+#pragma unroll
+        for (int t = 0; t < LOSS_TERMS; ++t) {
+            const int target = t % 5;
+            const float cnt = (target == 1 || target == 4) ? n3 : n1;
+            coef[t] = ((P.enabled >> t) & 1u) ? go * P.weight[t] / cnt : 0.f;
+        }
+    }
+
+    for (long long q = (long long)blockIdx.x * 256 + threadIdx.x; q < quads; q += (long long)gridDim.x * 256) {
+        const int img = (int)(q / quadsPerImage);
+        const long long r = q % quadsPerImage;
+        const int Y = (int)(r / QW), X0 = 4 * (int)(r % QW);
+        const size_t base = (size_t)img * 6 * plane + (size_t)Y * P.W + X0;
+        float4 g4[6], p4[6], v4[6];
+#pragma unroll
+        for (int c = 0; c < 6; ++c) {
+            g4[c] = *reinterpret_cast<const float4*>(P.gt + base + c * plane);
+            p4[c] = *reinterpret_cast<const float4*>(P.pred + base + c * plane);
+            v4[c] = P.prev ? *reinterpret_cast<const float4*>(P.prev + base + c * plane) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+        float4 gp4[6], gv4[6];
+        const bool rowInside = Y >= P.pad && Y < P.H - P.pad;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int X = X0 + k;
+            const bool inside = rowInside && X >= P.pad && X < P.W - P.pad;
+            float g[6], p[6], v[6], gp[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, gv[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int c = 0; c < 6; ++c) {
+                g[c] = reinterpret_cast<const float*>(&g4[c])[k];
+                p[c] = reinterpret_cast<const float*>(&p4[c])[k];
+                v[c] = reinterpret_cast<const float*>(&v4[c])[k];
+            }
+            // a zeroed border pixel gives identical fields for gt / pred / prev: no contribution, no gradient
+            if (inside) {
+                const float gate = clamp01(g[0] * 0.5f + 0.5f);
+                Fields fg, fp, fv;
+                eval_fields(P, g, gate, fg);
+                eval_fields(P, p, gate, fp);
+                if (P.prev) eval_fields(P, v, gate, fv);
+                // differences b - a per field component: [0] mask, [1..3] normal, [4] ao, [5] depth, [6..8] colour
+                float dg[9] = {fp.m - fg.m, fp.n[0] - fg.n[0], fp.n[1] - fg.n[1], fp.n[2] - fg.n[2], fp.ao - fg.ao, fp.d - fg.d,
+                               fp.col[0] - fg.col[0], fp.col[1] - fg.col[1], fp.col[2] - fg.col[2]};
+                float dv[9] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+                if (P.prev) {
+                    dv[0] = fp.m - fv.m; dv[1] = fp.n[0] - fv.n[0]; dv[2] = fp.n[1] - fv.n[1]; dv[3] = fp.n[2] - fv.n[2];
+                    dv[4] = fp.ao - fv.ao; dv[5] = fp.d - fv.d;
+                    dv[6] = fp.col[0] - fv.col[0]; dv[7] = fp.col[1] - fv.col[1]; dv[8] = fp.col[2] - fv.col[2];
+                }
+                // component -> target
+                constexpr int tgt[9] = {0, 1, 1, 1, 2, 3, 4, 4, 4};
+                if (!BACKWARD) {
+#pragma unroll
+                    for (int c = 0; c < 9; ++c) {
+                        sums[0 + tgt[c]] += dg[c] * dg[c];
+                        sums[5 + tgt[c]] += fabsf(dg[c]);
+                        sums[10 + tgt[c]] += dv[c] * dv[c];
+                    }
+                } else {
+                    float up[9], uv[9];
+#pragma unroll
+                    for (int c = 0; c < 9; ++c) {
+                        const float tv = 2.f * coef[10 + tgt[c]] * dv[c];
+                        up[c] = 2.f * coef[0 + tgt[c]] * dg[c] + coef[5 + tgt[c]] * sgn(dg[c]) + tv;
+                        uv[c] = -tv;
+                    }
+                    FieldGrad fgp = {up[0], {up[1], up[2], up[3]}, up[4], up[5], {up[6], up[7], up[8]}};
+                    backprop_fields(P, fp, gate, fgp, gp);
+                    if (P.gprev) {
+                        FieldGrad fgv = {uv[0], {uv[1], uv[2], uv[3]}, uv[4], uv[5], {uv[6], uv[7], uv[8]}};
+                        backprop_fields(P, fv, gate, fgv, gv);
+                    }
+                }
+            }
+            if (BACKWARD) {
+#pragma unroll
+                for (int c = 0; c < 6; ++c) {
+                    reinterpret_cast<float*>(&gp4[c])[k] = gp[c];
+                    reinterpret_cast<float*>(&gv4[c])[k] = gv[c];
+                }
+            }
+        }
+        if (BACKWARD) {
+#pragma unroll
+            for (int c = 0; c < 6; ++c) {
+                *reinterpret_cast<float4*>(P.gpred + base + c * plane) = gp4[c];
+                if (P.gprev) *reinterpret_cast<float4*>(P.gprev + base + c * plane) = gv4[c];
+            }
+        }
+    }
+
+    if (!BACKWARD) {
+        __shared__ float red[4][LOSS_SLOTS];
+        const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+        for (int t = 0; t < LOSS_TERMS; ++t) {
+            float s = sums[t];
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
+            if (lane == 0) red[wave][t] = s;
+        }
+        __syncthreads();
+        if (threadIdx.x < LOSS_TERMS)
+            P.partial[(size_t)blockIdx.x * LOSS_SLOTS + threadIdx.x] =
+                (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
+    }
+}
+
+// one workgroup of 16 waves: wave t sums term t over the blocks in a fixed order, thread 0 forms the total
+__global__ __launch_bounds__(1024) void loss_finalize_kernel(LossParams P)
+{
+    __shared__ float mean[LOSS_SLOTS];
+    const int lane = threadIdx.x & 63, t = threadIdx.x >> 6;
+    if (t < LOSS_TERMS) {
+        float s = 0.f;
+        for (int b = lane; b < P.blocks; b += 64) s += P.partial[(size_t)b * LOSS_SLOTS + t];
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
+        if (lane == 0) {
+            const int target = t % 5;
+            const double cnt = (double)P.N * P.H * P.W * ((target == 1 || target == 4) ? 3.0 : 1.0);
+            mean[t] = ((P.enabled >> t) & 1u) ? (float)((double)s / cnt) : 0.f;
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float total = 0.f;
+        for (int k = 0; k < LOSS_TERMS; ++k) {
+            P.values[k] = mean[k];
+            if ((P.enabled >> k) & 1u) total += P.weight[k] * mean[k];
+        }
+        P.values[LOSS_TERMS] = total;
+    }
+}
+
+int fill_loss_params(LossParams& P, const float* gt, const float* pred, const float* prev, int N, int H, int W, int pad,
+                     const float* weights15, unsigned enabled, const float* shading12, float ao_strength, int inverse_ao)
+{
+    if (!gt || !pred || !weights15 || !shading12 || N <= 0 || H <= 0 || W <= 0 || (W & 3) || pad < 0) return -1;
+    if (2 * pad >= H || 2 * pad >= W) return -1;
+    P.gt = gt; P.pred = pred; P.prev = prev;
+    P.N = N; P.H = H; P.W = W; P.pad = pad;
+    for (int t = 0; t < LOSS_TERMS; ++t) P.weight[t] = weights15[t];
+    P.enabled = enabled & ((1u << LOSS_TERMS) - 1u);
+    if (!prev) P.enabled &= (1u << 10) - 1u;
+    for (int k = 0; k < 3; ++k) {
+        P.ambmat[k] = shading12[k]; P.diffmat[k] = shading12[3 + k]; P.light[k] = shading12[6 + k]; P.bg[k] = shading12[9 + k];
+    }
+    P.ao_strength = ao_strength; P.inverse_ao = inverse_ao;
+    long long quads = (long long)N * H * (W / 4);
+    long long blocks = (quads + 255) / 256;
+    P.blocks = (int)(blocks > 1024 ? 1024 : blocks);
+    P.partial = nullptr; P.values = nullptr; P.gout = nullptr; P.gpred = nullptr; P.gprev = nullptr;
+    return 0;
+}
+
+} // namespace
+
+extern "C" {
+
+int isrUpsample2xForward(const float* x, float* y, long long planes, int h, int w, void* stream)
+{
+    if (!x || !y || planes <= 0 || h <= 0 || w <= 0 || (w & 1)) return -1;
+    const long long quads = planes * (2LL * h) * (2 * w / 4);
+    long long blocks = (quads + 255) / 256;
+    if (blocks > 8192) blocks = 8192;
+    hipLaunchKernelGGL(upsample2x_fwd_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, x, y, h, w, quads);
+    return hipGetLastError() == hipSuccess ? 0 : -2;
+}
+
+int isrUpsample2xBackward(const float* gy, float* gx, long long planes, int h, int w, void* stream)
+{
+    if (!gy || !gx || planes <= 0 || h <= 0 || w <= 0) return -1;
+    const long long count = planes * h * w;
+    long long blocks = (count + 255) / 256;
+    if (blocks > 16384) blocks = 16384;
+    hipLaunchKernelGGL(upsample2x_bwd_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, gy, gx, h, w, count);
+    return hipGetLastError() == hipSuccess ? 0 : -2;
+}
+
+long long isrLossUnshadedWorkspace(void) { return (long long)1024 * LOSS_SLOTS * sizeof(float); }
+
+int isrLossUnshadedForward(const float* gt, const float* pred, const float* prev, int N, int H, int W, int pad,
+                           const float* weights15, unsigned enabled, const float* shading12, float ao_strength, int inverse_ao,
+                           void* workspace, float* values16, void* stream)
+{
+    LossParams P;
+    if (!workspace || !values16) return -1;
+    if (int rc = fill_loss_params(P, gt, pred, prev, N, H, W, pad, weights15, enabled, shading12, ao_strength, inverse_ao)) return rc;
+    P.partial = (float*)workspace; P.values = values16;
+    hipLaunchKernelGGL(loss_unshaded_kernel<false>, dim3(P.blocks), dim3(256), 0, (hipStream_t)stream, P);
+    hipLaunchKernelGGL(loss_finalize_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, P);
+    return hipGetLastError() == hipSuccess ? 0 : -2;
+}
+
+int isrLossUnshadedBackward(const float* gt, const float* pred, const float* prev, int N, int H, int W, int pad,
+                            const float* weights15, unsigned enabled, const float* shading12, float ao_strength, int inverse_ao,
+                            const float* gvalues16, float* gpred, float* gprev, void* stream)
+{
+    LossParams P;
+    if (!gvalues16 || !gpred) return -1;
+    if (gprev && !prev) return -1;
+    if (int rc = fill_loss_params(P, gt, pred, prev, N, H, W, pad, weights15, enabled, shading12, ao_strength, inverse_ao)) return rc;
+    P.gout = gvalues16; P.gpred = gpred; P.gprev = gprev;
+    hipLaunchKernelGGL(loss_unshaded_kernel<true>, dim3(P.blocks), dim3(256), 0, (hipStream_t)stream, P);
+    return hipGetLastError() == hipSuccess ? 0 : -2;
+}
+
+} // extern "C"

@@ -23,6 +23,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
+from .. import ops
 from ..utils import ScreenSpaceShading
 from .lossbuilder import LossBuilder
 
@@ -35,6 +36,11 @@ class LossNetUnshaded(nn.Module):
         # the reference returns the per-term values as Python floats (one device synchronisation per term and frame);
         # lazy_values = True returns detached tensors instead, so that a training step can be enqueued without stalls
         self.lazy_values = False
+        # GPU tensors: the whole forward is ONE launch of isrLossUnshadedForward (+ a one-workgroup reduction) and the
+        # whole backward ONE launch of isrLossUnshadedBackward (csrc/sr_train.hip) instead of ~350 PyTorch launches per
+        # frame; fused = False keeps the module path below (what the CPU runs, and what the GPU tests compare against)
+        self.fused = True
+        self._fused_cfg = (None, None)
         self.padding = padding
         self.upsample = opt.upsample
         assert input_channels == 5
@@ -96,10 +102,33 @@ class LossNetUnshaded(nn.Module):
         assert out.shape[2] == h and out.shape[3] == w
         return out
 
+    def _fusable(self, gt, pred, prev):
+        return (self.fused and pred.is_cuda and gt.is_cuda and pred.dtype == torch.float32 and gt.dtype == torch.float32
+                and pred.shape[3] % 4 == 0 and 2 * self.padding < min(pred.shape[2], pred.shape[3])
+                and not self.shading.enable_specular
+                and (prev is None or (prev.is_cuda and prev.dtype == torch.float32 and prev.shape == pred.shape)))
+
+    def _forward_fused(self, gt, pred, prev):
+        key = (tuple(self.shading.packed_parameters()), self.shading._ao, bool(self.shading.inverse_ao), self.padding,
+               tuple(sorted(self.weight_dict.items())))
+        if self._fused_cfg[0] != key:
+            self._fused_cfg = (key, ops.loss_unshaded_config(self.weight_dict, self.padding, self.shading))
+        vals = ops.loss_unshaded(gt, pred, prev if self.has_temporal_l2_loss else None, self._fused_cfg[1])
+        host = None if self.lazy_values else vals.detach().tolist()
+        values = {}
+        for kind in ('mse', 'l1', 'temp-l2'):
+            for target in ('mask', 'normal', 'ao', 'depth', 'color'):
+                if (kind, target) in self.weight_dict:
+                    t = ops.LOSS_KINDS.index(kind) * 5 + ops.LOSS_TARGETS.index(target)
+                    values[(kind, target)] = vals[t].detach() if self.lazy_values else host[t]
+        return vals[15], values
+
     def forward(self, gt, pred, input, prev_input_warped, prev_pred_warped):
         B, Cout, Hh, Wh = gt.shape
         assert Cout == 6
         assert gt.shape == pred.shape
+        if self._fusable(gt, pred, prev_pred_warped):
+            return self._forward_fused(gt, pred, prev_pred_warped)
         gt = LossNetUnshaded.pad(gt, self.padding)
         pred = LossNetUnshaded.pad(pred, self.padding)
         if prev_pred_warped is not None:

@@ -1,0 +1,135 @@
+"""GPU parity of the training-side elementwise kernels (csrc/sr_train.hip, through the C-ABI of libisr_sr.so):
+the x2 bilinear upsampling and the fused LossNetUnshaded, forward and backward, against the PyTorch module path
+(the restatement of SuperresolutionNetwork/losses/lossnet_unshaded.py and models/enhancenet.py:116,119)."""
+import argparse
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("shape", [(2, 3, 5, 6), (1, 64, 32, 32), (3, 1, 1, 2), (1, 2, 7, 10), (16, 64, 16, 16)])
+def test_upsample2x_forward_backward_match_torch(shape):
+    from isosurfacesuperresolution_amd import ops
+    g = torch.Generator().manual_seed(7)
+    x = torch.randn(shape, generator=g).cuda().requires_grad_(True)
+    xr = x.detach().clone().requires_grad_(True)
+    y = ops.bilinear_upsample2x(x)
+    yr = F.interpolate(xr, scale_factor=2, mode='bilinear', align_corners=False)
+    assert y.shape == yr.shape
+    assert (y - yr).abs().max().item() <= 1e-6          # tolerance: fp32 rounding of a 4-term blend on O(1) data
+    gy = torch.randn(y.shape, generator=g).cuda()
+    y.backward(gy)
+    yr.backward(gy)
+    assert (x.grad - xr.grad).abs().max().item() <= 1e-5   # 16-term sums, different association than the atomics
+    # the adjoint is a gather: bitwise reproducible
+    x2 = x.detach().clone().requires_grad_(True)
+    ops.bilinear_upsample2x(x2).backward(gy)
+    assert torch.equal(x2.grad, x.grad)
+
+
+def _opt(losses, ao=0.0):
+    return argparse.Namespace(upsample='bilinear', losses=losses, lossAO=ao, lossAmbient=0.1, lossDiffuse=0.9, lossSpecular=0.0)
+
+
+def _clip(n, h, w, seed):
+    g = torch.Generator().manual_seed(seed)
+    def img():
+        t = torch.randn(n, 6, h, w, generator=g)
+        t[:, 0] = t[:, 0] * 1.5                      # masks beyond [-1, 1]: exercises the clamps of gate and shading
+        t[:, 5] = t[:, 5] * 0.8 + 0.4                # ao below 0 and above 1
+        t[:, 4] = t[:, 4] * 0.5 + 0.5
+        return t
+    gt, pred, prev = img(), img(), img()
+    pred[:, 1:4, 5, 7] = 0.0                         # zero normals: the 1e-7 floor of normalize()
+    prev[:, 1:4, 6, 9] = 0.0
+    return gt.cuda(), pred.cuda(), prev.cuda()
+
+
+RECIPE = "l1:mask:1,l1:ao:1,l1:normal:10,l1:depth:10,temp-l2:color:0.1"
+EVERYTHING = ("mse:mask:0.3,mse:normal:2,mse:ao:0.7,mse:depth:1.5,mse:color:0.9,l1:mask:1,l1:normal:3,l1:ao:0.4,l1:depth:2,"
+              "l1:color:0.6,temp-l2:mask:0.2,temp-l2:normal:0.8,temp-l2:ao:0.5,temp-l2:depth:1.1,temp-l2:color:0.1")
+
+
+@pytest.mark.parametrize("losses,ao,pad,size", [(RECIPE, 0.0, 4, (32, 32)), (EVERYTHING, 0.35, 3, (20, 24)), (EVERYTHING, 1.0, 0, (9, 12)),
+                                                ("l1:normal:1", 0.0, 16, (128, 128))])
+def test_fused_unshaded_loss_matches_module_path(losses, ao, pad, size):
+    from isosurfacesuperresolution_amd import losses as L
+    crit = L.LossNetUnshaded('cuda', 5, 6, size[0], pad, _opt(losses, ao)).cuda()
+    gt, pred, prev = _clip(3, size[0], size[1], 11)
+    out = {}
+    for fused in (True, False):
+        crit.fused = fused
+        p = pred.clone().requires_grad_(True)
+        v = prev.clone().requires_grad_(True)
+        total, values = crit(gt, p, None, None, v)
+        (total * 1.7).backward()                          # an upstream factor other than one
+        out[fused] = (total.detach(), values, p.grad, v.grad)
+    tf, vf, gpf, gvf = out[True]
+    tm, vm, gpm, gvm = out[False]
+    assert set(vf) == set(vm)
+    for k in vm:
+        assert abs(vf[k] - vm[k]) <= 1e-5 * max(1.0, abs(vm[k])), k
+    assert abs(tf.item() - tm.item()) <= 1e-5 * max(1.0, abs(tm.item()))
+    # gradients: entries are weight / count sized, compare relative to the largest one
+    scale = gpm.abs().max().item()
+    assert (gpf - gpm).abs().max().item() <= 2e-5 * scale
+    if crit.has_temporal_l2_loss:
+        assert (gvf - gvm).abs().max().item() <= 2e-5 * max(gvm.abs().max().item(), 1e-12)
+    else:
+        assert gvf is None or gvf.abs().max().item() == 0.0
+    # the border the module zeroes receives no gradient
+    if pad:
+        assert gpf[:, :, :pad].abs().max().item() == 0.0 and gpf[:, :, :, -pad:].abs().max().item() == 0.0
+
+
+def test_fused_loss_first_frame_has_no_previous_gradient():
+    """Frame 0 compares against the ground truth of frame 0 (mainVideoUnshaded.py:431): prev needs no gradient."""
+    from isosurfacesuperresolution_amd import losses as L
+    crit = L.LossNetUnshaded('cuda', 5, 6, 32, 4, _opt(RECIPE)).cuda()
+    crit.lazy_values = True
+    gt, pred, prev = _clip(2, 32, 32, 5)
+    p = pred.clone().requires_grad_(True)
+    total, values = crit(gt, p, None, None, gt)
+    total.backward()
+    assert torch.isfinite(p.grad).all()
+    assert all(torch.is_tensor(v) and not v.requires_grad for v in values.values())
+
+
+def test_clip_gradients_with_fused_kernels_match_module_path():
+    """Loss and weight gradients of a clip (T = 3 frames, recurrence, BPTT) with the fused loss + hand-written
+    upsampling against the PyTorch module path of both.  The upsampled features differ from PyTorch's in the last bit
+    (another FMA contraction), so of the ~3.5 M ReLU inputs behind them a handful within 1e-6 of zero switch, each
+    moving the weight gradients by O(1e-4) in relative L2 (tools/dbg_train_parity.py: the fused loss alone stays at
+    8e-7, the distance between two runs of the module path with its atomics; cf.
+    test_conv_gpu.py::test_enhancenet_gpu_train_step_matches_cpu)."""
+    from isosurfacesuperresolution_amd import models, losses as L, train, ops
+    opt = argparse.Namespace(upsample='bilinear', reconType='residual', useBN=False, numResidualLayers=2, losses=RECIPE,
+                             lossAO=0.0, lossAmbient=0.1, lossDiffuse=0.9, lossSpecular=0.0)
+    g = torch.Generator().manual_seed(3)
+    B, T = 2, 3
+    inp = torch.rand(B, T, 5, 16, 16, generator=g).cuda(); inp[:, :, 0] = inp[:, :, 0] * 2 - 1
+    flow = ((torch.rand(B, T, 2, 16, 16, generator=g) - 0.5) * 0.05).cuda()
+    tgt = torch.rand(B, T, 6, 64, 64, generator=g).cuda(); tgt[:, :, 0] = tgt[:, :, 0] * 2 - 1
+    results = []
+    for fused in (True, False):
+        torch.manual_seed(124)
+        net = models.createNetwork('EnhanceNet', 4, 101, [0, 1, 2, 3, 4], 6, opt).cuda()
+        crit = L.LossNetUnshaded('cuda', 5, 6, 64, 8, opt).cuda()
+        crit.fused = fused
+        saved = ops.bilinear_upsample2x
+        if not fused:
+            ops.bilinear_upsample2x = lambda x: F.interpolate(x, scale_factor=2, mode='bilinear', align_corners=False)
+        try:
+            loss, loss_sum = train.clip_loss(net, crit, inp, flow, tgt, initial_image="zero")
+            loss.backward()
+        finally:
+            ops.bilinear_upsample2x = saved
+        results.append((loss_sum.item(), [p.grad.detach().clone() for p in net.parameters()]))
+    (lf, gf), (lm, gm) = results
+    assert abs(lf - lm) <= 1e-5 * max(1.0, abs(lm))
+    errs = [((a - b).norm() / b.norm()).item() for a, b in zip(gf, gm)]
+    assert max(errs) <= 1e-2, max(errs)
+    assert sorted(errs)[len(errs) // 2] <= 1e-3, sorted(errs)[-8:]
