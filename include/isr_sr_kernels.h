@@ -72,6 +72,15 @@ long long isrConvWeightGradWorkspace(int N, int Cin, int H, int W, int Cout);
 int isrConv3x3WeightGrad(const float* x, const float* gz, float* dw, float* db, void* workspace,
                          int N, int Cin, int H, int W, int Cout, void* stream);
 
+/* The same weight (and bias) gradient summed over `segments` (<= isrConvWeightGradMaxSegments()) pairs of tensors
+ * xs[k]: [N][Cin][H][W], gzs[k]: [N][Cout][H][W] in ONE pass: the T frames of a training clip
+ * (SuperresolutionNetwork/mainVideoUnshaded.py:416-466) share the network's weights, so instead of T launches per
+ * layer followed by T-1 accumulations the clip's weight gradient is one launch over all frames' pixels.  xs / gzs
+ * are HOST arrays of device pointers (copied into the kernel arguments). */
+int isrConvWeightGradMaxSegments(void);
+int isrConv3x3WeightGradSegments(const float* const* xs, const float* const* gzs, int segments, float* dw, float* db, void* workspace,
+                                 int N, int Cin, int H, int W, int Cout, void* stream);
+
 /* x2 bilinear upsampling, align_corners=False (nn.Upsample(scale_factor=2, mode='bilinear') of
  * SuperresolutionNetwork/models/enhancenet.py:116,119 when it is not fused into the following convolution, i.e. in
  * training) and its adjoint.  x / gx: [planes][h][w], y / gy: [planes][2h][2w], packed; w even.  The adjoint is a

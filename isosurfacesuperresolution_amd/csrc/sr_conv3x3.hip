@@ -793,10 +793,14 @@ constexpr int GZ_STRIDE = WG_PX + 1;          // 129
 constexpr int XP_W = WG_TW + 2;               // 34
 constexpr int XP_PLANE = (WG_TH + 2) * XP_W + 1;   // 205
 
+constexpr int WG_MAX_SEG = 32;
 struct WGradParams {
-    const float* x;     // [N][Cin][H][W]
-    const float* gz;    // [N][Cout][H][W]
+    // K runs over the pixels of `segments` tensor pairs of N images each (the frames of a training clip share the
+    // weights, so one launch can take all of them: train.py defers the weight gradients to the end of the backward)
+    const float* x[WG_MAX_SEG];     // each [N][Cin][H][W]
+    const float* gz[WG_MAX_SEG];    // each [N][Cout][H][W]
     float* slabs;       // [G][9][64][64]
+    float* bslabs;      // [G][64] partial sums of gz per output channel (bias gradient), or NULL
     int N, Cin, H, W, Cout;
     int ci0, co0;       // channel group handled by this launch
     int tilesX, tilesY, ntiles;
@@ -841,14 +845,15 @@ __global__ __launch_bounds__(NTHREADS, 1) void conv3x3_wgrad_kernel(const WGradP
     float gv[NGZ], xv[NXE];
 
     auto fetch = [&](int tile) {
-        const int n = tile / tilesPerImage;
-        const int t2 = tile - n * tilesPerImage;
+        const int ng = tile / tilesPerImage;             // image index over all segments
+        const int t2 = tile - ng * tilesPerImage;
+        const int seg = ng / p.N, n = ng - seg * p.N;
         const int ty = t2 / p.tilesX, tx = t2 - ty * p.tilesX;
         const int oy0 = ty * WG_TH, ox0 = tx * WG_TW;
         const int gzc = p.Cout - p.co0, xc = p.Cin - p.ci0;
-        const rsrc_t grs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.gz + ((size_t)n * p.Cout + p.co0) * p.H * p.W), 0,
+        const rsrc_t grs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.gz[seg] + ((size_t)n * p.Cout + p.co0) * p.H * p.W), 0,
                                                              (int)((gzc < 64 ? gzc : 64) * planeBytes), 0x00020000);
-        const rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.x + ((size_t)n * p.Cin + p.ci0) * p.H * p.W), 0,
+        const rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.x[seg] + ((size_t)n * p.Cin + p.ci0) * p.H * p.W), 0,
                                                              (int)((xc < 64 ? xc : 64) * planeBytes), 0x00020000);
 #pragma unroll
         for (int i = 0; i < NGZ; ++i) {
@@ -880,6 +885,7 @@ __global__ __launch_bounds__(NTHREADS, 1) void conv3x3_wgrad_kernel(const WGradP
         }
     };
 
+    float bsum = 0.0f;                                   // this lane's share of sum(gz[co = m*32+j]) (pixels kh, kh+2, ..)
     int tile = g;
     if (tile < p.ntiles) { fetch(tile); park(); }
     __syncthreads();
@@ -894,6 +900,7 @@ __global__ __launch_bounds__(NTHREADS, 1) void conv3x3_wgrad_kernel(const WGradP
 #pragma unroll 4
             for (int rx = 0; rx < WG_TW; rx += 2) {
                 const float a = ga[ry * WG_TW + rx];
+                bsum += a;
 #pragma unroll
                 for (int t = 0; t < TAPS; ++t) {
                     const int tap = TAPS == 9 ? t : -1;
@@ -916,13 +923,23 @@ __global__ __launch_bounds__(NTHREADS, 1) void conv3x3_wgrad_kernel(const WGradP
             const int co = m * 32 + (i & 3) + 8 * (i >> 2) + 4 * kh;
             slab[((size_t)(tap0 + t) * 64 + co) * 64 + nn * 32 + j] = acc[t][i];
         }
+    // bias gradient: the A operand already passes every gz value of the tile set through the waves with nn == 0
+    const float btot = bsum + __shfl_xor(bsum, 32, 64);
+    if (p.bslabs && nn == 0 && tap0 == 0 && kh == 0) p.bslabs[(size_t)g * 64 + m * 32 + j] = btot;
 }
 
 __global__ void wgrad_reduce_kernel(const float* __restrict__ slabs, int G, float* __restrict__ dw,
-                                    int Cout, int Cin, int co0, int ci0)
+                                    int Cout, int Cin, int co0, int ci0, const float* __restrict__ bslabs, float* __restrict__ db)
 {
-    const int e = blockIdx.x * blockDim.x + threadIdx.x;     // over [9][64][64]
-    if (e >= 9 * 64 * 64) return;
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;     // over [9][64][64] (+ 64 bias sums)
+    if (e >= 9 * 64 * 64) {
+        const int co = e - 9 * 64 * 64;
+        if (!bslabs || co >= 64 || co0 + co >= Cout) return;
+        float s[4] = { 0.f, 0.f, 0.f, 0.f };
+        for (int g = 0; g < G; ++g) s[g & 3] += bslabs[(size_t)g * 64 + co];
+        db[co0 + co] = (s[0] + s[1]) + (s[2] + s[3]);
+        return;
+    }
     const int ci = e & 63, co = (e >> 6) & 63, tap = e >> 12;
     if (co0 + co >= Cout || ci0 + ci >= Cin) return;
     // eight interleaved partial sums (slab g goes to sum g % 8) keep eight loads in flight; the order is fixed,
@@ -936,38 +953,6 @@ __global__ void wgrad_reduce_kernel(const float* __restrict__ slabs, int G, floa
     }
     for (int k = 0; g < G; ++g, ++k) s[k] += src[(size_t)g * 9 * 64 * 64];
     dw[((size_t)(co0 + co) * Cin + (ci0 + ci)) * 9 + tap] = ((s[0] + s[1]) + (s[2] + s[3])) + ((s[4] + s[5]) + (s[6] + s[7]));
-}
-
-// db[c] = sum over n,y,x of gz[n][c][y][x]; one workgroup per channel, fixed reduction order
-// (four interleaved partial sums per thread, float4 loads when the planes allow it).
-__global__ __launch_bounds__(256) void bias_grad_kernel(const float* __restrict__ gz, float* __restrict__ db,
-                                                         int N, int C, long long HW)
-{
-    __shared__ float red[256];
-    const int c = blockIdx.x;
-    float s0 = 0.0f, s1 = 0.0f, s2 = 0.0f, s3 = 0.0f;
-    if ((HW & 3) == 0) {
-        const long long q = HW >> 2;
-        for (int n = 0; n < N; ++n) {
-            const float4* src = reinterpret_cast<const float4*>(gz + ((size_t)n * C + c) * HW);
-            for (long long i = threadIdx.x; i < q; i += 256) {
-                const float4 v = src[i];
-                s0 += v.x; s1 += v.y; s2 += v.z; s3 += v.w;
-            }
-        }
-    } else {
-        for (int n = 0; n < N; ++n) {
-            const float* src = gz + ((size_t)n * C + c) * HW;
-            for (long long i = threadIdx.x; i < HW; i += 256) s0 += src[i];
-        }
-    }
-    red[threadIdx.x] = (s0 + s1) + (s2 + s3);
-    __syncthreads();
-    for (int off = 128; off > 0; off >>= 1) {
-        if ((int)threadIdx.x < off) red[threadIdx.x] += red[threadIdx.x + off];
-        __syncthreads();
-    }
-    if (threadIdx.x == 0) db[c] = red[0];
 }
 
 constexpr int WGRAD_MAX_SLABS = 512;
@@ -1167,34 +1152,50 @@ int isrActBackward(const float* gy, const float* y, float* gz, long long count, 
 long long isrConvWeightGradWorkspace(int N, int Cin, int H, int W, int Cout)
 {
     (void)N; (void)Cin; (void)H; (void)W; (void)Cout;
-    return (long long)WGRAD_MAX_SLABS * 9 * 64 * 64 * sizeof(float);
+    return (long long)WGRAD_MAX_SLABS * (9 * 64 * 64 + 64) * sizeof(float);
+}
+
+int isrConvWeightGradMaxSegments(void) { return WG_MAX_SEG; }
+
+int isrConv3x3WeightGradSegments(const float* const* xs, const float* const* gzs, int segments, float* dw, float* db, void* workspace,
+                                 int N, int Cin, int H, int W, int Cout, void* stream)
+{
+    if (!xs || !gzs || segments <= 0 || segments > WG_MAX_SEG || !dw || !workspace || N <= 0 || Cin <= 0 || Cout <= 0 || H <= 0 || W <= 0)
+        return -1;
+    hipStream_t s = (hipStream_t)stream;
+    WGradParams p;
+    for (int k = 0; k < WG_MAX_SEG; ++k) {
+        p.x[k] = k < segments ? xs[k] : nullptr;
+        p.gz[k] = k < segments ? gzs[k] : nullptr;
+        if (k < segments && (!xs[k] || !gzs[k])) return -1;
+    }
+    p.slabs = (float*)workspace;
+    float* bslabs = p.slabs + (size_t)WGRAD_MAX_SLABS * 9 * 64 * 64;
+    p.N = N; p.Cin = Cin; p.H = H; p.W = W; p.Cout = Cout;
+    p.tilesX = (W + WG_TW - 1) / WG_TW; p.tilesY = (H + WG_TH - 1) / WG_TH;
+    const long long nt = (long long)N * segments * p.tilesX * p.tilesY;
+    if (nt > 0x7fffffffLL) return -1;
+    p.ntiles = (int)nt;
+    if ((long long)(Cin < 64 ? Cin : 64) * H * W * 4 > 0x7fffffffLL || (long long)(Cout < 64 ? Cout : 64) * H * W * 4 > 0x7fffffffLL) return -1;
+    // one slab per workgroup; with many tiles one workgroup per CU (fewer slabs to reduce, same balance)
+    const int G = p.ntiles >= 1024 ? 256 : (p.ntiles < WGRAD_MAX_SLABS ? p.ntiles : WGRAD_MAX_SLABS);
+    const bool split = G <= 192;        // few tiles: one workgroup per row of the 3x3 instead of one per tile set
+    for (int co0 = 0; co0 < Cout; co0 += 64)
+        for (int ci0 = 0; ci0 < Cin; ci0 += 64) {
+            p.co0 = co0; p.ci0 = ci0;
+            p.bslabs = (db && ci0 == 0) ? bslabs : nullptr;
+            if (split) hipLaunchKernelGGL(conv3x3_wgrad_kernel<3>, dim3(3 * G), dim3(NTHREADS), 0, s, p);
+            else hipLaunchKernelGGL(conv3x3_wgrad_kernel<9>, dim3(G), dim3(NTHREADS), 0, s, p);
+            hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((9 * 64 * 64 + 64 + 255) / 256), dim3(256), 0, s,
+                               p.slabs, G, dw, Cout, Cin, co0, ci0, (const float*)p.bslabs, db);
+        }
+    return hipGetLastError() == hipSuccess ? 0 : -2;
 }
 
 int isrConv3x3WeightGrad(const float* x, const float* gz, float* dw, float* db, void* workspace,
                          int N, int Cin, int H, int W, int Cout, void* stream)
 {
-    if (!x || !gz || !dw || !workspace || N <= 0 || Cin <= 0 || Cout <= 0 || H <= 0 || W <= 0) return -1;
-    hipStream_t s = (hipStream_t)stream;
-    WGradParams p;
-    p.x = x; p.gz = gz; p.slabs = (float*)workspace;
-    p.N = N; p.Cin = Cin; p.H = H; p.W = W; p.Cout = Cout;
-    p.tilesX = (W + WG_TW - 1) / WG_TW; p.tilesY = (H + WG_TH - 1) / WG_TH;
-    const long long nt = (long long)N * p.tilesX * p.tilesY;
-    if (nt > 0x7fffffffLL) return -1;
-    p.ntiles = (int)nt;
-    if ((long long)(Cin < 64 ? Cin : 64) * H * W * 4 > 0x7fffffffLL || (long long)(Cout < 64 ? Cout : 64) * H * W * 4 > 0x7fffffffLL) return -1;
-    const int G = p.ntiles < WGRAD_MAX_SLABS ? p.ntiles : WGRAD_MAX_SLABS;
-    const bool split = G <= 192;        // few tiles: one workgroup per row of the 3x3 instead of one per tile set
-    for (int co0 = 0; co0 < Cout; co0 += 64)
-        for (int ci0 = 0; ci0 < Cin; ci0 += 64) {
-            p.co0 = co0; p.ci0 = ci0;
-            if (split) hipLaunchKernelGGL(conv3x3_wgrad_kernel<3>, dim3(3 * G), dim3(NTHREADS), 0, s, p);
-            else hipLaunchKernelGGL(conv3x3_wgrad_kernel<9>, dim3(G), dim3(NTHREADS), 0, s, p);
-            hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((9 * 64 * 64 + 255) / 256), dim3(256), 0, s,
-                               p.slabs, G, dw, Cout, Cin, co0, ci0);
-        }
-    if (db) hipLaunchKernelGGL(bias_grad_kernel, dim3(Cout), dim3(256), 0, s, gz, db, N, Cout, (long long)H * W);
-    return hipGetLastError() == hipSuccess ? 0 : -2;
+    return isrConv3x3WeightGradSegments(&x, &gz, 1, dw, db, workspace, N, Cin, H, W, Cout, stream);
 }
 
 }  // extern "C"

@@ -37,6 +37,9 @@ def _sr():
         lib.isrConv3x3ForwardStrided.restype = ci
         lib.isrConvWeightGradWorkspace.argtypes = [ci, ci, ci, ci, ci]; lib.isrConvWeightGradWorkspace.restype = ll
         lib.isrConv3x3WeightGrad.argtypes = [vp, vp, vp, vp, vp, ci, ci, ci, ci, ci, vp]; lib.isrConv3x3WeightGrad.restype = ci
+        lib.isrConvWeightGradMaxSegments.argtypes = []; lib.isrConvWeightGradMaxSegments.restype = ci
+        lib.isrConv3x3WeightGradSegments.argtypes = [vp, vp, ci, vp, vp, vp, ci, ci, ci, ci, ci, vp]
+        lib.isrConv3x3WeightGradSegments.restype = ci
         lib.isrActBackward.argtypes = [vp, vp, vp, ll, ci, cf, vp]; lib.isrActBackward.restype = ci
         lib.isrAssembleInput.argtypes = [vp, vp, vp, vp, ci, ci, ci, ci, vp]; lib.isrAssembleInput.restype = ci
         lib.isrConvSmallCinPad.argtypes = [ci]; lib.isrConvSmallCinPad.restype = ci
@@ -230,6 +233,62 @@ def _wgrad_workspace(device, nbytes):
     return ws
 
 
+def _weight_grad(xs, gzs, weight, has_bias):
+    """(dw, db) summed over the pairs (xs[k], gzs[k]) -- ``isrConv3x3WeightGradSegments``, one pass per <= 32 pairs."""
+    lib = _sr()
+    cout, cin = weight.shape[0], weight.shape[1]
+    n, _, h, w = xs[0].shape
+    ws = _wgrad_workspace(weight.device, lib.isrConvWeightGradWorkspace(n, cin, h, w, cout))
+    most = lib.isrConvWeightGradMaxSegments()
+    gw = gb = None
+    for k in range(0, len(xs), most):
+        part_x, part_g = xs[k:k + most], gzs[k:k + most]
+        dw = torch.empty_like(weight, memory_format=torch.contiguous_format)
+        db = torch.empty(cout, dtype=torch.float32, device=weight.device) if has_bias else None
+        px = (ctypes.c_void_p * len(part_x))(*[t.data_ptr() for t in part_x])
+        pg = (ctypes.c_void_p * len(part_g))(*[t.data_ptr() for t in part_g])
+        rc = lib.isrConv3x3WeightGradSegments(px, pg, len(part_x), _ptr(dw), _ptr(db), _ptr(ws), n, cin, h, w, cout, _stream())
+        if rc != 0:
+            raise RuntimeError("isrConv3x3WeightGradSegments failed (%d)" % rc)
+        gw = dw if gw is None else gw + dw
+        gb = db if gb is None or db is None else gb + db
+    return gw, gb
+
+
+# Deferred weight gradients.  The frames of a training clip run the SAME layers one after the other, and backward
+# through time visits them again in reverse: per layer that is T weight-gradient launches over few pixels each (a
+# 32x32 crop batch fills a quarter of the GPU), T slab reductions and T-1 accumulations into .grad.  Inside
+# ``deferred_weight_gradients()`` the backward of ``conv3x3`` only records (input, output gradient) and returns no
+# weight gradient; leaving the context runs ONE weight-gradient pass per layer over all recorded frames and adds the
+# result to ``weight.grad`` / ``bias.grad`` -- the same sums in another order.
+_deferred = None
+
+
+class deferred_weight_gradients:
+    def __enter__(self):
+        global _deferred
+        if _deferred is not None:
+            raise RuntimeError("deferred_weight_gradients() does not nest")
+        _deferred = {}
+        return self
+
+    def __exit__(self, exc_type, exc, tb):
+        global _deferred
+        pending, _deferred = _deferred, None
+        if exc_type is not None:
+            return False
+        for (_, shape), (weight, bias, xs, gzs) in pending.items():
+            gw, gb = _weight_grad(xs, gzs, weight, bias is not None)
+            for param, g in ((weight, gw), (bias, gb)):
+                if param is None or g is None or not param.requires_grad:
+                    continue
+                if param.grad is None:
+                    param.grad = g.view_as(param)
+                else:
+                    param.grad.add_(g.view_as(param))
+        return False
+
+
 class _Conv3x3Function(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, weight, bias, residual, act, slope):
@@ -240,6 +299,8 @@ class _Conv3x3Function(torch.autograd.Function):
         y = _launch_forward(x, prepare_weights(weight), b, res, cin, cout, act, slope, False)
         ctx.act, ctx.slope = act, slope
         ctx.has_bias, ctx.has_res = bias is not None, residual is not None
+        ctx.bias = bias if (bias is not None and bias.requires_grad) else None
+        ctx.weight = weight
         if act != 'none' and residual is not None:
             raise RuntimeError("conv3x3: activation together with a fused residual is inference-only")
         ctx.save_for_backward(x, weight, y if act != 'none' else None)
@@ -251,7 +312,6 @@ class _Conv3x3Function(torch.autograd.Function):
         x, weight, y = ctx.saved_tensors
         gy = gy.contiguous()
         cout, cin = weight.shape[0], weight.shape[1]
-        n, _, h, w = x.shape
         if ctx.act != 'none':
             gz = torch.empty_like(gy)
             rc = lib.isrActBackward(_ptr(gy), _ptr(y), _ptr(gz), gy.numel(), ACT_CODES[ctx.act], float(ctx.slope), _stream())
@@ -264,12 +324,13 @@ class _Conv3x3Function(torch.autograd.Function):
             # data gradient = the same fused kernel on flipped / transposed weights
             gx = _launch_forward(gz, prepare_weights(weight, transpose_flip=True), None, None, cout, cin, 'none', 0.0, False)
         if ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2]):
-            gw = torch.empty_like(weight, memory_format=torch.contiguous_format)
-            gb = torch.empty(cout, dtype=torch.float32, device=x.device) if ctx.has_bias else None
-            ws = _wgrad_workspace(x.device, lib.isrConvWeightGradWorkspace(n, cin, h, w, cout))
-            rc = lib.isrConv3x3WeightGrad(_ptr(x), _ptr(gz), _ptr(gw), _ptr(gb), _ptr(ws), n, cin, h, w, cout, _stream())
-            if rc != 0:
-                raise RuntimeError("isrConv3x3WeightGrad failed (%d)" % rc)
+            leaf = ctx.weight
+            if _deferred is not None and leaf.is_leaf and (ctx.bias is None or ctx.bias.is_leaf):
+                entry = _deferred.setdefault((id(leaf), tuple(x.shape)), (leaf, ctx.bias, [], []))
+                entry[2].append(x)
+                entry[3].append(gz)
+            else:
+                gw, gb = _weight_grad([x], [gz], weight, ctx.has_bias)
         if ctx.has_res and ctx.needs_input_grad[3]:
             gres = gy
         return gx, gw, gb, gres, None, None

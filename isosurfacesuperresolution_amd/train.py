@@ -24,8 +24,16 @@ import torch
 import torch.distributed as dist
 import torch.nn.functional as F
 
+from . import ops
 from .models import VideoTools
 from .utils import ScreenSpaceShading, initialImage
+
+
+def backward(loss):
+    """``loss.backward()`` with the weight gradients of the HIP convolutions deferred to ONE pass per layer over all
+    frames of the clip (``ops.deferred_weight_gradients``) instead of one pass per layer and frame."""
+    with ops.deferred_weight_gradients():
+        loss.backward()
 
 
 def clip_loss(model, criterion, input, flow, target, initial_image="zero", upscale=4, upsample="bilinear",
@@ -78,7 +86,7 @@ def train_step(model, criterion, optimizer, batch, **kw):
     input, flow, target = batch
     optimizer.zero_grad()
     loss, loss_sum = clip_loss(model, criterion, input, flow, target, **kw)
-    loss.backward()
+    backward(loss)
     optimizer.step()
     return float(loss_sum.item()) / target.shape[1]
 
@@ -113,7 +121,7 @@ class GraphedTrainStep:
         input, flow, target = self.static
         self.optimizer.zero_grad(set_to_none=True)
         loss, loss_sum = clip_loss(self.model, self.criterion, input, flow, target, **self.kw)
-        loss.backward()
+        backward(loss)
         if self.all_reduce is not None:
             self.all_reduce()
         self.optimizer.step()
@@ -176,7 +184,7 @@ class DataParallelTrainer:
         input, flow, target = local_batch
         self.optimizer.zero_grad()
         loss, loss_sum = clip_loss(self.model, self.criterion, input, flow, target, **kw)
-        loss.backward()
+        backward(loss)
         if self.world > 1:
             self._allreduce_gradients()
         self.optimizer.step()

@@ -133,3 +133,59 @@ def test_clip_gradients_with_fused_kernels_match_module_path():
     errs = [((a - b).norm() / b.norm()).item() for a, b in zip(gf, gm)]
     assert max(errs) <= 1e-2, max(errs)
     assert sorted(errs)[len(errs) // 2] <= 1e-3, sorted(errs)[-8:]
+
+
+@pytest.mark.parametrize("case", [(3, 2, 64, 64, 12, 20), (5, 1, 101, 64, 9, 7), (2, 3, 64, 6, 8, 40), (33, 1, 8, 8, 4, 4)])
+def test_weight_gradient_over_segments_matches_fp64(case):
+    """isrConv3x3WeightGradSegments: dw / db summed over several (x, gz) pairs in one pass (33 pairs: two passes)."""
+    from isosurfacesuperresolution_amd import ops
+    segs, n, cin, cout, h, w = case
+    g = torch.Generator().manual_seed(segs * 100 + cin)
+    xs = [torch.randn(n, cin, h, w, generator=g) for _ in range(segs)]
+    gzs = [torch.randn(n, cout, h, w, generator=g) for _ in range(segs)]
+    weight = torch.zeros(cout, cin, 3, 3).cuda()
+    gw, gb = ops._weight_grad([t.cuda() for t in xs], [t.cuda() for t in gzs], weight, True)
+    wref = torch.zeros(cout, cin, 3, 3, dtype=torch.float64, requires_grad=True)
+    bref = torch.zeros(cout, dtype=torch.float64, requires_grad=True)
+    for x, gz in zip(xs, gzs):
+        (F.conv2d(x.double(), wref, bref, padding=1) * gz.double()).sum().backward()
+    scale = wref.grad.abs().max().item()
+    assert (gw.cpu().double() - wref.grad).abs().max().item() <= 1e-5 * scale     # fp32 sums of n*h*w*segs products
+    assert (gb.cpu().double() - bref.grad).abs().max().item() <= 1e-5 * bref.grad.abs().max().item()
+
+
+def test_deferred_weight_gradients_equal_per_frame_accumulation():
+    """ops.deferred_weight_gradients (one weight-gradient pass per layer over the clip's frames) against autograd's
+    per-frame weight gradients + accumulation: the forward passes are identical, only the summation order differs."""
+    from isosurfacesuperresolution_amd import models, losses as L, train, ops
+    opt = argparse.Namespace(upsample='bilinear', reconType='residual', useBN=False, numResidualLayers=2, losses=RECIPE,
+                             lossAO=0.0, lossAmbient=0.1, lossDiffuse=0.9, lossSpecular=0.0)
+    g = torch.Generator().manual_seed(9)
+    B, T = 2, 4
+    inp = torch.rand(B, T, 5, 16, 16, generator=g).cuda(); inp[:, :, 0] = inp[:, :, 0] * 2 - 1
+    flow = ((torch.rand(B, T, 2, 16, 16, generator=g) - 0.5) * 0.05).cuda()
+    tgt = torch.rand(B, T, 6, 64, 64, generator=g).cuda(); tgt[:, :, 0] = tgt[:, :, 0] * 2 - 1
+    torch.manual_seed(124)
+    net = models.createNetwork('EnhanceNet', 4, 101, [0, 1, 2, 3, 4], 6, opt).cuda()
+    crit = L.LossNetUnshaded('cuda', 5, 6, 64, 8, opt).cuda()
+    grads = []
+    for deferred in (False, True):
+        net.zero_grad(set_to_none=True)
+        loss, _ = train.clip_loss(net, crit, inp, flow, tgt, initial_image="zero")
+        if deferred:
+            train.backward(loss)
+        else:
+            loss.backward()
+        grads.append([p.grad.detach().clone() for p in net.parameters()])
+    assert all(a is not None for a in grads[1])
+    for (name, _), a, b in zip(net.named_parameters(), grads[0], grads[1]):
+        assert ((a - b).norm() / a.norm()).item() <= 1e-5, name
+    # accumulation into existing gradients: a second deferred backward doubles them
+    loss, _ = train.clip_loss(net, crit, inp, flow, tgt, initial_image="zero")
+    train.backward(loss)
+    for p, b in zip(net.parameters(), grads[1]):
+        assert ((p.grad - 2 * b).norm() / b.norm()).item() <= 1e-5
+    with pytest.raises(RuntimeError):
+        with ops.deferred_weight_gradients():
+            with ops.deferred_weight_gradients():
+                pass
