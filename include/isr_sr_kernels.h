@@ -21,6 +21,8 @@ extern "C" {
 #define ISR_ACT_NONE 0
 #define ISR_ACT_RELU 1
 #define ISR_ACT_LEAKY 2   /* LeakyReLU / single-parameter PReLU with slope `slope` */
+#define ISR_ACT_GATE 3    /* isrConv3x3Forward[Strided] only: y = residual > 0 ? conv + bias : 0 -- the ReLU backward of a
+                             conv -> ReLU pair folded into the data-gradient launch (residual = the ReLU's output) */
 
 /* Padded sizes of the kernel-side weight layout [9][cinPad][coutPad]. */
 int isrConvCinPad(int Cin);

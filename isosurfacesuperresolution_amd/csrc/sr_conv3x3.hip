@@ -400,7 +400,12 @@ __device__ __forceinline__ void conv_epilogue(const ConvParams& p, f32x16 (&acc)
                     const unsigned roffs = ok ? off + (unsigned)((co0 + co) * rplaneBytes) : BAD_OFFSET;
                     const u32x4 rr = __builtin_amdgcn_raw_buffer_load_b128(rrs, (int)roffs, 0, 0);
                     const float4 rf = __builtin_bit_cast(float4, rr);
-                    v.x += rf.x; v.y += rf.y; v.z += rf.z; v.w += rf.w;
+                    if (p.act == ISR_ACT_GATE) {
+                        v.x = rf.x > 0.f ? v.x : 0.f; v.y = rf.y > 0.f ? v.y : 0.f;
+                        v.z = rf.z > 0.f ? v.z : 0.f; v.w = rf.w > 0.f ? v.w : 0.f;
+                    } else {
+                        v.x += rf.x; v.y += rf.y; v.z += rf.z; v.w += rf.w;
+                    }
                 }
                 __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), yrs, (int)voffs, 0, 0);
             }
@@ -428,7 +433,8 @@ __device__ __forceinline__ void conv_epilogue(const ConvParams& p, f32x16 (&acc)
                 float v = acc[m][r][i] + bv[m][i];
                 if (p.act == ISR_ACT_RELU) v = v > 0.f ? v : 0.f;
                 else if (p.act == ISR_ACT_LEAKY) v = v > 0.f ? v : v * p.slope;
-                v += rv[i];
+                if (p.act == ISR_ACT_GATE) v = rv[i] > 0.f ? v : 0.f;
+                else v += rv[i];
                 __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), yrs, (int)pix, soff, 0);
             }
         }
@@ -928,31 +934,38 @@ __global__ __launch_bounds__(NTHREADS, 1) void conv3x3_wgrad_kernel(const WGradP
     if (p.bslabs && nn == 0 && tap0 == 0 && kh == 0) p.bslabs[(size_t)g * 64 + m * 32 + j] = btot;
 }
 
-__global__ void wgrad_reduce_kernel(const float* __restrict__ slabs, int G, float* __restrict__ dw,
+// dw[co][ci][tap] = sum over the G slabs, in a fixed order (bitwise reproducible run to run).  A workgroup owns 64
+// consecutive slab elements; its four waves take the slabs g % 4 == wave with four loads in flight each and the
+// four partial sums are combined through LDS -- 576 workgroups x 16 independent loads instead of 144 x 8, the
+// reduction of 256 slabs (38 MB) is latency bound otherwise.  Workgroup 576 reduces the 64 bias sums the same way.
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ slabs, int G, float* __restrict__ dw,
                                     int Cout, int Cin, int co0, int ci0, const float* __restrict__ bslabs, float* __restrict__ db)
 {
-    const int e = blockIdx.x * blockDim.x + threadIdx.x;     // over [9][64][64] (+ 64 bias sums)
-    if (e >= 9 * 64 * 64) {
-        const int co = e - 9 * 64 * 64;
-        if (!bslabs || co >= 64 || co0 + co >= Cout) return;
-        float s[4] = { 0.f, 0.f, 0.f, 0.f };
-        for (int g = 0; g < G; ++g) s[g & 3] += bslabs[(size_t)g * 64 + co];
-        db[co0 + co] = (s[0] + s[1]) + (s[2] + s[3]);
+    __shared__ float part[4][64];
+    const int lane = threadIdx.x & 63, q = threadIdx.x >> 6;
+    const bool isBias = blockIdx.x == 9 * 64;
+    if (isBias && !bslabs) return;
+    const size_t stride = isBias ? 64 : (size_t)9 * 64 * 64;
+    const float* src = (isBias ? bslabs : slabs + (size_t)blockIdx.x * 64) + lane;
+    float s[4] = { 0.f, 0.f, 0.f, 0.f };
+    int g = q;
+    for (; g + 12 < G; g += 16) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) s[k] += src[(size_t)(g + 4 * k) * stride];
+    }
+    for (int k = 0; g < G; g += 4, ++k) s[k] += src[(size_t)g * stride];
+    part[q][lane] = (s[0] + s[1]) + (s[2] + s[3]);
+    __syncthreads();
+    if (q != 0) return;
+    const float total = (part[0][lane] + part[1][lane]) + (part[2][lane] + part[3][lane]);
+    if (isBias) {
+        if (co0 + lane < Cout) db[co0 + lane] = total;
         return;
     }
+    const int e = blockIdx.x * 64 + lane;                    // over [9][64][64]
     const int ci = e & 63, co = (e >> 6) & 63, tap = e >> 12;
     if (co0 + co >= Cout || ci0 + ci >= Cin) return;
-    // eight interleaved partial sums (slab g goes to sum g % 8) keep eight loads in flight; the order is fixed,
-    // so the result is bitwise reproducible run to run
-    float s[8] = { 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f };
-    const float* src = slabs + e;
-    int g = 0;
-    for (; g + 8 <= G; g += 8) {
-#pragma unroll
-        for (int k = 0; k < 8; ++k) s[k] += src[(size_t)(g + k) * 9 * 64 * 64];
-    }
-    for (int k = 0; g < G; ++g, ++k) s[k] += src[(size_t)g * 9 * 64 * 64];
-    dw[((size_t)(co0 + co) * Cin + (ci0 + ci)) * 9 + tap] = ((s[0] + s[1]) + (s[2] + s[3])) + ((s[4] + s[5]) + (s[6] + s[7]));
+    dw[((size_t)(co0 + co) * Cin + (ci0 + ci)) * 9 + tap] = total;
 }
 
 constexpr int WGRAD_MAX_SLABS = 512;
@@ -1040,7 +1053,8 @@ int isrConv3x3ForwardStrided(const float* x, const float* wprep, const float* bi
 {
     if (!x || !wprep || !y || N <= 0 || Cin <= 0 || Cout <= 0 || H <= 0 || W <= 0) return -1;
     if (upsample2x && ((H & 1) || (W & 1))) return -1;
-    if (act < ISR_ACT_NONE || act > ISR_ACT_LEAKY) return -1;
+    if (act < ISR_ACT_NONE || act > ISR_ACT_GATE) return -1;
+    if (act == ISR_ACT_GATE && !residual) return -1;
     {
         const long long rowsIn = (long long)(upsample2x ? H / 2 : H) * (upsample2x ? W / 2 : W);
         if (xPlane < rowsIn || yPlane < (long long)H * W || (residual && rPlane < (long long)H * W)) return -1;
@@ -1186,7 +1200,7 @@ int isrConv3x3WeightGradSegments(const float* const* xs, const float* const* gzs
             p.bslabs = (db && ci0 == 0) ? bslabs : nullptr;
             if (split) hipLaunchKernelGGL(conv3x3_wgrad_kernel<3>, dim3(3 * G), dim3(NTHREADS), 0, s, p);
             else hipLaunchKernelGGL(conv3x3_wgrad_kernel<9>, dim3(G), dim3(NTHREADS), 0, s, p);
-            hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((9 * 64 * 64 + 64 + 255) / 256), dim3(256), 0, s,
+            hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(9 * 64 + 1), dim3(256), 0, s,
                                p.slabs, G, dw, Cout, Cin, co0, ci0, (const float*)p.bslabs, db);
         }
     return hipGetLastError() == hipSuccess ? 0 : -2;
@@ -1425,6 +1439,7 @@ int isrConv3x3SmallCoutStrided(const float* x, const float* w8, const float* bia
 {
     if (!x || !w8 || !bias8 || !y || N <= 0 || Cin <= 0 || Cout <= 0 || Cout > 8 || H <= 0 || W <= 0) return -1;
     if (xPlane < (long long)H * W || (long long)Cin * xPlane * 4 >= (1LL << 31)) return -1;
+    if (act < ISR_ACT_NONE || act > ISR_ACT_LEAKY) return -1;
     SmallConvParams p;
     p.x = x; p.wq = w8; p.bias8 = bias8; p.residual = residual; p.y = y;
     p.N = N; p.Cin = Cin; p.H = H; p.W = W; p.Cout = Cout;

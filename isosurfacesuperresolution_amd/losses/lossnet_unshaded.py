@@ -31,6 +31,10 @@ _TARGETS = ('mask', 'normal', 'color', 'ao', 'depth', 'all')
 
 
 class LossNetUnshaded(nn.Module):
+    # forward() accepts the upsampled low-resolution input and its warped predecessor like the reference's, but none of
+    # the supported terms reads them (only the adversarial ones would): train.clip_loss skips producing them
+    uses_input = False
+
     def __init__(self, device, input_channels, output_channels, high_res, padding, opt):
         super().__init__()
         # the reference returns the per-term values as Python floats (one device synchronisation per term and frame);

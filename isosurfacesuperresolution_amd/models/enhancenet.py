@@ -91,8 +91,7 @@ class EnhanceNet(nn.Module):
         pre = self.preblock[0]
         f = c(inputs, pre.weight, pre.bias, act='relu')
         for block in self.blocks:
-            t = c(f, block[0].weight, block[0].bias, act='relu')
-            f = c(t, block[2].weight, block[2].bias, residual=f)
+            f = ops.residual_block(f, block[0].weight, block[0].bias, block[2].weight, block[2].bias)
         p = self.postblock
         f = c(f, p[1].weight, p[1].bias, act='relu', upsample2x=True)
         f = c(f, p[4].weight, p[4].bias, act='relu', upsample2x=True)

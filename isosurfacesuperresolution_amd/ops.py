@@ -19,7 +19,7 @@ import torch.nn.functional as F
 
 from . import _native
 
-ACT_CODES = {'none': 0, 'relu': 1, 'leaky': 2}
+ACT_CODES = {'none': 0, 'relu': 1, 'leaky': 2, 'gate': 3}     # 'gate': internal (data gradient through a ReLU)
 _lib = None
 
 
@@ -289,6 +289,58 @@ class deferred_weight_gradients:
         return False
 
 
+def _weight_grad_or_defer(weight, bias, has_bias, x, gz):
+    """Inside deferred_weight_gradients(): record the pair and return (None, None); else compute (dw, db) now."""
+    if _deferred is not None and weight.is_leaf and (bias is None or bias.is_leaf):
+        entry = _deferred.setdefault((id(weight), tuple(x.shape)), (weight, bias, [], []))
+        entry[2].append(x)
+        entry[3].append(gz)
+        return None, None
+    return _weight_grad([x], [gz], weight, has_bias)
+
+
+class _ResidualBlockFunction(torch.autograd.Function):
+    """y = x + conv2(relu(conv1(x))) -- EnhanceNet's residual block (enhancenet.py:18-33,141) as ONE autograd node of
+    two fused launches forward and two backward: the data gradient of conv2 is gated by relu's output in its epilogue
+    (ISR_ACT_GATE) and the data gradient of conv1 adds the skip path's gradient in its epilogue, where separate
+    nodes need an activation-backward launch and an accumulation launch in between."""
+
+    @staticmethod
+    def forward(ctx, x, w1, b1, w2, b2):
+        x = x.contiguous()
+        c = w1.shape[0]
+        t = _launch_forward(x, prepare_weights(w1), b1.contiguous() if b1 is not None else None, None, c, c, 'relu', 0.0, False)
+        y = _launch_forward(t, prepare_weights(w2), b2.contiguous() if b2 is not None else None, x, c, c, 'none', 0.0, False)
+        ctx.params = (w1, b1, w2, b2)
+        ctx.save_for_backward(x, t)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, t = ctx.saved_tensors
+        w1, b1, w2, b2 = ctx.params
+        gy = gy.contiguous()
+        c = w1.shape[0]
+        gz1 = _launch_forward(gy, prepare_weights(w2, transpose_flip=True), None, t, c, c, 'gate', 0.0, False)
+        gx = None
+        if ctx.needs_input_grad[0]:
+            gx = _launch_forward(gz1, prepare_weights(w1, transpose_flip=True), None, gy, c, c, 'none', 0.0, False)
+        gw1 = gb1 = gw2 = gb2 = None
+        if ctx.needs_input_grad[3] or (b2 is not None and ctx.needs_input_grad[4]):
+            gw2, gb2 = _weight_grad_or_defer(w2, b2 if (b2 is not None and b2.requires_grad) else None, b2 is not None, t, gy)
+        if ctx.needs_input_grad[1] or (b1 is not None and ctx.needs_input_grad[2]):
+            gw1, gb1 = _weight_grad_or_defer(w1, b1 if (b1 is not None and b1.requires_grad) else None, b1 is not None, x, gz1)
+        return gx, gw1, gb1, gw2, gb2
+
+
+def residual_block(x, w1, b1, w2, b2):
+    """x + conv3x3(relu(conv3x3(x, w1, b1)), w2, b2), 64 -> 64 -> 64 channels."""
+    needs_grad = torch.is_grad_enabled() and any(t is not None and t.requires_grad for t in (x, w1, b1, w2, b2))
+    if x.is_cuda and needs_grad and x.dtype == torch.float32 and w1.shape[0] == w1.shape[1] == w2.shape[0] == w2.shape[1]:
+        return _ResidualBlockFunction.apply(x, w1, b1, w2, b2)
+    return conv3x3(conv3x3(x, w1, b1, act='relu'), w2, b2, residual=x)
+
+
 class _Conv3x3Function(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, weight, bias, residual, act, slope):
@@ -324,13 +376,7 @@ class _Conv3x3Function(torch.autograd.Function):
             # data gradient = the same fused kernel on flipped / transposed weights
             gx = _launch_forward(gz, prepare_weights(weight, transpose_flip=True), None, None, cout, cin, 'none', 0.0, False)
         if ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2]):
-            leaf = ctx.weight
-            if _deferred is not None and leaf.is_leaf and (ctx.bias is None or ctx.bias.is_leaf):
-                entry = _deferred.setdefault((id(leaf), tuple(x.shape)), (leaf, ctx.bias, [], []))
-                entry[2].append(x)
-                entry[3].append(gz)
-            else:
-                gw, gb = _weight_grad([x], [gz], weight, ctx.has_bias)
+            gw, gb = _weight_grad_or_defer(ctx.weight, ctx.bias, ctx.has_bias, x, gz)
         if ctx.has_res and ctx.needs_input_grad[3]:
             gres = gy
         return gx, gw, gb, gres, None, None
@@ -346,7 +392,7 @@ def _act_cpu(z, act, slope):
 
 def conv3x3(x, weight, bias=None, act='none', slope=0.01, residual=None, upsample2x=False):
     """See module docstring.  x [N,Cin,h,w], weight [Cout,Cin,3,3] -> [N,Cout,H,W]."""
-    if act not in ACT_CODES:
+    if act not in ('none', 'relu', 'leaky'):
         raise ValueError("unknown activation %r" % (act,))
     if not x.is_cuda:
         if upsample2x:

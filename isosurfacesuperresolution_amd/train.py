@@ -49,19 +49,27 @@ def clip_loss(model, criterion, input, flow, target, initial_image="zero", upsca
     if lazy_before is not None:
         criterion.lazy_values = True
     kw = dict(mode=upsample, **({"align_corners": False} if upsample in ("bilinear", "bicubic") else {}))
+    # the reference upsamples (and warps) the low-resolution inputs for every frame and hands them to the criterion
+    # (mainVideoUnshaded.py:432-452); LossNetUnshaded never reads them (only the GAN terms would), so a criterion
+    # that says so (uses_input = False) is not fed
+    feed_inputs = getattr(criterion, 'uses_input', True)
+    previous_input = input_high = None
     for j in range(T):
         if j == 0 or disable_temporal:
             previous_warped = initialImage(input[:, 0], Cout, initial_image, False, upscale)
             previous_warped_loss = target[:, 0]
-            previous_input = F.interpolate(input[:, 0], size=(Hh, Wh), **kw)
+            if feed_inputs:
+                previous_input = F.interpolate(input[:, 0], size=(Hh, Wh), **kw)
         else:
             previous_warped = VideoTools.warp_upscale(previous_output, flow[:, j - 1], upscale, special_mask=True)
             previous_warped_loss = previous_warped
-            previous_input = F.interpolate(input[:, j - 1], size=(Hh, Wh), **kw)
-            previous_input = VideoTools.warp_upscale(previous_input, flow[:, j - 1], upscale, special_mask=True)
+            if feed_inputs:
+                previous_input = F.interpolate(input[:, j - 1], size=(Hh, Wh), **kw)
+                previous_input = VideoTools.warp_upscale(previous_input, flow[:, j - 1], upscale, special_mask=True)
         single_input = torch.cat((input[:, j], VideoTools.flatten_high(previous_warped, upscale)), dim=1)
         prediction, _ = model(single_input)
-        input_high = F.interpolate(input[:, j], size=(Hh, Wh), **kw)
+        if feed_inputs:
+            input_high = F.interpolate(input[:, j], size=(Hh, Wh), **kw)
         loss0, _ = criterion(target[:, j], prediction, input_high, previous_input, previous_warped_loss)
         loss = loss + loss0
         loss_sum = loss0.detach() if loss_sum is None else loss_sum + loss0.detach()

@@ -189,3 +189,31 @@ def test_deferred_weight_gradients_equal_per_frame_accumulation():
         with ops.deferred_weight_gradients():
             with ops.deferred_weight_gradients():
                 pass
+
+
+@pytest.mark.parametrize("shape", [(2, 64, 12, 20), (1, 64, 9, 7), (3, 64, 32, 32)])
+def test_residual_block_function_matches_fp64(shape):
+    """ops.residual_block (one autograd node, gated data gradient + fused skip gradient) vs fp64 PyTorch."""
+    from isosurfacesuperresolution_amd import ops
+    g = torch.Generator().manual_seed(21)
+    n, c, h, w = shape
+    x = torch.randn(shape, generator=g)
+    ws = [torch.randn(c, c, 3, 3, generator=g) * 0.05 for _ in range(2)]
+    bs = [torch.randn(c, generator=g) * 0.1 for _ in range(2)]
+    gy = torch.randn(shape, generator=g)
+    dev = [t.cuda().requires_grad_(True) for t in (x, ws[0], bs[0], ws[1], bs[1])]
+    y = ops.residual_block(*dev)
+    y.backward(gy.cuda())
+    ref = [t.double().requires_grad_(True) for t in (x, ws[0], bs[0], ws[1], bs[1])]
+    yr = ref[0] + F.conv2d(F.relu(F.conv2d(ref[0], ref[1], ref[2], padding=1)), ref[3], ref[4], padding=1)
+    yr.backward(gy.double())
+    assert (y.detach().cpu().double() - yr.detach()).abs().max().item() <= 1e-4
+    for a, b in zip(dev, ref):
+        assert (a.grad.cpu().double() - b.grad).abs().max().item() <= 1e-4 * max(1.0, b.grad.abs().max().item())
+    # and the same numbers as the two separate conv3x3 nodes it replaces
+    sep = [t.detach().clone().requires_grad_(True) for t in dev]
+    ys = ops.conv3x3(ops.conv3x3(sep[0], sep[1], sep[2], act='relu'), sep[3], sep[4], residual=sep[0])
+    ys.backward(gy.cuda())
+    assert torch.equal(ys, y)
+    for a, b in zip(dev, sep):
+        assert (a.grad - b.grad).abs().max().item() <= 1e-5 * max(1.0, b.grad.abs().max().item())
