@@ -108,6 +108,19 @@ int isrLossUnshadedBackward(const float* gt, const float* pred, const float* pre
                             const float* weights15, unsigned enabled, const float* shading12, float ao_strength, int inverse_ao,
                             const float* gvalues16, float* gpred, float* gprev, void* stream);
 
+/* Recurrent network input of a training clip for frames t > 0 (SuperresolutionNetwork/mainVideoUnshaded.py:436-447,
+ * 463-466 with models/videotools.py:8-25,51-87), fused:
+ *   previous_output = cat(clamp(p0,-1,1), normalize(p1..3), clamp(p4,0,1), clamp(p5,0,1))   p = prev_raw [B][6][4h][4w]
+ *   warped    [B][6][4h][4w] = warp_upscale(previous_output, flow, 4, special_mask=True)
+ *   net_input [B][101][h][w] = cat(input, flatten_high(warped, 4))
+ * input: [B][5][h][w], flow: [B][2][h][w], both with an explicit batch stride in floats (views of [B][T][..] clips).
+ * Backward: g_net_input / g_warped (either may be NULL) -> g_prev_raw; scratch: B*6*4h*4w floats (the gradient of
+ * previous_output, accumulated with float atomics like PyTorch's grid_sampler backward). */
+int isrRecurrentInputForward(const float* prev_raw, const float* input, const float* flow, float* net_input, float* warped,
+                             int B, int h, int w, long long inputBatchStride, long long flowBatchStride, void* stream);
+int isrRecurrentInputBackward(const float* prev_raw, const float* flow, const float* g_net_input, const float* g_warped,
+                              float* scratch, float* g_prev_raw, int B, int h, int w, long long flowBatchStride, void* stream);
+
 /* gz = gy * act'(y) for the activations above (y is the post-activation output, before the residual add). */
 int isrActBackward(const float* gy, const float* y, float* gz, long long count, int act, float slope, void* stream);
 

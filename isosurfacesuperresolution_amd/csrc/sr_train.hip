@@ -346,6 +346,173 @@ int fill_loss_params(LossParams& P, const float* gt, const float* pred, const fl
     return 0;
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// Recurrent network input of a training clip (mainVideoUnshaded.py:436-447,463-466), frames t > 0:
+//   previous_output = cat(clamp(p0,-1,1), normalize(p1..3), clamp(p4,0,1), clamp(p5,0,1))     p = raw prediction t-1
+//   warped          = VideoTools.warp_upscale(previous_output, flow[t-1], 4, special_mask=True)
+//   net_input       = cat(input[t], VideoTools.flatten_high(warped, 4))
+// forward: one gather pass that writes `warped` (the loss's temp-l2 partner) and `net_input`;
+// backward: one scatter pass (float atomics, as in PyTorch's grid_sampler backward) into the gradient of
+// previous_output, one pass through clamp / normalize to the gradient of p.
+// ---------------------------------------------------------------------------------------------------------
+struct RecurParams {
+    const float* raw;        // [B][6][H][W] raw prediction of the previous frame
+    const float* input;      // [B][5][h][w] (batch stride inStride)
+    const float* flow;       // [B][2][h][w] (batch stride flowStride)
+    float* netin;            // [B][101][h][w]
+    float* warped;           // [B][6][H][W]
+    long long inStride, flowStride;
+    int B, h, w;
+    const float* gnetin;     // backward: [B][101][h][w] or NULL
+    const float* gwarped;    // [B][6][H][W] or NULL
+    float* gout;             // [B][6][H][W] gradient of previous_output (zeroed before the scatter)
+    float* graw;             // [B][6][H][W]
+};
+
+struct WarpTaps { size_t b00; float w00, w01, w10, w11; bool v00, v01, v10, v11; };
+
+__device__ __forceinline__ WarpTaps warp_taps(const float* fx, const float* fy, int h, int w, int Y, int X)
+{
+    const int H = 4 * h, W = 4 * w;
+    int y0, y1, x0, x1; float ly, lx;
+    isr_src_index(Y, 0.25f, h, y0, y1, ly);
+    isr_src_index(X, 0.25f, w, x0, x1, lx);
+    const float hy = 1.f - ly, hx = 1.f - lx;
+    // flow scaled by (-2, +2), then bilinearly upsampled (videotools.py:65-70)
+    const float f00x = fx[y0 * w + x0] * -2.0f, f01x = fx[y0 * w + x1] * -2.0f;
+    const float f10x = fx[y1 * w + x0] * -2.0f, f11x = fx[y1 * w + x1] * -2.0f;
+    const float f00y = fy[y0 * w + x0] * 2.0f, f01y = fy[y0 * w + x1] * 2.0f;
+    const float f10y = fy[y1 * w + x0] * 2.0f, f11y = fy[y1 * w + x1] * 2.0f;
+    const float flx = hy * (hx * f00x + lx * f01x) + ly * (hx * f10x + lx * f11x);
+    const float fly = hy * (hx * f00y + lx * f01y) + ly * (hx * f10y + lx * f11y);
+    // grid = linspace(-1, 1) + flow; bilinear sampler with align_corners=True and zero padding
+    const float gx = (-1.0f + 2.0f * (float)X / (float)(W - 1)) + flx;
+    const float gy = (-1.0f + 2.0f * (float)Y / (float)(H - 1)) + fly;
+    const float sx = (gx + 1.0f) * (0.5f * (float)(W - 1)), sy = (gy + 1.0f) * (0.5f * (float)(H - 1));
+    const float fx0 = floorf(sx), fy0 = floorf(sy);
+    const int ix0 = (int)fx0, iy0 = (int)fy0;
+    const float wx1 = sx - fx0, wy1 = sy - fy0, wx0 = 1.f - wx1, wy0 = 1.f - wy1;
+    const bool vx0 = (unsigned)ix0 < (unsigned)W, vx1 = (unsigned)(ix0 + 1) < (unsigned)W;
+    const bool vy0 = (unsigned)iy0 < (unsigned)H, vy1 = (unsigned)(iy0 + 1) < (unsigned)H;
+    WarpTaps t;
+    t.b00 = (size_t)((long long)iy0 * W + ix0);
+    t.w00 = wx0 * wy0; t.w01 = wx1 * wy0; t.w10 = wx0 * wy1; t.w11 = wx1 * wy1;
+    t.v00 = vy0 && vx0; t.v01 = vy0 && vx1; t.v10 = vy1 && vx0; t.v11 = vy1 && vx1;
+    return t;
+}
+
+// previous_output at one pixel from the raw prediction (mask already mapped to [0,1] for the special-mask warp)
+__device__ __forceinline__ void prev_output_at(const float* raw, size_t hplane, size_t at, float (&o)[6])
+{
+    const float m = fminf(fmaxf(raw[at], -1.f), 1.f);
+    const float nx = raw[hplane + at], ny = raw[2 * hplane + at], nz = raw[3 * hplane + at];
+    const float den = fmaxf(sqrtf(nx * nx + ny * ny + nz * nz), 1e-7f);
+    o[0] = m * 0.5f + 0.5f;
+    o[1] = nx / den; o[2] = ny / den; o[3] = nz / den;
+    o[4] = clamp01(raw[4 * hplane + at]);
+    o[5] = clamp01(raw[5 * hplane + at]);
+}
+
+// one thread per (low-res pixel, dx), loop over dy: as assemble_input_kernel of the inference path
+__global__ __launch_bounds__(256) void recurrent_input_fwd_kernel(const RecurParams p)
+{
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    const int x = t >> 2, dx = t & 3;
+    const int y = blockIdx.y, b = blockIdx.z;
+    if (x >= p.w) return;
+    const int H = 4 * p.h, W = 4 * p.w;
+    const size_t plane = (size_t)p.h * p.w, hplane = (size_t)H * W;
+    const size_t pix = (size_t)y * p.w + x;
+    float* out = p.netin + (size_t)b * 101 * plane;
+    if (dx == 0) {
+        const float* in = p.input + (size_t)b * p.inStride;
+#pragma unroll
+        for (int c = 0; c < 5; ++c) out[c * plane + pix] = in[c * plane + pix];
+    }
+    const float* fx = p.flow + (size_t)b * p.flowStride;
+    const float* fy = fx + plane;
+    const float* raw = p.raw + (size_t)b * 6 * hplane;
+    float* wout = p.warped + (size_t)b * 6 * hplane;
+    float* o = out + 5 * plane + pix;
+    const int X = 4 * x + dx;
+    for (int dy = 0; dy < 4; ++dy) {
+        const int Y = 4 * y + dy;
+        const WarpTaps tp = warp_taps(fx, fy, p.h, p.w, Y, X);
+        float a[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, bq[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        float c_[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, d[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        if (tp.v00) prev_output_at(raw, hplane, tp.b00, a);
+        if (tp.v01) prev_output_at(raw, hplane, tp.b00 + 1, bq);
+        if (tp.v10) prev_output_at(raw, hplane, tp.b00 + W, c_);
+        if (tp.v11) prev_output_at(raw, hplane, tp.b00 + W + 1, d);
+#pragma unroll
+        for (int c = 0; c < 6; ++c) {
+            float r = a[c] * tp.w00 + bq[c] * tp.w01 + c_[c] * tp.w10 + d[c] * tp.w11;
+            if (c == 0) r = r * 2.0f - 1.0f;      // special mask: zero padding means "mask = -1"
+            o[(size_t)(c * 16 + dy * 4 + dx) * plane] = r;
+            wout[(size_t)c * hplane + (size_t)Y * W + X] = r;
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void recurrent_input_scatter_kernel(const RecurParams p)
+{
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    const int x = t >> 2, dx = t & 3;
+    const int y = blockIdx.y, b = blockIdx.z;
+    if (x >= p.w) return;
+    const int H = 4 * p.h, W = 4 * p.w;
+    const size_t plane = (size_t)p.h * p.w, hplane = (size_t)H * W;
+    const size_t pix = (size_t)y * p.w + x;
+    const float* fx = p.flow + (size_t)b * p.flowStride;
+    const float* fy = fx + plane;
+    const float* gn = p.gnetin ? p.gnetin + (size_t)b * 101 * plane + 5 * plane + pix : nullptr;
+    const float* gw = p.gwarped ? p.gwarped + (size_t)b * 6 * hplane : nullptr;
+    float* go = p.gout + (size_t)b * 6 * hplane;
+    const int X = 4 * x + dx;
+    for (int dy = 0; dy < 4; ++dy) {
+        const int Y = 4 * y + dy;
+        const WarpTaps tp = warp_taps(fx, fy, p.h, p.w, Y, X);
+#pragma unroll
+        for (int c = 0; c < 6; ++c) {
+            float g = 0.f;
+            if (gn) g += gn[(size_t)(c * 16 + dy * 4 + dx) * plane];
+            if (gw) g += gw[(size_t)c * hplane + (size_t)Y * W + X];
+            // c == 0: d(2 * sample(m/2 + 1/2) - 1) / dm = the plain bilinear weights
+            float* q = go + (size_t)c * hplane;
+            if (tp.v00) unsafeAtomicAdd(q + tp.b00, g * tp.w00);
+            if (tp.v01) unsafeAtomicAdd(q + tp.b00 + 1, g * tp.w01);
+            if (tp.v10) unsafeAtomicAdd(q + tp.b00 + W, g * tp.w10);
+            if (tp.v11) unsafeAtomicAdd(q + tp.b00 + W + 1, g * tp.w11);
+        }
+    }
+}
+
+// gradient of previous_output -> gradient of the raw prediction (clamps pass inside their closed range, as
+// torch.clamp does; normalize as in backprop_fields)
+__global__ __launch_bounds__(256) void recurrent_input_post_kernel(const RecurParams p, long long pixels)
+{
+    const size_t hplane = (size_t)16 * p.h * p.w;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < pixels; i += (long long)gridDim.x * 256) {
+        const size_t b = (size_t)(i / (long long)hplane), at = (size_t)(i % (long long)hplane);
+        const float* raw = p.raw + b * 6 * hplane + at;
+        const float* go = p.gout + b * 6 * hplane + at;
+        float* gr = p.graw + b * 6 * hplane + at;
+        const float m = raw[0], nx = raw[hplane], ny = raw[2 * hplane], nz = raw[3 * hplane], dp = raw[4 * hplane], ao = raw[5 * hplane];
+        gr[0] = (m >= -1.f && m <= 1.f) ? go[0] : 0.f;
+        const float g1 = go[hplane], g2 = go[2 * hplane], g3 = go[3 * hplane];
+        const float len = sqrtf(nx * nx + ny * ny + nz * nz);
+        if (len > 1e-7f) {
+            const float hx = nx / len, hy = ny / len, hz = nz / len;
+            const float dot = hx * g1 + hy * g2 + hz * g3;
+            gr[hplane] = (g1 - hx * dot) / len; gr[2 * hplane] = (g2 - hy * dot) / len; gr[3 * hplane] = (g3 - hz * dot) / len;
+        } else {
+            gr[hplane] = g1 / 1e-7f; gr[2 * hplane] = g2 / 1e-7f; gr[3 * hplane] = g3 / 1e-7f;
+        }
+        gr[4 * hplane] = (dp >= 0.f && dp <= 1.f) ? go[4 * hplane] : 0.f;
+        gr[5 * hplane] = (ao >= 0.f && ao <= 1.f) ? go[5 * hplane] : 0.f;
+    }
+}
+
 } // namespace
 
 extern "C" {
@@ -395,6 +562,37 @@ int isrLossUnshadedBackward(const float* gt, const float* pred, const float* pre
     if (int rc = fill_loss_params(P, gt, pred, prev, N, H, W, pad, weights15, enabled, shading12, ao_strength, inverse_ao)) return rc;
     P.gout = gvalues16; P.gpred = gpred; P.gprev = gprev;
     hipLaunchKernelGGL(loss_unshaded_kernel<true>, dim3(P.blocks), dim3(256), 0, (hipStream_t)stream, P);
+    return hipGetLastError() == hipSuccess ? 0 : -2;
+}
+
+int isrRecurrentInputForward(const float* prev_raw, const float* input, const float* flow, float* net_input, float* warped,
+                             int B, int h, int w, long long inputBatchStride, long long flowBatchStride, void* stream)
+{
+    if (!prev_raw || !input || !flow || !net_input || !warped || B <= 0 || h <= 0 || w <= 0 || B > 65535 || h > 65535) return -1;
+    if (inputBatchStride < 5LL * h * w || flowBatchStride < 2LL * h * w) return -1;
+    RecurParams p = {};
+    p.raw = prev_raw; p.input = input; p.flow = flow; p.netin = net_input; p.warped = warped;
+    p.inStride = inputBatchStride; p.flowStride = flowBatchStride; p.B = B; p.h = h; p.w = w;
+    hipLaunchKernelGGL(recurrent_input_fwd_kernel, dim3((4 * w + 255) / 256, h, B), dim3(256), 0, (hipStream_t)stream, p);
+    return hipGetLastError() == hipSuccess ? 0 : -2;
+}
+
+int isrRecurrentInputBackward(const float* prev_raw, const float* flow, const float* g_net_input, const float* g_warped,
+                              float* scratch, float* g_prev_raw, int B, int h, int w, long long flowBatchStride, void* stream)
+{
+    if (!prev_raw || !flow || !scratch || !g_prev_raw || B <= 0 || h <= 0 || w <= 0 || B > 65535 || h > 65535) return -1;
+    if (flowBatchStride < 2LL * h * w) return -1;
+    RecurParams p = {};
+    p.raw = prev_raw; p.flow = flow; p.flowStride = flowBatchStride; p.B = B; p.h = h; p.w = w;
+    p.gnetin = g_net_input; p.gwarped = g_warped; p.gout = scratch; p.graw = g_prev_raw;
+    hipStream_t s = (hipStream_t)stream;
+    const long long pixels = 16LL * B * h * w;
+    if (hipMemsetAsync(scratch, 0, (size_t)pixels * 6 * sizeof(float), s) != hipSuccess) return -2;
+    if (g_net_input || g_warped)
+        hipLaunchKernelGGL(recurrent_input_scatter_kernel, dim3((4 * w + 255) / 256, h, B), dim3(256), 0, s, p);
+    long long blocks = (pixels + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(recurrent_input_post_kernel, dim3((unsigned)blocks), dim3(256), 0, s, p, pixels);
     return hipGetLastError() == hipSuccess ? 0 : -2;
 }
 

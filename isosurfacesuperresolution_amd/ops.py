@@ -61,6 +61,8 @@ def _sr():
         lib.isrLossUnshadedForward.restype = ci
         lib.isrLossUnshadedBackward.argtypes = [vp, vp, vp, ci, ci, ci, ci, vp, ctypes.c_uint, vp, cf, ci, vp, vp, vp, vp]
         lib.isrLossUnshadedBackward.restype = ci
+        lib.isrRecurrentInputForward.argtypes = [vp, vp, vp, vp, vp, ci, ci, ci, ll, ll, vp]; lib.isrRecurrentInputForward.restype = ci
+        lib.isrRecurrentInputBackward.argtypes = [vp, vp, vp, vp, vp, vp, ci, ci, ci, ll, vp]; lib.isrRecurrentInputBackward.restype = ci
         lib.isrProfileEnable.argtypes = [ci]; lib.isrProfileEnable.restype = ci
         lib.isrProfileCount.argtypes = []; lib.isrProfileCount.restype = ci
         lib.isrProfileGet.argtypes = [ci, vp, vp, vp]; lib.isrProfileGet.restype = ci
@@ -449,6 +451,61 @@ def bilinear_upsample2x(x):
     if not x.is_cuda or x.dtype != torch.float32 or x.shape[3] % 2:
         return F.interpolate(x, scale_factor=2, mode='bilinear', align_corners=False)
     return _Upsample2xFunction.apply(x)
+
+
+def _batch_view(t, c, h, w):
+    """(tensor, batch stride in floats) of a [B, c, h, w] view whose images are packed (a frame of a [B, T, ..] clip)."""
+    if t.stride(3) == 1 and t.stride(2) == w and t.stride(1) == h * w and (t.shape[0] == 1 or t.stride(0) >= c * h * w):
+        return t, (t.stride(0) if t.shape[0] > 1 else c * h * w)
+    t = t.contiguous()
+    return t, c * h * w
+
+
+class _RecurrentInputFunction(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, prev_raw, input_low, flow_low):
+        prev_raw = prev_raw.contiguous()
+        b, _, h, w = input_low.shape
+        inp, istride = _batch_view(input_low, 5, h, w)
+        flo, fstride = _batch_view(flow_low, 2, h, w)
+        netin = torch.empty((b, 101, h, w), dtype=torch.float32, device=prev_raw.device)
+        warped = torch.empty((b, 6, 4 * h, 4 * w), dtype=torch.float32, device=prev_raw.device)
+        rc = _sr().isrRecurrentInputForward(_ptr(prev_raw), _ptr(inp), _ptr(flo), _ptr(netin), _ptr(warped), b, h, w,
+                                            istride, fstride, _stream())
+        if rc != 0:
+            raise RuntimeError("isrRecurrentInputForward failed (%d)" % rc)
+        ctx.save_for_backward(prev_raw, flo)
+        ctx.fstride = fstride
+        return netin, warped
+
+    @staticmethod
+    def backward(ctx, g_netin, g_warped):
+        prev_raw, flo = ctx.saved_tensors
+        b, _, H, W = prev_raw.shape
+        g_netin = g_netin.contiguous() if g_netin is not None else None
+        g_warped = g_warped.contiguous() if g_warped is not None else None
+        scratch = torch.empty_like(prev_raw)
+        g_raw = torch.empty_like(prev_raw)
+        rc = _sr().isrRecurrentInputBackward(_ptr(prev_raw), _ptr(flo), _ptr(g_netin), _ptr(g_warped), _ptr(scratch), _ptr(g_raw),
+                                             b, H // 4, W // 4, ctx.fstride, _stream())
+        if rc != 0:
+            raise RuntimeError("isrRecurrentInputBackward failed (%d)" % rc)
+        return g_raw, None, None
+
+
+def recurrent_input(prev_raw, input_low, flow_low):
+    """Network input of frame t > 0 of a training clip and the warped previous frame the temp-l2 loss compares against:
+    (net_input [B,101,h,w], warped [B,6,4h,4w]) from the RAW prediction of frame t-1 [B,6,4h,4w], the frame's low-res
+    input [B,5,h,w] and the flow [B,2,h,w]; differentiable w.r.t. prev_raw.  Replaces clamp / normalize / cat,
+    ``VideoTools.warp_upscale(.., special_mask=True)``, ``VideoTools.flatten_high`` and the final cat (~25 launches
+    forward, ~35 backward) by one launch forward and three backward."""
+    return _RecurrentInputFunction.apply(prev_raw, input_low, flow_low)
+
+
+def recurrent_input_supported(prev_raw, input_low, flow_low, upscale):
+    return (upscale == 4 and prev_raw.is_cuda and prev_raw.dtype == torch.float32 and input_low.dtype == torch.float32
+            and prev_raw.shape[1] == 6 and input_low.shape[1] == 5 and not flow_low.requires_grad and not input_low.requires_grad
+            and prev_raw.shape[2] == 4 * input_low.shape[2] and prev_raw.shape[3] == 4 * input_low.shape[3])
 
 
 LOSS_KINDS = ('mse', 'l1', 'temp-l2')

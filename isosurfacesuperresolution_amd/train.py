@@ -37,12 +37,12 @@ def backward(loss):
 
 
 def clip_loss(model, criterion, input, flow, target, initial_image="zero", upscale=4, upsample="bilinear",
-              disable_temporal=False):
+              disable_temporal=False, fused_recurrence=True):
     """input [B,T,5,h,w], flow [B,T,2,h,w], target [B,T,6,4h,4w] -> (loss tensor, sum of the per-frame losses).
     The reference reads every frame's loss back with ``.item()`` (mainVideoUnshaded.py:454); here the sum is accumulated
     on the device and read back ONCE after the last frame, so the whole clip is enqueued without a stall."""
     B, T, Cout, Hh, Wh = target.shape
-    previous_output = None
+    prediction = None
     loss = 0
     loss_sum = None
     lazy_before = getattr(criterion, 'lazy_values', None)
@@ -60,24 +60,29 @@ def clip_loss(model, criterion, input, flow, target, initial_image="zero", upsca
             previous_warped_loss = target[:, 0]
             if feed_inputs:
                 previous_input = F.interpolate(input[:, 0], size=(Hh, Wh), **kw)
+            single_input = torch.cat((input[:, j], VideoTools.flatten_high(previous_warped, upscale)), dim=1)
         else:
-            previous_warped = VideoTools.warp_upscale(previous_output, flow[:, j - 1], upscale, special_mask=True)
+            if fused_recurrence and ops.recurrent_input_supported(prediction, input[:, j], flow[:, j - 1], upscale):
+                # clamp / normalize of the previous prediction, warp, space-to-depth and cat in one kernel
+                single_input, previous_warped = ops.recurrent_input(prediction, input[:, j], flow[:, j - 1])
+            else:
+                previous_output = torch.cat([
+                    torch.clamp(prediction[:, 0:1], -1, +1),
+                    ScreenSpaceShading.normalize(prediction[:, 1:4], dim=1),
+                    torch.clamp(prediction[:, 4:5], 0, +1),
+                    torch.clamp(prediction[:, 5:6], 0, +1)], dim=1)       # NOT detached: gradients flow through time
+                previous_warped = VideoTools.warp_upscale(previous_output, flow[:, j - 1], upscale, special_mask=True)
+                single_input = torch.cat((input[:, j], VideoTools.flatten_high(previous_warped, upscale)), dim=1)
             previous_warped_loss = previous_warped
             if feed_inputs:
                 previous_input = F.interpolate(input[:, j - 1], size=(Hh, Wh), **kw)
                 previous_input = VideoTools.warp_upscale(previous_input, flow[:, j - 1], upscale, special_mask=True)
-        single_input = torch.cat((input[:, j], VideoTools.flatten_high(previous_warped, upscale)), dim=1)
         prediction, _ = model(single_input)
         if feed_inputs:
             input_high = F.interpolate(input[:, j], size=(Hh, Wh), **kw)
         loss0, _ = criterion(target[:, j], prediction, input_high, previous_input, previous_warped_loss)
         loss = loss + loss0
         loss_sum = loss0.detach() if loss_sum is None else loss_sum + loss0.detach()
-        previous_output = torch.cat([
-            torch.clamp(prediction[:, 0:1], -1, +1),
-            ScreenSpaceShading.normalize(prediction[:, 1:4], dim=1),
-            torch.clamp(prediction[:, 4:5], 0, +1),
-            torch.clamp(prediction[:, 5:6], 0, +1)], dim=1)
     if lazy_before is not None:
         criterion.lazy_values = lazy_before
     return loss, loss_sum
