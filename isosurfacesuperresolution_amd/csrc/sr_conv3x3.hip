@@ -817,7 +817,10 @@ struct WGradParams {
 // parked in LDS after it.  TAPS = 9: one workgroup accumulates all taps (144 accumulator registers per wave);
 // TAPS = 3: three workgroups share a tile set, one row of the 3x3 each -- three times the workgroups for small
 // problems (the 32x32 training crops are 128 tiles for 256 CUs).
-template <int TAPS>
+// KSPLIT (at most 32 output channels in this launch, e.g. the 64 -> 6 output layer): instead of idling on an empty
+// second channel block, the waves m = 1 take rows 2..3 of every tile and the waves m = 0 rows 0..1, each pair writes
+// its own slab (g and G + g) -- half the MFMAs per workgroup.
+template <int TAPS, bool KSPLIT = false>
 __global__ __launch_bounds__(NTHREADS, 1) void conv3x3_wgrad_kernel(const WGradParams p)
 {
     __shared__ float gzs[64 * GZ_STRIDE];
@@ -899,10 +902,11 @@ __global__ __launch_bounds__(NTHREADS, 1) void conv3x3_wgrad_kernel(const WGradP
         const bool more = tile + nslab < p.ntiles;
         if (more) fetch(tile + nslab);
         __builtin_amdgcn_sched_barrier(0);               // the loads stay above the MFMA block
-        const float* ga = &gzs[(m * 32 + j) * GZ_STRIDE + kh];
+        const float* ga = &gzs[((KSPLIT ? 0 : m * 32) + j) * GZ_STRIDE + kh];
         const float* xb = &xps[(nn * 32 + j) * XP_PLANE + kh];
 #pragma unroll
-        for (int ry = 0; ry < WG_TH; ++ry) {
+        for (int r2 = 0; r2 < (KSPLIT ? WG_TH / 2 : WG_TH); ++r2) {
+            const int ry = KSPLIT ? m * (WG_TH / 2) + r2 : r2;
 #pragma unroll 4
             for (int rx = 0; rx < WG_TW; rx += 2) {
                 const float a = ga[ry * WG_TW + rx];
@@ -921,17 +925,18 @@ __global__ __launch_bounds__(NTHREADS, 1) void conv3x3_wgrad_kernel(const WGradP
         __syncthreads();
     }
     // slab[g][tap][co(64)][ci(64)]
-    float* slab = p.slabs + (size_t)g * 9 * 64 * 64;
+    const int gs = KSPLIT ? g + m * nslab : g;        // KSPLIT: slabs [0, G) hold rows 0..1, [G, 2G) rows 2..3; channels 32.. stay 0
+    float* slab = p.slabs + (size_t)gs * 9 * 64 * 64;
 #pragma unroll
     for (int t = 0; t < TAPS; ++t)
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
-            const int co = m * 32 + (i & 3) + 8 * (i >> 2) + 4 * kh;
+            const int co = (KSPLIT ? 0 : m * 32) + (i & 3) + 8 * (i >> 2) + 4 * kh;
             slab[((size_t)(tap0 + t) * 64 + co) * 64 + nn * 32 + j] = acc[t][i];
         }
     // bias gradient: the A operand already passes every gz value of the tile set through the waves with nn == 0
     const float btot = bsum + __shfl_xor(bsum, 32, 64);
-    if (p.bslabs && nn == 0 && tap0 == 0 && kh == 0) p.bslabs[(size_t)g * 64 + m * 32 + j] = btot;
+    if (p.bslabs && nn == 0 && tap0 == 0 && kh == 0) p.bslabs[(size_t)gs * 64 + (KSPLIT ? 0 : m * 32) + j] = btot;
 }
 
 // dw[co][ci][tap] = sum over the G slabs, in a fixed order (bitwise reproducible run to run).  A workgroup owns 64
@@ -1198,10 +1203,12 @@ int isrConv3x3WeightGradSegments(const float* const* xs, const float* const* gzs
         for (int ci0 = 0; ci0 < Cin; ci0 += 64) {
             p.co0 = co0; p.ci0 = ci0;
             p.bslabs = (db && ci0 == 0) ? bslabs : nullptr;
+            const bool ksplit = !split && Cout - co0 <= 32 && G <= WGRAD_MAX_SLABS / 2;
             if (split) hipLaunchKernelGGL(conv3x3_wgrad_kernel<3>, dim3(3 * G), dim3(NTHREADS), 0, s, p);
+            else if (ksplit) hipLaunchKernelGGL((conv3x3_wgrad_kernel<9, true>), dim3(G), dim3(NTHREADS), 0, s, p);
             else hipLaunchKernelGGL(conv3x3_wgrad_kernel<9>, dim3(G), dim3(NTHREADS), 0, s, p);
             hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(9 * 64 + 1), dim3(256), 0, s,
-                               p.slabs, G, dw, Cout, Cin, co0, ci0, (const float*)p.bslabs, db);
+                               p.slabs, ksplit ? 2 * G : G, dw, Cout, Cin, co0, ci0, (const float*)p.bslabs, db);
         }
     return hipGetLastError() == hipSuccess ? 0 : -2;
 }

@@ -487,6 +487,12 @@ __global__ __launch_bounds__(256) void recurrent_input_scatter_kernel(const Recu
     }
 }
 
+__global__ __launch_bounds__(256) void zero_fill_kernel(float4* __restrict__ dst, long long quads)
+{
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < quads; i += (long long)gridDim.x * 256)
+        dst[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+}
+
 // gradient of previous_output -> gradient of the raw prediction (clamps pass inside their closed range, as
 // torch.clamp does; normalize as in backprop_fields)
 __global__ __launch_bounds__(256) void recurrent_input_post_kernel(const RecurParams p, long long pixels)
@@ -587,7 +593,13 @@ int isrRecurrentInputBackward(const float* prev_raw, const float* flow, const fl
     p.gnetin = g_net_input; p.gwarped = g_warped; p.gout = scratch; p.graw = g_prev_raw;
     hipStream_t s = (hipStream_t)stream;
     const long long pixels = 16LL * B * h * w;
-    if (hipMemsetAsync(scratch, 0, (size_t)pixels * 6 * sizeof(float), s) != hipSuccess) return -2;
+    // (a kernel, not hipMemsetAsync: captured in a HIP graph the memset node did not take effect on replay)
+    {
+        const long long quads = pixels * 6 / 4;              // pixels is a multiple of 16
+        long long zb = (quads + 255) / 256;
+        if (zb > 4096) zb = 4096;
+        hipLaunchKernelGGL(zero_fill_kernel, dim3((unsigned)zb), dim3(256), 0, s, reinterpret_cast<float4*>(scratch), quads);
+    }
     if (g_net_input || g_warped)
         hipLaunchKernelGGL(recurrent_input_scatter_kernel, dim3((4 * w + 255) / 256, h, B), dim3(256), 0, s, p);
     long long blocks = (pixels + 255) / 256;

@@ -350,7 +350,10 @@ class _Conv3x3Function(torch.autograd.Function):
         res = residual.contiguous() if residual is not None else None
         b = bias.contiguous() if bias is not None else None
         cout, cin = weight.shape[0], weight.shape[1]
-        y = _launch_forward(x, prepare_weights(weight), b, res, cin, cout, act, slope, False)
+        if cout <= 8 and cin * x.shape[2] * x.shape[3] * 4 < 2 ** 31:
+            y = _launch_small(x, weight, b, res, act, slope)      # the 64 -> 6 output layer: 4x4x1 MFMA blocks
+        else:
+            y = _launch_forward(x, prepare_weights(weight), b, res, cin, cout, act, slope, False)
         ctx.act, ctx.slope = act, slope
         ctx.has_bias, ctx.has_res = bias is not None, residual is not None
         ctx.bias = bias if (bias is not None and bias.requires_grad) else None
