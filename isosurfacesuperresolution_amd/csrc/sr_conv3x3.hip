@@ -742,6 +742,107 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv3x3_fwd2_kernel(const ConvPar
 template <int MT>
 constexpr size_t conv_fwd_lds_bytes() { return (size_t)(2 * CHUNK + 2 * 9 * CK * MT * 32 + 4 * NTHREADS) * sizeof(float); }
 
+// ---- forward for small problems: one output row per workgroup, K split over the waves -------------
+// A batch of 32x32 training crops is 256 workgroups of the 4x32 tiling (16 crops; 32 for the two crops per GPU of
+// BASELINE config #3): at most one wave per SIMD, each running its 288 dependent k-steps alone -- 13 us of workgroup
+// life however few pixels there are.  Here a workgroup is ONE output row of 32 pixels x 32 output channels and its
+// four waves split the input channels; partial sums meet in LDS.  Four times the workgroups with a quarter of the
+// serial chain each.  Operands come straight from global memory / L2 (one dword per lane and MFMA operand, both
+// coalesced: weights [tap][ci][co] along co, pixels along x) through buffer descriptors whose out-of-range reads
+// return the zero padding; no staging, no barriers in the loop.
+constexpr int ROW_VARIANT = 12;
+
+__global__ __launch_bounds__(NTHREADS) void conv3x3_rowsplit_kernel(const ConvParams p)
+{
+    constexpr int KSB = 8;      // k-steps per block of up-front operand loads (144 registers; with 4 and more waves per
+                                // SIMD the kernel is L1/TA bound and loses to the LDS-staged tiling from ~200 tiles on)
+    __shared__ float part[4][16][64];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int j = lane & 31, kh = lane >> 5;
+    int bid = blockIdx.x;
+    const int cg = bid % p.cgroups; bid /= p.cgroups;
+    const int tx = bid % p.tilesX; bid /= p.tilesX;
+    const int oy = bid % p.H, n = bid / p.H;
+    const int ox0 = tx * 32, co0 = cg * 32;
+
+    const int chPerWave = p.cinPad >> 2;                     // cinPad is a multiple of 16
+    const int c0 = wave * chPerWave;
+    const rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.x + (size_t)n * p.xImage), 0,
+                                                         (int)((size_t)p.Cin * p.xPlane * 4), 0x00020000);
+    const rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.w), 0, (int)((size_t)9 * p.cinPad * p.coutPad * 4), 0x00020000);
+    // per-lane pixel offsets of the 9 taps inside a channel plane (BAD_OFFSET = zero padding)
+    unsigned xoff[9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+        const int iy = oy + t / 3 - 1, ix = ox0 + j + t % 3 - 1;
+        xoff[t] = ((unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W) ? (unsigned)(iy * p.W + ix) * 4u : BAD_OFFSET;
+    }
+    const unsigned planeBytes = (unsigned)p.xPlane * 4u;
+    const unsigned wTap = (unsigned)(p.cinPad * p.coutPad) * 4u, wRow = (unsigned)p.coutPad * 4u;
+    f32x16 acc;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[i] = 0.0f;
+
+    // a block of KS k-steps (2 channels each): ALL operand loads are issued before the first MFMA, so the wave pays
+    // one L2 round trip per block instead of one per k-step (there is no other wave on the SIMD to hide it)
+    auto block = [&](auto ks_tag, int c) {
+        constexpr int KS = decltype(ks_tag)::value;
+        float a[KS][9], b[KS][9];
+#pragma unroll
+        for (int k = 0; k < KS; ++k) {
+            const unsigned ci = (unsigned)(c + 2 * k + kh);
+            const unsigned cx = ci * planeBytes;
+            const unsigned cw = ci * wRow + (unsigned)(co0 + j) * 4u;
+#pragma unroll
+            for (int t = 0; t < 9; ++t) {
+                a[k][t] = buf_load(wrs, cw + (unsigned)t * wTap);
+                b[k][t] = buf_load(xrs, xoff[t] == BAD_OFFSET ? BAD_OFFSET : cx + xoff[t]);
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < KS; ++k)
+#pragma unroll
+            for (int t = 0; t < 9; ++t) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[k][t], b[k][t], acc, 0, 0, 0);
+    };
+    unsigned long long st0 = 0, st1 = 0, st2 = 0;
+    if (p.dbg & 8) st0 = __builtin_amdgcn_s_memtime();
+    int c = c0, rem = chPerWave >> 1;
+    for (; rem >= KSB; rem -= KSB, c += 2 * KSB) block(std::integral_constant<int, KSB>{}, c);
+    for (; rem >= 2; rem -= 2, c += 4) block(std::integral_constant<int, 2>{}, c);
+    if (p.dbg & 8) { st1 = __builtin_amdgcn_s_memtime(); }
+#pragma unroll
+    for (int i = 0; i < 16; ++i) part[wave][i][lane] = acc[i];
+    __syncthreads();
+    // wave w finishes accumulator registers 4w .. 4w+3: D row (cout) = (reg & 3) + 8 * (reg >> 2) + 4 * kh, col (pixel) = j
+    const int ox = ox0 + j;
+    const rsrc_t yrs = __builtin_amdgcn_make_buffer_rsrc(p.y + (size_t)n * p.yImage, 0, (int)((size_t)p.Cout * p.yPlane * 4), 0x00020000);
+    const rsrc_t rrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.residual ? p.residual + (size_t)n * p.rImage : p.y), 0,
+                                                         p.residual ? (int)((size_t)p.Cout * p.rPlane * 4) : 0, 0x00020000);
+    const unsigned pix = ox < p.W ? (unsigned)(oy * p.W + ox) * 4u : BAD_OFFSET;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int reg = wave * 4 + q;
+        const int co = co0 + (reg & 3) + 8 * (reg >> 2) + 4 * kh;
+        float v = (part[0][reg][lane] + part[1][reg][lane]) + (part[2][reg][lane] + part[3][reg][lane]);
+        v += p.bias[min(co, p.Cout - 1)];
+        if (p.act == ISR_ACT_RELU) v = v > 0.f ? v : 0.f;
+        else if (p.act == ISR_ACT_LEAKY) v = v > 0.f ? v : v * p.slope;
+        const bool ok = pix != BAD_OFFSET && co < p.Cout;
+        if (p.residual) {
+            const float r = buf_load(rrs, ok ? pix + (unsigned)co * (unsigned)p.rPlane * 4u : BAD_OFFSET);
+            if (p.act == ISR_ACT_GATE) v = r > 0.f ? v : 0.f; else v += r;
+        }
+        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), yrs, ok ? (int)(pix + (unsigned)co * (unsigned)p.yPlane * 4u) : (int)BAD_OFFSET, 0, 0);
+    }
+    if ((p.dbg & 8) && tid == 0 && p.stamps) {
+        st2 = __builtin_amdgcn_s_memtime();
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const unsigned long long st3 = __builtin_amdgcn_s_memtime();
+        unsigned long long* o = p.stamps + (size_t)blockIdx.x * 4;
+        o[0] = st0; o[1] = st1; o[2] = st2; o[3] = st3;
+    }
+}
+
 // ---- weight re-layout ------------------------------------------------------------------------
 __global__ void prepare_weights_kernel(const float* __restrict__ w, float* __restrict__ wp,
                                        int Cout, int Cin, int cinPad, int coutPad, int transpose_flip)
@@ -995,7 +1096,10 @@ static hipEvent_t pool_event()
 }
 
 static int g_conv_dbg = 0;
-static int g_conv_tile = 0;   // 0: automatic, 1: always 4x32 tiles, 2: always 16x32 tiles (tools / tests)
+static int g_conv_tile = 0;   // 0: automatic, 1: always 4x32 tiles, 2: always 16x32 tiles, 3: one row per workgroup (tools / tests)
+static long long g_row_threshold = 160;   // automatic: rows when the 4x32 tiling has at most this many workgroups
+                                          // (HIP-graph chain of 64 -> 64 layers on N crops of 32x32, rows vs 4x32 tiles:
+                                          //  N=2 7.5 vs 15.1 us, N=4 8.4 vs 15.2, N=8 12.1 vs 15.1, N=12 16.1 vs 16.0, N=16 19.5 vs 16.1)
 static int g_conv_algo = 1;   // 0: one workgroup per CU (64 channels), 1: two per CU (32 channels each)
 static unsigned long long* g_conv_stamps = nullptr;
 
@@ -1025,6 +1129,7 @@ int isrProfileGet(int i, int* variant, double* flops, float* ms)
 void isrDebugSetAblation(int bits) { g_conv_dbg = bits; }
 void isrDebugSetForwardAlgo(int a) { g_conv_algo = a; }
 void isrDebugSetForwardTile(int t) { g_conv_tile = t; }   // not part of the public header
+void isrDebugSetRowThreshold(long long n) { g_row_threshold = n; }
 void isrDebugSetStampBuffer(void* p) { g_conv_stamps = (unsigned long long*)p; }
 
 int isrConvCinPad(int Cin) { return ((Cin + CK - 1) / CK) * CK; }
@@ -1113,6 +1218,19 @@ int isrConv3x3ForwardStrided(const float* x, const float* wprep, const float* bi
         // small problems: 4x32 tiles (one row per wave) when the 16x32 tiling would leave most of the 2 x #CU slots empty
         const long long tilesY4 = (H + 3) / 4, nwgSmall = (long long)N * p.tilesX * tilesY4 * p.cgroups;
         const bool small = (g_conv_tile == 1) || (g_conv_tile == 0 && nwg * p.cgroups < 384 && nwgSmall <= 0x7fffffffLL);
+        // smaller still (at most one 4x32 workgroup per CU): one output row per workgroup, K split over its waves
+        const long long nwgRow = (long long)N * H * p.tilesX * p.cgroups;
+        const bool rows = !upsample2x && nwgRow <= 0x7fffffffLL &&
+                          ((g_conv_tile == 3) || (g_conv_tile == 0 && small && nwgSmall <= g_row_threshold));
+        if (rows) {
+            hipEvent_t e0 = nullptr, e1 = nullptr;
+            if (g_profile) {
+                e0 = pool_event(); e1 = pool_event();
+                g_records.push_back({ ROW_VARIANT, 2.0 * 9 * Cin * Cout * (double)N * H * W, e0, e1 });
+            }
+            ISR_LAUNCH(conv3x3_rowsplit_kernel, dim3((unsigned)nwgRow), block, 0, s, e0, e1, p);
+            return hipGetLastError() == hipSuccess ? 0 : -2;
+        }
         if (small) {
             p.tilesY = (int)tilesY4;
             hipEvent_t e0 = nullptr, e1 = nullptr;

@@ -114,7 +114,7 @@ def prepare_weights(weight, transpose_flip=False):
 VARIANT_NAMES = {6: "conv3x3_small_cout_kernel", 2: "conv3x3_fwd_kernel<1,false>", 3: "conv3x3_fwd_kernel<1,true>",
                  4: "conv3x3_fwd_kernel<2,false>", 5: "conv3x3_fwd_kernel<2,true>",
                  8: "conv3x3_fwd2_kernel<false,4>", 9: "conv3x3_fwd2_kernel<true,4>",
-                 10: "conv3x3_fwd2_kernel<false,1>", 11: "conv3x3_fwd2_kernel<true,1>"}
+                 10: "conv3x3_fwd2_kernel<false,1>", 11: "conv3x3_fwd2_kernel<true,1>", 12: "conv3x3_rowsplit_kernel"}
 
 
 def profile_enable(on):

@@ -66,11 +66,12 @@ def test_conv3x3_forward(case):
     assert err <= 1e-4, err
 
 
-@pytest.mark.parametrize("tile", [1, 2])
+@pytest.mark.parametrize("tile", [1, 2, 3])
 @pytest.mark.parametrize("case", [c for c in CASES if c[2] > 8 or c[8]])
 def test_conv3x3_forward_both_tilings(case, tile):
-    """The forward kernel has a 16x32 and a 4x32 tiling (picked by problem size); both must give the reference
-    result on every case, whatever the heuristic would choose."""
+    """The forward kernel has a 16x32 and a 4x32 tiling and a one-row-per-workgroup form with K split over the waves
+    (picked by problem size; 3 = the latter, which has no upsampling variant and falls back to the 4x32 tiling
+    there); all must give the reference result on every case, whatever the heuristic would choose."""
     from isosurfacesuperresolution_amd import ops
     lib = ops._sr()
     lib.isrDebugSetForwardTile(tile)
