@@ -749,7 +749,11 @@ constexpr size_t conv_fwd_lds_bytes() { return (size_t)(2 * CHUNK + 2 * 9 * CK *
 // four waves split the input channels; partial sums meet in LDS.  Four times the workgroups with a quarter of the
 // serial chain each.  Operands come straight from global memory / L2 (one dword per lane and MFMA operand, both
 // coalesced: weights [tap][ci][co] along co, pixels along x) through buffer descriptors whose out-of-range reads
-// return the zero padding; no staging, no barriers in the loop.
+// return the zero padding; no staging, no barriers in the loop.  The loads bound it: a dword-per-lane buffer load
+// occupies the texture path for 16 cycles per wave (stamps: 9200 cycles for the 4 x 144 loads of a CU's workgroup,
+// the 72 MFMAs of a wave are 4600).  Tried and dropped: channel / tap offsets as the instruction's scalar offset
+// (45 % slower), one dwordx3 load per patch row (dword-aligned multi-dword buffer loads return the first dword in
+// every component on this part), a second accumulator (no change: the chain is not what the wave waits for).
 constexpr int ROW_VARIANT = 12;
 
 __global__ __launch_bounds__(NTHREADS) void conv3x3_rowsplit_kernel(const ConvParams p)
