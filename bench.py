@@ -13,6 +13,7 @@ Rank 0 prints ONE JSON line.
 import argparse
 import contextlib
 import json
+import math
 import os
 import sys
 import time
@@ -34,6 +35,7 @@ def parse():
     ap.add_argument("--no-temporal", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--raymarch-variant", type=int, default=0)
+    ap.add_argument("--no-fast-mode", action="store_true", help="skip the separately reported fp16 fast-mode leg")
     ap.add_argument("--no-overlap", action="store_true", help="render frame t and super-resolve it back to back on one stream")
     ap.add_argument("--cpu-frames", type=int, default=6, help="frames in the CPU baseline sample (about 2 s each on 16 cores)")
     ap.add_argument("--side-waves", type=int, default=0, help="wave cap of the overlapped ray-march (0 = 4 per CU)")
@@ -182,12 +184,52 @@ def main():
                      "ms_per_frame": rm_time * 1e3, "alone_ms_per_frame": rm_alone * 1e3},
     }
 
+    if rank == 0 and world == 1 and not args.no_fast_mode:
+        result["f16_fast_mode"] = fast_mode_leg(pipe, origins, Wm, K, overlap, sync)
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         result.update(cpu_reference_leg(args, vol, iso, net, pipe, origins[Wm], low_w, low_h, result, rm_alone))
     if rank == 0:
         print(json.dumps(result))
     if world > 1:
         dist.destroy_process_group()
+
+
+def fast_mode_leg(pipe, origins, Wm, K, overlap, sync):
+    """The same frames with the convolutions in the fp16 fast mode (csrc/sr_conv_f16.hip), OUTSIDE the timed region of
+    the headline number and reported separately: it is not the parity path, its quality figure is a PSNR against the
+    fp32 frames."""
+    import torch
+    from isosurfacesuperresolution_amd import ops
+    n = min(K, 20)
+
+    def run(collect):
+        pipe.reset()
+        frames = []
+        for k in range(Wm):
+            pipe.frame(origins[k], origins[k + 1] if overlap else None)
+        pipe.reset()
+        sync()
+        t0 = time.perf_counter()
+        for k in range(n):
+            rgb, _ = pipe.frame(origins[Wm + k], origins[Wm + k + 1] if overlap and k + 1 < n else None)
+            if collect:
+                frames.append(rgb.clone())
+        sync()
+        return time.perf_counter() - t0, frames
+
+    _, ref = run(True)                       # fp32 frames of the same camera path
+    ops.FAST_F16 = True
+    try:
+        _, fast = run(True)
+        elapsed, _ = run(False)
+    finally:
+        ops.FAST_F16 = False
+    mse = [((a - b) ** 2).mean().item() for a, b in zip(fast, ref)]
+    psnr = [10.0 * math.log10(1.0 / m) if m > 0 else 100.0 for m in mse]
+    return {"value": n / elapsed, "unit": "frames/s", "ms_per_step": elapsed / n * 1e3, "frames": n,
+            "dtype": "f16 operands, f32 accumulation and tensors (convolutions with more than 8 output channels)",
+            "psnr_rgb_vs_f32_db_first": psnr[0], "psnr_rgb_vs_f32_db_min": min(psnr), "psnr_rgb_vs_f32_db_last": psnr[-1],
+            "note": "separate from `value`: not the 1e-4 parity path; the recurrence feeds its own output back, so the PSNR is that of the whole temporal sequence (random-init weights: rounding differences grow from frame to frame)"}
 
 
 def host_cores():
