@@ -20,6 +20,7 @@
 //   * two workgroups per CU (80 KB of LDS each) overlap one's staging with the other's MFMAs.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <type_traits>
 
 #include "../../include/isr_sr_kernels.h"
 
@@ -68,7 +69,13 @@ __global__ __launch_bounds__(B_THREADS, 2) void conv3x3_f16_kernel(const F16Conv
     extern __shared__ u32x4 patch[];                                         // B_UNITS patch units, then two weight buffers
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int j = lane & 31, h = lane >> 5;
-    int bid = blockIdx.x;
+    // workgroups are dealt to the 8 XCDs round robin: give every XCD (= every L2) a contiguous range of tiles, so that
+    // the halo lines a tile shares with its neighbours are fetched into one L2 once instead of into several
+    int bid;
+    {
+        const int nwg = gridDim.x, q = nwg >> 3, r = nwg & 7, xcd = blockIdx.x & 7;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (blockIdx.x >> 3);
+    }
     const int cg = bid % p.cgroups; bid /= p.cgroups;
     const int tx = bid % p.tilesX; bid /= p.tilesX;
     const int ty = bid % p.tilesY, n = bid / p.tilesY;
@@ -94,6 +101,35 @@ __global__ __launch_bounds__(B_THREADS, 2) void conv3x3_f16_kernel(const F16Conv
         // ---- stage the 64-channel patch: unit u = (channel group g, patch pixel) ----------------------------------
         // four units (32 dword loads) in flight per thread: with 8 the kernel sat at 2.1 TB/s, the bandwidth that
         // 16 KB in flight per CU buys at ~2 us of memory latency
+        // weights of a k-step: 1152 units [tap][lane half][64 couts], 4.5 per thread, L2 -> registers -> LDS
+        const int ks0 = cin0 >> 4;
+        const int nks = min(4, p.ksteps - ks0);
+        const int couts = min(64, p.coutPad - co0);
+        u32x4 wreg[4][5];
+        auto wfetch = [&](auto stag) {
+            constexpr int S = decltype(stag)::value;
+            if (S >= nks) return;
+#pragma unroll
+            for (int i = 0; i < 5; ++i) {
+                const int q = tid + i * B_THREADS;
+                const int tap = q >> 7, hh = (q >> 6) & 1, c = q & 63;
+                if (q < B_WUNITS && c < couts) wreg[S][i] = p.wq[(size_t)((tap * p.ksteps + ks0 + S) * 2 + hh) * p.coutPad + co0 + c];
+            }
+        };
+        auto wpark = [&](auto stag) {
+            constexpr int S = decltype(stag)::value;
+            if constexpr (S < 4) {
+                if (S >= nks) return;
+#pragma unroll
+                for (int i = 0; i < 5; ++i) {
+                    const int q = tid + i * B_THREADS;
+                    if (q < B_WUNITS && (q & 63) < couts) wbuf[(S & 1) * B_WUNITS + q] = wreg[S][i];
+                }
+            }
+        };
+        using K0 = std::integral_constant<int, 0>; using K1 = std::integral_constant<int, 1>;
+        using K2 = std::integral_constant<int, 2>; using K3 = std::integral_constant<int, 3>;
+        wfetch(K0{}); wfetch(K1{});                                      // in flight under the staging
         if (p.quads) {
             // rows of 4-pixel groups aligned to 16 bytes (W, plane stride and tile origin are multiples of 4): one
             // dwordx4 per channel covers 4 pixels -- a quarter of the load instructions (the texture path takes 16
@@ -157,35 +193,18 @@ __global__ __launch_bounds__(B_THREADS, 2) void conv3x3_f16_kernel(const F16Conv
                 if (u < B_UNITS) patch[u] = __builtin_bit_cast(u32x4, q);
             }
         }
-        // weights of a k-step: 1152 units [tap][lane half][64 couts], 4.5 per thread, L2 -> registers -> LDS
-        const int ks0 = cin0 >> 4;
-        const int nks = min(4, p.ksteps - ks0);
-        const int couts = min(64, p.coutPad - co0);
-        u32x4 wreg[5];
-        auto wfetch = [&](int s) {
-#pragma unroll
-            for (int i = 0; i < 5; ++i) {
-                const int q = tid + i * B_THREADS;
-                const int tap = q >> 7, hh = (q >> 6) & 1, c = q & 63;
-                if (q < B_WUNITS && c < couts) wreg[i] = p.wq[(size_t)((tap * p.ksteps + ks0 + s) * 2 + hh) * p.coutPad + co0 + c];
-            }
-        };
-        auto wpark = [&](int buf) {
-#pragma unroll
-            for (int i = 0; i < 5; ++i) {
-                const int q = tid + i * B_THREADS;
-                if (q < B_WUNITS && (q & 63) < couts) wbuf[buf * B_WUNITS + q] = wreg[i];
-            }
-        };
-        wfetch(0);
-        wpark(0);
+        wpark(K0{});
+        wfetch(K2{}); wfetch(K3{});                                      // two k-steps of MFMAs to arrive
         __syncthreads();
         if (p.stamps) st1 = __builtin_amdgcn_s_memtime();
         // ---- MFMAs: k-steps of 16 channels x 9 taps x (2 channel blocks x 2 rows) ---------------------------------
-        for (int s = 0; s < nks; ++s) {
-            if (s + 1 < nks) wfetch(s + 1);                                  // in flight under this k-step's MFMAs
-            const u32x4* wl = wbuf + (s & 1) * B_WUNITS + h * 64 + j;
-            const u32x4* bl = patch + (2 * s + h) * BP_PIX + (wave * 2) * BP_W + j;
+        auto kstep = [&](auto stag) {
+            constexpr int S = decltype(stag)::value;
+            if (S >= nks) return;
+            // the next k-step's weights go to the other buffer first (its readers passed the last barrier)
+            wpark(std::integral_constant<int, S + 1>{});
+            const u32x4* wl = wbuf + (S & 1) * B_WUNITS + h * 64 + j;
+            const u32x4* bl = patch + (2 * S + h) * BP_PIX + (wave * 2) * BP_W + j;
 #pragma unroll
             for (int tap = 0; tap < 9; ++tap) {
                 const int dy = tap / 3, dx = tap - dy * 3;
@@ -198,9 +217,9 @@ __global__ __launch_bounds__(B_THREADS, 2) void conv3x3_f16_kernel(const F16Conv
                     if (second) acc[1][r] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1, b, acc[1][r], 0, 0, 0);
                 }
             }
-            if (s + 1 < nks) wpark((s + 1) & 1);
             __syncthreads();
-        }
+        };
+        kstep(K0{}); kstep(K1{}); kstep(K2{}); kstep(K3{});
     }
 
     if (p.stamps) st2 = __builtin_amdgcn_s_memtime();
@@ -215,6 +234,41 @@ __global__ __launch_bounds__(B_THREADS, 2) void conv3x3_f16_kernel(const F16Conv
 #pragma unroll
         for (int i = 0; i < 16; ++i)
             bv[cb][i] = p.bias ? p.bias[min(co0 + cb * 32 + (i & 3) + 8 * (i >> 2) + 4 * h, p.Cout - 1)] : 0.0f;
+    if (((p.W | p.yPlane | p.rPlane) & 3) == 0) {
+        // wide path: each wave transposes one output row (64 couts x 32 pixels) through 8 KB of the now idle patch, so
+        // that a lane owns 4 consecutive pixels of one channel and the stores are dwordx4 (4x fewer instructions)
+        float* tr = reinterpret_cast<float*>(patch) + wave * (64 * 32);
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
+            const int oy = oy0 + wave * 2 + r;
+#pragma unroll
+            for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    float v = acc[cb][r][i] + bv[cb][i];
+                    if (p.act == ISR_ACT_RELU) v = v > 0.f ? v : 0.f;
+                    else if (p.act == ISR_ACT_LEAKY) v = v > 0.f ? v : v * p.slope;
+                    tr[(cb * 32 + (i & 3) + 8 * (i >> 2) + 4 * h) * 32 + j] = v;
+                }
+            __builtin_amdgcn_s_waitcnt(0xC07F);                              // lgkmcnt(0): same-wave hand-off through LDS
+#pragma unroll
+            for (int t = 0; t < 8; ++t) {
+                const int q = lane + 64 * t;                                 // float4 index: cout = q / 8, pixel group = q % 8
+                const int co = co0 + (q >> 3), px = ox0 + (q & 7) * 4;
+                const bool ok = oy < p.H && px < p.W && co < p.Cout;
+                float4 v = reinterpret_cast<const float4*>(tr)[q];
+                const unsigned pixoff = (unsigned)(oy * p.W + px) * 4u;
+                if (p.residual) {
+                    const u32x4 rr = __builtin_amdgcn_raw_buffer_load_b128(rrs, (int)(ok ? pixoff + (unsigned)co * (unsigned)p.rPlane * 4u : BAD_OFFSET), 0, 0);
+                    const float4 rf = __builtin_bit_cast(float4, rr);
+                    v.x += rf.x; v.y += rf.y; v.z += rf.z; v.w += rf.w;
+                }
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), yrs,
+                                                       (int)(ok ? pixoff + (unsigned)co * (unsigned)p.yPlane * 4u : BAD_OFFSET), 0, 0);
+            }
+            __builtin_amdgcn_s_waitcnt(0xC07F);                              // reads done before the next row overwrites the slab
+        }
+    } else {
 #pragma unroll
     for (int cb = 0; cb < 2; ++cb) {
         if (cb == 1 && !second) break;
@@ -234,6 +288,7 @@ __global__ __launch_bounds__(B_THREADS, 2) void conv3x3_f16_kernel(const F16Conv
                                                       ok ? (int)(pix + (unsigned)co * (unsigned)p.yPlane * 4u) : (int)BAD_OFFSET, 0, 0);
             }
         }
+    }
     }
     if (p.stamps && tid == 0) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
