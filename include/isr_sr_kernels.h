@@ -71,13 +71,16 @@ int isrConv3x3SmallCoutStrided(const float* x, const float* w8, const float* bia
  * reduced-precision mode be reported separately, judged by PSNR): operands rounded to fp16 (saturating) on their way
  * into LDS, v_mfma_f32_32x32x16_f16 with fp32 accumulation, fp32 tensors in memory as above (strides in floats, rows packed).  wq: prepared by
  * isrConvF16Prepare into isrConvF16WeightBytes(Cin, Cout) bytes of device memory (layout private to the kernel).
- * act: ISR_ACT_NONE / RELU / LEAKY; no upsampling variant (run isrUpsample2xForward first). */
+ * act: ISR_ACT_NONE / RELU / LEAKY. */
 long long isrConvF16WeightBytes(int Cin, int Cout);
 int isrConvF16Prepare(const float* w, void* wq, int Cout, int Cin, void* stream);
 int isrConv3x3ForwardF16(const float* x, const void* wq, const float* bias, const float* residual, float* y,
-                          int N, int Cin, int H, int W, int Cout, int act, float slope,
-                          long long xPlane, long long xImage, long long yPlane, long long yImage,
-                          long long rPlane, long long rImage, void* stream);
+                         int N, int Cin, int H, int W, int Cout, int act, float slope, int upsample2x,
+                         long long xPlane, long long xImage, long long yPlane, long long yImage,
+                         long long rPlane, long long rImage, void* stream);
+/* upsample2x = 1 (x: [N][Cin][H/2][W/2], fused bilinear x2) needs W/2 % 4 == 0, plane / image strides % 4 == 0 and a
+ * 16-byte aligned x (else -3): this predicate says so beforehand. */
+int isrConvF16SupportsUpsample(long long x_address, int Win, long long xPlane, long long xImage);
 
 /* Weight gradient of the same convolution: dw[Cout][Cin][3][3] = sum_{n,y,x} gz[n][co][y][x] * x[n][ci][y+ky-1][x+kx-1]
  * and db[Cout] = sum gz.  x: [N][Cin][H][W], gz: [N][Cout][H][W] (gradient w.r.t. the pre-activation).

@@ -23,6 +23,7 @@
 #include <type_traits>
 
 #include "../../include/isr_sr_kernels.h"
+#include "sr_finish.h"
 
 namespace {
 
@@ -51,6 +52,7 @@ struct F16ConvParams {
     int cgroups;         // 64-channel output groups covered by the grid
     int tilesX, tilesY;
     int act; float slope;
+    int Hin, Win;                 // input size: (H, W), or (H / 2, W / 2) for the upsampling variant
     int quads;                    // 1: W, the plane stride of x and its base address allow aligned dwordx4 staging
     unsigned long long* stamps;   // diagnostics (tools/bench_conv_f16.py): per-workgroup s_memtime stamps, or NULL
 };
@@ -64,6 +66,11 @@ __device__ __forceinline__ float buf_load(rsrc_t r, unsigned voff)
     return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, (int)voff, 0, 0));
 }
 
+// UPS: the convolution reads U(x), the x2 bilinear upsampling (align_corners=False) of x [Cin][H/2][W/2]: the low-res
+// region under the tile's patch (6 x 18 pixels x 64 channels, fp32) is staged into the LDS that will hold the weights,
+// and the fp16 patch is built from it with the four-tap blend of isrUpsample2xForward -- the upsampled tensor (530 MB
+// at 1080p, written once and read 1.3 times) never exists.
+template <bool UPS>
 __global__ __launch_bounds__(B_THREADS, 2) void conv3x3_f16_kernel(const F16ConvParams p)
 {
     extern __shared__ u32x4 patch[];                                         // B_UNITS patch units, then two weight buffers
@@ -130,7 +137,64 @@ __global__ __launch_bounds__(B_THREADS, 2) void conv3x3_f16_kernel(const F16Conv
         using K0 = std::integral_constant<int, 0>; using K1 = std::integral_constant<int, 1>;
         using K2 = std::integral_constant<int, 2>; using K3 = std::integral_constant<int, 3>;
         wfetch(K0{}); wfetch(K1{});                                      // in flight under the staging
-        if (p.quads) {
+        if (UPS) {
+            constexpr int LR_H = BT_H / 2 + 2, LR_W = BT_W / 2 + 2;         // 6 x 18 low-res pixels: rows oy0/2 - 1 .., cols ox0/2 - 1 ..
+            constexpr int LQ = (BT_W / 2 + 8) / 4;                           // 6 aligned quads per row: columns ox0/2 - 4 .. ox0/2 + 19
+            constexpr int LUNITS = B_CHUNK * LR_H * LQ;                      // (channel, row, quad) = 2304
+            float* tmp = reinterpret_cast<float*>(wbuf);                     // [64][6][18] fp32 = 27.6 KB of the 36.9 KB weight area
+            const int ly0 = oy0 / 2 - 1, lx0 = ox0 / 2 - 1;
+            for (int u0 = tid; u0 < LUNITS; u0 += 3 * B_THREADS) {
+                u32x4 v[3];
+#pragma unroll
+                for (int k = 0; k < 3; ++k) {
+                    const int u = u0 + k * B_THREADS;
+                    const int c = u / (LR_H * LQ), rem = u - c * (LR_H * LQ);
+                    const int r = rem / LQ, q = rem - r * LQ;
+                    const int iy = ly0 + r, ix = ox0 / 2 - 4 + 4 * q;
+                    const bool ok = u < LUNITS && (unsigned)iy < (unsigned)p.Hin && (unsigned)ix < (unsigned)p.Win;
+                    v[k] = __builtin_amdgcn_raw_buffer_load_b128(xrs, (int)(ok ? (unsigned)(cin0 + c) * planeBytes + (unsigned)(iy * p.Win + ix) * 4u
+                                                                               : BAD_OFFSET), 0, 0);
+                }
+#pragma unroll
+                for (int k = 0; k < 3; ++k) {
+                    const int u = u0 + k * B_THREADS;
+                    if (u >= LUNITS) continue;
+                    const int c = u / (LR_H * LQ), rem = u - c * (LR_H * LQ);
+                    const int r = rem / LQ, q = rem - r * LQ;
+                    const float4 f = __builtin_bit_cast(float4, v[k]);
+                    float* dst = tmp + (c * LR_H + r) * LR_W + 4 * q - 3;      // quad q holds low-res patch columns 4q - 3 .. 4q
+                    if (q > 0) dst[0] = f.x;
+                    if (q > 0 && q < LQ - 1) { dst[1] = f.y; dst[2] = f.z; }
+                    if (q < LQ - 1) dst[3] = f.w;
+                }
+            }
+            __syncthreads();
+            for (int u = tid; u < B_UNITS; u += B_THREADS) {
+                const int g = u / BP_PIX, pix = u - g * BP_PIX;
+                const int r = pix / BP_W, c = pix - r * BP_W;
+                const int Y = oy0 + r - 1, X = ox0 + c - 1;
+                f16x8 o;
+                if ((unsigned)Y < (unsigned)p.H && (unsigned)X < (unsigned)p.W) {
+                    int y0, y1, x0, x1; float ly, lx;
+                    isr_src_index(Y, 0.5f, p.Hin, y0, y1, ly);
+                    isr_src_index(X, 0.5f, p.Win, x0, x1, lx);
+                    const float hy = 1.f - ly, hx = 1.f - lx;
+                    const float* t0 = tmp + (g * 8) * (LR_H * LR_W) + (y0 - ly0) * LR_W - lx0;
+                    const float* t1 = tmp + (g * 8) * (LR_H * LR_W) + (y1 - ly0) * LR_W - lx0;
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) {
+                        const float* a = t0 + e * (LR_H * LR_W);
+                        const float* b = t1 + e * (LR_H * LR_W);
+                        o[e] = to_half(hy * (hx * a[x0] + lx * a[x1]) + ly * (hx * b[x0] + lx * b[x1]));
+                    }
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) o[e] = (_Float16)0.0f;
+                }
+                patch[u] = __builtin_bit_cast(u32x4, o);
+            }
+            __syncthreads();                                                 // tmp is free: the weights may land on it
+        } else if (p.quads) {
             // rows of 4-pixel groups aligned to 16 bytes (W, plane stride and tile origin are multiples of 4): one
             // dwordx4 per channel covers 4 pixels -- a quarter of the load instructions (the texture path takes 16
             // cycles per wave instruction whatever its width) and 4x the bytes in flight.  Unit = (channel group g,
@@ -343,17 +407,23 @@ int isrConvF16Prepare(const float* w, void* wq, int Cout, int Cin, void* stream)
 }
 
 int isrConv3x3ForwardF16(const float* x, const void* wq, const float* bias, const float* residual, float* y,
-                          int N, int Cin, int H, int W, int Cout, int act, float slope,
-                          long long xPlane, long long xImage, long long yPlane, long long yImage,
-                          long long rPlane, long long rImage, void* stream)
+                         int N, int Cin, int H, int W, int Cout, int act, float slope, int upsample2x,
+                         long long xPlane, long long xImage, long long yPlane, long long yImage,
+                         long long rPlane, long long rImage, void* stream)
 {
     if (!x || !wq || !y || N <= 0 || Cin <= 0 || Cout <= 0 || H <= 0 || W <= 0) return -1;
     if (act < ISR_ACT_NONE || act > ISR_ACT_LEAKY) return -1;
-    if (xPlane < (long long)H * W || yPlane < (long long)H * W || (residual && rPlane < (long long)H * W)) return -1;
+    const int Hin = upsample2x ? H / 2 : H, Win = upsample2x ? W / 2 : W;
+    if (upsample2x && ((H & 1) || (W & 1))) return -1;
+    if (xPlane < (long long)Hin * Win || yPlane < (long long)H * W || (residual && rPlane < (long long)H * W)) return -1;
     if (xPlane * Cin * 4 > 0x7fffffffLL || yPlane * Cout * 4 > 0x7fffffffLL || (residual && rPlane * Cout * 4 > 0x7fffffffLL)) return -1;
+    const bool aligned = (xPlane & 3) == 0 && (xImage & 3) == 0 && ((uintptr_t)x & 15) == 0;
+    // the upsampling variant stages aligned groups of four low-res pixels: isrConvF16SupportsUpsample() tells callers
+    if (upsample2x && !((Win & 3) == 0 && aligned)) return -3;
     F16ConvParams p;
     p.x = x; p.wq = (const u32x4*)wq; p.bias = bias; p.residual = residual; p.y = y;
     p.N = N; p.Cin = Cin; p.H = H; p.W = W; p.Cout = Cout;
+    p.Hin = Hin; p.Win = Win;
     p.xPlane = (int)xPlane; p.yPlane = (int)yPlane; p.rPlane = (int)(residual ? rPlane : yPlane);
     p.xImage = xImage; p.yImage = yImage; p.rImage = rImage;
     p.ksteps = (Cin + 15) / 16; p.coutPad = ((Cout + 31) / 32) * 32;
@@ -361,16 +431,23 @@ int isrConv3x3ForwardF16(const float* x, const void* wq, const float* bias, cons
     p.tilesX = (W + BT_W - 1) / BT_W; p.tilesY = (H + BT_H - 1) / BT_H;
     p.act = act; p.slope = slope;
     p.stamps = g_f16_stamps;
-    p.quads = ((W & 3) == 0 && (xPlane & 3) == 0 && (xImage & 3) == 0 && ((uintptr_t)x & 15) == 0) ? 1 : 0;
+    p.quads = ((W & 3) == 0 && aligned) ? 1 : 0;
     const long long nwg = (long long)N * p.tilesX * p.tilesY * p.cgroups;
     if (nwg > 0x7fffffffLL) return -1;
     static bool attr_done = false;
     if (!attr_done) {   // > 64 KiB of LDS needs an explicit opt-in
-        (void)hipFuncSetAttribute((const void*)conv3x3_f16_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, B_LDS_BYTES);
+        (void)hipFuncSetAttribute((const void*)conv3x3_f16_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, B_LDS_BYTES);
+        (void)hipFuncSetAttribute((const void*)conv3x3_f16_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, B_LDS_BYTES);
         attr_done = true;
     }
-    hipLaunchKernelGGL(conv3x3_f16_kernel, dim3((unsigned)nwg), dim3(B_THREADS), B_LDS_BYTES, (hipStream_t)stream, p);
+    if (upsample2x) hipLaunchKernelGGL(conv3x3_f16_kernel<true>, dim3((unsigned)nwg), dim3(B_THREADS), B_LDS_BYTES, (hipStream_t)stream, p);
+    else hipLaunchKernelGGL(conv3x3_f16_kernel<false>, dim3((unsigned)nwg), dim3(B_THREADS), B_LDS_BYTES, (hipStream_t)stream, p);
     return hipGetLastError() == hipSuccess ? 0 : -2;
+}
+
+int isrConvF16SupportsUpsample(long long x_address, int Win, long long xPlane, long long xImage)
+{
+    return ((Win & 3) == 0 && (xPlane & 3) == 0 && (xImage & 3) == 0 && (x_address & 15) == 0) ? 1 : 0;
 }
 
 } // extern "C"

@@ -65,7 +65,8 @@ def _sr():
         lib.isrRecurrentInputBackward.argtypes = [vp, vp, vp, vp, vp, vp, ci, ci, ci, ll, vp]; lib.isrRecurrentInputBackward.restype = ci
         lib.isrConvF16WeightBytes.argtypes = [ci, ci]; lib.isrConvF16WeightBytes.restype = ll
         lib.isrConvF16Prepare.argtypes = [vp, vp, ci, ci, vp]; lib.isrConvF16Prepare.restype = ci
-        lib.isrConv3x3ForwardF16.argtypes = [vp, vp, vp, vp, vp, ci, ci, ci, ci, ci, ci, cf, ll, ll, ll, ll, ll, ll, vp]
+        lib.isrConv3x3ForwardF16.argtypes = [vp, vp, vp, vp, vp, ci, ci, ci, ci, ci, ci, cf, ci, ll, ll, ll, ll, ll, ll, vp]
+        lib.isrConvF16SupportsUpsample.argtypes = [ll, ci, ll, ll]; lib.isrConvF16SupportsUpsample.restype = ci
         lib.isrConv3x3ForwardF16.restype = ci
         lib.isrProfileEnable.argtypes = [ci]; lib.isrProfileEnable.restype = ci
         lib.isrProfileCount.argtypes = []; lib.isrProfileCount.restype = ci
@@ -262,18 +263,22 @@ def conv3x3_f16(x, weight, bias=None, act='none', slope=0.01, residual=None, ups
         raise ValueError("unknown activation %r" % (act,))
     lib = _sr()
     with torch.no_grad():
-        if upsample2x:
-            x = bilinear_upsample2x(x)
-        n, cin, h, w = x.shape
-        cout = weight.shape[0]
         x, xp, xi = _plane_strides(x)
+        fuse = False
+        if upsample2x:
+            fuse = bool(lib.isrConvF16SupportsUpsample(x.data_ptr(), x.shape[3], xp, xi))
+            if not fuse:          # unaligned low-res rows: the resize runs as its own kernel first
+                x, xp, xi = _plane_strides(bilinear_upsample2x(x))
+        n, cin = x.shape[0], x.shape[1]
+        h, w = (2 * x.shape[2], 2 * x.shape[3]) if fuse else (x.shape[2], x.shape[3])
+        cout = weight.shape[0]
         rp = ri = 0
         if residual is not None:
             residual, rp, ri = _plane_strides(residual)
         y = empty_planes(n, cout, h, w, x.device)
         rc = lib.isrConv3x3ForwardF16(_ptr(x), _ptr(_prepare_f16(weight)), _ptr(bias.contiguous() if bias is not None else None),
-                                       _ptr(residual), _ptr(y), n, cin, h, w, cout, ACT_CODES[act], float(slope),
-                                       xp, xi, y.stride(1), cout * y.stride(1), rp, ri, _stream())
+                                      _ptr(residual), _ptr(y), n, cin, h, w, cout, ACT_CODES[act], float(slope), 1 if fuse else 0,
+                                      xp, xi, y.stride(1), cout * y.stride(1), rp, ri, _stream())
         if rc != 0:
             raise RuntimeError("isrConv3x3ForwardF16 failed (%d)" % rc)
     return y

@@ -15,7 +15,10 @@ CASES = [
     (1, 64, 64, 16, 32, 'relu', True, False, False),
     (1, 64, 64, 37, 45, 'none', True, True, False),       # ragged tile edges + fused skip
     (2, 101, 64, 20, 33, 'relu', True, False, False),     # two staging passes, the second one partly empty
-    (1, 64, 64, 18, 22, 'relu', True, False, True),       # x2 upsampling in front
+    (1, 64, 64, 18, 22, 'relu', True, False, True),       # x2 upsampling as its own kernel in front (rows not 16-byte aligned)
+    (1, 64, 64, 20, 24, 'relu', True, False, True),       # x2 upsampling fused into the staging
+    (2, 64, 64, 16, 32, 'none', True, True, True),
+    (1, 64, 64, 67, 120, 'relu', True, False, True),      # ragged tiles, several XCD ranges
     (3, 5, 7, 9, 11, 'leaky', False, False, False),
     (1, 64, 96, 20, 40, 'none', True, False, False),      # three 32-channel blocks: the last group has one
     (1, 64, 64, 1, 1, 'relu', True, False, False),
@@ -51,6 +54,12 @@ def test_f16_conv_is_the_same_operator(case):
         ref = _ref(xq, wq, b, act, 0.1, res, False)
         assert y.shape == ref.shape
         assert (y.cpu().double() - ref).abs().max().item() <= 1e-5
+    else:                                        # the fused resize against the separate kernel + the same convolution
+        up = ops.bilinear_upsample2x(x.cuda())
+        y1 = ops.conv3x3_f16(x.cuda(), wt.cuda(), b.cuda() if has_b else None, act, 0.1, res.cuda() if has_r else None, upsample2x=True)
+        y2 = ops.conv3x3_f16(up, wt.cuda(), b.cuda() if has_b else None, act, 0.1, res.cuda() if has_r else None)
+        # same blend; an FMA contracted differently flips single fp16 roundings (2^-11 relative) of the operands
+        assert (y1 - y2).abs().max().item() <= 1e-3
     # arbitrary fp32 inputs: fp16 rounding of both operands, ~2^-12 relative per product, averaging out over the sum
     y = ops.conv3x3_f16(x.cuda(), wt.cuda(), b.cuda() if has_b else None, act, 0.1, res.cuda() if has_r else None, upsample2x=ups)
     ref = _ref(x, wt, b, act, 0.1, res, ups)
