@@ -54,6 +54,7 @@ struct F16ConvParams {
     int act; float slope;
     int Hin, Win;                 // input size: (H, W), or (H / 2, W / 2) for the upsampling variant
     int quads;                    // 1: W, the plane stride of x and its base address allow aligned dwordx4 staging
+    int dbg;                      // diagnostics: 1 skip the MFMAs, 2 skip the staging loads, 4 skip the stores
     unsigned long long* stamps;   // diagnostics (tools/bench_conv_f16.py): per-workgroup s_memtime stamps, or NULL
 };
 
@@ -194,6 +195,8 @@ __global__ __launch_bounds__(B_THREADS, 2) void conv3x3_f16_kernel(const F16Conv
                 patch[u] = __builtin_bit_cast(u32x4, o);
             }
             __syncthreads();                                                 // tmp is free: the weights may land on it
+        } else if (p.dbg & 2) {
+            __syncthreads();
         } else if (p.quads) {
             // rows of 4-pixel groups aligned to 16 bytes (W, plane stride and tile origin are multiples of 4): one
             // dwordx4 per channel covers 4 pixels -- a quarter of the load instructions (the texture path takes 16
@@ -283,7 +286,7 @@ __global__ __launch_bounds__(B_THREADS, 2) void conv3x3_f16_kernel(const F16Conv
             }
             __syncthreads();
         };
-        kstep(K0{}); kstep(K1{}); kstep(K2{}); kstep(K3{});
+        if (!(p.dbg & 1)) { kstep(K0{}); kstep(K1{}); kstep(K2{}); kstep(K3{}); }
     }
 
     if (p.stamps) st2 = __builtin_amdgcn_s_memtime();
@@ -298,7 +301,8 @@ __global__ __launch_bounds__(B_THREADS, 2) void conv3x3_f16_kernel(const F16Conv
 #pragma unroll
         for (int i = 0; i < 16; ++i)
             bv[cb][i] = p.bias ? p.bias[min(co0 + cb * 32 + (i & 3) + 8 * (i >> 2) + 4 * h, p.Cout - 1)] : 0.0f;
-    if (((p.W | p.yPlane | p.rPlane) & 3) == 0) {
+    if (p.dbg & 4) {
+    } else if (((p.W | p.yPlane | p.rPlane) & 3) == 0) {
         // wide path: each wave transposes one output row (64 couts x 32 pixels) through 8 KB of the now idle patch, so
         // that a lane owns 4 consecutive pixels of one channel and the stores are dwordx4 (4x fewer instructions)
         float* tr = reinterpret_cast<float*>(patch) + wave * (64 * 32);
@@ -385,10 +389,12 @@ __global__ void prepare_weights_f16_kernel(const float* __restrict__ w, u32x4* _
 } // namespace
 
 static unsigned long long* g_f16_stamps = nullptr;
+static int g_f16_dbg = 0;
 
 extern "C" {
 
 void isrDebugSetF16StampBuffer(unsigned long long* buf) { g_f16_stamps = buf; }   // not part of the public header
+void isrDebugSetF16Ablation(int bits) { g_f16_dbg = bits; }
 
 long long isrConvF16WeightBytes(int Cin, int Cout)
 {
@@ -431,6 +437,7 @@ int isrConv3x3ForwardF16(const float* x, const void* wq, const float* bias, cons
     p.tilesX = (W + BT_W - 1) / BT_W; p.tilesY = (H + BT_H - 1) / BT_H;
     p.act = act; p.slope = slope;
     p.stamps = g_f16_stamps;
+    p.dbg = g_f16_dbg;
     p.quads = ((W & 3) == 0 && aligned) ? 1 : 0;
     const long long nwg = (long long)N * p.tilesX * p.tilesY * p.cgroups;
     if (nwg > 0x7fffffffLL) return -1;

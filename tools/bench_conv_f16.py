@@ -27,6 +27,15 @@ with torch.no_grad():
         st = buf.cpu().numpy().reshape(-1, 4).astype(np.float64); d = np.diff(st, axis=1)
         print("   cycles per workgroup: staging %.0f  MFMA loop %.0f  epilogue %.0f  life %.0f" % (
             np.median(d[:, 0]), np.median(d[:, 1]), np.median(d[:, 2]), np.median(st[:, 3] - st[:, 0])))
+        if (h, w) == (1080, 1920):
+            for bits, name in ((1, "no MFMAs"), (2, "no staging loads"), (4, "no stores"), (3, "stores only"), (5, "staging only"), (6, "MFMAs only")):
+                lib.isrDebugSetF16Ablation(bits)
+                ops.conv3x3_f16(x, wt, b, act='relu'); torch.cuda.synchronize()
+                e0.record()
+                for _ in range(10): ops.conv3x3_f16(x, wt, b, act='relu')
+                e1.record(); torch.cuda.synchronize()
+                print("   ablation %-18s %.3f ms" % (name, e0.elapsed_time(e1) / 10))
+            lib.isrDebugSetF16Ablation(0)
         gb = (cin * h * w * 4 * 1.2 + cout * h * w * 4) / 1e9
         print("%3d->%d %4dx%-4d fp32 %.3f ms  f16 %.3f ms  (x%.1f; %.0f GB/s of activations, %.0f TFLOP/s)" % (
             cin, cout, w, h, res["fp32"], res["f16"], res["fp32"] / res["f16"], gb / res["f16"] * 1e3,
