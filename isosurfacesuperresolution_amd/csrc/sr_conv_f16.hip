@@ -204,10 +204,11 @@ __global__ __launch_bounds__(B_THREADS, 2) void conv3x3_f16_kernel(const F16Conv
             // patch row r, quad q); quad q holds columns ox0 - 4 + 4q .. +3, i.e. patch columns 4q - 3 .. 4q.
             constexpr int QPR = (BT_W + 8) / 4;                              // 10 quads per patch row
             constexpr int QUNITS = B_GROUPS * BP_H * QPR;                    // 800
-            for (int u0 = tid; u0 < QUNITS; u0 += 2 * B_THREADS) {
-                u32x4 v[2][8];
+            constexpr int QB = 2;                                            // units (8 dwordx4 loads each) in flight per thread
+            for (int u0 = tid; u0 < QUNITS; u0 += QB * B_THREADS) {
+                u32x4 v[QB][8];
 #pragma unroll
-                for (int k = 0; k < 2; ++k) {
+                for (int k = 0; k < QB; ++k) {
                     const int u = u0 + k * B_THREADS;
                     const int g = u / (BP_H * QPR), rem = u - g * (BP_H * QPR);
                     const int r = rem / QPR, q = rem - r * QPR;
@@ -219,7 +220,7 @@ __global__ __launch_bounds__(B_THREADS, 2) void conv3x3_f16_kernel(const F16Conv
                         v[k][e] = __builtin_amdgcn_raw_buffer_load_b128(xrs, (int)(ok ? base + (unsigned)e * planeBytes : BAD_OFFSET), 0, 0);
                 }
 #pragma unroll
-                for (int k = 0; k < 2; ++k) {
+                for (int k = 0; k < QB; ++k) {
                     const int u = u0 + k * B_THREADS;
                     if (u >= QUNITS) continue;
                     const int g = u / (BP_H * QPR), rem = u - g * (BP_H * QPR);
