@@ -204,7 +204,7 @@ __global__ __launch_bounds__(B_THREADS, 2) void conv3x3_f16_kernel(const F16Conv
             // patch row r, quad q); quad q holds columns ox0 - 4 + 4q .. +3, i.e. patch columns 4q - 3 .. 4q.
             constexpr int QPR = (BT_W + 8) / 4;                              // 10 quads per patch row
             constexpr int QUNITS = B_GROUPS * BP_H * QPR;                    // 800
-            constexpr int QB = 2;                                            // units (8 dwordx4 loads each) in flight per thread
+            constexpr int QB = 2;                                            // units (8 dwordx4 loads each) in flight per thread; 3 or 4 spill (256-register budget)
             for (int u0 = tid; u0 < QUNITS; u0 += QB * B_THREADS) {
                 u32x4 v[QB][8];
 #pragma unroll
