@@ -36,6 +36,8 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--raymarch-variant", type=int, default=0)
     ap.add_argument("--no-fast-mode", action="store_true", help="skip the separately reported fp16 fast-mode leg")
+    ap.add_argument("--raymarch-large", default="", help="extra leg: the ray-march kernel alone on a volume that exceeds the caches, "
+                    "e.g. cloud512@1920x1080 (algorithmic bytes counted by the CPU restatement like the cpu_baseline leg)")
     ap.add_argument("--no-overlap", action="store_true", help="render frame t and super-resolve it back to back on one stream")
     ap.add_argument("--cpu-frames", type=int, default=6, help="frames in the CPU baseline sample (about 2 s each on 16 cores)")
     ap.add_argument("--side-waves", type=int, default=0, help="wave cap of the overlapped ray-march (0 = 4 per CU)")
@@ -188,6 +190,8 @@ def main():
         result["f16_fast_mode"] = fast_mode_leg(pipe, origins, Wm, K, overlap, sync)
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         result.update(cpu_reference_leg(args, vol, iso, net, pipe, origins[Wm], low_w, low_h, result, rm_alone))
+    if rank == 0 and world == 1 and args.raymarch_large:
+        result["raymarch_large"] = raymarch_large_leg(args.raymarch_large, renderer)
     if rank == 0:
         print(json.dumps(result))
     if world > 1:
@@ -230,6 +234,48 @@ def fast_mode_leg(pipe, origins, Wm, K, overlap, sync):
             "dtype": "f16 operands, f32 accumulation and tensors (convolutions with more than 8 output channels)",
             "psnr_rgb_vs_f32_db_first": psnr[0], "psnr_rgb_vs_f32_db_min": min(psnr), "psnr_rgb_vs_f32_db_last": psnr[-1],
             "note": "separate from `value`: not the 1e-4 parity path; the recurrence feeds its own output back, so the PSNR is that of the whole temporal sequence (random-init weights: rounding differences grow from frame to frame)"}
+
+
+def raymarch_large_leg(spec, renderer):
+    """The ray-march kernel on its own on a volume larger than L2 + Infinity Cache ("for 512^3 the
+    HBM figure becomes meaningful"): time from the dispatch-packet events, algorithmic bytes = bricks the CPU
+    restatement touches x 2048 B + W*H*48 B (counted here the way the cpu_baseline leg does), one frame."""
+    import torch
+    from isosurfacesuperresolution_amd import volumes as V
+    from oracle import iso_oracle
+    name, res = spec.split("@")
+    w, h = (int(v) for v in res.split("x"))
+    n = int(name.replace("cloud", "").replace("ejecta", ""))
+    vol = V.cloud(n) if name.startswith("cloud") else V.ejecta(n)
+    iso = 0.30 if name.startswith("cloud") else 0.34
+    renderer.load_dense(vol)
+    for c, v in [("cameraLookAt", "0,0,0"), ("cameraUp", "0,1,0"), ("cameraFoV", "30.000"), ("isovalue", "%5.3f" % iso),
+                 ("aosamples", "0"), ("resolution", "%d,%d" % (w, h)), ("viewport", "0,0,%d,%d" % (w, h))]:
+        renderer.send_command(c, v)
+    renderer.set_kernel_variant(0)
+    out = torch.empty((h, w, 12), dtype=torch.float32, device="cuda")
+    origins = [V.quantize3(V.orbit_camera(k)) for k in range(12)]
+    for k in range(2):
+        renderer.send_command("cameraOrigin", V.fmt3(origins[k]))
+        renderer.render_direct(out)
+    renderer.profile_enable(True)
+    for k in range(2, 12):
+        renderer.send_command("cameraOrigin", V.fmt3(origins[k]))
+        renderer.render_async(out, torch.cuda.current_stream())
+    torch.cuda.synchronize()
+    ms = renderer.profile_times_ms()
+    renderer.profile_enable(False)
+    t = sum(ms) / len(ms) * 1e-3
+    cores = host_cores()
+    ov = iso_oracle.OracleVolume(vol)
+    p = iso_oracle.make_params(w, h, origin=origins[11], fov=30.0, isovalue=float("%5.3f" % iso), last_origin=origins[10])
+    ref, stats = iso_oracle.render(ov, p, threads=cores)
+    gbuf = out.cpu().numpy()
+    bytes_alg = stats["bricks_touched"] * 2048 + w * h * 48
+    return {"volume": name, "resolution": "%dx%d" % (w, h), "kernel": "iso_render_gather", "ms_per_frame": t * 1e3,
+            "bricks_touched": stats["bricks_touched"], "samples": stats["samples"], "algorithmic_bytes": bytes_alg,
+            "achieved_GBps": bytes_alg / t / 1e9, "frac_of_8TBps": bytes_alg / t / 8e12, "samples_per_s": stats["samples"] / t,
+            "mask_mismatches_vs_cpu": int((gbuf[..., 3] != ref[..., 3]).sum())}
 
 
 def host_cores():
