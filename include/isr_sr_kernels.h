@@ -78,6 +78,15 @@ int isrConv3x3ForwardF16(const float* x, const void* wq, const float* bias, cons
                          int N, int Cin, int H, int W, int Cout, int act, float slope, int upsample2x,
                          long long xPlane, long long xImage, long long yPlane, long long yImage,
                          long long rPlane, long long rImage, void* stream);
+/* The same kernel with bf16 operands (same buffer sizes and calling convention; wq from isrConvBf16Prepare): the
+ * mixed-precision TRAINING mode uses it for the forward and data-gradient convolutions, whose operands (gradients)
+ * span the fp32 exponent range -- fp16 would flush the small ones to zero.  Both variants also accept
+ * act = ISR_ACT_GATE (y = residual > 0 ? conv + bias : 0). */
+int isrConvBf16Prepare(const float* w, void* wq, int Cout, int Cin, void* stream);
+int isrConv3x3ForwardBf16(const float* x, const void* wq, const float* bias, const float* residual, float* y,
+                          int N, int Cin, int H, int W, int Cout, int act, float slope, int upsample2x,
+                          long long xPlane, long long xImage, long long yPlane, long long yImage,
+                          long long rPlane, long long rImage, void* stream);
 /* upsample2x = 1 (x: [N][Cin][H/2][W/2], fused bilinear x2) needs W/2 % 4 == 0, plane / image strides % 4 == 0 and a
  * 16-byte aligned x (else -3): this predicate says so beforehand. */
 int isrConvF16SupportsUpsample(long long x_address, int Win, long long xPlane, long long xImage);

@@ -29,6 +29,7 @@ namespace {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 typedef __amdgpu_buffer_rsrc_t rsrc_t;
 
@@ -62,6 +63,20 @@ struct F16ConvParams {
 // layers -- but an overflow to infinity would turn into NaNs downstream)
 __device__ __forceinline__ _Float16 to_half(float v) { return (_Float16)fminf(fmaxf(v, -65504.0f), 65504.0f); }
 
+// operand type of the matrix instruction: fp16 (inference fast mode: three more mantissa bits) or bf16 (the
+// mixed-precision training mode: gradients span the fp32 exponent range, fp16 would flush the small ones to zero)
+template <bool BF> struct Operand;
+template <> struct Operand<false> {
+    typedef f16x8 V;
+    static __device__ __forceinline__ _Float16 cvt(float v) { return to_half(v); }
+    static __device__ __forceinline__ f32x16 mfma(V a, V b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0); }
+};
+template <> struct Operand<true> {
+    typedef bf16x8 V;
+    static __device__ __forceinline__ __bf16 cvt(float v) { return (__bf16)v; }
+    static __device__ __forceinline__ f32x16 mfma(V a, V b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0); }
+};
+
 __device__ __forceinline__ float buf_load(rsrc_t r, unsigned voff)
 {
     return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, (int)voff, 0, 0));
@@ -71,9 +86,11 @@ __device__ __forceinline__ float buf_load(rsrc_t r, unsigned voff)
 // region under the tile's patch (6 x 18 pixels x 64 channels, fp32) is staged into the LDS that will hold the weights,
 // and the fp16 patch is built from it with the four-tap blend of isrUpsample2xForward -- the upsampled tensor (530 MB
 // at 1080p, written once and read 1.3 times) never exists.
-template <bool UPS>
+template <bool UPS, bool BF>
 __global__ __launch_bounds__(B_THREADS, 2) void conv3x3_f16_kernel(const F16ConvParams p)
 {
+    using O = Operand<BF>;
+    using opx8 = typename O::V;
     extern __shared__ u32x4 patch[];                                         // B_UNITS patch units, then two weight buffers
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int j = lane & 31, h = lane >> 5;
@@ -174,7 +191,7 @@ __global__ __launch_bounds__(B_THREADS, 2) void conv3x3_f16_kernel(const F16Conv
                 const int g = u / BP_PIX, pix = u - g * BP_PIX;
                 const int r = pix / BP_W, c = pix - r * BP_W;
                 const int Y = oy0 + r - 1, X = ox0 + c - 1;
-                f16x8 o;
+                opx8 o;
                 if ((unsigned)Y < (unsigned)p.H && (unsigned)X < (unsigned)p.W) {
                     int y0, y1, x0, x1; float ly, lx;
                     isr_src_index(Y, 0.5f, p.Hin, y0, y1, ly);
@@ -186,11 +203,11 @@ __global__ __launch_bounds__(B_THREADS, 2) void conv3x3_f16_kernel(const F16Conv
                     for (int e = 0; e < 8; ++e) {
                         const float* a = t0 + e * (LR_H * LR_W);
                         const float* b = t1 + e * (LR_H * LR_W);
-                        o[e] = to_half(hy * (hx * a[x0] + lx * a[x1]) + ly * (hx * b[x0] + lx * b[x1]));
+                        o[e] = O::cvt(hy * (hx * a[x0] + lx * a[x1]) + ly * (hx * b[x0] + lx * b[x1]));
                     }
                 } else {
 #pragma unroll
-                    for (int e = 0; e < 8; ++e) o[e] = (_Float16)0.0f;
+                    for (int e = 0; e < 8; ++e) o[e] = O::cvt(0.0f);
                 }
                 patch[u] = __builtin_bit_cast(u32x4, o);
             }
@@ -225,11 +242,11 @@ __global__ __launch_bounds__(B_THREADS, 2) void conv3x3_f16_kernel(const F16Conv
                     if (u >= QUNITS) continue;
                     const int g = u / (BP_H * QPR), rem = u - g * (BP_H * QPR);
                     const int r = rem / QPR, q = rem - r * QPR;
-                    f16x8 o0, o1, o2, o3;
+                    opx8 o0, o1, o2, o3;
 #pragma unroll
                     for (int e = 0; e < 8; ++e) {
                         const float4 f = __builtin_bit_cast(float4, v[k][e]);
-                        o0[e] = to_half(f.x); o1[e] = to_half(f.y); o2[e] = to_half(f.z); o3[e] = to_half(f.w);
+                        o0[e] = O::cvt(f.x); o1[e] = O::cvt(f.y); o2[e] = O::cvt(f.z); o3[e] = O::cvt(f.w);
                     }
                     u32x4* dst = patch + g * BP_PIX + r * BP_W + 4 * q - 3;
                     // quad 0 contributes only its last pixel (patch column 0), quad 9 only its first (column 33)
@@ -255,9 +272,9 @@ __global__ __launch_bounds__(B_THREADS, 2) void conv3x3_f16_kernel(const F16Conv
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
                 const int u = u0 + k * B_THREADS;
-                f16x8 q;
+                opx8 q;
 #pragma unroll
-                for (int e = 0; e < 8; ++e) q[e] = to_half(v[k][e]);
+                for (int e = 0; e < 8; ++e) q[e] = O::cvt(v[k][e]);
                 if (u < B_UNITS) patch[u] = __builtin_bit_cast(u32x4, q);
             }
         }
@@ -276,13 +293,13 @@ __global__ __launch_bounds__(B_THREADS, 2) void conv3x3_f16_kernel(const F16Conv
 #pragma unroll
             for (int tap = 0; tap < 9; ++tap) {
                 const int dy = tap / 3, dx = tap - dy * 3;
-                const f16x8 a0 = __builtin_bit_cast(f16x8, wl[tap * 128]);
-                const f16x8 a1 = __builtin_bit_cast(f16x8, wl[tap * 128 + (second ? 32 : 0)]);
+                const opx8 a0 = __builtin_bit_cast(opx8, wl[tap * 128]);
+                const opx8 a1 = __builtin_bit_cast(opx8, wl[tap * 128 + (second ? 32 : 0)]);
 #pragma unroll
                 for (int r = 0; r < 2; ++r) {
-                    const f16x8 b = __builtin_bit_cast(f16x8, bl[(r + dy) * BP_W + dx]);
-                    acc[0][r] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0, b, acc[0][r], 0, 0, 0);
-                    if (second) acc[1][r] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1, b, acc[1][r], 0, 0, 0);
+                    const opx8 b = __builtin_bit_cast(opx8, bl[(r + dy) * BP_W + dx]);
+                    acc[0][r] = O::mfma(a0, b, acc[0][r]);
+                    if (second) acc[1][r] = O::mfma(a1, b, acc[1][r]);
                 }
             }
             __syncthreads();
@@ -330,7 +347,12 @@ __global__ __launch_bounds__(B_THREADS, 2) void conv3x3_f16_kernel(const F16Conv
                 if (p.residual) {
                     const u32x4 rr = __builtin_amdgcn_raw_buffer_load_b128(rrs, (int)(ok ? pixoff + (unsigned)co * (unsigned)p.rPlane * 4u : BAD_OFFSET), 0, 0);
                     const float4 rf = __builtin_bit_cast(float4, rr);
-                    v.x += rf.x; v.y += rf.y; v.z += rf.z; v.w += rf.w;
+                    if (p.act == ISR_ACT_GATE) {
+                        v.x = rf.x > 0.f ? v.x : 0.f; v.y = rf.y > 0.f ? v.y : 0.f;
+                        v.z = rf.z > 0.f ? v.z : 0.f; v.w = rf.w > 0.f ? v.w : 0.f;
+                    } else {
+                        v.x += rf.x; v.y += rf.y; v.z += rf.z; v.w += rf.w;
+                    }
                 }
                 __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), yrs,
                                                        (int)(ok ? pixoff + (unsigned)co * (unsigned)p.yPlane * 4u : BAD_OFFSET), 0, 0);
@@ -352,7 +374,10 @@ __global__ __launch_bounds__(B_THREADS, 2) void conv3x3_f16_kernel(const F16Conv
                 if (p.act == ISR_ACT_RELU) v = v > 0.f ? v : 0.f;
                 else if (p.act == ISR_ACT_LEAKY) v = v > 0.f ? v : v * p.slope;
                 const bool ok = pix != BAD_OFFSET && co < p.Cout;
-                if (p.residual) v += buf_load(rrs, ok ? pix + (unsigned)co * (unsigned)p.rPlane * 4u : BAD_OFFSET);
+                if (p.residual) {
+                    const float rv = buf_load(rrs, ok ? pix + (unsigned)co * (unsigned)p.rPlane * 4u : BAD_OFFSET);
+                    if (p.act == ISR_ACT_GATE) v = rv > 0.f ? v : 0.f; else v += rv;
+                }
                 __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), yrs,
                                                       ok ? (int)(pix + (unsigned)co * (unsigned)p.yPlane * 4u) : (int)BAD_OFFSET, 0, 0);
             }
@@ -369,19 +394,21 @@ __global__ __launch_bounds__(B_THREADS, 2) void conv3x3_f16_kernel(const F16Conv
 
 // w[Cout][Cin][3][3] fp32 -> wq[tap][k-step][lane half h][coutPad][8 x fp16]; element e of (k-step s, half h) is input
 // channel 16 s + 8 h + e (zero beyond Cin / Cout)
+template <bool BF>
 __global__ void prepare_weights_f16_kernel(const float* __restrict__ w, u32x4* __restrict__ wq, int Cout, int Cin, int ksteps, int coutPad)
 {
+    using O = Operand<BF>;
     const int total = 9 * ksteps * 2 * coutPad;
     for (int u = blockIdx.x * blockDim.x + threadIdx.x; u < total; u += gridDim.x * blockDim.x) {
         const int co = u % coutPad;
         const int hh = (u / coutPad) & 1;
         const int s = (u / (coutPad * 2)) % ksteps;
         const int tap = u / (coutPad * 2 * ksteps);
-        f16x8 q;
+        typename O::V q;
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
             const int ci = 16 * s + 8 * hh + e;
-            q[e] = to_half((co < Cout && ci < Cin) ? w[((size_t)co * Cin + ci) * 9 + tap] : 0.0f);
+            q[e] = O::cvt((co < Cout && ci < Cin) ? w[((size_t)co * Cin + ci) * 9 + tap] : 0.0f);
         }
         wq[u] = __builtin_bit_cast(u32x4, q);
     }
@@ -403,23 +430,26 @@ long long isrConvF16WeightBytes(int Cin, int Cout)
     return (long long)9 * ((Cin + 15) / 16) * 2 * (((Cout + 31) / 32) * 32) * 16;
 }
 
-int isrConvF16Prepare(const float* w, void* wq, int Cout, int Cin, void* stream)
+static int prepare_lp(const float* w, void* wq, int Cout, int Cin, void* stream, bool bf)
 {
     if (!w || !wq || Cout <= 0 || Cin <= 0) return -1;
     const int ksteps = (Cin + 15) / 16, coutPad = ((Cout + 31) / 32) * 32;
     const int total = 9 * ksteps * 2 * coutPad;
-    hipLaunchKernelGGL(prepare_weights_f16_kernel, dim3((total + 255) / 256), dim3(256), 0, (hipStream_t)stream,
-                       w, (u32x4*)wq, Cout, Cin, ksteps, coutPad);
+    if (bf) hipLaunchKernelGGL(prepare_weights_f16_kernel<true>, dim3((total + 255) / 256), dim3(256), 0, (hipStream_t)stream,
+                               w, (u32x4*)wq, Cout, Cin, ksteps, coutPad);
+    else hipLaunchKernelGGL(prepare_weights_f16_kernel<false>, dim3((total + 255) / 256), dim3(256), 0, (hipStream_t)stream,
+                            w, (u32x4*)wq, Cout, Cin, ksteps, coutPad);
     return hipGetLastError() == hipSuccess ? 0 : -2;
 }
 
-int isrConv3x3ForwardF16(const float* x, const void* wq, const float* bias, const float* residual, float* y,
-                         int N, int Cin, int H, int W, int Cout, int act, float slope, int upsample2x,
-                         long long xPlane, long long xImage, long long yPlane, long long yImage,
-                         long long rPlane, long long rImage, void* stream)
+static int forward_lp(const float* x, const void* wq, const float* bias, const float* residual, float* y,
+                      int N, int Cin, int H, int W, int Cout, int act, float slope, int upsample2x,
+                      long long xPlane, long long xImage, long long yPlane, long long yImage,
+                      long long rPlane, long long rImage, void* stream, bool bf)
 {
     if (!x || !wq || !y || N <= 0 || Cin <= 0 || Cout <= 0 || H <= 0 || W <= 0) return -1;
-    if (act < ISR_ACT_NONE || act > ISR_ACT_LEAKY) return -1;
+    if (act < ISR_ACT_NONE || act > ISR_ACT_GATE) return -1;
+    if (act == ISR_ACT_GATE && !residual) return -1;
     const int Hin = upsample2x ? H / 2 : H, Win = upsample2x ? W / 2 : W;
     if (upsample2x && ((H & 1) || (W & 1))) return -1;
     if (xPlane < (long long)Hin * Win || yPlane < (long long)H * W || (residual && rPlane < (long long)H * W)) return -1;
@@ -444,13 +474,41 @@ int isrConv3x3ForwardF16(const float* x, const void* wq, const float* bias, cons
     if (nwg > 0x7fffffffLL) return -1;
     static bool attr_done = false;
     if (!attr_done) {   // > 64 KiB of LDS needs an explicit opt-in
-        (void)hipFuncSetAttribute((const void*)conv3x3_f16_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, B_LDS_BYTES);
-        (void)hipFuncSetAttribute((const void*)conv3x3_f16_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, B_LDS_BYTES);
+        (void)hipFuncSetAttribute((const void*)conv3x3_f16_kernel<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, B_LDS_BYTES);
+        (void)hipFuncSetAttribute((const void*)conv3x3_f16_kernel<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, B_LDS_BYTES);
+        (void)hipFuncSetAttribute((const void*)conv3x3_f16_kernel<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, B_LDS_BYTES);
+        (void)hipFuncSetAttribute((const void*)conv3x3_f16_kernel<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, B_LDS_BYTES);
         attr_done = true;
     }
-    if (upsample2x) hipLaunchKernelGGL(conv3x3_f16_kernel<true>, dim3((unsigned)nwg), dim3(B_THREADS), B_LDS_BYTES, (hipStream_t)stream, p);
-    else hipLaunchKernelGGL(conv3x3_f16_kernel<false>, dim3((unsigned)nwg), dim3(B_THREADS), B_LDS_BYTES, (hipStream_t)stream, p);
+    const dim3 grid((unsigned)nwg), block(B_THREADS);
+    hipStream_t s = (hipStream_t)stream;
+    if (upsample2x) {
+        if (bf) hipLaunchKernelGGL((conv3x3_f16_kernel<true, true>), grid, block, B_LDS_BYTES, s, p);
+        else hipLaunchKernelGGL((conv3x3_f16_kernel<true, false>), grid, block, B_LDS_BYTES, s, p);
+    } else {
+        if (bf) hipLaunchKernelGGL((conv3x3_f16_kernel<false, true>), grid, block, B_LDS_BYTES, s, p);
+        else hipLaunchKernelGGL((conv3x3_f16_kernel<false, false>), grid, block, B_LDS_BYTES, s, p);
+    }
     return hipGetLastError() == hipSuccess ? 0 : -2;
+}
+
+int isrConvF16Prepare(const float* w, void* wq, int Cout, int Cin, void* stream) { return prepare_lp(w, wq, Cout, Cin, stream, false); }
+int isrConvBf16Prepare(const float* w, void* wq, int Cout, int Cin, void* stream) { return prepare_lp(w, wq, Cout, Cin, stream, true); }
+
+int isrConv3x3ForwardF16(const float* x, const void* wq, const float* bias, const float* residual, float* y,
+                         int N, int Cin, int H, int W, int Cout, int act, float slope, int upsample2x,
+                         long long xPlane, long long xImage, long long yPlane, long long yImage,
+                         long long rPlane, long long rImage, void* stream)
+{
+    return forward_lp(x, wq, bias, residual, y, N, Cin, H, W, Cout, act, slope, upsample2x, xPlane, xImage, yPlane, yImage, rPlane, rImage, stream, false);
+}
+
+int isrConv3x3ForwardBf16(const float* x, const void* wq, const float* bias, const float* residual, float* y,
+                          int N, int Cin, int H, int W, int Cout, int act, float slope, int upsample2x,
+                          long long xPlane, long long xImage, long long yPlane, long long yImage,
+                          long long rPlane, long long rImage, void* stream)
+{
+    return forward_lp(x, wq, bias, residual, y, N, Cin, H, W, Cout, act, slope, upsample2x, xPlane, xImage, yPlane, yImage, rPlane, rImage, stream, true);
 }
 
 int isrConvF16SupportsUpsample(long long x_address, int Win, long long xPlane, long long xImage)

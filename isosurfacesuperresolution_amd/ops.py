@@ -67,6 +67,8 @@ def _sr():
         lib.isrConvF16Prepare.argtypes = [vp, vp, ci, ci, vp]; lib.isrConvF16Prepare.restype = ci
         lib.isrConv3x3ForwardF16.argtypes = [vp, vp, vp, vp, vp, ci, ci, ci, ci, ci, ci, cf, ci, ll, ll, ll, ll, ll, ll, vp]
         lib.isrConvF16SupportsUpsample.argtypes = [ll, ci, ll, ll]; lib.isrConvF16SupportsUpsample.restype = ci
+        lib.isrConvBf16Prepare.argtypes = [vp, vp, ci, ci, vp]; lib.isrConvBf16Prepare.restype = ci
+        lib.isrConv3x3ForwardBf16.argtypes = lib.isrConv3x3ForwardF16.argtypes; lib.isrConv3x3ForwardBf16.restype = ci
         lib.isrConv3x3ForwardF16.restype = ci
         lib.isrProfileEnable.argtypes = [ci]; lib.isrProfileEnable.restype = ci
         lib.isrProfileCount.argtypes = []; lib.isrProfileCount.restype = ci
@@ -237,51 +239,85 @@ FAST_F16 = False
 _f16_cache = {}
 
 
-def _prepare_f16(weight):
+def _prepare_lp(weight, transpose_flip=False, bf16=False):
+    """Weights in the low-precision kernel's layout (fp16, or bf16 for the training mode); transpose_flip: the
+    data-gradient weights w'[ci][co][ky][kx] = w[co][ci][2-ky][2-kx]."""
     lib = _sr()
-    key = id(weight)
+    key = (id(weight), bool(transpose_flip), bool(bf16))
     hit = _f16_cache.get(key)
     if hit is not None:
         ref, version, ptr, wq = hit
         if ref() is weight and version == weight._version and ptr == weight.data_ptr():
             return wq
-    cout, cin = weight.shape[0], weight.shape[1]
+    w = weight.detach()
+    if transpose_flip:
+        w = w.flip(2, 3).transpose(0, 1)
+    w = w.contiguous()
+    cout, cin = w.shape[0], w.shape[1]
     wq = torch.empty(lib.isrConvF16WeightBytes(cin, cout), dtype=torch.uint8, device=weight.device)
-    rc = lib.isrConvF16Prepare(_ptr(weight.detach().contiguous()), _ptr(wq), cout, cin, _stream())
+    rc = (lib.isrConvBf16Prepare if bf16 else lib.isrConvF16Prepare)(_ptr(w), _ptr(wq), cout, cin, _stream())
     if rc != 0:
-        raise RuntimeError("isrConvF16Prepare failed (%d)" % rc)
-    if len(_f16_cache) > 256:
+        raise RuntimeError("isrConv%sPrepare failed (%d)" % ("Bf16" if bf16 else "F16", rc))
+    if len(_f16_cache) > 512:
         for k in [k for k, v in _f16_cache.items() if v[0]() is None]:
             del _f16_cache[k]
     _f16_cache[key] = (weakref.ref(weight), weight._version, weight.data_ptr(), wq)
     return wq
 
 
+def _prepare_f16(weight):
+    return _prepare_lp(weight)
+
+
+def _launch_lp(x, wq, bias, residual, cout, act, slope, upsample2x, bf16):
+    """One launch of isrConv3x3ForwardF16 / Bf16 (x: fp32 NCHW, channel planes may be padded)."""
+    lib = _sr()
+    x, xp, xi = _plane_strides(x)
+    fuse = False
+    if upsample2x:
+        fuse = bool(lib.isrConvF16SupportsUpsample(x.data_ptr(), x.shape[3], xp, xi))
+        if not fuse:          # unaligned low-res rows: the resize runs as its own kernel first
+            x, xp, xi = _plane_strides(bilinear_upsample2x(x))
+    n, cin = x.shape[0], x.shape[1]
+    h, w = (2 * x.shape[2], 2 * x.shape[3]) if fuse else (x.shape[2], x.shape[3])
+    rp = ri = 0
+    if residual is not None:
+        residual, rp, ri = _plane_strides(residual)
+    y = empty_planes(n, cout, h, w, x.device)
+    fn = lib.isrConv3x3ForwardBf16 if bf16 else lib.isrConv3x3ForwardF16
+    rc = fn(_ptr(x), _ptr(wq), _ptr(bias), _ptr(residual), _ptr(y), n, cin, h, w, cout, ACT_CODES[act], float(slope),
+            1 if fuse else 0, xp, xi, y.stride(1), cout * y.stride(1), rp, ri, _stream())
+    if rc != 0:
+        raise RuntimeError("isrConv3x3Forward%s failed (%d)" % ("Bf16" if bf16 else "F16", rc))
+    return y
+
+
 def conv3x3_f16(x, weight, bias=None, act='none', slope=0.01, residual=None, upsample2x=False):
     """``conv3x3`` in the fp16 fast mode (no autograd): y = act(conv3x3(U(x), fp16(w)) + bias) + residual."""
     if act not in ('none', 'relu', 'leaky'):
         raise ValueError("unknown activation %r" % (act,))
-    lib = _sr()
     with torch.no_grad():
-        x, xp, xi = _plane_strides(x)
-        fuse = False
-        if upsample2x:
-            fuse = bool(lib.isrConvF16SupportsUpsample(x.data_ptr(), x.shape[3], xp, xi))
-            if not fuse:          # unaligned low-res rows: the resize runs as its own kernel first
-                x, xp, xi = _plane_strides(bilinear_upsample2x(x))
-        n, cin = x.shape[0], x.shape[1]
-        h, w = (2 * x.shape[2], 2 * x.shape[3]) if fuse else (x.shape[2], x.shape[3])
-        cout = weight.shape[0]
-        rp = ri = 0
-        if residual is not None:
-            residual, rp, ri = _plane_strides(residual)
-        y = empty_planes(n, cout, h, w, x.device)
-        rc = lib.isrConv3x3ForwardF16(_ptr(x), _ptr(_prepare_f16(weight)), _ptr(bias.contiguous() if bias is not None else None),
-                                      _ptr(residual), _ptr(y), n, cin, h, w, cout, ACT_CODES[act], float(slope), 1 if fuse else 0,
-                                      xp, xi, y.stride(1), cout * y.stride(1), rp, ri, _stream())
-        if rc != 0:
-            raise RuntimeError("isrConv3x3ForwardF16 failed (%d)" % rc)
-    return y
+        return _launch_lp(x, _prepare_lp(weight), bias.contiguous() if bias is not None else None, residual, weight.shape[0],
+                          act, slope, upsample2x, False)
+
+
+# ---- mixed-precision training mode (opt-in, NOT the parity path) ------------------------------------------------------
+# TRAIN_BF16 = True runs the forward and data-gradient convolutions of the autograd functions below with bf16 MFMA
+# operands (fp32 accumulation, fp32 tensors, fp32 master weights; the weight gradients and everything else stay
+# fp32).  bf16 rather than fp16: gradients span the fp32 exponent range.  Layers with at most 8 input or output
+# channels (the 64 -> 6 output layer and its data gradient) keep their fp32 kernels.
+TRAIN_BF16 = False
+
+
+def _train_conv(x, weight, transpose_flip, bias, residual, act):
+    """Forward (or, with transpose_flip, data-gradient) convolution of the training graph."""
+    cout, cin = (weight.shape[1], weight.shape[0]) if transpose_flip else (weight.shape[0], weight.shape[1])
+    # the low-precision kernel is a streaming kernel with 8x32-pixel x 64-channel tiles: it pays from a few hundred
+    # tiles on (the 128x128 layers of a crop batch); below that the fp32 kernels' finer decompositions are faster
+    tiles = x.shape[0] * ((x.shape[2] + 7) // 8) * ((x.shape[3] + 31) // 32)
+    if TRAIN_BF16 and cout > 8 and cin > 8 and tiles >= 256:
+        return _launch_lp(x, _prepare_lp(weight, transpose_flip, True), bias, residual, cout, act, 0.0, False, True)
+    return _launch_forward(x, prepare_weights(weight, transpose_flip=transpose_flip), bias, residual, cin, cout, act, 0.0, False)
 
 
 _workspace = {}
@@ -371,8 +407,8 @@ class _ResidualBlockFunction(torch.autograd.Function):
     def forward(ctx, x, w1, b1, w2, b2):
         x = x.contiguous()
         c = w1.shape[0]
-        t = _launch_forward(x, prepare_weights(w1), b1.contiguous() if b1 is not None else None, None, c, c, 'relu', 0.0, False)
-        y = _launch_forward(t, prepare_weights(w2), b2.contiguous() if b2 is not None else None, x, c, c, 'none', 0.0, False)
+        t = _train_conv(x, w1, False, b1.contiguous() if b1 is not None else None, None, 'relu')
+        y = _train_conv(t, w2, False, b2.contiguous() if b2 is not None else None, x, 'none')
         ctx.params = (w1, b1, w2, b2)
         ctx.save_for_backward(x, t)
         return y
@@ -383,10 +419,10 @@ class _ResidualBlockFunction(torch.autograd.Function):
         w1, b1, w2, b2 = ctx.params
         gy = gy.contiguous()
         c = w1.shape[0]
-        gz1 = _launch_forward(gy, prepare_weights(w2, transpose_flip=True), None, t, c, c, 'gate', 0.0, False)
+        gz1 = _train_conv(gy, w2, True, None, t, 'gate')
         gx = None
         if ctx.needs_input_grad[0]:
-            gx = _launch_forward(gz1, prepare_weights(w1, transpose_flip=True), None, gy, c, c, 'none', 0.0, False)
+            gx = _train_conv(gz1, w1, True, None, gy, 'none')
         gw1 = gb1 = gw2 = gb2 = None
         if ctx.needs_input_grad[3] or (b2 is not None and ctx.needs_input_grad[4]):
             gw2, gb2 = _weight_grad_or_defer(w2, b2 if (b2 is not None and b2.requires_grad) else None, b2 is not None, t, gy)
@@ -412,8 +448,10 @@ class _Conv3x3Function(torch.autograd.Function):
         cout, cin = weight.shape[0], weight.shape[1]
         if cout <= 8 and cin * x.shape[2] * x.shape[3] * 4 < 2 ** 31:
             y = _launch_small(x, weight, b, res, act, slope)      # the 64 -> 6 output layer: 4x4x1 MFMA blocks
-        else:
+        elif act == 'leaky':
             y = _launch_forward(x, prepare_weights(weight), b, res, cin, cout, act, slope, False)
+        else:
+            y = _train_conv(x, weight, False, b, res, act)
         ctx.act, ctx.slope = act, slope
         ctx.has_bias, ctx.has_res = bias is not None, residual is not None
         ctx.bias = bias if (bias is not None and bias.requires_grad) else None
@@ -439,7 +477,7 @@ class _Conv3x3Function(torch.autograd.Function):
         gx = gw = gb = gres = None
         if ctx.needs_input_grad[0]:
             # data gradient = the same fused kernel on flipped / transposed weights
-            gx = _launch_forward(gz, prepare_weights(weight, transpose_flip=True), None, None, cout, cin, 'none', 0.0, False)
+            gx = _train_conv(gz, weight, True, None, None, 'none')
         if ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2]):
             gw, gb = _weight_grad_or_defer(ctx.weight, ctx.bias, ctx.has_bias, x, gz)
         if ctx.has_res and ctx.needs_input_grad[3]:

@@ -301,3 +301,40 @@ def test_clip_gradients_inside_a_hip_graph_are_reproduced_by_every_replay():
         assert abs(total.item() - ref_loss) <= 1e-5 * abs(ref_loss)
         for (name, p), r in zip(net.named_parameters(), ref):
             assert ((p.grad - r).norm() / r.norm()).item() <= 1e-3, (replay, name)
+
+
+def test_mixed_precision_training_mode_tracks_the_fp32_step():
+    """ops.TRAIN_BF16 (forward / data-gradient convolutions with bf16 MFMA operands, everything else fp32) is opt-in
+    and not a parity mode: its loss and weight gradients must stay close to the fp32 step's (bf16 operand rounding,
+    2^-9 relative per product), and switching it off must give the fp32 numbers back."""
+    from isosurfacesuperresolution_amd import models, losses as L, train, ops
+    opt = argparse.Namespace(upsample='bilinear', reconType='residual', useBN=False, numResidualLayers=3, losses=RECIPE,
+                             lossAO=0.0, lossAmbient=0.1, lossDiffuse=0.9, lossSpecular=0.0)
+    g = torch.Generator().manual_seed(13)
+    B, T = 2, 3
+    inp = torch.rand(B, T, 5, 32, 32, generator=g).cuda(); inp[:, :, 0] = inp[:, :, 0] * 2 - 1
+    flow = ((torch.rand(B, T, 2, 32, 32, generator=g) - 0.5) * 0.05).cuda()
+    tgt = torch.rand(B, T, 6, 128, 128, generator=g).cuda(); tgt[:, :, 0] = tgt[:, :, 0] * 2 - 1
+    torch.manual_seed(124)
+    net = models.createNetwork('EnhanceNet', 4, 101, [0, 1, 2, 3, 4], 6, opt).cuda()
+    crit = L.LossNetUnshaded('cuda', 5, 6, 128, 16, opt).cuda()
+
+    def grads():
+        net.zero_grad(set_to_none=True)
+        loss, total = train.clip_loss(net, crit, inp, flow, tgt, initial_image="zero")
+        train.backward(loss)
+        return total.item(), [p.grad.detach().clone() for p in net.parameters()]
+
+    l32, g32 = grads()
+    ops.TRAIN_BF16 = True
+    try:
+        l16, g16 = grads()
+    finally:
+        ops.TRAIN_BF16 = False
+    l32b, g32b = grads()
+    # (not bitwise: the scatter of the warp's backward uses float atomics)
+    assert l32b == l32 and all(((a - b).norm() / b.norm()).item() <= 1e-5 for a, b in zip(g32b, g32))
+    assert abs(l16 - l32) <= 2e-2 * abs(l32), (l16, l32)
+    errs = [((a - b).norm() / b.norm()).item() for a, b in zip(g16, g32)]
+    assert max(errs) <= 0.15, max(errs)
+    assert sorted(errs)[len(errs) // 2] <= 5e-2, sorted(errs)[-6:]

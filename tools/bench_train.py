@@ -10,6 +10,8 @@ steps = int(sys.argv[3]) if len(sys.argv) > 3 else 5
 opt = argparse.Namespace(upsample='bilinear', reconType='residual', useBN=False, numResidualLayers=10,
                          losses="l1:mask:1,l1:ao:1,l1:normal:10,l1:depth:10,temp-l2:color:0.1",
                          lossAO=0.0, lossAmbient=0.1, lossDiffuse=0.9, lossSpecular=0.0)
+if "bf16" in sys.argv:
+    ops.TRAIN_BF16 = True       # forward + data-gradient convolutions with bf16 MFMA operands (opt-in mixed precision)
 torch.manual_seed(124)
 net = models.createNetwork('EnhanceNet', 4, 101, [0, 1, 2, 3, 4], 6, opt).cuda()
 crit = losses.LossNetUnshaded('cuda', 5, 6, 128, 16, opt).cuda()
