@@ -4,7 +4,7 @@ import sys
 sys.path.insert(0, '.')
 import argparse
 import torch
-from isosurfacesuperresolution_amd import models, parallel_sr
+from isosurfacesuperresolution_amd import models, ops, parallel_sr
 from isosurfacesuperresolution_amd.inference import LoadedModel
 from isosurfacesuperresolution_amd.pipeline import default_shading
 opt = argparse.Namespace(upsample='bilinear', reconType='residual', useBN=False, numResidualLayers=10)
@@ -12,7 +12,10 @@ torch.manual_seed(0)
 net = models.createNetwork('EnhanceNet', 4, 101, [0, 1, 2, 3, 4], 6, opt)
 lm = LoadedModel.from_model(net, "cuda", parameters={"initialImage": "zero"})
 sr = parallel_sr.StripSuperResolution(lm, default_shading("cuda", 30.0))
-h, w = (int(v) for v in (sys.argv[1] if len(sys.argv) > 1 else "540x960").split("x"))
+_size = [a for a in sys.argv[1:] if "x" in a]
+h, w = (int(v) for v in (_size[0] if _size else "540x960").split("x"))
+if "f16" in sys.argv:
+    ops.FAST_F16 = True          # the opt-in fp16 fast mode, not the parity path
 g = torch.rand(h, w, 12, device="cuda")
 g[..., 3] = (g[..., 3] > 0.4).float()
 g[..., 8:10] = (g[..., 8:10] - 0.5) * 0.02
