@@ -106,6 +106,10 @@ int isrConv3x3WeightGrad(const float* x, const float* gz, float* dw, float* db, 
 int isrConvWeightGradMaxSegments(void);
 int isrConv3x3WeightGradSegments(const float* const* xs, const float* const* gzs, int segments, float* dw, float* db, void* workspace,
                                  int N, int Cin, int H, int W, int Cout, void* stream);
+/* The same sums with bf16 MFMA operands (fp32 accumulation and results; bias gradient from the fp32 values): the
+ * weight-gradient half of the opt-in mixed-precision training mode.  W % 4 == 0 and 16-byte aligned gzs[k] (else -3 / -1). */
+int isrConv3x3WeightGradSegmentsBf16(const float* const* xs, const float* const* gzs, int segments, float* dw, float* db, void* workspace,
+                                     int N, int Cin, int H, int W, int Cout, void* stream);
 
 /* x2 bilinear upsampling, align_corners=False (nn.Upsample(scale_factor=2, mode='bilinear') of
  * SuperresolutionNetwork/models/enhancenet.py:116,119 when it is not fused into the following convolution, i.e. in

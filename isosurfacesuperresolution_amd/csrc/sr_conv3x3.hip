@@ -1044,6 +1044,155 @@ __global__ __launch_bounds__(NTHREADS, 1) void conv3x3_wgrad_kernel(const WGradP
     if (p.bslabs && nn == 0 && tap0 == 0 && kh == 0) p.bslabs[(size_t)gs * 64 + (KSPLIT ? 0 : m * 32) + j] = btot;
 }
 
+// ---- weight gradient with bf16 operands (the opt-in mixed-precision training mode, not the parity step) ----------------
+// Same decomposition (M = co, N = ci, K = pixels of 4x32 tiles, one slab per workgroup, the same reduction), but the
+// tile is rounded to bf16 on its way into LDS and multiplied by v_mfma_f32_32x32x16_bf16 (16 pixels per instruction):
+// A fragment = 8 consecutive pixels of one gz channel (one ds_read_b128 from [co][pixel]), B fragment = 8 consecutive
+// pixels of one x channel SHIFTED by the tap: the row is read once as five dwords (10 pixels) and the three horizontal
+// taps are dwords 0..3, the 16-bit funnel shifts of neighbouring dwords, and dwords 1..4 -- no shifted copies in LDS.
+// At this MFMA rate the kernel is bound by streaming the tile (84 KB per 2300 MFMA cycles).  Needs W % 4 == 0.
+typedef __bf16 wbf16x8 __attribute__((ext_vector_type(8)));
+constexpr int BG_PITCH = 272;                  // bytes per gz channel row in LDS: 128 pixels x 2 + 16 (bank spread)
+constexpr int BX_ROW = 80;                     // bytes per x patch row: 40 pixels (34 used), 16-byte aligned rows
+constexpr int BX_PITCH = 6 * BX_ROW + 16;      // 496 bytes per x channel
+constexpr int BX_PAIRS = 17;                   // packed pixel pairs per patch row (34 columns)
+
+__device__ __forceinline__ unsigned pack_bf16(float lo, float hi)
+{
+    typedef __bf16 bf2 __attribute__((ext_vector_type(2)));
+    bf2 v; v[0] = (__bf16)lo; v[1] = (__bf16)hi;
+    return __builtin_bit_cast(unsigned, v);
+}
+
+__global__ __launch_bounds__(NTHREADS, 1) void conv3x3_wgrad_bf16_kernel(const WGradParams p)
+{
+    __shared__ __attribute__((aligned(16))) unsigned char gzs[64 * BG_PITCH];
+    __shared__ __attribute__((aligned(16))) unsigned char xps[64 * BX_PITCH];
+    constexpr int NGQ = 64 * WG_PX / 4 / NTHREADS;                              // 8 gz quads per thread and tile
+    constexpr int NXP = (64 * (WG_TH + 2) * BX_PAIRS + NTHREADS - 1) / NTHREADS;  // 26 x pairs
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int m = wave >> 1, nn = wave & 1;
+    const int j = lane & 31, kh = lane >> 5;
+    const int g = blockIdx.x, nslab = gridDim.x;
+
+    f32x16 acc[9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[t][i] = 0.0f;
+    float bs[NGQ];                                                             // fp32 sums of gz per thread (channel tid/32 + 8 i)
+#pragma unroll
+    for (int i = 0; i < NGQ; ++i) bs[i] = 0.0f;
+
+    const size_t planeBytes = (size_t)p.H * p.W * 4;
+    const int tilesPerImage = p.tilesX * p.tilesY;
+    u32x4 gq[NGQ];
+    float xlo[NXP], xhi[NXP];
+
+    auto fetch = [&](int tile) {
+        const int ng = tile / tilesPerImage;
+        const int t2 = tile - ng * tilesPerImage;
+        const int seg = ng / p.N, n = ng - seg * p.N;
+        const int ty = t2 / p.tilesX, tx = t2 - ty * p.tilesX;
+        const int oy0 = ty * WG_TH, ox0 = tx * WG_TW;
+        const int gzc = p.Cout - p.co0, xc = p.Cin - p.ci0;
+        const rsrc_t grs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.gz[seg] + ((size_t)n * p.Cout + p.co0) * p.H * p.W), 0,
+                                                             (int)((gzc < 64 ? gzc : 64) * planeBytes), 0x00020000);
+        const rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.x[seg] + ((size_t)n * p.Cin + p.ci0) * p.H * p.W), 0,
+                                                             (int)((xc < 64 ? xc : 64) * planeBytes), 0x00020000);
+#pragma unroll
+        for (int i = 0; i < NGQ; ++i) {                                        // quad q = (channel q / 32, 4 pixels)
+            const int q = tid + i * NTHREADS;
+            const int c = q >> 5, px = (q & 31) * 4, ry = px >> 5, rx = px & 31;
+            const int gy = oy0 + ry, gx = ox0 + rx;
+            const bool ok = gy < p.H && gx < p.W;                              // W % 4 == 0: a quad is inside or outside as a whole
+            gq[i] = __builtin_amdgcn_raw_buffer_load_b128(grs, (int)(ok ? (unsigned)((c * p.H + gy) * p.W + gx) * 4u : BAD_OFFSET), 0, 0);
+        }
+#pragma unroll
+        for (int i = 0; i < NXP; ++i) {                                        // pair e = (channel, patch row, patch columns 2 pr, 2 pr + 1)
+            const int e = tid + i * NTHREADS;
+            const int c = e / ((WG_TH + 2) * BX_PAIRS), rem = e - c * ((WG_TH + 2) * BX_PAIRS);
+            const int r = rem / BX_PAIRS, pr = rem - r * BX_PAIRS;
+            const int gy = oy0 + r - 1, gx = ox0 + 2 * pr - 1;
+            const bool in = e < 64 * (WG_TH + 2) * BX_PAIRS && (unsigned)gy < (unsigned)p.H;
+            const unsigned off = (unsigned)((c * p.H + gy) * p.W + gx) * 4u;
+            xlo[i] = buf_load(xrs, (in && (unsigned)gx < (unsigned)p.W) ? off : BAD_OFFSET);
+            xhi[i] = buf_load(xrs, (in && (unsigned)(gx + 1) < (unsigned)p.W) ? off + 4u : BAD_OFFSET);
+        }
+    };
+    auto park = [&]() {
+#pragma unroll
+        for (int i = 0; i < NGQ; ++i) {
+            const int q = tid + i * NTHREADS;
+            const float4 f = __builtin_bit_cast(float4, gq[i]);
+            bs[i] += (f.x + f.y) + (f.z + f.w);
+            uint2 v; v.x = pack_bf16(f.x, f.y); v.y = pack_bf16(f.z, f.w);
+            *reinterpret_cast<uint2*>(gzs + (q >> 5) * BG_PITCH + (q & 31) * 8) = v;
+        }
+#pragma unroll
+        for (int i = 0; i < NXP; ++i) {
+            const int e = tid + i * NTHREADS;
+            if (e < 64 * (WG_TH + 2) * BX_PAIRS) {
+                const int c = e / ((WG_TH + 2) * BX_PAIRS), rem = e - c * ((WG_TH + 2) * BX_PAIRS);
+                const int r = rem / BX_PAIRS, pr = rem - r * BX_PAIRS;
+                *reinterpret_cast<unsigned*>(xps + c * BX_PITCH + r * BX_ROW + pr * 4) = pack_bf16(xlo[i], xhi[i]);
+            }
+        }
+    };
+
+    int tile = g;
+    if (tile < p.ntiles) { fetch(tile); park(); }
+    __syncthreads();
+    for (; tile < p.ntiles; tile += nslab) {
+        const bool more = tile + nslab < p.ntiles;
+        if (more) fetch(tile + nslab);
+        __builtin_amdgcn_sched_barrier(0);
+        const unsigned char* ga = gzs + (m * 32 + j) * BG_PITCH + kh * 16;
+        const unsigned char* xb = xps + (nn * 32 + j) * BX_PITCH + kh * 16;
+#pragma unroll
+        for (int ry = 0; ry < WG_TH; ++ry) {
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {                                   // k-step = 16 pixels of the row: columns 16 ks + 8 kh ..
+                const wbf16x8 a = __builtin_bit_cast(wbf16x8, *reinterpret_cast<const u32x4*>(ga + (ry * 32 + ks * 16) * 2));
+#pragma unroll
+                for (int dy = 0; dy < 3; ++dy) {
+                    const unsigned char* row = xb + (ry + dy) * BX_ROW + ks * 32;
+                    const u32x4 d = *reinterpret_cast<const u32x4*>(row);
+                    const unsigned d4 = *reinterpret_cast<const unsigned*>(row + 16);
+                    u32x4 f1, f2;
+                    f1.x = __builtin_amdgcn_alignbit(d.y, d.x, 16); f1.y = __builtin_amdgcn_alignbit(d.z, d.y, 16);
+                    f1.z = __builtin_amdgcn_alignbit(d.w, d.z, 16); f1.w = __builtin_amdgcn_alignbit(d4, d.w, 16);
+                    f2.x = d.y; f2.y = d.z; f2.z = d.w; f2.w = d4;
+                    acc[dy * 3 + 0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, __builtin_bit_cast(wbf16x8, d), acc[dy * 3 + 0], 0, 0, 0);
+                    acc[dy * 3 + 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, __builtin_bit_cast(wbf16x8, f1), acc[dy * 3 + 1], 0, 0, 0);
+                    acc[dy * 3 + 2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, __builtin_bit_cast(wbf16x8, f2), acc[dy * 3 + 2], 0, 0, 0);
+                }
+            }
+        }
+        __syncthreads();
+        if (more) park();
+        __syncthreads();
+    }
+    float* slab = p.slabs + (size_t)g * 9 * 64 * 64;
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const int co = m * 32 + (i & 3) + 8 * (i >> 2) + 4 * kh;
+            slab[((size_t)t * 64 + co) * 64 + nn * 32 + j] = acc[t][i];
+        }
+    // bias gradient from the fp32 values: thread t's sum i belongs to channel t / 32 + 8 i; reduce over the 32 lanes
+    if (p.bslabs) {
+#pragma unroll
+        for (int i = 0; i < NGQ; ++i) {
+            float v = bs[i];
+#pragma unroll
+            for (int off = 16; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+            if ((lane & 31) == 0) p.bslabs[(size_t)g * 64 + (tid >> 5) + 8 * i] = v;
+        }
+    }
+}
+
 // dw[co][ci][tap] = sum over the G slabs, in a fixed order (bitwise reproducible run to run).  A workgroup owns 64
 // consecutive slab elements; its four waves take the slabs g % 4 == wave with four loads in flight each and the
 // four partial sums are combined through LDS -- 576 workgroups x 16 independent loads instead of 144 x 8, the
@@ -1331,6 +1480,39 @@ int isrConv3x3WeightGradSegments(const float* const* xs, const float* const* gzs
             else hipLaunchKernelGGL(conv3x3_wgrad_kernel<9>, dim3(G), dim3(NTHREADS), 0, s, p);
             hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(9 * 64 + 1), dim3(256), 0, s,
                                p.slabs, ksplit ? 2 * G : G, dw, Cout, Cin, co0, ci0, (const float*)p.bslabs, db);
+        }
+    return hipGetLastError() == hipSuccess ? 0 : -2;
+}
+
+int isrConv3x3WeightGradSegmentsBf16(const float* const* xs, const float* const* gzs, int segments, float* dw, float* db, void* workspace,
+                                     int N, int Cin, int H, int W, int Cout, void* stream)
+{
+    if (!xs || !gzs || segments <= 0 || segments > WG_MAX_SEG || !dw || !workspace || N <= 0 || Cin <= 0 || Cout <= 0 || H <= 0 || W <= 0)
+        return -1;
+    if (W & 3) return -3;                          // the gz tile is fetched as aligned groups of four pixels
+    hipStream_t s = (hipStream_t)stream;
+    WGradParams p;
+    for (int k = 0; k < WG_MAX_SEG; ++k) {
+        p.x[k] = k < segments ? xs[k] : nullptr;
+        p.gz[k] = k < segments ? gzs[k] : nullptr;
+        if (k < segments && (!xs[k] || !gzs[k] || ((uintptr_t)gzs[k] & 15))) return -1;
+    }
+    p.slabs = (float*)workspace;
+    float* bslabs = p.slabs + (size_t)WGRAD_MAX_SLABS * 9 * 64 * 64;
+    p.N = N; p.Cin = Cin; p.H = H; p.W = W; p.Cout = Cout;
+    p.tilesX = (W + WG_TW - 1) / WG_TW; p.tilesY = (H + WG_TH - 1) / WG_TH;
+    const long long nt = (long long)N * segments * p.tilesX * p.tilesY;
+    if (nt > 0x7fffffffLL) return -1;
+    p.ntiles = (int)nt;
+    if ((long long)(Cin < 64 ? Cin : 64) * H * W * 4 > 0x7fffffffLL || (long long)(Cout < 64 ? Cout : 64) * H * W * 4 > 0x7fffffffLL) return -1;
+    const int G = p.ntiles >= 512 ? 256 : (p.ntiles < WGRAD_MAX_SLABS ? p.ntiles : WGRAD_MAX_SLABS);
+    for (int co0 = 0; co0 < Cout; co0 += 64)
+        for (int ci0 = 0; ci0 < Cin; ci0 += 64) {
+            p.co0 = co0; p.ci0 = ci0;
+            p.bslabs = (db && ci0 == 0) ? bslabs : nullptr;
+            hipLaunchKernelGGL(conv3x3_wgrad_bf16_kernel, dim3(G), dim3(NTHREADS), 0, s, p);
+            hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(9 * 64 + 1), dim3(256), 0, s,
+                               p.slabs, G, dw, Cout, Cin, co0, ci0, (const float*)p.bslabs, db);
         }
     return hipGetLastError() == hipSuccess ? 0 : -2;
 }

@@ -40,6 +40,8 @@ def _sr():
         lib.isrConvWeightGradMaxSegments.argtypes = []; lib.isrConvWeightGradMaxSegments.restype = ci
         lib.isrConv3x3WeightGradSegments.argtypes = [vp, vp, ci, vp, vp, vp, ci, ci, ci, ci, ci, vp]
         lib.isrConv3x3WeightGradSegments.restype = ci
+        lib.isrConv3x3WeightGradSegmentsBf16.argtypes = lib.isrConv3x3WeightGradSegments.argtypes
+        lib.isrConv3x3WeightGradSegmentsBf16.restype = ci
         lib.isrActBackward.argtypes = [vp, vp, vp, ll, ci, cf, vp]; lib.isrActBackward.restype = ci
         lib.isrAssembleInput.argtypes = [vp, vp, vp, vp, ci, ci, ci, ci, vp]; lib.isrAssembleInput.restype = ci
         lib.isrConvSmallCinPad.argtypes = [ci]; lib.isrConvSmallCinPad.restype = ci
@@ -345,7 +347,10 @@ def _weight_grad(xs, gzs, weight, has_bias):
         db = torch.empty(cout, dtype=torch.float32, device=weight.device) if has_bias else None
         px = (ctypes.c_void_p * len(part_x))(*[t.data_ptr() for t in part_x])
         pg = (ctypes.c_void_p * len(part_g))(*[t.data_ptr() for t in part_g])
-        rc = lib.isrConv3x3WeightGradSegments(px, pg, len(part_x), _ptr(dw), _ptr(db), _ptr(ws), n, cin, h, w, cout, _stream())
+        # mixed-precision mode: bf16 operands once there are enough 4x32-pixel tiles to stream (the kernel is memory bound)
+        tiles = n * len(part_x) * ((h + 3) // 4) * ((w + 31) // 32)
+        fn = lib.isrConv3x3WeightGradSegmentsBf16 if (TRAIN_BF16 and w % 4 == 0 and tiles >= 1024 and cout > 8) else lib.isrConv3x3WeightGradSegments
+        rc = fn(px, pg, len(part_x), _ptr(dw), _ptr(db), _ptr(ws), n, cin, h, w, cout, _stream())
         if rc != 0:
             raise RuntimeError("isrConv3x3WeightGradSegments failed (%d)" % rc)
         gw = dw if gw is None else gw + dw

@@ -338,3 +338,36 @@ def test_mixed_precision_training_mode_tracks_the_fp32_step():
     errs = [((a - b).norm() / b.norm()).item() for a, b in zip(g16, g32)]
     assert max(errs) <= 0.15, max(errs)
     assert sorted(errs)[len(errs) // 2] <= 5e-2, sorted(errs)[-6:]
+
+
+@pytest.mark.parametrize("case", [(3, 4, 64, 64, 64, 64), (2, 8, 101, 64, 32, 64), (1, 9, 64, 96, 62, 60)])
+def test_bf16_weight_gradient_is_the_same_sum(case):
+    """isrConv3x3WeightGradSegmentsBf16 (mixed-precision mode): exactly the fp32 sums when the operands are
+    representable in bf16 (products exact, fp32 accumulation), bf16 rounding otherwise; bias gradient from fp32 values."""
+    from isosurfacesuperresolution_amd import ops
+    segs, n, cin, cout, h, w = case
+    g = torch.Generator().manual_seed(segs * 17 + cin)
+    xs = [torch.randn(n, cin, h, w, generator=g) for _ in range(segs)]
+    gzs = [torch.randn(n, cout, h, w, generator=g) for _ in range(segs)]
+    weight = torch.zeros(cout, cin, 3, 3).cuda()
+
+    def reference(xl, gl):
+        wref = torch.zeros(cout, cin, 3, 3, dtype=torch.float64, requires_grad=True)
+        bref = torch.zeros(cout, dtype=torch.float64, requires_grad=True)
+        for x, gz in zip(xl, gl):
+            (F.conv2d(x.double(), wref, bref, padding=1) * gz.double()).sum().backward()
+        return wref.grad, bref.grad
+
+    ops.TRAIN_BF16 = True
+    try:
+        xq, gq = [t.bfloat16().float() for t in xs], [t.bfloat16().float() for t in gzs]
+        gw, gb = ops._weight_grad([t.cuda() for t in xq], [t.cuda() for t in gq], weight, True)
+        wr, br = reference(xq, gq)
+        assert (gw.cpu().double() - wr).abs().max().item() <= 1e-5 * wr.abs().max().item()
+        assert (gb.cpu().double() - br).abs().max().item() <= 1e-5 * br.abs().max().item()
+        gw, gb = ops._weight_grad([t.cuda() for t in xs], [t.cuda() for t in gzs], weight, True)
+    finally:
+        ops.TRAIN_BF16 = False
+    wr, br = reference(xs, gzs)
+    assert ((gw.cpu().double() - wr).norm() / wr.norm()).item() <= 1e-2
+    assert (gb.cpu().double() - br).abs().max().item() <= 1e-5 * br.abs().max().item()       # fp32 path
