@@ -5,7 +5,7 @@ B=${1:-16}; T=${2:-10}
 cd $GRAFT_REPO_ROOT
 export TMPDIR=/tmp
 rm -rf gpurun_out/prof_train
-rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_train -o train -- python3 tools/bench_train.py $B $T 5 > gpurun_out/prof_train.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_train -o train -- python3 tools/bench_train.py $B $T 5 $3 > gpurun_out/prof_train.log 2>&1
 python3 - <<'PY'
 import csv, glob
 p = glob.glob('gpurun_out/prof_train/**/*kernel_stats.csv', recursive=True)[0]
