@@ -60,9 +60,15 @@ int isoLoadDenseHost(const float* hostData, int nx, int ny, int nz);
 int isoLoadDenseDevice(unsigned long long devicePtr, int nx, int ny, int nz);
 
 /* Load one tile of a larger volume (multi-GPU object-space decomposition): the dense
- * data are the tile plus its halo, `origin` is the global index of local voxel (0,0,0), the world
- * normalisation and the isovalue scale come from the GLOBAL active bbox / maximum, and rays are clipped
- * to the region [clipLo, clipHi) (global index coordinates) this tile owns. An all-zero tile is valid. */
+ * data are the tile plus a halo (>= 2 voxels below and 3 above the owned region, or up to the volume's
+ * border), `origin` is the global index of local voxel (0,0,0) and a multiple of 8.  World normalisation,
+ * isovalue scale and the box rays are clipped to come from the GLOBAL active bbox / maximum; the ray is
+ * walked in global index coordinates exactly as in the unsplit volume and the tile processes only the
+ * leaves inside [clipLo, clipHi) (global index coordinates, clipLo a multiple of 8), so the pixels it
+ * produces are bit for bit those of the unsplit render wherever its leaves hold the first crossing, and
+ * the nearest-hit composite of all tiles equals the unsplit image.  An all-zero tile is valid.  Ray-cast
+ * AO sees only the tile's own leaves (use aosamples=0); semantics=gvdb is not available for tiles.
+ * 0 ok, -2 on failure (misaligned origin / clipLo, region outside the stored data, no memory). */
 int isoLoadDenseTileHost(const float* hostData, int nx, int ny, int nz, const int origin[3],
                          const int globalActiveMin[3], const int globalActiveMax[3], float globalMax,
                          const int clipLo[3], const int clipHi[3]);

@@ -47,6 +47,9 @@ struct Volume {
     bool loaded = false;
     int nx = 0, ny = 0, nz = 0, nbx = 0, nby = 0, nbz = 0, n1x = 0, n1y = 0, n1z = 0;
     int nslots = 0, nleaf = 0;
+    int org[3] = { 0, 0, 0 };    // global index of stored voxel (0,0,0); non-zero only for a tile of a larger volume
+    int n1o[3] = { 0, 0, 0 };
+    bool tile = false;
     int bbmin[3] = { 0, 0, 0 }, bbmax[3] = { 0, 0, 0 };
     float maxValue = 0.f;
     double s = 1, sinv = 1, t[3] = { 0, 0, 0 };
@@ -223,13 +226,18 @@ float orderBitsToFloat(unsigned int u)
     return f;
 }
 
-// Placement of a tile inside a larger (multi-GPU) volume: the world map and the isovalue scale come
-// from the GLOBAL volume, rays are clipped to the tile's own region.
+// Placement of a tile inside a larger (multi-GPU) volume.  A tile walks the GLOBAL ray:
+// world map, isovalue scale and the node-level bounding box the ray is clipped to come from the global volume, the
+// 4096/128/8 DDAs run in global index coordinates, and the tile merely owns a subset of the leaves (the others are
+// stepped over like empty space).  The reference re-initialises the voxel DDA per leaf from the leaf's own span
+// (CPURenderer/IsoVolumeRayTracer.h:37-46), so what a ray computes inside a leaf does not depend on which other leaves
+// exist: the tile that owns the first leaf with a crossing produces bit for bit the pixel of the unsplit render, and a
+// nearest-hit composite of the tiles IS the unsplit image.
 struct TileInfo {
-    int origin[3];                 // global index of local voxel (0,0,0)
+    int origin[3];                 // global index of local voxel (0,0,0), multiple of 8
     int gmin[3], gmax[3];          // global active-voxel bbox
     float globalMax;
-    int clipLo[3], clipHi[3];      // region owned by this tile, global index coordinates, [lo, hi)
+    int clipLo[3], clipHi[3];      // leaves owned by this tile, global index coordinates, [lo, hi), lo a multiple of 8
 };
 
 // Dense device volume -> bricks, occupancy hierarchy, bbox, max, world map.
@@ -239,7 +247,21 @@ bool uploadFromDevice(const float* dense, int nx, int ny, int nz, const TileInfo
     Volume v;
     v.nx = nx; v.ny = ny; v.nz = nz;
     v.nbx = (nx + 7) / 8; v.nby = (ny + 7) / 8; v.nbz = (nz + 7) / 8;
-    v.n1x = (nx + 127) / 128; v.n1y = (ny + 127) / 128; v.n1z = (nz + 127) / 128;
+    const int dims[3] = { nx, ny, nz };
+    if (tile) {
+        v.tile = true;
+        for (int k = 0; k < 3; ++k) {
+            // the stored region must sit on the global leaf grid, inside the one 4096^3 level-2 node, and hold what a
+            // march through an owned leaf [8b, 8b+8) can read: voxels [8b-2, 8b+10] (trilinear +1, gradient +-1)
+            if (tile->origin[k] < 0 || (tile->origin[k] & 7) || (tile->clipLo[k] & 7) || tile->origin[k] + dims[k] > 4096) return false;
+            if (tile->clipLo[k] < tile->origin[k] || tile->clipHi[k] > tile->origin[k] + dims[k]) return false;
+            v.org[k] = tile->origin[k];
+            v.n1o[k] = tile->origin[k] >> 7;
+        }
+    }
+    v.n1x = ((v.org[0] + nx - 1) >> 7) - v.n1o[0] + 1;
+    v.n1y = ((v.org[1] + ny - 1) >> 7) - v.n1o[1] + 1;
+    v.n1z = ((v.org[2] + nz - 1) >> 7) - v.n1o[2] + 1;
     const size_t nb = size_t(v.nbx) * v.nby * v.nbz;
     uint8_t *dFlag9 = nullptr;
     int* dBBox = nullptr;
@@ -273,9 +295,15 @@ bool uploadFromDevice(const float* dense, int nx, int ny, int nz, const TileInfo
             for (int x = 0; x < v.nbx; ++x) {
                 const size_t b = (size_t(z) * v.nby + y) * v.nbx + x;
                 slot[b] = flag9[b] ? nslots++ : -1;
+                if (leaf[b] && tile) {   // leaves of the halo belong to a neighbour
+                    const int c[3] = { v.org[0] + x * 8, v.org[1] + y * 8, v.org[2] + z * 8 };
+                    for (int k = 0; k < 3; ++k)
+                        if (c[k] < tile->clipLo[k] || c[k] >= tile->clipHi[k]) leaf[b] = 0;
+                }
                 if (leaf[b]) {
                     ++nleaf;
-                    node1[(size_t(z >> 4) * v.n1y + (y >> 4)) * v.n1x + (x >> 4)] = 1;
+                    const int gx = v.org[0] + x * 8, gy = v.org[1] + y * 8, gz = v.org[2] + z * 8;
+                    node1[(size_t((gz >> 7) - v.n1o[2]) * v.n1y + ((gy >> 7) - v.n1o[1])) * v.n1x + ((gx >> 7) - v.n1o[0])] = 1;
                     if (x < lmin[0]) lmin[0] = x; if (x > lmax[0]) lmax[0] = x;
                     if (y < lmin[1]) lmin[1] = y; if (y > lmax[1]) lmax[1] = y;
                     if (z < lmin[2]) lmin[2] = z; if (z > lmax[2]) lmax[2] = z;
@@ -297,8 +325,14 @@ bool uploadFromDevice(const float* dense, int nx, int ny, int nz, const TileInfo
     // CPURenderer.cpp:448-458 with unit voxels: scale longest active-bbox edge to 1, centre at 0
     double ext[3], cen[3];
     if (tile) {
-        for (int k = 0; k < 3; ++k) { bbox[k] = tile->gmin[k]; bbox[3 + k] = tile->gmax[k]; }
+        for (int k = 0; k < 3; ++k) {
+            bbox[k] = tile->gmin[k]; bbox[3 + k] = tile->gmax[k];
+            // the ray is clipped to the GLOBAL node-level box: the leaf holding the extreme active voxel bounds it
+            v.bbmin[k] = tile->gmin[k] & ~7;
+            v.bbmax[k] = (tile->gmax[k] & ~7) + 7 + 1;
+        }
         v.maxValue = tile->globalMax;
+        HIP_OK(hipMemcpy(v.leaf, leaf.data(), nb, hipMemcpyHostToDevice));   // existence AND ownership
     }
     for (int k = 0; k < 3; ++k) {
         const double lo = double(bbox[k]), hi = double(bbox[3 + k]);
@@ -313,15 +347,6 @@ bool uploadFromDevice(const float* dense, int nx, int ny, int nz, const TileInfo
     v.s = 1.0 * scale;
     v.sinv = 1.0 / v.s;
     for (int k = 0; k < 3; ++k) v.t[k] = (-cen[k]) * scale;
-    if (tile) {
-        // local index = global index - origin  =>  world = local*s + (t + origin*s); rays see only [clipLo, clipHi)
-        for (int k = 0; k < 3; ++k) {
-            v.t[k] = v.t[k] + double(tile->origin[k]) * v.s;
-            const int lo = tile->clipLo[k] - tile->origin[k], hi = tile->clipHi[k] - tile->origin[k];
-            if (lo > v.bbmin[k]) v.bbmin[k] = lo;
-            if (hi < v.bbmax[k]) v.bbmax[k] = hi;
-        }
-    }
 
     HIP_OK(hipMalloc(&v.slot, nb * sizeof(int32_t)));
     HIP_OK(hipMalloc(&v.node1, node1.size()));
@@ -451,6 +476,7 @@ bool launchFrame(float* out, hipStream_t stream)
     p.nx = v.nx; p.ny = v.ny; p.nz = v.nz;
     p.nbx = v.nbx; p.nby = v.nby; p.nbz = v.nbz;
     p.n1x = v.n1x; p.n1y = v.n1y; p.n1z = v.n1z;
+    for (int k = 0; k < 3; ++k) { p.org[k] = v.org[k]; p.n1o[k] = v.n1o[k]; }
     p.any_leaf = v.nleaf > 0;
     p.bricks = v.bricks; p.slot = v.slot; p.leaf = v.leaf; p.leafRange = v.leafRange; p.node1 = v.node1;
     p.out = out;
@@ -465,6 +491,7 @@ bool launchFrame(float* out, hipStream_t stream)
         else e0 = e1 = nullptr;
     }
     if (g.semantics == 1) {
+        if (v.tile) return false;    // the CUDA renderer's arithmetic is implemented for whole volumes only
         IsoGvdbFrame f;
         buildGvdbFrame(f, a, v, g.lastOrigin, g.lastLookAt);
         iso_launch_render_gvdb(p, f, stream, e0, e1);

@@ -83,8 +83,11 @@ __device__ __forceinline__ bool dda_step(DDA& d)
 
 // ---- volume access -------------------------------------------------------------------------
 
+// Coordinates are GLOBAL index coordinates throughout; P.org (a multiple of 8, zero unless the volume is one tile of a
+// larger one) is subtracted only where a table or a brick of the locally stored region is addressed.
 __device__ __forceinline__ float voxel_value(const IsoRenderParams& P, int x, int y, int z)
 {
+    x -= P.org[0]; y -= P.org[1]; z -= P.org[2];
     if ((unsigned)x >= (unsigned)P.nx || (unsigned)y >= (unsigned)P.ny || (unsigned)z >= (unsigned)P.nz) return 0.0f;
     const int s = P.slot[((z >> 3) * P.nby + (y >> 3)) * P.nbx + (x >> 3)];
     if (s < 0) return 0.0f;
@@ -119,10 +122,11 @@ __device__ __forceinline__ float interp_global(const IsoRenderParams& P, double 
     const float u = (float)px - (float)cx;
     const float v = (float)py - (float)cy;
     const float w = (float)pz - (float)cz;
-    if ((unsigned)cx < (unsigned)P.nx && (unsigned)cy < (unsigned)P.ny && (unsigned)cz < (unsigned)P.nz) {
-        const int s = P.slot[((cz >> 3) * P.nby + (cy >> 3)) * P.nbx + (cx >> 3)];
+    const int lx = cx - P.org[0], ly = cy - P.org[1], lz = cz - P.org[2];
+    if ((unsigned)lx < (unsigned)P.nx && (unsigned)ly < (unsigned)P.ny && (unsigned)lz < (unsigned)P.nz) {
+        const int s = P.slot[((lz >> 3) * P.nby + (ly >> 3)) * P.nbx + (lx >> 3)];
         if (s < 0) return 0.0f;   // all 27 candidate corners are zero: 0 + (0-0)*w ... == +0
-        return interp_from_brick(P.bricks + (size_t)s * ISO_BRICK_STRIDE, cx & 7, cy & 7, cz & 7, u, v, w);
+        return interp_from_brick(P.bricks + (size_t)s * ISO_BRICK_STRIDE, lx & 7, ly & 7, lz & 7, u, v, w);
     }
     // cell on or outside the low/high border of the grid: per-corner fetch (background 0 outside)
     return trilerp(voxel_value(P, cx, cy, cz), voxel_value(P, cx, cy, cz + 1),
@@ -139,8 +143,10 @@ __device__ __forceinline__ float interp_value(const IsoRenderParams& P, const Ra
     return (float)((double)interp_global(P, px, py, pz) - P.iso);
 }
 
+// In a tile, P.leaf holds "leaf exists AND is owned by this tile": leaves of the halo are walked past like empty space.
 __device__ __forceinline__ bool has_leaf(const IsoRenderParams& P, int x, int y, int z)
 {
+    x -= P.org[0]; y -= P.org[1]; z -= P.org[2];
     if ((unsigned)x >= (unsigned)P.nx || (unsigned)y >= (unsigned)P.ny || (unsigned)z >= (unsigned)P.nz) return false;
     return P.leaf[((z >> 3) * P.nby + (y >> 3)) * P.nbx + (x >> 3)] != 0;
 }
@@ -152,16 +158,19 @@ __device__ __forceinline__ bool has_leaf(const IsoRenderParams& P, int x, int y,
 // low-density fringe or the dense core without meeting the surface were the tail the whole frame waited for.
 __device__ __forceinline__ bool leaf_may_cross(const IsoRenderParams& P, int x, int y, int z)
 {
+    x -= P.org[0]; y -= P.org[1]; z -= P.org[2];
     const float* mm = P.leafRange + 2 * (size_t)(((z >> 3) * P.nby + (y >> 3)) * P.nbx + (x >> 3));
     const double lo = (double)mm[0], hi = (double)mm[1];
     const double pad = 4e-6 * fmax(fabs(lo), fabs(hi));
     return !(P.iso < lo - pad || P.iso > hi + pad);
 }
 
+// node1 is indexed by GLOBAL 128^3 node coordinates relative to the first node the stored region overlaps (P.n1o)
 __device__ __forceinline__ bool has_node1(const IsoRenderParams& P, int x, int y, int z)
 {
-    if ((unsigned)x >= (unsigned)P.nx || (unsigned)y >= (unsigned)P.ny || (unsigned)z >= (unsigned)P.nz) return false;
-    return P.node1[((z >> 7) * P.n1y + (y >> 7)) * P.n1x + (x >> 7)] != 0;
+    const int ax = (x >> 7) - P.n1o[0], ay = (y >> 7) - P.n1o[1], az = (z >> 7) - P.n1o[2];
+    if ((unsigned)ax >= (unsigned)P.n1x || (unsigned)ay >= (unsigned)P.n1y || (unsigned)az >= (unsigned)P.n1z) return false;
+    return P.node1[(az * P.n1y + ay) * P.n1x + ax] != 0;
 }
 __device__ __forceinline__ bool has_node2(const IsoRenderParams& P, int x, int y, int z)
 {
@@ -537,7 +546,7 @@ __device__ __forceinline__ bool walk_next_leaf(const IsoRenderParams& P, Walk& w
         } else {
             if (has_leaf(P, w.d0.vx, w.d0.vy, w.d0.vz) && leaf_may_cross(P, w.d0.vx, w.d0.vy, w.d0.vz)) {
                 ray.t0 = w.d0.t0; ray.t1 = dda_next(w.d0);
-                brick = ((w.d0.vz >> 3) * P.nby + (w.d0.vy >> 3)) * P.nbx + (w.d0.vx >> 3);
+                brick = (((w.d0.vz - P.org[2]) >> 3) * P.nby + ((w.d0.vy - P.org[1]) >> 3)) * P.nbx + ((w.d0.vx - P.org[0]) >> 3);
                 return true;
             }
             if (!dda_step(w.d0)) {
@@ -563,8 +572,9 @@ __device__ __forceinline__ float interp_cached(const IsoRenderParams& P, const f
                                                double px, double py, double pz)
 {
     const int cx = (int)floor(px), cy = (int)floor(py), cz = (int)floor(pz);
-    if ((unsigned)cx < (unsigned)P.nx && (unsigned)cy < (unsigned)P.ny && (unsigned)cz < (unsigned)P.nz &&
-        ((cz >> 3) * P.nby + (cy >> 3)) * P.nbx + (cx >> 3) == cachedBrick) {
+    const int lx = cx - P.org[0], ly = cy - P.org[1], lz = cz - P.org[2];
+    if ((unsigned)lx < (unsigned)P.nx && (unsigned)ly < (unsigned)P.ny && (unsigned)lz < (unsigned)P.nz &&
+        ((lz >> 3) * P.nby + (ly >> 3)) * P.nbx + (lx >> 3) == cachedBrick) {
         const float u = (float)px - (float)cx;
         const float v = (float)py - (float)cy;
         const float w = (float)pz - (float)cz;

@@ -28,8 +28,10 @@ struct IsoRenderParams {
     int vp[4];
     int nx, ny, nz;              // voxel dims
     int nbx, nby, nbz;           // 8^3 brick grid
-    int n1x, n1y, n1z;           // 128^3 node grid
-    int bbmin[3], bbmax[3];      // node-level bbox (max already +1)
+    int n1x, n1y, n1z;           // 128^3 node grid (of the stored region)
+    int org[3];                  // global index of stored voxel (0,0,0): multiple of 8; non-zero only for a tile of a larger volume
+    int n1o[3];                  // global 128^3 node coordinate of node1[0][0][0] (= org >> 7)
+    int bbmin[3], bbmax[3];      // node-level bbox (max already +1), GLOBAL index coordinates
     int any_leaf;
     const float* bricks;         // [slot][ISO_BRICK_STRIDE], local index (z*9+y)*9+x
     const int32_t* slot;         // [nbz][nby][nbx] -> slot or -1 (all 9^3 values zero)

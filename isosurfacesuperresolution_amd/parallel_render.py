@@ -2,10 +2,16 @@
 (BASELINE config #5: 1024^3 as 2x2x2 tiles of 512^3).
 
 The reference has nothing like this (single device).  Every rank ray-marches the FULL low-res image
-against its own tile (loaded with ``DirectRenderer.load_tile``: world map and isovalue scale of the
-global volume, rays clipped to the tile's region), then the 12-channel G-buffers are exchanged with
-ONE all-gather (RCCL over xGMI: 24.9 MB per GPU at 960x540) and composited per pixel by nearest hit
--- valid because the first isosurface hit along a ray is the minimum over the disjoint convex tiles.
+against its own tile (loaded with ``DirectRenderer.load_tile``), then the 12-channel G-buffers are
+exchanged with ONE all-gather (RCCL over xGMI: 24.9 MB per GPU at 960x540) and composited per pixel by
+nearest hit.
+
+The composite is BIT-IDENTICAL to the render of the unsplit volume: a tile walks the global ray (global
+world map, isovalue scale, clip box and 4096/128/8-voxel DDAs in global index coordinates) and only
+*processes* the leaves it owns.  The reference's tracer re-initialises its voxel DDA per leaf from the
+leaf's own span (``CPURenderer/IsoVolumeRayTracer.h:37-46``), so what happens inside a leaf does not
+depend on which other leaves exist; the tile that owns the first leaf with a crossing therefore computes
+exactly the unsplit pixel, every other tile a later hit or none, and the minimum depth selects it.
 """
 import numpy as np
 import torch
@@ -25,7 +31,8 @@ def tile_boxes(shape, splits):
     """[(lo(x,y,z), hi(x,y,z))] of an (sz, sy, sx) split of a [z][y][x] volume, z-major rank order."""
     nz, ny, nx = shape
     sz, sy, sx = splits
-    edges = lambda n, s: [round(i * n / s) for i in range(s + 1)]
+    # interior edges on the 8^3 leaf grid: a leaf belongs to exactly one tile
+    edges = lambda n, s: [0] + [min(n, 8 * round(i * n / s / 8)) for i in range(1, s)] + [n]
     ex, ey, ez = edges(nx, sx), edges(ny, sy), edges(nz, sz)
     boxes = []
     for k in range(sz):
@@ -51,6 +58,64 @@ def partition_volume(volume, splits=(2, 2, 2)):
     gmin, gmax, gmaxval = global_stats(volume)
     fn = lambda z0, z1, y0, y1, x0, x1: volume[z0:z1, y0:y1, x0:x1]
     return [make_tile(fn, volume.shape, box, gmin, gmax, gmaxval) for box in tile_boxes(volume.shape, splits)]
+
+
+def generate_tiles(field, splits=(2, 2, 2), ranks=None, reduce_max=None, reduce_min=None):
+    """Tiles of a volume that exists only as a generator (``volumes.EjectaField``): each tile evaluates
+    its own box plus halo once; the normalising maximum and the active bounding box are reductions
+    over the tiles' own values (between ranks: ``reduce_max`` / ``reduce_min`` callables over numpy
+    arrays, e.g. an all-reduce; in one process the loop below).  ``ranks``: tile indices to build
+    (default all).  Returns the tile descriptors in ``tile_boxes`` order (None for skipped ranks)."""
+    n = field.n
+    shape = (n, n, n)
+    boxes = tile_boxes(shape, splits)
+    ranks = list(range(len(boxes))) if ranks is None else list(ranks)
+    raws, metas = {}, {}
+    for k in ranks:
+        (x0, y0, z0), (x1, y1, z1) = boxes[k]
+        ox, oy, oz = max(0, x0 - HALO), max(0, y0 - HALO), max(0, z0 - HALO)
+        ex, ey, ez = min(n, x1 + HALO), min(n, y1 + HALO), min(n, z1 + HALO)
+        raws[k] = field.raw((oz, ez, oy, ey, ox, ex))
+        metas[k] = (ox, oy, oz)
+    gmaxraw = np.array([max(float(r.max()) for r in raws.values())], dtype=np.float64)
+    if reduce_max is not None:
+        gmaxraw = reduce_max(gmaxraw)
+    lo = np.full(3, np.iinfo(np.int64).max, dtype=np.int64)
+    hi = np.full(3, -1, dtype=np.int64)
+    vmax = np.zeros(1, dtype=np.float64)
+    data = {}
+    for k in ranks:
+        d = field.finalize(raws.pop(k), gmaxraw[0])
+        data[k] = d
+        (x0, y0, z0), (x1, y1, z1) = boxes[k]
+        ox, oy, oz = metas[k]
+        own = d[z0 - oz:z1 - oz, y0 - oy:y1 - oy, x0 - ox:x1 - ox]
+        for axis, base in ((2, x0), (1, y0), (0, z0)):             # (x, y, z) order
+            other = tuple(a for a in (0, 1, 2) if a != axis)
+            nzi = np.flatnonzero(own.any(axis=other))
+            if nzi.size:
+                lo[2 - axis] = min(lo[2 - axis], base + int(nzi[0]))
+                hi[2 - axis] = max(hi[2 - axis], base + int(nzi[-1]))
+        vmax[0] = max(vmax[0], float(own.max()))
+    if reduce_max is not None:
+        hi, vmax = reduce_max(hi), reduce_max(vmax)
+    if reduce_min is not None:
+        lo = reduce_min(lo)
+    tiles = [None] * len(boxes)
+    for k in ranks:
+        tiles[k] = {"data": data[k], "origin": metas[k], "gmin": [int(v) for v in lo], "gmax": [int(v) for v in hi],
+                    "gmaxval": float(np.float32(vmax[0])), "clip_lo": boxes[k][0], "clip_hi": boxes[k][1]}
+    return tiles
+
+
+def assemble(tiles, shape):
+    """The dense volume the tiles were cut from (tests, single-GPU rehearsal of config #5)."""
+    vol = np.zeros(shape, dtype=np.float32)
+    for t in tiles:
+        (x0, y0, z0), (x1, y1, z1) = t["clip_lo"], t["clip_hi"]
+        ox, oy, oz = t["origin"]
+        vol[z0:z1, y0:y1, x0:x1] = t["data"][z0 - oz:z1 - oz, y0 - oy:y1 - oy, x0 - ox:x1 - ox]
+    return vol
 
 
 def composite(gbuffers):

@@ -87,6 +87,43 @@ def cloud(n=512, seed=49):
     return _sparsify(v.astype(np.float32))
 
 
+class EjectaField:
+    """The ejecta recipe evaluated region by region, for volumes no single process wants to hold
+    (V1024, BASELINE config #5: "8 tiles of 512^3 generated tile-wise from the same global lattice",
+    SURVEY.md 8(d)).  ``raw(box)`` is the un-normalised field of an index box, ``finalize(raw, gmax)``
+    rescales by the GLOBAL maximum (the maximum over all tiles' raw maxima -- one scalar max-reduction
+    between ranks) and applies the sparsity threshold.  Every step is element-wise, so
+    ``finalize(raw(everything), raw(everything).max())`` is bit for bit ``ejecta(n, seed)``."""
+
+    def __init__(self, n=1024, seed=1024):
+        self.n = n
+        rng = np.random.default_rng(seed)
+        self.lattices = [rng.random((l, l, l), dtype=np.float32) for l in ([8, 16, 32] if n >= 64 else [4, 8, 16])]
+
+    def raw(self, box):
+        z0, z1, y0, y1, x0, x1 = box
+        n = self.n
+        total, wsum = None, 0.0
+        for o, lat in enumerate(self.lattices):
+            wgt = 0.5 ** o
+            a = _upsample_axis(lat, n, 0)[z0:z1]
+            a = _upsample_axis(a, n, 1)[:, y0:y1]
+            a = _upsample_axis(a, n, 2)[:, :, x0:x1]
+            a = a * np.float32(wgt)
+            total = a if total is None else total + a
+            wsum += wgt
+        total /= np.float32(wsum)
+        c = (np.arange(n, dtype=np.float32) + 0.5) / n - 0.5
+        r = np.sqrt(c[z0:z1, None, None] ** 2 + c[None, y0:y1, None] ** 2 + c[None, None, x0:x1] ** 2)
+        total *= np.exp(-((r - 0.30) / 0.12) ** 2).astype(np.float32)
+        return total
+
+    @staticmethod
+    def finalize(raw, gmax):
+        v = raw / np.float32(gmax)
+        return _sparsify(v.astype(np.float32))
+
+
 VOLUMES = {
     "sphere64": (sphere64, 0.5),
     "ejecta256": (lambda: ejecta(256), 0.34),

@@ -104,13 +104,21 @@ iso_volume* iso_volume_create(const float* dense, int nx, int ny, int nz)
     return v;
 }
 
-/* Tile of a larger volume (tests of the multi-GPU tiled render): same placement rules as the
- * product's isoLoadDenseTileHost -- world map and isovalue scale from the GLOBAL volume, rays clipped
- * to the tile's own region.  An all-zero tile is allowed (renders nothing). */
+/* Tile of a larger volume (tests of the multi-GPU tiled render): same rules as the product's
+ * isoLoadDenseTileHost.  The tile walks the GLOBAL ray -- world map, isovalue scale and node-level bbox of
+ * the global volume, DDAs in global index coordinates -- and owns the leaves inside [clip_lo, clip_hi);
+ * all other leaves are stepped over.  Because the reference re-initialises the voxel DDA per leaf from the
+ * leaf's span (IsoVolumeRayTracer.h:37-46), the tile owning the first leaf with a crossing computes exactly
+ * the unsplit pixel.  origin and clip_lo must be multiples of 8.  An all-zero tile is allowed. */
 iso_volume* iso_volume_create_tile(const float* dense, int nx, int ny, int nz, const int origin[3],
                                    const int gmin[3], const int gmax[3], float global_max,
                                    const int clip_lo[3], const int clip_hi[3])
 {
+    const int dims[3] = { nx, ny, nz };
+    for (int k = 0; k < 3; ++k) {
+        if (origin[k] < 0 || (origin[k] & 7) || (clip_lo[k] & 7) || origin[k] + dims[k] > 4096) return NULL;
+        if (clip_lo[k] < origin[k] || clip_hi[k] > origin[k] + dims[k]) return NULL;
+    }
     size_t n = (size_t)nx * ny * nz;
     int any = 0;
     for (size_t i = 0; i < n && !any; ++i) any = dense[i] != 0.0f;
@@ -122,10 +130,30 @@ iso_volume* iso_volume_create_tile(const float* dense, int nx, int ny, int nz, c
         tmp[0] = 1.0f;                       /* build the containers, then forget the dummy voxel */
         v = iso_volume_create(tmp, nx, ny, nz);
         free(tmp);
-        if (v) { v->data[0] = 0.0f; memset(v->leaf, 0, (size_t)v->bx * v->by * v->bz); memset(v->node1, 0, (size_t)v->mx * v->my * v->mz);
-                 v->any_leaf = 0; v->nleaf = 0; for (int k = 0; k < 3; ++k) { v->nbox_min[k] = 0; v->nbox_max[k] = 0; } }
+        if (v) { v->data[0] = 0.0f; memset(v->leaf, 0, (size_t)v->bx * v->by * v->bz); }
     }
     if (!v) return NULL;
+    for (int k = 0; k < 3; ++k) { v->org[k] = origin[k]; v->n1o[k] = origin[k] >> 7; }
+    /* node1 over GLOBAL 128^3 node coordinates; leaf = exists AND owned */
+    free(v->node1);
+    v->mx = ((origin[0] + nx - 1) >> 7) - v->n1o[0] + 1;
+    v->my = ((origin[1] + ny - 1) >> 7) - v->n1o[1] + 1;
+    v->mz = ((origin[2] + nz - 1) >> 7) - v->n1o[2] + 1;
+    v->node1 = (unsigned char*)calloc((size_t)v->mx * v->my * v->mz, 1);
+    int nleaf = 0;
+    for (int z = 0; z < v->bz; ++z)
+        for (int y = 0; y < v->by; ++y)
+            for (int x = 0; x < v->bx; ++x) {
+                unsigned char* lf = &v->leaf[((size_t)z * v->by + y) * v->bx + x];
+                const int c[3] = { origin[0] + x * 8, origin[1] + y * 8, origin[2] + z * 8 };
+                for (int k = 0; k < 3; ++k) if (c[k] < clip_lo[k] || c[k] >= clip_hi[k]) *lf = 0;
+                if (*lf) {
+                    ++nleaf;
+                    v->node1[((size_t)((c[2] >> 7) - v->n1o[2]) * v->my + ((c[1] >> 7) - v->n1o[1])) * v->mx + ((c[0] >> 7) - v->n1o[0])] = 1;
+                }
+            }
+    v->nleaf = nleaf;
+    v->any_leaf = nleaf > 0;
     double ext[3], cen[3];
     for (int k = 0; k < 3; ++k) { double lo = (double)gmin[k], hi = (double)gmax[k]; ext[k] = hi - lo; cen[k] = (lo + hi) * 0.5; }
     double m = ext[0];
@@ -137,10 +165,9 @@ iso_volume* iso_volume_create_tile(const float* dense, int nx, int ny, int nz, c
     v->max_value = global_max;
     for (int k = 0; k < 3; ++k) {
         v->t[k] = (-cen[k]) * scale;
-        v->t[k] = v->t[k] + (double)origin[k] * v->s;
-        int lo = clip_lo[k] - origin[k], hi = clip_hi[k] - origin[k];
-        if (lo > v->nbox_min[k]) v->nbox_min[k] = lo;
-        if (hi < v->nbox_max[k]) v->nbox_max[k] = hi;
+        v->abox_min[k] = gmin[k]; v->abox_max[k] = gmax[k];
+        v->nbox_min[k] = gmin[k] & ~7;               /* the leaf holding the extreme active voxel bounds the global box */
+        v->nbox_max[k] = (gmax[k] & ~7) + 7 + 1;
     }
     return v;
 }
@@ -329,14 +356,17 @@ static inline int dda_step(dda_t* d)
 
 typedef struct { long long samples, steps; } counters_t;
 
+/* coordinates are GLOBAL index coordinates; v->org is zero unless the volume is a tile */
 static inline float grid_value(const iso_volume* v, int x, int y, int z)
 {
+    x -= v->org[0]; y -= v->org[1]; z -= v->org[2];
     if ((unsigned)x >= (unsigned)v->nx || (unsigned)y >= (unsigned)v->ny || (unsigned)z >= (unsigned)v->nz) return 0.0f;
     return v->data[((size_t)z * v->ny + y) * v->nx + x];
 }
 
 static inline void touch(const iso_volume* v, int x, int y, int z)
 {
+    x -= v->org[0]; y -= v->org[1]; z -= v->org[2];
     if ((unsigned)x >= (unsigned)v->nx || (unsigned)y >= (unsigned)v->ny || (unsigned)z >= (unsigned)v->nz) return;
     unsigned char* p = &v->touched[((size_t)(z >> 3) * v->by + (y >> 3)) * v->bx + (x >> 3)];
     if (!*p) *p = 1;
@@ -381,13 +411,15 @@ static inline float interp_value(const iso_volume* v, const ray_t* r, double iso
 
 static inline int has_leaf(const iso_volume* v, const int c[3])
 {
-    if ((unsigned)c[0] >= (unsigned)v->nx || (unsigned)c[1] >= (unsigned)v->ny || (unsigned)c[2] >= (unsigned)v->nz) return 0;
-    return v->leaf[((size_t)(c[2] >> 3) * v->by + (c[1] >> 3)) * v->bx + (c[0] >> 3)];
+    const int x = c[0] - v->org[0], y = c[1] - v->org[1], z = c[2] - v->org[2];
+    if ((unsigned)x >= (unsigned)v->nx || (unsigned)y >= (unsigned)v->ny || (unsigned)z >= (unsigned)v->nz) return 0;
+    return v->leaf[((size_t)(z >> 3) * v->by + (y >> 3)) * v->bx + (x >> 3)];
 }
 static inline int has_node1(const iso_volume* v, const int c[3])
 {
-    if ((unsigned)c[0] >= (unsigned)v->nx || (unsigned)c[1] >= (unsigned)v->ny || (unsigned)c[2] >= (unsigned)v->nz) return 0;
-    return v->node1[((size_t)(c[2] >> 7) * v->my + (c[1] >> 7)) * v->mx + (c[0] >> 7)];
+    const int x = (c[0] >> 7) - v->n1o[0], y = (c[1] >> 7) - v->n1o[1], z = (c[2] >> 7) - v->n1o[2];
+    if ((unsigned)x >= (unsigned)v->mx || (unsigned)y >= (unsigned)v->my || (unsigned)z >= (unsigned)v->mz) return 0;
+    return v->node1[((size_t)z * v->my + y) * v->mx + x];
 }
 static inline int has_node2(const iso_volume* v, const int c[3])
 {

@@ -4,6 +4,8 @@
 
 struct iso_volume {
     int nx, ny, nz;
+    int org[3];               /* global index of stored voxel (0,0,0); non-zero only for a tile (multiple of 8) */
+    int n1o[3];               /* global 128^3 node coordinate of node1[0][0][0] */
     float* data;              /* [z][y][x] */
     int bx, by, bz;           /* 8^3 leaf counts */
     unsigned char* leaf;      /* [bz][by][bx] : leaf node exists */

@@ -1,0 +1,169 @@
+"""GPU parity at the sizes BASELINE.json's configs name (the small-size cases live in test_render_gpu.py /
+test_conv_gpu.py): config #2's 256^3 volume at 480x270 -> 1920x1080, config #4's 512^3 cloud, config #3's
+B=16 / T=10 training step, config #5's object-space tiles at 256^3.  Everything goes through the C-ABI libraries.
+
+Bar (north_star): hit mask bit-exact; normals / depth / colour / flow and the super-resolved frame within 1e-4 of
+the CPU path (oracle ray-marcher + CPU PyTorch network with identical weights).  The SR comparison is a ONE-FRAME
+statement: with random-init weights the recurrence amplifies rounding differences ~2.4x per frame.
+"""
+import argparse
+
+import numpy as np
+import pytest
+import torch
+
+from isosurfacesuperresolution_amd import volumes as V
+
+pytestmark = pytest.mark.gpu
+
+TOL = 1e-4
+OPT = argparse.Namespace(upsample='bilinear', reconType='residual', useBN=False, numResidualLayers=10)
+
+
+@pytest.fixture(scope="module")
+def renderer():
+    assert torch.cuda.is_available()
+    from isosurfacesuperresolution_amd.inference import DirectRenderer
+    r = DirectRenderer()
+    r.set_kernel_variant(0)
+    return r
+
+
+def _setup(r, W, H, origin, fov, iso):
+    for c, v in (("cameraOrigin", V.fmt3(origin)), ("cameraLookAt", "0,0,0"), ("cameraUp", "0,1,0"), ("cameraFoV", "%.3f" % fov),
+                 ("isovalue", "%5.3f" % iso), ("resolution", "%d,%d" % (W, H)), ("viewport", "0,0,%d,%d" % (W, H)),
+                 ("aoradius", "0.010"), ("aosamples", "0")):
+        assert r.send_command(c, v) == 0
+
+
+def _render(r, W, H):
+    out = torch.full((H, W, 12), 7.0, dtype=torch.float32, device="cuda")
+    assert r.render_direct(out) >= 0
+    return out
+
+
+def _compare_gbuffer(gpu, ref):
+    assert np.array_equal(gpu[..., 3], ref[..., 3]), "hit mask differs in %d pixels" % int((gpu[..., 3] != ref[..., 3]).sum())
+    assert np.array_equal(gpu[..., 10:12], ref[..., 10:12])
+    for name, sl in (("colour", slice(0, 3)), ("normal", slice(4, 7)), ("depth", slice(7, 8)), ("flow", slice(8, 10))):
+        err = np.abs(gpu[..., sl] - ref[..., sl]).max()
+        assert err <= TOL, "%s differs by %g" % (name, err)
+
+
+def test_config2_ejecta256_480x270_frame_matches_cpu_path(renderer, oracle):
+    """BASELINE config #2 at its full size: 256^3 volume, 480x270 G-buffer vs the oracle (mask bit-exact, 1e-4), then the
+    whole frame (flow fill, input assembly, EnhanceNet on the fp32 MFMA kernels, clamp / normalise) at 1920x1080 vs
+    CPU PyTorch with the same weights on the oracle's G-buffer (1e-4, first frame of a sequence)."""
+    from isosurfacesuperresolution_amd import models, utils
+    from isosurfacesuperresolution_amd.inference import LoadedModel
+    from isosurfacesuperresolution_amd.pipeline import SuperResolutionPipeline, default_shading
+    vol = V.ejecta(256)
+    W, H = 480, 270
+    renderer.load_dense(vol)
+    ov = oracle.OracleVolume(vol)
+    o0, o1 = V.quantize3(V.orbit_camera(4)), V.quantize3(V.orbit_camera(5))
+    _setup(renderer, W, H, o0, 30.0, 0.34)
+    _render(renderer, W, H)                                   # o0 becomes the flow reference
+    _setup(renderer, W, H, o1, 30.0, 0.34)
+    gpu = _render(renderer, W, H).cpu().numpy()
+    ref, stats = oracle.render(ov, oracle.make_params(W, H, origin=o1, fov=30.0, isovalue=0.34, last_origin=o0))
+    assert stats["hits"] > 20000
+    _compare_gbuffer(gpu, ref)
+    # the super-resolved frame
+    torch.manual_seed(0)
+    net = models.createNetwork('EnhanceNet', 4, 101, [0, 1, 2, 3, 4], 6, OPT)
+    cpu_net = models.createNetwork('EnhanceNet', 4, 101, [0, 1, 2, 3, 4], 6, OPT)
+    cpu_net.load_state_dict(net.state_dict())
+    pipe = SuperResolutionPipeline(renderer, LoadedModel.from_model(net, "cuda", parameters={"initialImage": "zero"}),
+                                   default_shading("cuda", 30.0), (W, H))
+    pipe.set_static(fov=30.0, isovalue=0.34)
+    rgb, raw = pipe.frame(o1)
+    torch.cuda.synchronize()
+    assert rgb.shape == (1, 3, 1080, 1920) and raw.shape == (1, 6, 1080, 1920)
+    assert np.array_equal(pipe.gbuffer.cpu().numpy()[..., 3], ref[..., 3])
+    cpu_model = LoadedModel.from_model(cpu_net.eval(), "cpu", parameters={"initialImage": "zero"})
+    low = torch.from_numpy(ref).permute(2, 0, 1).unsqueeze(0)
+    raw_cpu = cpu_model.inference(low, None)
+    raw_cpu = torch.cat([raw_cpu[:, 0:1].clamp(-1, 1), utils.ScreenSpaceShading.normalize(raw_cpu[:, 1:4], dim=1),
+                         raw_cpu[:, 4:].clamp(0, 1)], dim=1)
+    err = (raw.cpu() - raw_cpu).abs().max().item()
+    assert err <= TOL, "super-resolved 1080p frame differs from the CPU path by %g" % err
+    rgb_cpu = default_shading("cpu", 30.0)(raw_cpu)
+    assert (rgb.cpu() - rgb_cpu).abs().max().item() <= TOL
+
+
+def test_config4_cloud512_matches_oracle(renderer, oracle):
+    """BASELINE config #4's volume at its full size (512^3 cloud, 537 MB dense: larger than L2 + Infinity Cache) at a
+    reduced image: hit mask bit-exact, G-buffer within 1e-4 of the oracle, two camera positions (flow included)."""
+    vol = V.cloud(512)
+    W, H = 480, 270
+    renderer.load_dense(vol)
+    info = renderer.volume_info()
+    assert info["dims"] == [512, 512, 512] and info["bricks"] > 100000
+    ov = oracle.OracleVolume(vol)
+    o0, o1 = V.quantize3(V.orbit_camera(30)), V.quantize3(V.orbit_camera(31))
+    _setup(renderer, W, H, o0, 30.0, 0.30)
+    _render(renderer, W, H)
+    _setup(renderer, W, H, o1, 30.0, 0.30)
+    gpu = _render(renderer, W, H).cpu().numpy()
+    ref, stats = oracle.render(ov, oracle.make_params(W, H, origin=o1, fov=30.0, isovalue=0.30, last_origin=o0))
+    assert stats["hits"] > 20000
+    _compare_gbuffer(gpu, ref)
+
+
+def test_config5_tiles_256_composite_is_bit_identical(renderer, oracle):
+    """Object-space 2x2x2 tiles of a 256^3 volume generated tile-wise (each tile evaluates only its own box + halo of the
+    global lattice): the nearest-hit composite of the eight full-image renders equals the unsplit render in all 12
+    channels, bit for bit, and a tile equals the oracle's tile mode (mask bit-exact, 1e-4)."""
+    from isosurfacesuperresolution_amd import parallel_render as PR
+    n, W, H = 256, 480, 270
+    tiles = PR.generate_tiles(V.EjectaField(n, seed=272), (2, 2, 2))
+    vol = PR.assemble(tiles, (n, n, n))
+    assert np.array_equal(vol, V.ejecta(n))                   # tile-wise generation == the whole-volume recipe
+    o0, o1 = V.quantize3(V.orbit_camera(12)), V.quantize3(V.orbit_camera(13))
+    _setup(renderer, W, H, o0, 30.0, 0.34)
+    renderer.load_dense(vol)                                  # a load makes the current camera (o0) the flow reference
+    _setup(renderer, W, H, o1, 30.0, 0.34)
+    full = _render(renderer, W, H)
+    bufs = []
+    for tile in tiles:
+        _setup(renderer, W, H, o0, 30.0, 0.34)
+        renderer.load_tile(tile)
+        _setup(renderer, W, H, o1, 30.0, 0.34)
+        bufs.append(_render(renderer, W, H))
+    comp = PR.composite(torch.stack(bufs))
+    assert int(full[..., 3].sum()) > 20000
+    assert torch.equal(comp, full), "%d values differ" % int((comp != full).sum())
+    ref, _ = oracle.render(oracle.OracleVolume(tiles[6]["data"], tile=tiles[6]),
+                           oracle.make_params(W, H, origin=o1, fov=30.0, isovalue=0.34, last_origin=o0))
+    _compare_gbuffer(bufs[6].cpu().numpy(), ref)
+
+
+def test_config3_b16_t10_training_step_matches_cpu():
+    """BASELINE config #3's step shape on one GPU: B=16 clips of T=10 frames, 32^2 -> 128^2 crops, README loss recipe,
+    forward + backward through time + Adam on the HIP training kernels vs the same step on CPU PyTorch (loss within 1e-4
+    relative, as in smoke(); LossNetUnshaded itself is parity-unpinned)."""
+    from isosurfacesuperresolution_amd import losses, models, train
+    topt = argparse.Namespace(upsample='bilinear', reconType='residual', useBN=False, numResidualLayers=10,
+                              losses="l1:mask:1,l1:ao:1,l1:normal:10,l1:depth:10,temp-l2:color:0.1",
+                              lossAO=0.0, lossAmbient=0.1, lossDiffuse=0.9, lossSpecular=0.0)
+    g = torch.Generator().manual_seed(124)
+    B, T = 16, 10
+    inp = torch.rand(B, T, 5, 32, 32, generator=g); inp[:, :, 0] = inp[:, :, 0] * 2 - 1
+    flow = (torch.rand(B, T, 2, 32, 32, generator=g) - 0.5) * 0.05
+    tgt = torch.rand(B, T, 6, 128, 128, generator=g); tgt[:, :, 0] = tgt[:, :, 0] * 2 - 1
+    torch.set_num_threads(16)
+    loss, upd = {}, {}
+    for dev in ("cpu", "cuda"):
+        torch.manual_seed(124)
+        net = models.createNetwork('EnhanceNet', 4, 101, [0, 1, 2, 3, 4], 6, topt).to(dev)
+        init = torch.cat([p.detach().reshape(-1).cpu() for p in net.parameters()])
+        crit = losses.LossNetUnshaded(dev, 5, 6, 128, 16, topt).to(dev)
+        optim, _ = train.make_optimizer(net)
+        loss[dev] = train.train_step(net, crit, optim, (inp.to(dev), flow.to(dev), tgt.to(dev)), initial_image="zero")
+        upd[dev] = torch.cat([p.detach().reshape(-1).cpu() for p in net.parameters()]) - init
+        assert all(torch.isfinite(q).all() for q in net.parameters())
+    assert abs(loss["cuda"] - loss["cpu"]) <= 1e-4 * max(1.0, abs(loss["cpu"])), loss
+    # Adam's first step is lr * sign-like: compare the update vectors' direction
+    cos = torch.dot(upd["cpu"], upd["cuda"]) / (upd["cpu"].norm() * upd["cuda"].norm())
+    assert cos > 0.99, cos

@@ -246,9 +246,7 @@ dist.destroy_process_group()
     p = oracle.make_params(80, 48, origin=V.quantize3(V.orbit_camera(21)), fov=30.0, isovalue=0.34)
     full, _ = oracle.render(oracle.OracleVolume(vol), p)
     assert full[..., 3].sum() > 100
-    assert int((comp[..., 3] != full[..., 3]).sum()) <= 2           # tile-entry rounding may move a silhouette pixel
-    both = (comp[..., 3] == 1) & (full[..., 3] == 1)
-    assert np.abs(comp - full)[both].max() <= 1e-4
+    assert np.array_equal(comp, full)      # tiles walk the global ray: the composite IS the unsplit render, all 12 channels
 
 
 def _strip_sequence(seed=5, frames=3, h=70, w=40):

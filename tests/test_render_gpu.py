@@ -145,9 +145,7 @@ def test_tiled_render_composite_matches_full_volume(renderer, oracle):
         bufs.append(torch.from_numpy(_render_gpu(renderer, W, H, origin, 30.0, 0.34)))
     comp = PR.composite(torch.stack(bufs)).numpy()
     assert full[..., 3].sum() > 1000
-    assert int((comp[..., 3] != full[..., 3]).sum()) <= 2
-    both = (comp[..., 3] == 1) & (full[..., 3] == 1)
-    assert np.abs(comp - full)[both].max() <= 1e-4
+    assert np.array_equal(comp, full)      # tiles walk the global ray: the composite IS the unsplit render, all 12 channels
     # and each tile equals the oracle's tile render bit-for-bit in the mask
     tile = PR.partition_volume(vol, (2, 2, 2))[5]
     renderer.load_tile(tile)
