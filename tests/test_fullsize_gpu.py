@@ -153,17 +153,18 @@ def test_config3_b16_t10_training_step_matches_cpu():
     flow = (torch.rand(B, T, 2, 32, 32, generator=g) - 0.5) * 0.05
     tgt = torch.rand(B, T, 6, 128, 128, generator=g); tgt[:, :, 0] = tgt[:, :, 0] * 2 - 1
     torch.set_num_threads(16)
-    loss, upd = {}, {}
+    loss, grad = {}, {}
     for dev in ("cpu", "cuda"):
         torch.manual_seed(124)
         net = models.createNetwork('EnhanceNet', 4, 101, [0, 1, 2, 3, 4], 6, topt).to(dev)
-        init = torch.cat([p.detach().reshape(-1).cpu() for p in net.parameters()])
         crit = losses.LossNetUnshaded(dev, 5, 6, 128, 16, topt).to(dev)
         optim, _ = train.make_optimizer(net)
         loss[dev] = train.train_step(net, crit, optim, (inp.to(dev), flow.to(dev), tgt.to(dev)), initial_image="zero")
-        upd[dev] = torch.cat([p.detach().reshape(-1).cpu() for p in net.parameters()]) - init
+        grad[dev] = [p.grad.detach().cpu() for p in net.parameters()]
         assert all(torch.isfinite(q).all() for q in net.parameters())
     assert abs(loss["cuda"] - loss["cpu"]) <= 1e-4 * max(1.0, abs(loss["cpu"])), loss
-    # Adam's first step is lr * sign-like: compare the update vectors' direction
-    cos = torch.dot(upd["cpu"], upd["cuda"]) / (upd["cpu"].norm() * upd["cuda"].norm())
-    assert cos > 0.99, cos
+    # gradients: both sides are fp32 with different summation orders, and a ReLU whose pre-activation sits within
+    # rounding of zero may switch on one side only (cf. test_conv_gpu.py) -- every tensor to 1e-2, most far closer
+    errs = [((a - b).norm() / a.norm()).item() for a, b in zip(grad["cpu"], grad["cuda"])]
+    assert max(errs) <= 1e-2, max(errs)
+    assert sum(e <= 1e-3 for e in errs) >= 0.8 * len(errs), sorted(errs)[-12:]
