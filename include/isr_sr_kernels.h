@@ -67,6 +67,22 @@ int isrConv3x3SmallCoutStrided(const float* x, const float* w8, const float* bia
                                int N, int Cin, int H, int W, int Cout, int act, float slope,
                                long long xPlane, long long xImage, void* stream);
 
+/* SPLIT-OPERAND form of the same fused convolution: fp32-equivalent accuracy on the fp16 matrix pipe (the default
+ * inference path; what it replaces is the cuDNN convolution behind nn.Conv2d in
+ * SuperresolutionNetwork/models/enhancenet.py:92-125, as isrConv3x3Forward does).  Every fp32 operand v is split into
+ * two fp16 numbers hi = RN16(v), lo = RN16(v - hi) (22 significand bits) and x*w becomes the three products
+ * x_hi*w_hi + x_hi*w_lo + x_lo*w_hi on v_mfma_f32_32x32x16_f16, accumulated in fp32; the weights are pre-scaled by a
+ * per-layer power of two (undone exactly in the epilogue) so that w_lo stays a normal fp16 number.  Error vs an fp64
+ * convolution: that of the exact fp32 kernel.  Inputs must satisfy |x| < 65520 (larger values become inf, loudly).
+ * Same tensors / strides / act / residual / upsample2x conventions as isrConv3x3ForwardF16 below; wq: prepared by
+ * isrConvSplitPrepare into isrConvSplitWeightBytes(Cin, Cout) bytes of device memory (layout private to the kernel). */
+long long isrConvSplitWeightBytes(int Cin, int Cout);
+int isrConvSplitPrepare(const float* w, void* wq, int Cout, int Cin, void* stream);
+int isrConv3x3ForwardSplit(const float* x, const void* wq, const float* bias, const float* residual, float* y,
+                           int N, int Cin, int H, int W, int Cout, int act, float slope, int upsample2x,
+                           long long xPlane, long long xImage, long long yPlane, long long yImage,
+                           long long rPlane, long long rImage, void* stream);
+
 /* HALF-PRECISION FAST MODE of the same fused convolution (inference; not the parity path -- SURVEY.md 8(d) lets a
  * reduced-precision mode be reported separately, judged by PSNR): operands rounded to fp16 (saturating) on their way
  * into LDS, v_mfma_f32_32x32x16_f16 with fp32 accumulation, fp32 tensors in memory as above (strides in floats, rows packed).  wq: prepared by

@@ -27,6 +27,7 @@
 
 #include "../../include/isr_sr_kernels.h"
 #include "sr_finish.h"
+#include "sr_profile.h"
 
 // Launch with start/stop events on the dispatch packet when profiling, as a plain launch otherwise (plain launches can be
 // captured into a HIP graph -- train.GraphedTrainStep -- the Ext form cannot be relied upon there).
@@ -1246,6 +1247,13 @@ static hipEvent_t pool_event()
         g_event_pool.push_back(e);
     }
     return g_event_pool[g_pool_used++];
+}
+
+void isr_profile_record(int variant, double flops, hipEvent_t* e0, hipEvent_t* e1)
+{
+    if (!g_profile) return;
+    *e0 = pool_event(); *e1 = pool_event();
+    g_records.push_back({ variant, flops, *e0, *e1 });
 }
 
 static int g_conv_dbg = 0;

@@ -1,0 +1,11 @@
+// Per-dispatch timing shared by the translation units of libisr_sr.so (bench.py reads it through isrProfile*):
+// while profiling is enabled, a launcher asks for a start/stop event pair that rides on its dispatch packet
+// (hipExtLaunchKernelGGL) and registers the launch's kernel variant and algorithmic flops.
+#pragma once
+#include <hip/hip_runtime.h>
+
+constexpr int ISR_VARIANT_SPLIT = 13;       // conv3x3_split_kernel<false>
+constexpr int ISR_VARIANT_SPLIT_UPS = 14;   // conv3x3_split_kernel<true>
+
+// Sets *e0 / *e1 to an event pair (and records the launch) when profiling is on, leaves them untouched otherwise.
+void isr_profile_record(int variant, double flops, hipEvent_t* e0, hipEvent_t* e1);

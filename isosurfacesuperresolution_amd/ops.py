@@ -72,6 +72,9 @@ def _sr():
         lib.isrConvBf16Prepare.argtypes = [vp, vp, ci, ci, vp]; lib.isrConvBf16Prepare.restype = ci
         lib.isrConv3x3ForwardBf16.argtypes = lib.isrConv3x3ForwardF16.argtypes; lib.isrConv3x3ForwardBf16.restype = ci
         lib.isrConv3x3ForwardF16.restype = ci
+        lib.isrConvSplitWeightBytes.argtypes = [ci, ci]; lib.isrConvSplitWeightBytes.restype = ll
+        lib.isrConvSplitPrepare.argtypes = [vp, vp, ci, ci, vp]; lib.isrConvSplitPrepare.restype = ci
+        lib.isrConv3x3ForwardSplit.argtypes = lib.isrConv3x3ForwardF16.argtypes; lib.isrConv3x3ForwardSplit.restype = ci
         lib.isrProfileEnable.argtypes = [ci]; lib.isrProfileEnable.restype = ci
         lib.isrProfileCount.argtypes = []; lib.isrProfileCount.restype = ci
         lib.isrProfileGet.argtypes = [ci, vp, vp, vp]; lib.isrProfileGet.restype = ci
@@ -123,7 +126,8 @@ def prepare_weights(weight, transpose_flip=False):
 VARIANT_NAMES = {6: "conv3x3_small_cout_kernel", 2: "conv3x3_fwd_kernel<1,false>", 3: "conv3x3_fwd_kernel<1,true>",
                  4: "conv3x3_fwd_kernel<2,false>", 5: "conv3x3_fwd_kernel<2,true>",
                  8: "conv3x3_fwd2_kernel<false,4>", 9: "conv3x3_fwd2_kernel<true,4>",
-                 10: "conv3x3_fwd2_kernel<false,1>", 11: "conv3x3_fwd2_kernel<true,1>", 12: "conv3x3_rowsplit_kernel"}
+                 10: "conv3x3_fwd2_kernel<false,1>", 11: "conv3x3_fwd2_kernel<true,1>", 12: "conv3x3_rowsplit_kernel",
+                 13: "conv3x3_split_kernel<false>", 14: "conv3x3_split_kernel<true>"}
 
 
 def profile_enable(on):
@@ -301,6 +305,74 @@ def conv3x3_f16(x, weight, bias=None, act='none', slope=0.01, residual=None, ups
     with torch.no_grad():
         return _launch_lp(x, _prepare_lp(weight), bias.contiguous() if bias is not None else None, residual, weight.shape[0],
                           act, slope, upsample2x, False)
+
+
+# ---- split-operand mode: fp32-equivalent accuracy on the fp16 matrix pipe (inference; THE default parity path) ----------
+# SPLIT_F16 = True routes the no-grad ``conv3x3`` of layers with more than 8 output channels through
+# ``isrConv3x3ForwardSplit`` (csrc/sr_conv_split.hip): every operand is split into two fp16 numbers (22 significand
+# bits), a product is three fp16 MFMAs accumulated in fp32 -- 5.3x fewer matrix cycles than the fp32 MFMA at an error
+# against fp64 that matches the exact fp32 kernel's (tests/test_conv_gpu.py).  SPLIT_F16 = False restores the exact
+# k-ordered fmaf-chain kernels of sr_conv3x3.hip (training always uses those).
+SPLIT_F16 = True
+_split_cache = {}
+
+
+def _prepare_split(weight):
+    """Weights as scaled (hi, lo) fp16 pairs in the split kernel's layout, cached like ``prepare_weights``."""
+    lib = _sr()
+    key = id(weight)
+    hit = _split_cache.get(key)
+    if hit is not None:
+        ref, version, ptr, wq = hit
+        if ref() is weight and version == weight._version and ptr == weight.data_ptr():
+            return wq
+    w = weight.detach().contiguous()
+    cout, cin = w.shape[0], w.shape[1]
+    wq = torch.empty(lib.isrConvSplitWeightBytes(cin, cout), dtype=torch.uint8, device=weight.device)
+    rc = lib.isrConvSplitPrepare(_ptr(w), _ptr(wq), cout, cin, _stream())
+    if rc != 0:
+        raise RuntimeError("isrConvSplitPrepare failed (%d)" % rc)
+    if len(_split_cache) > 512:
+        for k in [k for k, v in _split_cache.items() if v[0]() is None]:
+            del _split_cache[k]
+    _split_cache[key] = (weakref.ref(weight), weight._version, weight.data_ptr(), wq)
+    return wq
+
+
+def _split_fits(x, cout, upsample2x):
+    """The split kernel addresses one image through 32-bit buffer offsets: every tensor of a launch must stay below 2 GiB."""
+    h, w = (2 * x.shape[2], 2 * x.shape[3]) if upsample2x else (x.shape[2], x.shape[3])
+    xplane = max(x.stride(1), x.shape[2] * x.shape[3]) if x.stride(3) == 1 else x.shape[2] * x.shape[3]
+    return x.shape[1] * xplane * (16 if upsample2x else 4) < 2 ** 31 and cout * (h * w + plane_pad(h, w)) * 4 < 2 ** 31
+
+
+def conv3x3_split(x, weight, bias=None, act='none', slope=0.01, residual=None, upsample2x=False):
+    """``conv3x3`` on the split-operand kernel (no autograd): y = act(conv3x3(U(x), w) + bias) + residual."""
+    if act not in ('none', 'relu', 'leaky'):
+        raise ValueError("unknown activation %r" % (act,))
+    lib = _sr()
+    with torch.no_grad():
+        wq = _prepare_split(weight)
+        bias = bias.contiguous() if bias is not None else None
+        x, xp, xi = _plane_strides(x)
+        fuse = False
+        if upsample2x:
+            fuse = bool(lib.isrConvF16SupportsUpsample(x.data_ptr(), x.shape[3], xp, xi))
+            if not fuse:          # unaligned low-res rows: the resize runs as its own kernel first
+                x, xp, xi = _plane_strides(bilinear_upsample2x(x))
+        n, cin = x.shape[0], x.shape[1]
+        cout = weight.shape[0]
+        h, w = (2 * x.shape[2], 2 * x.shape[3]) if fuse else (x.shape[2], x.shape[3])
+        rp = ri = 0
+        if residual is not None:
+            residual, rp, ri = _plane_strides(residual)
+        y = empty_planes(n, cout, h, w, x.device)
+        rc = lib.isrConv3x3ForwardSplit(_ptr(x), _ptr(wq), _ptr(bias), _ptr(residual), _ptr(y), n, cin, h, w, cout,
+                                        ACT_CODES[act], float(slope), 1 if fuse else 0, xp, xi, y.stride(1), cout * y.stride(1),
+                                        rp, ri, _stream())
+        if rc != 0:
+            raise RuntimeError("isrConv3x3ForwardSplit failed (%d)" % rc)
+        return y
 
 
 # ---- mixed-precision training mode (opt-in, NOT the parity path) ------------------------------------------------------
@@ -516,6 +588,8 @@ def conv3x3(x, weight, bias=None, act='none', slope=0.01, residual=None, upsampl
         cout, cin = weight.shape[0], weight.shape[1]
         if FAST_F16 and cout > 8:
             return conv3x3_f16(x, weight, bias, act, slope, residual, upsample2x)
+        if SPLIT_F16 and cout > 8 and _split_fits(x, cout, upsample2x):
+            return conv3x3_split(x, weight, bias, act, slope, residual, upsample2x)
         if cout <= 8 and not upsample2x and cin * x.shape[2] * x.shape[3] * 4 < 2 ** 31:
             return _launch_small(x, weight, bias, residual.contiguous() if residual is not None else None, act, slope)
         return _launch_forward(x, prepare_weights(weight),

@@ -46,8 +46,32 @@ CASES = [
 ]
 
 
+@pytest.fixture(params=["split", "exact"])
+def conv_mode(request):
+    """Inference convolutions run on the split-operand kernel (ops.SPLIT_F16, the default) or on the exact k-ordered
+    fmaf-chain kernels; both must meet the same bar on every case."""
+    from isosurfacesuperresolution_amd import ops
+    old = ops.SPLIT_F16
+    ops.SPLIT_F16 = request.param == "split"
+    yield request.param
+    ops.SPLIT_F16 = old
+
+
+@pytest.fixture
+def exact_mode():
+    from isosurfacesuperresolution_amd import ops
+    old = ops.SPLIT_F16
+    ops.SPLIT_F16 = False
+    yield
+    ops.SPLIT_F16 = old
+
+
 @pytest.mark.parametrize("case", CASES)
-def test_conv3x3_forward(case):
+def test_conv3x3_forward(case, conv_mode):
+    _forward_case(case)
+
+
+def _forward_case(case):
     from isosurfacesuperresolution_amd import ops
     N, Cin, Cout, h, w, act, has_b, has_r, ups = case
     g = torch.Generator().manual_seed(hash(case) % (2 ** 31))
@@ -68,7 +92,7 @@ def test_conv3x3_forward(case):
 
 @pytest.mark.parametrize("tile", [1, 2, 3])
 @pytest.mark.parametrize("case", [c for c in CASES if c[2] > 8 or c[8]])
-def test_conv3x3_forward_both_tilings(case, tile):
+def test_conv3x3_forward_both_tilings(case, tile, exact_mode):
     """The forward kernel has a 16x32 and a 4x32 tiling and a one-row-per-workgroup form with K split over the waves
     (picked by problem size; 3 = the latter, which has no upsampling variant and falls back to the 4x32 tiling
     there); all must give the reference result on every case, whatever the heuristic would choose."""
@@ -76,12 +100,12 @@ def test_conv3x3_forward_both_tilings(case, tile):
     lib = ops._sr()
     lib.isrDebugSetForwardTile(tile)
     try:
-        test_conv3x3_forward(case)
+        _forward_case(case)
     finally:
         lib.isrDebugSetForwardTile(0)
 
 
-def test_conv3x3_padded_channel_planes():
+def test_conv3x3_padded_channel_planes(conv_mode):
     """Tensors with padded channel planes (ops.empty_planes) go through the strided C entry points unchanged."""
     from isosurfacesuperresolution_amd import ops
     g = torch.Generator().manual_seed(11)
@@ -107,8 +131,67 @@ def test_conv3x3_padded_channel_planes():
     assert (y2.cpu().double() - ref2).abs().max().item() <= 1e-4
 
 
-def test_conv3x3_is_exact_fma_chain_on_integers():
-    """fp32 MFMA is an exact fmaf chain: small-integer data must come out exactly."""
+def test_split_operand_accuracy_matches_the_exact_kernel():
+    """The split-operand kernel (three fp16 MFMAs per product, fp32 accumulation) against an fp64 convolution, next to
+    the exact fp32 kernel on the same data: 64 -> 64 channels (K = 576), O(1) activations, weights of the network's
+    scale, plus the corners of the fp16 range -- tiny activations (x_lo subnormal), large ones (|x| up to 2000),
+    tiny and large weights (the per-layer power-of-two scale)."""
+    from isosurfacesuperresolution_amd import ops
+    g = torch.Generator().manual_seed(21)
+    old = ops.SPLIT_F16
+    try:
+        for xs, ws in ((1.0, 0.06), (1e-3, 0.06), (2000.0, 0.06), (1.0, 1e-5), (1.0, 300.0), (30.0, 0.5)):
+            x = (torch.rand(1, 64, 40, 64, generator=g) * 2 - 1) * xs
+            x[:, ::3] = torch.relu(x[:, ::3])                               # exact zeros as after a ReLU
+            w = (torch.rand(64, 64, 3, 3, generator=g) * 2 - 1) * ws
+            b = (torch.rand(64, generator=g) - 0.5) * xs * ws
+            ref = F.conv2d(x.double(), w.double(), b.double(), padding=1)
+            scale = ref.abs().max().item()
+            err = {}
+            for mode in (True, False):
+                ops.SPLIT_F16 = mode
+                with torch.no_grad():
+                    y = ops.conv3x3(x.cuda(), w.cuda(), b.cuda())
+                err[mode] = (y.cpu().double() - ref).abs().max().item() / scale
+            # both are at the level of fp32 rounding of a 576-term sum; the split kernel must not be worse than 2x the exact one
+            assert err[True] <= 2.0 * err[False] + 2e-7, (xs, ws, err)
+            assert err[True] <= 2e-6, (xs, ws, err)
+    finally:
+        ops.SPLIT_F16 = old
+
+
+def test_split_operand_network_matches_the_exact_kernels():
+    """The whole EnhanceNet forward on the split-operand kernels and on the exact fp32 kernels against the same network
+    in fp64 on the CPU: both sit at the same distance from the fp64 answer (the split path at most 2x the exact one),
+    far inside the 1e-4 bar."""
+    from isosurfacesuperresolution_amd import models, ops
+    opt = argparse.Namespace(upsample='bilinear', reconType='residual', useBN=False, numResidualLayers=10)
+    torch.manual_seed(0)
+    net = models.createNetwork('EnhanceNet', 4, 101, [0, 1, 2, 3, 4], 6, opt).eval()
+    x = torch.rand(1, 101, 24, 32, generator=torch.Generator().manual_seed(2))
+    net64 = models.createNetwork('EnhanceNet', 4, 101, [0, 1, 2, 3, 4], 6, opt).eval().double()
+    net64.load_state_dict({k: v.double() for k, v in net.state_dict().items()})
+    with torch.no_grad():
+        ref = net64(x.double())[0]
+    net = net.cuda()
+    old = ops.SPLIT_F16
+    out = {}
+    try:
+        for mode in (True, False):
+            ops.SPLIT_F16 = mode
+            with torch.no_grad():
+                out[mode] = net(x.cuda())[0].cpu().double()
+    finally:
+        ops.SPLIT_F16 = old
+    assert not torch.equal(out[True], out[False])                           # two different kernels did run
+    e_split, e_exact = (out[True] - ref).abs().max().item(), (out[False] - ref).abs().max().item()
+    assert e_exact <= 1e-4 and e_split <= 1e-4, (e_split, e_exact)
+    assert e_split <= 2.0 * e_exact + 1e-6, (e_split, e_exact)
+
+
+def test_conv3x3_is_exact_fma_chain_on_integers(conv_mode):
+    """fp32 MFMA is an exact fmaf chain: small-integer data must come out exactly (and so it must on the split-operand
+    kernel: small integers are their own fp16 'hi' part, 'lo' is zero, products and fp32 sums are exact)."""
     from isosurfacesuperresolution_amd import ops
     g = torch.Generator().manual_seed(5)
     x = torch.randint(-3, 4, (1, 64, 19, 35), generator=g).float()
