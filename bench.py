@@ -22,7 +22,9 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 MFMA_F32_PEAK_TFLOPS = 157.3      # /opt/skills/guides/MI355X_MICROARCH.md, chip-level parameters
+MFMA_F16_PEAK_TFLOPS = 2500.0     # dense fp16/bf16 MFMA (same table)
 HBM_PEAK_GBS = 8000.0
+PMC_TRAFFIC_FILES = ("r02_pmc_traffic.json", "r01_pmc_traffic.json")   # committed rocprofv3 --pmc passes of this command
 
 
 def parse():
@@ -36,6 +38,8 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--raymarch-variant", type=int, default=0)
     ap.add_argument("--no-fast-mode", action="store_true", help="skip the separately reported fp16 fast-mode leg")
+    ap.add_argument("--exact", action="store_true", help="convolutions on the exact k-ordered fp32 fmaf-chain kernels (fp32 MFMA) instead "
+                    "of the split-operand kernels (three fp16 MFMAs per product, fp32-equivalent accuracy)")
     ap.add_argument("--raymarch-large", default="", help="extra leg: the ray-march kernel alone on a volume that exceeds the caches, "
                     "e.g. cloud512@1920x1080 (algorithmic bytes counted by the CPU restatement like the cpu_baseline leg)")
     ap.add_argument("--no-overlap", action="store_true", help="render frame t and super-resolve it back to back on one stream")
@@ -72,6 +76,8 @@ def main():
             dist.init_process_group(backend)
     assert args.gpus == world, "--gpus must equal the number of launched ranks"
 
+    if args.exact:
+        ops.SPLIT_F16 = False
     low_w, low_h = (int(v) for v in args.low.split("x"))
     iso = {"ejecta256": 0.34, "ejecta128": 0.34, "sphere64": 0.5}[args.volume]
     vol = V.VOLUMES[args.volume][0]()
@@ -121,10 +127,15 @@ def main():
     rm_ms = renderer.profile_times_ms()
     ops.profile_enable(False)
     renderer.profile_enable(False)
+    rccl_ranks = None
     if world > 1:
         tmax = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = tmax.item()
+        # how many ranks the collective backend really joined: a sum of ones over a DEVICE all-reduce (RCCL when nccl)
+        ones = torch.ones(1, dtype=torch.float32, device="cuda" if backend == "nccl" else "cpu")
+        dist.all_reduce(ones)
+        rccl_ranks = int(ones.item())
 
     per = {}
     for name, flops, ms in records:
@@ -153,12 +164,20 @@ def main():
 
     # HBM traffic of the dominant kernel: PMC counters cannot be read from inside this process; the
     # committed rocprofv3 --pmc passes of this same command (profiles/r01_pmc_summary.md) provide it.
-    traffic = None
-    try:
-        with open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")) as f:
-            traffic = json.load(f)[dom_name]["traffic_bytes_per_launch"]
-    except (OSError, KeyError, ValueError):
-        pass
+    traffic = traffic_file = None
+    for name in PMC_TRAFFIC_FILES:
+        try:
+            with open(os.path.join(ROOT, "profiles", name)) as f:
+                traffic = json.load(f)[dom_name]["traffic_bytes_per_launch"]
+            traffic_file = name
+            break
+        except (OSError, KeyError, ValueError):
+            continue
+    # Roofline of the dominant kernel.  `achieved` is always ALGORITHMIC: 2*9*Cin*Cout flops per output pixel.  The exact
+    # kernels spend one fp32 MFMA multiply-accumulate per algorithmic one (peak 157.3); the split-operand kernels spend
+    # three fp16 ones (x_hi*w_hi + x_hi*w_lo + x_lo*w_hi), so their ceiling is a third of the dense fp16 MFMA peak.
+    split = dom_name.startswith("conv3x3_split")
+    peak = MFMA_F16_PEAK_TFLOPS / 3.0 if split else MFMA_F32_PEAK_TFLOPS
 
     result = {
         "metric": baseline_metric(),
@@ -169,15 +188,21 @@ def main():
         "higher_is_better": True,
         "scaling": "weak",
         "vs_baseline": None,
-        "dtype": "f32",
+        "dtype": "f32" if args.exact else "f32 (fp32 tensors and accumulation; each product as three fp16 MFMAs on split operands, error vs fp64 = the fp32 kernels')",
         "data": "synthetic (V256-ejecta stand-in volume, seeded random-init EnhanceNet weights)",
         "config": {"workload": "%s volume, %dx%d -> %dx%d 4x SR inference, orbit camera, temporal=%s" % (
             args.volume, low_w, low_h, 4 * low_w, 4 * low_h, "off" if args.no_temporal else "on"),
             "frames_per_rank": K, "sharding": "contiguous frame chunks per rank, no collective",
-            "overlap": ("render(t+1) on a side HIP stream || SR(t), %d ray-march waves" % pipe.side_waves) if overlap else "off"},
-        "roofline": {"kernel": dom_name, "bound": "mfma", "achieved": achieved, "peak": MFMA_F32_PEAK_TFLOPS,
-                     "unit": "TFLOP/s", "frac": achieved / MFMA_F32_PEAK_TFLOPS, "traffic": traffic,
-                     "traffic_source": "profiles/r01_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, bytes per launch)" if traffic else None,
+            "overlap": ("render(t+1) on a side HIP stream || SR(t), %d ray-march waves" % pipe.side_waves) if overlap else "off",
+            "conv_kernels": "exact fp32 fmaf chain (v_mfma_f32_32x32x2_f32)" if args.exact else
+                            "split-operand: 3 x v_mfma_f32_32x32x16_f16 per product, fp32 accumulation (bench.py --exact = fp32 MFMA kernels)"},
+        "rccl_ranks": rccl_ranks,
+        "roofline": {"kernel": dom_name, "bound": "mfma", "achieved": achieved, "peak": peak,
+                     "unit": "TFLOP/s", "frac": achieved / peak, "traffic": traffic,
+                     "peak_source": ("dense fp16 MFMA %.0f TFLOP/s / 3 matrix products per algorithmic multiply-accumulate" % MFMA_F16_PEAK_TFLOPS)
+                                    if split else "fp32 MFMA",
+                     "matrix_tflops_executed": achieved * (3.0 if split else 1.0),
+                     "traffic_source": ("profiles/%s (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, bytes per launch)" % traffic_file) if traffic else None,
                      "avg_launch_ms": dom_time / dom_launches * 1e3, "launches_per_frame": dom_launches / K,
                      "flops_per_launch": dom_flops / dom_launches},
         "kernels": {n: {"tflops": v[0] / v[1] / 1e12, "ms_per_frame": v[1] / K * 1e3, "launches_per_frame": v[2] / K}
@@ -357,7 +382,9 @@ def cpu_reference_leg(args, vol, iso, net, pipe, origin, low_w, low_h, result, r
         "cpu_baseline": {"value": n_frames / (t_render + t_sr), "unit": "frames/s", "cores": cores, "kind": "port",
                          "sample": "%d frames of the bench sequence: oracle ray-march %dx%d (%.3f s, OpenMP %d threads) + PyTorch CPU flow fill, warp, EnhanceNet, shading (%.3f s, %d threads)" % (
                              n_frames, low_w, low_h, t_render, cores, t_sr, cores)},
-        "parity": {"mask_mismatches": int((gbuf[..., 3] != ref[..., 3]).sum()),
+        "parity": {"frames_compared": 1,     # the FIRST frame of a sequence: with random-init weights the recurrence amplifies
+                                             # rounding differences ~2.4x per frame, so later frames drift
+                   "mask_mismatches": int((gbuf[..., 3] != ref[..., 3]).sum()),
                    "gbuffer_max_abs_err_excl_flow": float(np.abs(np.delete(gbuf, [8, 9], axis=2) - np.delete(ref, [8, 9], axis=2)).max()),
                    "sr_raw_max_abs_err": float((raw_gpu.cpu() - raw).abs().max().item()),
                    "psnr_rgb_vs_cpu_db": float(psnr)},

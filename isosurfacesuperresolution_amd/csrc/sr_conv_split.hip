@@ -10,11 +10,15 @@
 // chain.  Against an fp64 convolution the result is as close as the exact fp32 kernel's (tests/test_conv_gpu.py),
 // so this IS the parity path for inference (ops.SPLIT_F16, default on); the exact kernels remain one switch away.
 //
-// Range: fp16 normals end at 2^-14, subnormals have an absolute spacing of 2^-24.
-//   * weights (|w| ~ 0.06 for this network: w_lo would be subnormal) are pre-scaled per layer by 2^S so that
-//     max |w| 2^S is in [2^13, 2^14); the epilogue multiplies the accumulator by 2^-S (exact);
-//   * activations are not scaled: for |x| < 2^-3 x_lo is subnormal and x is represented to an ABSOLUTE 2^-25 = 3e-8 --
-//     half an fp32 ulp of a value in [0.25, 0.5) -- which is what the O(1) activations of this network carry anyway;
+// Range: fp16 normals end at 2^-14 and subnormals have an absolute spacing of 2^-24, so a plain `lo` of an O(1) value
+// (|lo| <= 2^-11 |v|) would sit among the subnormals and lose its bits.  Both operands are therefore kept in range:
+//   * weights (|w| ~ 0.06 for this network) are pre-scaled per layer by 2^S so that max |w| 2^S is in [2^13, 2^14);
+//     the epilogue multiplies the accumulator by 2^-S (exact).  w_lo is then a normal number for every weight within
+//     2^-17 of the largest one (smaller ones are represented to an absolute 2^-25 -- 2^-38 of the largest);
+//   * activations cannot be scaled without knowing their range, so their low part is stored scaled,
+//     x_lo' = RN16((x - x_hi) 2^11)  (|x_lo'| <= |x|: a normal number whenever x_hi is), and the product that uses it
+//     multiplies by w_hi 2^-11 instead -- an exponent shift of the A fragment in registers (four v_pk_mul_f16 per
+//     fragment, issued in the shadow of the MFMAs).  x is carried to 2^-22 relative for 2^-14 <= |x| < 65520;
 //     |x| >= 65520 overflows fp16 and shows up as inf/NaN (loud, not silent).
 //
 // Structure (from the streaming fp16 kernel of sr_conv_f16.hip): workgroup = 8 x 32 output pixels x 64 output
@@ -71,6 +75,12 @@ __device__ __forceinline__ void split16(float v, _Float16& hi, _Float16& lo)
 {
     hi = (_Float16)v;
     lo = (_Float16)(v - (float)hi);
+}
+// activations: the low part scaled by 2^11 (exact), see the header comment
+__device__ __forceinline__ void split16x(float v, _Float16& hi, _Float16& lo)
+{
+    hi = (_Float16)v;
+    lo = (_Float16)((v - (float)hi) * 2048.0f);
 }
 
 __device__ __forceinline__ float buf_load(rsrc_t r, unsigned voff)
@@ -193,7 +203,7 @@ __global__ __launch_bounds__(S_THREADS, 2) void conv3x3_split_kernel(const Split
                         const float* a = t0 + e * (LR_H * LR_W);
                         const float* b = t1 + e * (LR_H * LR_W);
                         _Float16 vh, vl;
-                        split16(hy * (hx * a[x0] + lx * a[x1]) + ly * (hx * b[x0] + lx * b[x1]), vh, vl);
+                        split16x(hy * (hx * a[x0] + lx * a[x1]) + ly * (hx * b[x0] + lx * b[x1]), vh, vl);
                         oh[e] = vh; ol[e] = vl;
                     }
                 } else {
@@ -237,10 +247,10 @@ __global__ __launch_bounds__(S_THREADS, 2) void conv3x3_split_kernel(const Split
                     for (int e = 0; e < 8; ++e) {
                         const float4 f = __builtin_bit_cast(float4, v[k][e]);
                         _Float16 a, b;
-                        split16(f.x, a, b); h0[e] = a; l0[e] = b;
-                        split16(f.y, a, b); h1[e] = a; l1[e] = b;
-                        split16(f.z, a, b); h2[e] = a; l2[e] = b;
-                        split16(f.w, a, b); h3[e] = a; l3[e] = b;
+                        split16x(f.x, a, b); h0[e] = a; l0[e] = b;
+                        split16x(f.y, a, b); h1[e] = a; l1[e] = b;
+                        split16x(f.z, a, b); h2[e] = a; l2[e] = b;
+                        split16x(f.w, a, b); h3[e] = a; l3[e] = b;
                     }
                     u32x4* dst = patch + g * SP_PIX + r * SP_W + 4 * q - 3;
                     // quad 0 contributes only its last pixel (patch column 0), quad 9 only its first (column 33)
@@ -271,7 +281,7 @@ __global__ __launch_bounds__(S_THREADS, 2) void conv3x3_split_kernel(const Split
                     const int u = u0 + k * S_THREADS;
                     f16x8 qh, ql;
 #pragma unroll
-                    for (int e = 0; e < 8; ++e) { _Float16 a, b; split16(v[k][e], a, b); qh[e] = a; ql[e] = b; }
+                    for (int e = 0; e < 8; ++e) { _Float16 a, b; split16x(v[k][e], a, b); qh[e] = a; ql[e] = b; }
                     if (u < S_PART) { patch[u] = __builtin_bit_cast(u32x4, qh); patch[S_PART + u] = __builtin_bit_cast(u32x4, ql); }
                 }
             }
@@ -294,17 +304,19 @@ __global__ __launch_bounds__(S_THREADS, 2) void conv3x3_split_kernel(const Split
                         const f16x8 a0l = __builtin_bit_cast(f16x8, wl[S_WPART + tap * 128]);
                         const f16x8 a1h = __builtin_bit_cast(f16x8, wl[tap * 128 + (second ? 32 : 0)]);
                         const f16x8 a1l = __builtin_bit_cast(f16x8, wl[S_WPART + tap * 128 + (second ? 32 : 0)]);
+                        const f16x8 a0s = a0h * (_Float16)0.00048828125f;   // w_hi 2^-11: partner of the scaled x_lo'
+                        const f16x8 a1s = a1h * (_Float16)0.00048828125f;
 #pragma unroll
                         for (int r = 0; r < 2; ++r) {
                             const f16x8 bh = __builtin_bit_cast(f16x8, bl[(r + dy) * SP_W + dx]);
                             const f16x8 bo = __builtin_bit_cast(f16x8, bl[S_PART + (r + dy) * SP_W + dx]);
                             // the two small cross terms first, then the leading term
                             acc[0][r] = mfma16(a0l, bh, acc[0][r]);
-                            acc[0][r] = mfma16(a0h, bo, acc[0][r]);
+                            acc[0][r] = mfma16(a0s, bo, acc[0][r]);
                             acc[0][r] = mfma16(a0h, bh, acc[0][r]);
                             if (second) {
                                 acc[1][r] = mfma16(a1l, bh, acc[1][r]);
-                                acc[1][r] = mfma16(a1h, bo, acc[1][r]);
+                                acc[1][r] = mfma16(a1s, bo, acc[1][r]);
                                 acc[1][r] = mfma16(a1h, bh, acc[1][r]);
                             }
                         }
@@ -318,7 +330,7 @@ __global__ __launch_bounds__(S_THREADS, 2) void conv3x3_split_kernel(const Split
 
     if (p.stamps) st2 = __builtin_amdgcn_s_memtime();
     // ---- epilogue: D row (cout) = (reg & 3) + 8 * (reg >> 2) + 4 * h, column (pixel) = j ----------------------------
-    const float unscale = __builtin_bit_cast(float, p.wq[0].y);             // 2^-S (header of the prepared weights)
+    const float unscale = reinterpret_cast<const float*>(p.wq)[1];          // 2^-S (header of the prepared weights)
     const rsrc_t yrs = __builtin_amdgcn_make_buffer_rsrc(p.y + (size_t)n * p.yImage, 0, (int)((size_t)p.Cout * p.yPlane * 4), 0x00020000);
     const rsrc_t rrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.residual ? p.residual + (size_t)n * p.rImage : p.y), 0,
                                                          p.residual ? (int)((size_t)p.Cout * p.rPlane * 4) : 0, 0x00020000);
@@ -433,7 +445,7 @@ __global__ __launch_bounds__(256) void split_scale_kernel(const float* __restric
 // element e of (k-step s, half h) is input channel 16 s + 8 h + e (zero beyond Cin / Cout); part 0 = hi, 1 = lo of w 2^S
 __global__ void prepare_weights_split_kernel(const float* __restrict__ w, u32x4* __restrict__ wq, int Cout, int Cin, int ksteps, int coutPad)
 {
-    const float scale = __builtin_bit_cast(float, wq[0].x);
+    const float scale = reinterpret_cast<const float*>(wq)[0];
     const int total = 9 * ksteps * 2 * coutPad;                              // (tap, k-step, half, cout)
     for (int u = blockIdx.x * blockDim.x + threadIdx.x; u < total; u += gridDim.x * blockDim.x) {
         const int co = u % coutPad;
