@@ -47,11 +47,13 @@ def main():
         wr = mean("WRITE_SIZE")
         rd_b = rd * 1024 * 2 if rd is not None else None
         wr_b = wr * 1024 if wr is not None else None
-        busy, mops = mean("SQ_VALU_MFMA_BUSY_CYCLES"), mean("SQ_INSTS_VALU_MFMA_MOPS_F32")
+        busy, mops, mops16 = mean("SQ_VALU_MFMA_BUSY_CYCLES"), mean("SQ_INSTS_VALU_MFMA_MOPS_F32"), mean("SQ_INSTS_VALU_MFMA_MOPS_F16")
         per = None
         if busy and mops:
-            # MOPS_F32 counts 512-flop units: one 32x32x2 f32 MFMA = 4096 flops = 8 units... report busy per instruction
+            # MOPS_* count 512-flop units: one 32x32x2 f32 MFMA = 4096 flops = 8 units... report busy per instruction
             per = busy / (mops / 8.0) if mops else None
+        elif busy and mops16:
+            per = busy / (mops16 / 64.0)      # one 32x32x16 f16 MFMA = 32768 flops = 64 units
         conf = mean("SQ_LDS_BANK_CONFLICT")
         if rd_b is not None and wr_b is not None:
             out[k] = {"launches": n, "hbm_read_bytes_per_launch": rd_b, "hbm_write_bytes_per_launch": wr_b,
