@@ -24,7 +24,9 @@ extern "C" {
 int initGVDB(void);
 
 /* Replaces GPURendererDirect.cpp:248-285.  Loads a GVDB .vbx volume: 0 ok, -1 if the name does
- * not end in ".vbx", -2 if loading fails.  Clears the previous volume and resets the "last
+ * not end in ".vbx", -2 if loading fails (unreadable / malformed / truncated file, sizes that exceed the file, no
+ * memory -- never an exception or abort).  The file's 8^3 bricks are uploaded as they are: memory is proportional
+ * to the bricks, not to the box they span (bricks 4000 voxels apart cost two bricks).  Clears the previous volume and resets the "last
  * camera" used for the flow channels (GPURendererDirect.cpp:280-281). */
 int loadGrid(const char* filename);
 
@@ -101,6 +103,11 @@ int isoSetWaveCap(int waves);
  * enqueued on its side stream, it makes the ray-march waves land on an idle GPU -- one per SIMD -- instead of racing
  * the network's next kernel for slots.  Returns 0, -1 before initGVDB. */
 int isoGateResident(void* stream, int timeoutUs);
+
+/* Overrides the "last camera" the flow channels (8, 9) are measured against (render() / isoRenderAsync() set it to the
+ * camera they rendered; GPURendererDirect.cpp:440-442).  For callers that rendered a frame ahead and then discard it:
+ * the flow reference must go back to the last frame that was actually displayed.  0 ok, -1 on null pointers. */
+int isoSetLastCamera(const double origin[3], const double lookAt[3]);
 
 /* Host-only helpers around the .vbx reader (no GPU needed): volume dims [x,y,z] of the dense box
  * spanned by the stored bricks, and the dense fp32 data [z][y][x] itself. 0 ok, -2 on failure. */

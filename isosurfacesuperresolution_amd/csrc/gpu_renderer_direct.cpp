@@ -14,7 +14,9 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <algorithm>
 #include <string>
+#include <unordered_map>
 #include <utility>
 #include <vector>
 
@@ -72,6 +74,7 @@ struct State {
     float* aoRot = nullptr;
     unsigned* tileQueue = nullptr;   // 8 per-XCD work counters of kernel variant 2 (+ 1 resident-wave counter)
     unsigned residentTarget = 0;     // waves launched by all variant-2 renders so far (what the counter will reach)
+    unsigned gatedTarget = 0;        // residentTarget at the last isoGateResident: a gate with nothing new to wait for is a no-op
     bool profile = false;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> events;   // one pair per profiled frame
 };
@@ -240,6 +243,54 @@ struct TileInfo {
     int clipLo[3], clipHi[3];      // leaves owned by this tile, global index coordinates, [lo, hi), lo a multiple of 8
 };
 
+// Node-level bbox, world map and installation of a volume whose device tables are complete.
+// bbox: active-voxel bbox of the stored data (min xyz, max xyz); lmin / lmax: extreme leaf coordinates (bricks).
+bool finalizeVolume(Volume& v, int bbox[6], float maxValue, int lmin[3], int lmax[3], const TileInfo* tile)
+{
+    if (v.nleaf == 0 && !tile) {   // the reference throws on empty grids (IsoVolumeRayTracer.h:188-190)
+        freeVolume(v);
+        return false;
+    }
+    if (v.nleaf == 0) {            // an empty tile of a larger volume renders nothing
+        for (int k = 0; k < 3; ++k) { lmin[k] = 0; lmax[k] = -1; }
+    }
+    for (int k = 0; k < 3; ++k) {   // IsoVolumeRayTracer.h:195-197
+        v.bbmin[k] = lmin[k] * 8;
+        v.bbmax[k] = lmax[k] * 8 + 7 + 1;
+    }
+    v.maxValue = maxValue;
+    // CPURenderer.cpp:448-458 with unit voxels: scale longest active-bbox edge to 1, centre at 0
+    double ext[3], cen[3];
+    if (tile) {
+        for (int k = 0; k < 3; ++k) {
+            bbox[k] = tile->gmin[k]; bbox[3 + k] = tile->gmax[k];
+            // the ray is clipped to the GLOBAL node-level box: the leaf holding the extreme active voxel bounds it
+            v.bbmin[k] = tile->gmin[k] & ~7;
+            v.bbmax[k] = (tile->gmax[k] & ~7) + 7 + 1;
+        }
+        v.maxValue = tile->globalMax;
+    }
+    for (int k = 0; k < 3; ++k) {
+        const double lo = double(bbox[k]), hi = double(bbox[3 + k]);
+        ext[k] = hi - lo;
+        cen[k] = (lo + hi) * 0.5;
+    }
+    double m = ext[0];
+    if (ext[1] > m) m = ext[1];
+    if (ext[2] > m) m = ext[2];
+    if (!(m > 0)) { freeVolume(v); return false; }
+    const double scale = 1.0 / m;
+    v.s = 1.0 * scale;
+    v.sinv = 1.0 / v.s;
+    for (int k = 0; k < 3; ++k) v.t[k] = (-cen[k]) * scale;
+    v.loaded = true;
+    freeVolume(g.vol);
+    g.vol = v;
+    // GPURendererDirect.cpp:280-281
+    for (int k = 0; k < 3; ++k) { g.lastOrigin[k] = g.args.cameraOrigin[k]; g.lastLookAt[k] = g.args.cameraLookAt[k]; }
+    return true;
+}
+
 // Dense device volume -> bricks, occupancy hierarchy, bbox, max, world map.
 bool uploadFromDevice(const float* dense, int nx, int ny, int nz, const TileInfo* tile = nullptr)
 {
@@ -317,53 +368,162 @@ bool uploadFromDevice(const float* dense, int nx, int ny, int nz, const TileInfo
         for (int k = 0; k < 3; ++k) { lmin[k] = 0; lmax[k] = -1; }
     }
     v.nslots = nslots; v.nleaf = nleaf;
-    for (int k = 0; k < 3; ++k) {   // IsoVolumeRayTracer.h:195-197
-        v.bbmin[k] = lmin[k] * 8;
-        v.bbmax[k] = lmax[k] * 8 + 7 + 1;
-    }
-    v.maxValue = orderBitsToFloat(maxbits);
-    // CPURenderer.cpp:448-458 with unit voxels: scale longest active-bbox edge to 1, centre at 0
-    double ext[3], cen[3];
-    if (tile) {
-        for (int k = 0; k < 3; ++k) {
-            bbox[k] = tile->gmin[k]; bbox[3 + k] = tile->gmax[k];
-            // the ray is clipped to the GLOBAL node-level box: the leaf holding the extreme active voxel bounds it
-            v.bbmin[k] = tile->gmin[k] & ~7;
-            v.bbmax[k] = (tile->gmax[k] & ~7) + 7 + 1;
-        }
-        v.maxValue = tile->globalMax;
-        HIP_OK(hipMemcpy(v.leaf, leaf.data(), nb, hipMemcpyHostToDevice));   // existence AND ownership
-    }
-    for (int k = 0; k < 3; ++k) {
-        const double lo = double(bbox[k]), hi = double(bbox[3 + k]);
-        ext[k] = hi - lo;
-        cen[k] = (lo + hi) * 0.5;
-    }
-    double m = ext[0];
-    if (ext[1] > m) m = ext[1];
-    if (ext[2] > m) m = ext[2];
-    if (!(m > 0)) { freeVolume(v); return false; }
-    const double scale = 1.0 / m;
-    v.s = 1.0 * scale;
-    v.sinv = 1.0 / v.s;
-    for (int k = 0; k < 3; ++k) v.t[k] = (-cen[k]) * scale;
-
     HIP_OK(hipMalloc(&v.slot, nb * sizeof(int32_t)));
     HIP_OK(hipMalloc(&v.node1, node1.size()));
-    HIP_OK(hipMalloc(&v.bricks, size_t(nslots) * ISO_BRICK_STRIDE * sizeof(float)));
+    HIP_OK(hipMalloc(&v.bricks, size_t(nslots > 0 ? nslots : 1) * ISO_BRICK_STRIDE * sizeof(float)));
     HIP_OK(hipMemcpy(v.slot, slot.data(), nb * sizeof(int32_t), hipMemcpyHostToDevice));
     HIP_OK(hipMemcpy(v.node1, node1.data(), node1.size(), hipMemcpyHostToDevice));
+    if (tile) HIP_OK(hipMemcpy(v.leaf, leaf.data(), nb, hipMemcpyHostToDevice));   // existence AND ownership
     iso_launch_brick_fill(dense, nx, ny, nz, v.nbx, v.nby, v.nbz, v.slot, v.bricks, nullptr);
     HIP_OK(hipMalloc(&v.leafRange, nb * 2 * sizeof(float)));
     iso_launch_leaf_range(dense, nx, ny, nz, v.nbx, v.nby, v.nbz, v.leafRange, nullptr);
     HIP_OK(hipGetLastError());
     HIP_OK(hipDeviceSynchronize());
-    v.loaded = true;
-    freeVolume(g.vol);
-    g.vol = v;
-    // GPURendererDirect.cpp:280-281
-    for (int k = 0; k < 3; ++k) { g.lastOrigin[k] = g.args.cameraOrigin[k]; g.lastLookAt[k] = g.args.cameraLookAt[k]; }
-    return true;
+    return finalizeVolume(v, bbox, orderBitsToFloat(maxbits), lmin, lmax, tile);
+}
+
+// Sparse brick list (a .vbx file: 8^3 bricks at arbitrary positions of a box of up to 4096^3) -> the same device
+// structures as uploadFromDevice, without ever materialising the box: host work and host memory are proportional to
+// the number of bricks; the device holds the bricks plus the three per-position tables of the box (9 bytes per 8^3
+// position: 1.2 GB for a box of 4096^3, memset on the device and filled by a scatter of the existing positions).
+bool uploadFromBricks(const VbxBricks& vb)
+{
+    if (vb.bd != 8) return false;
+    const int nx = vb.dims[0], ny = vb.dims[1], nz = vb.dims[2];
+    if (nx <= 0 || ny <= 0 || nz <= 0 || nx > 4096 || ny > 4096 || nz > 4096) return false;
+    Volume v;
+    v.nx = nx; v.ny = ny; v.nz = nz;
+    v.nbx = (nx + 7) / 8; v.nby = (ny + 7) / 8; v.nbz = (nz + 7) / 8;
+    v.n1x = ((nx - 1) >> 7) + 1; v.n1y = ((ny - 1) >> 7) + 1; v.n1z = ((nz - 1) >> 7) + 1;
+    const long long nbx = v.nbx, nby = v.nby;
+    const size_t nb = size_t(v.nbx) * v.nby * v.nbz;
+    auto lin = [&](int bx, int by, int bz) { return (long long)((bz * nby + by) * nbx + bx); };
+    // bricks that hold a non-zero voxel, by position; active bbox and maximum over their voxels
+    std::unordered_map<long long, const float*> have;
+    have.reserve(vb.count() * 2);
+    int bbox[6] = { INT32_MAX, INT32_MAX, INT32_MAX, INT32_MIN, INT32_MIN, INT32_MIN };
+    float maxv = -3.0e38f;
+    for (size_t k = 0; k < vb.count(); ++k) {
+        const float* d = vb.data.data() + k * 512;
+        const int px = vb.pos[3 * k], py = vb.pos[3 * k + 1], pz = vb.pos[3 * k + 2];
+        bool any = false;
+        for (int i = 0; i < 512; ++i) {
+            const float f = d[i];
+            if (f == 0.0f) continue;
+            any = true;
+            const int x = px + (i & 7), y = py + ((i >> 3) & 7), z = pz + (i >> 6);
+            if (x < bbox[0]) bbox[0] = x; if (x > bbox[3]) bbox[3] = x;
+            if (y < bbox[1]) bbox[1] = y; if (y > bbox[4]) bbox[4] = y;
+            if (z < bbox[2]) bbox[2] = z; if (z > bbox[5]) bbox[5] = z;
+            if (f > maxv) maxv = f;
+        }
+        if (any) have[lin(px >> 3, py >> 3, pz >> 3)] = d;
+    }
+    // positions whose 9^3 apron can hold a non-zero value: a non-zero brick and its seven lower neighbours
+    std::vector<long long> cand;
+    cand.reserve(have.size() * 8);
+    for (const auto& kv : have) {
+        const long long b = kv.first;
+        const int bx = int(b % nbx), by = int((b / nbx) % nby), bz = int(b / (nbx * nby));
+        for (int o = 0; o < 8; ++o) {
+            const int x = bx - (o & 1), y = by - ((o >> 1) & 1), z = bz - (o >> 2);
+            if (x >= 0 && y >= 0 && z >= 0) cand.push_back(lin(x, y, z));
+        }
+    }
+    std::sort(cand.begin(), cand.end());
+    cand.erase(std::unique(cand.begin(), cand.end()), cand.end());
+    std::vector<long long> index;
+    std::vector<int32_t> slotv;
+    std::vector<uint8_t> leafv;
+    std::vector<float> rangev, bricks;
+    std::vector<uint8_t> node1(size_t(v.n1x) * v.n1y * v.n1z, 0);
+    int lmin[3] = { INT32_MAX, INT32_MAX, INT32_MAX }, lmax[3] = { INT32_MIN, INT32_MIN, INT32_MIN };
+    int nslots = 0, nleaf = 0;
+    for (const long long b : cand) {
+        const int bx = int(b % nbx), by = int((b / nbx) % nby), bz = int(b / (nbx * nby));
+        // the 27 bricks around the position
+        const float* nbr[3][3][3];
+        for (int dz = -1; dz <= 1; ++dz)
+            for (int dy = -1; dy <= 1; ++dy)
+                for (int dx = -1; dx <= 1; ++dx) {
+                    const int x = bx + dx, y = by + dy, z = bz + dz;
+                    const float* q = nullptr;
+                    if (x >= 0 && y >= 0 && z >= 0 && x < v.nbx && y < v.nby && z < v.nbz) {
+                        auto it = have.find(lin(x, y, z));
+                        if (it != have.end()) q = it->second;
+                    }
+                    nbr[dz + 1][dy + 1][dx + 1] = q;
+                }
+        // voxel at offset (lx, ly, lz) in [-1, 9] from the position's corner; 0 outside the box / between bricks
+        auto at = [&](int lx, int ly, int lz) -> float {
+            const float* q = nbr[(lz + 8) >> 3][(ly + 8) >> 3][(lx + 8) >> 3];
+            return q ? q[((lz & 7) * 8 + (ly & 7)) * 8 + (lx & 7)] : 0.0f;
+        };
+        bool any9 = false;
+        float tmp[ISO_BRICK_STRIDE];
+        for (int k = 0; k < ISO_BRICK_STRIDE; ++k) tmp[k] = 0.0f;
+        for (int lz = 0; lz < 9; ++lz)
+            for (int ly = 0; ly < 9; ++ly)
+                for (int lx = 0; lx < 9; ++lx) {
+                    const float f = at(lx, ly, lz);
+                    tmp[(lz * 9 + ly) * 9 + lx] = f;
+                    any9 = any9 || f != 0.0f;
+                }
+        const bool leaf = nbr[1][1][1] != nullptr;
+        if (!any9 && !leaf) continue;
+        float lo = 3.0e38f, hi = -3.0e38f;
+        if (leaf) {   // iso_leaf_range: every value a march through the leaf can read, [8b - 1, 8b + 9]^3
+            for (int lz = -1; lz < 10; ++lz)
+                for (int ly = -1; ly < 10; ++ly)
+                    for (int lx = -1; lx < 10; ++lx) {
+                        const float f = at(lx, ly, lz);
+                        lo = f < lo ? f : lo; hi = f > hi ? f : hi;
+                    }
+            ++nleaf;
+            node1[(size_t(bz >> 4) * v.n1y + (by >> 4)) * v.n1x + (bx >> 4)] = 1;
+            if (bx < lmin[0]) lmin[0] = bx; if (bx > lmax[0]) lmax[0] = bx;
+            if (by < lmin[1]) lmin[1] = by; if (by > lmax[1]) lmax[1] = by;
+            if (bz < lmin[2]) lmin[2] = bz; if (bz > lmax[2]) lmax[2] = bz;
+        } else {
+            lo = hi = 0.0f;
+        }
+        index.push_back(b);
+        leafv.push_back(leaf ? 1 : 0);
+        rangev.push_back(lo); rangev.push_back(hi);
+        if (any9) {
+            slotv.push_back(nslots++);
+            bricks.insert(bricks.end(), tmp, tmp + ISO_BRICK_STRIDE);
+        } else {
+            slotv.push_back(-1);
+        }
+    }
+    if (nleaf == 0) return false;
+    v.nslots = nslots; v.nleaf = nleaf;
+    HIP_OK(hipMalloc(&v.slot, nb * sizeof(int32_t)));
+    HIP_OK(hipMalloc(&v.leaf, nb));
+    HIP_OK(hipMalloc(&v.leafRange, nb * 2 * sizeof(float)));
+    HIP_OK(hipMalloc(&v.node1, node1.size()));
+    HIP_OK(hipMalloc(&v.bricks, size_t(nslots > 0 ? nslots : 1) * ISO_BRICK_STRIDE * sizeof(float)));
+    HIP_OK(hipMemset(v.slot, 0xFF, nb * sizeof(int32_t)));              // -1: nothing stored
+    HIP_OK(hipMemset(v.leaf, 0, nb));
+    HIP_OK(hipMemset(v.leafRange, 0, nb * 2 * sizeof(float)));
+    HIP_OK(hipMemcpy(v.node1, node1.data(), node1.size(), hipMemcpyHostToDevice));
+    if (nslots > 0) HIP_OK(hipMemcpy(v.bricks, bricks.data(), bricks.size() * sizeof(float), hipMemcpyHostToDevice));
+    const int n = int(index.size());
+    long long* dIndex = nullptr; int32_t* dSlot = nullptr; uint8_t* dLeaf = nullptr; float* dRange = nullptr;
+    HIP_OK(hipMalloc(&dIndex, size_t(n) * sizeof(long long)));
+    HIP_OK(hipMalloc(&dSlot, size_t(n) * sizeof(int32_t)));
+    HIP_OK(hipMalloc(&dLeaf, size_t(n)));
+    HIP_OK(hipMalloc(&dRange, size_t(n) * 2 * sizeof(float)));
+    HIP_OK(hipMemcpy(dIndex, index.data(), size_t(n) * sizeof(long long), hipMemcpyHostToDevice));
+    HIP_OK(hipMemcpy(dSlot, slotv.data(), size_t(n) * sizeof(int32_t), hipMemcpyHostToDevice));
+    HIP_OK(hipMemcpy(dLeaf, leafv.data(), size_t(n), hipMemcpyHostToDevice));
+    HIP_OK(hipMemcpy(dRange, rangev.data(), size_t(n) * 2 * sizeof(float), hipMemcpyHostToDevice));
+    iso_launch_scatter_tables(n, dIndex, dSlot, dLeaf, dRange, v.slot, v.leaf, v.leafRange, nullptr);
+    HIP_OK(hipGetLastError());
+    HIP_OK(hipDeviceSynchronize());
+    (void)hipFree(dIndex); (void)hipFree(dSlot); (void)hipFree(dLeaf); (void)hipFree(dRange);
+    return finalizeVolume(v, bbox, maxv, lmin, lmax, nullptr);
 }
 
 // ---- semantics=gvdb: the CUDA renderer's camera / transform, as constants of one frame --------------------------
@@ -543,14 +703,27 @@ int loadGrid(const char* filename)
         return -1;
     }
     if (!g.initialised) return -2;
-    std::vector<float> dense;
-    int nx = 0, ny = 0, nz = 0;
-    std::string err;
-    if (!vbx_read_dense(name.c_str(), dense, nx, ny, nz, err)) {
-        std::printf("Unable to load VBX file: %s\n", err.c_str());
+    try {
+        VbxBricks vb;
+        std::string err;
+        if (!vbx_read_bricks(name.c_str(), vb, err)) {
+            std::printf("Unable to load VBX file: %s\n", err.c_str());
+            return -2;
+        }
+        if (vb.bd == 8) return uploadFromBricks(vb) ? 0 : -2;      // the reference's <5,5,5,4,3> trees: bricks as they are
+        // other brick sizes are re-bricked from a dense copy (refused beyond 2^31 voxels)
+        std::vector<float> dense;
+        int nx = 0, ny = 0, nz = 0;
+        vb = VbxBricks();
+        if (!vbx_read_dense(name.c_str(), dense, nx, ny, nz, err)) {
+            std::printf("Unable to load VBX file: %s\n", err.c_str());
+            return -2;
+        }
+        return isoLoadDenseHost(dense.data(), nx, ny, nz);
+    } catch (...) {      // nothing may unwind through the C boundary
+        std::printf("Unable to load VBX file: out of memory\n");
         return -2;
     }
-    return isoLoadDenseHost(dense.data(), nx, ny, nz);
 }
 
 int setParameter(const char* cmd_, const char* value)
@@ -692,6 +865,10 @@ int isoSetWaveCap(int waves)
 int isoGateResident(void* stream, int timeoutUs)
 {
     if (!g.initialised || !g.tileQueue || timeoutUs < 0) return -1;
+    // no variant-2 render was enqueued since the last gate: there is nothing to wait for (a gate that spun until its
+    // timeout every frame would stall the caller's stream, e.g. after a failed prefetch)
+    if (g.residentTarget == g.gatedTarget) return 0;
+    g.gatedTarget = g.residentTarget;
     iso_launch_gate(g.tileQueue + 8, g.residentTarget, timeoutUs, stream);
     return hipGetLastError() == hipSuccess ? 0 : -1;
 }
@@ -719,24 +896,40 @@ int isoProfileGet(int i, float* ms)
     return hipEventElapsedTime(ms, g.events[i].first, g.events[i].second) == hipSuccess ? 0 : -2;
 }
 
+int isoSetLastCamera(const double origin[3], const double lookAt[3])
+{
+    if (!origin || !lookAt) return -1;
+    for (int k = 0; k < 3; ++k) { g.lastOrigin[k] = origin[k]; g.lastLookAt[k] = lookAt[k]; }
+    return 0;
+}
+
 int isoVbxInfo(const char* path, int dims[3])
 {
-    std::vector<float> dense;
-    std::string err;
-    int nx, ny, nz;
-    if (!path || !vbx_read_dense(path, dense, nx, ny, nz, err)) return -2;
-    dims[0] = nx; dims[1] = ny; dims[2] = nz;
-    return 0;
+    if (!path || !dims) return -2;
+    try {
+        VbxBricks vb;
+        std::string err;
+        if (!vbx_read_bricks(path, vb, err)) return -2;
+        for (int k = 0; k < 3; ++k) dims[k] = vb.dims[k];
+        return 0;
+    } catch (...) {
+        return -2;
+    }
 }
 
 int isoVbxReadDense(const char* path, float* hostOut)
 {
-    std::vector<float> dense;
-    std::string err;
-    int nx, ny, nz;
-    if (!path || !hostOut || !vbx_read_dense(path, dense, nx, ny, nz, err)) return -2;
-    std::memcpy(hostOut, dense.data(), dense.size() * sizeof(float));
-    return 0;
+    if (!path || !hostOut) return -2;
+    try {
+        std::vector<float> dense;
+        std::string err;
+        int nx, ny, nz;
+        if (!vbx_read_dense(path, dense, nx, ny, nz, err)) return -2;
+        std::memcpy(hostOut, dense.data(), dense.size() * sizeof(float));
+        return 0;
+    } catch (...) {
+        return -2;
+    }
 }
 
 void isoShutdown(void)

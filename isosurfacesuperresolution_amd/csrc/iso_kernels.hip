@@ -762,7 +762,28 @@ __global__ __launch_bounds__(64) void iso_leaf_range(const float* __restrict__ d
     if (threadIdx.x == 0) { range[2 * (size_t)b] = lo; range[2 * (size_t)b + 1] = hi; }
 }
 
+// sparse loads (.vbx brick lists): the tables of the few existing positions are scattered into memset tables
+__global__ __launch_bounds__(256) void iso_scatter_tables(int n, const long long* __restrict__ index, const int32_t* __restrict__ slotv,
+                                                         const uint8_t* __restrict__ leafv, const float* __restrict__ rangev,
+                                                         int32_t* __restrict__ slot, uint8_t* __restrict__ leaf, float* __restrict__ range)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const long long b = index[i];
+    slot[b] = slotv[i];
+    leaf[b] = leafv[i];
+    range[2 * b] = rangev[2 * i];
+    range[2 * b + 1] = rangev[2 * i + 1];
+}
+
 }  // namespace
+
+void iso_launch_scatter_tables(int n, const long long* index, const int32_t* slotv, const uint8_t* leafv, const float* rangev,
+                               int32_t* slot, uint8_t* leaf, float* range, void* stream)
+{
+    if (n > 0)
+        hipLaunchKernelGGL(iso_scatter_tables, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, n, index, slotv, leafv, rangev, slot, leaf, range);
+}
 
 void iso_launch_leaf_range(const float* dense, int nx, int ny, int nz, int nbx, int nby, int nbz, float* range, void* stream)
 {

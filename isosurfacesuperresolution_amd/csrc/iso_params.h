@@ -71,5 +71,7 @@ void iso_launch_gate(const unsigned* resident, unsigned target, int timeoutUs, v
 void iso_launch_brick_flags(const float* dense, int nx, int ny, int nz, int nbx, int nby, int nbz,
                             uint8_t* flag9, uint8_t* leaf, int* bbox6, unsigned int* maxbits, void* stream);
 void iso_launch_leaf_range(const float* dense, int nx, int ny, int nz, int nbx, int nby, int nbz, float* range, void* stream);
+void iso_launch_scatter_tables(int n, const long long* index, const int32_t* slotv, const uint8_t* leafv, const float* rangev,
+                               int32_t* slot, uint8_t* leaf, float* range, void* stream);
 void iso_launch_brick_fill(const float* dense, int nx, int ny, int nz, int nbx, int nby, int nbz,
                            const int32_t* slot, float* bricks, void* stream);

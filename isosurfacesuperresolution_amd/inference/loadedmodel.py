@@ -9,13 +9,53 @@ for the unshaded networks of the hot path.  Differences, all additive or forced 
 * ``LoadedModel.from_model`` wraps an in-memory network (no checkpoint files ship with the
   reference, README.md:68);
 * reference checkpoints pickle whole ``models.enhancenet.EnhanceNet`` objects
-  (``mainVideoUnshaded.py:801``); they are unpickled with ``weights_only=False`` under a module
-  alias so that ``models`` resolves to this package's ``models``.
+  (``mainVideoUnshaded.py:801``), so they cannot be read with ``weights_only=True``.  They are read through a
+  RESTRICTED unpickler instead of a plain ``torch.load(weights_only=False)``: ``models.*`` / ``utils.*`` resolve to
+  this package's modules (whatever top-level ``models`` the host process may have), tensors / storages / containers /
+  optimizer and scheduler state resolve to torch and the standard library, and anything else -- the arbitrary
+  callables a malicious pickle would name -- is refused.  A checkpoint is still code-adjacent data: load files you trust.
 """
+import importlib
 import os.path
-import sys
+import pickle
 
 import torch
+
+
+class _CheckpointPickle:
+    """``pickle_module`` for ``torch.load``: an allow-list ``find_class``."""
+    __name__ = "isosurfacesuperresolution_amd.checkpoint_pickle"
+    _ALIASES = {"models": "isosurfacesuperresolution_amd.models", "utils": "isosurfacesuperresolution_amd.utils",
+                "losses": "isosurfacesuperresolution_amd.losses"}
+    _ALLOWED_ROOTS = ("torch", "collections", "argparse", "numpy", "isosurfacesuperresolution_amd")
+    _ALLOWED_BUILTINS = {"set", "frozenset", "dict", "list", "tuple", "slice", "range", "complex", "int", "float", "bool",
+                         "str", "bytes", "bytearray", "object", "getattr"}
+
+    class Unpickler(pickle.Unpickler):
+        def find_class(self, module, name):
+            cls = _CheckpointPickle
+            root = module.split(".")[0]
+            if root in cls._ALIASES:
+                module = cls._ALIASES[root] + module[len(root):]
+            elif root in ("builtins", "__builtin__"):
+                if name not in cls._ALLOWED_BUILTINS or name == "getattr":
+                    raise pickle.UnpicklingError("checkpoint refers to builtins.%s: refused" % name)
+                return super().find_class(module, name)
+            elif root not in cls._ALLOWED_ROOTS:
+                raise pickle.UnpicklingError("checkpoint refers to %s.%s: only torch / numpy / this package's "
+                                             "models, utils and losses are loaded" % (module, name))
+            if root == "torch" and (name in ("load", "save") or module.startswith(("torch.utils.cpp_extension", "torch.hub",
+                                                                                      "torch.distributed", "torch.multiprocessing"))):
+                raise pickle.UnpicklingError("checkpoint refers to %s.%s: refused" % (module, name))
+            mod = importlib.import_module(module)
+            obj = mod
+            for part in name.split("."):
+                obj = getattr(obj, part)
+            return obj
+
+    load = staticmethod(pickle.load)
+    dump = staticmethod(pickle.dump)
+    Pickler = pickle.Pickler
 
 from ..models import VideoTools
 from ..utils import initialImage
@@ -27,18 +67,7 @@ class LoadedModel:
         self.name = os.path.splitext(os.path.basename(name))[0]
         self.device = device
         self.upscale_factor = upscale_factor
-        from .. import models as _models, utils as _utils
-        aliases = {'models': _models, 'models.enhancenet': _models.enhancenet,
-                   'models.videotools': _models.videotools, 'utils': _utils}
-        saved = {k: sys.modules.get(k) for k in aliases}
-        try:
-            for k, v in aliases.items():
-                sys.modules.setdefault(k, v)
-            checkpoint = torch.load(name, map_location=device, weights_only=False)
-        finally:
-            for k, v in saved.items():
-                if v is None:
-                    sys.modules.pop(k, None)
+        checkpoint = torch.load(name, map_location=device, weights_only=False, pickle_module=_CheckpointPickle)
         parameters = checkpoint.get('parameters', dict())
         if not isinstance(parameters, dict):
             parameters = vars(parameters)

@@ -1,14 +1,18 @@
 """ctypes binding of libGPURendererDirect.so.
 
 Mirrors ``SuperresolutionNetwork/inference/renderer.py:78-117`` (class ``DirectRenderer``:
-``load``, ``send_command``, ``render_direct``, ``get_time``, ``close``) and ``Material``
-(``:9-15``).  Additive: ``load_dense`` (dense numpy / device tensor volumes), ``render_async``,
+``load``, ``send_command``, ``render_direct``, ``get_time``, ``close``), ``Material``
+(``:9-15``) and the pipe flavour ``Renderer`` (``:16-76``: ``send_command``, ``render``,
+``read_image``, ``get_time``, ``close``) -- the latter over the same in-process library instead of
+a child process.  Additive: ``load_dense`` (dense numpy / device tensor volumes), ``render_async``,
 return codes are surfaced instead of being dropped.
 """
+import collections
 import ctypes
 import os
 
 from .. import _native
+from .camera import Camera
 
 
 class Material:
@@ -68,6 +72,8 @@ class DirectRenderer:
         lib.isoProfileGet.restype = ctypes.c_int
         lib.isoShutdown.argtypes = []
         lib.isoShutdown.restype = None
+        lib.isoSetLastCamera.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
+        lib.isoSetLastCamera.restype = ctypes.c_int
         if lib.initGVDB() != 0:
             raise RuntimeError("initGVDB failed: no usable HIP device")
 
@@ -143,6 +149,11 @@ class DirectRenderer:
             out.append(ms.value)
         return out
 
+    def set_last_camera(self, origin, lookat=(0.0, 0.0, 0.0)):
+        """Additive: see isoSetLastCamera (the flow reference after a frame rendered ahead was discarded)."""
+        d3 = lambda v: (ctypes.c_double * 3)(*[float(a) for a in v])
+        return self.lib.isoSetLastCamera(d3(origin), d3(lookat))
+
     def gate_resident(self, stream, timeout_us=100):
         """Additive: see isoGateResident.  ``stream``: a torch.cuda.Stream."""
         return self.lib.isoGateResident(ctypes.c_void_p(stream.cuda_stream), int(timeout_us))
@@ -160,3 +171,100 @@ class DirectRenderer:
 
     def close(self):
         pass  # No-op, as in the reference
+
+
+class Renderer:
+    """The reference's pipe-flavour renderer (``inference/renderer.py:16-76``; protocol of
+    ``CPURenderer/CPURenderer.cpp:688-787``) with the same methods and the same command strings, served by the
+    in-process HIP library instead of a ``CPURenderer.exe ... PIPE`` child: ``send_command("cmd=value\\n")`` or
+    ``send_command("cmd", value)``, ``render()`` / ``send_command("render\\n")``, then
+    ``read_image(resX, resY, channels=12) -> np.float32[12, resY, resX]`` (planar, the pipe's layout) and
+    ``get_time()`` (the trailing float of a pipe frame).  This is what ``mainPSNR2_AllAngles.py:184-276`` drives.
+
+    ``renderer``: path of libGPURendererDirect.so (anything that is not an existing file selects the in-tree
+    build -- the reference passes the path of an EXE here).  ``inputfile``: a ``.vbx`` path, or (additive) a dense
+    numpy volume ``[z][y][x]``.  ``backend`` (additive): an object with ``DirectRenderer``'s methods
+    (``send_command`` / ``render_direct`` / ``load`` / ``load_dense``); tests drive the protocol on CPU tensors with it.
+    As in pipe mode, ``resolution`` also resets the viewport to the whole image, unknown commands end the session
+    (here: ``RuntimeError``), and every frame is synchronous."""
+
+    def __init__(self, renderer, inputfile, material, camera, backend=None, device="cuda"):
+        assert isinstance(renderer, str)
+        assert isinstance(material, Material)
+        assert isinstance(camera, Camera)
+        if backend is None:
+            backend = DirectRenderer(renderer if os.path.isfile(renderer) and renderer.endswith(".so") else None)
+        self.backend = backend
+        self.device = device
+        if isinstance(inputfile, str):
+            rc = backend.load(inputfile)
+            if rc != 0:
+                raise RuntimeError("Renderer: cannot load %r (rc=%d)" % (inputfile, rc))
+        else:
+            backend.load_dense(inputfile)
+        self.resX, self.resY = int(camera.resX), int(camera.resY)
+        f3 = lambda v: "%5.3f,%5.3f,%5.3f" % (v[0], v[1], v[2])
+        # the EXE's command line (renderer.py:26-43)
+        for cmd, value in (("resolution", "%d,%d" % (self.resX, self.resY)), ("cameraOrigin", f3(camera.getOrigin())),
+                           ("cameraLookAt", f3(camera.getLookAt())), ("cameraUp", f3(camera.getUp())),
+                           ("isovalue", str(material.isovalue)), ("unshaded", "0"), ("diffuse", f3(material.diffuseColor)),
+                           ("specular", f3(material.specularColor)), ("exponent", str(material.specularExponent)),
+                           ("light", material.light), ("aoradius", "0.01")):
+            self._apply(cmd, value)
+        self._frames = collections.deque()
+        self._buffer = None
+        self.time = 0
+        self.closed = False
+
+    def _apply(self, cmd, value):
+        if self.backend.send_command(cmd, value) != 0:
+            raise RuntimeError("Unknown command: %r (the reference's pipe renderer exits here)" % cmd)
+        if cmd == "resolution":
+            self.resX, self.resY = (int(v) for v in value.split(","))
+            self.backend.send_command("viewport", "0,0,%d,%d" % (self.resX, self.resY))
+
+    def send_command(self, cmd, value=None):
+        if self.closed:
+            raise RuntimeError("Renderer is closed")
+        if value is not None:
+            cmd = cmd + "=" + str(value) + "\n"
+        for line in cmd.split("\n"):
+            line = line.strip()
+            if not line:
+                continue
+            if line == "exit":
+                self.closed = True
+            elif line == "render":
+                self._render()
+            else:
+                name, sep, val = line.partition("=")
+                if not sep:
+                    raise RuntimeError("Unknown command format: %r" % line)
+                self._apply(name, val)
+
+    def _render(self):
+        import torch
+        if self._buffer is None or tuple(self._buffer.shape[:2]) != (self.resY, self.resX):
+            self._buffer = torch.empty((self.resY, self.resX, 12), dtype=torch.float32, device=self.device)
+        seconds = self.backend.render_direct(self._buffer)
+        planar = self._buffer.permute(2, 0, 1).contiguous().cpu().numpy()
+        self._frames.append((planar, float(seconds)))
+
+    def render(self):
+        self.send_command("render\n")
+
+    def read_image(self, resX, resY, channels=12):
+        if not self._frames:
+            raise RuntimeError("read_image: no rendered frame is waiting (the pipe would block forever)")
+        image, seconds = self._frames.popleft()
+        if image.shape != (channels, resY, resX):
+            raise RuntimeError("read_image(%d, %d, %d): the frame waiting in the pipe is %s" % (resX, resY, channels, image.shape))
+        self.time = seconds
+        return image
+
+    def close(self):
+        self.closed = True
+
+    def get_time(self):
+        """Returns the time of the last render pass in seconds"""
+        return self.time

@@ -1,2 +1,3 @@
 from .lossbuilder import LossBuilder
 from .lossnet_unshaded import LossNetUnshaded
+from .lossnet import LossNet

@@ -12,6 +12,7 @@
 * CPU tensors: the reference's own CPU path, i.e. plain PyTorch ops (BASELINE config #1).
 """
 import ctypes
+import warnings
 import weakref
 
 import torch
@@ -21,6 +22,14 @@ from . import _native
 
 ACT_CODES = {'none': 0, 'relu': 1, 'leaky': 2, 'gate': 3}     # 'gate': internal (data gradient through a ReLU)
 _lib = None
+_warned = set()
+
+
+def _warn_once(key, message):
+    """A device tensor took a PyTorch (MIOpen / ATen) route instead of a kernel of this package: say so, once."""
+    if key not in _warned:
+        _warned.add(key)
+        warnings.warn(message, RuntimeWarning, stacklevel=3)
 
 
 def _sr():
@@ -220,7 +229,9 @@ def _plane_strides(t):
     return t, h * w, c * h * w
 
 
-def _launch_forward(x, wprep, bias, residual, cin, cout, act, slope, upsample2x):
+def _launch_forward(x, wprep, bias, residual, cin, cout, act, slope, upsample2x, packed=False):
+    """``packed``: the result is an ordinary contiguous tensor (the autograd paths hand raw pointers of saved outputs
+    to kernels that index them flat); otherwise large channel planes are padded (``empty_planes``)."""
     lib = _sr()
     n, _, hin, win = x.shape
     h, w = (hin * 2, win * 2) if upsample2x else (hin, win)
@@ -228,7 +239,7 @@ def _launch_forward(x, wprep, bias, residual, cin, cout, act, slope, upsample2x)
     rp = ri = 0
     if residual is not None:
         residual, rp, ri = _plane_strides(residual)
-    y = empty_planes(n, cout, h, w, x.device)
+    y = torch.empty((n, cout, h, w), dtype=torch.float32, device=x.device) if packed else empty_planes(n, cout, h, w, x.device)
     rc = lib.isrConv3x3ForwardStrided(_ptr(x), _ptr(wprep), _ptr(bias), _ptr(residual), _ptr(y),
                                       n, cin, h, w, cout, ACT_CODES[act], float(slope), 1 if upsample2x else 0,
                                       xp, xi, y.stride(1), cout * y.stride(1), rp, ri, _stream())
@@ -275,8 +286,9 @@ def _prepare_f16(weight):
     return _prepare_lp(weight)
 
 
-def _launch_lp(x, wq, bias, residual, cout, act, slope, upsample2x, bf16):
-    """One launch of isrConv3x3ForwardF16 / Bf16 (x: fp32 NCHW, channel planes may be padded)."""
+def _launch_lp(x, wq, bias, residual, cout, act, slope, upsample2x, bf16, packed=False):
+    """One launch of isrConv3x3ForwardF16 / Bf16 (x: fp32 NCHW, channel planes may be padded; ``packed`` as in
+    ``_launch_forward``)."""
     lib = _sr()
     x, xp, xi = _plane_strides(x)
     fuse = False
@@ -289,7 +301,7 @@ def _launch_lp(x, wq, bias, residual, cout, act, slope, upsample2x, bf16):
     rp = ri = 0
     if residual is not None:
         residual, rp, ri = _plane_strides(residual)
-    y = empty_planes(n, cout, h, w, x.device)
+    y = torch.empty((n, cout, h, w), dtype=torch.float32, device=x.device) if packed else empty_planes(n, cout, h, w, x.device)
     fn = lib.isrConv3x3ForwardBf16 if bf16 else lib.isrConv3x3ForwardF16
     rc = fn(_ptr(x), _ptr(wq), _ptr(bias), _ptr(residual), _ptr(y), n, cin, h, w, cout, ACT_CODES[act], float(slope),
             1 if fuse else 0, xp, xi, y.stride(1), cout * y.stride(1), rp, ri, _stream())
@@ -384,14 +396,17 @@ TRAIN_BF16 = False
 
 
 def _train_conv(x, weight, transpose_flip, bias, residual, act):
-    """Forward (or, with transpose_flip, data-gradient) convolution of the training graph."""
+    """Forward (or, with transpose_flip, data-gradient) convolution of the training graph.  Results are PACKED
+    tensors: they are saved for backward and their raw pointers go to ``isrActBackward`` and the weight-gradient
+    kernels, which index [N, C, H, W] flat (inference outputs may have padded channel planes, these never do)."""
     cout, cin = (weight.shape[1], weight.shape[0]) if transpose_flip else (weight.shape[0], weight.shape[1])
     # the low-precision kernel is a streaming kernel with 8x32-pixel x 64-channel tiles: it pays from a few hundred
     # tiles on (the 128x128 layers of a crop batch); below that the fp32 kernels' finer decompositions are faster
     tiles = x.shape[0] * ((x.shape[2] + 7) // 8) * ((x.shape[3] + 31) // 32)
     if TRAIN_BF16 and cout > 8 and cin > 8 and tiles >= 256:
-        return _launch_lp(x, _prepare_lp(weight, transpose_flip, True), bias, residual, cout, act, 0.0, False, True)
-    return _launch_forward(x, prepare_weights(weight, transpose_flip=transpose_flip), bias, residual, cin, cout, act, 0.0, False)
+        return _launch_lp(x, _prepare_lp(weight, transpose_flip, True), bias, residual, cout, act, 0.0, False, True, packed=True)
+    return _launch_forward(x, prepare_weights(weight, transpose_flip=transpose_flip), bias, residual, cin, cout, act, 0.0, False,
+                           packed=True)
 
 
 _workspace = {}
@@ -464,9 +479,20 @@ class deferred_weight_gradients:
         return False
 
 
+def _has_grad_hooks(p):
+    return p is not None and bool(getattr(p, '_backward_hooks', None) or getattr(p, '_post_accumulate_grad_hooks', None))
+
+
 def _weight_grad_or_defer(weight, bias, has_bias, x, gz):
-    """Inside deferred_weight_gradients(): record the pair and return (None, None); else compute (dw, db) now."""
-    if _deferred is not None and weight.is_leaf and (bias is None or bias.is_leaf):
+    """Inside deferred_weight_gradients(): record the pair and return (None, None); else compute (dw, db) now.
+
+    Deferred gradients are written to ``param.grad`` when the context exits, AFTER ``loss.backward()`` and without
+    passing through autograd's accumulation: tensor hooks and post-accumulate-grad hooks (DDP-style reducers,
+    per-parameter clipping / logging) would never fire and ``torch.autograd.grad(..., weights)`` would see None.  A
+    parameter that carries such hooks is therefore NOT deferred (its gradient is computed here, per frame, and flows
+    through autograd as usual); ``torch.autograd.grad`` on convolution weights must be called outside the context."""
+    if _deferred is not None and weight.is_leaf and (bias is None or bias.is_leaf) \
+            and not _has_grad_hooks(weight) and not _has_grad_hooks(bias):
         entry = _deferred.setdefault((id(weight), tuple(x.shape)), (weight, bias, [], []))
         entry[2].append(x)
         entry[3].append(gz)
@@ -526,7 +552,7 @@ class _Conv3x3Function(torch.autograd.Function):
         if cout <= 8 and cin * x.shape[2] * x.shape[3] * 4 < 2 ** 31:
             y = _launch_small(x, weight, b, res, act, slope)      # the 64 -> 6 output layer: 4x4x1 MFMA blocks
         elif act == 'leaky':
-            y = _launch_forward(x, prepare_weights(weight), b, res, cin, cout, act, slope, False)
+            y = _launch_forward(x, prepare_weights(weight), b, res, cin, cout, act, slope, False, packed=True)
         else:
             y = _train_conv(x, weight, False, b, res, act)
         ctx.act, ctx.slope = act, slope
@@ -592,6 +618,9 @@ def conv3x3(x, weight, bias=None, act='none', slope=0.01, residual=None, upsampl
             return conv3x3_split(x, weight, bias, act, slope, residual, upsample2x)
         if cout <= 8 and not upsample2x and cin * x.shape[2] * x.shape[3] * 4 < 2 ** 31:
             return _launch_small(x, weight, bias, residual.contiguous() if residual is not None else None, act, slope)
+        if cout <= 8 and not upsample2x:
+            _warn_once("small_cout_2g", "conv3x3: %d x %d x %d input exceeds the small-Cout kernel's 2 GiB addressing; the layer "
+                       "runs on the general fp32 MFMA kernel (output channels padded to 32)" % (cin, x.shape[2], x.shape[3]))
         return _launch_forward(x, prepare_weights(weight),
                                bias.contiguous() if bias is not None else None,
                                residual,
@@ -631,6 +660,9 @@ def bilinear_upsample2x(x):
     (gather, deterministic) backward on the GPU; PyTorch's launch takes ~340 us for a 64-channel 64^2 -> 128^2 batch
     of 16 that moves 84 MB."""
     if not x.is_cuda or x.dtype != torch.float32 or x.shape[3] % 2:
+        if x.is_cuda:
+            _warn_once("upsample2x", "bilinear_upsample2x: %s input of width %d goes through F.interpolate (the HIP kernel needs "
+                       "fp32 and an even width)" % (x.dtype, x.shape[3]))
         return F.interpolate(x, scale_factor=2, mode='bilinear', align_corners=False)
     return _Upsample2xFunction.apply(x)
 

@@ -54,6 +54,7 @@ class SuperResolutionPipeline:
         self._frame_start = torch.cuda.Event() if self._render_stream else None
         self._slot = 0
         self._prefetched = None           # (origin tuple, slot) of a render already in flight
+        self._displayed = None            # origin of the last frame handed to the network: the flow reference
         # a prefetched frame is rendered by the 128-register ray-marcher (kernel variant 2) with one wave per
         # SIMD, so that it sits beside the conv waves instead of displacing them (csrc/iso_kernels.hip)
         self.side_waves = 4 * torch.cuda.get_device_properties(device).multi_processor_count if self._render_stream else 0
@@ -67,6 +68,7 @@ class SuperResolutionPipeline:
 
     def set_static(self, fov, isovalue, lookat=(0.0, 0.0, 0.0), up=(0.0, 1.0, 0.0)):
         r = self.renderer
+        self._lookat = tuple(float(v) for v in fmt3(lookat).split(","))
         r.send_command("cameraLookAt", fmt3(lookat))
         r.send_command("cameraUp", fmt3(up))
         r.send_command("cameraFoV", "%.3f" % fov)
@@ -78,7 +80,16 @@ class SuperResolutionPipeline:
 
     def reset(self):
         self.previous = None
-        self._prefetched = None
+        self._drop_prefetched()
+
+    def _drop_prefetched(self):
+        """Forget a frame that was rendered ahead but is not going to be displayed.  The renderer's "last camera" is
+        already that frame's camera; the flow of whatever is rendered next must be measured against the last frame
+        that was DISPLAYED, so the reference is put back (``isoSetLastCamera``)."""
+        if self._prefetched is not None:
+            self._prefetched = None
+            if self._displayed is not None:
+                self.renderer.set_last_camera(self._displayed, self._lookat)
 
     def prefetch(self, origin):
         """Start rendering the G-buffer of ``origin`` on the side stream (used by ``frame(..., next_origin=)``)."""
@@ -106,15 +117,19 @@ class SuperResolutionPipeline:
             cur.wait_event(self._ready[slot])
             self._prefetched = None
         else:
+            self._drop_prefetched()       # ``next_origin`` of the previous call was not honoured: that frame is discarded
             slot = self._slot
             self._flow_ready[slot] = False
             self.renderer.send_command("cameraOrigin", fmt3(origin))
             self.renderer.render_async(self._gbuffers[slot], cur)
         self._slot = slot
         self.gbuffer = self._gbuffers[slot]
+        self._displayed = tuple(float(v) for v in fmt3(origin).split(","))   # what the renderer parsed
         return self.gbuffer
 
     def render_low(self, origin):
+        self._drop_prefetched()
+        self._displayed = tuple(float(v) for v in fmt3(origin).split(","))
         self.renderer.send_command("cameraOrigin", fmt3(origin))
         self.renderer.render_async(self.gbuffer, torch.cuda.current_stream())
         return self.gbuffer.permute(2, 0, 1).unsqueeze(0)

@@ -31,7 +31,12 @@ from .utils import ScreenSpaceShading, initialImage
 
 def backward(loss):
     """``loss.backward()`` with the weight gradients of the HIP convolutions deferred to ONE pass per layer over all
-    frames of the clip (``ops.deferred_weight_gradients``) instead of one pass per layer and frame."""
+    frames of the clip (``ops.deferred_weight_gradients``) instead of one pass per layer and frame.
+
+    Limitation: a deferred gradient is added to ``param.grad`` when the context exits and does not pass through
+    autograd's accumulation, so hooks registered on a convolution weight would not see it -- parameters that carry
+    tensor hooks or post-accumulate-grad hooks are detected and keep the ordinary per-frame path
+    (``ops._weight_grad_or_defer``).  ``DataParallelTrainer`` reduces ``param.grad`` after this call and is unaffected."""
     with ops.deferred_weight_gradients():
         loss.backward()
 

@@ -27,18 +27,37 @@ def write_vbx(path, dense, apron=1, voxelsize=(1.0, 1.0, 1.0)):
     dense = np.ascontiguousarray(dense, dtype=np.float32)
     nz, ny, nx = dense.shape
     bz, by, bx = (nz + 7) // 8, (ny + 7) // 8, (nx + 7) // 8
-    padded = np.zeros((bz * 8 + 2 * apron, by * 8 + 2 * apron, bx * 8 + 2 * apron), np.float32)
-    padded[apron:apron + nz, apron:apron + ny, apron:apron + nx] = dense
+    padded = np.zeros((bz * 8, by * 8, bx * 8), np.float32)
+    padded[:nz, :ny, :nx] = dense
     blocks = dense_blocks_nonzero(dense, bz, by, bx)
-    bricks = [(z, y, x) for z in range(bz) for y in range(by) for x in range(bx) if blocks[z, y, x]]
+    bricks = {(x * 8, y * 8, z * 8): padded[z * 8:z * 8 + 8, y * 8:y * 8 + 8, x * 8:x * 8 + 8]
+              for z in range(bz) for y in range(by) for x in range(bx) if blocks[z, y, x]}
+    return write_vbx_bricks(path, bricks, apron, voxelsize)
+
+
+def write_vbx_bricks(path, bricks, apron=1, voxelsize=(1.0, 1.0, 1.0)):
+    """bricks: {(x, y, z) corner in voxels, multiples of 8, >= 0: float32 [8][8][8] (z, y, x)} -- a genuinely sparse
+    volume (bricks may be thousands of voxels apart; nothing dense is built).  Returns the number of bricks."""
     if not bricks:
         raise ValueError("empty volume")
-    nb = len(bricks)
+    keys = sorted(bricks, key=lambda p: (p[2], p[1], p[0]))                # z-major, as a scan of a dense volume
+    nb = len(keys)
     bd = 8 + 2 * apron
     cx = int(np.ceil(nb ** (1.0 / 3.0)))
     cy = cx
     cz = (nb + cx * cy - 1) // (cx * cy)
     atlas = np.zeros((cz * bd, cy * bd, cx * bd), np.float32)
+
+    def apron_block(pos):
+        """the brick with its apron layers, gathered from the (up to 26) neighbouring bricks"""
+        blk = np.zeros((8 * 3, 8 * 3, 8 * 3), np.float32)
+        for dz in (-1, 0, 1):
+            for dy in (-1, 0, 1):
+                for dx in (-1, 0, 1):
+                    q = bricks.get((pos[0] + 8 * dx, pos[1] + 8 * dy, pos[2] + 8 * dz))
+                    if q is not None:
+                        blk[8 * (dz + 1):8 * (dz + 2), 8 * (dy + 1):8 * (dy + 2), 8 * (dx + 1):8 * (dx + 2)] = q
+        return blk[8 - apron:16 + apron, 8 - apron:16 + apron, 8 - apron:16 + apron]
 
     ranges = [8]
     for l in range(1, 5):
@@ -46,11 +65,9 @@ def write_vbx(path, dense, apron=1, voxelsize=(1.0, 1.0, 1.0)):
     # nodes per level: dict pos(tuple x,y,z in voxels) -> index
     level_nodes = [dict() for _ in range(5)]
     node_records = [[] for _ in range(5)]      # (pos, value, parent_pos)
-    for k, (z, y, x) in enumerate(bricks):
+    for k, pos in enumerate(keys):
         ax, ay, az = (k % cx) * bd + apron, ((k // cx) % cy) * bd + apron, (k // (cx * cy)) * bd + apron
-        atlas[az - apron:az + 8 + apron, ay - apron:ay + 8 + apron, ax - apron:ax + 8 + apron] = \
-            padded[z * 8:z * 8 + bd, y * 8:y * 8 + bd, x * 8:x * 8 + bd]
-        pos = (x * 8, y * 8, z * 8)
+        atlas[az - apron:az + 8 + apron, ay - apron:ay + 8 + apron, ax - apron:ax + 8 + apron] = apron_block(pos)
         level_nodes[0][pos] = k
         node_records[0].append((pos, (ax, ay, az)))
     for l in range(1, 5):

@@ -375,3 +375,146 @@ def test_dataset_video_contract(tmp_path):
     assert np.array_equal(l2, low.numpy()[:, :, ::-1]) and np.array_equal(f2[:, 0], -flow.numpy()[:, 0, ::-1])
     batch = next(iter(torch.utils.data.DataLoader(train_set, batch_size=4)))
     assert batch[0].shape == (4, 4, 5, 32, 32)
+
+
+def test_vbx_sparse_and_malformed_files(libs, tmp_path):
+    """A genuinely sparse .vbx (two bricks 4000 voxels apart in every axis) is read as a brick LIST: a few hundred KB,
+    not the 4008^3 box it spans (a dense copy of that box is refused, not attempted); files whose pool / atlas sizes
+    exceed the file, or that are cut short, give -2 -- no exception crosses the C boundary."""
+    import psutil
+    rend, _ = libs
+    b = np.full((8, 8, 8), 0.7, np.float32)
+    path = str(tmp_path / "far.vbx")
+    assert vbx.write_vbx_bricks(path, {(0, 0, 0): b, (4000, 4000, 4000): b}) == 2
+    dims = (ctypes.c_int * 3)()
+    rss = psutil.Process().memory_info().rss
+    assert rend.isoVbxInfo(path.encode(), dims) == 0 and list(dims) == [4008, 4008, 4008]
+    assert psutil.Process().memory_info().rss - rss < 64 << 20
+    out = np.zeros(8, np.float32)
+    assert rend.isoVbxReadDense(path.encode(), out.ctypes.data_as(ctypes.c_void_p)) == -2
+    good = str(tmp_path / "good.vbx")
+    vbx.write_vbx(good, V.ejecta(32))
+    raw = bytearray(open(good, "rb").read())
+    assert rend.isoVbxInfo(good.encode(), dims) == 0
+    # header layout (vbx.py): 2 + 48 + 4 + 1 + 8 bytes, then the grid header: name 256, 3 bytes, voxelsize 12, then leafcnt ...
+    topo = 2 + 48 + 4 + 1 + 8 + 256 + 3 + 12 + 4 + 12 + 4 + 4 + 8 + 1 + 4 + 1 + 12 + 12 + 4 + 8   # first level record
+    for field, value in ((5, 0x7fffffff), (6, 0x7fffffff)):               # cnt0 / width0 of level 0
+        bad = bytearray(raw)
+        bad[topo + 4 * field: topo + 4 * field + 4] = int(value).to_bytes(4, "little")
+        (tmp_path / "bad.vbx").write_bytes(bytes(bad))
+        assert rend.isoVbxInfo(str(tmp_path / "bad.vbx").encode(), dims) == -2
+    for cut in (len(raw) // 2, len(raw) - 4, topo + 8):
+        (tmp_path / "cut.vbx").write_bytes(bytes(raw[:cut]))
+        assert rend.isoVbxInfo(str(tmp_path / "cut.vbx").encode(), dims) == -2
+
+
+class _OracleBackend:
+    """A CPU stand-in for DirectRenderer behind inference.Renderer (tests only): same command strings, frames by the
+    oracle into a caller-owned [H, W, 12] CPU tensor."""
+
+    def __init__(self, oracle):
+        self.o = oracle
+        self.args = {"cameraOrigin": [0, 0, -1], "cameraLookAt": [0, 0, 0], "cameraUp": [0, 1, 0], "cameraFoV": [45.0],
+                     "resolution": [512, 512], "isovalue": [0.0], "viewport": [0, 0, 512, 512], "aosamples": [32], "aoradius": [0.01]}
+        self.material = {}
+        self.last = None
+        self.log = []
+
+    def load_dense(self, vol):
+        self.vol = self.o.OracleVolume(vol)
+
+    def send_command(self, cmd, value):
+        self.log.append((cmd, value))
+        cmd = {"fov": "cameraFoV"}.get(cmd, cmd)
+        if cmd in self.args:
+            self.args[cmd] = [float(v) for v in value.split(",")]
+        elif cmd in ("diffuse", "specular", "ambient"):
+            self.material[cmd] = [float(v) for v in value.split(",")]
+        elif cmd == "exponent":
+            self.material["specular_exponent"] = int(value)
+        elif cmd not in ("unshaded", "light"):
+            return -1
+        return 0
+
+    def render_direct(self, tensor):
+        a = self.args
+        w, h = int(a["resolution"][0]), int(a["resolution"][1])
+        p = self.o.make_params(w, h, origin=a["cameraOrigin"], lookat=a["cameraLookAt"], up=a["cameraUp"], fov=a["cameraFoV"][0],
+                               isovalue=a["isovalue"][0], last_origin=self.last, viewport=[int(v) for v in a["viewport"]],
+                               ao_samples=int(a["aosamples"][0]), ao_radius=a["aoradius"][0], **self.material)
+        img, _ = self.o.render(self.vol, p, threads=2)
+        tensor.copy_(torch.from_numpy(img))
+        self.last = list(a["cameraOrigin"])
+        return 0.125
+
+
+def test_pipe_renderer_call_sequence(oracle):
+    """``inference.Renderer`` (the reference's pipe flavour, renderer.py:16-76) driven exactly the way
+    ``mainPSNR2_AllAngles.py:184-276`` drives it: construct with (exe, file, Material, Camera), ``aoradius=...\\\\n``, per
+    sample the camera commands + ``aosamples=0\\\\n``, ``resolution=W,H\\\\n`` + ``render\\\\n`` + ``read_image(W, H)`` for
+    the ground truth, then the same at W/4 x H/4 -- planar [12, H, W] frames, and the time of the last frame."""
+    vol = V.sphere64()
+    backend = _OracleBackend(oracle)
+    RES = (96, 64)
+    r = inference.Renderer("renderer.exe", vol, inference.Material(0.5), inference.Camera(RES[0], RES[1]), backend=backend, device="cpu")
+    r.send_command("aoradius=%5.3f\n" % 0.01)
+    images = []
+    for org in ((0.0, 0.6, -1.9), (1.2, 0.4, 1.5)):
+        r.send_command("aosamples=0\n")
+        r.send_command("cameraOrigin=%5.3f,%5.3f,%5.3f\n" % org)
+        r.send_command("cameraLookAt=%5.3f,%5.3f,%5.3f\n" % (0, 0, 0))
+        r.send_command("cameraUp=%5.3f,%5.3f,%5.3f\n" % (0, 1, 0))
+        r.send_command("resolution=%d,%d\n" % RES)
+        r.send_command("render\n")
+        gt = r.read_image(RES[0], RES[1])
+        assert gt.shape == (12, RES[1], RES[0]) and gt.dtype == np.float32 and r.get_time() == 0.125
+        r.send_command("resolution=%d,%d\n" % (RES[0] // 4, RES[1] // 4))
+        r.render()
+        low = r.read_image(RES[0] // 4, RES[1] // 4)
+        assert low.shape == (12, RES[1] // 4, RES[0] // 4)
+        images.append((gt, low))
+    gt, low = images[1]
+    assert gt[3].sum() > 300 and set(np.unique(gt[3])) <= {0.0, 1.0}
+    assert np.allclose(np.linalg.norm(gt[4:7], axis=0)[gt[3] == 1], 1.0, atol=1e-5)
+    assert (gt[10] == 1).all() and (gt[11] == 0).all()                      # AO off, no shadow
+    assert np.abs(gt[8:10][:, gt[3] == 1]).max() > 0                        # flow vs the previous camera
+    # the planar frame is the interleaved frame of the same commands
+    p = oracle.make_params(RES[0], RES[1], origin=(1.2, 0.4, 1.5), fov=45.0, isovalue=0.5, last_origin=(0.0, 0.6, -1.9),
+                           diffuse=[0.7, 0.2, 0.2], specular=[0.1, 0.1, 0.1], specular_exponent=16)
+    ref, _ = oracle.render(oracle.OracleVolume(vol), p, threads=2)
+    assert np.array_equal(gt, ref.transpose(2, 0, 1))
+    # resolution resets the viewport (pipe mode), the material went through the command protocol
+    assert ("viewport", "0,0,%d,%d" % (RES[0] // 4, RES[1] // 4)) in backend.log and ("exponent", "16") in backend.log
+    # protocol errors: reading without a pending frame, wrong size, unknown command, use after close
+    with pytest.raises(RuntimeError):
+        r.read_image(*RES)
+    r.render()
+    with pytest.raises(RuntimeError):
+        r.read_image(*RES)                                                  # the waiting frame is 24x16
+    with pytest.raises(RuntimeError):
+        r.send_command("bogus=1\n")
+    r.close()
+    with pytest.raises(RuntimeError):
+        r.render()
+
+
+def test_losses_surface_and_checkpoint_unpickler(tmp_path):
+    """``losses.LossNet`` exists and says why it is out of scope; checkpoints are read through an allow-list unpickler:
+    the reference-format fixture loads, a pickle that names an arbitrary callable is refused."""
+    import zipfile
+    assert {"LossBuilder", "LossNetUnshaded", "LossNet"} <= set(dir(losses))
+    with pytest.raises(NotImplementedError):
+        losses.LossNet("cpu", 5, 6, 128, 16, None)
+    here = os.path.join(os.path.dirname(__file__), "golden")
+    with zipfile.ZipFile(os.path.join(here, "ref_checkpoint.zip")) as z:
+        z.extractall(tmp_path)
+    lm = inference.LoadedModel(str(tmp_path / "model_epoch_12.pth"), "cpu", 4)
+    assert type(lm.model).__module__ == "isosurfacesuperresolution_amd.models.enhancenet"
+
+    class Evil:
+        def __reduce__(self):
+            return (os.system, ("true",))
+    torch.save({"model": Evil()}, str(tmp_path / "evil.pth"))
+    import pickle
+    with pytest.raises(pickle.UnpicklingError):
+        inference.LoadedModel(str(tmp_path / "evil.pth"), "cpu", 4)

@@ -278,3 +278,101 @@ def test_leaf_range_skipping_is_exact_over_isovalues(renderer, oracle):
                 gpu[..., 8:10] = ref[..., 8:10]
             _compare(gpu, ref)
             last = origin
+
+
+def test_sparse_vbx_loads_without_densifying(renderer, tmp_path):
+    """loadGrid() of a .vbx whose two blobs sit ~4000 voxels apart in every axis: the bricks are uploaded as a list
+    (host memory stays far below the 275 GB a dense 4008^3 box would take), and the volume renders -- both blobs."""
+    import psutil
+    from isosurfacesuperresolution_amd import vbx
+    z, y, x = np.meshgrid(*[np.arange(16, dtype=np.float32)] * 3, indexing="ij")
+    blob = np.clip((6.0 - np.sqrt((x - 7.5) ** 2 + (y - 7.5) ** 2 + (z - 7.5) ** 2)) / 3.0, 0.0, 1.0).astype(np.float32)
+    bricks = {}
+    for base in (0, 3992):
+        for bz in (0, 8):
+            for by in (0, 8):
+                for bx in (0, 8):
+                    bricks[(base + bx, base + by, base + bz)] = blob[bz:bz + 8, by:by + 8, bx:bx + 8]
+    path = str(tmp_path / "far.vbx")
+    vbx.write_vbx_bricks(path, bricks)
+    rss = psutil.Process().memory_info().rss
+    assert renderer.load(path) == 0
+    assert psutil.Process().memory_info().rss - rss < 1 << 30
+    info = renderer.volume_info()
+    assert info["dims"] == [4008, 4008, 4008] and info["leaves"] == 16 and info["bricks"] <= 16 * 8
+    renderer.set_kernel_variant(0)
+    # the box is normalised to the unit cube, so each 9-voxel blob is ~0.002 across: aim a camera at each from 0.05 away
+    for c in (-0.499, 0.499):
+        img = _render_gpu(renderer, 128, 128, (c, c, c - 0.05), 30.0, 0.5, lookat=(c, c, c))
+        hit = np.argwhere(img[..., 3] == 1)
+        assert 20 < len(hit) < 2000, len(hit)
+        assert np.abs(hit.mean(0) - 63.5).max() < 16                # a small disc around the image centre
+        assert abs(img[..., 7][img[..., 3] == 1].min() - 0.05) < 0.005   # at the distance the camera was put
+    renderer.load_dense(V.sphere64())       # leave a small volume behind for the next test
+
+
+def test_pipe_flavour_renderer_matches_direct_renderer(renderer):
+    """inference.Renderer (the pipe flavour's methods over the in-process library) returns the DirectRenderer frame,
+    planar, for the same command sequence."""
+    import torch
+    from isosurfacesuperresolution_amd import inference
+    vol = V.sphere64()
+    origin = V.quantize3(V.orbit_camera(9))
+    pr = inference.Renderer("GPURenderer.exe", vol, inference.Material(0.5), inference.Camera(160, 96), backend=renderer)
+    pr.send_command("aosamples=0\n")
+    pr.send_command("cameraFoV=45.000\n")
+    pr.send_command("cameraOrigin=%s\n" % V.fmt3(origin))
+    pr.send_command("cameraLookAt=0.000,0.000,0.000\n")
+    pr.send_command("cameraUp=0.000,1.000,0.000\n")
+    pr.send_command("resolution=160,96\n")
+    pr.render()
+    pr.render()
+    pr.read_image(160, 96)
+    planar = pr.read_image(160, 96)
+    assert pr.get_time() > 0
+    out = torch.empty((96, 160, 12), device="cuda")
+    renderer.render_direct(out)
+    assert np.array_equal(planar, out.permute(2, 0, 1).cpu().numpy())
+    assert planar[3].sum() > 500
+    # restore the defaults the other tests assume
+    for c, v in (("diffuse", "0.7,0.7,0.7"), ("specular", "1,1,1"), ("exponent", "32")):
+        renderer.send_command(c, v)
+
+
+def test_discarded_prefetch_does_not_disturb_the_flow(renderer):
+    """frame(o1, next_origin=o2) renders o2 ahead; if the caller then asks for o3 instead, the frame rendered ahead is
+    dropped and the flow of o3 is measured against o1 (the last DISPLAYED camera), exactly as without prefetching."""
+    import argparse
+    import torch
+    from isosurfacesuperresolution_amd import models
+    from isosurfacesuperresolution_amd.inference import LoadedModel
+    from isosurfacesuperresolution_amd.pipeline import SuperResolutionPipeline, default_shading
+    renderer.load_dense(V.sphere64())
+    opt = argparse.Namespace(upsample='bilinear', reconType='residual', useBN=False, numResidualLayers=10)
+    torch.manual_seed(0)
+    net = models.createNetwork('EnhanceNet', 4, 101, [0, 1, 2, 3, 4], 6, opt)
+    model = LoadedModel.from_model(net, "cuda", parameters={"initialImage": "zero"})
+    o1, o2, o3 = (V.quantize3(V.orbit_camera(k)) for k in (3, 4, 9))
+    frames = {}
+    for mode in ("plain", "discarded"):
+        pipe = SuperResolutionPipeline(renderer, model, default_shading("cuda", 45.0), (64, 48))
+        pipe.set_static(fov=45.0, isovalue=0.5)
+        pipe.frame(o1)                      # establishes o1 as the flow reference in both runs
+        if mode == "plain":
+            pipe.frame(o1)
+        else:
+            pipe.frame(o1, next_origin=o2)
+        rgb, raw = pipe.frame(o3)
+        torch.cuda.synchronize()
+        frames[mode] = (pipe.gbuffer.clone(), raw.clone())
+    assert torch.equal(frames["plain"][0], frames["discarded"][0])
+    assert frames["plain"][0][..., 8:10].abs().max() > 0
+    assert torch.equal(frames["plain"][1], frames["discarded"][1])
+    # a gate with no render in flight since the last one returns at once (no spin until its timeout)
+    s = torch.cuda.current_stream()
+    assert renderer.gate_resident(s, 2000000) == 0
+    import time
+    t0 = time.perf_counter()
+    assert renderer.gate_resident(s, 2000000) == 0
+    torch.cuda.synchronize()
+    assert time.perf_counter() - t0 < 0.5

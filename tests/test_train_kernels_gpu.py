@@ -371,3 +371,62 @@ def test_bf16_weight_gradient_is_the_same_sum(case):
     wr, br = reference(xs, gzs)
     assert ((gw.cpu().double() - wr).norm() / wr.norm()).item() <= 1e-2
     assert (gb.cpu().double() - br).abs().max().item() <= 1e-5 * br.abs().max().item()       # fp32 path
+
+
+def test_backward_is_correct_when_large_planes_would_be_padded():
+    """Inference outputs get padded channel planes once a plane reaches 4 MiB (ops.empty_planes); the autograd paths
+    hand raw pointers of saved outputs to kernels that index [N, C, H, W] flat, so THEIR outputs must stay packed.
+    With the padding forced at every size: gradients of a conv + ReLU, a residual block and a leaky conv vs fp64."""
+    from isosurfacesuperresolution_amd import ops
+    g = torch.Generator().manual_seed(4)
+    x = torch.rand(2, 64, 24, 40, generator=g) * 2 - 1
+    w1 = (torch.rand(64, 64, 3, 3, generator=g) * 2 - 1) / 24.0
+    w2 = (torch.rand(64, 64, 3, 3, generator=g) * 2 - 1) / 24.0
+    b1, b2 = torch.rand(64, generator=g) - 0.5, torch.rand(64, generator=g) - 0.5
+    gy = torch.rand(2, 64, 24, 40, generator=g) * 2 - 1
+
+    def run(dev, dt):
+        t = [v.to(dev).to(dt).requires_grad_() for v in (x, w1, b1, w2, b2)]
+        xx, a1, c1, a2, c2 = t
+        if dev == "cpu":
+            y = F.relu(F.conv2d(xx, a1, c1, padding=1))
+            y = y + F.conv2d(F.relu(F.conv2d(y, a2, c2, padding=1)), a1, c1, padding=1)
+            y = F.leaky_relu(F.conv2d(y, a2, c2, padding=1), 0.1)
+        else:
+            y = ops.conv3x3(xx, a1, c1, act='relu')
+            y = ops.residual_block(y, a2, c2, a1, c1)
+            y = ops.conv3x3(y, a2, c2, act='leaky', slope=0.1)
+            assert y.is_contiguous()
+        y.backward(gy.to(dev).to(dt))
+        return [v.grad.detach().cpu().double() for v in t]
+
+    old = ops.plane_pad
+    ops.plane_pad = lambda h, w: 52
+    try:
+        got = run("cuda", torch.float32)
+    finally:
+        ops.plane_pad = old
+    ref = run("cpu", torch.float64)
+    for a, b in zip(ref, got):
+        assert ((a - b).norm() / a.norm()).item() <= 1e-5
+
+
+def test_deferred_weight_gradients_respect_parameter_hooks():
+    """Deferred weight gradients bypass autograd's accumulation; a parameter with a tensor hook keeps the ordinary
+    path, so the hook fires with the gradient and the result is unchanged."""
+    from isosurfacesuperresolution_amd import ops
+    g = torch.Generator().manual_seed(8)
+    x = (torch.rand(2, 64, 16, 32, generator=g) * 2 - 1).cuda()
+    w = ((torch.rand(64, 64, 3, 3, generator=g) * 2 - 1) / 24.0).cuda().requires_grad_()
+    b = (torch.rand(64, generator=g) - 0.5).cuda().requires_grad_()
+    seen = []
+    with ops.deferred_weight_gradients():
+        ops.conv3x3(x, w, b, act='relu').square().sum().backward()
+    deferred = w.grad.clone()
+    w.grad = None; b.grad = None
+    h = w.register_hook(lambda grad: seen.append(grad.clone()))
+    with ops.deferred_weight_gradients():
+        ops.conv3x3(x, w, b, act='relu').square().sum().backward()
+        assert len(seen) == 1                      # fired inside backward, not skipped
+    h.remove()
+    assert torch.allclose(seen[0], deferred, rtol=1e-5, atol=1e-6) and torch.allclose(w.grad, deferred, rtol=1e-5, atol=1e-6)
