@@ -9,6 +9,15 @@ stand-in volume, seeded random-init EnhanceNet weights).  With N > 1 (launched b
 torch.distributed.run, one rank per GPU) every rank renders its own contiguous chunk of the
 sequence, started with ``initialImage``: weak scaling, no data-path collective.
 Rank 0 prints ONE JSON line.
+
+Two further modes time the collectives SURVEY.md 8(e) defines (each prints its own JSON line, with its own metric):
+
+    --mode train   BASELINE config #3: the mainVideoUnshaded.py step (B=16 clips x T=10 frames, 32^2 -> 128^2 crops, l1 +
+                   temp-l2 losses, Adam), the global batch split over the ranks, ONE flat 3.64 MB gradient all-reduce per
+                   step captured with the step in a HIP graph (train.DataParallelTrainer.graphed)
+    --mode tiled   BASELINE config #5: a 1024^3 volume generated tile-wise, one object-space tile per rank, every rank
+                   ray-marches the full 960x540 image, all-gather + nearest-hit composite, 4x SR in screen strips with a
+                   second all-gather -> 3840x2160
 """
 import argparse
 import contextlib
@@ -27,13 +36,18 @@ HBM_PEAK_GBS = 8000.0
 PMC_TRAFFIC_FILES = ("r02_pmc_traffic.json", "r01_pmc_traffic.json")   # committed rocprofv3 --pmc passes of this command
 
 
-def parse():
+def parse(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=30)
     ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--mode", default="infer", choices=["infer", "train", "tiled"])
     ap.add_argument("--volume", default="ejecta256", choices=["ejecta256", "ejecta128", "sphere64"])
-    ap.add_argument("--low", default="480x270")
+    ap.add_argument("--low", default="", help="low-resolution image, WxH (default 480x270; 960x540 in --mode tiled)")
+    ap.add_argument("--train-batch", type=int, default=16, help="--mode train: GLOBAL batch (clips), split over the ranks")
+    ap.add_argument("--train-frames", type=int, default=10)
+    ap.add_argument("--train-crop", type=int, default=32)
+    ap.add_argument("--tiled-n", type=int, default=1024, help="--mode tiled: edge of the volume")
     ap.add_argument("--no-temporal", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--raymarch-variant", type=int, default=0)
@@ -45,40 +59,110 @@ def parse():
     ap.add_argument("--no-overlap", action="store_true", help="render frame t and super-resolve it back to back on one stream")
     ap.add_argument("--cpu-frames", type=int, default=6, help="frames in the CPU baseline sample (about 2 s each on 16 cores)")
     ap.add_argument("--side-waves", type=int, default=0, help="wave cap of the overlapped ray-march (0 = 4 per CU)")
-    return ap.parse_args()
+    return ap.parse_args(argv)
 
 
-def main():
-    args = parse()
+class Job:
+    """The process group of one bench run: one process per GPU, RCCL (backend "nccl") unless
+    BENCH_DIST_BACKEND=gloo rehearses the multi-rank path (with BENCH_SHARE_DEVICE=1 on a one-GPU box, with
+    BENCH_DEVICE=cpu on CPU tensors -- the CPU tests of the train / tiled modes).  A failed init raises: nothing here
+    re-executes a process that has touched the GPU."""
+
+    def __init__(self, args):
+        import torch
+        import torch.distributed as dist
+        self.world = int(os.environ.get("WORLD_SIZE", "1"))
+        self.rank = int(os.environ.get("RANK", "0"))
+        local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+        if self.world > 1:
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        self.backend = os.environ.get("BENCH_DIST_BACKEND", "nccl")
+        self.cpu = os.environ.get("BENCH_DEVICE") == "cpu"
+        if self.cpu:
+            assert self.backend == "gloo" or self.world == 1, "BENCH_DEVICE=cpu needs BENCH_DIST_BACKEND=gloo"
+            self.device = "cpu"
+        else:
+            assert torch.cuda.is_available(), "bench.py needs an MI355X"
+            if os.environ.get("BENCH_SHARE_DEVICE") == "1":
+                local_rank = 0
+            torch.cuda.set_device(local_rank)
+            self.device = "cuda"
+        if self.world > 1:
+            if self.backend == "nccl":
+                dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+            else:
+                dist.init_process_group(self.backend)
+        assert args.gpus == self.world, "--gpus must equal the number of launched ranks"
+        # tensors a collective can take: device tensors with RCCL, CPU tensors with gloo
+        self.coll_device = "cuda" if (self.backend == "nccl" and not self.cpu) else "cpu"
+
+    def sync(self):
+        import torch
+        import torch.distributed as dist
+        if not self.cpu:
+            torch.cuda.synchronize()
+        if self.world > 1:
+            dist.barrier()
+            if not self.cpu:
+                torch.cuda.synchronize()
+
+    def max_over_ranks(self, value):
+        import torch
+        import torch.distributed as dist
+        if self.world == 1:
+            return value
+        t = torch.tensor([value], dtype=torch.float64, device=self.coll_device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return t.item()
+
+    def joined_ranks(self):
+        """How many ranks the collective backend really joined: a sum of ones over an all-reduce (on DEVICE tensors,
+        i.e. through RCCL, when the backend is nccl)."""
+        import torch
+        import torch.distributed as dist
+        if self.world == 1:
+            return None
+        ones = torch.ones(1, dtype=torch.float32, device=self.coll_device)
+        dist.all_reduce(ones)
+        return int(ones.item())
+
+    def close(self):
+        import torch.distributed as dist
+        if self.world > 1:
+            dist.destroy_process_group()
+
+
+def main(argv=None, **hooks):
+    args = parse(argv)
+    job = Job(args)
+    try:
+        if args.mode == "train":
+            result = run_train(args, job)
+        elif args.mode == "tiled":
+            result = run_tiled(args, job, **hooks)
+        else:
+            result = run_infer(args, job)
+        if job.rank == 0:
+            print(json.dumps(result), flush=True)
+    finally:
+        job.close()
+    return result
+
+
+def run_infer(args, job):
     import numpy as np
     import torch
     import torch.distributed as dist
     from isosurfacesuperresolution_amd import models, ops, volumes as V
     from isosurfacesuperresolution_amd.inference import DirectRenderer, LoadedModel
     from isosurfacesuperresolution_amd.pipeline import SuperResolutionPipeline, default_shading
-
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-    assert torch.cuda.is_available(), "bench.py needs an MI355X"
-    # BENCH_DIST_BACKEND=gloo + BENCH_SHARE_DEVICE=1 rehearse the multi-rank path on a one-GPU box
-    backend = os.environ.get("BENCH_DIST_BACKEND", "nccl")
-    if os.environ.get("BENCH_SHARE_DEVICE") == "1":
-        local_rank = 0
-    torch.cuda.set_device(local_rank)
-    if world > 1:
-        if backend == "nccl":
-            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-        else:
-            dist.init_process_group(backend)
-    assert args.gpus == world, "--gpus must equal the number of launched ranks"
+    assert not job.cpu, "--mode infer measures the HIP path: it needs an MI355X"
+    world, rank, backend = job.world, job.rank, job.backend
 
     if args.exact:
         ops.SPLIT_F16 = False
-    low_w, low_h = (int(v) for v in args.low.split("x"))
+    low_w, low_h = (int(v) for v in (args.low or "480x270").split("x"))
     iso = {"ejecta256": 0.34, "ejecta128": 0.34, "sphere64": 0.5}[args.volume]
     vol = V.VOLUMES[args.volume][0]()
     renderer = DirectRenderer()
@@ -101,11 +185,7 @@ def main():
     first = rank * K                      # this rank's contiguous chunk of the orbit
     origins = [V.orbit_camera(first + k - Wm, K=max(64, world * K)) for k in range(Wm + K)]
 
-    def sync():
-        torch.cuda.synchronize()
-        if world > 1:
-            dist.barrier()
-            torch.cuda.synchronize()
+    sync = job.sync
 
     for k in range(Wm):
         pipe.frame(origins[k], origins[k + 1] if overlap else None)
@@ -127,15 +207,8 @@ def main():
     rm_ms = renderer.profile_times_ms()
     ops.profile_enable(False)
     renderer.profile_enable(False)
-    rccl_ranks = None
-    if world > 1:
-        tmax = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        elapsed = tmax.item()
-        # how many ranks the collective backend really joined: a sum of ones over a DEVICE all-reduce (RCCL when nccl)
-        ones = torch.ones(1, dtype=torch.float32, device="cuda" if backend == "nccl" else "cpu")
-        dist.all_reduce(ones)
-        rccl_ranks = int(ones.item())
+    elapsed = job.max_over_ranks(elapsed)
+    rccl_ranks = job.joined_ranks()
 
     per = {}
     for name, flops, ms in records:
@@ -217,10 +290,223 @@ def main():
         result.update(cpu_reference_leg(args, vol, iso, net, pipe, origins[Wm], low_w, low_h, result, rm_alone))
     if rank == 0 and world == 1 and args.raymarch_large:
         result["raymarch_large"] = raymarch_large_leg(args.raymarch_large, renderer)
-    if rank == 0:
-        print(json.dumps(result))
+    return result
+
+
+TRAIN_FLOPS_PER_SAMPLE_FRAME = 13.4e9      # conv forward + data gradient + weight gradient of one 32^2 -> 128^2 crop
+TRAIN_OPT = dict(upsample='bilinear', reconType='residual', useBN=False, numResidualLayers=10,
+                 losses="l1:mask:1,l1:ao:1,l1:normal:10,l1:depth:10,temp-l2:color:0.1",
+                 lossAO=0.0, lossAmbient=0.1, lossDiffuse=0.9, lossSpecular=0.0)
+
+
+def _clip_batch(torch, B, T, crop, seed, device):
+    g = torch.Generator().manual_seed(seed)
+    inp = torch.rand(B, T, 5, crop, crop, generator=g); inp[:, :, 0] = inp[:, :, 0] * 2 - 1
+    flow = (torch.rand(B, T, 2, crop, crop, generator=g) - 0.5) * 0.05
+    tgt = torch.rand(B, T, 6, 4 * crop, 4 * crop, generator=g); tgt[:, :, 0] = tgt[:, :, 0] * 2 - 1
+    return tuple(t.to(device) for t in (inp, flow, tgt))
+
+
+def run_train(args, job):
+    """BASELINE config #3: the training step of mainVideoUnshaded.py:397-473 data-parallel over
+    the ranks.  Global batch fixed (strong scaling), rank-0 broadcast of the weights, one flat all-reduce of the
+    911 046 fp32 gradients per step -- on the GPU captured with the whole step in ONE HIP graph."""
+    import torch
+    import torch.distributed as dist
+    from isosurfacesuperresolution_amd import losses, models, train
+    world, rank, dev = job.world, job.rank, job.device
+    B, T, crop = args.train_batch, args.train_frames, args.train_crop
+    assert B % world == 0, "--train-batch must be divisible by the number of ranks"
+    per = B // world
+    opt = argparse.Namespace(**TRAIN_OPT)
+    torch.manual_seed(124)                                              # mainVideoUnshaded.py:157
+    with contextlib.redirect_stdout(sys.stderr):
+        net = models.createNetwork('EnhanceNet', 4, 101, [0, 1, 2, 3, 4], 6, opt).to(dev)
+        crit = losses.LossNetUnshaded(dev, 5, 6, 4 * crop, crop // 2, opt).to(dev)
+    optim, _ = train.make_optimizer(net, capturable=(dev == "cuda"))
+    trainer = train.DataParallelTrainer(net, crit, optim)
+    batch = _clip_batch(torch, per, T, crop, 1000 + rank, dev)
+    graphed = dev == "cuda" and (world == 1 or job.backend == "nccl")     # gloo collectives cannot be captured
+    if graphed:
+        step_fn = trainer.graphed(batch, initial_image="zero")
+        step = lambda: step_fn(batch)
+    else:
+        step = lambda: trainer.step(batch, initial_image="zero")
+    K, Wm = args.steps, args.warmup
+    loss = None
+    for _ in range(Wm):
+        loss = step()
+    job.sync()
+    t0 = time.perf_counter()
+    for _ in range(K):
+        loss = step()
+    job.sync()
+    elapsed = job.max_over_ranks(time.perf_counter() - t0)
+    loss = float(loss)
+    # the collective on its own: the flat gradient bucket, as in the step
+    allreduce = None
     if world > 1:
-        dist.destroy_process_group()
+        n = 20
+        for _ in range(3):
+            dist.all_reduce(trainer.bucket)
+        job.sync()
+        t1 = time.perf_counter()
+        for _ in range(n):
+            dist.all_reduce(trainer.bucket)
+        job.sync()
+        allreduce = {"bytes": trainer.numel * 4, "us": job.max_over_ranks(time.perf_counter() - t1) / n * 1e6,
+                     "buckets": 1, "backend": "RCCL" if job.backend == "nccl" else job.backend}
+    flops = TRAIN_FLOPS_PER_SAMPLE_FRAME * (crop / 32.0) ** 2 * B * T
+    achieved = flops / (elapsed / K) / 1e12
+    result = {
+        "metric": "training clips/sec (mainVideoUnshaded.py step, BASELINE config #3), data-parallel over the GPUs of one node",
+        "value": B * K / elapsed, "unit": "clips/s", "n_gpus": world, "steps": K, "warmup": Wm,
+        "ms_per_step": elapsed / K * 1e3, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+        "dtype": "f32", "data": "synthetic (random clips of the dataset's shapes, seeded random-init EnhanceNet)",
+        "config": {"workload": "EnhanceNet training step: global batch %d clips x %d frames, %dx%d -> %dx%d crops, "
+                               "losses l1:mask:1,l1:ao:1,l1:normal:10,l1:depth:10,temp-l2:color:0.1, Adam 1e-4" % (B, T, crop, crop, 4 * crop, 4 * crop),
+                   "clips_per_rank": per, "parallelism": "dp%d, one flat %.2f MB gradient all-reduce per step" % (world, trainer.numel * 4 / 1e6),
+                   "step": "one HIP graph (forward x T, backward through time, deferred weight gradients, all-reduce, Adam)" if graphed else "eager"},
+        "rccl_ranks": job.joined_ranks(), "allreduce": allreduce, "loss": loss,
+        "roofline": {"kernel": "conv forward + data gradient + weight gradient of the step (all fp32 MFMA kernels)", "bound": "mfma",
+                     "achieved": achieved, "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": achieved / MFMA_F32_PEAK_TFLOPS,
+                     "traffic": None, "flops_per_step": flops},
+        "cpu_baseline": None,
+    }
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        cores = host_cores()
+        torch.set_num_threads(cores)
+        torch.manual_seed(124)
+        with contextlib.redirect_stdout(sys.stderr):
+            cnet = models.createNetwork('EnhanceNet', 4, 101, [0, 1, 2, 3, 4], 6, opt)
+            ccrit = losses.LossNetUnshaded("cpu", 5, 6, 4 * crop, crop // 2, opt)
+        coptim, _ = train.make_optimizer(cnet)
+        cb = _clip_batch(torch, 2, T, crop, 1000, "cpu")
+        train.train_step(cnet, ccrit, coptim, cb, initial_image="zero")
+        t1 = time.perf_counter()
+        n = 3
+        for _ in range(n):
+            train.train_step(cnet, ccrit, coptim, cb, initial_image="zero")
+        dt = (time.perf_counter() - t1) / n
+        result["cpu_baseline"] = {"value": 2 / dt, "unit": "clips/s", "cores": cores, "kind": "port",
+                                  "sample": "%d steps of 2 clips x %d frames on CPU PyTorch (%d threads), %.2f s per step" % (n, T, cores, dt)}
+    return result
+
+
+TILE_SPLITS = {1: (1, 1, 1), 2: (2, 1, 1), 4: (2, 2, 1), 8: (2, 2, 2)}
+
+
+def run_tiled(args, job, make_local_renderer=None):
+    """BASELINE config #5: a volume too large to want on one GPU, split in object space, one tile per
+    rank.  Every rank generates ONLY its tile of the global lattice (one scalar max / bbox reduction between ranks),
+    ray-marches the full low-resolution image against it, one all-gather + nearest-hit composite gives every rank the
+    frame (bit-identical to the unsplit render), the 4x network runs in screen strips with a second all-gather.
+    ``make_local_renderer(tile) -> object with .render(tensor[H,W,12], origin)``: CPU rehearsals of the exchange (tests)."""
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+    from isosurfacesuperresolution_amd import models, parallel_render as PR, parallel_sr, volumes as V
+    from isosurfacesuperresolution_amd.inference import LoadedModel
+    from isosurfacesuperresolution_amd.pipeline import default_shading
+    world, rank, dev = job.world, job.rank, job.device
+    assert world in TILE_SPLITS, "--mode tiled runs on 1, 2, 4 or 8 ranks"
+    n = args.tiled_n
+    low_w, low_h = (int(v) for v in (args.low or "960x540").split("x"))
+
+    def reducer(op):
+        def fn(a):
+            if world == 1:
+                return a
+            t = torch.from_numpy(np.ascontiguousarray(a)).to(job.coll_device)
+            dist.all_reduce(t, op=op)
+            return t.cpu().numpy()
+        return fn
+    t0 = time.perf_counter()
+    tiles = PR.generate_tiles(V.EjectaField(n, seed=1024 if n == 1024 else 272), TILE_SPLITS[world], ranks=[rank],
+                              reduce_max=reducer(dist.ReduceOp.MAX), reduce_min=reducer(dist.ReduceOp.MIN))
+    tile = tiles[rank]
+    t_gen = time.perf_counter() - t0
+    if make_local_renderer is not None:
+        local = make_local_renderer(tile)
+        renderer = None
+    else:
+        from isosurfacesuperresolution_amd.inference import DirectRenderer
+        renderer = DirectRenderer()
+        for c, v in (("cameraLookAt", "0,0,0"), ("cameraUp", "0,1,0"), ("cameraFoV", "30.000"), ("isovalue", "0.340"), ("aosamples", "0"),
+                     ("resolution", "%d,%d" % (low_w, low_h)), ("viewport", "0,0,%d,%d" % (low_w, low_h)),
+                     ("cameraOrigin", V.fmt3(V.orbit_camera(-1)))):
+            renderer.send_command(c, v)
+        t0 = time.perf_counter()
+        renderer.load_tile(tile)
+        t_load = time.perf_counter() - t0
+
+        class _Local:
+            def render(self, tensor, origin):
+                renderer.send_command("cameraOrigin", V.fmt3(origin))
+                return renderer.render_direct(tensor)
+        local = _Local()
+    del tiles
+    opt = argparse.Namespace(upsample='bilinear', reconType='residual', useBN=False, numResidualLayers=10)
+    torch.manual_seed(0)
+    with contextlib.redirect_stdout(sys.stderr):
+        net = models.createNetwork('EnhanceNet', 4, 101, [0, 1, 2, 3, 4], 6, opt)
+    lm = LoadedModel.from_model(net, dev, parameters={"initialImage": "zero"})
+    sr = parallel_sr.StripSuperResolution(lm, default_shading(dev, 30.0))
+    mine = torch.empty((low_h, low_w, 12), dtype=torch.float32, device=dev)
+    gathered = torch.empty((world, low_h, low_w, 12), dtype=torch.float32, device=dev)
+    K, Wm = args.steps, args.warmup
+    phases = {"render": 0.0, "allgather": 0.0, "composite": 0.0, "sr_strip_and_allgather": 0.0}
+
+    def tick():
+        if dev == "cuda":
+            torch.cuda.synchronize()
+        return time.perf_counter()
+
+    def frame(k, timed):
+        origin = V.orbit_camera(k)
+        a = tick()
+        local.render(mine, origin)
+        b = tick()
+        if world > 1:
+            dist.all_gather_into_tensor(gathered.view(world * low_h, low_w, 12), mine)
+        else:
+            gathered[0].copy_(mine)
+        c = tick()
+        comp = PR.composite(gathered)
+        d = tick()
+        rgb, raw = sr.frame(comp)
+        e = tick()
+        if timed:
+            for name, dt in zip(phases, (b - a, c - b, d - c, e - d)):
+                phases[name] += dt
+        return comp, rgb
+
+    for k in range(Wm):
+        frame(k - Wm, False)
+    sr.reset()
+    job.sync()
+    t0 = time.perf_counter()
+    for k in range(K):
+        comp, rgb = frame(k, True)
+    job.sync()
+    elapsed = job.max_over_ranks(time.perf_counter() - t0)
+    ms = {name: job.max_over_ranks(v) / K * 1e3 for name, v in phases.items()}
+    hits = int((comp[..., 3] == 1).sum().item())
+    return {
+        "metric": "frames/sec (object-space tiled %d^3 render + all-gather composite + 4x SR in screen strips, BASELINE config #5)" % n,
+        "value": K / elapsed, "unit": "frames/s", "n_gpus": world, "steps": K, "warmup": Wm,
+        "ms_per_step": elapsed / K * 1e3, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+        "dtype": "f32", "data": "synthetic (ejecta %d^3 stand-in volume generated tile-wise, seeded random-init EnhanceNet weights)" % n,
+        "config": {"workload": "%d^3 volume in %s object-space tiles, %dx%d -> %dx%d, temporal on" % (
+                       n, "x".join(str(v) for v in TILE_SPLITS[world]), low_w, low_h, 4 * low_w, 4 * low_h),
+                   "sharding": "one tile per rank; all-gather of %.1f MB G-buffers + nearest-hit composite; SR in %d strips with a 24-px halo + all-gather"
+                               % (low_w * low_h * 48 / 1e6, world)},
+        "rccl_ranks": job.joined_ranks(),
+        "phases_ms_max_over_ranks": ms,
+        "tile": {"generate_s": t_gen, "voxels": [int(v) for v in tile["data"].shape[::-1]]},
+        "hit_pixels": hits, "rgb_mean": float(rgb.mean().item()),
+        "roofline": None, "cpu_baseline": None,
+    }
 
 
 def fast_mode_leg(pipe, origins, Wm, K, overlap, sync):
