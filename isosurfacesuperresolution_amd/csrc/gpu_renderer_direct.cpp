@@ -60,6 +60,7 @@ struct Volume {
     uint8_t* leaf = nullptr;
     float* leafRange = nullptr;  // (min, max) per brick position, see iso_kernels.hip: leaf_may_cross
     uint8_t* node1 = nullptr;
+    float* node1Range = nullptr; // (min, max) over the ranges of a 128^3 node's existing leaves
 };
 
 struct State {
@@ -75,6 +76,7 @@ struct State {
     unsigned* tileQueue = nullptr;   // 8 per-XCD work counters of kernel variant 2 (+ 1 resident-wave counter)
     unsigned residentTarget = 0;     // waves launched by all variant-2 renders so far (what the counter will reach)
     unsigned gatedTarget = 0;        // residentTarget at the last isoGateResident: a gate with nothing new to wait for is a no-op
+    long long* statsOut = nullptr;   // diagnostics: isoDebugSetStatsBuffer
     bool profile = false;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> events;   // one pair per profiled frame
 };
@@ -97,6 +99,7 @@ void freeVolume(Volume& v)
     if (v.leaf) (void)hipFree(v.leaf);
     if (v.leafRange) (void)hipFree(v.leafRange);
     if (v.node1) (void)hipFree(v.node1);
+    if (v.node1Range) (void)hipFree(v.node1Range);
     v = Volume();
 }
 
@@ -283,6 +286,12 @@ bool finalizeVolume(Volume& v, int bbox[6], float maxValue, int lmin[3], int lma
     v.s = 1.0 * scale;
     v.sinv = 1.0 / v.s;
     for (int k = 0; k < 3; ++k) v.t[k] = (-cen[k]) * scale;
+    {
+        const size_t n1 = size_t(v.n1x) * v.n1y * v.n1z;
+        if (hipMalloc(&v.node1Range, n1 * 2 * sizeof(float)) != hipSuccess) { freeVolume(v); return false; }
+        iso_launch_node_range(v.leaf, v.leafRange, v.nbx, v.nby, v.nbz, v.org, v.n1x, v.n1y, v.n1z, v.n1o, v.node1Range, nullptr);
+        if (hipGetLastError() != hipSuccess || hipDeviceSynchronize() != hipSuccess) { freeVolume(v); return false; }
+    }
     v.loaded = true;
     freeVolume(g.vol);
     g.vol = v;
@@ -638,7 +647,7 @@ bool launchFrame(float* out, hipStream_t stream)
     p.n1x = v.n1x; p.n1y = v.n1y; p.n1z = v.n1z;
     for (int k = 0; k < 3; ++k) { p.org[k] = v.org[k]; p.n1o[k] = v.n1o[k]; }
     p.any_leaf = v.nleaf > 0;
-    p.bricks = v.bricks; p.slot = v.slot; p.leaf = v.leaf; p.leafRange = v.leafRange; p.node1 = v.node1;
+    p.bricks = v.bricks; p.slot = v.slot; p.leaf = v.leaf; p.leafRange = v.leafRange; p.node1 = v.node1; p.node1Range = v.node1Range;
     p.out = out;
     p.aoSamples = a.aoSamples < 0 ? 0 : (a.aoSamples > 512 ? 512 : a.aoSamples);   // GPURendererDirect.cpp:350
     p.aoRadius = double(a.aoRadius);
@@ -655,6 +664,8 @@ bool launchFrame(float* out, hipStream_t stream)
         IsoGvdbFrame f;
         buildGvdbFrame(f, a, v, g.lastOrigin, g.lastLookAt);
         iso_launch_render_gvdb(p, f, stream, e0, e1);
+    } else if (g.statsOut) {
+        iso_launch_render_stats(p, g.statsOut, stream);
     } else {
         iso_launch_render(p, g.variant, stream, e0, e1, g.waveCap);
         if (g.variant == 2) {
@@ -875,10 +886,14 @@ int isoGateResident(void* stream, int timeoutUs)
 
 int isoSetKernelVariant(int variant)
 {
-    if (variant < 0 || variant > 2) return -1;
+    if (variant < 0 || variant > 3) return -1;
     g.variant = variant;
     return 0;
 }
+
+// Diagnostics, not part of the public header: while a device buffer of 6 * tiles int64 is set, frames are rendered by the
+// instrumented variant-0 kernel, which also writes per-tile clocks and per-ray step counts (tools/raymarch_stats.py).
+void isoDebugSetStatsBuffer(unsigned long long devicePtr) { g.statsOut = reinterpret_cast<long long*>(devicePtr); }
 
 int isoProfileEnable(int on)
 {

@@ -108,10 +108,14 @@ __device__ __forceinline__ float trilerp(float V000, float V001, float V010, flo
     return C + (D - C) * u;
 }
 
+// the corners (x, x+1) are neighbours in the brick: four 8-byte loads (dword aligned) instead of eight 4-byte ones
+typedef float float2u __attribute__((ext_vector_type(2), aligned(4)));
 __device__ __forceinline__ float interp_from_brick(const float* __restrict__ b, int lx, int ly, int lz, float u, float v, float w)
 {
     const float* q = b + (lz * 9 + ly) * 9 + lx;
-    return trilerp(q[0], q[81], q[9], q[90], q[1], q[82], q[10], q[91], u, v, w);
+    const float2u c00 = *reinterpret_cast<const float2u*>(q), c01 = *reinterpret_cast<const float2u*>(q + 81);
+    const float2u c10 = *reinterpret_cast<const float2u*>(q + 9), c11 = *reinterpret_cast<const float2u*>(q + 90);
+    return trilerp(c00.x, c01.x, c10.x, c11.x, c00.y, c01.y, c10.y, c11.y, u, v, w);
 }
 
 // Trilinear sample at index-space position (px,py,pz); Stencils.h:110-114 (cell = floor of the
@@ -172,21 +176,44 @@ __device__ __forceinline__ bool has_node1(const IsoRenderParams& P, int x, int y
     if ((unsigned)ax >= (unsigned)P.n1x || (unsigned)ay >= (unsigned)P.n1y || (unsigned)az >= (unsigned)P.n1z) return false;
     return P.node1[(az * P.n1y + ay) * P.n1x + ax] != 0;
 }
+// The same exact skipping one level up: node1Range = (min, max) over the ranges of the node's existing leaves.  If the
+// isovalue lies outside it (with the leaf test's pad), no leaf of the node can be marched, and since the leaf-level DDA
+// is re-initialised per node (IsoVolumeRayTracer.h:37-46) stepping over the whole node changes nothing downstream.
+__device__ __forceinline__ bool node1_may_cross(const IsoRenderParams& P, int x, int y, int z)
+{
+    const int ax = (x >> 7) - P.n1o[0], ay = (y >> 7) - P.n1o[1], az = (z >> 7) - P.n1o[2];
+    const float* mm = P.node1Range + 2 * (size_t)((az * P.n1y + ay) * P.n1x + ax);
+    const double lo = (double)mm[0], hi = (double)mm[1];
+    const double pad = 4e-6 * fmax(fabs(lo), fabs(hi));
+    return !(P.iso < lo - pad || P.iso > hi + pad);
+}
+
 __device__ __forceinline__ bool has_node2(const IsoRenderParams& P, int x, int y, int z)
 {
     return P.any_leaf && x == 0 && y == 0 && z == 0;
 }
 
+// Diagnostics (tools/raymarch_stats.py): what one ray did.  The product kernels pass NoTrace, which compiles to nothing.
+struct NoTrace { __device__ __forceinline__ void sample(int) {} __device__ __forceinline__ void leaf(bool) {} };
+struct Trace {
+    int samples = 0, leaves = 0, skipped = 0;
+    __device__ __forceinline__ void sample(int n) { samples += n; }
+    __device__ __forceinline__ void leaf(bool marched) { if (marched) ++leaves; else ++skipped; }
+};
+
 // IsoVolumeRayTracer.h:81-114
-__device__ __forceinline__ bool hits_voxel(const IsoRenderParams& P, const Ray& ray, double& time)
+template <typename TR>
+__device__ __forceinline__ bool hits_voxel(const IsoRenderParams& P, const Ray& ray, double& time, TR& tr)
 {
     DDA d;
     dda_init<0>(d, ray);
     double t0 = d.t0;
     float v0 = interp_value(P, ray, t0);
+    tr.sample(1);
     do {
         double t1 = dda_next(d);
         float v1 = interp_value(P, ray, t1);
+        tr.sample(1);
         if (v0 * v1 <= 0.0f) {
             double t = 0.5 * (t0 + t1);
             for (int i = 0; i < 5; ++i) {
@@ -195,6 +222,7 @@ __device__ __forceinline__ bool hits_voxel(const IsoRenderParams& P, const Ray& 
                 else { t0 = t; v0 = v2; }
                 t = 0.5 * (t0 + t1);
             }
+            tr.sample(5);
             time = t;
             return true;
         }
@@ -203,9 +231,15 @@ __device__ __forceinline__ bool hits_voxel(const IsoRenderParams& P, const Ray& 
     } while (dda_step(d));
     return false;
 }
+__device__ __forceinline__ bool hits_voxel(const IsoRenderParams& P, const Ray& ray, double& time)
+{
+    NoTrace nt;
+    return hits_voxel(P, ray, time, nt);
+}
 
 // IsoVolumeRayTracer.h:37-46 for node sizes 4096, 128, 8
-__device__ bool hits_hierarchy(const IsoRenderParams& P, Ray& ray, double& time)
+template <typename TR>
+__device__ bool hits_hierarchy(const IsoRenderParams& P, Ray& ray, double& time, TR& tr)
 {
     DDA d2;
     dda_init<12>(d2, ray);
@@ -215,14 +249,18 @@ __device__ bool hits_hierarchy(const IsoRenderParams& P, Ray& ray, double& time)
             DDA d1;
             dda_init<7>(d1, ray);
             do {
-                if (has_node1(P, d1.vx, d1.vy, d1.vz)) {
+                if (has_node1(P, d1.vx, d1.vy, d1.vz) && node1_may_cross(P, d1.vx, d1.vy, d1.vz)) {
                     ray.t0 = d1.t0; ray.t1 = dda_next(d1);
                     DDA d0;
                     dda_init<3>(d0, ray);
                     do {
-                        if (has_leaf(P, d0.vx, d0.vy, d0.vz) && leaf_may_cross(P, d0.vx, d0.vy, d0.vz)) {
-                            ray.t0 = d0.t0; ray.t1 = dda_next(d0);
-                            if (hits_voxel(P, ray, time)) return true;
+                        if (has_leaf(P, d0.vx, d0.vy, d0.vz)) {
+                            const bool march = leaf_may_cross(P, d0.vx, d0.vy, d0.vz);
+                            tr.leaf(march);
+                            if (march) {
+                                ray.t0 = d0.t0; ray.t1 = dda_next(d0);
+                                if (hits_voxel(P, ray, time, tr)) return true;
+                            }
                         }
                     } while (dda_step(d0));
                 }
@@ -230,6 +268,11 @@ __device__ bool hits_hierarchy(const IsoRenderParams& P, Ray& ray, double& time)
         }
     } while (dda_step(d2));
     return false;
+}
+__device__ bool hits_hierarchy(const IsoRenderParams& P, Ray& ray, double& time)
+{
+    NoTrace nt;
+    return hits_hierarchy(P, ray, time, nt);
 }
 
 __device__ __forceinline__ double len3(double x, double y, double z) { return sqrt(x * x + y * y + z * z); }
@@ -427,9 +470,9 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg)
 
 // ---- variant 0: per-lane gather ------------------------------------------------------------
 template <bool AO>
-__device__ __forceinline__ void render_gather_tile(const IsoRenderParams& P, int vb, int tiles_x, int ntiles, int lane)
+__device__ __forceinline__ void render_gather_tile(const IsoRenderParams& P, int vb, int tiles_x, int ntiles, int lane, bool remap = true)
 {
-    const int tile = xcd_remap(vb, ntiles);
+    const int tile = remap ? xcd_remap(vb, ntiles) : vb;
     const int i = (tile % tiles_x) * 8 + (lane & 7);
     const int j = (tile / tiles_x) * 8 + (lane >> 3);
     if (i >= P.W || j >= P.H) return;
@@ -456,6 +499,68 @@ template <bool AO>
 __global__ __launch_bounds__(64) void iso_render_gather(const IsoRenderParams P)
 {
     render_gather_pixel<AO>(P);
+}
+
+// ---- diagnostics: variant 0 with per-tile clocks and per-ray step counts (never on the product path) ------------------
+// out[tile] = { cycles of the wave (s_memtime), samples of its busiest ray, leaves marched / skipped by that ray,
+//               sum of samples over its rays, rays that hit }
+__global__ __launch_bounds__(64) void iso_render_stats(const IsoRenderParams P, long long* __restrict__ out)
+{
+    const long long c0 = (long long)__builtin_amdgcn_s_memtime();
+    const int tiles_x = (P.W + 7) >> 3, ntiles = tiles_x * ((P.H + 7) >> 3);
+    const int tile = xcd_remap(blockIdx.x, ntiles), lane = threadIdx.x;
+    const int i = (tile % tiles_x) * 8 + (lane & 7), j = (tile / tiles_x) * 8 + (lane >> 3);
+    Trace tr;
+    int hit = 0;
+    if (i < P.W && j < P.H && i >= P.vp[0] && j >= P.vp[1] && i < P.vp[2] && j < P.vp[3]) {
+        Ray r;
+        double wdx, wdy, wdz, it;
+        float o[12] = { 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 1.0f, 0.f };
+        if (make_ray(P, i, j, r, wdx, wdy, wdz) && hits_hierarchy(P, r, it, tr)) {
+            shade_hit<false>(P, r, it, wdx, wdy, wdz, i, j, o);
+            hit = 1;
+        }
+        store_pixel(P, i, j, o);
+    }
+    int best = tr.samples, lv = tr.leaves, sk = tr.skipped, sum = tr.samples, hits = hit;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        const int ob = __shfl_xor(best, off), ol = __shfl_xor(lv, off), os = __shfl_xor(sk, off);
+        if (ob > best) { best = ob; lv = ol; sk = os; }
+        sum += __shfl_xor(sum, off);
+        hits += __shfl_xor(hits, off);
+    }
+    const long long c1 = (long long)__builtin_amdgcn_s_memtime();
+    if (lane == 0) {
+        long long* q = out + (size_t)tile * 6;
+        q[0] = c1 - c0; q[1] = best; q[2] = lv; q[3] = sk; q[4] = sum; q[5] = hits;
+    }
+}
+
+// ---- variant 3: the slot table of the volume in LDS ------------------------------------------------------------
+// Every sample is a dependent pair of gathers: slot[brick position] -> 8 corners inside that brick.  For volumes of up
+// to 32 768 brick positions (256^3) the whole slot table is 128 KB: one workgroup of eight waves (= eight 8x8 pixel
+// tiles) per CU copies it into LDS once, and the first gather of every sample never leaves the CU.  The traversal code
+// is the same (it sees a parameter block whose `slot` pointer addresses LDS), so the results are bit-identical.
+template <bool AO>
+__global__ __launch_bounds__(512) void iso_render_gather_ldsslot(const IsoRenderParams P)
+{
+    extern __shared__ __attribute__((aligned(16))) int32_t slotLds[];
+    const int nb = P.nbx * P.nby * P.nbz;
+    {
+        const int4* src = reinterpret_cast<const int4*>(P.slot);
+        int4* dst = reinterpret_cast<int4*>(slotLds);
+        const int quads = nb >> 2;
+        for (int q = threadIdx.x; q < quads; q += 512) dst[q] = src[q];
+        for (int k = (quads << 2) + threadIdx.x; k < nb; k += 512) slotLds[k] = P.slot[k];
+    }
+    __syncthreads();
+    IsoRenderParams Q = P;
+    Q.slot = slotLds;
+    const int tiles_x = (P.W + 7) >> 3, ntiles = tiles_x * ((P.H + 7) >> 3);
+    // the eight tiles of a workgroup are neighbours in the image, and an XCD gets a contiguous run of workgroups
+    const int vb = xcd_remap(blockIdx.x, gridDim.x) * 8 + (threadIdx.x >> 6);
+    if (vb < ntiles) render_gather_tile<AO>(Q, vb, tiles_x, ntiles, threadIdx.x & 63, false);
 }
 
 // ---- variant 2: the same code in a 128-register budget ----------------------------------------
@@ -535,7 +640,7 @@ __device__ __forceinline__ bool walk_next_leaf(const IsoRenderParams& P, Walk& w
                 w.lvl = 1;
             } else if (!dda_step(w.d2)) return false;
         } else if (w.lvl == 1) {
-            if (has_node1(P, w.d1.vx, w.d1.vy, w.d1.vz)) {
+            if (has_node1(P, w.d1.vx, w.d1.vy, w.d1.vz) && node1_may_cross(P, w.d1.vx, w.d1.vy, w.d1.vz)) {
                 ray.t0 = w.d1.t0; ray.t1 = dda_next(w.d1);
                 dda_init<3>(w.d0, ray);
                 w.lvl = 0;
@@ -762,6 +867,31 @@ __global__ __launch_bounds__(64) void iso_leaf_range(const float* __restrict__ d
     if (threadIdx.x == 0) { range[2 * (size_t)b] = lo; range[2 * (size_t)b + 1] = hi; }
 }
 
+// nodeRange[n] = (min of the leaf minima, max of the leaf maxima) over the existing leaves of 128^3 node n
+__global__ __launch_bounds__(64) void iso_node_range(const uint8_t* __restrict__ leaf, const float* __restrict__ leafRange,
+                                                    int nbx, int nby, int nbz, int ox, int oy, int oz, int n1x, int n1y, int n1ox, int n1oy, int n1oz,
+                                                    float* __restrict__ nodeRange)
+{
+    const int n = blockIdx.x;
+    const int ax = n % n1x, ay = (n / n1x) % n1y, az = n / (n1x * n1y);
+    float lo = 3.0e38f, hi = -3.0e38f;
+    for (int k = threadIdx.x; k < 4096; k += 64) {
+        // global brick coordinates of the node's k-th leaf position, then local to the stored region
+        const int bx = ((ax + n1ox) << 4) + (k & 15) - (ox >> 3), by = ((ay + n1oy) << 4) + ((k >> 4) & 15) - (oy >> 3),
+                  bz = ((az + n1oz) << 4) + (k >> 8) - (oz >> 3);
+        if ((unsigned)bx >= (unsigned)nbx || (unsigned)by >= (unsigned)nby || (unsigned)bz >= (unsigned)nbz) continue;
+        const size_t b = ((size_t)bz * nby + by) * nbx + bx;
+        if (!leaf[b]) continue;
+        lo = fminf(lo, leafRange[2 * b]); hi = fmaxf(hi, leafRange[2 * b + 1]);
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        lo = fminf(lo, __shfl_xor(lo, off));
+        hi = fmaxf(hi, __shfl_xor(hi, off));
+    }
+    if (threadIdx.x == 0) { nodeRange[2 * (size_t)n] = lo; nodeRange[2 * (size_t)n + 1] = hi; }
+}
+
 // sparse loads (.vbx brick lists): the tables of the few existing positions are scattered into memset tables
 __global__ __launch_bounds__(256) void iso_scatter_tables(int n, const long long* __restrict__ index, const int32_t* __restrict__ slotv,
                                                          const uint8_t* __restrict__ leafv, const float* __restrict__ rangev,
@@ -777,6 +907,13 @@ __global__ __launch_bounds__(256) void iso_scatter_tables(int n, const long long
 }
 
 }  // namespace
+
+void iso_launch_node_range(const uint8_t* leaf, const float* leafRange, int nbx, int nby, int nbz, const int org[3],
+                           int n1x, int n1y, int n1z, const int n1o[3], float* nodeRange, void* stream)
+{
+    hipLaunchKernelGGL(iso_node_range, dim3(n1x * n1y * n1z), dim3(64), 0, (hipStream_t)stream, leaf, leafRange, nbx, nby, nbz,
+                       org[0], org[1], org[2], n1x, n1y, n1o[0], n1o[1], n1o[2], nodeRange);
+}
 
 void iso_launch_scatter_tables(int n, const long long* index, const int32_t* slotv, const uint8_t* leafv, const float* rangev,
                                int32_t* slot, uint8_t* leaf, float* range, void* stream)
@@ -800,6 +937,19 @@ void iso_launch_render(const IsoRenderParams& p, int variant, void* stream, void
     if (variant == 1) {
         if (p.aoSamples > 0) hipExtLaunchKernelGGL(iso_render_lds<true>, grid, block, 0, st, e0, e1, 0, p);
         else hipExtLaunchKernelGGL(iso_render_lds<false>, grid, block, 0, st, e0, e1, 0, p);
+    } else if (variant == 3 && (long long)p.nbx * p.nby * p.nbz <= 32768) {
+        // one workgroup of eight tiles per launch slot; tiles are XCD-remapped inside render_gather_tile, so the eight
+        // tiles of a workgroup are spread -- keep them neighbours instead: the remap is applied to the workgroup
+        const size_t lds = (size_t)p.nbx * p.nby * p.nbz * sizeof(int32_t);
+        static bool attr = false;
+        if (!attr) {
+            (void)hipFuncSetAttribute((const void*)iso_render_gather_ldsslot<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
+            (void)hipFuncSetAttribute((const void*)iso_render_gather_ldsslot<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
+            attr = true;
+        }
+        const dim3 g8((tiles + 7) / 8), b8(512);
+        if (p.aoSamples > 0) hipExtLaunchKernelGGL(iso_render_gather_ldsslot<true>, g8, b8, lds, st, e0, e1, 0, p);
+        else hipExtLaunchKernelGGL(iso_render_gather_ldsslot<false>, g8, b8, lds, st, e0, e1, 0, p);
     } else if (variant == 2) {
         const int waves = waveCap > 0 && waveCap < tiles ? (waveCap + 7) & ~7 : (tiles + 7) & ~7;   // 0 = one wave per tile
         const dim3 capped(waves / 4), block4(256);                                                  // 4 waves per workgroup
@@ -810,6 +960,12 @@ void iso_launch_render(const IsoRenderParams& p, int variant, void* stream, void
         if (p.aoSamples > 0) hipExtLaunchKernelGGL(iso_render_gather<true>, grid, block, 0, st, e0, e1, 0, p);
         else hipExtLaunchKernelGGL(iso_render_gather<false>, grid, block, 0, st, e0, e1, 0, p);
     }
+}
+
+void iso_launch_render_stats(const IsoRenderParams& p, long long* out, void* stream)
+{
+    const int tiles = ((p.W + 7) >> 3) * ((p.H + 7) >> 3);
+    hipLaunchKernelGGL(iso_render_stats, dim3(tiles), dim3(64), 0, (hipStream_t)stream, p, out);
 }
 
 void iso_launch_gate(const unsigned* resident, unsigned target, int timeoutUs, void* stream)

@@ -38,6 +38,7 @@ struct IsoRenderParams {
     const uint8_t* leaf;         // [nbz][nby][nbx] leaf node exists
     const float* leafRange;      // [nbz][nby][nbx][2] min / max of every value a march through that leaf can read
     const uint8_t* node1;        // [n1z][n1y][n1x]
+    const float* node1Range;     // [n1z][n1y][n1x][2] min / max over the ranges of the node's existing leaves
     float* out;                  // [H][W][12]
     int aoSamples;               // 0 -> AO channel == 1
     double aoRadius;             // world units
@@ -66,11 +67,15 @@ struct IsoGvdbFrame {
 // waveCap: variant 2 only -- launch at most this many one-wave workgroups (0 = one per 8x8 tile)
 void iso_launch_render(const IsoRenderParams& p, int variant, void* stream, void* startEvent, void* stopEvent, int waveCap);
 void iso_launch_render_gvdb(const IsoRenderParams& p, const IsoGvdbFrame& f, void* stream, void* startEvent, void* stopEvent);
+// diagnostics: variant 0 with per-tile clocks and step counts, out[tiles][6] (see iso_render_stats)
+void iso_launch_render_stats(const IsoRenderParams& p, long long* out, void* stream);
 // One wave on `stream` that spins until *resident has reached `target` (wrap-safe) or `timeoutUs` have passed.
 void iso_launch_gate(const unsigned* resident, unsigned target, int timeoutUs, void* stream);
 void iso_launch_brick_flags(const float* dense, int nx, int ny, int nz, int nbx, int nby, int nbz,
                             uint8_t* flag9, uint8_t* leaf, int* bbox6, unsigned int* maxbits, void* stream);
 void iso_launch_leaf_range(const float* dense, int nx, int ny, int nz, int nbx, int nby, int nbz, float* range, void* stream);
+void iso_launch_node_range(const uint8_t* leaf, const float* leafRange, int nbx, int nby, int nbz, const int org[3],
+                           int n1x, int n1y, int n1z, const int n1o[3], float* nodeRange, void* stream);
 void iso_launch_scatter_tables(int n, const long long* index, const int32_t* slotv, const uint8_t* leafv, const float* rangev,
                                int32_t* slot, uint8_t* leaf, float* range, void* stream);
 void iso_launch_brick_fill(const float* dense, int nx, int ny, int nz, int nbx, int nby, int nbz,

@@ -262,9 +262,11 @@ def test_load_grid_vbx_renders_like_dense(renderer, tmp_path):
 
 def test_leaf_range_skipping_is_exact_over_isovalues(renderer, oracle):
     """The ray-marcher steps over leaves whose value range (over everything a march through them can read) excludes
-    the isovalue.  That must never change a bit: sweep isovalues from the fringe to the core, several cameras, two
-    volumes -- hit mask bit-exact against the oracle (which marches every occupied leaf), the rest within 1e-4."""
-    for name, vol in (("ejecta64", V.ejecta(64)), ("cloud64", V.cloud(64))):
+    the isovalue, and whole 128^3 nodes none of whose leaves can be marched.  That must never change a bit: sweep
+    isovalues from the fringe to the core, several cameras, three volumes (the 160^3 one has 2x2x2 nodes, some of them
+    below the higher isovalues) -- hit mask bit-exact against the oracle (which marches every occupied leaf), the rest
+    within 1e-4."""
+    for name, vol in (("ejecta64", V.ejecta(64)), ("cloud64", V.cloud(64)), ("cloud160", V.cloud(160))):
         renderer.set_kernel_variant(0)
         renderer.load_dense(vol)
         ov = oracle.OracleVolume(vol)
