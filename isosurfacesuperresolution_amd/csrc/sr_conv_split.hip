@@ -90,6 +90,89 @@ __device__ __forceinline__ float buf_load(rsrc_t r, unsigned voff)
 
 __device__ __forceinline__ f32x16 mfma16(f16x8 a, f16x8 b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0); }
 
+// Epilogue shared by the split kernels: acc * 2^-S + bias, activation, residual / gate, store.  D row (cout) =
+// (reg & 3) + 8 * (reg >> 2) + 4 * h, column (pixel) = j.  The wide path transposes through the (idle) patch buffer.
+__device__ __forceinline__ void split_epilogue(const SplitConvParams& p, f32x16 (&acc)[2][2], u32x4* patch, int n, int oy0, int ox0, int co0,
+                                               bool second, int lane, int wave, int j, int h)
+{
+    const float unscale = reinterpret_cast<const float*>(p.wq)[1];          // 2^-S (header of the prepared weights)
+    const rsrc_t yrs = __builtin_amdgcn_make_buffer_rsrc(p.y + (size_t)n * p.yImage, 0, (int)((size_t)p.Cout * p.yPlane * 4), 0x00020000);
+    const rsrc_t rrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.residual ? p.residual + (size_t)n * p.rImage : p.y), 0,
+                                                         p.residual ? (int)((size_t)p.Cout * p.rPlane * 4) : 0, 0x00020000);
+    const int ox = ox0 + j;
+    float bv[2][16];                                                         // all bias values first: one latency, not 128
+#pragma unroll
+    for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+        for (int i = 0; i < 16; ++i)
+            bv[cb][i] = p.bias ? p.bias[min(co0 + cb * 32 + (i & 3) + 8 * (i >> 2) + 4 * h, p.Cout - 1)] : 0.0f;
+    if (p.dbg & 4) {
+    } else if (((p.W | p.yPlane | p.rPlane) & 3) == 0) {
+        // wide path: each wave transposes one output row (64 couts x 32 pixels) through 8 KB of the now idle patch, so
+        // that a lane owns 4 consecutive pixels of one channel and the stores are dwordx4 (4x fewer instructions)
+        float* tr = reinterpret_cast<float*>(patch) + wave * (64 * 32);
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
+            const int oy = oy0 + wave * 2 + r;
+#pragma unroll
+            for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    float v = acc[cb][r][i] * unscale + bv[cb][i];
+                    if (p.act == ISR_ACT_RELU) v = v > 0.f ? v : 0.f;
+                    else if (p.act == ISR_ACT_LEAKY) v = v > 0.f ? v : v * p.slope;
+                    tr[(cb * 32 + (i & 3) + 8 * (i >> 2) + 4 * h) * 32 + j] = v;
+                }
+            __builtin_amdgcn_s_waitcnt(0xC07F);                              // lgkmcnt(0): same-wave hand-off through LDS
+#pragma unroll
+            for (int t = 0; t < 8; ++t) {
+                const int q = lane + 64 * t;                                 // float4 index: cout = q / 8, pixel group = q % 8
+                const int co = co0 + (q >> 3), px = ox0 + (q & 7) * 4;
+                const bool ok = oy < p.H && px < p.W && co < p.Cout;
+                float4 v = reinterpret_cast<const float4*>(tr)[q];
+                const unsigned pixoff = (unsigned)(oy * p.W + px) * 4u;
+                if (p.residual) {
+                    const u32x4 rr = __builtin_amdgcn_raw_buffer_load_b128(rrs, (int)(ok ? pixoff + (unsigned)co * (unsigned)p.rPlane * 4u : BAD_OFFSET), 0, 0);
+                    const float4 rf = __builtin_bit_cast(float4, rr);
+                    if (p.act == ISR_ACT_GATE) {
+                        v.x = rf.x > 0.f ? v.x : 0.f; v.y = rf.y > 0.f ? v.y : 0.f;
+                        v.z = rf.z > 0.f ? v.z : 0.f; v.w = rf.w > 0.f ? v.w : 0.f;
+                    } else {
+                        v.x += rf.x; v.y += rf.y; v.z += rf.z; v.w += rf.w;
+                    }
+                }
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), yrs,
+                                                       (int)(ok ? pixoff + (unsigned)co * (unsigned)p.yPlane * 4u : BAD_OFFSET), 0, 0);
+            }
+            __builtin_amdgcn_s_waitcnt(0xC07F);                              // reads done before the next row overwrites the slab
+        }
+    } else {
+#pragma unroll
+    for (int cb = 0; cb < 2; ++cb) {
+        if (cb == 1 && !second) break;
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
+            const int oy = oy0 + wave * 2 + r;
+            const unsigned pix = (oy < p.H && ox < p.W) ? (unsigned)(oy * p.W + ox) * 4u : BAD_OFFSET;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const int co = co0 + cb * 32 + (i & 3) + 8 * (i >> 2) + 4 * h;
+                float v = acc[cb][r][i] * unscale + bv[cb][i];
+                if (p.act == ISR_ACT_RELU) v = v > 0.f ? v : 0.f;
+                else if (p.act == ISR_ACT_LEAKY) v = v > 0.f ? v : v * p.slope;
+                const bool ok = pix != BAD_OFFSET && co < p.Cout;
+                if (p.residual) {
+                    const float rv = buf_load(rrs, ok ? pix + (unsigned)co * (unsigned)p.rPlane * 4u : BAD_OFFSET);
+                    if (p.act == ISR_ACT_GATE) v = rv > 0.f ? v : 0.f; else v += rv;
+                }
+                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), yrs,
+                                                      ok ? (int)(pix + (unsigned)co * (unsigned)p.yPlane * 4u) : (int)BAD_OFFSET, 0, 0);
+            }
+        }
+    }
+    }
+}
+
 template <bool UPS>
 __global__ __launch_bounds__(S_THREADS, 2) void conv3x3_split_kernel(const SplitConvParams p)
 {
@@ -329,88 +412,429 @@ __global__ __launch_bounds__(S_THREADS, 2) void conv3x3_split_kernel(const Split
     }
 
     if (p.stamps) st2 = __builtin_amdgcn_s_memtime();
-    // ---- epilogue: D row (cout) = (reg & 3) + 8 * (reg >> 2) + 4 * h, column (pixel) = j ----------------------------
-    const float unscale = reinterpret_cast<const float*>(p.wq)[1];          // 2^-S (header of the prepared weights)
-    const rsrc_t yrs = __builtin_amdgcn_make_buffer_rsrc(p.y + (size_t)n * p.yImage, 0, (int)((size_t)p.Cout * p.yPlane * 4), 0x00020000);
-    const rsrc_t rrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.residual ? p.residual + (size_t)n * p.rImage : p.y), 0,
-                                                         p.residual ? (int)((size_t)p.Cout * p.rPlane * 4) : 0, 0x00020000);
-    const int ox = ox0 + j;
-    float bv[2][16];                                                         // all bias values first: one latency, not 128
-#pragma unroll
-    for (int cb = 0; cb < 2; ++cb)
-#pragma unroll
-        for (int i = 0; i < 16; ++i)
-            bv[cb][i] = p.bias ? p.bias[min(co0 + cb * 32 + (i & 3) + 8 * (i >> 2) + 4 * h, p.Cout - 1)] : 0.0f;
-    if (p.dbg & 4) {
-    } else if (((p.W | p.yPlane | p.rPlane) & 3) == 0) {
-        // wide path: each wave transposes one output row (64 couts x 32 pixels) through 8 KB of the now idle patch, so
-        // that a lane owns 4 consecutive pixels of one channel and the stores are dwordx4 (4x fewer instructions)
-        float* tr = reinterpret_cast<float*>(patch) + wave * (64 * 32);
-#pragma unroll
-        for (int r = 0; r < 2; ++r) {
-            const int oy = oy0 + wave * 2 + r;
-#pragma unroll
-            for (int cb = 0; cb < 2; ++cb)
-#pragma unroll
-                for (int i = 0; i < 16; ++i) {
-                    float v = acc[cb][r][i] * unscale + bv[cb][i];
-                    if (p.act == ISR_ACT_RELU) v = v > 0.f ? v : 0.f;
-                    else if (p.act == ISR_ACT_LEAKY) v = v > 0.f ? v : v * p.slope;
-                    tr[(cb * 32 + (i & 3) + 8 * (i >> 2) + 4 * h) * 32 + j] = v;
-                }
-            __builtin_amdgcn_s_waitcnt(0xC07F);                              // lgkmcnt(0): same-wave hand-off through LDS
-#pragma unroll
-            for (int t = 0; t < 8; ++t) {
-                const int q = lane + 64 * t;                                 // float4 index: cout = q / 8, pixel group = q % 8
-                const int co = co0 + (q >> 3), px = ox0 + (q & 7) * 4;
-                const bool ok = oy < p.H && px < p.W && co < p.Cout;
-                float4 v = reinterpret_cast<const float4*>(tr)[q];
-                const unsigned pixoff = (unsigned)(oy * p.W + px) * 4u;
-                if (p.residual) {
-                    const u32x4 rr = __builtin_amdgcn_raw_buffer_load_b128(rrs, (int)(ok ? pixoff + (unsigned)co * (unsigned)p.rPlane * 4u : BAD_OFFSET), 0, 0);
-                    const float4 rf = __builtin_bit_cast(float4, rr);
-                    if (p.act == ISR_ACT_GATE) {
-                        v.x = rf.x > 0.f ? v.x : 0.f; v.y = rf.y > 0.f ? v.y : 0.f;
-                        v.z = rf.z > 0.f ? v.z : 0.f; v.w = rf.w > 0.f ? v.w : 0.f;
-                    } else {
-                        v.x += rf.x; v.y += rf.y; v.z += rf.z; v.w += rf.w;
-                    }
-                }
-                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), yrs,
-                                                       (int)(ok ? pixoff + (unsigned)co * (unsigned)p.yPlane * 4u : BAD_OFFSET), 0, 0);
-            }
-            __builtin_amdgcn_s_waitcnt(0xC07F);                              // reads done before the next row overwrites the slab
-        }
-    } else {
-#pragma unroll
-    for (int cb = 0; cb < 2; ++cb) {
-        if (cb == 1 && !second) break;
-#pragma unroll
-        for (int r = 0; r < 2; ++r) {
-            const int oy = oy0 + wave * 2 + r;
-            const unsigned pix = (oy < p.H && ox < p.W) ? (unsigned)(oy * p.W + ox) * 4u : BAD_OFFSET;
-#pragma unroll
-            for (int i = 0; i < 16; ++i) {
-                const int co = co0 + cb * 32 + (i & 3) + 8 * (i >> 2) + 4 * h;
-                float v = acc[cb][r][i] * unscale + bv[cb][i];
-                if (p.act == ISR_ACT_RELU) v = v > 0.f ? v : 0.f;
-                else if (p.act == ISR_ACT_LEAKY) v = v > 0.f ? v : v * p.slope;
-                const bool ok = pix != BAD_OFFSET && co < p.Cout;
-                if (p.residual) {
-                    const float rv = buf_load(rrs, ok ? pix + (unsigned)co * (unsigned)p.rPlane * 4u : BAD_OFFSET);
-                    if (p.act == ISR_ACT_GATE) v = rv > 0.f ? v : 0.f; else v += rv;
-                }
-                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), yrs,
-                                                      ok ? (int)(pix + (unsigned)co * (unsigned)p.yPlane * 4u) : (int)BAD_OFFSET, 0, 0);
-            }
-        }
-    }
-    }
+    split_epilogue(p, acc, patch, n, oy0, ox0, co0, second, lane, wave, j, h);
     if (p.stamps && tid == 0) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         const unsigned long long st3 = __builtin_amdgcn_s_memtime();
         unsigned long long* o = p.stamps + (size_t)blockIdx.x * 4;
         o[0] = st0; o[1] = st1; o[2] = st2; o[3] = st3;
+    }
+}
+
+// One k-step of MFMAs: 16 input channels x 9 taps x (2 channel blocks x 2 rows) x 3 products.  wl: this lane's weight
+// units of the k-step in LDS (hi; lo at + S_WPART), bl: this lane's patch units (hi; lo at + S_PART).
+__device__ __forceinline__ void split_kstep(f32x16 (&acc)[2][2], const u32x4* wl, const u32x4* bl, bool second)
+{
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap) {
+        const int dy = tap / 3, dx = tap - dy * 3;
+        const f16x8 a0h = __builtin_bit_cast(f16x8, wl[tap * 128]);
+        const f16x8 a0l = __builtin_bit_cast(f16x8, wl[S_WPART + tap * 128]);
+        const f16x8 a1h = __builtin_bit_cast(f16x8, wl[tap * 128 + (second ? 32 : 0)]);
+        const f16x8 a1l = __builtin_bit_cast(f16x8, wl[S_WPART + tap * 128 + (second ? 32 : 0)]);
+        const f16x8 a0s = a0h * (_Float16)0.00048828125f;                   // w_hi 2^-11: partner of the scaled x_lo'
+        const f16x8 a1s = a1h * (_Float16)0.00048828125f;
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
+            const f16x8 bh = __builtin_bit_cast(f16x8, bl[(r + dy) * SP_W + dx]);
+            const f16x8 bo = __builtin_bit_cast(f16x8, bl[S_PART + (r + dy) * SP_W + dx]);
+            // the two small cross terms first, then the leading term
+            acc[0][r] = mfma16(a0l, bh, acc[0][r]);
+            acc[0][r] = mfma16(a0s, bo, acc[0][r]);
+            acc[0][r] = mfma16(a0h, bh, acc[0][r]);
+            if (second) {
+                acc[1][r] = mfma16(a1l, bh, acc[1][r]);
+                acc[1][r] = mfma16(a1s, bo, acc[1][r]);
+                acc[1][r] = mfma16(a1h, bh, acc[1][r]);
+            }
+        }
+    }
+}
+
+// ---- the streaming form: persistent workgroups, the next k-step's operands in flight under the MFMAs -----------------
+// In conv3x3_split_kernel a workgroup's life is: stage (global loads -> convert -> LDS), barrier, MFMAs, ..., epilogue --
+// only 20 % of it issues MFMAs and the staging latency is covered by nothing but the CU's other workgroup.  Here a
+// workgroup walks a list of tiles as ONE pipeline of 16-channel k-steps: the patch buffer is two k-step slots; while the
+// MFMAs of k-step s read slot s % 2, the activations (one 8-channel x 4-pixel unit per thread) and the weights of k-step
+// s + 1 -- of this tile or the first of the next one -- are in flight from HBM / L2 into registers, and are split and
+// parked into the other slot after the barrier that ends k-step s.  Only a workgroup's very first k-step waits for memory.
+// Plain (non-upsampling) layers whose rows allow aligned dwordx4 staging (p.quads).
+constexpr int SQ_QPR = (ST_W + 8) / 4;                                       // 10 quads per patch row
+constexpr int SQ_UNITS = 2 * SP_H * SQ_QPR;                                  // 200 (channel group, patch row, quad) units per k-step
+constexpr int SQ_SLOT = 2 * SP_PIX;                                          // 16-byte units of one k-step slot of the hi (or lo) patch
+
+__global__ __launch_bounds__(S_THREADS, 2) void conv3x3_split_stream_kernel(const SplitConvParams p)
+{
+    extern __shared__ u32x4 patch[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int j = lane & 31, h = lane >> 5;
+    u32x4* wbuf = patch + S_PUNITS;
+    // the tile list: every XCD (= every L2) owns a contiguous range, its workgroups take the tiles of the range round
+    // robin, so that workgroups running at the same time on one XCD work on neighbouring tiles (shared halo lines)
+    const int ntiles = p.N * p.tilesY * p.tilesX * p.cgroups;
+    const int xcd = blockIdx.x & 7, jw = blockIdx.x >> 3;
+    const int njw = ((int)gridDim.x >> 3) + (xcd < ((int)gridDim.x & 7) ? 1 : 0);
+    const int tq = ntiles >> 3, trm = ntiles & 7;
+    const int tstart = xcd < trm ? xcd * (tq + 1) : trm * (tq + 1) + (xcd - trm) * tq;
+    const int tcount = tq + (xcd < trm ? 1 : 0);
+    if (jw >= tcount) return;
+    const unsigned planeBytes = (unsigned)p.xPlane * 4u;
+
+    struct Tile { int n, oy0, ox0, co0; };
+    auto decode = [&](int t) {
+        int b = tstart + t;
+        Tile r;
+        r.co0 = (b % p.cgroups) * 64; b /= p.cgroups;
+        r.ox0 = (b % p.tilesX) * ST_W; b /= p.tilesX;
+        r.oy0 = (b % p.tilesY) * ST_H; r.n = b / p.tilesY;
+        return r;
+    };
+    // this thread's staging unit (the same for every tile and k-step): channel group ug of the k-step, patch row ur, quad uq
+    const bool staging = tid < SQ_UNITS;
+    const int ug = tid / (SP_H * SQ_QPR), urem = tid - ug * (SP_H * SQ_QPR);
+    const int ur = urem / SQ_QPR, uq = urem - ur * SQ_QPR;
+    u32x4 v[8];
+    auto issue_loads = [&](const Tile& t, int ks) {
+        const rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.x + (size_t)t.n * p.xImage), 0,
+                                                             (int)((size_t)p.Cin * p.xPlane * 4), 0x00020000);
+        const int iy = t.oy0 + ur - 1, ix = t.ox0 - 4 + 4 * uq;
+        const bool ok = staging && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W && !(p.dbg & 2);
+        const unsigned base = (unsigned)(ks * 16 + ug * 8) * planeBytes + (unsigned)(iy * p.W + ix) * 4u;
+#pragma unroll
+        for (int e = 0; e < 8; ++e)
+            v[e] = __builtin_amdgcn_raw_buffer_load_b128(xrs, (int)(ok ? base + (unsigned)e * planeBytes : BAD_OFFSET), 0, 0);
+    };
+    auto park_loads = [&](int slot) {
+        if (!staging) return;
+        f16x8 h0, h1, h2, h3, l0, l1, l2, l3;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const float4 f = __builtin_bit_cast(float4, v[e]);
+            _Float16 a, b;
+            split16x(f.x, a, b); h0[e] = a; l0[e] = b;
+            split16x(f.y, a, b); h1[e] = a; l1[e] = b;
+            split16x(f.z, a, b); h2[e] = a; l2[e] = b;
+            split16x(f.w, a, b); h3[e] = a; l3[e] = b;
+        }
+        u32x4* dst = patch + slot * SQ_SLOT + ug * SP_PIX + ur * SP_W + 4 * uq - 3;
+        // quad 0 contributes only its last pixel (patch column 0), quad 9 only its first (column 33)
+        if (uq > 0) { dst[0] = __builtin_bit_cast(u32x4, h0); dst[S_PART] = __builtin_bit_cast(u32x4, l0); }
+        if (uq > 0 && uq < SQ_QPR - 1) {
+            dst[1] = __builtin_bit_cast(u32x4, h1); dst[S_PART + 1] = __builtin_bit_cast(u32x4, l1);
+            dst[2] = __builtin_bit_cast(u32x4, h2); dst[S_PART + 2] = __builtin_bit_cast(u32x4, l2);
+        }
+        if (uq < SQ_QPR - 1) { dst[3] = __builtin_bit_cast(u32x4, h3); dst[S_PART + 3] = __builtin_bit_cast(u32x4, l3); }
+    };
+    u32x4 wreg[9];
+    auto wfetch = [&](int ks, int co0) {
+        const int couts = min(64, p.coutPad - co0);
+#pragma unroll
+        for (int i = 0; i < 9; ++i) {
+            const int q = tid + i * S_THREADS;
+            const int part = q / S_WPART, rem = q - part * S_WPART;
+            const int tap = rem >> 7, hh = (rem >> 6) & 1, c = rem & 63;
+            if (c < couts) wreg[i] = p.wq[1 + (size_t)(((tap * p.ksteps + ks) * 2 + part) * 2 + hh) * p.coutPad + co0 + c];
+        }
+    };
+    auto wpark = [&](int co0) {
+        const int couts = min(64, p.coutPad - co0);
+#pragma unroll
+        for (int i = 0; i < 9; ++i) {
+            const int q = tid + i * S_THREADS;
+            if ((q & 63) < couts) wbuf[q] = wreg[i];
+        }
+    };
+
+    Tile cur = decode(jw);
+    issue_loads(cur, 0);
+    wfetch(0, cur.co0);
+    park_loads(0);
+    wpark(cur.co0);
+    __syncthreads();
+    int slot = 0;                                                            // patch slot of the k-step about to be multiplied
+    for (int t = jw; t < tcount; t += njw) {
+        const bool more = t + njw < tcount;
+        Tile nxt = cur;
+        if (more) nxt = decode(t + njw);
+        const bool second = cur.co0 + 32 < p.coutPad;
+        f32x16 acc[2][2];
+#pragma unroll
+        for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+            for (int r = 0; r < 2; ++r)
+#pragma unroll
+                for (int i = 0; i < 16; ++i) acc[cb][r][i] = 0.0f;
+#pragma unroll 1
+        for (int ks = 0; ks + 1 < p.ksteps; ++ks) {
+            // operands of the next k-step travel under these MFMAs
+            issue_loads(cur, ks + 1);
+            wfetch(ks + 1, cur.co0);
+            if (!(p.dbg & 1)) split_kstep(acc, wbuf + h * 64 + j, patch + slot * SQ_SLOT + h * SP_PIX + (wave * 2) * SP_W + j, second);
+            __syncthreads();                                                 // slot ^ 1 (read by k-step ks - 1) and the weight buffer are free
+            park_loads(slot ^ 1);
+            wpark(cur.co0);
+            __syncthreads();
+            slot ^= 1;
+        }
+        // last k-step of the tile: the first k-step of the next tile travels under it
+        if (more) {
+            issue_loads(nxt, 0);
+            wfetch(0, nxt.co0);
+        }
+        if (!(p.dbg & 1)) split_kstep(acc, wbuf + h * 64 + j, patch + slot * SQ_SLOT + h * SP_PIX + (wave * 2) * SP_W + j, second);
+        // the epilogue transposes through the patch slot that was just multiplied; the other slot and the weight buffer
+        // take the next tile's first k-step meanwhile (their last readers passed the barrier)
+        __syncthreads();
+        if (more) { park_loads(slot ^ 1); wpark(nxt.co0); }
+        split_epilogue(p, acc, patch + slot * SQ_SLOT, cur.n, cur.oy0, cur.ox0, cur.co0, second, lane, wave, j, h);
+        __syncthreads();
+        slot ^= 1;
+        cur = nxt;
+    }
+}
+
+// ---- the wide form: one 512-thread workgroup per CU, hand-pipelined operand reads ------------------------------------
+// (isrDebugSetSplitAlgo(2); not the default: measured 0.59 vs 0.545 ms on the 1080p layer.  It exists because it answered a
+// question: with the fragment reads pipelined by hand and one barrier per k-step the layer does not get faster, because at
+// 1080p the layer is POWER bound -- rocm-smi during the streaming kernel: 1333 W package power, shader clock down from 2.39
+// to 2.05 GHz; MFMAs alone: 1010 W at 2.39 GHz.  Dynamic energy per launch 0.60 J, of which the MFMAs and their operand
+// reads are 0.26 J: at the board's 1.4 kW limit that energy cannot be spent in less than 0.52 ms, and the kernel takes 0.55.)
+// What the two kernels above leave on the table is inside the MFMA loop: hipcc sinks every ds_read to just in front of
+// the MFMAs that use it, so each tap exposes the LDS latency two or three times and the loop runs at ~55 % of the matrix
+// pipe (MFMAs-only ablation of a 1080p layer: 0.346 ms for 0.182 ms of MFMA issue).  Double-buffering the fragments by
+// hand needs registers the 256-thread kernels do not have (weights + activations of the next k-step in flight, 9 + 8
+// x 4 registers per thread).  With 512 threads per workgroup -- tile 16 x 32 pixels x 64 channels, wave = one 32-channel
+// block x 4 rows -- the per-thread staging halves, and one workgroup per CU has the LDS for TWO weight buffers:
+//   * LDS: activations 2 k-step slots x (hi | lo) x 2 groups x 18 x 34 pixels x 16 B = 78 336 B, weights 2 x 36 864 B;
+//   * per k-step ONE barrier: operands of k-step s + 1 are loaded at the start of k-step s, split / parked into the other
+//     slot and the other weight buffer two thirds through its MFMAs (their last readers passed the previous barrier);
+//   * per (tap, row) step: the B fragments of the next step and, once per tap, the A fragments of the next tap are read
+//     before the step's three MFMAs (sched_barrier fences keep hipcc from sinking them).
+constexpr int WT_H = 16, WP_H = WT_H + 2, WP_PIX = WP_H * SP_W;              // 18 x 34 = 612 patch pixels
+constexpr int W_SLOT = 2 * WP_PIX;                                           // units of one k-step slot, one part (2 channel groups)
+constexpr int W_PART = 2 * W_SLOT;                                           // hi (or lo) part: two slots
+constexpr int W_PUNITS = 2 * W_PART;                                         // 4896 units = 78 336 B
+constexpr int W_THREADS = 512;
+constexpr int W_UNITS = 2 * WP_H * SQ_QPR;                                   // 360 staging units per k-step
+constexpr int W_LDS_BYTES = (W_PUNITS + 2 * S_WUNITS) * 16;                  // 78 336 + 73 728 = 152 064
+
+__global__ __launch_bounds__(W_THREADS, 1) void conv3x3_split_wide_kernel(const SplitConvParams p)
+{
+    extern __shared__ u32x4 patch[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int j = lane & 31, h = lane >> 5;
+    const int cb = wave & 1, rg = wave >> 1;                                 // this wave: channel block cb, rows 4 rg .. 4 rg + 3
+    u32x4* wbuf = patch + W_PUNITS;
+    const int ntiles = p.N * p.tilesY * p.tilesX * p.cgroups;
+    const int xcd = blockIdx.x & 7, jw = blockIdx.x >> 3;
+    const int njw = ((int)gridDim.x >> 3) + (xcd < ((int)gridDim.x & 7) ? 1 : 0);
+    const int tq = ntiles >> 3, trm = ntiles & 7;
+    const int tstart = xcd < trm ? xcd * (tq + 1) : trm * (tq + 1) + (xcd - trm) * tq;
+    const int tcount = tq + (xcd < trm ? 1 : 0);
+    if (jw >= tcount) return;
+    const unsigned planeBytes = (unsigned)p.xPlane * 4u;
+    const float unscale = reinterpret_cast<const float*>(p.wq)[1];          // 2^-S (header of the prepared weights)
+
+    struct Tile { int n, oy0, ox0, co0; };
+    auto decode = [&](int t) {
+        int b = tstart + t;
+        Tile r;
+        r.co0 = (b % p.cgroups) * 64; b /= p.cgroups;
+        r.ox0 = (b % p.tilesX) * ST_W; b /= p.tilesX;
+        r.oy0 = (b % p.tilesY) * WT_H; r.n = b / p.tilesY;
+        return r;
+    };
+    const bool staging = tid < W_UNITS;
+    const int ug = tid / (WP_H * SQ_QPR), urem = tid - ug * (WP_H * SQ_QPR);
+    const int ur = urem / SQ_QPR, uq = urem - ur * SQ_QPR;
+    u32x4 v[8];
+    auto issue_loads = [&](const Tile& t, int ks) {
+        const rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.x + (size_t)t.n * p.xImage), 0,
+                                                             (int)((size_t)p.Cin * p.xPlane * 4), 0x00020000);
+        const int iy = t.oy0 + ur - 1, ix = t.ox0 - 4 + 4 * uq;
+        const bool ok = staging && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W && !(p.dbg & 2);
+        const unsigned base = (unsigned)(ks * 16 + ug * 8) * planeBytes + (unsigned)(iy * p.W + ix) * 4u;
+#pragma unroll
+        for (int e = 0; e < 8; ++e)
+            v[e] = __builtin_amdgcn_raw_buffer_load_b128(xrs, (int)(ok ? base + (unsigned)e * planeBytes : BAD_OFFSET), 0, 0);
+    };
+    auto park_loads = [&](int slot) {
+        if (!staging) return;
+        f16x8 h0, h1, h2, h3, l0, l1, l2, l3;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const float4 f = __builtin_bit_cast(float4, v[e]);
+            _Float16 a, b;
+            split16x(f.x, a, b); h0[e] = a; l0[e] = b;
+            split16x(f.y, a, b); h1[e] = a; l1[e] = b;
+            split16x(f.z, a, b); h2[e] = a; l2[e] = b;
+            split16x(f.w, a, b); h3[e] = a; l3[e] = b;
+        }
+        u32x4* dst = patch + slot * W_SLOT + ug * WP_PIX + ur * SP_W + 4 * uq - 3;
+        if (uq > 0) { dst[0] = __builtin_bit_cast(u32x4, h0); dst[W_PART] = __builtin_bit_cast(u32x4, l0); }
+        if (uq > 0 && uq < SQ_QPR - 1) {
+            dst[1] = __builtin_bit_cast(u32x4, h1); dst[W_PART + 1] = __builtin_bit_cast(u32x4, l1);
+            dst[2] = __builtin_bit_cast(u32x4, h2); dst[W_PART + 2] = __builtin_bit_cast(u32x4, l2);
+        }
+        if (uq < SQ_QPR - 1) { dst[3] = __builtin_bit_cast(u32x4, h3); dst[W_PART + 3] = __builtin_bit_cast(u32x4, l3); }
+    };
+    u32x4 wreg[5];
+    auto wfetch = [&](int ks, int co0) {
+        const int couts = min(64, p.coutPad - co0);
+#pragma unroll
+        for (int i = 0; i < 5; ++i) {
+            const int q = tid + i * W_THREADS;
+            const int part = q / S_WPART, rem = q - part * S_WPART;
+            const int tap = rem >> 7, hh = (rem >> 6) & 1, c = rem & 63;
+            if (q < S_WUNITS && c < couts) wreg[i] = p.wq[1 + (size_t)(((tap * p.ksteps + ks) * 2 + part) * 2 + hh) * p.coutPad + co0 + c];
+        }
+    };
+    auto wpark = [&](int buf, int co0) {
+        const int couts = min(64, p.coutPad - co0);
+#pragma unroll
+        for (int i = 0; i < 5; ++i) {
+            const int q = tid + i * W_THREADS;
+            if (q < S_WUNITS && (q & 63) < couts) wbuf[buf * S_WUNITS + q] = wreg[i];
+        }
+    };
+
+    f32x16 acc[4];
+    // one k-step of this wave: 9 taps x 4 rows x 3 products, fragments double-buffered by hand; `mid` runs after two
+    // thirds of the steps (the parking of the next k-step's operands)
+    auto kstep = [&](int slot, int buf, bool active, auto&& mid) {
+        const u32x4* wl = wbuf + buf * S_WUNITS + h * 64 + cb * 32 + j;
+        const u32x4* bl = patch + slot * W_SLOT + h * WP_PIX + (4 * rg) * SP_W + j;
+        f16x8 ah[2], al[2], bh[2], bo[2];
+        if (active) {
+            ah[0] = __builtin_bit_cast(f16x8, wl[0]);
+            al[0] = __builtin_bit_cast(f16x8, wl[S_WPART]);
+            bh[0] = __builtin_bit_cast(f16x8, bl[0]);
+            bo[0] = __builtin_bit_cast(f16x8, bl[W_PART]);
+        }
+        f16x8 as;
+#pragma unroll
+        for (int i = 0; i < 36; ++i) {
+            const int tap = i >> 2, r = i & 3;
+            if (active) {
+                if (i + 1 < 36) {                                            // B fragments of the next (tap, row) step
+                    const int t1 = (i + 1) >> 2, r1 = (i + 1) & 3;
+                    const int off = (r1 + t1 / 3) * SP_W + (t1 % 3);
+                    bh[(i + 1) & 1] = __builtin_bit_cast(f16x8, bl[off]);
+                    bo[(i + 1) & 1] = __builtin_bit_cast(f16x8, bl[W_PART + off]);
+                }
+                if (r == 0 && tap + 1 < 9) {                                 // A fragments of the next tap
+                    ah[(tap + 1) & 1] = __builtin_bit_cast(f16x8, wl[(tap + 1) * 128]);
+                    al[(tap + 1) & 1] = __builtin_bit_cast(f16x8, wl[S_WPART + (tap + 1) * 128]);
+                }
+                if (r == 0) as = ah[tap & 1] * (_Float16)0.00048828125f;     // w_hi 2^-11: partner of the scaled x_lo'
+                __builtin_amdgcn_sched_barrier(0);
+                acc[r] = mfma16(al[tap & 1], bh[i & 1], acc[r]);
+                acc[r] = mfma16(as, bo[i & 1], acc[r]);
+                acc[r] = mfma16(ah[tap & 1], bh[i & 1], acc[r]);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            if (i == 23) mid();
+        }
+    };
+
+    Tile cur = decode(jw);
+    issue_loads(cur, 0);
+    wfetch(0, cur.co0);
+    park_loads(0);
+    wpark(0, cur.co0);
+    __syncthreads();
+    int slot = 0;                                                            // patch slot / weight buffer of the k-step about to be multiplied
+    for (int t = jw; t < tcount; t += njw) {
+        const bool more = t + njw < tcount;
+        Tile nxt = cur;
+        if (more) nxt = decode(t + njw);
+        const bool active = cur.co0 + cb * 32 < p.coutPad && !(p.dbg & 1);
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[r][i] = 0.0f;
+#pragma unroll 1
+        for (int ks = 0; ks + 1 < p.ksteps; ++ks) {
+            issue_loads(cur, ks + 1);                                        // operands of the next k-step travel under these MFMAs
+            wfetch(ks + 1, cur.co0);
+            kstep(slot, slot, active, [&]() { park_loads(slot ^ 1); wpark(slot ^ 1, cur.co0); });
+            __syncthreads();
+            slot ^= 1;
+        }
+        if (more) {                                                          // last k-step: the next tile's first one travels under it
+            issue_loads(nxt, 0);
+            wfetch(0, nxt.co0);
+        }
+        kstep(slot, slot, active, [&]() { if (more) { park_loads(slot ^ 1); wpark(slot ^ 1, nxt.co0); } });
+        __syncthreads();
+        // ---- epilogue: D row (cout) = (reg & 3) + 8 * (reg >> 2) + 4 * h, column (pixel) = j; each wave transposes one
+        // output row (32 couts x 32 pixels) at a time through 4 KB of the patch slot that was just multiplied
+        if (cur.co0 + cb * 32 < p.coutPad && !(p.dbg & 4)) {
+            const rsrc_t yrs = __builtin_amdgcn_make_buffer_rsrc(p.y + (size_t)cur.n * p.yImage, 0, (int)((size_t)p.Cout * p.yPlane * 4), 0x00020000);
+            const rsrc_t rrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.residual ? p.residual + (size_t)cur.n * p.rImage : p.y), 0,
+                                                                 p.residual ? (int)((size_t)p.Cout * p.rPlane * 4) : 0, 0x00020000);
+            float bv[16];
+#pragma unroll
+            for (int i = 0; i < 16; ++i)
+                bv[i] = p.bias ? p.bias[min(cur.co0 + cb * 32 + (i & 3) + 8 * (i >> 2) + 4 * h, p.Cout - 1)] : 0.0f;
+            float* tr = reinterpret_cast<float*>(patch + (wave >> 2) * W_PART + slot * W_SLOT) + (wave & 3) * (32 * 32);
+            const bool wide = ((p.W | p.yPlane | p.rPlane) & 3) == 0;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int oy = cur.oy0 + 4 * rg + r;
+                if (wide) {
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) {
+                        float val = acc[r][i] * unscale + bv[i];
+                        if (p.act == ISR_ACT_RELU) val = val > 0.f ? val : 0.f;
+                        else if (p.act == ISR_ACT_LEAKY) val = val > 0.f ? val : val * p.slope;
+                        tr[((i & 3) + 8 * (i >> 2) + 4 * h) * 32 + j] = val;
+                    }
+                    __builtin_amdgcn_s_waitcnt(0xC07F);                      // lgkmcnt(0): same-wave hand-off through LDS
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        const int q = lane + 64 * k;                         // float4 index: cout = q / 8, pixel group = q % 8
+                        const int co = cur.co0 + cb * 32 + (q >> 3), px = cur.ox0 + (q & 7) * 4;
+                        const bool ok = oy < p.H && px < p.W && co < p.Cout;
+                        float4 val = reinterpret_cast<const float4*>(tr)[q];
+                        const unsigned pixoff = (unsigned)(oy * p.W + px) * 4u;
+                        if (p.residual) {
+                            const u32x4 rr = __builtin_amdgcn_raw_buffer_load_b128(rrs, (int)(ok ? pixoff + (unsigned)co * (unsigned)p.rPlane * 4u : BAD_OFFSET), 0, 0);
+                            const float4 rf = __builtin_bit_cast(float4, rr);
+                            if (p.act == ISR_ACT_GATE) {
+                                val.x = rf.x > 0.f ? val.x : 0.f; val.y = rf.y > 0.f ? val.y : 0.f;
+                                val.z = rf.z > 0.f ? val.z : 0.f; val.w = rf.w > 0.f ? val.w : 0.f;
+                            } else {
+                                val.x += rf.x; val.y += rf.y; val.z += rf.z; val.w += rf.w;
+                            }
+                        }
+                        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, val), yrs,
+                                                               (int)(ok ? pixoff + (unsigned)co * (unsigned)p.yPlane * 4u : BAD_OFFSET), 0, 0);
+                    }
+                    __builtin_amdgcn_s_waitcnt(0xC07F);                      // reads done before the next row overwrites the slab
+                } else {
+                    const int ox = cur.ox0 + j;
+                    const unsigned pix = (oy < p.H && ox < p.W) ? (unsigned)(oy * p.W + ox) * 4u : BAD_OFFSET;
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) {
+                        const int co = cur.co0 + cb * 32 + (i & 3) + 8 * (i >> 2) + 4 * h;
+                        float val = acc[r][i] * unscale + bv[i];
+                        if (p.act == ISR_ACT_RELU) val = val > 0.f ? val : 0.f;
+                        else if (p.act == ISR_ACT_LEAKY) val = val > 0.f ? val : val * p.slope;
+                        const bool ok = pix != BAD_OFFSET && co < p.Cout;
+                        if (p.residual) {
+                            const float rv = buf_load(rrs, ok ? pix + (unsigned)co * (unsigned)p.rPlane * 4u : BAD_OFFSET);
+                            if (p.act == ISR_ACT_GATE) val = rv > 0.f ? val : 0.f; else val += rv;
+                        }
+                        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, val), yrs,
+                                                              ok ? (int)(pix + (unsigned)co * (unsigned)p.yPlane * 4u) : (int)BAD_OFFSET, 0, 0);
+                    }
+                }
+            }
+        }
+        __syncthreads();                                                     // the scratch is a patch slot: done before the next k-step parks into it
+        slot ^= 1;
+        cur = nxt;
     }
 }
 
@@ -470,11 +894,13 @@ __global__ void prepare_weights_split_kernel(const float* __restrict__ w, u32x4*
 
 static unsigned long long* g_split_stamps = nullptr;
 static int g_split_dbg = 0;
+static int g_split_algo = 1;      // plain layers: 1 persistent streaming kernel (default), 2 wide 512-thread kernel, 0 one workgroup per tile
 
 extern "C" {
 
 void isrDebugSetSplitStampBuffer(unsigned long long* buf) { g_split_stamps = buf; }   // not part of the public header
 void isrDebugSetSplitAblation(int bits) { g_split_dbg = bits; }
+void isrDebugSetSplitAlgo(int a) { g_split_algo = a; }
 
 long long isrConvSplitWeightBytes(int Cin, int Cout)
 {
@@ -532,6 +958,41 @@ int isrConv3x3ForwardSplit(const float* x, const void* wq, const float* bias, co
     const dim3 grid((unsigned)nwg), block(S_THREADS);
     hipStream_t s = (hipStream_t)stream;
     hipEvent_t e0 = nullptr, e1 = nullptr;
+    if (!upsample2x && p.quads && !g_split_stamps && g_split_algo == 2) {
+        // wide form: one 512-thread workgroup per CU, 16 x 32 tiles, hand-pipelined fragment reads
+        static int cus = 0;
+        if (!cus) {
+            int dev = 0;
+            (void)hipGetDevice(&dev);
+            if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
+            (void)hipFuncSetAttribute((const void*)conv3x3_split_wide_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, W_LDS_BYTES);
+        }
+        p.tilesY = (H + WT_H - 1) / WT_H;
+        const long long ntiles = (long long)N * p.tilesX * p.tilesY * p.cgroups;
+        const long long want = ntiles < cus ? ((ntiles + 7) / 8) * 8 : cus;
+        isr_profile_record(ISR_VARIANT_SPLIT, 2.0 * 9 * Cin * Cout * (double)N * H * W, &e0, &e1);
+        const dim3 pgrid((unsigned)want), wblock(W_THREADS);
+        if (e0 || e1) hipExtLaunchKernelGGL(conv3x3_split_wide_kernel, pgrid, wblock, W_LDS_BYTES, s, e0, e1, 0, p);
+        else hipLaunchKernelGGL(conv3x3_split_wide_kernel, pgrid, wblock, W_LDS_BYTES, s, p);
+        return hipGetLastError() == hipSuccess ? 0 : -2;
+    }
+    if (!upsample2x && p.quads && !g_split_stamps && g_split_algo == 1) {
+        // persistent form: two workgroups per CU walk the tile list with the next chunk's loads in flight under the MFMAs
+        static int slots = 0;
+        if (!slots) {
+            int dev = 0, cus = 0;
+            (void)hipGetDevice(&dev);
+            if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
+            slots = 2 * cus;
+            (void)hipFuncSetAttribute((const void*)conv3x3_split_stream_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, S_LDS_BYTES);
+        }
+        const long long want = nwg < slots ? ((nwg + 7) / 8) * 8 : slots;
+        isr_profile_record(ISR_VARIANT_SPLIT, 2.0 * 9 * Cin * Cout * (double)N * H * W, &e0, &e1);
+        const dim3 pgrid((unsigned)want);
+        if (e0 || e1) hipExtLaunchKernelGGL(conv3x3_split_stream_kernel, pgrid, block, S_LDS_BYTES, s, e0, e1, 0, p);
+        else hipLaunchKernelGGL(conv3x3_split_stream_kernel, pgrid, block, S_LDS_BYTES, s, p);
+        return hipGetLastError() == hipSuccess ? 0 : -2;
+    }
     // algorithmic flops of the convolution (2 * 9 * Cin * Cout per output pixel), not the 3x matrix flops spent on it
     isr_profile_record(upsample2x ? ISR_VARIANT_SPLIT_UPS : ISR_VARIANT_SPLIT, 2.0 * 9 * Cin * Cout * (double)N * H * W, &e0, &e1);
     if (upsample2x) {

@@ -10,6 +10,7 @@ e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=Tr
 lib = ops._sr()
 lib.isrDebugSetSplitStampBuffer.argtypes = [ctypes.c_void_p]
 lib.isrDebugSetSplitAblation.argtypes = [ctypes.c_int]
+lib.isrDebugSetSplitAlgo.argtypes = [ctypes.c_int]
 
 
 def timed(fn, n=20):
@@ -33,6 +34,14 @@ with torch.no_grad():
         res["fp32"] = timed(lambda: ops.conv3x3(x, wt, b, act='relu', upsample2x=ups))
         ops.SPLIT_F16 = True
         res["split"] = timed(lambda: ops.conv3x3_split(x, wt, b, act='relu', upsample2x=ups))
+        if not ups:      # one workgroup per tile (no prefetch) vs the persistent streaming kernel, same process
+            lib.isrDebugSetSplitAlgo(0)
+            res["split_tile"] = timed(lambda: ops.conv3x3_split(x, wt, b, act='relu'))
+            lib.isrDebugSetSplitAlgo(1)
+            res["split_stream"] = timed(lambda: ops.conv3x3_split(x, wt, b, act='relu'))
+            lib.isrDebugSetSplitAlgo(2)
+            print("   plain layer: one workgroup per tile %.3f ms, persistent streaming %.3f ms, wide (512 threads, pipelined reads) %.3f ms" % (
+                res["split_tile"], res["split_stream"], res["split"]))
         res["f16"] = timed(lambda: ops.conv3x3_f16(x, wt, b, act='relu', upsample2x=ups))
         nwg = ((H + 7) // 8) * ((W + 31) // 32) * ((cout + 63) // 64)
         buf = torch.zeros(nwg * 4, dtype=torch.int64, device='cuda')
