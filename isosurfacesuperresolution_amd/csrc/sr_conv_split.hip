@@ -582,12 +582,16 @@ __global__ __launch_bounds__(S_THREADS, 2) void conv3x3_split_stream_kernel(cons
             wfetch(0, nxt.co0);
         }
         if (!(p.dbg & 1)) split_kstep(acc, wbuf + h * 64 + j, patch + slot * SQ_SLOT + h * SP_PIX + (wave * 2) * SP_W + j, second);
-        // the epilogue transposes through the patch slot that was just multiplied; the other slot and the weight buffer
-        // take the next tile's first k-step meanwhile (their last readers passed the barrier)
+        // the epilogue transposes through the whole (now idle) patch buffer -- 4 x 8 KB, more than one k-step slot -- so the
+        // next tile's first k-step stays in registers until it is done
         __syncthreads();
-        if (more) { park_loads(slot ^ 1); wpark(nxt.co0); }
-        split_epilogue(p, acc, patch + slot * SQ_SLOT, cur.n, cur.oy0, cur.ox0, cur.co0, second, lane, wave, j, h);
+        split_epilogue(p, acc, patch, cur.n, cur.oy0, cur.ox0, cur.co0, second, lane, wave, j, h);
         __syncthreads();
+        if (more) {
+            park_loads(slot ^ 1);
+            wpark(nxt.co0);
+            __syncthreads();
+        }
         slot ^= 1;
         cur = nxt;
     }
@@ -894,6 +898,7 @@ __global__ void prepare_weights_split_kernel(const float* __restrict__ w, u32x4*
 
 static unsigned long long* g_split_stamps = nullptr;
 static int g_split_dbg = 0;
+static int g_split_slots = 0;     // tests: cap on the persistent kernels' grid (0 = two / one workgroup per CU)
 static int g_split_algo = 1;      // plain layers: 1 persistent streaming kernel (default), 2 wide 512-thread kernel, 0 one workgroup per tile
 
 extern "C" {
@@ -901,6 +906,7 @@ extern "C" {
 void isrDebugSetSplitStampBuffer(unsigned long long* buf) { g_split_stamps = buf; }   // not part of the public header
 void isrDebugSetSplitAblation(int bits) { g_split_dbg = bits; }
 void isrDebugSetSplitAlgo(int a) { g_split_algo = a; }
+void isrDebugSetSplitSlots(int n) { g_split_slots = n; }
 
 long long isrConvSplitWeightBytes(int Cin, int Cout)
 {
@@ -969,7 +975,8 @@ int isrConv3x3ForwardSplit(const float* x, const void* wq, const float* bias, co
         }
         p.tilesY = (H + WT_H - 1) / WT_H;
         const long long ntiles = (long long)N * p.tilesX * p.tilesY * p.cgroups;
-        const long long want = ntiles < cus ? ((ntiles + 7) / 8) * 8 : cus;
+        const int cap = g_split_slots > 0 ? g_split_slots : cus;
+        const long long want = ntiles < cap ? ((ntiles + 7) / 8) * 8 : cap;
         isr_profile_record(ISR_VARIANT_SPLIT, 2.0 * 9 * Cin * Cout * (double)N * H * W, &e0, &e1);
         const dim3 pgrid((unsigned)want), wblock(W_THREADS);
         if (e0 || e1) hipExtLaunchKernelGGL(conv3x3_split_wide_kernel, pgrid, wblock, W_LDS_BYTES, s, e0, e1, 0, p);
@@ -986,7 +993,8 @@ int isrConv3x3ForwardSplit(const float* x, const void* wq, const float* bias, co
             slots = 2 * cus;
             (void)hipFuncSetAttribute((const void*)conv3x3_split_stream_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, S_LDS_BYTES);
         }
-        const long long want = nwg < slots ? ((nwg + 7) / 8) * 8 : slots;
+        const int cap = g_split_slots > 0 ? g_split_slots : slots;
+        const long long want = nwg < cap ? ((nwg + 7) / 8) * 8 : cap;
         isr_profile_record(ISR_VARIANT_SPLIT, 2.0 * 9 * Cin * Cout * (double)N * H * W, &e0, &e1);
         const dim3 pgrid((unsigned)want);
         if (e0 || e1) hipExtLaunchKernelGGL(conv3x3_split_stream_kernel, pgrid, block, S_LDS_BYTES, s, e0, e1, 0, p);

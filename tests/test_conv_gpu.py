@@ -131,6 +131,40 @@ def test_conv3x3_padded_channel_planes(conv_mode):
     assert (y2.cpu().double() - ref2).abs().max().item() <= 1e-4
 
 
+@pytest.mark.parametrize("algo", [0, 1, 2])
+@pytest.mark.parametrize("slots", [8, 24])
+def test_split_kernel_forms_agree_when_workgroups_walk_many_tiles(algo, slots):
+    """The plain split-operand layer has three kernel forms (one workgroup per tile; persistent streaming; wide 512-thread).
+    The persistent ones walk a list of tiles per workgroup -- with the grid capped to a few workgroups even a small image
+    exercises the tile-to-tile hand-over (next tile's operands in flight under the last k-step, epilogue scratch vs parked
+    data), ragged last tile rows (H % 16 != 0) and an odd number of k-steps (Cin = 101)."""
+    import ctypes
+    from isosurfacesuperresolution_amd import ops
+    lib = ops._sr()
+    lib.isrDebugSetSplitAlgo.argtypes = [ctypes.c_int]
+    lib.isrDebugSetSplitSlots.argtypes = [ctypes.c_int]
+    g = torch.Generator().manual_seed(31)
+    old = ops.SPLIT_F16
+    ops.SPLIT_F16 = True
+    lib.isrDebugSetSplitAlgo(algo)
+    lib.isrDebugSetSplitSlots(slots)
+    try:
+        for N, Cin, Cout, h, w, act, has_r in ((1, 64, 64, 70, 96, 'relu', False), (2, 101, 64, 45, 64, 'none', True), (1, 64, 32, 30, 128, 'relu', True)):
+            x = torch.rand(N, Cin, h, w, generator=g) * 2 - 1
+            wt = (torch.rand(Cout, Cin, 3, 3, generator=g) * 2 - 1) / (3.0 * Cin ** 0.5)
+            b = torch.rand(Cout, generator=g) - 0.5
+            res = torch.rand(N, Cout, h, w, generator=g) if has_r else None
+            ref = _ref(x, wt, b, act, 0.1, res, False)
+            with torch.no_grad():
+                y = ops.conv3x3(x.cuda(), wt.cuda(), b.cuda(), act=act, residual=res.cuda() if has_r else None)
+            err = (y.cpu().double() - ref).abs().max().item()
+            assert err <= 1e-4, (algo, slots, (N, Cin, Cout, h, w), err)
+    finally:
+        lib.isrDebugSetSplitAlgo(1)
+        lib.isrDebugSetSplitSlots(0)
+        ops.SPLIT_F16 = old
+
+
 def test_split_operand_accuracy_matches_the_exact_kernel():
     """The split-operand kernel (three fp16 MFMAs per product, fp32 accumulation) against an fp64 convolution, next to
     the exact fp32 kernel on the same data: 64 -> 64 channels (K = 576), O(1) activations, weights of the network's
