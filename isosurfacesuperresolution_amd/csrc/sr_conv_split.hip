@@ -977,7 +977,7 @@ int isrConv3x3ForwardSplit(const float* x, const void* wq, const float* bias, co
         const long long ntiles = (long long)N * p.tilesX * p.tilesY * p.cgroups;
         const int cap = g_split_slots > 0 ? g_split_slots : cus;
         const long long want = ntiles < cap ? ((ntiles + 7) / 8) * 8 : cap;
-        isr_profile_record(ISR_VARIANT_SPLIT, 2.0 * 9 * Cin * Cout * (double)N * H * W, &e0, &e1);
+        isr_profile_record(ISR_VARIANT_SPLIT_WIDE, 2.0 * 9 * Cin * Cout * (double)N * H * W, &e0, &e1);
         const dim3 pgrid((unsigned)want), wblock(W_THREADS);
         if (e0 || e1) hipExtLaunchKernelGGL(conv3x3_split_wide_kernel, pgrid, wblock, W_LDS_BYTES, s, e0, e1, 0, p);
         else hipLaunchKernelGGL(conv3x3_split_wide_kernel, pgrid, wblock, W_LDS_BYTES, s, p);
@@ -995,7 +995,7 @@ int isrConv3x3ForwardSplit(const float* x, const void* wq, const float* bias, co
         }
         const int cap = g_split_slots > 0 ? g_split_slots : slots;
         const long long want = nwg < cap ? ((nwg + 7) / 8) * 8 : cap;
-        isr_profile_record(ISR_VARIANT_SPLIT, 2.0 * 9 * Cin * Cout * (double)N * H * W, &e0, &e1);
+        isr_profile_record(ISR_VARIANT_SPLIT_STREAM, 2.0 * 9 * Cin * Cout * (double)N * H * W, &e0, &e1);
         const dim3 pgrid((unsigned)want);
         if (e0 || e1) hipExtLaunchKernelGGL(conv3x3_split_stream_kernel, pgrid, block, S_LDS_BYTES, s, e0, e1, 0, p);
         else hipLaunchKernelGGL(conv3x3_split_stream_kernel, pgrid, block, S_LDS_BYTES, s, p);

@@ -136,7 +136,8 @@ VARIANT_NAMES = {6: "conv3x3_small_cout_kernel", 2: "conv3x3_fwd_kernel<1,false>
                  4: "conv3x3_fwd_kernel<2,false>", 5: "conv3x3_fwd_kernel<2,true>",
                  8: "conv3x3_fwd2_kernel<false,4>", 9: "conv3x3_fwd2_kernel<true,4>",
                  10: "conv3x3_fwd2_kernel<false,1>", 11: "conv3x3_fwd2_kernel<true,1>", 12: "conv3x3_rowsplit_kernel",
-                 13: "conv3x3_split_kernel<false>", 14: "conv3x3_split_kernel<true>"}
+                 13: "conv3x3_split_kernel<false>", 14: "conv3x3_split_kernel<true>",
+                 15: "conv3x3_split_stream_kernel", 16: "conv3x3_split_wide_kernel"}
 
 
 def profile_enable(on):
