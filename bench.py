@@ -368,7 +368,8 @@ def run_train(args, job):
                    "clips_per_rank": per, "parallelism": "dp%d, one flat %.2f MB gradient all-reduce per step" % (world, trainer.numel * 4 / 1e6),
                    "step": "one HIP graph (forward x T, backward through time, deferred weight gradients, all-reduce, Adam)" if graphed else "eager"},
         "rccl_ranks": job.joined_ranks(), "allreduce": allreduce, "loss": loss,
-        "roofline": {"kernel": "conv forward + data gradient + weight gradient of the step (all fp32 MFMA kernels)", "bound": "mfma",
+        "roofline": {"kernel": "conv forward + data gradient + weight gradient of the step (layers with many tiles: split-operand fp16 MFMA "
+                               "kernels at fp32-equivalent accuracy; 32^2-crop layers: exact fp32 MFMA kernels); peak = fp32 MFMA", "bound": "mfma",
                      "achieved": achieved, "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": achieved / MFMA_F32_PEAK_TFLOPS,
                      "traffic": None, "flops_per_step": flops},
         "cpu_baseline": None,

@@ -122,8 +122,14 @@ int isrConv3x3WeightGrad(const float* x, const float* gz, float* dw, float* db, 
 int isrConvWeightGradMaxSegments(void);
 int isrConv3x3WeightGradSegments(const float* const* xs, const float* const* gzs, int segments, float* dw, float* db, void* workspace,
                                  int N, int Cin, int H, int W, int Cout, void* stream);
-/* The same sums with bf16 MFMA operands (fp32 accumulation and results; bias gradient from the fp32 values): the
+/* ...Split: the same sums on SPLIT operands -- every gz and x value as two fp16 numbers, three fp16 MFMAs per product,
+ * fp32 accumulation (see isrConv3x3ForwardSplit): the fp32 kernel's accuracy against fp64 at 5.3x fewer matrix cycles;
+ * gz is scaled by a power of two taken from its maximum over the launch (two small kernels) and unscaled exactly by the
+ * slab reduction.  The training default for layers with many tiles.  W % 4 == 0 and 16-byte aligned gzs[k] (else -3 / -1).
+ * ...Bf16: the same sums with bf16 MFMA operands (fp32 accumulation and results; bias gradient from the fp32 values): the
  * weight-gradient half of the opt-in mixed-precision training mode.  W % 4 == 0 and 16-byte aligned gzs[k] (else -3 / -1). */
+int isrConv3x3WeightGradSegmentsSplit(const float* const* xs, const float* const* gzs, int segments, float* dw, float* db, void* workspace,
+                                      int N, int Cin, int H, int W, int Cout, void* stream);
 int isrConv3x3WeightGradSegmentsBf16(const float* const* xs, const float* const* gzs, int segments, float* dw, float* db, void* workspace,
                                      int N, int Cin, int H, int W, int Cout, void* stream);
 

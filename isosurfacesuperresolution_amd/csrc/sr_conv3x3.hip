@@ -916,6 +916,7 @@ struct WGradParams {
     int N, Cin, H, W, Cout;
     int ci0, co0;       // channel group handled by this launch
     int tilesX, tilesY, ntiles;
+    const float* scale; // split-operand kernel only: { 2^S, 2^-S } with max |gz| 2^S in [2^13, 2^14)
 };
 
 // Staging is branch-free and software pipelined: the next tile's 8 + 51 elements per thread are fetched through
@@ -1194,12 +1195,228 @@ __global__ __launch_bounds__(NTHREADS, 1) void conv3x3_wgrad_bf16_kernel(const W
     }
 }
 
+// ---- weight gradient on split operands: fp32-equivalent accuracy on the fp16 matrix pipe (the training default) --------
+// The decomposition and tile pipeline of conv3x3_wgrad_bf16_kernel, with every operand carried as two fp16 numbers
+// (csrc/sr_conv_split.hip): gz, whose magnitude is unknown, is first scaled by a power of two taken from max |gz| over
+// the launch's tensors (wgrad_absmax / wgrad_scale kernels; undone exactly by the slab reduction) and split as
+// hi = RN16(g), lo = RN16(g - hi); x is split as hi = RN16(x), lo' = RN16((x - hi) 2^11) and meets gz_hi 2^-11 (an
+// exponent shift of the A fragment in registers).  A product is gz_lo x_hi + (gz_hi 2^-11) x_lo' + gz_hi x_hi: three
+// v_mfma_f32_32x32x16_f16 instead of eight v_mfma_f32_32x32x2_f32 at twice the cycles each -> 5.3x fewer matrix cycles.
+typedef _Float16 wf16x8 __attribute__((ext_vector_type(8)));
+constexpr int WS_LDS_BYTES = 2 * (64 * BG_PITCH + 64 * BX_PITCH);          // hi and lo planes of gz and x: 98 304 B
+
+__device__ __forceinline__ void split_pair(float a, float b, float lo_scale, unsigned& hi, unsigned& lo)
+{
+    typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+    h2 vh, vl;
+    vh[0] = (_Float16)a; vh[1] = (_Float16)b;
+    vl[0] = (_Float16)((a - (float)vh[0]) * lo_scale); vl[1] = (_Float16)((b - (float)vh[1]) * lo_scale);
+    hi = __builtin_bit_cast(unsigned, vh); lo = __builtin_bit_cast(unsigned, vl);
+}
+
+__global__ __launch_bounds__(NTHREADS, 1) void conv3x3_wgrad_split_kernel(const WGradParams p)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char wsl[];
+    unsigned char* gzh = wsl;
+    unsigned char* gzl = gzh + 64 * BG_PITCH;
+    unsigned char* xph = gzl + 64 * BG_PITCH;
+    unsigned char* xpl = xph + 64 * BX_PITCH;
+    constexpr int NGQ = 64 * WG_PX / 4 / NTHREADS;                              // 8 gz quads per thread and tile
+    constexpr int NXP = (64 * (WG_TH + 2) * BX_PAIRS + NTHREADS - 1) / NTHREADS;  // 26 x pairs
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int m = wave >> 1, nn = wave & 1;
+    const int j = lane & 31, kh = lane >> 5;
+    const int g = blockIdx.x, nslab = gridDim.x;
+    const float gscale = p.scale[0];
+
+    f32x16 acc[9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[t][i] = 0.0f;
+    float bs[NGQ];                                                             // fp32 sums of gz per thread (channel tid/32 + 8 i)
+#pragma unroll
+    for (int i = 0; i < NGQ; ++i) bs[i] = 0.0f;
+
+    const size_t planeBytes = (size_t)p.H * p.W * 4;
+    const int tilesPerImage = p.tilesX * p.tilesY;
+    u32x4 gq[NGQ];
+    float xlo[NXP], xhi[NXP];
+
+    auto fetch = [&](int tile) {
+        const int ng = tile / tilesPerImage;
+        const int t2 = tile - ng * tilesPerImage;
+        const int seg = ng / p.N, n = ng - seg * p.N;
+        const int ty = t2 / p.tilesX, tx = t2 - ty * p.tilesX;
+        const int oy0 = ty * WG_TH, ox0 = tx * WG_TW;
+        const int gzc = p.Cout - p.co0, xc = p.Cin - p.ci0;
+        const rsrc_t grs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.gz[seg] + ((size_t)n * p.Cout + p.co0) * p.H * p.W), 0,
+                                                             (int)((gzc < 64 ? gzc : 64) * planeBytes), 0x00020000);
+        const rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.x[seg] + ((size_t)n * p.Cin + p.ci0) * p.H * p.W), 0,
+                                                             (int)((xc < 64 ? xc : 64) * planeBytes), 0x00020000);
+#pragma unroll
+        for (int i = 0; i < NGQ; ++i) {                                        // quad q = (channel q / 32, 4 pixels)
+            const int q = tid + i * NTHREADS;
+            const int c = q >> 5, px = (q & 31) * 4, ry = px >> 5, rx = px & 31;
+            const int gy = oy0 + ry, gx = ox0 + rx;
+            const bool ok = gy < p.H && gx < p.W;                              // W % 4 == 0: a quad is inside or outside as a whole
+            gq[i] = __builtin_amdgcn_raw_buffer_load_b128(grs, (int)(ok ? (unsigned)((c * p.H + gy) * p.W + gx) * 4u : BAD_OFFSET), 0, 0);
+        }
+#pragma unroll
+        for (int i = 0; i < NXP; ++i) {                                        // pair e = (channel, patch row, patch columns 2 pr, 2 pr + 1)
+            const int e = tid + i * NTHREADS;
+            const int c = e / ((WG_TH + 2) * BX_PAIRS), rem = e - c * ((WG_TH + 2) * BX_PAIRS);
+            const int r = rem / BX_PAIRS, pr = rem - r * BX_PAIRS;
+            const int gy = oy0 + r - 1, gx = ox0 + 2 * pr - 1;
+            const bool in = e < 64 * (WG_TH + 2) * BX_PAIRS && (unsigned)gy < (unsigned)p.H;
+            const unsigned off = (unsigned)((c * p.H + gy) * p.W + gx) * 4u;
+            xlo[i] = buf_load(xrs, (in && (unsigned)gx < (unsigned)p.W) ? off : BAD_OFFSET);
+            xhi[i] = buf_load(xrs, (in && (unsigned)(gx + 1) < (unsigned)p.W) ? off + 4u : BAD_OFFSET);
+        }
+    };
+    auto park = [&]() {
+#pragma unroll
+        for (int i = 0; i < NGQ; ++i) {
+            const int q = tid + i * NTHREADS;
+            const float4 f = __builtin_bit_cast(float4, gq[i]);
+            bs[i] += (f.x + f.y) + (f.z + f.w);
+            uint2 vh, vl;
+            split_pair(f.x * gscale, f.y * gscale, 1.0f, vh.x, vl.x);
+            split_pair(f.z * gscale, f.w * gscale, 1.0f, vh.y, vl.y);
+            *reinterpret_cast<uint2*>(gzh + (q >> 5) * BG_PITCH + (q & 31) * 8) = vh;
+            *reinterpret_cast<uint2*>(gzl + (q >> 5) * BG_PITCH + (q & 31) * 8) = vl;
+        }
+#pragma unroll
+        for (int i = 0; i < NXP; ++i) {
+            const int e = tid + i * NTHREADS;
+            if (e < 64 * (WG_TH + 2) * BX_PAIRS) {
+                const int c = e / ((WG_TH + 2) * BX_PAIRS), rem = e - c * ((WG_TH + 2) * BX_PAIRS);
+                const int r = rem / BX_PAIRS, pr = rem - r * BX_PAIRS;
+                unsigned vh, vl;
+                split_pair(xlo[i], xhi[i], 2048.0f, vh, vl);
+                *reinterpret_cast<unsigned*>(xph + c * BX_PITCH + r * BX_ROW + pr * 4) = vh;
+                *reinterpret_cast<unsigned*>(xpl + c * BX_PITCH + r * BX_ROW + pr * 4) = vl;
+            }
+        }
+    };
+
+    int tile = g;
+    if (tile < p.ntiles) { fetch(tile); park(); }
+    __syncthreads();
+    for (; tile < p.ntiles; tile += nslab) {
+        const bool more = tile + nslab < p.ntiles;
+        if (more) fetch(tile + nslab);
+        __builtin_amdgcn_sched_barrier(0);
+        const int ga = (m * 32 + j) * BG_PITCH + kh * 16;
+        const int xb = (nn * 32 + j) * BX_PITCH + kh * 16;
+#pragma unroll
+        for (int ry = 0; ry < WG_TH; ++ry) {
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {                                   // k-step = 16 pixels of the row: columns 16 ks + 8 kh ..
+                const wf16x8 ah = __builtin_bit_cast(wf16x8, *reinterpret_cast<const u32x4*>(gzh + ga + (ry * 32 + ks * 16) * 2));
+                const wf16x8 al = __builtin_bit_cast(wf16x8, *reinterpret_cast<const u32x4*>(gzl + ga + (ry * 32 + ks * 16) * 2));
+                const wf16x8 as = ah * (_Float16)0.00048828125f;              // gz_hi 2^-11: partner of the scaled x_lo'
+#pragma unroll
+                for (int dy = 0; dy < 3; ++dy) {
+                    const int row = xb + (ry + dy) * BX_ROW + ks * 32;
+                    const u32x4 dh = *reinterpret_cast<const u32x4*>(xph + row);
+                    const unsigned dh4 = *reinterpret_cast<const unsigned*>(xph + row + 16);
+                    const u32x4 dl = *reinterpret_cast<const u32x4*>(xpl + row);
+                    const unsigned dl4 = *reinterpret_cast<const unsigned*>(xpl + row + 16);
+                    u32x4 h1, h2, l1, l2;
+                    h1.x = __builtin_amdgcn_alignbit(dh.y, dh.x, 16); h1.y = __builtin_amdgcn_alignbit(dh.z, dh.y, 16);
+                    h1.z = __builtin_amdgcn_alignbit(dh.w, dh.z, 16); h1.w = __builtin_amdgcn_alignbit(dh4, dh.w, 16);
+                    h2.x = dh.y; h2.y = dh.z; h2.z = dh.w; h2.w = dh4;
+                    l1.x = __builtin_amdgcn_alignbit(dl.y, dl.x, 16); l1.y = __builtin_amdgcn_alignbit(dl.z, dl.y, 16);
+                    l1.z = __builtin_amdgcn_alignbit(dl.w, dl.z, 16); l1.w = __builtin_amdgcn_alignbit(dl4, dl.w, 16);
+                    l2.x = dl.y; l2.y = dl.z; l2.z = dl.w; l2.w = dl4;
+#define ISR_WS3(T, BH, BL)                                                                                              \
+                    acc[T] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, __builtin_bit_cast(wf16x8, BH), acc[T], 0, 0, 0);   \
+                    acc[T] = __builtin_amdgcn_mfma_f32_32x32x16_f16(as, __builtin_bit_cast(wf16x8, BL), acc[T], 0, 0, 0);   \
+                    acc[T] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, __builtin_bit_cast(wf16x8, BH), acc[T], 0, 0, 0);
+                    ISR_WS3(dy * 3 + 0, dh, dl)
+                    ISR_WS3(dy * 3 + 1, h1, l1)
+                    ISR_WS3(dy * 3 + 2, h2, l2)
+#undef ISR_WS3
+                }
+            }
+        }
+        __syncthreads();
+        if (more) park();
+        __syncthreads();
+    }
+    float* slab = p.slabs + (size_t)g * 9 * 64 * 64;
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const int co = m * 32 + (i & 3) + 8 * (i >> 2) + 4 * kh;
+            slab[((size_t)t * 64 + co) * 64 + nn * 32 + j] = acc[t][i];
+        }
+    // bias gradient from the fp32 values: thread t's sum i belongs to channel t / 32 + 8 i; reduce over the 32 lanes
+    if (p.bslabs) {
+#pragma unroll
+        for (int i = 0; i < NGQ; ++i) {
+            float v = bs[i];
+#pragma unroll
+            for (int off = 16; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+            if ((lane & 31) == 0) p.bslabs[(size_t)g * 64 + (tid >> 5) + 8 * i] = v;
+        }
+    }
+}
+
+// max |gz| over the tensors of a launch: one partial per workgroup, then { 2^S, 2^-S } with max |gz| 2^S in [2^13, 2^14)
+struct AbsMaxParams { const float* t[WG_MAX_SEG]; int segments; long long count; };
+__global__ __launch_bounds__(256) void wgrad_absmax_kernel(const AbsMaxParams p, float* __restrict__ partial)
+{
+    __shared__ float red[256];
+    float mx = 0.0f;
+    const long long quads = p.count >> 2;
+    for (int s = 0; s < p.segments; ++s) {
+        const float4* src = reinterpret_cast<const float4*>(p.t[s]);
+        for (long long q = (long long)blockIdx.x * 256 + threadIdx.x; q < quads; q += (long long)gridDim.x * 256) {
+            const float4 f = src[q];
+            mx = fmaxf(fmaxf(mx, fmaxf(fabsf(f.x), fabsf(f.y))), fmaxf(fabsf(f.z), fabsf(f.w)));
+        }
+        if (blockIdx.x == 0 && threadIdx.x < (p.count & 3)) mx = fmaxf(mx, fabsf(p.t[s][(quads << 2) + threadIdx.x]));
+    }
+    red[threadIdx.x] = mx;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if ((int)threadIdx.x < s) red[threadIdx.x] = fmaxf(red[threadIdx.x], red[threadIdx.x + s]);
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) partial[blockIdx.x] = red[0];
+}
+__global__ __launch_bounds__(256) void wgrad_scale_kernel(const float* __restrict__ partial, int n, float* __restrict__ scale)
+{
+    __shared__ float red[256];
+    float mx = 0.0f;
+    for (int i = threadIdx.x; i < n; i += 256) mx = fmaxf(mx, partial[i]);
+    red[threadIdx.x] = mx;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if ((int)threadIdx.x < s) red[threadIdx.x] = fmaxf(red[threadIdx.x], red[threadIdx.x + s]);
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        int S = 0;
+        if (red[0] > 0.0f && red[0] < 3.0e38f) {
+            S = 13 - ilogbf(red[0]);
+            S = S < -100 ? -100 : (S > 100 ? 100 : S);
+        }
+        scale[0] = ldexpf(1.0f, S);
+        scale[1] = ldexpf(1.0f, -S);
+    }
+}
+
 // dw[co][ci][tap] = sum over the G slabs, in a fixed order (bitwise reproducible run to run).  A workgroup owns 64
 // consecutive slab elements; its four waves take the slabs g % 4 == wave with four loads in flight each and the
 // four partial sums are combined through LDS -- 576 workgroups x 16 independent loads instead of 144 x 8, the
 // reduction of 256 slabs (38 MB) is latency bound otherwise.  Workgroup 576 reduces the 64 bias sums the same way.
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ slabs, int G, float* __restrict__ dw,
-                                    int Cout, int Cin, int co0, int ci0, const float* __restrict__ bslabs, float* __restrict__ db)
+                                    int Cout, int Cin, int co0, int ci0, const float* __restrict__ bslabs, float* __restrict__ db,
+                                    const float* __restrict__ scale = nullptr)      // split kernel: slabs hold sums scaled by scale[0]
 {
     __shared__ float part[4][64];
     const int lane = threadIdx.x & 63, q = threadIdx.x >> 6;
@@ -1225,7 +1442,7 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
     const int e = blockIdx.x * 64 + lane;                    // over [9][64][64]
     const int ci = e & 63, co = (e >> 6) & 63, tap = e >> 12;
     if (co0 + co >= Cout || ci0 + ci >= Cin) return;
-    dw[((size_t)(co0 + co) * Cin + (ci0 + ci)) * 9 + tap] = total;
+    dw[((size_t)(co0 + co) * Cin + (ci0 + ci)) * 9 + tap] = scale ? total * scale[1] : total;
 }
 
 constexpr int WGRAD_MAX_SLABS = 512;
@@ -1450,7 +1667,7 @@ int isrActBackward(const float* gy, const float* y, float* gz, long long count, 
 long long isrConvWeightGradWorkspace(int N, int Cin, int H, int W, int Cout)
 {
     (void)N; (void)Cin; (void)H; (void)W; (void)Cout;
-    return (long long)WGRAD_MAX_SLABS * (9 * 64 * 64 + 64) * sizeof(float);
+    return (long long)WGRAD_MAX_SLABS * (9 * 64 * 64 + 64) * sizeof(float) + 4096;     // + partial maxima and the scale pair of the split kernel
 }
 
 int isrConvWeightGradMaxSegments(void) { return WG_MAX_SEG; }
@@ -1468,6 +1685,7 @@ int isrConv3x3WeightGradSegments(const float* const* xs, const float* const* gzs
         if (k < segments && (!xs[k] || !gzs[k])) return -1;
     }
     p.slabs = (float*)workspace;
+    p.scale = nullptr;
     float* bslabs = p.slabs + (size_t)WGRAD_MAX_SLABS * 9 * 64 * 64;
     p.N = N; p.Cin = Cin; p.H = H; p.W = W; p.Cout = Cout;
     p.tilesX = (W + WG_TW - 1) / WG_TW; p.tilesY = (H + WG_TH - 1) / WG_TH;
@@ -1506,6 +1724,7 @@ int isrConv3x3WeightGradSegmentsBf16(const float* const* xs, const float* const*
         if (k < segments && (!xs[k] || !gzs[k] || ((uintptr_t)gzs[k] & 15))) return -1;
     }
     p.slabs = (float*)workspace;
+    p.scale = nullptr;
     float* bslabs = p.slabs + (size_t)WGRAD_MAX_SLABS * 9 * 64 * 64;
     p.N = N; p.Cin = Cin; p.H = H; p.W = W; p.Cout = Cout;
     p.tilesX = (W + WG_TW - 1) / WG_TW; p.tilesY = (H + WG_TH - 1) / WG_TH;
@@ -1521,6 +1740,55 @@ int isrConv3x3WeightGradSegmentsBf16(const float* const* xs, const float* const*
             hipLaunchKernelGGL(conv3x3_wgrad_bf16_kernel, dim3(G), dim3(NTHREADS), 0, s, p);
             hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(9 * 64 + 1), dim3(256), 0, s,
                                p.slabs, G, dw, Cout, Cin, co0, ci0, (const float*)p.bslabs, db);
+        }
+    return hipGetLastError() == hipSuccess ? 0 : -2;
+}
+
+int isrConv3x3WeightGradSegmentsSplit(const float* const* xs, const float* const* gzs, int segments, float* dw, float* db, void* workspace,
+                                      int N, int Cin, int H, int W, int Cout, void* stream)
+{
+    if (!xs || !gzs || segments <= 0 || segments > WG_MAX_SEG || !dw || !workspace || N <= 0 || Cin <= 0 || Cout <= 0 || H <= 0 || W <= 0)
+        return -1;
+    if (W & 3) return -3;                          // the gz tile is fetched as aligned groups of four pixels
+    hipStream_t s = (hipStream_t)stream;
+    WGradParams p;
+    AbsMaxParams ap;
+    for (int k = 0; k < WG_MAX_SEG; ++k) {
+        p.x[k] = k < segments ? xs[k] : nullptr;
+        p.gz[k] = k < segments ? gzs[k] : nullptr;
+        ap.t[k] = p.gz[k];
+        if (k < segments && (!xs[k] || !gzs[k] || ((uintptr_t)gzs[k] & 15))) return -1;
+    }
+    ap.segments = segments;
+    ap.count = (long long)N * Cout * H * W;
+    p.slabs = (float*)workspace;
+    float* bslabs = p.slabs + (size_t)WGRAD_MAX_SLABS * 9 * 64 * 64;
+    float* partial = bslabs + (size_t)WGRAD_MAX_SLABS * 64;       // 512 partial maxima, then the scale pair
+    float* scale = partial + 512;
+    p.scale = scale;
+    p.N = N; p.Cin = Cin; p.H = H; p.W = W; p.Cout = Cout;
+    p.tilesX = (W + WG_TW - 1) / WG_TW; p.tilesY = (H + WG_TH - 1) / WG_TH;
+    const long long nt = (long long)N * segments * p.tilesX * p.tilesY;
+    if (nt > 0x7fffffffLL) return -1;
+    p.ntiles = (int)nt;
+    if ((long long)(Cin < 64 ? Cin : 64) * H * W * 4 > 0x7fffffffLL || (long long)(Cout < 64 ? Cout : 64) * H * W * 4 > 0x7fffffffLL) return -1;
+    static bool attr_done = false;
+    if (!attr_done) {
+        (void)hipFuncSetAttribute((const void*)conv3x3_wgrad_split_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, WS_LDS_BYTES);
+        attr_done = true;
+    }
+    const long long quads = ap.count >> 2;
+    const int AB = (int)(quads < 512LL * 256 ? (quads + 255) / 256 > 0 ? (quads + 255) / 256 : 1 : 512);
+    hipLaunchKernelGGL(wgrad_absmax_kernel, dim3(AB), dim3(256), 0, s, ap, partial);
+    hipLaunchKernelGGL(wgrad_scale_kernel, dim3(1), dim3(256), 0, s, (const float*)partial, AB, scale);
+    const int G = p.ntiles >= 512 ? 256 : (p.ntiles < WGRAD_MAX_SLABS ? p.ntiles : WGRAD_MAX_SLABS);
+    for (int co0 = 0; co0 < Cout; co0 += 64)
+        for (int ci0 = 0; ci0 < Cin; ci0 += 64) {
+            p.co0 = co0; p.ci0 = ci0;
+            p.bslabs = (db && ci0 == 0) ? bslabs : nullptr;
+            hipLaunchKernelGGL(conv3x3_wgrad_split_kernel, dim3(G), dim3(NTHREADS), WS_LDS_BYTES, s, p);
+            hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(9 * 64 + 1), dim3(256), 0, s,
+                               p.slabs, G, dw, Cout, Cin, co0, ci0, (const float*)p.bslabs, db, (const float*)scale);
         }
     return hipGetLastError() == hipSuccess ? 0 : -2;
 }

@@ -51,6 +51,8 @@ def _sr():
         lib.isrConv3x3WeightGradSegments.restype = ci
         lib.isrConv3x3WeightGradSegmentsBf16.argtypes = lib.isrConv3x3WeightGradSegments.argtypes
         lib.isrConv3x3WeightGradSegmentsBf16.restype = ci
+        lib.isrConv3x3WeightGradSegmentsSplit.argtypes = lib.isrConv3x3WeightGradSegments.argtypes
+        lib.isrConv3x3WeightGradSegmentsSplit.restype = ci
         lib.isrActBackward.argtypes = [vp, vp, vp, ll, ci, cf, vp]; lib.isrActBackward.restype = ci
         lib.isrAssembleInput.argtypes = [vp, vp, vp, vp, ci, ci, ci, ci, vp]; lib.isrAssembleInput.restype = ci
         lib.isrConvSmallCinPad.argtypes = [ci]; lib.isrConvSmallCinPad.restype = ci
@@ -330,16 +332,20 @@ SPLIT_F16 = True
 _split_cache = {}
 
 
-def _prepare_split(weight):
-    """Weights as scaled (hi, lo) fp16 pairs in the split kernel's layout, cached like ``prepare_weights``."""
+def _prepare_split(weight, transpose_flip=False):
+    """Weights as scaled (hi, lo) fp16 pairs in the split kernel's layout, cached like ``prepare_weights``;
+    transpose_flip: the data-gradient weights w'[ci][co][ky][kx] = w[co][ci][2-ky][2-kx]."""
     lib = _sr()
-    key = id(weight)
+    key = (id(weight), bool(transpose_flip))
     hit = _split_cache.get(key)
     if hit is not None:
         ref, version, ptr, wq = hit
         if ref() is weight and version == weight._version and ptr == weight.data_ptr():
             return wq
-    w = weight.detach().contiguous()
+    w = weight.detach()
+    if transpose_flip:
+        w = w.flip(2, 3).transpose(0, 1)
+    w = w.contiguous()
     cout, cin = w.shape[0], w.shape[1]
     wq = torch.empty(lib.isrConvSplitWeightBytes(cin, cout), dtype=torch.uint8, device=weight.device)
     rc = lib.isrConvSplitPrepare(_ptr(w), _ptr(wq), cout, cin, _stream())
@@ -363,29 +369,32 @@ def conv3x3_split(x, weight, bias=None, act='none', slope=0.01, residual=None, u
     """``conv3x3`` on the split-operand kernel (no autograd): y = act(conv3x3(U(x), w) + bias) + residual."""
     if act not in ('none', 'relu', 'leaky'):
         raise ValueError("unknown activation %r" % (act,))
-    lib = _sr()
     with torch.no_grad():
-        wq = _prepare_split(weight)
-        bias = bias.contiguous() if bias is not None else None
-        x, xp, xi = _plane_strides(x)
-        fuse = False
-        if upsample2x:
-            fuse = bool(lib.isrConvF16SupportsUpsample(x.data_ptr(), x.shape[3], xp, xi))
-            if not fuse:          # unaligned low-res rows: the resize runs as its own kernel first
-                x, xp, xi = _plane_strides(bilinear_upsample2x(x))
-        n, cin = x.shape[0], x.shape[1]
-        cout = weight.shape[0]
-        h, w = (2 * x.shape[2], 2 * x.shape[3]) if fuse else (x.shape[2], x.shape[3])
-        rp = ri = 0
-        if residual is not None:
-            residual, rp, ri = _plane_strides(residual)
-        y = empty_planes(n, cout, h, w, x.device)
-        rc = lib.isrConv3x3ForwardSplit(_ptr(x), _ptr(wq), _ptr(bias), _ptr(residual), _ptr(y), n, cin, h, w, cout,
-                                        ACT_CODES[act], float(slope), 1 if fuse else 0, xp, xi, y.stride(1), cout * y.stride(1),
-                                        rp, ri, _stream())
-        if rc != 0:
-            raise RuntimeError("isrConv3x3ForwardSplit failed (%d)" % rc)
-        return y
+        return _launch_split(x, _prepare_split(weight), bias.contiguous() if bias is not None else None, residual, weight.shape[0],
+                             act, slope, upsample2x)
+
+
+def _launch_split(x, wq, bias, residual, cout, act, slope, upsample2x, packed=False):
+    """One launch of isrConv3x3ForwardSplit (x: fp32 NCHW, channel planes may be padded; ``packed`` as in ``_launch_forward``)."""
+    lib = _sr()
+    x, xp, xi = _plane_strides(x)
+    fuse = False
+    if upsample2x:
+        fuse = bool(lib.isrConvF16SupportsUpsample(x.data_ptr(), x.shape[3], xp, xi))
+        if not fuse:          # unaligned low-res rows: the resize runs as its own kernel first
+            x, xp, xi = _plane_strides(bilinear_upsample2x(x))
+    n, cin = x.shape[0], x.shape[1]
+    h, w = (2 * x.shape[2], 2 * x.shape[3]) if fuse else (x.shape[2], x.shape[3])
+    rp = ri = 0
+    if residual is not None:
+        residual, rp, ri = _plane_strides(residual)
+    y = torch.empty((n, cout, h, w), dtype=torch.float32, device=x.device) if packed else empty_planes(n, cout, h, w, x.device)
+    rc = lib.isrConv3x3ForwardSplit(_ptr(x), _ptr(wq), _ptr(bias), _ptr(residual), _ptr(y), n, cin, h, w, cout,
+                                    ACT_CODES[act], float(slope), 1 if fuse else 0, xp, xi, y.stride(1), cout * y.stride(1),
+                                    rp, ri, _stream())
+    if rc != 0:
+        raise RuntimeError("isrConv3x3ForwardSplit failed (%d)" % rc)
+    return y
 
 
 # ---- mixed-precision training mode (opt-in, NOT the parity path) ------------------------------------------------------
@@ -394,6 +403,12 @@ def conv3x3_split(x, weight, bias=None, act='none', slope=0.01, residual=None, u
 # fp32).  bf16 rather than fp16: gradients span the fp32 exponent range.  Layers with at most 8 input or output
 # channels (the 64 -> 6 output layer and its data gradient) keep their fp32 kernels.
 TRAIN_BF16 = False
+# Forward and data-gradient convolutions of the training graph on the split-operand kernels (csrc/sr_conv_split.hip:
+# three fp16 MFMAs per product on (hi, lo) operand pairs, fp32 accumulation -- the fp32 kernels' accuracy against fp64,
+# NOT a reduced-precision mode) for layers with at least TRAIN_SPLIT_MIN_TILES tiles of 8x32 pixels; smaller layers and
+# all weight gradients stay on the exact fp32 MFMA kernels.
+TRAIN_SPLIT = True
+TRAIN_SPLIT_MIN_TILES = 256
 
 
 def _train_conv(x, weight, transpose_flip, bias, residual, act):
@@ -406,6 +421,10 @@ def _train_conv(x, weight, transpose_flip, bias, residual, act):
     tiles = x.shape[0] * ((x.shape[2] + 7) // 8) * ((x.shape[3] + 31) // 32)
     if TRAIN_BF16 and cout > 8 and cin > 8 and tiles >= 256:
         return _launch_lp(x, _prepare_lp(weight, transpose_flip, True), bias, residual, cout, act, 0.0, False, True, packed=True)
+    # the split-operand kernel (fp32-equivalent accuracy, 2.3x the fp32 MFMA kernel) once a layer has enough 8x32-pixel
+    # tiles to fill the persistent grid: the 64^2 / 128^2 post-block layers of a crop batch, 54 % of the step's flops
+    if TRAIN_SPLIT and cout > 8 and cin > 8 and tiles >= TRAIN_SPLIT_MIN_TILES and x.shape[3] % 4 == 0 and _split_fits(x, cout, False):
+        return _launch_split(x, _prepare_split(weight, transpose_flip), bias, residual, cout, act, 0.0, False, packed=True)
     return _launch_forward(x, prepare_weights(weight, transpose_flip=transpose_flip), bias, residual, cin, cout, act, 0.0, False,
                            packed=True)
 
@@ -437,7 +456,9 @@ def _weight_grad(xs, gzs, weight, has_bias):
         pg = (ctypes.c_void_p * len(part_g))(*[t.data_ptr() for t in part_g])
         # mixed-precision mode: bf16 operands once there are enough 4x32-pixel tiles to stream (the kernel is memory bound)
         tiles = n * len(part_x) * ((h + 3) // 4) * ((w + 31) // 32)
-        fn = lib.isrConv3x3WeightGradSegmentsBf16 if (TRAIN_BF16 and w % 4 == 0 and tiles >= 1024 and cout > 8) else lib.isrConv3x3WeightGradSegments
+        big = w % 4 == 0 and tiles >= 1024 and cout > 8 and all(t.data_ptr() % 16 == 0 for t in part_g)
+        fn = lib.isrConv3x3WeightGradSegmentsBf16 if (TRAIN_BF16 and big) else (
+            lib.isrConv3x3WeightGradSegmentsSplit if (TRAIN_SPLIT and big) else lib.isrConv3x3WeightGradSegments)
         rc = fn(px, pg, len(part_x), _ptr(dw), _ptr(db), _ptr(ws), n, cin, h, w, cout, _stream())
         if rc != 0:
             raise RuntimeError("isrConv3x3WeightGradSegments failed (%d)" % rc)

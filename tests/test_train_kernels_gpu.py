@@ -430,3 +430,40 @@ def test_deferred_weight_gradients_respect_parameter_hooks():
         assert len(seen) == 1                      # fired inside backward, not skipped
     h.remove()
     assert torch.allclose(seen[0], deferred, rtol=1e-5, atol=1e-6) and torch.allclose(w.grad, deferred, rtol=1e-5, atol=1e-6)
+
+
+@pytest.mark.parametrize("gz_scale", [1.0, 3e-6, 2e3])
+@pytest.mark.parametrize("case", [(10, 16, 64, 64, 32, 32), (3, 12, 101, 64, 64, 64), (2, 16, 64, 64, 128, 128)])
+def test_split_operand_weight_gradient_matches_fp64(case, gz_scale):
+    """isrConv3x3WeightGradSegmentsSplit (three fp16 MFMAs per product on (hi, lo) operand pairs, gz scaled by a power of
+    two from its maximum) against fp64, next to the exact fp32 kernel on the same data: as close to fp64 as the fp32
+    kernel (within 2x), whatever the magnitude of the gradients -- 3e-6 would be flushed by a plain fp16 operand."""
+    from isosurfacesuperresolution_amd import ops
+    segs, n, cin, cout, h, w = case
+    g = torch.Generator().manual_seed(segs * 100 + cin)
+    xs = [torch.relu(torch.randn(n, cin, h, w, generator=g)) for _ in range(segs)]          # activations: half of them exact zeros
+    gzs = [torch.randn(n, cout, h, w, generator=g) * gz_scale * (0.02 + torch.rand(1, cout, 1, 1, generator=g)) for _ in range(segs)]
+    weight = torch.zeros(cout, cin, 3, 3).cuda()
+    assert n * segs * ((h + 3) // 4) * ((w + 31) // 32) >= 1024                             # the route that picks the split kernel
+    # fp64 reference through the equivalent correlation: dw = conv(x^T, gz^T) summed over the pairs
+    wref = torch.zeros(cout, cin, 3, 3, dtype=torch.float64)
+    bref = torch.zeros(cout, dtype=torch.float64)
+    for x, gz in zip(xs, gzs):
+        xd, gd = x.double().cuda(), gz.double().cuda()
+        # dw[co][ci][ky][kx] = sum_{n,y,x} gz[n][co][y][x] * xpad[n][ci][y+ky][x+kx]
+        dw = F.conv2d(F.pad(xd, (1, 1, 1, 1)).transpose(0, 1), gd.transpose(0, 1)).transpose(0, 1)
+        wref += dw.cpu()
+        bref += gd.sum(dim=(0, 2, 3)).cpu()
+    err = {}
+    old = ops.TRAIN_SPLIT
+    try:
+        for mode in (True, False):
+            ops.TRAIN_SPLIT = mode
+            gw, gb = ops._weight_grad([t.cuda() for t in xs], [t.cuda() for t in gzs], weight, True)
+            err[mode] = ((gw.cpu().double() - wref).abs().max() / wref.abs().max()).item()
+            assert (gb.cpu().double() - bref).abs().max().item() <= 1e-5 * bref.abs().max().item()
+    finally:
+        ops.TRAIN_SPLIT = old
+    assert err[True] != err[False]                                                          # two different kernels did run
+    assert err[True] <= 2.0 * err[False] + 5e-7, err
+    assert err[True] <= 1e-5, err
