@@ -842,15 +842,223 @@ __global__ __launch_bounds__(W_THREADS, 1) void conv3x3_split_wide_kernel(const 
     }
 }
 
-// header unit of the prepared weights: { 2^S, 2^-S, S (int), 0 } with max |w| 2^S in [2^13, 2^14)
-__global__ __launch_bounds__(256) void split_scale_kernel(const float* __restrict__ w, int count, u32x4* __restrict__ wq)
+// ---- the small-image form: 2-row tiles, weights two k-steps at a time ------------------------------------------------
+// A batch of 32 x 32 training crops is 64 tiles of 8 x 32 pixels: a quarter of the CUs, each running its 432 MFMAs per
+// wave alone -- and on the fp32 kernel 7.7 us of matrix work in a 17.8 us launch, 419 times per training step.  Here a
+// tile is 2 rows x 32 pixels x 64 channels (256 workgroups for 16 crops), a wave = one row x one 32-channel block = ONE
+// accumulator and 108 MFMAs for 64 input channels; the whole 64-channel patch (4 x 34 pixels) is staged at once and the
+// weights pass through LDS two k-steps at a time (73.7 KB), the next pair in flight under the MFMAs of the current one.
+// One workgroup per CU (108 KB of LDS); the launch is a chain of latencies, not of arithmetic.
+constexpr int R2_H = 2, R2_PH = R2_H + 2, R2_PIX = R2_PH * SP_W;             // 4 x 34 = 136 patch pixels
+constexpr int R2_PART = 8 * R2_PIX;                                          // units of the hi (or lo) patch of a 64-channel chunk: 1088
+constexpr int R2_PUNITS = 2 * R2_PART;                                       // 2176 units = 34 816 B
+constexpr int R2_WUNITS = 2 * S_WUNITS;                                      // two k-steps of weights: 4608 units = 73 728 B
+constexpr int R2_UNITS = 8 * R2_PH * SQ_QPR;                                 // 320 staging units (channel group, patch row, quad) per chunk
+constexpr int R2_LDS_BYTES = (R2_PUNITS + R2_WUNITS) * 16;                   // 108 544
+
+__global__ __launch_bounds__(S_THREADS, 1) void conv3x3_split_rows2_kernel(const SplitConvParams p)
 {
-    __shared__ float red[256];
-    float m = 0.0f;
-    for (int i = threadIdx.x; i < count; i += 256) m = fmaxf(m, fabsf(w[i]));
-    red[threadIdx.x] = m;
+    extern __shared__ u32x4 patch[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int j = lane & 31, h = lane >> 5;
+    const int row = wave >> 1, cb = wave & 1;
+    u32x4* wbuf = patch + R2_PUNITS;
+    int bid;
+    {
+        const int nwg = gridDim.x, q = nwg >> 3, r = nwg & 7, xcd = blockIdx.x & 7;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (blockIdx.x >> 3);
+    }
+    const int cg = bid % p.cgroups; bid /= p.cgroups;
+    const int tx = bid % p.tilesX; bid /= p.tilesX;
+    const int ty = bid % p.tilesY, n = bid / p.tilesY;
+    const int oy0 = ty * R2_H, ox0 = tx * ST_W, co0 = cg * 64;
+    const int couts = min(64, p.coutPad - co0);
+    const bool active = co0 + cb * 32 < p.coutPad;
+    const rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.x + (size_t)n * p.xImage), 0,
+                                                         (int)((size_t)p.Cin * p.xPlane * 4), 0x00020000);
+    const unsigned planeBytes = (unsigned)p.xPlane * 4u;
+
+    // staging units of this thread: u = tid and (for the first 64 threads) tid + 256
+    u32x4 v[2][8];
+    auto issue_loads = [&](int cin0) {
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            const int u = tid + k * S_THREADS;
+            const int g = u / (R2_PH * SQ_QPR), rem = u - g * (R2_PH * SQ_QPR);
+            const int r = rem / SQ_QPR, q = rem - r * SQ_QPR;
+            const int iy = oy0 + r - 1, ix = ox0 - 4 + 4 * q;
+            const bool ok = u < R2_UNITS && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
+            const unsigned base = (unsigned)(cin0 + g * 8) * planeBytes + (unsigned)(iy * p.W + ix) * 4u;
+#pragma unroll
+            for (int e = 0; e < 8; ++e)
+                v[k][e] = __builtin_amdgcn_raw_buffer_load_b128(xrs, (int)(ok ? base + (unsigned)e * planeBytes : BAD_OFFSET), 0, 0);
+        }
+    };
+    auto park_loads = [&]() {
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            const int u = tid + k * S_THREADS;
+            if (u >= R2_UNITS) continue;
+            const int g = u / (R2_PH * SQ_QPR), rem = u - g * (R2_PH * SQ_QPR);
+            const int r = rem / SQ_QPR, q = rem - r * SQ_QPR;
+            f16x8 h0, h1, h2, h3, l0, l1, l2, l3;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const float4 f = __builtin_bit_cast(float4, v[k][e]);
+                _Float16 a, b;
+                split16x(f.x, a, b); h0[e] = a; l0[e] = b;
+                split16x(f.y, a, b); h1[e] = a; l1[e] = b;
+                split16x(f.z, a, b); h2[e] = a; l2[e] = b;
+                split16x(f.w, a, b); h3[e] = a; l3[e] = b;
+            }
+            u32x4* dst = patch + g * R2_PIX + r * SP_W + 4 * q - 3;
+            if (q > 0) { dst[0] = __builtin_bit_cast(u32x4, h0); dst[R2_PART] = __builtin_bit_cast(u32x4, l0); }
+            if (q > 0 && q < SQ_QPR - 1) {
+                dst[1] = __builtin_bit_cast(u32x4, h1); dst[R2_PART + 1] = __builtin_bit_cast(u32x4, l1);
+                dst[2] = __builtin_bit_cast(u32x4, h2); dst[R2_PART + 2] = __builtin_bit_cast(u32x4, l2);
+            }
+            if (q < SQ_QPR - 1) { dst[3] = __builtin_bit_cast(u32x4, h3); dst[R2_PART + 3] = __builtin_bit_cast(u32x4, l3); }
+        }
+    };
+    // weights of the k-step pair (2 pr, 2 pr + 1): 4608 units, 18 per thread
+    u32x4 wreg[18];
+    auto wfetch = [&](int pr) {
+#pragma unroll
+        for (int i = 0; i < 18; ++i) {
+            const int q = tid + i * S_THREADS;
+            const int kk = q / S_WUNITS, q1 = q - kk * S_WUNITS;
+            const int part = q1 / S_WPART, rem = q1 - part * S_WPART;
+            const int tap = rem >> 7, hh = (rem >> 6) & 1, c = rem & 63;
+            const int ks = 2 * pr + kk;
+            if (c < couts && ks < p.ksteps) wreg[i] = p.wq[1 + (size_t)(((tap * p.ksteps + ks) * 2 + part) * 2 + hh) * p.coutPad + co0 + c];
+        }
+    };
+    auto wpark = [&](int pr) {
+#pragma unroll
+        for (int i = 0; i < 18; ++i) {
+            const int q = tid + i * S_THREADS;
+            const int kk = q / S_WUNITS;
+            if ((q & 63) < couts && 2 * pr + kk < p.ksteps) wbuf[q] = wreg[i];
+        }
+    };
+
+    f32x16 acc;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[i] = 0.0f;
+    const int npairs = (p.ksteps + 1) >> 1;
+    issue_loads(0);
+    wfetch(0);
+    park_loads();
+    wpark(0);
     __syncthreads();
-    for (int s = 128; s > 0; s >>= 1) {
+    for (int pr = 0; pr < npairs; ++pr) {
+        const bool more = pr + 1 < npairs;
+        const bool restage = more && ((pr + 1) & 1) == 0;                    // the next pair starts a new 64-channel chunk
+        if (more) wfetch(pr + 1);                                            // in flight under this pair's MFMAs
+        if (restage) issue_loads((pr + 1) * 32);
+        if (active) {
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk) {
+                if (2 * pr + kk < p.ksteps) {
+                    const u32x4* wl = wbuf + kk * S_WUNITS + h * 64 + cb * 32 + j;
+                    const u32x4* bl = patch + (2 * (2 * (pr & 1) + kk) + h) * R2_PIX + row * SP_W + j;
+#pragma unroll
+                    for (int tap = 0; tap < 9; ++tap) {
+                        const int dy = tap / 3, dx = tap - dy * 3;
+                        const f16x8 ah = __builtin_bit_cast(f16x8, wl[tap * 128]);
+                        const f16x8 al = __builtin_bit_cast(f16x8, wl[S_WPART + tap * 128]);
+                        const f16x8 as = ah * (_Float16)0.00048828125f;     // w_hi 2^-11: partner of the scaled x_lo'
+                        const f16x8 bh = __builtin_bit_cast(f16x8, bl[dy * SP_W + dx]);
+                        const f16x8 bo = __builtin_bit_cast(f16x8, bl[R2_PART + dy * SP_W + dx]);
+                        acc = mfma16(al, bh, acc);
+                        acc = mfma16(as, bo, acc);
+                        acc = mfma16(ah, bh, acc);
+                    }
+                }
+            }
+        }
+        __syncthreads();                                                     // weight buffer (and, before a new chunk, the patch) free
+        if (more) {
+            if (restage) park_loads();
+            wpark(pr + 1);
+            __syncthreads();
+        }
+    }
+    // ---- epilogue: one output row x 32 channels per wave, transposed through 4 KB of the idle patch buffer ---------
+    if (!active || (p.dbg & 4)) return;
+    const float unscale = reinterpret_cast<const float*>(p.wq)[1];
+    const rsrc_t yrs = __builtin_amdgcn_make_buffer_rsrc(p.y + (size_t)n * p.yImage, 0, (int)((size_t)p.Cout * p.yPlane * 4), 0x00020000);
+    const rsrc_t rrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.residual ? p.residual + (size_t)n * p.rImage : p.y), 0,
+                                                         p.residual ? (int)((size_t)p.Cout * p.rPlane * 4) : 0, 0x00020000);
+    const int oy = oy0 + row;
+    float* tr = reinterpret_cast<float*>(patch) + wave * (32 * 32);
+    const bool wide = ((p.W | p.yPlane | p.rPlane) & 3) == 0;
+    if (wide) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const int c = (i & 3) + 8 * (i >> 2) + 4 * h;
+            float val = acc[i] * unscale + (p.bias ? p.bias[min(co0 + cb * 32 + c, p.Cout - 1)] : 0.0f);
+            if (p.act == ISR_ACT_RELU) val = val > 0.f ? val : 0.f;
+            else if (p.act == ISR_ACT_LEAKY) val = val > 0.f ? val : val * p.slope;
+            tr[c * 32 + j] = val;
+        }
+        __builtin_amdgcn_s_waitcnt(0xC07F);                                  // lgkmcnt(0): same-wave hand-off through LDS
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int q = lane + 64 * k;                                     // float4 index: cout = q / 8, pixel group = q % 8
+            const int co = co0 + cb * 32 + (q >> 3), px = ox0 + (q & 7) * 4;
+            const bool ok = oy < p.H && px < p.W && co < p.Cout;
+            float4 val = reinterpret_cast<const float4*>(tr)[q];
+            const unsigned pixoff = (unsigned)(oy * p.W + px) * 4u;
+            if (p.residual) {
+                const u32x4 rr = __builtin_amdgcn_raw_buffer_load_b128(rrs, (int)(ok ? pixoff + (unsigned)co * (unsigned)p.rPlane * 4u : BAD_OFFSET), 0, 0);
+                const float4 rf = __builtin_bit_cast(float4, rr);
+                if (p.act == ISR_ACT_GATE) {
+                    val.x = rf.x > 0.f ? val.x : 0.f; val.y = rf.y > 0.f ? val.y : 0.f;
+                    val.z = rf.z > 0.f ? val.z : 0.f; val.w = rf.w > 0.f ? val.w : 0.f;
+                } else {
+                    val.x += rf.x; val.y += rf.y; val.z += rf.z; val.w += rf.w;
+                }
+            }
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, val), yrs,
+                                                   (int)(ok ? pixoff + (unsigned)co * (unsigned)p.yPlane * 4u : BAD_OFFSET), 0, 0);
+        }
+    } else {
+        const int ox = ox0 + j;
+        const unsigned pix = (oy < p.H && ox < p.W) ? (unsigned)(oy * p.W + ox) * 4u : BAD_OFFSET;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const int co = co0 + cb * 32 + (i & 3) + 8 * (i >> 2) + 4 * h;
+            float val = acc[i] * unscale + (p.bias ? p.bias[min(co, p.Cout - 1)] : 0.0f);
+            if (p.act == ISR_ACT_RELU) val = val > 0.f ? val : 0.f;
+            else if (p.act == ISR_ACT_LEAKY) val = val > 0.f ? val : val * p.slope;
+            const bool ok = pix != BAD_OFFSET && co < p.Cout;
+            if (p.residual) {
+                const float rv = buf_load(rrs, ok ? pix + (unsigned)co * (unsigned)p.rPlane * 4u : BAD_OFFSET);
+                if (p.act == ISR_ACT_GATE) val = rv > 0.f ? val : 0.f; else val += rv;
+            }
+            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, val), yrs,
+                                                  ok ? (int)(pix + (unsigned)co * (unsigned)p.yPlane * 4u) : (int)BAD_OFFSET, 0, 0);
+        }
+    }
+}
+
+// header unit of the prepared weights: { 2^S, 2^-S, S (int), 0 } with max |w| 2^S in [2^13, 2^14)
+__global__ __launch_bounds__(1024) void split_scale_kernel(const float* __restrict__ w, int count, u32x4* __restrict__ wq)
+{
+    // one workgroup, but wide and with independent loads in flight: training re-prepares every layer's weights (and their
+    // flipped / transposed twin) after every optimizer step, 48 times per step
+    __shared__ float red[1024];
+    float m0 = 0.0f, m1 = 0.0f, m2 = 0.0f, m3 = 0.0f;
+    int i = threadIdx.x;
+    for (; i + 3072 < count; i += 4096) {
+        m0 = fmaxf(m0, fabsf(w[i])); m1 = fmaxf(m1, fabsf(w[i + 1024]));
+        m2 = fmaxf(m2, fabsf(w[i + 2048])); m3 = fmaxf(m3, fabsf(w[i + 3072]));
+    }
+    for (; i < count; i += 1024) m0 = fmaxf(m0, fabsf(w[i]));
+    red[threadIdx.x] = fmaxf(fmaxf(m0, m1), fmaxf(m2, m3));
+    __syncthreads();
+    for (int s = 512; s > 0; s >>= 1) {
         if ((int)threadIdx.x < s) red[threadIdx.x] = fmaxf(red[threadIdx.x], red[threadIdx.x + s]);
         __syncthreads();
     }
@@ -898,6 +1106,7 @@ __global__ void prepare_weights_split_kernel(const float* __restrict__ w, u32x4*
 
 static unsigned long long* g_split_stamps = nullptr;
 static int g_split_dbg = 0;
+static int g_split_small = 1;     // 2-row-tile kernel for small images (isrDebugSetSplitSmall)
 static int g_split_slots = 0;     // tests: cap on the persistent kernels' grid (0 = two / one workgroup per CU)
 static int g_split_algo = 1;      // plain layers: 1 persistent streaming kernel (default), 2 wide 512-thread kernel, 0 one workgroup per tile
 
@@ -907,6 +1116,7 @@ void isrDebugSetSplitStampBuffer(unsigned long long* buf) { g_split_stamps = buf
 void isrDebugSetSplitAblation(int bits) { g_split_dbg = bits; }
 void isrDebugSetSplitAlgo(int a) { g_split_algo = a; }
 void isrDebugSetSplitSlots(int n) { g_split_slots = n; }
+void isrDebugSetSplitSmall(int on) { g_split_small = on; }
 
 long long isrConvSplitWeightBytes(int Cin, int Cout)
 {
@@ -919,7 +1129,7 @@ int isrConvSplitPrepare(const float* w, void* wq, int Cout, int Cin, void* strea
     if (!w || !wq || Cout <= 0 || Cin <= 0) return -1;
     const int ksteps = (Cin + 15) / 16, coutPad = ((Cout + 31) / 32) * 32;
     const int total = 9 * ksteps * 2 * coutPad;
-    hipLaunchKernelGGL(split_scale_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, w, Cout * Cin * 9, (u32x4*)wq);
+    hipLaunchKernelGGL(split_scale_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, w, Cout * Cin * 9, (u32x4*)wq);
     hipLaunchKernelGGL(prepare_weights_split_kernel, dim3((total + 255) / 256), dim3(256), 0, (hipStream_t)stream,
                        w, (u32x4*)wq, Cout, Cin, ksteps, coutPad);
     return hipGetLastError() == hipSuccess ? 0 : -2;
@@ -964,6 +1174,21 @@ int isrConv3x3ForwardSplit(const float* x, const void* wq, const float* bias, co
     const dim3 grid((unsigned)nwg), block(S_THREADS);
     hipStream_t s = (hipStream_t)stream;
     hipEvent_t e0 = nullptr, e1 = nullptr;
+    // small images (a batch of training crops): 2-row tiles when the 8-row tiling would leave most CUs idle
+    const long long tiles2 = (long long)N * p.tilesX * ((H + R2_H - 1) / R2_H) * p.cgroups;
+    if (!upsample2x && p.quads && !g_split_stamps && g_split_small && nwg < 256 && tiles2 >= 64 && tiles2 <= 0x7fffffffLL) {
+        static bool attr2 = false;
+        if (!attr2) {
+            (void)hipFuncSetAttribute((const void*)conv3x3_split_rows2_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, R2_LDS_BYTES);
+            attr2 = true;
+        }
+        p.tilesY = (H + R2_H - 1) / R2_H;
+        isr_profile_record(ISR_VARIANT_SPLIT_ROWS2, 2.0 * 9 * Cin * Cout * (double)N * H * W, &e0, &e1);
+        const dim3 g2((unsigned)tiles2);
+        if (e0 || e1) hipExtLaunchKernelGGL(conv3x3_split_rows2_kernel, g2, block, R2_LDS_BYTES, s, e0, e1, 0, p);
+        else hipLaunchKernelGGL(conv3x3_split_rows2_kernel, g2, block, R2_LDS_BYTES, s, p);
+        return hipGetLastError() == hipSuccess ? 0 : -2;
+    }
     if (!upsample2x && p.quads && !g_split_stamps && g_split_algo == 2) {
         // wide form: one 512-thread workgroup per CU, 16 x 32 tiles, hand-pipelined fragment reads
         static int cus = 0;

@@ -139,7 +139,7 @@ VARIANT_NAMES = {6: "conv3x3_small_cout_kernel", 2: "conv3x3_fwd_kernel<1,false>
                  8: "conv3x3_fwd2_kernel<false,4>", 9: "conv3x3_fwd2_kernel<true,4>",
                  10: "conv3x3_fwd2_kernel<false,1>", 11: "conv3x3_fwd2_kernel<true,1>", 12: "conv3x3_rowsplit_kernel",
                  13: "conv3x3_split_kernel<false>", 14: "conv3x3_split_kernel<true>",
-                 15: "conv3x3_split_stream_kernel", 16: "conv3x3_split_wide_kernel"}
+                 15: "conv3x3_split_stream_kernel", 16: "conv3x3_split_wide_kernel", 17: "conv3x3_split_rows2_kernel"}
 
 
 def profile_enable(on):
@@ -409,6 +409,7 @@ TRAIN_BF16 = False
 # all weight gradients stay on the exact fp32 MFMA kernels.
 TRAIN_SPLIT = True
 TRAIN_SPLIT_MIN_TILES = 256
+TRAIN_SPLIT_MIN_TILES2 = 128      # small images: 2-row tiles (the library picks that form below 256 tiles of 8x32 pixels)
 
 
 def _train_conv(x, weight, transpose_flip, bias, residual, act):
@@ -423,7 +424,10 @@ def _train_conv(x, weight, transpose_flip, bias, residual, act):
         return _launch_lp(x, _prepare_lp(weight, transpose_flip, True), bias, residual, cout, act, 0.0, False, True, packed=True)
     # the split-operand kernel (fp32-equivalent accuracy, 2.3x the fp32 MFMA kernel) once a layer has enough 8x32-pixel
     # tiles to fill the persistent grid: the 64^2 / 128^2 post-block layers of a crop batch, 54 % of the step's flops
-    if TRAIN_SPLIT and cout > 8 and cin > 8 and tiles >= TRAIN_SPLIT_MIN_TILES and x.shape[3] % 4 == 0 and _split_fits(x, cout, False):
+    # ... or, for a batch of small crops, enough 2-row tiles for the small-image form (conv3x3_split_rows2_kernel)
+    tiles2 = x.shape[0] * ((x.shape[2] + 1) // 2) * ((x.shape[3] + 31) // 32)
+    if TRAIN_SPLIT and cout > 8 and cin > 8 and (tiles >= TRAIN_SPLIT_MIN_TILES or tiles2 >= TRAIN_SPLIT_MIN_TILES2) \
+            and x.shape[3] % 4 == 0 and _split_fits(x, cout, False):
         return _launch_split(x, _prepare_split(weight, transpose_flip), bias, residual, cout, act, 0.0, False, packed=True)
     return _launch_forward(x, prepare_weights(weight, transpose_flip=transpose_flip), bias, residual, cin, cout, act, 0.0, False,
                            packed=True)

@@ -131,25 +131,28 @@ def test_conv3x3_padded_channel_planes(conv_mode):
     assert (y2.cpu().double() - ref2).abs().max().item() <= 1e-4
 
 
-@pytest.mark.parametrize("algo", [0, 1, 2])
+@pytest.mark.parametrize("form", ["tile", "stream", "wide", "rows2"])
 @pytest.mark.parametrize("slots", [8, 24])
-def test_split_kernel_forms_agree_when_workgroups_walk_many_tiles(algo, slots):
-    """The plain split-operand layer has three kernel forms (one workgroup per tile; persistent streaming; wide 512-thread).
-    The persistent ones walk a list of tiles per workgroup -- with the grid capped to a few workgroups even a small image
-    exercises the tile-to-tile hand-over (next tile's operands in flight under the last k-step, epilogue scratch vs parked
-    data), ragged last tile rows (H % 16 != 0) and an odd number of k-steps (Cin = 101)."""
+def test_split_kernel_forms_agree_when_workgroups_walk_many_tiles(form, slots):
+    """The plain split-operand layer has four kernel forms (one workgroup per 8x32 tile; persistent streaming; wide
+    512-thread; 2-row tiles for small images).  The persistent ones walk a list of tiles per workgroup -- with the grid
+    capped to a few workgroups even a small image exercises the tile-to-tile hand-over (next tile's operands in flight
+    under the last k-step, epilogue scratch vs parked data); all of them see ragged last tile rows and an odd number of
+    k-steps (Cin = 101: four 64-channel-chunk / k-step-pair boundaries), a 32-channel output and a fused skip."""
     import ctypes
     from isosurfacesuperresolution_amd import ops
     lib = ops._sr()
-    lib.isrDebugSetSplitAlgo.argtypes = [ctypes.c_int]
-    lib.isrDebugSetSplitSlots.argtypes = [ctypes.c_int]
+    for fn in (lib.isrDebugSetSplitAlgo, lib.isrDebugSetSplitSlots, lib.isrDebugSetSplitSmall):
+        fn.argtypes = [ctypes.c_int]
     g = torch.Generator().manual_seed(31)
     old = ops.SPLIT_F16
     ops.SPLIT_F16 = True
-    lib.isrDebugSetSplitAlgo(algo)
+    lib.isrDebugSetSplitAlgo({"tile": 0, "stream": 1, "wide": 2, "rows2": 1}[form])
+    lib.isrDebugSetSplitSmall(1 if form == "rows2" else 0)
     lib.isrDebugSetSplitSlots(slots)
     try:
-        for N, Cin, Cout, h, w, act, has_r in ((1, 64, 64, 70, 96, 'relu', False), (2, 101, 64, 45, 64, 'none', True), (1, 64, 32, 30, 128, 'relu', True)):
+        for N, Cin, Cout, h, w, act, has_r in ((1, 64, 64, 70, 96, 'relu', False), (2, 101, 64, 45, 64, 'none', True), (1, 64, 32, 31, 128, 'relu', True),
+                                               (16, 64, 64, 32, 32, 'relu', True)):
             x = torch.rand(N, Cin, h, w, generator=g) * 2 - 1
             wt = (torch.rand(Cout, Cin, 3, 3, generator=g) * 2 - 1) / (3.0 * Cin ** 0.5)
             b = torch.rand(Cout, generator=g) - 0.5
@@ -158,10 +161,11 @@ def test_split_kernel_forms_agree_when_workgroups_walk_many_tiles(algo, slots):
             with torch.no_grad():
                 y = ops.conv3x3(x.cuda(), wt.cuda(), b.cuda(), act=act, residual=res.cuda() if has_r else None)
             err = (y.cpu().double() - ref).abs().max().item()
-            assert err <= 1e-4, (algo, slots, (N, Cin, Cout, h, w), err)
+            assert err <= 1e-4, (form, slots, (N, Cin, Cout, h, w), err)
     finally:
         lib.isrDebugSetSplitAlgo(1)
         lib.isrDebugSetSplitSlots(0)
+        lib.isrDebugSetSplitSmall(1)
         ops.SPLIT_F16 = old
 
 
