@@ -460,8 +460,10 @@ def _weight_grad(xs, gzs, weight, has_bias):
         pg = (ctypes.c_void_p * len(part_g))(*[t.data_ptr() for t in part_g])
         # mixed-precision mode: bf16 operands once there are enough 4x32-pixel tiles to stream (the kernel is memory bound)
         tiles = n * len(part_x) * ((h + 3) // 4) * ((w + 31) // 32)
-        big = w % 4 == 0 and tiles >= 1024 and cout > 8 and all(t.data_ptr() % 16 == 0 for t in part_g)
-        fn = lib.isrConv3x3WeightGradSegmentsBf16 if (TRAIN_BF16 and big) else (
+        big = w % 4 == 0 and tiles >= 1024 and all(t.data_ptr() % 16 == 0 for t in part_g)
+        # (the split kernel also takes the 64 -> 6 output layer: its 32-row MFMA tile is mostly padding there, but at a
+        # fifth of the matrix cycles it still beats the fp32 K-split kernel)
+        fn = lib.isrConv3x3WeightGradSegmentsBf16 if (TRAIN_BF16 and big and cout > 8) else (
             lib.isrConv3x3WeightGradSegmentsSplit if (TRAIN_SPLIT and big) else lib.isrConv3x3WeightGradSegments)
         rc = fn(px, pg, len(part_x), _ptr(dw), _ptr(db), _ptr(ws), n, cin, h, w, cout, _stream())
         if rc != 0:

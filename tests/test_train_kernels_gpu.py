@@ -433,7 +433,7 @@ def test_deferred_weight_gradients_respect_parameter_hooks():
 
 
 @pytest.mark.parametrize("gz_scale", [1.0, 3e-6, 2e3])
-@pytest.mark.parametrize("case", [(10, 16, 64, 64, 32, 32), (3, 12, 101, 64, 64, 64), (2, 16, 64, 64, 128, 128)])
+@pytest.mark.parametrize("case", [(10, 16, 64, 64, 32, 32), (3, 12, 101, 64, 64, 64), (2, 16, 64, 64, 128, 128), (2, 16, 64, 6, 128, 128)])
 def test_split_operand_weight_gradient_matches_fp64(case, gz_scale):
     """isrConv3x3WeightGradSegmentsSplit (three fp16 MFMAs per product on (hi, lo) operand pairs, gz scaled by a power of
     two from its maximum) against fp64, next to the exact fp32 kernel on the same data: as close to fp64 as the fp32
