@@ -359,10 +359,11 @@ def _prepare_split(weight, transpose_flip=False):
 
 
 def _split_fits(x, cout, upsample2x):
-    """The split kernel addresses one image through 32-bit buffer offsets: every tensor of a launch must stay below 2 GiB."""
+    """The split kernels address one image through 32-bit buffer offsets: input and output of a launch must each stay
+    below 2 GiB (the caller falls back to the exact fp32 kernels otherwise)."""
     h, w = (2 * x.shape[2], 2 * x.shape[3]) if upsample2x else (x.shape[2], x.shape[3])
     xplane = max(x.stride(1), x.shape[2] * x.shape[3]) if x.stride(3) == 1 else x.shape[2] * x.shape[3]
-    return x.shape[1] * xplane * (16 if upsample2x else 4) < 2 ** 31 and cout * (h * w + plane_pad(h, w)) * 4 < 2 ** 31
+    return x.shape[1] * xplane * 4 < 2 ** 31 and cout * (h * w + plane_pad(h, w)) * 4 < 2 ** 31
 
 
 def conv3x3_split(x, weight, bias=None, act='none', slope=0.01, residual=None, upsample2x=False):
