@@ -665,7 +665,7 @@ bool launchFrame(float* out, hipStream_t stream)
         buildGvdbFrame(f, a, v, g.lastOrigin, g.lastLookAt);
         iso_launch_render_gvdb(p, f, stream, e0, e1);
     } else if (g.statsOut) {
-        iso_launch_render_stats(p, g.statsOut, stream);
+        iso_launch_render_stats(p, g.variant, g.statsOut, stream);
     } else {
         iso_launch_render(p, g.variant, stream, e0, e1, g.waveCap);
         if (g.variant == 2) {
@@ -886,7 +886,7 @@ int isoGateResident(void* stream, int timeoutUs)
 
 int isoSetKernelVariant(int variant)
 {
-    if (variant < 0 || variant > 3) return -1;
+    if (variant < 0 || variant > 5) return -1;
     g.variant = variant;
     return 0;
 }

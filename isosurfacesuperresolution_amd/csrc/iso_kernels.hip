@@ -275,6 +275,137 @@ __device__ bool hits_hierarchy(const IsoRenderParams& P, Ray& ray, double& time)
     return hits_hierarchy(P, ray, time, nt);
 }
 
+// ---- the same traversal as ONE flat per-lane state machine ------------------------------------------------------------
+// hits_hierarchy() nests four loops; a wave runs them in lock step, so every round of the leaf loop lasts as long as the
+// longest voxel march any of its 64 rays does in that round while the rays whose leaf is skipped wait: the heaviest tile of
+// the bench frame costs 1.13 M cycles although its busiest ray, marched alone, costs 0.26 M (tools/raymarch_lone.py).
+// Here every lane carries a state and each iteration of the single loop does at most WALK hierarchy steps and then ONE
+// trilinear sample -- the leaf's first sample, a march sample or a bisection sample, all through the same code -- so a wave
+// lasts about as long as its busiest ray.  Same operations on the same values in the same per-ray order: bit-identical.
+// A level's DDA keeps only what changes: the per-axis step and delta are +-DIM and DIM * |1/dir| (DDA.h:79-103), recomputed
+// from the ray where an axis is stepped; the end of a level's interval is the parent's dda_next.  Level 2 (4096^3 nodes)
+// has one node, so it is a prologue.
+struct Lvl { double t0, nx, ny, nz; int vx, vy, vz; };
+
+template <int LOG2DIM>
+__device__ __forceinline__ void lvl_init(Lvl& d, const Ray& r, double t0)
+{
+    constexpr int DIM = 1 << LOG2DIM;
+    d.t0 = t0;
+    double px, py, pz;
+    ray_at(r, d.t0, px, py, pz);
+    d.vx = ((int)floor(px)) & (~(DIM - 1));
+    d.vy = ((int)floor(py)) & (~(DIM - 1));
+    d.vz = ((int)floor(pz)) & (~(DIM - 1));
+#define ISO_AXIS(V, N, P, DIR, INV)                                          \
+    if (DIR == 0.0) N = DBL_MAX;                                              \
+    else if (INV > 0) N = d.t0 + ((double)(V + DIM) - P) * INV;               \
+    else N = d.t0 + ((double)V - P) * INV;
+    ISO_AXIS(d.vx, d.nx, px, r.dx, r.ix)
+    ISO_AXIS(d.vy, d.ny, py, r.dy, r.iy)
+    ISO_AXIS(d.vz, d.nz, pz, r.dz, r.iz)
+#undef ISO_AXIS
+}
+
+template <int DIM>
+__device__ __forceinline__ void lvl_axis(double dir, double inv, int& S, double& D)
+{
+    if (dir == 0.0) { S = 0; D = DBL_MAX; }
+    else if (inv > 0) { S = DIM; D = (double)S * inv; }
+    else { S = -DIM; D = (double)S * inv; }
+}
+
+__device__ __forceinline__ double lvl_next(const Lvl& d, double t1)
+{
+    double a = t1 < d.nx ? t1 : d.nx;
+    double b = d.ny < d.nz ? d.ny : d.nz;
+    return b < a ? b : a;
+}
+
+template <int LOG2DIM>
+__device__ __forceinline__ bool lvl_step(Lvl& d, const Ray& r, double t1)
+{
+    constexpr int DIM = 1 << LOG2DIM;
+    const int key = ((d.nx < d.ny) << 2) + ((d.nx < d.nz) << 1) + (d.ny < d.nz);
+    int S; double D;
+    if (key >= 6) { lvl_axis<DIM>(r.dx, r.ix, S, D); d.t0 = d.nx; d.nx += D; d.vx += S; }
+    else if (key == 1 || key == 3) { lvl_axis<DIM>(r.dy, r.iy, S, D); d.t0 = d.ny; d.ny += D; d.vy += S; }
+    else { lvl_axis<DIM>(r.dz, r.iz, S, D); d.t0 = d.nz; d.nz += D; d.vz += S; }
+    return d.t0 <= t1;
+}
+
+enum { FS_STEP1 = 0, FS_NODE1 = 1, FS_LEAF = 2, FS_ENTER = 3, FS_MARCH = 4, FS_BISECT = 5, FS_MISS = 10, FS_HIT = 11 };
+
+template <int WALK, typename TR>
+__device__ __forceinline__ bool hits_flat(const IsoRenderParams& P, const Ray& ray, double& time, TR& tr)
+{
+    double T2;                       // end of the level-2 node's interval = d1.t1
+    Lvl d1;
+    {
+        DDA d2;
+        dda_init<12>(d2, ray);
+        bool found = false;
+        do {
+            if (has_node2(P, d2.vx, d2.vy, d2.vz)) { found = true; break; }
+        } while (dda_step(d2));
+        if (!found) return false;    // no other level-2 node exists: once the walk below leaves this one, the ray has missed
+        T2 = dda_next(d2);
+        lvl_init<7>(d1, ray, d2.t0);
+    }
+    Lvl d0, dv;
+    d0.t0 = d0.nx = d0.ny = d0.nz = 0.0; d0.vx = d0.vy = d0.vz = 0;
+    dv = d0;
+    double t1_0 = 0.0, t1_v = 0.0;   // ends of the current node's / leaf's interval (dda_next of the parent level)
+    double b1 = 0.0;                 // bisection: [dv.t0, b1]
+    float v0 = 0.0f;
+    int st = FS_NODE1;
+    while (st < FS_MISS) {
+#pragma unroll
+        for (int k = 0; k < WALK; ++k) {
+            if (st == FS_STEP1) st = lvl_step<7>(d1, ray, T2) ? FS_NODE1 : FS_MISS;
+            if (st == FS_NODE1) {
+                if (has_node1(P, d1.vx, d1.vy, d1.vz) && node1_may_cross(P, d1.vx, d1.vy, d1.vz)) {
+                    t1_0 = lvl_next(d1, T2);
+                    lvl_init<3>(d0, ray, d1.t0);
+                    st = FS_LEAF;
+                } else st = FS_STEP1;
+            } else if (st == FS_LEAF) {
+                bool march = false;
+                if (has_leaf(P, d0.vx, d0.vy, d0.vz)) {
+                    march = leaf_may_cross(P, d0.vx, d0.vy, d0.vz);
+                    tr.leaf(march);
+                }
+                if (march) {
+                    t1_v = lvl_next(d0, t1_0);
+                    lvl_init<0>(dv, ray, d0.t0);
+                    st = FS_ENTER;
+                } else if (!lvl_step<3>(d0, ray, t1_0)) st = FS_STEP1;
+            }
+        }
+        if (st >= FS_ENTER && st < FS_MISS) {
+            double t;
+            if (st == FS_ENTER) t = dv.t0;
+            else if (st == FS_MARCH) t = lvl_next(dv, t1_v);
+            else t = 0.5 * (dv.t0 + b1);
+            const float v = interp_value(P, ray, t);
+            tr.sample(1);
+            if (st == FS_ENTER) { v0 = v; st = FS_MARCH; }
+            else if (st == FS_MARCH) {
+                if (v0 * v <= 0.0f) { b1 = t; st = FS_BISECT; }             // the crossing lies in [dv.t0, t]
+                else {
+                    v0 = v;
+                    if (!lvl_step<0>(dv, ray, t1_v)) st = lvl_step<3>(d0, ray, t1_0) ? FS_LEAF : FS_STEP1;
+                }
+            } else {
+                if (v0 * v <= 0.0f) b1 = t;
+                else { dv.t0 = t; v0 = v; }
+                if (++st == FS_BISECT + 5) { time = 0.5 * (dv.t0 + b1); st = FS_HIT; }
+            }
+        }
+    }
+    return st == FS_HIT;
+}
+
 __device__ __forceinline__ double len3(double x, double y, double z) { return sqrt(x * x + y * y + z * z); }
 
 // Vec3::normalize(eps = 1e-7), TP/openvdb/math/Vec3.h:377-385
@@ -469,7 +600,8 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg)
 }
 
 // ---- variant 0: per-lane gather ------------------------------------------------------------
-template <bool AO>
+// FLAT: 0 = the nested loops of hits_hierarchy, k > 0 = hits_flat with k hierarchy steps per sample
+template <bool AO, int FLAT = 0>
 __device__ __forceinline__ void render_gather_tile(const IsoRenderParams& P, int vb, int tiles_x, int ntiles, int lane, bool remap = true)
 {
     const int tile = remap ? xcd_remap(vb, ntiles) : vb;
@@ -482,28 +614,27 @@ __device__ __forceinline__ void render_gather_tile(const IsoRenderParams& P, int
         o[8] = -0.0f; o[9] = -0.0f;
         Ray r;
         double wdx, wdy, wdz, it;
-        if (make_ray(P, i, j, r, wdx, wdy, wdz) && hits_hierarchy(P, r, it))
-            shade_hit<AO>(P, r, it, wdx, wdy, wdz, i, j, o);
+        bool hit = make_ray(P, i, j, r, wdx, wdy, wdz);
+        if (hit) {
+            if (FLAT > 0) { NoTrace nt; hit = hits_flat<(FLAT > 0 ? FLAT : 1)>(P, r, it, nt); }
+            else hit = hits_hierarchy(P, r, it);
+        }
+        if (hit) shade_hit<AO>(P, r, it, wdx, wdy, wdz, i, j, o);
     }
     store_pixel(P, i, j, o);
 }
 
-template <bool AO>
-__device__ __forceinline__ void render_gather_pixel(const IsoRenderParams& P)
-{
-    const int tiles_x = (P.W + 7) >> 3, ntiles = tiles_x * ((P.H + 7) >> 3);
-    render_gather_tile<AO>(P, blockIdx.x, tiles_x, ntiles, threadIdx.x);
-}
-
-template <bool AO>
+template <bool AO, int FLAT>
 __global__ __launch_bounds__(64) void iso_render_gather(const IsoRenderParams P)
 {
-    render_gather_pixel<AO>(P);
+    const int tiles_x = (P.W + 7) >> 3, ntiles = tiles_x * ((P.H + 7) >> 3);
+    render_gather_tile<AO, FLAT>(P, blockIdx.x, tiles_x, ntiles, threadIdx.x);
 }
 
 // ---- diagnostics: variant 0 with per-tile clocks and per-ray step counts (never on the product path) ------------------
 // out[tile] = { cycles of the wave (s_memtime), samples of its busiest ray, leaves marched / skipped by that ray,
 //               sum of samples over its rays, rays that hit }
+template <int FLAT>
 __global__ __launch_bounds__(64) void iso_render_stats(const IsoRenderParams P, long long* __restrict__ out)
 {
     const long long c0 = (long long)__builtin_amdgcn_s_memtime();
@@ -516,7 +647,9 @@ __global__ __launch_bounds__(64) void iso_render_stats(const IsoRenderParams P, 
         Ray r;
         double wdx, wdy, wdz, it;
         float o[12] = { 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 1.0f, 0.f };
-        if (make_ray(P, i, j, r, wdx, wdy, wdz) && hits_hierarchy(P, r, it, tr)) {
+        bool h = make_ray(P, i, j, r, wdx, wdy, wdz);
+        if (h) h = FLAT > 0 ? hits_flat<(FLAT > 0 ? FLAT : 1)>(P, r, it, tr) : hits_hierarchy(P, r, it, tr);
+        if (h) {
             shade_hit<false>(P, r, it, wdx, wdy, wdz, i, j, o);
             hit = 1;
         }
@@ -956,16 +1089,24 @@ void iso_launch_render(const IsoRenderParams& p, int variant, void* stream, void
         (void)hipMemsetAsync(p.tileQueue, 0, 8 * sizeof(unsigned), st);
         if (p.aoSamples > 0) hipExtLaunchKernelGGL(iso_render_gather_slim<true>, capped, block4, 0, st, e0, e1, 0, p);
         else hipExtLaunchKernelGGL(iso_render_gather_slim<false>, capped, block4, 0, st, e0, e1, 0, p);
+    } else if (variant == 4) {
+        if (p.aoSamples > 0) hipExtLaunchKernelGGL((iso_render_gather<true, 1>), grid, block, 0, st, e0, e1, 0, p);
+        else hipExtLaunchKernelGGL((iso_render_gather<false, 1>), grid, block, 0, st, e0, e1, 0, p);
+    } else if (variant == 5) {
+        if (p.aoSamples > 0) hipExtLaunchKernelGGL((iso_render_gather<true, 2>), grid, block, 0, st, e0, e1, 0, p);
+        else hipExtLaunchKernelGGL((iso_render_gather<false, 2>), grid, block, 0, st, e0, e1, 0, p);
     } else {
-        if (p.aoSamples > 0) hipExtLaunchKernelGGL(iso_render_gather<true>, grid, block, 0, st, e0, e1, 0, p);
-        else hipExtLaunchKernelGGL(iso_render_gather<false>, grid, block, 0, st, e0, e1, 0, p);
+        if (p.aoSamples > 0) hipExtLaunchKernelGGL((iso_render_gather<true, 0>), grid, block, 0, st, e0, e1, 0, p);
+        else hipExtLaunchKernelGGL((iso_render_gather<false, 0>), grid, block, 0, st, e0, e1, 0, p);
     }
 }
 
-void iso_launch_render_stats(const IsoRenderParams& p, long long* out, void* stream)
+void iso_launch_render_stats(const IsoRenderParams& p, int variant, long long* out, void* stream)
 {
     const int tiles = ((p.W + 7) >> 3) * ((p.H + 7) >> 3);
-    hipLaunchKernelGGL(iso_render_stats, dim3(tiles), dim3(64), 0, (hipStream_t)stream, p, out);
+    if (variant == 4) hipLaunchKernelGGL(iso_render_stats<1>, dim3(tiles), dim3(64), 0, (hipStream_t)stream, p, out);
+    else if (variant == 5) hipLaunchKernelGGL(iso_render_stats<2>, dim3(tiles), dim3(64), 0, (hipStream_t)stream, p, out);
+    else hipLaunchKernelGGL(iso_render_stats<0>, dim3(tiles), dim3(64), 0, (hipStream_t)stream, p, out);
 }
 
 void iso_launch_gate(const unsigned* resident, unsigned target, int timeoutUs, void* stream)

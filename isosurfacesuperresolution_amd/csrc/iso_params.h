@@ -68,7 +68,7 @@ struct IsoGvdbFrame {
 void iso_launch_render(const IsoRenderParams& p, int variant, void* stream, void* startEvent, void* stopEvent, int waveCap);
 void iso_launch_render_gvdb(const IsoRenderParams& p, const IsoGvdbFrame& f, void* stream, void* startEvent, void* stopEvent);
 // diagnostics: variant 0 with per-tile clocks and step counts, out[tiles][6] (see iso_render_stats)
-void iso_launch_render_stats(const IsoRenderParams& p, long long* out, void* stream);
+void iso_launch_render_stats(const IsoRenderParams& p, int variant, long long* out, void* stream);
 // One wave on `stream` that spins until *resident has reached `target` (wrap-safe) or `timeoutUs` have passed.
 void iso_launch_gate(const unsigned* resident, unsigned target, int timeoutUs, void* stream);
 void iso_launch_brick_flags(const float* dense, int nx, int ny, int nz, int nbx, int nby, int nbz,

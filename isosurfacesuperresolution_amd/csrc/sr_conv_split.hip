@@ -39,6 +39,7 @@ namespace {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 typedef __amdgpu_buffer_rsrc_t rsrc_t;
 
@@ -241,7 +242,8 @@ __global__ __launch_bounds__(S_THREADS, 2) void conv3x3_split_kernel(const Split
             constexpr int LR_H = ST_H / 2 + 2, LR_W = ST_W / 2 + 2;         // 6 x 18 low-res pixels: rows oy0/2 - 1 .., cols ox0/2 - 1 ..
             constexpr int LQ = (ST_W / 2 + 8) / 4;                           // 6 aligned quads per row: columns ox0/2 - 4 .. ox0/2 + 19
             constexpr int LUNITS = S_CHUNK * LR_H * LQ;                      // (channel, row, quad) = 1152
-            float* tmp = reinterpret_cast<float*>(wbuf);                     // [32][6][18] fp32 = 13.8 KB of the 36.9 KB weight buffer
+            constexpr int LR_CS = 114;                                       // channel stride (108 used): the 8 four-channel groups of a wave land 8 banks apart
+            float* tmp = reinterpret_cast<float*>(wbuf);                     // [32][114] fp32 = 14.6 KB of the 36.9 KB weight buffer
             const int ly0 = oy0 / 2 - 1, lx0 = ox0 / 2 - 1;
             for (int u0 = tid; u0 < LUNITS; u0 += 5 * S_THREADS) {
                 u32x4 v[5];
@@ -262,39 +264,65 @@ __global__ __launch_bounds__(S_THREADS, 2) void conv3x3_split_kernel(const Split
                     const int c = u / (LR_H * LQ), rem = u - c * (LR_H * LQ);
                     const int r = rem / LQ, q = rem - r * LQ;
                     const float4 f = __builtin_bit_cast(float4, v[k]);
-                    float* dst = tmp + (c * LR_H + r) * LR_W + 4 * q - 3;      // quad q holds low-res patch columns 4q - 3 .. 4q
+                    float* dst = tmp + c * LR_CS + r * LR_W + 4 * q - 3;      // quad q holds low-res patch columns 4q - 3 .. 4q
                     if (q > 0) dst[0] = f.x;
                     if (q > 0 && q < LQ - 1) { dst[1] = f.y; dst[2] = f.z; }
                     if (q < LQ - 1) dst[3] = f.w;
                 }
             }
             __syncthreads();
-            for (int u = tid; u < S_PART; u += S_THREADS) {
-                const int g = u / SP_PIX, pix = u - g * SP_PIX;
-                const int r = pix / SP_W, c = pix - r * SP_W;
-                const int Y = oy0 + r - 1, X = ox0 + c - 1;
-                f16x8 oh, ol;
-                if ((unsigned)Y < (unsigned)p.H && (unsigned)X < (unsigned)p.W) {
-                    int y0, y1, x0, x1; float ly, lx;
-                    isr_src_index(Y, 0.5f, p.Hin, y0, y1, ly);
-                    isr_src_index(X, 0.5f, p.Win, x0, x1, lx);
-                    const float hy = 1.f - ly, hx = 1.f - lx;
-                    const float* t0 = tmp + (g * 8) * (LR_H * LR_W) + (y0 - ly0) * LR_W - lx0;
-                    const float* t1 = tmp + (g * 8) * (LR_H * LR_W) + (y1 - ly0) * LR_W - lx0;
+            // unit = (4-channel group, 2x2 quad of patch pixels): patch rows 2kr, 2kr+1 are image rows oy0-1+2kr (odd) and the
+            // next (even), which blend the same two low-res rows (likewise the columns), so the four source texels of a
+            // channel are read once for four outputs and the horizontal blends are shared by the two rows
+            constexpr int QR = SP_H / 2, QC = SP_W / 2, UQ = QR * QC;       // 5 x 17 quads
+            _Float16* patch16 = reinterpret_cast<_Float16*>(patch);
+            for (int u = tid; u < (S_CHUNK / 4) * UQ; u += S_THREADS) {
+                const int g4 = u & 7, q = u >> 3;                            // neighbouring lanes: the 8 groups of one quad
+                const int kr = q / QC, kc = q - kr * QC;
+                const int Yu = oy0 - 1 + 2 * kr, Xl = ox0 - 1 + 2 * kc;
+                const bool oku = (unsigned)Yu < (unsigned)p.H, okd = (unsigned)(Yu + 1) < (unsigned)p.H;
+                const bool okl = (unsigned)Xl < (unsigned)p.W, okr = (unsigned)(Xl + 1) < (unsigned)p.W;
+                int y0, y1, x0, x1, t0, t1; float lyu, lyd, lxl, lxr, t;
+                isr_src_index(oku ? Yu : Yu + 1, 0.5f, p.Hin, y0, y1, t);     // both rows of the pair blend these two source rows
+                isr_src_index(okl ? Xl : Xl + 1, 0.5f, p.Win, x0, x1, t);
+                isr_src_index(Yu, 0.5f, p.Hin, t0, t1, lyu);
+                isr_src_index(Yu + 1, 0.5f, p.Hin, t0, t1, lyd);
+                isr_src_index(Xl, 0.5f, p.Win, t0, t1, lxl);
+                isr_src_index(Xl + 1, 0.5f, p.Win, t0, t1, lxr);
+                const float hyu = 1.f - lyu, hyd = 1.f - lyd, hxl = 1.f - lxl, hxr = 1.f - lxr;
+                // rows / columns wholly outside the image (tile overhang) keep their indices inside the staged region
+                y0 = min(max(y0 - ly0, 0), LR_H - 1); y1 = min(max(y1 - ly0, 0), LR_H - 1);
+                x0 = min(max(x0 - lx0, 0), LR_W - 1); x1 = min(max(x1 - lx0, 0), LR_W - 1);
+                const float* ta = tmp + (g4 * 4) * LR_CS + y0 * LR_W;
+                const float* tb = tmp + (g4 * 4) * LR_CS + y1 * LR_W;
+                f16x4 h00, h01, h10, h11, l00, l01, l10, l11;
 #pragma unroll
-                    for (int e = 0; e < 8; ++e) {
-                        const float* a = t0 + e * (LR_H * LR_W);
-                        const float* b = t1 + e * (LR_H * LR_W);
-                        _Float16 vh, vl;
-                        split16x(hy * (hx * a[x0] + lx * a[x1]) + ly * (hx * b[x0] + lx * b[x1]), vh, vl);
-                        oh[e] = vh; ol[e] = vl;
-                    }
-                } else {
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) { oh[e] = (_Float16)0.0f; ol[e] = (_Float16)0.0f; }
+                for (int e = 0; e < 4; ++e) {
+                    const float a0 = ta[e * LR_CS + x0], a1 = ta[e * LR_CS + x1];
+                    const float b0 = tb[e * LR_CS + x0], b1 = tb[e * LR_CS + x1];
+                    const float al = hxl * a0 + lxl * a1, ar = hxr * a0 + lxr * a1;
+                    const float bl = hxl * b0 + lxl * b1, br = hxr * b0 + lxr * b1;
+                    _Float16 vh, vl;
+                    split16x(hyu * al + lyu * bl, vh, vl); h00[e] = vh; l00[e] = vl;
+                    split16x(hyu * ar + lyu * br, vh, vl); h01[e] = vh; l01[e] = vl;
+                    split16x(hyd * al + lyd * bl, vh, vl); h10[e] = vh; l10[e] = vl;
+                    split16x(hyd * ar + lyd * br, vh, vl); h11[e] = vh; l11[e] = vl;
                 }
-                patch[u] = __builtin_bit_cast(u32x4, oh);
-                patch[S_PART + u] = __builtin_bit_cast(u32x4, ol);
+                const f16x4 z = {(_Float16)0.0f, (_Float16)0.0f, (_Float16)0.0f, (_Float16)0.0f};
+                if (!(oku && okl)) { h00 = z; l00 = z; }
+                if (!(oku && okr)) { h01 = z; l01 = z; }
+                if (!(okd && okl)) { h10 = z; l10 = z; }
+                if (!(okd && okr)) { h11 = z; l11 = z; }
+                // 16-byte unit (8-channel group g4 / 2, pixel) holds 8 halves: this 4-channel group is its half (g4 & 1)
+                _Float16* d = patch16 + ((size_t)((g4 >> 1) * SP_PIX + (2 * kr) * SP_W + 2 * kc)) * 8 + (g4 & 1) * 4;
+                *reinterpret_cast<f16x4*>(d) = h00;
+                *reinterpret_cast<f16x4*>(d + 8) = h01;
+                *reinterpret_cast<f16x4*>(d + SP_W * 8) = h10;
+                *reinterpret_cast<f16x4*>(d + SP_W * 8 + 8) = h11;
+                *reinterpret_cast<f16x4*>(d + S_PART * 8) = l00;
+                *reinterpret_cast<f16x4*>(d + S_PART * 8 + 8) = l01;
+                *reinterpret_cast<f16x4*>(d + (S_PART + SP_W) * 8) = l10;
+                *reinterpret_cast<f16x4*>(d + (S_PART + SP_W) * 8 + 8) = l11;
             }
             __syncthreads();                                                 // tmp is free: the weights may land on it
         } else if (p.dbg & 2) {
