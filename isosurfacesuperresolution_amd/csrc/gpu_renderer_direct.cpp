@@ -61,6 +61,9 @@ struct Volume {
     float* leafRange = nullptr;  // (min, max) per brick position, see iso_kernels.hip: leaf_may_cross
     uint8_t* node1 = nullptr;
     float* node1Range = nullptr; // (min, max) over the ranges of a 128^3 node's existing leaves
+    uint8_t* marchFlags = nullptr;   // per leaf, then per 128^3 node: exists / must be marched at marchIso (iso_march_flags)
+    double marchIso = 0;
+    bool marchValid = false;
 };
 
 struct State {
@@ -100,6 +103,7 @@ void freeVolume(Volume& v)
     if (v.leafRange) (void)hipFree(v.leafRange);
     if (v.node1) (void)hipFree(v.node1);
     if (v.node1Range) (void)hipFree(v.node1Range);
+    if (v.marchFlags) (void)hipFree(v.marchFlags);
     v = Volume();
 }
 
@@ -613,6 +617,24 @@ void buildGvdbFrame(IsoGvdbFrame& f, const Args& a, const Volume& v, const doubl
     f.aoRadius = a.aoRadius;
 }
 
+// The traversal reads one byte per leaf / node: "exists" and "its value range holds the isovalue".  The table belongs to
+// one isovalue; a change (rare: the user moves the slider) waits for every render in flight, refills it and waits again,
+// so that renders on any stream see a finished table.
+bool updateMarchFlags(Volume& v, double iso, hipStream_t stream)
+{
+    if (v.marchValid && v.marchIso == iso) return true;
+    const size_t nb = size_t(v.nbx) * v.nby * v.nbz, n1 = size_t(v.n1x) * v.n1y * v.n1z;
+    if (!v.marchFlags) HIP_OK(hipMalloc(&v.marchFlags, nb + n1));
+    else HIP_OK(hipDeviceSynchronize());
+    iso_launch_march_flags(v.leaf, v.leafRange, int(nb), iso, v.marchFlags, stream);
+    iso_launch_march_flags(v.node1, v.node1Range, int(n1), iso, v.marchFlags + nb, stream);
+    HIP_OK(hipGetLastError());
+    HIP_OK(hipStreamSynchronize(stream));
+    v.marchIso = iso;
+    v.marchValid = true;
+    return true;
+}
+
 bool launchFrame(float* out, hipStream_t stream)
 {
     const Args& a = g.args;
@@ -648,6 +670,11 @@ bool launchFrame(float* out, hipStream_t stream)
     for (int k = 0; k < 3; ++k) { p.org[k] = v.org[k]; p.n1o[k] = v.n1o[k]; }
     p.any_leaf = v.nleaf > 0;
     p.bricks = v.bricks; p.slot = v.slot; p.leaf = v.leaf; p.leafRange = v.leafRange; p.node1 = v.node1; p.node1Range = v.node1Range;
+    if (g.semantics != 1) {
+        if (!updateMarchFlags(g.vol, p.iso, stream)) return false;
+        p.leafMarch = v.marchFlags;
+        p.node1March = v.marchFlags + size_t(v.nbx) * v.nby * v.nbz;
+    }
     p.out = out;
     p.aoSamples = a.aoSamples < 0 ? 0 : (a.aoSamples > 512 ? 512 : a.aoSamples);   // GPURendererDirect.cpp:350
     p.aoRadius = double(a.aoRadius);

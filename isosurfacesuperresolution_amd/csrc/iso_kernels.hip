@@ -147,45 +147,45 @@ __device__ __forceinline__ float interp_value(const IsoRenderParams& P, const Ra
     return (float)((double)interp_global(P, px, py, pz) - P.iso);
 }
 
+// Per-leaf / per-node flags for the frame's isovalue (iso_march_flags, refreshed by the host whenever the isovalue or the
+// volume changes): bit 0 = the leaf / node exists, bit 1 = it exists and must be marched.
 // In a tile, P.leaf holds "leaf exists AND is owned by this tile": leaves of the halo are walked past like empty space.
-__device__ __forceinline__ bool has_leaf(const IsoRenderParams& P, int x, int y, int z)
-{
-    x -= P.org[0]; y -= P.org[1]; z -= P.org[2];
-    if ((unsigned)x >= (unsigned)P.nx || (unsigned)y >= (unsigned)P.ny || (unsigned)z >= (unsigned)P.nz) return false;
-    return P.leaf[((z >> 3) * P.nby + (y >> 3)) * P.nbx + (x >> 3)] != 0;
-}
 // Min/max skipping, exact: every sample the voxel DDA of a leaf can take reads voxels of [8b-1, 8b+9]^3 only (cells
 // 8b-1 .. 8b+8: a position may sit a rounding error outside the leaf's faces), and a trilinear value stays inside the
 // range of its 8 corners up to ~11 ulp of the seven float lerps.  If the isovalue lies outside [min, max] of that
 // neighbourhood by more than the pad, (value - iso) has one strict sign along the whole march, the reference's
 // `v0 * v1 <= 0` never fires, and stepping over the leaf is the same computation.  Long rays that cross the thin
 // low-density fringe or the dense core without meeting the surface were the tail the whole frame waited for.
-__device__ __forceinline__ bool leaf_may_cross(const IsoRenderParams& P, int x, int y, int z)
+// The same one level up: node1Range = (min, max) over the ranges of the node's existing leaves.  If the isovalue lies
+// outside it, no leaf of the node can be marched, and since the leaf-level DDA is re-initialised per node
+// (IsoVolumeRayTracer.h:37-46) stepping over the whole node changes nothing downstream.
+__device__ __forceinline__ bool range_may_cross(const float* mm, double iso)
 {
-    x -= P.org[0]; y -= P.org[1]; z -= P.org[2];
-    const float* mm = P.leafRange + 2 * (size_t)(((z >> 3) * P.nby + (y >> 3)) * P.nbx + (x >> 3));
     const double lo = (double)mm[0], hi = (double)mm[1];
     const double pad = 4e-6 * fmax(fabs(lo), fabs(hi));
-    return !(P.iso < lo - pad || P.iso > hi + pad);
+    return !(iso < lo - pad || iso > hi + pad);
 }
 
-// node1 is indexed by GLOBAL 128^3 node coordinates relative to the first node the stored region overlaps (P.n1o)
-__device__ __forceinline__ bool has_node1(const IsoRenderParams& P, int x, int y, int z)
+__global__ __launch_bounds__(256) void iso_march_flags(const uint8_t* __restrict__ exists, const float* __restrict__ range, int n, double iso,
+                                                       uint8_t* __restrict__ flags)
 {
-    const int ax = (x >> 7) - P.n1o[0], ay = (y >> 7) - P.n1o[1], az = (z >> 7) - P.n1o[2];
-    if ((unsigned)ax >= (unsigned)P.n1x || (unsigned)ay >= (unsigned)P.n1y || (unsigned)az >= (unsigned)P.n1z) return false;
-    return P.node1[(az * P.n1y + ay) * P.n1x + ax] != 0;
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < n) flags[i] = exists[i] ? (uint8_t)(1 | (range_may_cross(range + 2 * (size_t)i, iso) ? 2 : 0)) : (uint8_t)0;
 }
-// The same exact skipping one level up: node1Range = (min, max) over the ranges of the node's existing leaves.  If the
-// isovalue lies outside it (with the leaf test's pad), no leaf of the node can be marched, and since the leaf-level DDA
-// is re-initialised per node (IsoVolumeRayTracer.h:37-46) stepping over the whole node changes nothing downstream.
-__device__ __forceinline__ bool node1_may_cross(const IsoRenderParams& P, int x, int y, int z)
+
+__device__ __forceinline__ int leaf_flags(const IsoRenderParams& P, int x, int y, int z)
+{
+    x -= P.org[0]; y -= P.org[1]; z -= P.org[2];
+    if ((unsigned)x >= (unsigned)P.nx || (unsigned)y >= (unsigned)P.ny || (unsigned)z >= (unsigned)P.nz) return 0;
+    return P.leafMarch[((z >> 3) * P.nby + (y >> 3)) * P.nbx + (x >> 3)];
+}
+
+// node tables are indexed by GLOBAL 128^3 node coordinates relative to the first node the stored region overlaps (P.n1o)
+__device__ __forceinline__ int node1_flags(const IsoRenderParams& P, int x, int y, int z)
 {
     const int ax = (x >> 7) - P.n1o[0], ay = (y >> 7) - P.n1o[1], az = (z >> 7) - P.n1o[2];
-    const float* mm = P.node1Range + 2 * (size_t)((az * P.n1y + ay) * P.n1x + ax);
-    const double lo = (double)mm[0], hi = (double)mm[1];
-    const double pad = 4e-6 * fmax(fabs(lo), fabs(hi));
-    return !(P.iso < lo - pad || P.iso > hi + pad);
+    if ((unsigned)ax >= (unsigned)P.n1x || (unsigned)ay >= (unsigned)P.n1y || (unsigned)az >= (unsigned)P.n1z) return 0;
+    return P.node1March[(az * P.n1y + ay) * P.n1x + ax];
 }
 
 __device__ __forceinline__ bool has_node2(const IsoRenderParams& P, int x, int y, int z)
@@ -249,13 +249,14 @@ __device__ bool hits_hierarchy(const IsoRenderParams& P, Ray& ray, double& time,
             DDA d1;
             dda_init<7>(d1, ray);
             do {
-                if (has_node1(P, d1.vx, d1.vy, d1.vz) && node1_may_cross(P, d1.vx, d1.vy, d1.vz)) {
+                if (node1_flags(P, d1.vx, d1.vy, d1.vz) & 2) {
                     ray.t0 = d1.t0; ray.t1 = dda_next(d1);
                     DDA d0;
                     dda_init<3>(d0, ray);
                     do {
-                        if (has_leaf(P, d0.vx, d0.vy, d0.vz)) {
-                            const bool march = leaf_may_cross(P, d0.vx, d0.vy, d0.vz);
+                        const int lf = leaf_flags(P, d0.vx, d0.vy, d0.vz);
+                        if (lf) {
+                            const bool march = (lf & 2) != 0;
                             tr.leaf(march);
                             if (march) {
                                 ray.t0 = d0.t0; ray.t1 = dda_next(d0);
@@ -364,17 +365,15 @@ __device__ __forceinline__ bool hits_flat(const IsoRenderParams& P, const Ray& r
         for (int k = 0; k < WALK; ++k) {
             if (st == FS_STEP1) st = lvl_step<7>(d1, ray, T2) ? FS_NODE1 : FS_MISS;
             if (st == FS_NODE1) {
-                if (has_node1(P, d1.vx, d1.vy, d1.vz) && node1_may_cross(P, d1.vx, d1.vy, d1.vz)) {
+                if (node1_flags(P, d1.vx, d1.vy, d1.vz) & 2) {
                     t1_0 = lvl_next(d1, T2);
                     lvl_init<3>(d0, ray, d1.t0);
                     st = FS_LEAF;
                 } else st = FS_STEP1;
             } else if (st == FS_LEAF) {
-                bool march = false;
-                if (has_leaf(P, d0.vx, d0.vy, d0.vz)) {
-                    march = leaf_may_cross(P, d0.vx, d0.vy, d0.vz);
-                    tr.leaf(march);
-                }
+                const int lf = leaf_flags(P, d0.vx, d0.vy, d0.vz);
+                const bool march = (lf & 2) != 0;
+                if (lf) tr.leaf(march);
                 if (march) {
                     t1_v = lvl_next(d0, t1_0);
                     lvl_init<0>(dv, ray, d0.t0);
@@ -773,7 +772,7 @@ __device__ __forceinline__ bool walk_next_leaf(const IsoRenderParams& P, Walk& w
                 w.lvl = 1;
             } else if (!dda_step(w.d2)) return false;
         } else if (w.lvl == 1) {
-            if (has_node1(P, w.d1.vx, w.d1.vy, w.d1.vz) && node1_may_cross(P, w.d1.vx, w.d1.vy, w.d1.vz)) {
+            if (node1_flags(P, w.d1.vx, w.d1.vy, w.d1.vz) & 2) {
                 ray.t0 = w.d1.t0; ray.t1 = dda_next(w.d1);
                 dda_init<3>(w.d0, ray);
                 w.lvl = 0;
@@ -782,7 +781,7 @@ __device__ __forceinline__ bool walk_next_leaf(const IsoRenderParams& P, Walk& w
                 w.lvl = 2;
             }
         } else {
-            if (has_leaf(P, w.d0.vx, w.d0.vy, w.d0.vz) && leaf_may_cross(P, w.d0.vx, w.d0.vy, w.d0.vz)) {
+            if (leaf_flags(P, w.d0.vx, w.d0.vy, w.d0.vz) & 2) {
                 ray.t0 = w.d0.t0; ray.t1 = dda_next(w.d0);
                 brick = (((w.d0.vz - P.org[2]) >> 3) * P.nby + ((w.d0.vy - P.org[1]) >> 3)) * P.nbx + ((w.d0.vx - P.org[0]) >> 3);
                 return true;
@@ -1058,6 +1057,11 @@ void iso_launch_scatter_tables(int n, const long long* index, const int32_t* slo
 void iso_launch_leaf_range(const float* dense, int nx, int ny, int nz, int nbx, int nby, int nbz, float* range, void* stream)
 {
     hipLaunchKernelGGL(iso_leaf_range, dim3(nbx * nby * nbz), dim3(64), 0, (hipStream_t)stream, dense, nx, ny, nz, nbx, nby, nbz, range);
+}
+
+void iso_launch_march_flags(const uint8_t* exists, const float* range, int n, double iso, uint8_t* flags, void* stream)
+{
+    if (n > 0) hipLaunchKernelGGL(iso_march_flags, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, exists, range, n, iso, flags);
 }
 
 void iso_launch_render(const IsoRenderParams& p, int variant, void* stream, void* startEvent, void* stopEvent, int waveCap)

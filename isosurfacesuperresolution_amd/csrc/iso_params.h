@@ -39,6 +39,8 @@ struct IsoRenderParams {
     const float* leafRange;      // [nbz][nby][nbx][2] min / max of every value a march through that leaf can read
     const uint8_t* node1;        // [n1z][n1y][n1x]
     const float* node1Range;     // [n1z][n1y][n1x][2] min / max over the ranges of the node's existing leaves
+    const uint8_t* leafMarch;    // [nbz][nby][nbx] bit 0: leaf exists, bit 1: exists and its range holds the isovalue (iso_march_flags)
+    const uint8_t* node1March;   // [n1z][n1y][n1x] the same per 128^3 node
     float* out;                  // [H][W][12]
     int aoSamples;               // 0 -> AO channel == 1
     double aoRadius;             // world units
@@ -74,6 +76,8 @@ void iso_launch_gate(const unsigned* resident, unsigned target, int timeoutUs, v
 void iso_launch_brick_flags(const float* dense, int nx, int ny, int nz, int nbx, int nby, int nbz,
                             uint8_t* flag9, uint8_t* leaf, int* bbox6, unsigned int* maxbits, void* stream);
 void iso_launch_leaf_range(const float* dense, int nx, int ny, int nz, int nbx, int nby, int nbz, float* range, void* stream);
+// flags[i] = exists[i] ? 1 | (range i may hold iso ? 2 : 0) : 0 -- the tables the traversal reads, per isovalue
+void iso_launch_march_flags(const uint8_t* exists, const float* range, int n, double iso, uint8_t* flags, void* stream);
 void iso_launch_node_range(const uint8_t* leaf, const float* leafRange, int nbx, int nby, int nbz, const int org[3],
                            int n1x, int n1y, int n1z, const int n1o[3], float* nodeRange, void* stream);
 void iso_launch_scatter_tables(int n, const long long* index, const int32_t* slotv, const uint8_t* leafv, const float* rangev,

@@ -17,7 +17,7 @@ r.load_dense(vol)
 for c, v in [("cameraLookAt", "0,0,0"), ("cameraUp", "0,1,0"), ("cameraFoV", "30.000"), ("isovalue", "%5.3f" % iso),
              ("aosamples", "0"), ("resolution", "%d,%d" % (w, h)), ("viewport", "0,0,%d,%d" % (w, h))]:
     r.send_command(c, v)
-r.set_kernel_variant(0)
+r.set_kernel_variant(int(__import__('os').environ.get('RM_VARIANT', '0')))
 out = torch.empty((h, w, 12), dtype=torch.float32, device="cuda")
 tiles = ((w + 7) // 8) * ((h + 7) // 8)
 stats = torch.zeros((tiles, 6), dtype=torch.int64, device="cuda")
