@@ -51,6 +51,7 @@ def parse(argv=None):
     ap.add_argument("--no-temporal", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--raymarch-variant", type=int, default=0)
+    ap.add_argument("--side-variant", type=int, default=-1, help="kernel variant of the render that runs under the network (diagnostics)")
     ap.add_argument("--no-fast-mode", action="store_true", help="skip the separately reported fp16 fast-mode leg")
     ap.add_argument("--exact", action="store_true", help="convolutions on the exact k-ordered fp32 fmaf-chain kernels (fp32 MFMA) instead "
                     "of the split-operand kernels (three fp16 MFMAs per product, fp32-equivalent accuracy)")
@@ -178,6 +179,8 @@ def run_infer(args, job):
     pipe.foreground_variant = args.raymarch_variant
     renderer.set_kernel_variant(args.raymarch_variant)
     overlap = not args.no_overlap
+    if args.side_variant >= 0:
+        pipe.side_variant = args.side_variant
     if args.side_waves > 0:
         pipe.side_waves = args.side_waves
 

@@ -405,6 +405,143 @@ __device__ __forceinline__ bool hits_flat(const IsoRenderParams& P, const Ray& r
     return st == FS_HIT;
 }
 
+// Two samples of one ray with their gathers in flight together (interp_value twice: same operations, same results).
+// B is fetched only where hasB.
+struct SamplePos { int cx, cy, cz, idx, loc; float u, v, w; bool inb; };
+
+__device__ __forceinline__ void sample_pos(const IsoRenderParams& P, const Ray& r, double t, SamplePos& q)
+{
+    double px, py, pz;
+    ray_at(r, t, px, py, pz);
+    q.cx = (int)floor(px); q.cy = (int)floor(py); q.cz = (int)floor(pz);
+    q.u = (float)px - (float)q.cx;
+    q.v = (float)py - (float)q.cy;
+    q.w = (float)pz - (float)q.cz;
+    const int lx = q.cx - P.org[0], ly = q.cy - P.org[1], lz = q.cz - P.org[2];
+    q.inb = (unsigned)lx < (unsigned)P.nx && (unsigned)ly < (unsigned)P.ny && (unsigned)lz < (unsigned)P.nz;
+    q.idx = ((lz >> 3) * P.nby + (ly >> 3)) * P.nbx + (lx >> 3);
+    q.loc = ((lz & 7) * 9 + (ly & 7)) * 9 + (lx & 7);
+}
+
+__device__ __forceinline__ float sample_border(const IsoRenderParams& P, const SamplePos& q)
+{
+    return trilerp(voxel_value(P, q.cx, q.cy, q.cz), voxel_value(P, q.cx, q.cy, q.cz + 1),
+                   voxel_value(P, q.cx, q.cy + 1, q.cz), voxel_value(P, q.cx, q.cy + 1, q.cz + 1),
+                   voxel_value(P, q.cx + 1, q.cy, q.cz), voxel_value(P, q.cx + 1, q.cy, q.cz + 1),
+                   voxel_value(P, q.cx + 1, q.cy + 1, q.cz), voxel_value(P, q.cx + 1, q.cy + 1, q.cz + 1), q.u, q.v, q.w);
+}
+
+__device__ __forceinline__ void interp_pair(const IsoRenderParams& P, const Ray& r, double tA, double tB, bool hasB, float& vA, float& vB)
+{
+    SamplePos a, b;
+    sample_pos(P, r, tA, a);
+    sample_pos(P, r, tB, b);
+    int sA = -1, sB = -1;
+    if (a.inb) sA = P.slot[a.idx];
+    if (hasB && b.inb) sB = P.slot[b.idx];
+    float2u a00, a01, a10, a11, b00, b01, b10, b11;
+    a00 = a01 = a10 = a11 = b00 = b01 = b10 = b11 = float2u{0.0f, 0.0f};
+    if (sA >= 0) {
+        const float* q = P.bricks + (size_t)sA * ISO_BRICK_STRIDE + a.loc;
+        a00 = *reinterpret_cast<const float2u*>(q); a01 = *reinterpret_cast<const float2u*>(q + 81);
+        a10 = *reinterpret_cast<const float2u*>(q + 9); a11 = *reinterpret_cast<const float2u*>(q + 90);
+    }
+    if (sB >= 0) {
+        const float* q = P.bricks + (size_t)sB * ISO_BRICK_STRIDE + b.loc;
+        b00 = *reinterpret_cast<const float2u*>(q); b01 = *reinterpret_cast<const float2u*>(q + 81);
+        b10 = *reinterpret_cast<const float2u*>(q + 9); b11 = *reinterpret_cast<const float2u*>(q + 90);
+    }
+    // an empty brick position reads as zero: 0 + (0 - 0) * w ... == +0, like the early return of interp_global
+    float fa = sA >= 0 ? trilerp(a00.x, a01.x, a10.x, a11.x, a00.y, a01.y, a10.y, a11.y, a.u, a.v, a.w) : 0.0f;
+    float fb = sB >= 0 ? trilerp(b00.x, b01.x, b10.x, b11.x, b00.y, b01.y, b10.y, b11.y, b.u, b.v, b.w) : 0.0f;
+    if (!a.inb) fa = sample_border(P, a);
+    if (hasB && !b.inb) fb = sample_border(P, b);
+    vA = (float)((double)fa - P.iso);
+    vB = (float)((double)fb - P.iso);
+}
+
+// hits_flat with the march two voxel steps per iteration: the DDA does not depend on the sampled values, so the sample
+// after the next boundary is fetched together with the one at it (its gathers overlap); it is dropped when the first one
+// turns out to be the crossing or the leaf's last.  Same operations per ray in the same order otherwise: bit-identical.
+template <typename TR>
+__device__ __forceinline__ bool hits_flat2(const IsoRenderParams& P, const Ray& ray, double& time, TR& tr)
+{
+    double T2;
+    Lvl d1;
+    {
+        DDA d2;
+        dda_init<12>(d2, ray);
+        bool found = false;
+        do {
+            if (has_node2(P, d2.vx, d2.vy, d2.vz)) { found = true; break; }
+        } while (dda_step(d2));
+        if (!found) return false;
+        T2 = dda_next(d2);
+        lvl_init<7>(d1, ray, d2.t0);
+    }
+    Lvl d0, dv;
+    d0.t0 = d0.nx = d0.ny = d0.nz = 0.0; d0.vx = d0.vy = d0.vz = 0;
+    dv = d0;
+    double t1_0 = 0.0, t1_v = 0.0, b1 = 0.0;
+    float v0 = 0.0f;
+    int st = FS_NODE1;
+    while (st < FS_MISS) {
+        if (st == FS_STEP1) st = lvl_step<7>(d1, ray, T2) ? FS_NODE1 : FS_MISS;
+        if (st == FS_NODE1) {
+            if (node1_flags(P, d1.vx, d1.vy, d1.vz) & 2) {
+                t1_0 = lvl_next(d1, T2);
+                lvl_init<3>(d0, ray, d1.t0);
+                st = FS_LEAF;
+            } else st = FS_STEP1;
+        } else if (st == FS_LEAF) {
+            const int lf = leaf_flags(P, d0.vx, d0.vy, d0.vz);
+            const bool march = (lf & 2) != 0;
+            if (lf) tr.leaf(march);
+            if (march) {
+                t1_v = lvl_next(d0, t1_0);
+                lvl_init<0>(dv, ray, d0.t0);
+                st = FS_ENTER;
+            } else if (!lvl_step<3>(d0, ray, t1_0)) st = FS_STEP1;
+        }
+        if (st >= FS_ENTER && st < FS_MISS) {
+            double tA, tB;
+            const double tprev = dv.t0;
+            bool hasB = true;
+            if (st == FS_ENTER) { tA = dv.t0; tB = lvl_next(dv, t1_v); }
+            else if (st == FS_MARCH) {
+                tA = lvl_next(dv, t1_v);
+                hasB = lvl_step<0>(dv, ray, t1_v);                           // taken back below if A is the crossing
+                tB = lvl_next(dv, t1_v);
+            } else { tA = 0.5 * (dv.t0 + b1); tB = tA; hasB = false; }
+            float vA, vB;
+            interp_pair(P, ray, tA, tB, hasB, vA, vB);
+            bool leafDone = false, stepAfter = false;
+            if (st >= FS_BISECT) {
+                tr.sample(1);
+                if (v0 * vA <= 0.0f) b1 = tA;
+                else { dv.t0 = tA; v0 = vA; }
+                if (++st == FS_BISECT + 5) { time = 0.5 * (dv.t0 + b1); st = FS_HIT; }
+            } else {
+                bool checkB = true;
+                if (st == FS_ENTER) { v0 = vA; tr.sample(1); st = FS_MARCH; }
+                else {
+                    tr.sample(1);
+                    if (v0 * vA <= 0.0f) { dv.t0 = tprev; b1 = tA; st = FS_BISECT; checkB = false; }
+                    else { v0 = vA; if (!hasB) { leafDone = true; checkB = false; } }
+                }
+                if (checkB) {
+                    tr.sample(1);
+                    if (v0 * vB <= 0.0f) { b1 = tB; st = FS_BISECT; }
+                    else { v0 = vB; stepAfter = true; }
+                }
+            }
+            if (stepAfter && !lvl_step<0>(dv, ray, t1_v)) leafDone = true;
+            if (leafDone) st = lvl_step<3>(d0, ray, t1_0) ? FS_LEAF : FS_STEP1;
+        }
+    }
+    return st == FS_HIT;
+}
+
 __device__ __forceinline__ double len3(double x, double y, double z) { return sqrt(x * x + y * y + z * z); }
 
 // Vec3::normalize(eps = 1e-7), TP/openvdb/math/Vec3.h:377-385
@@ -459,6 +596,7 @@ __device__ __forceinline__ bool make_ray(const IsoRenderParams& P, int i, int j,
 // ---- ambient occlusion ---------------------------------------------------------------------
 // render_kernel.cu:109-146 (mode 1: ray sampling) with the secondary rays cast by the same
 // double-precision hierarchy as the primary ray; tables of GPURendererDirect.cpp:146-189.
+template <int FLAT>
 __device__ bool cast_world(const IsoRenderParams& P, double ox, double oy, double oz, double dx, double dy, double dz,
                            double& hx, double& hy, double& hz)
 {
@@ -484,13 +622,17 @@ __device__ bool cast_world(const IsoRenderParams& P, double ox, double oy, doubl
 #undef ISO_SLAB
     r.t0 = t0; r.t1 = t1;
     double it;
-    if (!hits_hierarchy(P, r, it)) return false;
+    bool hit;
+    if (FLAT > 0) { NoTrace nt; hit = hits_flat<1>(P, r, it, nt); }        // the secondary rays take the one-sample form (registers)
+    else hit = hits_hierarchy(P, r, it);
+    if (!hit) return false;
     double px, py, pz;
     ray_at(r, it, px, py, pz);
     hx = px * P.s + P.t[0]; hy = py * P.s + P.t[1]; hz = pz * P.s + P.t[2];
     return true;
 }
 
+template <int FLAT>
 __device__ double ambient_occlusion(const IsoRenderParams& P, double px, double py, double pz,
                                     double nx, double ny, double nz, int x, int y)
 {
@@ -511,7 +653,7 @@ __device__ double ambient_occlusion(const IsoRenderParams& P, double px, double 
         normalize3(wx, wy, wz);
         double hx, hy, hz;
         double value = 1.0;
-        if (cast_world(P, px, py, pz, wx, wy, wz, hx, hy, hz)) {
+        if (cast_world<FLAT>(P, px, py, pz, wx, wy, wz, hx, hy, hz)) {
             const double dist = len3(px - hx, py - hy, pz - hz);
             double yv = 1.0 - P.aoRadius / dist;                 // smoothstep(1, 0, r/d)
             yv = yv < 0.0 ? 0.0 : (yv > 1.0 ? 1.0 : yv);
@@ -524,7 +666,7 @@ __device__ double ambient_occlusion(const IsoRenderParams& P, double px, double 
 
 // Everything after the hit time is known: position, normal, Phong, depth, flow
 // (IsoVolumeRayTracer.h:274-292,300-307,519-548; PhongShader.h:27-38; CPURenderer.cpp:726-737)
-template <bool AO>
+template <bool AO, int FLAT = 0>
 __device__ __forceinline__ void shade_hit(const IsoRenderParams& P, const Ray& r, double it,
                                           double wdx, double wdy, double wdz, int px_, int py_, float o[12])
 {
@@ -577,7 +719,7 @@ __device__ __forceinline__ void shade_hit(const IsoRenderParams& P, const Ray& r
             // hemisphere around the normal that faces the viewer, origin pulled back by aoBias = 1e-3
             double ax = nx, ay = ny, az = nz;
             if (nx * wdx + ny * wdy + nz * wdz > 0) { ax = -ax; ay = -ay; az = -az; }
-            o[10] = (float)ambient_occlusion(P, wx - 1e-3 * wdx, wy - 1e-3 * wdy, wz - 1e-3 * wdz, ax, ay, az, px_, py_);
+            o[10] = (float)ambient_occlusion<FLAT>(P, wx - 1e-3 * wdx, wy - 1e-3 * wdy, wz - 1e-3 * wdz, ax, ay, az, px_, py_);
         }
     }
 }
@@ -599,8 +741,8 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg)
 }
 
 // ---- variant 0: per-lane gather ------------------------------------------------------------
-// FLAT: 0 = the nested loops of hits_hierarchy, k > 0 = hits_flat with k hierarchy steps per sample
-template <bool AO, int FLAT = 0>
+// FLAT: 0 = the nested loops of hits_hierarchy, 1 = hits_flat (one sample per iteration), 3 = hits_flat2 (two)
+template <bool AO, int FLAT = 3>
 __device__ __forceinline__ void render_gather_tile(const IsoRenderParams& P, int vb, int tiles_x, int ntiles, int lane, bool remap = true)
 {
     const int tile = remap ? xcd_remap(vb, ntiles) : vb;
@@ -615,10 +757,11 @@ __device__ __forceinline__ void render_gather_tile(const IsoRenderParams& P, int
         double wdx, wdy, wdz, it;
         bool hit = make_ray(P, i, j, r, wdx, wdy, wdz);
         if (hit) {
-            if (FLAT > 0) { NoTrace nt; hit = hits_flat<(FLAT > 0 ? FLAT : 1)>(P, r, it, nt); }
+            if (FLAT == 3) { NoTrace nt; hit = hits_flat2(P, r, it, nt); }
+            else if (FLAT > 0) { NoTrace nt; hit = hits_flat<1>(P, r, it, nt); }
             else hit = hits_hierarchy(P, r, it);
         }
-        if (hit) shade_hit<AO>(P, r, it, wdx, wdy, wdz, i, j, o);
+        if (hit) shade_hit<AO, FLAT>(P, r, it, wdx, wdy, wdz, i, j, o);
     }
     store_pixel(P, i, j, o);
 }
@@ -647,7 +790,7 @@ __global__ __launch_bounds__(64) void iso_render_stats(const IsoRenderParams P, 
         double wdx, wdy, wdz, it;
         float o[12] = { 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 1.0f, 0.f };
         bool h = make_ray(P, i, j, r, wdx, wdy, wdz);
-        if (h) h = FLAT > 0 ? hits_flat<(FLAT > 0 ? FLAT : 1)>(P, r, it, tr) : hits_hierarchy(P, r, it, tr);
+        if (h) h = FLAT == 3 ? hits_flat2(P, r, it, tr) : (FLAT > 0 ? hits_flat<1>(P, r, it, tr) : hits_hierarchy(P, r, it, tr));
         if (h) {
             shade_hit<false>(P, r, it, wdx, wdy, wdz, i, j, o);
             hit = 1;
@@ -703,7 +846,7 @@ __global__ __launch_bounds__(512) void iso_render_gather_ldsslot(const IsoRender
 // provided there is never a second one on the same SIMD (2 x 128 + 360 > 512 would keep the next
 // conv workgroup off that CU), hence the wave cap: 4 x #CUs waves, striding over the tiles.
 // Same instructions on the same values: results are bit-identical to variant 0.
-template <bool AO>
+template <bool AO, int FLAT>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) void iso_render_gather_slim(const IsoRenderParams P)
 {
     // workgroups of FOUR independent waves: the hardware spreads the waves of a workgroup over the four SIMDs of its
@@ -725,7 +868,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
             if (lane == 0) i = atomicAdd(&P.tileQueue[k], 1u);
             i = (unsigned)__builtin_amdgcn_readfirstlane((int)i);
             if (i >= cnt) break;
-            render_gather_tile<AO>(P, (int)i * 8 + k, tiles_x, ntiles, lane);
+            render_gather_tile<AO, FLAT>(P, (int)i * 8 + k, tiles_x, ntiles, lane);
         }
     }
 }
@@ -1091,26 +1234,28 @@ void iso_launch_render(const IsoRenderParams& p, int variant, void* stream, void
         const int waves = waveCap > 0 && waveCap < tiles ? (waveCap + 7) & ~7 : (tiles + 7) & ~7;   // 0 = one wave per tile
         const dim3 capped(waves / 4), block4(256);                                                  // 4 waves per workgroup
         (void)hipMemsetAsync(p.tileQueue, 0, 8 * sizeof(unsigned), st);
-        if (p.aoSamples > 0) hipExtLaunchKernelGGL(iso_render_gather_slim<true>, capped, block4, 0, st, e0, e1, 0, p);
-        else hipExtLaunchKernelGGL(iso_render_gather_slim<false>, capped, block4, 0, st, e0, e1, 0, p);
+        // the one-sample flat traversal: 116 registers on its own, 21 cold values spilled under the 128-register cap
+        // (the two-sample form spills 77 and the frame is slower with it: 379 vs 393 frames/s)
+        if (p.aoSamples > 0) hipExtLaunchKernelGGL((iso_render_gather_slim<true, 1>), capped, block4, 0, st, e0, e1, 0, p);
+        else hipExtLaunchKernelGGL((iso_render_gather_slim<false, 1>), capped, block4, 0, st, e0, e1, 0, p);
     } else if (variant == 4) {
-        if (p.aoSamples > 0) hipExtLaunchKernelGGL((iso_render_gather<true, 1>), grid, block, 0, st, e0, e1, 0, p);
-        else hipExtLaunchKernelGGL((iso_render_gather<false, 1>), grid, block, 0, st, e0, e1, 0, p);
-    } else if (variant == 5) {
-        if (p.aoSamples > 0) hipExtLaunchKernelGGL((iso_render_gather<true, 2>), grid, block, 0, st, e0, e1, 0, p);
-        else hipExtLaunchKernelGGL((iso_render_gather<false, 2>), grid, block, 0, st, e0, e1, 0, p);
-    } else {
         if (p.aoSamples > 0) hipExtLaunchKernelGGL((iso_render_gather<true, 0>), grid, block, 0, st, e0, e1, 0, p);
         else hipExtLaunchKernelGGL((iso_render_gather<false, 0>), grid, block, 0, st, e0, e1, 0, p);
+    } else if (variant == 5) {
+        if (p.aoSamples > 0) hipExtLaunchKernelGGL((iso_render_gather<true, 1>), grid, block, 0, st, e0, e1, 0, p);
+        else hipExtLaunchKernelGGL((iso_render_gather<false, 1>), grid, block, 0, st, e0, e1, 0, p);
+    } else {
+        if (p.aoSamples > 0) hipExtLaunchKernelGGL((iso_render_gather<true, 3>), grid, block, 0, st, e0, e1, 0, p);
+        else hipExtLaunchKernelGGL((iso_render_gather<false, 3>), grid, block, 0, st, e0, e1, 0, p);
     }
 }
 
 void iso_launch_render_stats(const IsoRenderParams& p, int variant, long long* out, void* stream)
 {
     const int tiles = ((p.W + 7) >> 3) * ((p.H + 7) >> 3);
-    if (variant == 4) hipLaunchKernelGGL(iso_render_stats<1>, dim3(tiles), dim3(64), 0, (hipStream_t)stream, p, out);
-    else if (variant == 5) hipLaunchKernelGGL(iso_render_stats<2>, dim3(tiles), dim3(64), 0, (hipStream_t)stream, p, out);
-    else hipLaunchKernelGGL(iso_render_stats<0>, dim3(tiles), dim3(64), 0, (hipStream_t)stream, p, out);
+    if (variant == 4) hipLaunchKernelGGL(iso_render_stats<0>, dim3(tiles), dim3(64), 0, (hipStream_t)stream, p, out);
+    else if (variant == 5) hipLaunchKernelGGL(iso_render_stats<1>, dim3(tiles), dim3(64), 0, (hipStream_t)stream, p, out);
+    else hipLaunchKernelGGL(iso_render_stats<3>, dim3(tiles), dim3(64), 0, (hipStream_t)stream, p, out);
 }
 
 void iso_launch_gate(const unsigned* resident, unsigned target, int timeoutUs, void* stream)

@@ -58,6 +58,7 @@ class SuperResolutionPipeline:
         # a prefetched frame is rendered by the 128-register ray-marcher (kernel variant 2) with one wave per
         # SIMD, so that it sits beside the conv waves instead of displacing them (csrc/iso_kernels.hip)
         self.side_waves = 4 * torch.cuda.get_device_properties(device).multi_processor_count if self._render_stream else 0
+        self.side_variant = 2                            # the <= 128-register kernel that fits beside the conv waves
         self.previous = None
         self.foreground_variant = 0       # kernel variant of frames rendered on the main stream
         # fused=True: input assembly and frame finishing run as two HIP kernels (ops.assemble_input /
@@ -99,7 +100,7 @@ class SuperResolutionPipeline:
         rs.wait_event(self._frame_start)                 # ... and so has anything the caller enqueued before this frame()
                                                          # (``pipe.gbuffer`` stays valid until the next frame() call)
         self.renderer.send_command("cameraOrigin", fmt3(origin))
-        self.renderer.set_kernel_variant(2)
+        self.renderer.set_kernel_variant(self.side_variant)
         self.renderer.set_wave_cap(self.side_waves)
         self.renderer.render_async(self._gbuffers[slot], rs)
         self.renderer.set_kernel_variant(self.foreground_variant)

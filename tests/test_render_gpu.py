@@ -48,7 +48,7 @@ def _compare(gpu, ref):
         assert err <= TOL, "%s differs by %g" % (name, err)
 
 
-@pytest.mark.parametrize("variant", [0, 1, 2, 3])
+@pytest.mark.parametrize("variant", [0, 1, 2, 3, 4, 5])
 @pytest.mark.parametrize("case", [
     dict(vol="sphere64", W=128, H=128, fov=45.0, iso=0.5, frames=(0, 7, 19)),
     dict(vol="ejecta64", W=160, H=90, fov=30.0, iso=0.34, frames=(3, 40)),

@@ -1,12 +1,13 @@
-"""Kernel variants of the ray-marcher side by side: same frames, results compared bit for bit against variant 0.
-python tools/raymarch_variants.py [variants, e.g. 0,4,5] [cases, e.g. ejecta256@480x270,ejecta256@1920x1080,cloud512@1920x1080]"""
+"""Kernel variants of the ray-marcher side by side: same frames, results compared bit for bit against the first one listed
+(4 = the nested loops of the reference, 5 = flat state machine, 0 = the default: flat, two samples per iteration, 3 = 0 with the
+slot table in LDS, 2 = 5 in 128 registers).  python tools/raymarch_variants.py [variants, e.g. 4,5,0] [cases, e.g. ejecta256@480x270,ejecta256@1920x1080,cloud512@1920x1080]"""
 import sys
 sys.path.insert(0, '.')
 import torch
 from isosurfacesuperresolution_amd import volumes as V
 from isosurfacesuperresolution_amd.inference import DirectRenderer
 
-variants = [int(v) for v in (sys.argv[1] if len(sys.argv) > 1 else "0,4,5").split(",")]
+variants = [int(v) for v in (sys.argv[1] if len(sys.argv) > 1 else "4,5,0,3,2").split(",")]
 cases = (sys.argv[2] if len(sys.argv) > 2 else "ejecta256@480x270,ejecta256@1920x1080,cloud512@1920x1080").split(",")
 frames = 8
 r = DirectRenderer()
