@@ -298,10 +298,12 @@ __device__ __forceinline__ void lvl_init(Lvl& d, const Ray& r, double t0)
     d.vx = ((int)floor(px)) & (~(DIM - 1));
     d.vy = ((int)floor(py)) & (~(DIM - 1));
     d.vz = ((int)floor(pz)) & (~(DIM - 1));
+    // DDA.h:79-103 without branches: the far face for a positive direction, the near one otherwise
 #define ISO_AXIS(V, N, P, DIR, INV)                                          \
-    if (DIR == 0.0) N = DBL_MAX;                                              \
-    else if (INV > 0) N = d.t0 + ((double)(V + DIM) - P) * INV;               \
-    else N = d.t0 + ((double)V - P) * INV;
+    {                                                                         \
+        const double n_ = d.t0 + ((double)(V + (INV > 0 ? DIM : 0)) - P) * INV; \
+        N = DIR == 0.0 ? DBL_MAX : n_;                                        \
+    }
     ISO_AXIS(d.vx, d.nx, px, r.dx, r.ix)
     ISO_AXIS(d.vy, d.ny, py, r.dy, r.iy)
     ISO_AXIS(d.vz, d.nz, pz, r.dz, r.iz)
