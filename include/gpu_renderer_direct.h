@@ -83,10 +83,12 @@ int isoRenderAsync(unsigned long long devicePtr, void* stream);
  * [8..10] node bbox max, [11] bytes of brick storage (MiB), out_max = grid max value. */
 int isoGetVolumeInfo(int info[12], float* out_max);
 
-/* Kernel variant (all bit-identical): 0 = one lane per ray, global-memory gather (default); 1 = wave-cooperative LDS
- * brick cache; 2 = variant 0 in a 128-register budget with a capped, tile-pulling grid (rendering under another kernel,
- * see isoSetWaveCap); 3 = variant 0 with the slot table of a <= 256^3 volume in LDS (falls back to 0 for larger volumes).
- * Returns 0, -1 for an unknown variant. */
+/* Kernel variant (all bit-identical): 0 = one lane per ray, the traversal of IsoVolumeRayTracer.h:37-114 as one flat
+ * per-lane state machine marching two voxel boundaries per iteration (default); 1 = wave-cooperative LDS brick cache
+ * (nested loops); 2 = the flat traversal, one sample per iteration, in a 128-register budget with a capped, tile-pulling
+ * grid (rendering under another kernel, see isoSetWaveCap); 3 = variant 0 with the slot table of a <= 256^3 volume in
+ * LDS (falls back to 0 for larger volumes); 4 = the reference's four nested loops in lock step (what 0 replaced: 2.3x
+ * slower); 5 = the flat traversal with one sample per iteration.  Returns 0, -1 for an unknown variant. */
 int isoSetKernelVariant(int variant);
 
 /* Optional per-frame kernel timing for benchmarks: while enabled, each ray-march dispatch carries a

@@ -242,8 +242,8 @@ __global__ __launch_bounds__(S_THREADS, 2) void conv3x3_split_kernel(const Split
             constexpr int LR_H = ST_H / 2 + 2, LR_W = ST_W / 2 + 2;         // 6 x 18 low-res pixels: rows oy0/2 - 1 .., cols ox0/2 - 1 ..
             constexpr int LQ = (ST_W / 2 + 8) / 4;                           // 6 aligned quads per row: columns ox0/2 - 4 .. ox0/2 + 19
             constexpr int LUNITS = S_CHUNK * LR_H * LQ;                      // (channel, row, quad) = 1152
-            constexpr int LR_CS = 114;                                       // channel stride (108 used): the 8 four-channel groups of a wave land 8 banks apart
-            float* tmp = reinterpret_cast<float*>(wbuf);                     // [32][114] fp32 = 14.6 KB of the 36.9 KB weight buffer
+            constexpr int LR_CS = 113;                                       // channel stride (108 used): ds_read_b32 banks = dword mod 32, a half-wave = 8 four-channel groups x 4 quads -> 4 * 113 = 4 (mod 32) apart
+            float* tmp = reinterpret_cast<float*>(wbuf);                     // [32][113] fp32 = 14.5 KB of the 36.9 KB weight buffer
             const int ly0 = oy0 / 2 - 1, lx0 = ox0 / 2 - 1;
             for (int u0 = tid; u0 < LUNITS; u0 += 5 * S_THREADS) {
                 u32x4 v[5];

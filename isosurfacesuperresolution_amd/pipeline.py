@@ -58,7 +58,10 @@ class SuperResolutionPipeline:
         # a prefetched frame is rendered by the 128-register ray-marcher (kernel variant 2) with one wave per
         # SIMD, so that it sits beside the conv waves instead of displacing them (csrc/iso_kernels.hip)
         self.side_waves = 4 * torch.cuda.get_device_properties(device).multi_processor_count if self._render_stream else 0
-        self.side_variant = 2                            # the <= 128-register kernel that fits beside the conv waves
+        # kernel variant of the render that runs under the network.  None = the foreground variant: since the flat traversal
+        # (0.21 ms alone) the plain kernel beside the network gives 400 frames/s; the capped 128-register kernel (2), which
+        # round 1's 0.45 ms nested-loop kernel needed, gives 384 (tools/side_sweep.sh)
+        self.side_variant = None
         self.previous = None
         self.foreground_variant = 0       # kernel variant of frames rendered on the main stream
         # fused=True: input assembly and frame finishing run as two HIP kernels (ops.assemble_input /
@@ -100,8 +103,9 @@ class SuperResolutionPipeline:
         rs.wait_event(self._frame_start)                 # ... and so has anything the caller enqueued before this frame()
                                                          # (``pipe.gbuffer`` stays valid until the next frame() call)
         self.renderer.send_command("cameraOrigin", fmt3(origin))
-        self.renderer.set_kernel_variant(self.side_variant)
-        self.renderer.set_wave_cap(self.side_waves)
+        if self.side_variant is not None:
+            self.renderer.set_kernel_variant(self.side_variant)
+            self.renderer.set_wave_cap(self.side_waves)
         self.renderer.render_async(self._gbuffers[slot], rs)
         self.renderer.set_kernel_variant(self.foreground_variant)
         self._flow_ready[slot] = self.fused and self.temporal
@@ -150,8 +154,9 @@ class SuperResolutionPipeline:
                 self._frame_start.record(torch.cuda.current_stream())
             g = self._acquire_gbuffer(origin)
             if next_origin is not None:
-                # the next frame's render goes first, and this stream waits until its waves sit one per SIMD on the
-                # (momentarily idle) GPU; launched later they would race the network's kernels for slots
+                # the next frame's render goes first (enqueued after the trunk or the upsampling layers instead, the frame
+                # takes the same 2.50 ms).  With the capped 128-register kernel (side_variant = 2) this stream then waits
+                # until its waves sit one per SIMD on the momentarily idle GPU (a no-op for the other variants).
                 self.prefetch(next_origin)
                 self.renderer.gate_resident(torch.cuda.current_stream())
             prev = self.previous if self.temporal else None

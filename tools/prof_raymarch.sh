@@ -2,7 +2,7 @@
 # PMC passes of the ray-march kernel alone (GPU box): bash tools/prof_raymarch.sh -> gpurun_out/r02_rm/<case>_<group>/
 cd $GRAFT_REPO_ROOT
 export TMPDIR=/tmp
-OUT=gpurun_out/r02_rm
+OUT=gpurun_out/r02_rm${RM_TAG:-}
 rm -rf $OUT; mkdir -p $OUT
 for case in "ejecta256 480x270" "ejecta256 1920x1080" "cloud512 1920x1080"; do
   set -- $case
