@@ -83,11 +83,35 @@ def test_parity_with_oracle(renderer, oracle, case, variant):
         last = origin
 
 
-def test_ambient_occlusion_matches_restatement(renderer, oracle):
-    """Ray-cast AO (render_kernel.cu:109-146 restated on the CPU tracer's hierarchy).  The reference's
-    CPU renderer has no AO, so the oracle here is this project's own restatement (parity unpinned)."""
+@pytest.mark.parametrize("variant", [0, 2, 4, 5])
+@pytest.mark.parametrize("axis", ["x", "y", "z", "inside"])
+def test_axis_parallel_rays_and_camera_inside(renderer, oracle, variant, axis):
+    """Odd resolutions put a pixel exactly on the optical axis: with the camera on a coordinate axis that ray has two
+    zero direction components and its whole row / column one (the DDA's `dir == 0` cases, DDA.h:79-103: 1/dir = inf
+    must never reach a voxel boundary).  'inside': the camera sits inside the volume's box, rays start at their origin."""
     vol = V.ejecta(64)
+    renderer.set_kernel_variant(variant)
+    renderer.load_dense(vol)
+    ov = oracle.OracleVolume(vol)
+    origin, up = {"x": ((1.75, 0.0, 0.0), (0, 1, 0)), "y": ((0.0, -1.5, 0.0), (0, 0, 1)), "z": ((0.0, 0.0, 2.0), (0, 1, 0)),
+                  "inside": ((0.0, 0.0, 0.375), (0, 1, 0))}[axis]
+    W, H = 65, 47
+    _render_gpu(renderer, W, H, origin, 40.0, 0.34, up=up)        # sets last camera = origin
+    gpu = _render_gpu(renderer, W, H, origin, 40.0, 0.34, up=up)
+    p = oracle.make_params(W, H, origin=origin, up=up, fov=40.0, isovalue=0.34)
+    ref, _ = oracle.render(ov, p)
+    assert (ref[..., 3] == 1).sum() > 100
+    _compare(gpu, ref)
     renderer.set_kernel_variant(0)
+
+
+@pytest.mark.parametrize("variant", [0, 4])
+def test_ambient_occlusion_matches_restatement(renderer, oracle, variant):
+    """Ray-cast AO (render_kernel.cu:109-146 restated on the CPU tracer's hierarchy).  The reference's
+    CPU renderer has no AO, so the oracle here is this project's own restatement (parity unpinned).
+    Variant 0 casts the secondary rays with the flat traversal, variant 4 with the nested loops."""
+    vol = V.ejecta(64)
+    renderer.set_kernel_variant(variant)
     renderer.load_dense(vol)
     ov = oracle.OracleVolume(vol)
     origin = V.quantize3(V.orbit_camera(9))
@@ -102,6 +126,7 @@ def test_ambient_occlusion_matches_restatement(renderer, oracle):
     assert np.abs(gpu[..., 10] - ref[..., 10]).max() <= TOL
     gpu[..., 10] = ref[..., 10]
     _compare(gpu, ref)
+    renderer.set_kernel_variant(0)
 
 
 def test_viewport_and_ragged_resolution(renderer, oracle):

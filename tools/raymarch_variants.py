@@ -1,7 +1,7 @@
 """Kernel variants of the ray-marcher side by side: same frames, results compared bit for bit against the first one listed
 (4 = the nested loops of the reference, 5 = flat state machine, 0 = the default: flat, two samples per iteration, 3 = 0 with the
 slot table in LDS, 2 = 5 in 128 registers).  python tools/raymarch_variants.py [variants, e.g. 4,5,0] [cases, e.g. ejecta256@480x270,ejecta256@1920x1080,cloud512@1920x1080]"""
-import sys
+import os, sys
 sys.path.insert(0, '.')
 import torch
 from isosurfacesuperresolution_amd import volumes as V
@@ -19,7 +19,7 @@ for case in cases:
     iso = 0.30 if name.startswith("cloud") else 0.34
     r.load_dense(vol)
     for c, v in [("cameraLookAt", "0,0,0"), ("cameraUp", "0,1,0"), ("cameraFoV", "30.000"), ("isovalue", "%5.3f" % iso),
-                 ("aosamples", "0"), ("resolution", "%d,%d" % (w, h)), ("viewport", "0,0,%d,%d" % (w, h))]:
+                 ("aosamples", os.environ.get("RM_AO", "0")), ("aoradius", "0.050"), ("resolution", "%d,%d" % (w, h)), ("viewport", "0,0,%d,%d" % (w, h))]:
         r.send_command(c, v)
     ref = None
     for variant in variants:
