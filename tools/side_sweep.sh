@@ -10,11 +10,8 @@ d = json.loads([l for l in open("gpurun_out/sweep_%s.json" % sys.argv[1]) if l.s
 print("%-28s %7.1f frames/s  %.3f ms" % (sys.argv[1], d["value"], d["ms_per_step"]))
 PY
 }
-run side2_start --side-variant 2 &&
-run side0_start --side-variant 0 &&
-run side0_trunk --side-variant 0 --prefetch-at trunk &&
-run side0_up1 --side-variant 0 --prefetch-at up1 &&
-run side0_up2 --side-variant 0 --prefetch-at up2 &&
-run side5_trunk --side-variant 5 --prefetch-at trunk &&
+run default &&
+run side2_capped --side-variant 2 &&
+run side5 --side-variant 5 &&
 run no_overlap --no-overlap &&
-run side0_start_again --side-variant 0
+run default_again
