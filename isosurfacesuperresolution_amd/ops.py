@@ -409,6 +409,9 @@ TRAIN_BF16 = False
 # NOT a reduced-precision mode) for layers with at least TRAIN_SPLIT_MIN_TILES tiles of 8x32 pixels; smaller layers and
 # all weight gradients stay on the exact fp32 MFMA kernels.
 TRAIN_SPLIT = True
+# GATE_FUSION: a conv3x3 whose input is the output of a ReLU conv3x3 applies that ReLU's backward in the epilogue of its own
+# data gradient (one isrActBackward launch and a 3-tensor round trip less per such pair)
+GATE_FUSION = True
 TRAIN_SPLIT_MIN_TILES = 256
 TRAIN_SPLIT_MIN_TILES2 = 128      # small images: 2-row tiles (the library picks that form below 256 tiles of 8x32 pixels)
 
@@ -574,6 +577,9 @@ def residual_block(x, w1, b1, w2, b2):
 class _Conv3x3Function(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, weight, bias, residual, act, slope):
+        # x is the output of a ReLU convolution (tagged by conv3x3 below): the data gradient of THIS layer can then apply
+        # that ReLU's backward in its epilogue (ISR_ACT_GATE on x > 0) and the producer skips its isrActBackward launch
+        ctx.x_relu = bool(getattr(x, '_isr_relu_out', False)) and x.is_contiguous()
         x = x.contiguous()
         res = residual.contiguous() if residual is not None else None
         b = bias.contiguous() if bias is not None else None
@@ -599,7 +605,9 @@ class _Conv3x3Function(torch.autograd.Function):
         x, weight, y = ctx.saved_tensors
         gy = gy.contiguous()
         cout, cin = weight.shape[0], weight.shape[1]
-        if ctx.act != 'none':
+        if ctx.act == 'relu' and getattr(gy, '_isr_gated_by', None) == (y.data_ptr(), y._version, gy._version):
+            gz = gy              # the consumer's data gradient already multiplied by (y > 0), see below
+        elif ctx.act != 'none':
             gz = torch.empty_like(gy)
             rc = lib.isrActBackward(_ptr(gy), _ptr(y), _ptr(gz), gy.numel(), ACT_CODES[ctx.act], float(ctx.slope), _stream())
             if rc != 0:
@@ -609,7 +617,11 @@ class _Conv3x3Function(torch.autograd.Function):
         gx = gw = gb = gres = None
         if ctx.needs_input_grad[0]:
             # data gradient = the same fused kernel on flipped / transposed weights
-            gx = _train_conv(gz, weight, True, None, None, 'none')
+            if ctx.x_relu and GATE_FUSION:
+                gx = _train_conv(gz, weight, True, None, x, 'gate')
+                gx._isr_gated_by = (x.data_ptr(), x._version, gx._version)   # read by the backward of the layer that produced x
+            else:
+                gx = _train_conv(gz, weight, True, None, None, 'none')
         if ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2]):
             gw, gb = _weight_grad_or_defer(ctx.weight, ctx.bias, ctx.has_bias, x, gz)
         if ctx.has_res and ctx.needs_input_grad[3]:
@@ -658,7 +670,10 @@ def conv3x3(x, weight, bias=None, act='none', slope=0.01, residual=None, upsampl
         x = bilinear_upsample2x(x)
     if residual is not None and act != 'none':
         return _Conv3x3Function.apply(x, weight, bias, None, act, slope) + residual
-    return _Conv3x3Function.apply(x, weight, bias, residual, act, slope)
+    y = _Conv3x3Function.apply(x, weight, bias, residual, act, slope)
+    if act == 'relu' and residual is None:
+        y._isr_relu_out = True      # a consumer conv3x3 may fold this ReLU's backward into its data gradient
+    return y
 
 
 # ---- training-side elementwise kernels (csrc/sr_train.hip) ---------------------------------------

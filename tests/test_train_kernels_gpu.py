@@ -467,3 +467,62 @@ def test_split_operand_weight_gradient_matches_fp64(case, gz_scale):
     assert err[True] != err[False]                                                          # two different kernels did run
     assert err[True] <= 2.0 * err[False] + 5e-7, err
     assert err[True] <= 1e-5, err
+
+
+def test_relu_backward_folded_into_the_consumers_data_gradient():
+    """conv(relu) -> conv(relu) -> conv: with ops.GATE_FUSION the data gradient of a layer whose input is a ReLU conv3x3's
+    output applies that ReLU's backward in its epilogue and the producer skips its isrActBackward; every gradient must be
+    the one of the unfused graph (bit for bit: a select instead of a multiplication by 0 / 1), also when the ReLU output
+    has a second consumer (autograd then sums two gradients and the producer gates the sum as before)."""
+    from isosurfacesuperresolution_amd import ops
+    g = torch.Generator().manual_seed(77)
+    x0 = (torch.rand(2, 64, 64, 64, generator=g) - 0.5).cuda()
+    ws = [((torch.rand(co, ci, 3, 3, generator=g) - 0.5) * 0.1).cuda() for co, ci in ((64, 64), (64, 64), (6, 64))]
+    bs = [(torch.rand(w.shape[0], generator=g) - 0.5).cuda() for w in ws]
+    tgt = torch.rand(2, 6, 64, 64, generator=g).cuda()
+    lib = ops._sr()
+    calls = {"n": 0}
+    real = lib.isrActBackward
+
+    def run(fuse, second_consumer):
+        ops.GATE_FUSION = fuse
+        x = x0.clone().requires_grad_(True)
+        w = [t.clone().requires_grad_(True) for t in ws]
+        b = [t.clone().requires_grad_(True) for t in bs]
+        y1 = ops.conv3x3(x, w[0], b[0], act='relu')
+        y2 = ops.conv3x3(y1, w[1], b[1], act='relu')
+        y3 = ops.conv3x3(y2, w[2], b[2])
+        loss = ((y3 - tgt) ** 2).mean()
+        if second_consumer:
+            loss = loss + (y2 * 0.001).sum()
+        loss.backward()
+        return [x.grad] + [t.grad for t in w] + [t.grad for t in b]
+
+    old = ops.GATE_FUSION
+    try:
+        for second in (False, True):
+            ref = run(False, second)
+            got = run(True, second)
+            for a, c in zip(ref, got):
+                assert torch.equal(a, c), second
+        # the fused graph really launches fewer ReLU-backward kernels: count them through the profile-free path
+        import ctypes
+
+        class Counter:
+            def __init__(self, fn):
+                self.fn, self.n = fn, 0
+                self.argtypes, self.restype = fn.argtypes, fn.restype
+
+            def __call__(self, *a):
+                self.n += 1
+                return self.fn(*a)
+        for fuse, expect in ((False, 2), (True, 0)):
+            c = Counter(real)
+            lib.isrActBackward = c
+            try:
+                run(fuse, False)
+            finally:
+                lib.isrActBackward = real
+            assert c.n == expect, (fuse, c.n)
+    finally:
+        ops.GATE_FUSION = old
