@@ -140,6 +140,14 @@ int isrConv3x3WeightGradSegmentsBf16(const float* const* xs, const float* const*
 int isrUpsample2xForward(const float* x, float* y, long long planes, int h, int w, void* stream);
 int isrUpsample2xBackward(const float* gy, float* gx, long long planes, int h, int w, void* stream);
 
+/* Residual reconstruction of the network output (SuperresolutionNetwork/models/enhancenet.py:65-78, reconType='residual'):
+ * out[n][c] = y[n][c] + bilinear_x4(x[n][c]) (align_corners=False) for c < k, out[n][c] = y[n][c] for k <= c < Cout -- the
+ * slice / F.interpolate / add / cat of the reference as one launch.  y, out: [N][Cout][4h][4w], x: [N][Cin][h][w], packed.
+ * The backward w.r.t. y is the identity; isrReconResidualBackward writes the one w.r.t. x: gx [N][Cin][h][w], the adjoint of
+ * the resize for channels < k (a gather: bitwise reproducible), zero for the others.  0 ok, -1 bad arguments, -2 launch failure. */
+int isrReconResidualForward(const float* y, const float* x, float* out, int N, int Cout, int Cin, int k, int h, int w, void* stream);
+int isrReconResidualBackward(const float* gy, float* gx, int N, int Cout, int Cin, int k, int h, int w, void* stream);
+
 /* LossNetUnshaded (SuperresolutionNetwork/losses/lossnet_unshaded.py:236-388) for the l1 / mse / temp-l2 terms on
  * mask / normal / ao / depth / colour, fused: one pass forward (+ a one-workgroup reduction), one pass backward.
  * gt, pred, prev: [N][6][H][W] (mask, normal xyz, depth, ao), W % 4 == 0; prev = warped previous prediction or NULL

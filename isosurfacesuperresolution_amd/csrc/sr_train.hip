@@ -84,6 +84,79 @@ __global__ __launch_bounds__(256) void upsample2x_bwd_kernel(const float* __rest
 }
 
 // ---------------------------------------------------------------------------------------------------------
+// Residual reconstruction of the network output (enhancenet.py:65-78, reconType='residual'):
+// out[:, c] = y[:, c] + bilinear_x4(x[:, c]) for c < k, out[:, c] = y[:, c] beyond -- one launch instead of slice,
+// F.interpolate, add and cat; the adjoint w.r.t. x is a gather over the 8 x 8 output pixels that read an input pixel.
+// ---------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void recon_residual_fwd_kernel(const float* __restrict__ y, const float* __restrict__ x, float* __restrict__ out,
+                                                                 int cout, int cin, int k, int h, int w)
+{
+    const int W = 4 * w, H = 4 * h;
+    const int X = blockIdx.x * 256 + threadIdx.x, Y = blockIdx.y, n = blockIdx.z;
+    if (X >= W) return;
+    int y0, y1, x0, x1; float ly, lx;
+    isr_src_index(Y, 0.25f, h, y0, y1, ly);
+    isr_src_index(X, 0.25f, w, x0, x1, lx);
+    const float hy = 1.f - ly, hx = 1.f - lx;
+    const size_t hplane = (size_t)H * W, lplane = (size_t)h * w;
+    const size_t pix = (size_t)Y * W + X;
+    for (int c = 0; c < cout; ++c) {
+        float v = y[((size_t)n * cout + c) * hplane + pix];
+        if (c < k) {
+            const float* q = x + ((size_t)n * cin + c) * lplane;
+            v += hy * (hx * q[y0 * w + x0] + lx * q[y0 * w + x1]) + ly * (hx * q[y1 * w + x0] + lx * q[y1 * w + x1]);
+        }
+        out[((size_t)n * cout + c) * hplane + pix] = v;
+    }
+}
+
+__device__ __forceinline__ float up4_weight(int o, int i, int n)
+{
+    int i0, i1; float l1;
+    isr_src_index(o, 0.25f, n, i0, i1, l1);
+    return (i0 == i ? 1.f - l1 : 0.f) + (i1 == i ? l1 : 0.f);
+}
+
+// gx[n][c][iy][ix]: c < k: sum over the output pixels (4 iy - 2 .. 4 iy + 5) x (4 ix - 2 .. 4 ix + 5) that blend this
+// input pixel; c >= k: zero (the reconstruction does not read those channels)
+__global__ __launch_bounds__(256) void recon_residual_bwd_kernel(const float* __restrict__ gy, float* __restrict__ gx,
+                                                                 int cout, int cin, int k, int h, int w, long long count)
+{
+    const int W = 4 * w, H = 4 * h;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < count; i += (long long)gridDim.x * 256) {
+        const int ix = (int)(i % w);
+        long long r = i / w;
+        const int iy = (int)(r % h); r /= h;
+        const int c = (int)(r % cin), n = (int)(r / cin);
+        float acc = 0.f;
+        if (c < k) {
+            float wx[8];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                const int X = 4 * ix - 2 + q;
+                wx[q] = (X >= 0 && X < W) ? up4_weight(X, ix, w) : 0.f;
+            }
+            const float* plane = gy + ((size_t)n * cout + c) * (size_t)H * W;
+#pragma unroll 1
+            for (int j = 0; j < 8; ++j) {
+                const int Y = 4 * iy - 2 + j;
+                if (Y < 0 || Y >= H) continue;
+                const float wy = up4_weight(Y, iy, h);
+                const float* row = plane + (size_t)Y * W;
+                float s = 0.f;
+#pragma unroll
+                for (int q = 0; q < 8; ++q) {
+                    const int X = 4 * ix - 2 + q;
+                    if (X >= 0 && X < W) s += wx[q] * row[X];
+                }
+                acc += wy * s;
+            }
+        }
+        gx[i] = acc;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------
 // LossNetUnshaded
 // ---------------------------------------------------------------------------------------------------------
 constexpr int LOSS_TERMS = 15;        // kind * 5 + target;  kind: 0 mse, 1 l1, 2 temp-l2;  target: 0 mask 1 normal 2 ao 3 depth 4 colour
@@ -605,6 +678,23 @@ int isrRecurrentInputBackward(const float* prev_raw, const float* flow, const fl
     long long blocks = (pixels + 255) / 256;
     if (blocks > 4096) blocks = 4096;
     hipLaunchKernelGGL(recurrent_input_post_kernel, dim3((unsigned)blocks), dim3(256), 0, s, p, pixels);
+    return hipGetLastError() == hipSuccess ? 0 : -2;
+}
+
+int isrReconResidualForward(const float* y, const float* x, float* out, int N, int Cout, int Cin, int k, int h, int w, void* stream)
+{
+    if (!y || !x || !out || N <= 0 || Cout <= 0 || Cin <= 0 || k < 0 || k > Cout || k > Cin || h <= 0 || w <= 0 || N > 65535 || 4LL * h > 65535) return -1;
+    hipLaunchKernelGGL(recon_residual_fwd_kernel, dim3((4 * w + 255) / 256, 4 * h, N), dim3(256), 0, (hipStream_t)stream, y, x, out, Cout, Cin, k, h, w);
+    return hipGetLastError() == hipSuccess ? 0 : -2;
+}
+
+int isrReconResidualBackward(const float* gy, float* gx, int N, int Cout, int Cin, int k, int h, int w, void* stream)
+{
+    if (!gy || !gx || N <= 0 || Cout <= 0 || Cin <= 0 || k < 0 || k > Cout || k > Cin || h <= 0 || w <= 0) return -1;
+    const long long count = (long long)N * Cin * h * w;
+    long long blocks = (count + 255) / 256;
+    if (blocks > 16384) blocks = 16384;
+    hipLaunchKernelGGL(recon_residual_bwd_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, gy, gx, Cout, Cin, k, h, w, count);
     return hipGetLastError() == hipSuccess ? 0 : -2;
 }
 

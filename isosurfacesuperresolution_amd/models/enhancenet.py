@@ -73,6 +73,8 @@ class EnhanceNet(nn.Module):
             return outputs, outputs
         if k > self.output_channels:
             raise ValueError("number of output channels must be at least the number of masked input channels")
+        if self.upsample == 'bilinear' and ops.recon_residual_supported(outputs, inputs, k):
+            return ops.recon_residual(outputs, inputs, k), outputs     # slice + resize + add + cat as one HIP launch
         resized = F.interpolate(inputs[:, 0:k], size=[outputs.shape[2], outputs.shape[3]], mode=self.upsample,
                                 **({'align_corners': False} if self.upsample in ('bilinear', 'bicubic') else {}))
         if k == self.output_channels:

@@ -69,6 +69,8 @@ def _sr():
         lib.isrConvSmallFinishFrame.restype = ci
         lib.isrUpsample2xForward.argtypes = [vp, vp, ll, ci, ci, vp]; lib.isrUpsample2xForward.restype = ci
         lib.isrUpsample2xBackward.argtypes = [vp, vp, ll, ci, ci, vp]; lib.isrUpsample2xBackward.restype = ci
+        lib.isrReconResidualForward.argtypes = [vp, vp, vp, ci, ci, ci, ci, ci, ci, vp]; lib.isrReconResidualForward.restype = ci
+        lib.isrReconResidualBackward.argtypes = [vp, vp, ci, ci, ci, ci, ci, ci, vp]; lib.isrReconResidualBackward.restype = ci
         lib.isrLossUnshadedWorkspace.argtypes = []; lib.isrLossUnshadedWorkspace.restype = ll
         lib.isrLossUnshadedForward.argtypes = [vp, vp, vp, ci, ci, ci, ci, vp, ctypes.c_uint, vp, cf, ci, vp, vp, vp]
         lib.isrLossUnshadedForward.restype = ci
@@ -709,6 +711,44 @@ def bilinear_upsample2x(x):
                        "fp32 and an even width)" % (x.dtype, x.shape[3]))
         return F.interpolate(x, scale_factor=2, mode='bilinear', align_corners=False)
     return _Upsample2xFunction.apply(x)
+
+
+class _ReconResidualFunction(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, outputs, inputs, k):
+        outputs, inputs = outputs.contiguous(), inputs.contiguous()
+        n, cout, H, W = outputs.shape
+        cin, h, w = inputs.shape[1], inputs.shape[2], inputs.shape[3]
+        out = torch.empty_like(outputs)
+        rc = _sr().isrReconResidualForward(_ptr(outputs), _ptr(inputs), _ptr(out), n, cout, cin, k, h, w, _stream())
+        if rc != 0:
+            raise RuntimeError("isrReconResidualForward failed (%d)" % rc)
+        ctx.dims = (n, cout, cin, k, h, w)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        n, cout, cin, k, h, w = ctx.dims
+        g = g.contiguous()
+        gin = None
+        if ctx.needs_input_grad[1]:
+            gin = torch.empty((n, cin, h, w), dtype=torch.float32, device=g.device)
+            rc = _sr().isrReconResidualBackward(_ptr(g), _ptr(gin), n, cout, cin, k, h, w, _stream())
+            if rc != 0:
+                raise RuntimeError("isrReconResidualBackward failed (%d)" % rc)
+        return g, gin, None
+
+
+def recon_residual_supported(outputs, inputs, k):
+    return (outputs.is_cuda and outputs.dtype == torch.float32 and inputs.dtype == torch.float32 and outputs.dim() == 4
+            and outputs.shape[0] == inputs.shape[0] and outputs.shape[2] == 4 * inputs.shape[2] and outputs.shape[3] == 4 * inputs.shape[3]
+            and 0 < k <= min(outputs.shape[1], inputs.shape[1]) and outputs.shape[0] <= 65535 and outputs.shape[2] <= 65535)
+
+
+def recon_residual(outputs, inputs, k):
+    """``outputs`` with the bilinearly x4-resized first ``k`` channels of ``inputs`` added to its first ``k`` channels
+    (EnhanceNet's residual reconstruction) in one launch; differentiable w.r.t. both."""
+    return _ReconResidualFunction.apply(outputs, inputs, k)
 
 
 def _batch_view(t, c, h, w):

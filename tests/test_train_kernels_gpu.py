@@ -526,3 +526,31 @@ def test_relu_backward_folded_into_the_consumers_data_gradient():
             assert c.n == expect, (fuse, c.n)
     finally:
         ops.GATE_FUSION = old
+
+
+@pytest.mark.parametrize("shape", [(2, 6, 101, 5, 32, 32), (1, 6, 5, 5, 9, 7), (3, 6, 8, 6, 5, 12), (1, 4, 7, 2, 1, 1)])
+def test_residual_reconstruction_kernel_matches_interpolate_add_cat(shape):
+    """isrReconResidualForward / Backward against the reference's slice + F.interpolate(x4, bilinear) + add + cat
+    (enhancenet.py:65-78), values and both gradients."""
+    import torch.nn.functional as F
+    from isosurfacesuperresolution_amd import ops
+    n, cout, cin, k, h, w = shape
+    g = torch.Generator().manual_seed(3)
+    y0 = torch.rand(n, cout, 4 * h, 4 * w, generator=g).cuda()
+    x0 = torch.rand(n, cin, h, w, generator=g).cuda()
+    gout = torch.rand(n, cout, 4 * h, 4 * w, generator=g).cuda()
+
+    def ref(y, x):
+        r = F.interpolate(x[:, 0:k], size=[4 * h, 4 * w], mode='bilinear', align_corners=False)
+        return r + y if k == cout else torch.cat([r + y[:, 0:k], y[:, k:]], dim=1)
+
+    res = {}
+    for name, fn in (("ref", ref), ("hip", lambda y, x: ops.recon_residual(y, x, k))):
+        y, x = y0.clone().requires_grad_(True), x0.clone().requires_grad_(True)
+        assert ops.recon_residual_supported(y, x, k)
+        out = fn(y, x)
+        out.backward(gout)
+        res[name] = (out.detach(), y.grad, x.grad)
+    for a, b, tol in zip(res["ref"], res["hip"], (1e-6, 0.0, 2e-5)):
+        assert (a - b).abs().max().item() <= tol
+    assert res["hip"][2][:, k:].abs().max().item() == 0.0 if k < cin else True
