@@ -117,43 +117,42 @@ __device__ __forceinline__ float up4_weight(int o, int i, int n)
     return (i0 == i ? 1.f - l1 : 0.f) + (i1 == i ? l1 : 0.f);
 }
 
-// gx[n][c][iy][ix]: c < k: sum over the output pixels (4 iy - 2 .. 4 iy + 5) x (4 ix - 2 .. 4 ix + 5) that blend this
-// input pixel; c >= k: zero (the reconstruction does not read those channels)
+// gx[n][c][iy][ix], c < k: sum over the output pixels (4 iy - 2 .. 4 iy + 5) x (4 ix - 2 .. 4 ix + 5) that blend this input
+// pixel.  Eight neighbouring lanes take one output row each and add up through DPP-sized shuffles (a single thread walking
+// the 64 taps is a chain of eight load latencies: 20 us for a launch that moves 4 MB).  Channels >= k are zeroed by the caller.
 __global__ __launch_bounds__(256) void recon_residual_bwd_kernel(const float* __restrict__ gy, float* __restrict__ gx,
-                                                                 int cout, int cin, int k, int h, int w, long long count)
+                                                                 int cout, int cin, int k, int h, int w, long long count8)
 {
     const int W = 4 * w, H = 4 * h;
-    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < count; i += (long long)gridDim.x * 256) {
-        const int ix = (int)(i % w);
+    const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
+    const int j = (int)(t & 7);
+    const long long i = t >> 3;                       // (n, c < k, iy, ix)
+    float part = 0.f;
+    int ix = 0, iy = 0, c = 0, n = 0;
+    const bool live = t < count8;
+    if (live) {
+        ix = (int)(i % w);
         long long r = i / w;
-        const int iy = (int)(r % h); r /= h;
-        const int c = (int)(r % cin), n = (int)(r / cin);
-        float acc = 0.f;
-        if (c < k) {
-            float wx[8];
+        iy = (int)(r % h); r /= h;
+        c = (int)(r % k); n = (int)(r / k);
+        const int Y = 4 * iy - 2 + j;
+        if (Y >= 0 && Y < H) {
+            const float wy = up4_weight(Y, iy, h);
+            const float* row = gy + (((size_t)n * cout + c) * H + Y) * (size_t)W;
+            float s = 0.f;
 #pragma unroll
             for (int q = 0; q < 8; ++q) {
                 const int X = 4 * ix - 2 + q;
-                wx[q] = (X >= 0 && X < W) ? up4_weight(X, ix, w) : 0.f;
+                if (X >= 0 && X < W) s += up4_weight(X, ix, w) * row[X];
             }
-            const float* plane = gy + ((size_t)n * cout + c) * (size_t)H * W;
-#pragma unroll 1
-            for (int j = 0; j < 8; ++j) {
-                const int Y = 4 * iy - 2 + j;
-                if (Y < 0 || Y >= H) continue;
-                const float wy = up4_weight(Y, iy, h);
-                const float* row = plane + (size_t)Y * W;
-                float s = 0.f;
-#pragma unroll
-                for (int q = 0; q < 8; ++q) {
-                    const int X = 4 * ix - 2 + q;
-                    if (X >= 0 && X < W) s += wx[q] * row[X];
-                }
-                acc += wy * s;
-            }
+            part = wy * s;
         }
-        gx[i] = acc;
     }
+    // fixed-order sum of the eight rows (bitwise reproducible)
+    part += __shfl_xor(part, 1);
+    part += __shfl_xor(part, 2);
+    part += __shfl_xor(part, 4);
+    if (live && j == 0) gx[(((size_t)n * cin + c) * h + iy) * (size_t)w + ix] = part;
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -527,13 +526,17 @@ __global__ __launch_bounds__(256) void recurrent_input_fwd_kernel(const RecurPar
     }
 }
 
+// one thread per HIGH-resolution pixel (Y = 4y + dy, X): 6 channels x 4 taps of atomics each.  (One thread per low-res
+// column doing its four rows in turn left a 16 x 32^2 crop batch with 1 024 waves of four dependent load -> atomic rounds:
+// 123 us per launch for 25 MB of atomics.)
 __global__ __launch_bounds__(256) void recurrent_input_scatter_kernel(const RecurParams p)
 {
     const int t = blockIdx.x * blockDim.x + threadIdx.x;
-    const int x = t >> 2, dx = t & 3;
+    const int W = 4 * p.w, H = 4 * p.h;
+    const int dy = t / W, X = t - dy * W;
     const int y = blockIdx.y, b = blockIdx.z;
-    if (x >= p.w) return;
-    const int H = 4 * p.h, W = 4 * p.w;
+    if (dy >= 4) return;
+    const int x = X >> 2, dx = X & 3;
     const size_t plane = (size_t)p.h * p.w, hplane = (size_t)H * W;
     const size_t pix = (size_t)y * p.w + x;
     const float* fx = p.flow + (size_t)b * p.flowStride;
@@ -541,23 +544,29 @@ __global__ __launch_bounds__(256) void recurrent_input_scatter_kernel(const Recu
     const float* gn = p.gnetin ? p.gnetin + (size_t)b * 101 * plane + 5 * plane + pix : nullptr;
     const float* gw = p.gwarped ? p.gwarped + (size_t)b * 6 * hplane : nullptr;
     float* go = p.gout + (size_t)b * 6 * hplane;
-    const int X = 4 * x + dx;
-    for (int dy = 0; dy < 4; ++dy) {
-        const int Y = 4 * y + dy;
-        const WarpTaps tp = warp_taps(fx, fy, p.h, p.w, Y, X);
+    const int Y = 4 * y + dy;
+    float g[6];
 #pragma unroll
-        for (int c = 0; c < 6; ++c) {
-            float g = 0.f;
-            if (gn) g += gn[(size_t)(c * 16 + dy * 4 + dx) * plane];
-            if (gw) g += gw[(size_t)c * hplane + (size_t)Y * W + X];
-            // c == 0: d(2 * sample(m/2 + 1/2) - 1) / dm = the plain bilinear weights
-            float* q = go + (size_t)c * hplane;
-            if (tp.v00) unsafeAtomicAdd(q + tp.b00, g * tp.w00);
-            if (tp.v01) unsafeAtomicAdd(q + tp.b00 + 1, g * tp.w01);
-            if (tp.v10) unsafeAtomicAdd(q + tp.b00 + W, g * tp.w10);
-            if (tp.v11) unsafeAtomicAdd(q + tp.b00 + W + 1, g * tp.w11);
-        }
+    for (int c = 0; c < 6; ++c) {
+        g[c] = 0.f;
+        if (gn) g[c] += gn[(size_t)(c * 16 + dy * 4 + dx) * plane];
+        if (gw) g[c] += gw[(size_t)c * hplane + (size_t)Y * W + X];
     }
+    const WarpTaps tp = warp_taps(fx, fy, p.h, p.w, Y, X);
+#pragma unroll
+    for (int c = 0; c < 6; ++c) {
+        // c == 0: d(2 * sample(m/2 + 1/2) - 1) / dm = the plain bilinear weights
+        float* q = go + (size_t)c * hplane;
+        if (tp.v00) unsafeAtomicAdd(q + tp.b00, g[c] * tp.w00);
+        if (tp.v01) unsafeAtomicAdd(q + tp.b00 + 1, g[c] * tp.w01);
+        if (tp.v10) unsafeAtomicAdd(q + tp.b00 + W, g[c] * tp.w10);
+        if (tp.v11) unsafeAtomicAdd(q + tp.b00 + W + 1, g[c] * tp.w11);
+    }
+}
+
+__global__ __launch_bounds__(256) void zero_fill_floats_kernel(float* __restrict__ dst, long long count)
+{
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < count; i += (long long)gridDim.x * 256) dst[i] = 0.f;
 }
 
 __global__ __launch_bounds__(256) void zero_fill_kernel(float4* __restrict__ dst, long long quads)
@@ -674,7 +683,7 @@ int isrRecurrentInputBackward(const float* prev_raw, const float* flow, const fl
         hipLaunchKernelGGL(zero_fill_kernel, dim3((unsigned)zb), dim3(256), 0, s, reinterpret_cast<float4*>(scratch), quads);
     }
     if (g_net_input || g_warped)
-        hipLaunchKernelGGL(recurrent_input_scatter_kernel, dim3((4 * w + 255) / 256, h, B), dim3(256), 0, s, p);
+        hipLaunchKernelGGL(recurrent_input_scatter_kernel, dim3((16 * w + 255) / 256, h, B), dim3(256), 0, s, p);
     long long blocks = (pixels + 255) / 256;
     if (blocks > 4096) blocks = 4096;
     hipLaunchKernelGGL(recurrent_input_post_kernel, dim3((unsigned)blocks), dim3(256), 0, s, p, pixels);
@@ -691,10 +700,18 @@ int isrReconResidualForward(const float* y, const float* x, float* out, int N, i
 int isrReconResidualBackward(const float* gy, float* gx, int N, int Cout, int Cin, int k, int h, int w, void* stream)
 {
     if (!gy || !gx || N <= 0 || Cout <= 0 || Cin <= 0 || k < 0 || k > Cout || k > Cin || h <= 0 || w <= 0) return -1;
-    const long long count = (long long)N * Cin * h * w;
-    long long blocks = (count + 255) / 256;
-    if (blocks > 16384) blocks = 16384;
-    hipLaunchKernelGGL(recon_residual_bwd_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, gy, gx, Cout, Cin, k, h, w, count);
+    // (a kernel, not hipMemsetAsync: captured in a HIP graph the memset node did not take effect on replay)
+    {
+        const long long total = (long long)N * Cin * h * w;
+        long long zb = (total + 255) / 256;
+        if (zb > 4096) zb = 4096;
+        hipLaunchKernelGGL(zero_fill_floats_kernel, dim3((unsigned)zb), dim3(256), 0, (hipStream_t)stream, gx, total);
+    }
+    const long long count8 = (long long)N * k * h * w * 8;
+    if (count8 == 0) return hipGetLastError() == hipSuccess ? 0 : -2;
+    const long long blocks = (count8 + 255) / 256;
+    if (blocks > 0x7fffffffLL) return -1;
+    hipLaunchKernelGGL(recon_residual_bwd_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, gy, gx, Cout, Cin, k, h, w, count8);
     return hipGetLastError() == hipSuccess ? 0 : -2;
 }
 
