@@ -68,7 +68,7 @@ struct SplitConvParams {
     int Hin, Win;                 // input size: (H, W), or (H / 2, W / 2) for the upsampling variant
     int quads;                    // 1: W, the plane stride of x and its base address allow aligned dwordx4 staging
     int dbg;                      // diagnostics: 1 skip the MFMAs, 2 skip the staging loads, 4 skip the stores
-    unsigned long long* stamps;   // diagnostics: per-workgroup s_memtime stamps, or NULL
+    unsigned long long* stamps;   // diagnostics: per-workgroup s_memrealtime stamps (100 MHz, one clock for the whole chip), or NULL
 };
 
 // v = hi + lo (+ <= 2^-22 |v|): hi = RN16(v), lo = RN16(v - hi); the subtraction is exact in fp32
@@ -208,7 +208,7 @@ __global__ __launch_bounds__(S_THREADS, 2) void conv3x3_split_kernel(const Split
     const bool second = co0 + 32 < p.coutPad;                                // the second 32-channel block exists
     const int couts = min(64, p.coutPad - co0);
     unsigned long long st0 = 0, st1 = 0, st2 = 0;
-    if (p.stamps) st0 = __builtin_amdgcn_s_memtime();
+    if (p.stamps) st0 = __builtin_amdgcn_s_memrealtime();
 
     // weights of k-step ks: 2304 units [part][tap][lane half][64 couts], 9 per thread, L2 -> registers -> LDS
     u32x4 wreg[9];
@@ -399,7 +399,7 @@ __global__ __launch_bounds__(S_THREADS, 2) void conv3x3_split_kernel(const Split
         }
         wpark();                                                             // k-step ks0 (its readers passed the barrier that ended the previous chunk)
         __syncthreads();
-        if (p.stamps && cin0 == 0) st1 = __builtin_amdgcn_s_memtime();
+        if (p.stamps && cin0 == 0) st1 = __builtin_amdgcn_s_memrealtime();
         // ---- MFMAs: k-steps of 16 channels x 9 taps x (2 channel blocks x 2 rows) x 3 products --------------------
 #pragma unroll
         for (int S = 0; S < 2; ++S) {
@@ -439,11 +439,11 @@ __global__ __launch_bounds__(S_THREADS, 2) void conv3x3_split_kernel(const Split
         }
     }
 
-    if (p.stamps) st2 = __builtin_amdgcn_s_memtime();
+    if (p.stamps) st2 = __builtin_amdgcn_s_memrealtime();
     split_epilogue(p, acc, patch, n, oy0, ox0, co0, second, lane, wave, j, h);
     if (p.stamps && tid == 0) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        const unsigned long long st3 = __builtin_amdgcn_s_memtime();
+        const unsigned long long st3 = __builtin_amdgcn_s_memrealtime();
         unsigned long long* o = p.stamps + (size_t)blockIdx.x * 4;
         o[0] = st0; o[1] = st1; o[2] = st2; o[3] = st3;
     }
