@@ -78,6 +78,12 @@ int isrConv3x3SmallCoutStrided(const float* x, const float* w8, const float* bia
  * isrConvSplitPrepare into isrConvSplitWeightBytes(Cin, Cout) bytes of device memory (layout private to the kernel). */
 long long isrConvSplitWeightBytes(int Cin, int Cout);
 int isrConvSplitPrepare(const float* w, void* wq, int Cout, int Cin, void* stream);
+/* The same preparation for up to isrConvSplitPrepareManyMax() layers in two launches: per layer the forward image
+ * (wqForward[l], isrConvSplitWeightBytes(cin, cout) bytes, may be NULL) and the image of the data-gradient convolution
+ * w'[ci][co][ky][kx] = w[co][ci][2-ky][2-kx] (wqBackward[l], isrConvSplitWeightBytes(cout, cin) bytes, may be NULL).  Training
+ * re-prepares every layer after every optimizer step.  Pointer arrays are host arrays.  0 ok, -1 bad arguments, -2 launch failure. */
+int isrConvSplitPrepareManyMax(void);
+int isrConvSplitPrepareMany(int n, const float* const* w, void* const* wqForward, void* const* wqBackward, const int* cout, const int* cin, void* stream);
 int isrConv3x3ForwardSplit(const float* x, const void* wq, const float* bias, const float* residual, float* y,
                            int N, int Cin, int H, int W, int Cout, int act, float slope, int upsample2x,
                            long long xPlane, long long xImage, long long yPlane, long long yImage,

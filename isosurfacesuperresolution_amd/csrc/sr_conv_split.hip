@@ -1130,6 +1130,87 @@ __global__ void prepare_weights_split_kernel(const float* __restrict__ w, u32x4*
     }
 }
 
+// ---- all layers of a network prepared in two launches (training re-prepares every weight after every optimizer step) -------
+// Per layer: the forward weights and their data-gradient twin w'[ci][co][ky][kx] = w[co][ci][2 - ky][2 - kx] (same scale: the
+// same numbers), which isrConvSplitPrepare gets from a flipped / transposed copy made by the caller.
+constexpr int PM_MAX = 32;
+struct PrepManyParams {
+    const float* w[PM_MAX];
+    u32x4* fwd[PM_MAX];          // may be NULL
+    u32x4* bwd[PM_MAX];          // may be NULL
+    int cout[PM_MAX], cin[PM_MAX];
+    int n;
+};
+
+__global__ __launch_bounds__(1024) void split_scale_many_kernel(const PrepManyParams p)
+{
+    __shared__ float red[1024];
+    const int l = blockIdx.x;
+    const float* __restrict__ w = p.w[l];
+    const int count = p.cout[l] * p.cin[l] * 9;
+    float m0 = 0.0f, m1 = 0.0f, m2 = 0.0f, m3 = 0.0f;
+    int i = threadIdx.x;
+    for (; i + 3072 < count; i += 4096) {
+        m0 = fmaxf(m0, fabsf(w[i])); m1 = fmaxf(m1, fabsf(w[i + 1024]));
+        m2 = fmaxf(m2, fabsf(w[i + 2048])); m3 = fmaxf(m3, fabsf(w[i + 3072]));
+    }
+    for (; i < count; i += 1024) m0 = fmaxf(m0, fabsf(w[i]));
+    red[threadIdx.x] = fmaxf(fmaxf(m0, m1), fmaxf(m2, m3));
+    __syncthreads();
+    for (int s = 512; s > 0; s >>= 1) {
+        if ((int)threadIdx.x < s) red[threadIdx.x] = fmaxf(red[threadIdx.x], red[threadIdx.x + s]);
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        int S = 0;
+        const float mx = red[0];
+        if (mx > 0.0f && mx < 3.0e38f) {
+            S = 13 - ilogbf(mx);
+            S = S < -100 ? -100 : (S > 100 ? 100 : S);
+        }
+        u32x4 hdr;
+        hdr.x = __builtin_bit_cast(unsigned, ldexpf(1.0f, S));
+        hdr.y = __builtin_bit_cast(unsigned, ldexpf(1.0f, -S));
+        hdr.z = (unsigned)S; hdr.w = 0u;
+        if (p.fwd[l]) p.fwd[l][0] = hdr;
+        if (p.bwd[l]) p.bwd[l][0] = hdr;
+    }
+}
+
+// grid: (units, 2 n): blockIdx.y = 2 layer + orientation (0 forward, 1 data gradient)
+__global__ __launch_bounds__(256) void prepare_weights_split_many_kernel(const PrepManyParams p)
+{
+    const int l = blockIdx.y >> 1, tr = blockIdx.y & 1;
+    u32x4* __restrict__ wq = tr ? p.bwd[l] : p.fwd[l];
+    if (!wq) return;
+    const float* __restrict__ w = p.w[l];
+    const int Co = p.cout[l], Ci = p.cin[l];                 // of the stored tensor w[Co][Ci][3][3]
+    const int Cout = tr ? Ci : Co, Cin = tr ? Co : Ci;       // of the convolution this image serves
+    const int ksteps = (Cin + 15) / 16, coutPad = ((Cout + 31) / 32) * 32;
+    const float scale = reinterpret_cast<const float*>(wq)[0];
+    const int total = 9 * ksteps * 2 * coutPad;
+    for (int u = blockIdx.x * blockDim.x + threadIdx.x; u < total; u += gridDim.x * blockDim.x) {
+        const int co = u % coutPad;
+        const int hh = (u / coutPad) & 1;
+        const int s = (u / (coutPad * 2)) % ksteps;
+        const int tap = u / (coutPad * 2 * ksteps);
+        f16x8 qh, ql;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const int ci = 16 * s + 8 * hh + e;
+            float v = 0.0f;
+            if (co < Cout && ci < Cin)
+                v = tr ? w[((size_t)ci * Ci + co) * 9 + (8 - tap)] : w[((size_t)co * Ci + ci) * 9 + tap];
+            _Float16 a, b;
+            split16(v * scale, a, b);
+            qh[e] = a; ql[e] = b;
+        }
+        const size_t base = 1 + (size_t)(((tap * ksteps + s) * 2 + 0) * 2 + hh) * coutPad + co;
+        wq[base] = __builtin_bit_cast(u32x4, qh);
+        wq[base + (size_t)2 * coutPad] = __builtin_bit_cast(u32x4, ql);
+    }
+}
+
 } // namespace
 
 static unsigned long long* g_split_stamps = nullptr;
@@ -1263,6 +1344,32 @@ int isrConv3x3ForwardSplit(const float* x, const void* wq, const float* bias, co
         if (e0 || e1) hipExtLaunchKernelGGL((conv3x3_split_kernel<false>), grid, block, S_LDS_BYTES, s, e0, e1, 0, p);
         else hipLaunchKernelGGL((conv3x3_split_kernel<false>), grid, block, S_LDS_BYTES, s, p);
     }
+    return hipGetLastError() == hipSuccess ? 0 : -2;
+}
+
+int isrConvSplitPrepareManyMax(void) { return PM_MAX; }
+
+int isrConvSplitPrepareMany(int n, const float* const* w, void* const* wqForward, void* const* wqBackward, const int* cout, const int* cin, void* stream)
+{
+    if (n <= 0 || n > PM_MAX || !w || !cout || !cin || (!wqForward && !wqBackward)) return -1;
+    PrepManyParams p;
+    int most = 0;
+    for (int l = 0; l < PM_MAX; ++l) {
+        const bool on = l < n;
+        p.w[l] = on ? w[l] : nullptr;
+        p.fwd[l] = on && wqForward ? (u32x4*)wqForward[l] : nullptr;
+        p.bwd[l] = on && wqBackward ? (u32x4*)wqBackward[l] : nullptr;
+        p.cout[l] = on ? cout[l] : 0; p.cin[l] = on ? cin[l] : 0;
+        if (on) {
+            if (!w[l] || cout[l] <= 0 || cin[l] <= 0 || (!p.fwd[l] && !p.bwd[l])) return -1;
+            const int a = 9 * ((cin[l] + 15) / 16) * 2 * (((cout[l] + 31) / 32) * 32);
+            const int b = 9 * ((cout[l] + 15) / 16) * 2 * (((cin[l] + 31) / 32) * 32);
+            most = a > most ? a : most; most = b > most ? b : most;
+        }
+    }
+    p.n = n;
+    hipLaunchKernelGGL(split_scale_many_kernel, dim3(n), dim3(1024), 0, (hipStream_t)stream, p);
+    hipLaunchKernelGGL(prepare_weights_split_many_kernel, dim3((most + 255) / 256, 2 * n), dim3(256), 0, (hipStream_t)stream, p);
     return hipGetLastError() == hipSuccess ? 0 : -2;
 }
 

@@ -87,6 +87,8 @@ def _sr():
         lib.isrConv3x3ForwardF16.restype = ci
         lib.isrConvSplitWeightBytes.argtypes = [ci, ci]; lib.isrConvSplitWeightBytes.restype = ll
         lib.isrConvSplitPrepare.argtypes = [vp, vp, ci, ci, vp]; lib.isrConvSplitPrepare.restype = ci
+        lib.isrConvSplitPrepareManyMax.argtypes = []; lib.isrConvSplitPrepareManyMax.restype = ci
+        lib.isrConvSplitPrepareMany.argtypes = [ci, vp, vp, vp, vp, vp, vp]; lib.isrConvSplitPrepareMany.restype = ci
         lib.isrConv3x3ForwardSplit.argtypes = lib.isrConv3x3ForwardF16.argtypes; lib.isrConv3x3ForwardSplit.restype = ci
         lib.isrProfileEnable.argtypes = [ci]; lib.isrProfileEnable.restype = ci
         lib.isrProfileCount.argtypes = []; lib.isrProfileCount.restype = ci
@@ -358,6 +360,37 @@ def _prepare_split(weight, transpose_flip=False):
             del _split_cache[k]
     _split_cache[key] = (weakref.ref(weight), weight._version, weight.data_ptr(), wq)
     return wq
+
+
+def _split_cached(weight, transpose_flip):
+    hit = _split_cache.get((id(weight), bool(transpose_flip)))
+    return hit is not None and hit[0]() is weight and hit[1] == weight._version and hit[2] == weight.data_ptr()
+
+
+def prepare_split_many(weights):
+    """Bring the cached split-kernel images (forward AND data gradient) of all given [Cout, Cin, 3, 3] weights up to date in
+    two launches (``isrConvSplitPrepareMany``).  A training step changes every weight, and preparing them one by one costs two
+    launches per image plus a flip and a copy for each data-gradient twin -- ~140 small launches per step for EnhanceNet."""
+    lib = _sr()
+    stale = [w for w in weights if w.is_cuda and w.dtype == torch.float32 and w.dim() == 4 and tuple(w.shape[2:]) == (3, 3)
+             and w.is_contiguous() and not (_split_cached(w, False) and _split_cached(w, True))]
+    most = lib.isrConvSplitPrepareManyMax()
+    for k in range(0, len(stale), most):
+        part = stale[k:k + most]
+        n = len(part)
+        fwd = [torch.empty(lib.isrConvSplitWeightBytes(w.shape[1], w.shape[0]), dtype=torch.uint8, device=w.device) for w in part]
+        bwd = [torch.empty(lib.isrConvSplitWeightBytes(w.shape[0], w.shape[1]), dtype=torch.uint8, device=w.device) for w in part]
+        pw = (ctypes.c_void_p * n)(*[w.data_ptr() for w in part])
+        pf = (ctypes.c_void_p * n)(*[t.data_ptr() for t in fwd])
+        pb = (ctypes.c_void_p * n)(*[t.data_ptr() for t in bwd])
+        co = (ctypes.c_int * n)(*[w.shape[0] for w in part])
+        ci = (ctypes.c_int * n)(*[w.shape[1] for w in part])
+        rc = lib.isrConvSplitPrepareMany(n, pw, pf, pb, co, ci, _stream())
+        if rc != 0:
+            raise RuntimeError("isrConvSplitPrepareMany failed (%d)" % rc)
+        for w, f, b in zip(part, fwd, bwd):
+            _split_cache[(id(w), False)] = (weakref.ref(w), w._version, w.data_ptr(), f)
+            _split_cache[(id(w), True)] = (weakref.ref(w), w._version, w.data_ptr(), b)
 
 
 def _split_fits(x, cout, upsample2x):

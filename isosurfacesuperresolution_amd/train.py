@@ -47,6 +47,10 @@ def clip_loss(model, criterion, input, flow, target, initial_image="zero", upsca
     The reference reads every frame's loss back with ``.item()`` (mainVideoUnshaded.py:454); here the sum is accumulated
     on the device and read back ONCE after the last frame, so the whole clip is enqueued without a stall."""
     B, T, Cout, Hh, Wh = target.shape
+    if ops.TRAIN_SPLIT and not ops.TRAIN_BF16 and target.is_cuda and torch.is_grad_enabled():
+        # every weight changed in the last optimizer step: refresh all split-kernel weight images in two launches
+        ops.prepare_split_many([m.weight for m in model.modules()
+                                if isinstance(m, torch.nn.Conv2d) and m.kernel_size == (3, 3) and m.out_channels > 8 and m.in_channels > 8])
     prediction = None
     loss = 0
     loss_sum = None

@@ -554,3 +554,23 @@ def test_residual_reconstruction_kernel_matches_interpolate_add_cat(shape):
     for a, b, tol in zip(res["ref"], res["hip"], (1e-6, 0.0, 2e-5)):
         assert (a - b).abs().max().item() <= tol
     assert res["hip"][2][:, k:].abs().max().item() == 0.0 if k < cin else True
+
+
+def test_batched_weight_preparation_equals_the_per_layer_one():
+    """isrConvSplitPrepareMany (all layers, forward + data-gradient images, two launches) must write the very bytes that
+    isrConvSplitPrepare writes layer by layer (the data-gradient image there from a flipped / transposed copy)."""
+    from isosurfacesuperresolution_amd import ops
+    g = torch.Generator().manual_seed(9)
+    shapes = [(64, 64), (64, 101), (32, 40), (64, 64), (16, 9)]
+    ws = [((torch.rand(co, ci, 3, 3, generator=g) - 0.5) * (10.0 ** (k - 2))).cuda() for k, (co, ci) in enumerate(shapes)]
+    ref = [(ops._prepare_split(w, False).clone(), ops._prepare_split(w, True).clone()) for w in ws]
+    ops._split_cache.clear()
+    ops.prepare_split_many(ws)
+    for w, (f, b) in zip(ws, ref):
+        assert ops._split_cached(w, False) and ops._split_cached(w, True)
+        assert torch.equal(ops._prepare_split(w, False), f) and torch.equal(ops._prepare_split(w, True), b)
+    # a weight that changes in place is stale again
+    ws[1].add_(0.25)
+    assert not ops._split_cached(ws[1], False)
+    ops.prepare_split_many(ws)
+    assert ops._split_cached(ws[1], False) and not torch.equal(ops._prepare_split(ws[1], False), ref[1][0])
