@@ -53,6 +53,7 @@ def parse(argv=None):
     ap.add_argument("--raymarch-variant", type=int, default=0)
     ap.add_argument("--side-variant", type=int, default=-1, help="kernel variant of the render that runs under the network (diagnostics)")
     ap.add_argument("--no-fast-mode", action="store_true", help="skip the separately reported fp16 fast-mode leg")
+    ap.add_argument("--no-exact-leg", action="store_true", help="skip the separately reported IEEE-fp32 (exact fmaf-chain kernels) leg")
     ap.add_argument("--exact", action="store_true", help="convolutions on the exact k-ordered fp32 fmaf-chain kernels (fp32 MFMA) instead "
                     "of the split-operand kernels (three fp16 MFMAs per product, fp32-equivalent accuracy)")
     ap.add_argument("--raymarch-large", default="", help="extra leg: the ray-march kernel alone on a volume that exceeds the caches, "
@@ -127,6 +128,13 @@ class Job:
         ones = torch.ones(1, dtype=torch.float32, device=self.coll_device)
         dist.all_reduce(ones)
         return int(ones.item())
+
+    def rank_keys(self):
+        """{"backend", "ranks_joined", "rccl_ranks"} of the JSON line: ``rccl_ranks`` says how many ranks RCCL joined and
+        is null whenever the collectives went through anything else (a gloo rehearsal must not read as an RCCL run)."""
+        n = self.joined_ranks()
+        name = None if self.world == 1 else ("rccl" if self.backend == "nccl" else self.backend)
+        return {"backend": name, "ranks_joined": n, "rccl_ranks": n if self.backend == "nccl" else None}
 
     def close(self):
         import torch.distributed as dist
@@ -211,7 +219,7 @@ def run_infer(args, job):
     ops.profile_enable(False)
     renderer.profile_enable(False)
     elapsed = job.max_over_ranks(elapsed)
-    rccl_ranks = job.joined_ranks()
+    rank_keys = job.rank_keys()
 
     per = {}
     for name, flops, ms in records:
@@ -273,7 +281,7 @@ def run_infer(args, job):
                                                                        if pipe.side_variant == 2 else "")) if overlap else "off",
             "conv_kernels": "exact fp32 fmaf chain (v_mfma_f32_32x32x2_f32)" if args.exact else
                             "split-operand: 3 x v_mfma_f32_32x32x16_f16 per product, fp32 accumulation (bench.py --exact = fp32 MFMA kernels)"},
-        "rccl_ranks": rccl_ranks,
+        **rank_keys,
         "roofline": {"kernel": dom_name, "bound": "mfma", "achieved": achieved, "peak": peak,
                      "unit": "TFLOP/s", "frac": achieved / peak, "traffic": traffic,
                      "peak_source": ("dense fp16 MFMA %.0f TFLOP/s / 3 matrix products per algorithmic multiply-accumulate" % MFMA_F16_PEAK_TFLOPS)
@@ -288,6 +296,8 @@ def run_infer(args, job):
                      "ms_per_frame": rm_time * 1e3, "alone_ms_per_frame": rm_alone * 1e3},
     }
 
+    if rank == 0 and world == 1 and not args.exact and not args.no_exact_leg:
+        result["exact_f32"] = exact_leg(pipe, origins, Wm, K, overlap, sync)
     if rank == 0 and world == 1 and not args.no_fast_mode:
         result["f16_fast_mode"] = fast_mode_leg(pipe, origins, Wm, K, overlap, sync)
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
@@ -330,12 +340,13 @@ def run_train(args, job):
     optim, _ = train.make_optimizer(net, capturable=(dev == "cuda"))
     trainer = train.DataParallelTrainer(net, crit, optim)
     batch = _clip_batch(torch, per, T, crop, 1000 + rank, dev)
+    from isosurfacesuperresolution_amd import ops
+    # which kernel family every convolution of ONE step goes to (algorithmic flops; shapes decide, so one eager step tells)
+    ops.FLOP_TALLY = {}
+    trainer.step(batch, initial_image="zero")
+    tally, ops.FLOP_TALLY = ops.FLOP_TALLY, None
     graphed = dev == "cuda" and (world == 1 or job.backend == "nccl")     # gloo collectives cannot be captured
-    if graphed:
-        step_fn = trainer.graphed(batch, initial_image="zero")
-        step = lambda: step_fn(batch)
-    else:
-        step = lambda: trainer.step(batch, initial_image="zero")
+    step, step_kind = make_train_step(trainer, batch, graphed, sync=torch.cuda.synchronize if dev == "cuda" else (lambda: None))
     K, Wm = args.steps, args.warmup
     loss = None
     for _ in range(Wm):
@@ -362,20 +373,35 @@ def run_train(args, job):
                      "buckets": 1, "backend": "RCCL" if job.backend == "nccl" else job.backend}
     flops = TRAIN_FLOPS_PER_SAMPLE_FRAME * (crop / 32.0) ** 2 * B * T
     achieved = flops / (elapsed / K) / 1e12
+    # Roofline per kernel family, weighted by the flops each family carries: the time the step's convolutions would take
+    # at each family's own ceiling is sum(flops_f / peak_f); the step's ceiling is total / that time (a harmonic mean).
+    peaks = {"split": MFMA_F16_PEAK_TFLOPS / 3.0, "exact": MFMA_F32_PEAK_TFLOPS, "bf16": MFMA_F16_PEAK_TFLOPS}
+    tally_total = sum(tally.values()) or 1.0
+    shares = {k: v / tally_total for k, v in tally.items()}
+    peak = 1.0 / sum(share / peaks[k] for k, share in shares.items()) if shares else MFMA_F32_PEAK_TFLOPS
+    dtype = "f32" if not shares.get("split") else (
+        "f32 (fp32 tensors and accumulation; %.0f %% of the step's conv flops as three fp16 MFMAs per product on split operands, error vs "
+        "fp64 = the fp32 kernels'; the rest on fp32 MFMA)" % (100 * shares["split"]))
     result = {
         "metric": "training clips/sec (mainVideoUnshaded.py step, BASELINE config #3), data-parallel over the GPUs of one node",
         "value": B * K / elapsed, "unit": "clips/s", "n_gpus": world, "steps": K, "warmup": Wm,
         "ms_per_step": elapsed / K * 1e3, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
-        "dtype": "f32", "data": "synthetic (random clips of the dataset's shapes, seeded random-init EnhanceNet)",
+        "dtype": dtype, "data": "synthetic (random clips of the dataset's shapes, seeded random-init EnhanceNet)",
         "config": {"workload": "EnhanceNet training step: global batch %d clips x %d frames, %dx%d -> %dx%d crops, "
                                "losses l1:mask:1,l1:ao:1,l1:normal:10,l1:depth:10,temp-l2:color:0.1, Adam 1e-4" % (B, T, crop, crop, 4 * crop, 4 * crop),
                    "clips_per_rank": per, "parallelism": "dp%d, one flat %.2f MB gradient all-reduce per step" % (world, trainer.numel * 4 / 1e6),
-                   "step": "one HIP graph (forward x T, backward through time, deferred weight gradients, all-reduce, Adam)" if graphed else "eager"},
-        "rccl_ranks": job.joined_ranks(), "allreduce": allreduce, "loss": loss,
-        "roofline": {"kernel": "conv forward + data gradient + weight gradient of the step (layers with many tiles: split-operand fp16 MFMA "
-                               "kernels at fp32-equivalent accuracy; 32^2-crop layers: exact fp32 MFMA kernels); peak = fp32 MFMA", "bound": "mfma",
-                     "achieved": achieved, "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": achieved / MFMA_F32_PEAK_TFLOPS,
-                     "traffic": None, "flops_per_step": flops},
+                   "step": step_kind},
+        **job.rank_keys(), "allreduce": allreduce, "loss": loss,
+        "roofline": {"kernel": "all convolutions of the step (forward + data gradient + weight gradient), whole-step time", "bound": "mfma",
+                     "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak,
+                     "traffic": None, "flops_per_step": flops,
+                     "flop_share_by_kernel_family": shares,
+                     "peak_source": "flop-weighted over the kernel families of one step (ops.FLOP_TALLY): split-operand kernels against dense fp16 "
+                                    "MFMA %.0f / 3 products, exact kernels against fp32 MFMA %.1f TFLOP/s; peak = 1 / sum(share / family peak)"
+                                    % (MFMA_F16_PEAK_TFLOPS, MFMA_F32_PEAK_TFLOPS),
+                     "matrix_tflops_executed": achieved * sum(shares.get(k, 0.0) * (3.0 if k == "split" else 1.0) for k in shares),
+                     "note": "`achieved` divides the step's algorithmic conv flops by the WHOLE step (loss, warp, Adam, all-reduce "
+                             "included), so it understates the kernels; profiles/r03_train_kernel_stats.csv has the per-kernel times"},
         "cpu_baseline": None,
     }
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
@@ -396,6 +422,23 @@ def run_train(args, job):
         result["cpu_baseline"] = {"value": 2 / dt, "unit": "clips/s", "cores": cores, "kind": "port",
                                   "sample": "%d steps of 2 clips x %d frames on CPU PyTorch (%d threads), %.2f s per step" % (n, T, cores, dt)}
     return result
+
+
+def make_train_step(trainer, batch, want_graph, sync=lambda: None):
+    """-> (step callable, description).  ``want_graph``: capture the whole step (with its all-reduce) in ONE HIP graph.  A
+    failed capture (e.g. an RCCL build that cannot capture its all-reduce) must not end the run, and nothing may re-execute
+    a process that has touched the GPU: fall back to the eager step IN THIS PROCESS and say so in the line."""
+    eager = lambda: trainer.step(batch, initial_image="zero")
+    if not want_graph:
+        return eager, "eager"
+    try:
+        step_fn = trainer.graphed(batch, initial_image="zero")
+        return (lambda: step_fn(batch)), "one HIP graph (forward x T, backward through time, deferred weight gradients, all-reduce, Adam)"
+    except Exception as exc:      # noqa: BLE001 -- whatever the capture raised
+        sync()
+        trainer.zero_grad()
+        msg = str(exc).splitlines()[0][:160] if str(exc) else ""
+        return eager, "eager (capture failed: %s: %s)" % (type(exc).__name__, msg)
 
 
 TILE_SPLITS = {1: (1, 1, 1), 2: (2, 1, 1), 4: (2, 2, 1), 8: (2, 2, 2)}
@@ -488,7 +531,18 @@ def run_tiled(args, job, make_local_renderer=None):
 
     for k in range(Wm):
         frame(k - Wm, False)
+    if world > 1:
+        # a silently no-op all-gather must not pass: every rank's own hit count travels through a DIFFERENT collective
+        # (an all-reduce of a one-hot vector) and must equal the hit count of the slice the all-gather delivered for it
+        own = torch.zeros(world, dtype=torch.float64, device=job.coll_device)
+        own[rank] = float((mine[..., 3] == 1).sum().item())
+        dist.all_reduce(own)
+        got = [float((gathered[r][..., 3] == 1).sum().item()) for r in range(world)]
+        assert got == own.tolist(), "all-gather of the G-buffers delivered %s hit pixels per rank, the ranks rendered %s" % (got, own.tolist())
     sr.reset()
+    from isosurfacesuperresolution_amd import ops
+    if dev == "cuda":
+        ops.profile_enable(True)
     job.sync()
     t0 = time.perf_counter()
     for k in range(K):
@@ -497,6 +551,37 @@ def run_tiled(args, job, make_local_renderer=None):
     elapsed = job.max_over_ranks(time.perf_counter() - t0)
     ms = {name: job.max_over_ranks(v) / K * 1e3 for name, v in phases.items()}
     hits = int((comp[..., 3] == 1).sum().item())
+    # roofline of the dominant kernel: the strip's convolutions (same formula as the default mode)
+    y0, y1 = parallel_sr.strip_bounds(low_h, world, rank)
+    rows = min(low_h, y1 + sr.halo) - max(0, y0 - sr.halo)
+    strip_flops = 564.5e9 * (low_w * rows) / (480.0 * 270.0)             # SURVEY.md App. B, scaled to this rank's rows (halo included)
+    if dev == "cuda":
+        torch.cuda.synchronize()
+        per = {}
+        for name, flops, kms in ops.profile_records():
+            d = per.setdefault(name, [0.0, 0.0, 0])
+            d[0] += flops; d[1] += kms * 1e-3; d[2] += 1
+        ops.profile_enable(False)
+        dom_name, (dom_flops, dom_time, dom_launches) = max(per.items(), key=lambda kv: kv[1][1])
+        split = dom_name.startswith("conv3x3_split")
+        peak = MFMA_F16_PEAK_TFLOPS / 3.0 if split else MFMA_F32_PEAK_TFLOPS
+        achieved = dom_flops / dom_time / 1e12
+        roofline = {"kernel": dom_name, "bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak,
+                    "traffic": None, "avg_launch_ms": dom_time / dom_launches * 1e3, "launches_per_frame": dom_launches / K,
+                    "flops_per_launch": dom_flops / dom_launches,
+                    "peak_source": ("dense fp16 MFMA %.0f TFLOP/s / 3 matrix products per algorithmic multiply-accumulate" % MFMA_F16_PEAK_TFLOPS)
+                                   if split else "fp32 MFMA",
+                    "kernels": {n: {"tflops": v[0] / v[1] / 1e12, "ms_per_frame": v[1] / K * 1e3, "launches_per_frame": v[2] / K}
+                                for n, v in per.items()}}
+    else:
+        t_sr = phases["sr_strip_and_allgather"] / K
+        achieved = strip_flops / max(t_sr, 1e-9) / 1e12
+        roofline = {"kernel": "CPU rehearsal (BENCH_DEVICE=cpu): no HIP kernel ran; the strip's convolutions through PyTorch CPU ops",
+                    "bound": "mfma", "achieved": achieved, "peak": MFMA_F16_PEAK_TFLOPS / 3.0, "unit": "TFLOP/s",
+                    "frac": achieved / (MFMA_F16_PEAK_TFLOPS / 3.0), "traffic": None, "flops_per_strip": strip_flops}
+    cpu_baseline = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        cpu_baseline = tiled_cpu_leg(tile, low_w, low_h, net, dev)
     return {
         "metric": "frames/sec (object-space tiled %d^3 render + all-gather composite + 4x SR in screen strips, BASELINE config #5)" % n,
         "value": K / elapsed, "unit": "frames/s", "n_gpus": world, "steps": K, "warmup": Wm,
@@ -506,12 +591,83 @@ def run_tiled(args, job, make_local_renderer=None):
                        n, "x".join(str(v) for v in TILE_SPLITS[world]), low_w, low_h, 4 * low_w, 4 * low_h),
                    "sharding": "one tile per rank; all-gather of %.1f MB G-buffers + nearest-hit composite; SR in %d strips with a 24-px halo + all-gather"
                                % (low_w * low_h * 48 / 1e6, world)},
-        "rccl_ranks": job.joined_ranks(),
+        **job.rank_keys(),
         "phases_ms_max_over_ranks": ms,
         "tile": {"generate_s": t_gen, "voxels": [int(v) for v in tile["data"].shape[::-1]]},
         "hit_pixels": hits, "rgb_mean": float(rgb.mean().item()),
-        "roofline": None, "cpu_baseline": None,
+        "roofline": roofline, "cpu_baseline": cpu_baseline,
     }
+
+
+def tiled_cpu_leg(tile, low_w, low_h, net, dev):
+    """CPU baseline of the tiled mode on a bounded sample: ONE frame -- the oracle ray-marches the (single) tile at the low
+    resolution on the host cores, the same network super-resolves the whole frame on CPU PyTorch."""
+    import torch
+    from isosurfacesuperresolution_amd import models, volumes as V, utils
+    from isosurfacesuperresolution_amd.inference import LoadedModel
+    from isosurfacesuperresolution_amd.pipeline import default_shading
+    from oracle import iso_oracle
+    cores = host_cores()
+    torch.set_num_threads(cores)
+    t0 = time.perf_counter()
+    ov = iso_oracle.OracleVolume(tile["data"], tile=tile)
+    t_load = time.perf_counter() - t0
+    q, last = V.quantize3(V.orbit_camera(0)), V.quantize3(V.orbit_camera(-1))
+    p = iso_oracle.make_params(low_w, low_h, origin=q, fov=30.0, isovalue=0.34, last_origin=last)
+    t0 = time.perf_counter()
+    ref, _ = iso_oracle.render(ov, p, threads=cores, with_stats=False)
+    t_render = time.perf_counter() - t0
+    opt = argparse.Namespace(upsample='bilinear', reconType='residual', useBN=False, numResidualLayers=10)
+    with contextlib.redirect_stdout(sys.stderr):
+        cpu_net = models.createNetwork('EnhanceNet', 4, 101, [0, 1, 2, 3, 4], 6, opt)
+    cpu_net.load_state_dict({k: v.cpu() for k, v in net.state_dict().items()})
+    cpu_model = LoadedModel.from_model(cpu_net.eval(), "cpu", parameters={"initialImage": "zero"})
+    low = torch.from_numpy(ref).permute(2, 0, 1).unsqueeze(0)
+    t0 = time.perf_counter()
+    raw = cpu_model.inference(low, None)
+    raw = torch.cat([raw[:, 0:1].clamp(-1, 1), utils.ScreenSpaceShading.normalize(raw[:, 1:4], dim=1), raw[:, 4:].clamp(0, 1)], dim=1)
+    default_shading("cpu", 30.0)(raw)
+    t_sr = time.perf_counter() - t0
+    return {"value": 1.0 / (t_render + t_sr), "unit": "frames/s", "cores": cores, "kind": "port",
+            "sample": "1 frame: oracle ray-march of the tile %dx%d (%.3f s, OpenMP %d threads; brick build %.1f s not counted) + PyTorch CPU "
+                      "EnhanceNet and shading of the whole %dx%d frame (%.3f s, %d threads)" % (low_w, low_h, t_render, cores, t_load,
+                                                                                              4 * low_w, 4 * low_h, t_sr, cores)}
+
+
+def exact_leg(pipe, origins, Wm, K, overlap, sync):
+    """The same frames with every convolution on the exact k-ordered fp32 fmaf-chain kernels (v_mfma_f32_32x32x2_f32;
+    ``ops.SPLIT_F16 = False``, what ``--exact`` times as the headline), OUTSIDE the timed region of ``value``: the
+    IEEE-fp32 number next to the split-operand one, plus how far the two paths' frames are apart."""
+    import torch
+    from isosurfacesuperresolution_amd import ops
+    n = min(K, 10)
+
+    def run(collect):
+        pipe.reset()
+        for k in range(min(Wm, 3)):
+            pipe.frame(origins[k], origins[k + 1] if overlap else None)
+        pipe.reset()
+        sync()
+        t0 = time.perf_counter()
+        first = None
+        for k in range(n):
+            _, raw = pipe.frame(origins[Wm + k], origins[Wm + k + 1] if overlap and k + 1 < n else None)
+            if collect and k == 0:
+                first = raw.clone()
+        sync()
+        return time.perf_counter() - t0, first
+
+    _, split_first = run(True)
+    ops.SPLIT_F16 = False
+    try:
+        _, exact_first = run(True)
+        elapsed, _ = run(False)
+    finally:
+        ops.SPLIT_F16 = True
+    return {"value": n / elapsed, "unit": "frames/s", "ms_per_step": elapsed / n * 1e3, "frames": n,
+            "dtype": "f32 (exact k-ordered fmaf chain on v_mfma_f32_32x32x2_f32)",
+            "max_abs_diff_vs_split_first_frame": float((split_first - exact_first).abs().max().item()),
+            "note": "separate from `value`: the same frames with ops.SPLIT_F16 = False (bench.py --exact makes it the headline)"}
 
 
 def fast_mode_leg(pipe, origins, Wm, K, overlap, sync):

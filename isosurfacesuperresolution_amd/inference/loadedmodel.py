@@ -12,45 +12,83 @@ for the unshaded networks of the hot path.  Differences, all additive or forced 
   (``mainVideoUnshaded.py:801``), so they cannot be read with ``weights_only=True``.  They are read through a
   RESTRICTED unpickler instead of a plain ``torch.load(weights_only=False)``: ``models.*`` / ``utils.*`` resolve to
   this package's modules (whatever top-level ``models`` the host process may have), tensors / storages / containers /
-  optimizer and scheduler state resolve to torch and the standard library, and anything else -- the arbitrary
-  callables a malicious pickle would name -- is refused.  A checkpoint is still code-adjacent data: load files you trust.
+  optimizer and scheduler state resolve to torch and the standard library, and anything else is refused: names are matched as EXACT (module, name) pairs (no attribute walks), functions
+  come from a fixed list, everything else must be a class defined in the module the pickle names.  A checkpoint is still code-adjacent data: load files you trust.
 """
+import builtins
 import importlib
 import os.path
 import pickle
+import re
 
 import torch
 
 
 class _CheckpointPickle:
-    """``pickle_module`` for ``torch.load``: an allow-list ``find_class``."""
+    """``pickle_module`` for ``torch.load``: ``find_class`` resolves EXACT (module, name) pairs only.
+
+    * functions: the tensor / parameter rebuild helpers torch's own serializer emits and numpy's array reconstructors
+      (``_FUNCTIONS``), nothing else -- in particular no dotted names (``torch`` + ``os.getcwd`` style attribute walks),
+      and nothing that is merely *reachable* from an allowed package;
+    * classes: storages / sizes / dtypes, ``collections`` containers, ``argparse.Namespace``, and CLASSES (never
+      functions) defined in ``torch.nn.modules.*``, ``torch.optim.*`` and this package's ``models`` / ``utils`` /
+      ``losses`` (the reference pickles whole module, optimizer and scheduler objects, ``mainVideoUnshaded.py:799-811``).
+      The resolved object must be a type whose ``__module__`` is the module the pickle named, so a re-export such as
+      ``torch.nn.modules.x.os`` cannot be smuggled in.
+    """
     __name__ = "isosurfacesuperresolution_amd.checkpoint_pickle"
     _ALIASES = {"models": "isosurfacesuperresolution_amd.models", "utils": "isosurfacesuperresolution_amd.utils",
                 "losses": "isosurfacesuperresolution_amd.losses"}
-    _ALLOWED_ROOTS = ("torch", "collections", "argparse", "numpy", "isosurfacesuperresolution_amd")
-    _ALLOWED_BUILTINS = {"set", "frozenset", "dict", "list", "tuple", "slice", "range", "complex", "int", "float", "bool",
-                         "str", "bytes", "bytearray", "object", "getattr"}
+    _BUILTINS = {"set", "frozenset", "dict", "list", "tuple", "slice", "range", "complex", "int", "float", "bool",
+                 "str", "bytes", "bytearray", "object"}
+    _FUNCTIONS = {
+        ("torch._utils", "_rebuild_tensor"), ("torch._utils", "_rebuild_tensor_v2"), ("torch._utils", "_rebuild_parameter"),
+        ("torch._utils", "_rebuild_parameter_with_state"), ("torch._tensor", "_rebuild_from_type_v2"),
+        ("numpy.core.multiarray", "_reconstruct"), ("numpy._core.multiarray", "_reconstruct"),
+        ("numpy.core.multiarray", "scalar"), ("numpy._core.multiarray", "scalar"),
+    }
+    _CLASSES = {
+        ("collections", "OrderedDict"), ("collections", "defaultdict"), ("argparse", "Namespace"),
+        ("torch", "Size"), ("torch", "device"), ("torch", "Tensor"), ("torch.nn.parameter", "Parameter"),
+        ("numpy", "dtype"), ("numpy", "ndarray"),
+    }
+    _STORAGE = re.compile(r"^(Float|Double|Half|BFloat16|Long|Int|Short|Char|Byte|Bool)Storage$")
+    # packages whose CLASSES (checked below) may be named freely
+    _CLASS_PACKAGES = ("torch.nn.modules.", "torch.optim.", "isosurfacesuperresolution_amd.models", "isosurfacesuperresolution_amd.utils",
+                       "isosurfacesuperresolution_amd.losses")
 
     class Unpickler(pickle.Unpickler):
         def find_class(self, module, name):
             cls = _CheckpointPickle
+
+            def refuse(why):
+                raise pickle.UnpicklingError("checkpoint refers to %s.%s: %s" % (module, name, why))
+            if "." in name or not name.isidentifier():
+                refuse("dotted or malformed names are never resolved")
             root = module.split(".")[0]
             if root in cls._ALIASES:
                 module = cls._ALIASES[root] + module[len(root):]
-            elif root in ("builtins", "__builtin__"):
-                if name not in cls._ALLOWED_BUILTINS or name == "getattr":
-                    raise pickle.UnpicklingError("checkpoint refers to builtins.%s: refused" % name)
-                return super().find_class(module, name)
-            elif root not in cls._ALLOWED_ROOTS:
-                raise pickle.UnpicklingError("checkpoint refers to %s.%s: only torch / numpy / this package's "
-                                             "models, utils and losses are loaded" % (module, name))
-            if root == "torch" and (name in ("load", "save") or module.startswith(("torch.utils.cpp_extension", "torch.hub",
-                                                                                      "torch.distributed", "torch.multiprocessing"))):
-                raise pickle.UnpicklingError("checkpoint refers to %s.%s: refused" % (module, name))
-            mod = importlib.import_module(module)
-            obj = mod
-            for part in name.split("."):
-                obj = getattr(obj, part)
+            if module in ("builtins", "__builtin__"):
+                if name not in cls._BUILTINS:
+                    refuse("refused")
+                return getattr(builtins, name)
+            key = (module, name)
+            if key in cls._FUNCTIONS:
+                return getattr(importlib.import_module(module), name)
+            plain = key in cls._CLASSES or (module == "torch" and cls._STORAGE.match(name)) \
+                or (module == "torch" and name in ("float32", "float64", "float16", "bfloat16", "int64", "int32", "uint8", "bool"))
+            packaged = (module + ".").startswith(cls._CLASS_PACKAGES) or module in cls._CLASS_PACKAGES
+            if not (plain or packaged):
+                refuse("only tensors, containers, torch.nn / torch.optim classes and this package's models, utils and losses are loaded")
+            obj = getattr(importlib.import_module(module), name, None)
+            if obj is None:
+                refuse("no such attribute")
+            if isinstance(obj, torch.dtype):
+                return obj
+            if not isinstance(obj, type):
+                refuse("not a class")
+            if packaged and obj.__module__ != module:
+                refuse("defined in %s, not in the module the checkpoint names" % obj.__module__)
             return obj
 
     load = staticmethod(pickle.load)

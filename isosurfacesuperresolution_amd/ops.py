@@ -107,7 +107,18 @@ def _ptr(t):
 
 # Inference re-uses the re-laid-out weights for as long as the very same tensor object is alive and
 # unmodified (a data_ptr alone is not an identity: the caching allocator recycles addresses).
+# ``weight._version`` does not see every change: a HIP-graph replay of a training step (train.GraphedTrainStep) runs the
+# captured optimizer kernels on the parameters' memory without touching the Python-side version counter.  Whoever changes
+# weights behind autograd's back therefore calls ``invalidate_weight_images()``; every cached image carries the epoch
+# it was made in and is rebuilt when the epoch has moved on.
 _wcache = {}
+_images_epoch = 0
+
+
+def invalidate_weight_images():
+    """Declare every cached kernel-layout weight image (exact, small-Cout, fp16 / bf16, split) stale."""
+    global _images_epoch
+    _images_epoch += 1
 
 
 def prepare_weights(weight, transpose_flip=False):
@@ -117,8 +128,8 @@ def prepare_weights(weight, transpose_flip=False):
     key = (id(weight), bool(transpose_flip))
     hit = _wcache.get(key)
     if hit is not None:
-        ref, version, ptr, wp = hit
-        if ref() is weight and version == weight._version and ptr == weight.data_ptr():
+        ref, version, ptr, wp, epoch = hit
+        if ref() is weight and version == weight._version and ptr == weight.data_ptr() and epoch == _images_epoch:
             return wp
     w = weight.detach().contiguous()
     if transpose_flip:
@@ -132,7 +143,7 @@ def prepare_weights(weight, transpose_flip=False):
     if len(_wcache) > 512:
         for k in [k for k, v in _wcache.items() if v[0]() is None]:
             del _wcache[k]
-    _wcache[key] = (weakref.ref(weight), weight._version, weight.data_ptr(), wp)
+    _wcache[key] = (weakref.ref(weight), weight._version, weight.data_ptr(), wp, _images_epoch)
     return wp
 
 
@@ -174,8 +185,8 @@ def _prepare_small(weight, bias):
     bptr = bias.data_ptr() if bias is not None else 0
     bver = bias._version if bias is not None else 0
     if hit is not None:
-        ref, ver, ptr, bp, bv, w8, b8 = hit
-        if ref() is weight and ver == weight._version and ptr == weight.data_ptr() and bp == bptr and bv == bver:
+        ref, ver, ptr, bp, bv, w8, b8, epoch = hit
+        if ref() is weight and ver == weight._version and ptr == weight.data_ptr() and bp == bptr and bv == bver and epoch == _images_epoch:
             return w8, b8
     cout, cin = weight.shape[0], weight.shape[1]
     w8 = torch.empty(lib.isrConvSmallWeightFloats(cin), dtype=torch.float32, device=weight.device)
@@ -186,7 +197,7 @@ def _prepare_small(weight, bias):
         raise RuntimeError("isrConvSmallPrepare failed (%d)" % rc)
     if len(_small_cache) > 64:
         _small_cache.clear()
-    _small_cache[key] = (weakref.ref(weight), weight._version, weight.data_ptr(), bptr, bver, w8, b8)
+    _small_cache[key] = (weakref.ref(weight), weight._version, weight.data_ptr(), bptr, bver, w8, b8, _images_epoch)
     return w8, b8
 
 
@@ -270,8 +281,8 @@ def _prepare_lp(weight, transpose_flip=False, bf16=False):
     key = (id(weight), bool(transpose_flip), bool(bf16))
     hit = _f16_cache.get(key)
     if hit is not None:
-        ref, version, ptr, wq = hit
-        if ref() is weight and version == weight._version and ptr == weight.data_ptr():
+        ref, version, ptr, wq, epoch = hit
+        if ref() is weight and version == weight._version and ptr == weight.data_ptr() and epoch == _images_epoch:
             return wq
     w = weight.detach()
     if transpose_flip:
@@ -285,7 +296,7 @@ def _prepare_lp(weight, transpose_flip=False, bf16=False):
     if len(_f16_cache) > 512:
         for k in [k for k, v in _f16_cache.items() if v[0]() is None]:
             del _f16_cache[k]
-    _f16_cache[key] = (weakref.ref(weight), weight._version, weight.data_ptr(), wq)
+    _f16_cache[key] = (weakref.ref(weight), weight._version, weight.data_ptr(), wq, _images_epoch)
     return wq
 
 
@@ -343,8 +354,8 @@ def _prepare_split(weight, transpose_flip=False):
     key = (id(weight), bool(transpose_flip))
     hit = _split_cache.get(key)
     if hit is not None:
-        ref, version, ptr, wq = hit
-        if ref() is weight and version == weight._version and ptr == weight.data_ptr():
+        ref, version, ptr, wq, epoch = hit
+        if ref() is weight and version == weight._version and ptr == weight.data_ptr() and epoch == _images_epoch:
             return wq
     w = weight.detach()
     if transpose_flip:
@@ -358,13 +369,13 @@ def _prepare_split(weight, transpose_flip=False):
     if len(_split_cache) > 512:
         for k in [k for k, v in _split_cache.items() if v[0]() is None]:
             del _split_cache[k]
-    _split_cache[key] = (weakref.ref(weight), weight._version, weight.data_ptr(), wq)
+    _split_cache[key] = (weakref.ref(weight), weight._version, weight.data_ptr(), wq, _images_epoch)
     return wq
 
 
 def _split_cached(weight, transpose_flip):
     hit = _split_cache.get((id(weight), bool(transpose_flip)))
-    return hit is not None and hit[0]() is weight and hit[1] == weight._version and hit[2] == weight.data_ptr()
+    return hit is not None and hit[0]() is weight and hit[1] == weight._version and hit[2] == weight.data_ptr() and hit[4] == _images_epoch
 
 
 def prepare_split_many(weights):
@@ -389,8 +400,8 @@ def prepare_split_many(weights):
         if rc != 0:
             raise RuntimeError("isrConvSplitPrepareMany failed (%d)" % rc)
         for w, f, b in zip(part, fwd, bwd):
-            _split_cache[(id(w), False)] = (weakref.ref(w), w._version, w.data_ptr(), f)
-            _split_cache[(id(w), True)] = (weakref.ref(w), w._version, w.data_ptr(), b)
+            _split_cache[(id(w), False)] = (weakref.ref(w), w._version, w.data_ptr(), f, _images_epoch)
+            _split_cache[(id(w), True)] = (weakref.ref(w), w._version, w.data_ptr(), b, _images_epoch)
 
 
 def _split_fits(x, cout, upsample2x):
@@ -459,7 +470,9 @@ def _train_conv(x, weight, transpose_flip, bias, residual, act):
     # the low-precision kernel is a streaming kernel with 8x32-pixel x 64-channel tiles: it pays from a few hundred
     # tiles on (the 128x128 layers of a crop batch); below that the fp32 kernels' finer decompositions are faster
     tiles = x.shape[0] * ((x.shape[2] + 7) // 8) * ((x.shape[3] + 31) // 32)
+    flops = 2.0 * 9 * cin * cout * x.shape[0] * x.shape[2] * x.shape[3]
     if TRAIN_BF16 and cout > 8 and cin > 8 and tiles >= 256:
+        _tally("bf16", flops)
         return _launch_lp(x, _prepare_lp(weight, transpose_flip, True), bias, residual, cout, act, 0.0, False, True, packed=True)
     # the split-operand kernel (fp32-equivalent accuracy, 2.3x the fp32 MFMA kernel) once a layer has enough 8x32-pixel
     # tiles to fill the persistent grid: the 64^2 / 128^2 post-block layers of a crop batch, 54 % of the step's flops
@@ -467,9 +480,21 @@ def _train_conv(x, weight, transpose_flip, bias, residual, act):
     tiles2 = x.shape[0] * ((x.shape[2] + 1) // 2) * ((x.shape[3] + 31) // 32)
     if TRAIN_SPLIT and cout > 8 and cin > 8 and (tiles >= TRAIN_SPLIT_MIN_TILES or tiles2 >= TRAIN_SPLIT_MIN_TILES2) \
             and x.shape[3] % 4 == 0 and _split_fits(x, cout, False):
+        _tally("split", flops)
         return _launch_split(x, _prepare_split(weight, transpose_flip), bias, residual, cout, act, 0.0, False, packed=True)
+    _tally("exact", flops)
     return _launch_forward(x, prepare_weights(weight, transpose_flip=transpose_flip), bias, residual, cin, cout, act, 0.0, False,
                            packed=True)
+
+
+# Optional tally of the algorithmic flops a step dispatches to each kernel family ("split": three fp16 MFMAs per product,
+# ceiling 2500 / 3 TFLOP/s; "exact": fp32 MFMA, ceiling 157.3): bench.py --mode train prices its roofline with it.
+FLOP_TALLY = None
+
+
+def _tally(family, flops):
+    if FLOP_TALLY is not None:
+        FLOP_TALLY[family] = FLOP_TALLY.get(family, 0.0) + float(flops)
 
 
 _workspace = {}
@@ -504,6 +529,8 @@ def _weight_grad(xs, gzs, weight, has_bias):
         # fifth of the matrix cycles it still beats the fp32 K-split kernel)
         fn = lib.isrConv3x3WeightGradSegmentsBf16 if (TRAIN_BF16 and big and cout > 8) else (
             lib.isrConv3x3WeightGradSegmentsSplit if (TRAIN_SPLIT and big) else lib.isrConv3x3WeightGradSegments)
+        _tally("bf16" if (TRAIN_BF16 and big and cout > 8) else ("split" if (TRAIN_SPLIT and big) else "exact"),
+               2.0 * 9 * cin * cout * n * len(part_x) * h * w)
         rc = fn(px, pg, len(part_x), _ptr(dw), _ptr(db), _ptr(ws), n, cin, h, w, cout, _stream())
         if rc != 0:
             raise RuntimeError("isrConv3x3WeightGradSegments failed (%d)" % rc)
@@ -620,8 +647,10 @@ class _Conv3x3Function(torch.autograd.Function):
         b = bias.contiguous() if bias is not None else None
         cout, cin = weight.shape[0], weight.shape[1]
         if cout <= 8 and cin * x.shape[2] * x.shape[3] * 4 < 2 ** 31:
+            _tally("exact", 2.0 * 9 * cin * cout * x.shape[0] * x.shape[2] * x.shape[3])
             y = _launch_small(x, weight, b, res, act, slope)      # the 64 -> 6 output layer: 4x4x1 MFMA blocks
         elif act == 'leaky':
+            _tally("exact", 2.0 * 9 * cin * cout * x.shape[0] * x.shape[2] * x.shape[3])
             y = _launch_forward(x, prepare_weights(weight), b, res, cin, cout, act, slope, False, packed=True)
         else:
             y = _train_conv(x, weight, False, b, res, act)

@@ -20,6 +20,10 @@ MI355X form: one process per GPU, the global batch split over ranks, identical i
 launches), averaged, then a local Adam step.  Loss terms are batch means, so averaged gradients
 equal the single-process gradients of the global batch.
 """
+import math
+import os
+import warnings
+
 import torch
 import torch.distributed as dist
 import torch.nn.functional as F
@@ -97,10 +101,30 @@ def clip_loss(model, criterion, input, flow, target, initial_image="zero", upsca
     return loss, loss_sum
 
 
-def make_optimizer(model, lr=1e-4, lr_step=500, lr_gamma=0.5, capturable=False):
-    opt = torch.optim.Adam(model.parameters(), lr=lr, capturable=capturable)
+def make_optimizer(model, lr=1e-4, lr_step=500, lr_gamma=0.5, capturable=False, tensor_lr=False):
+    """Adam + StepLR of mainVideoUnshaded.py:287-300.  ``tensor_lr``: the learning rate lives in a device tensor, so that
+    a scheduler step is seen by an optimizer step captured in a HIP graph (needs ``capturable``)."""
+    params = list(model.parameters())
+    if tensor_lr:
+        lr = torch.tensor(float(lr), dtype=torch.float32, device=params[0].device)
+    opt = torch.optim.Adam(params, lr=lr, capturable=capturable)
     sched = torch.optim.lr_scheduler.StepLR(opt, lr_step, lr_gamma)
     return opt, sched
+
+
+def step_scheduler(optimizer, scheduler):
+    """``scheduler.step()`` at the START of an epoch, as the reference does (mainVideoUnshaded.py:399; torch >= 1.1 warns
+    about the order, the schedule is the reference's).  A learning rate kept in a device tensor is updated IN PLACE:
+    a captured optimizer step reads that very tensor."""
+    before = [g['lr'] for g in optimizer.param_groups]
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        scheduler.step()
+    for g, old in zip(optimizer.param_groups, before):
+        if isinstance(old, torch.Tensor) and g['lr'] is not old:
+            old.fill_(float(g['lr']))
+            g['lr'] = old
+    return float(optimizer.param_groups[0]['lr'])
 
 
 def train_step(model, criterion, optimizer, batch, **kw):
@@ -119,11 +143,19 @@ class GraphedTrainStep:
     eager loop is bound by Python, not by the GPU.  Needs a GPU, fixed batch shapes, an optimizer created with
     ``capturable=True`` and (as everywhere in this package) no host read-back inside the step; the loss of each step is
     returned as a device tensor.  ``all_reduce`` (optional callable) runs between backward and the optimizer step --
-    ``DataParallelTrainer`` passes its flat-bucket RCCL all-reduce, which is captured with the rest."""
+    ``DataParallelTrainer`` passes its flat-bucket RCCL all-reduce, which is captured with the rest.  ``zero_grad``
+    (optional callable) replaces ``optimizer.zero_grad(set_to_none=True)`` -- the data-parallel trainer's gradients are
+    views of its flat bucket and must stay those tensors.
 
-    def __init__(self, model, criterion, optimizer, example_batch, all_reduce=None, warmup=3, **kw):
+    A replay changes the weights WITHOUT advancing ``Parameter._version`` (the captured optimizer kernels write the
+    parameters' memory directly), so every replay declares the cached kernel-layout weight images stale
+    (``ops.invalidate_weight_images``): inference or an eager step after a replay re-prepares them from the current
+    weights.  The graph itself is unaffected: it refreshes its own image buffers at the start of every replay."""
+
+    def __init__(self, model, criterion, optimizer, example_batch, all_reduce=None, zero_grad=None, warmup=3, **kw):
         self.model, self.criterion, self.optimizer, self.kw = model, criterion, optimizer, kw
         self.all_reduce = all_reduce
+        self.zero_grad = zero_grad if zero_grad is not None else (lambda: self.optimizer.zero_grad(set_to_none=True))
         self.static = tuple(torch.empty_like(t) for t in example_batch)
         for dst, src in zip(self.static, example_batch):
             dst.copy_(src)
@@ -135,13 +167,14 @@ class GraphedTrainStep:
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
         self.graph = torch.cuda.CUDAGraph()
-        self.optimizer.zero_grad(set_to_none=True)
+        self.zero_grad()
         with torch.cuda.graph(self.graph):
             self.loss = self._eager()
+        ops.invalidate_weight_images()
 
     def _eager(self):
         input, flow, target = self.static
-        self.optimizer.zero_grad(set_to_none=True)
+        self.zero_grad()
         loss, loss_sum = clip_loss(self.model, self.criterion, input, flow, target, **self.kw)
         backward(loss)
         if self.all_reduce is not None:
@@ -153,11 +186,18 @@ class GraphedTrainStep:
         for dst, src in zip(self.static, batch):
             dst.copy_(src, non_blocking=True)
         self.graph.replay()
+        ops.invalidate_weight_images()
         return self.loss
 
 
 class DataParallelTrainer:
-    """Data-parallel ``train_step``: one process per GPU, one flat gradient all-reduce per step."""
+    """Data-parallel ``train_step``: one process per GPU, one flat gradient all-reduce per step.
+
+    Every parameter's ``.grad`` IS a view of the flat bucket (set once here): backward accumulates straight into it
+    (autograd adds in place into an existing ``.grad``; the deferred weight-gradient pass does ``grad.add_``), so the
+    exchange is ONE ``all_reduce`` + ONE ``div_`` and zeroing the gradients ONE ``zero_`` -- no per-parameter copies
+    around a 42 us collective.  Nothing may replace ``param.grad`` afterwards: use ``trainer.zero_grad()``, never
+    ``optimizer.zero_grad()`` (whose default sets the gradients to None)."""
 
     def __init__(self, model, criterion, optimizer, process_group=None):
         self.model, self.criterion, self.optimizer = model, criterion, optimizer
@@ -167,9 +207,27 @@ class DataParallelTrainer:
         self.numel = sum(p.numel() for p in self.params)
         first = self.params[0]
         self.bucket = torch.zeros(self.numel, dtype=first.dtype, device=first.device)
+        off = 0
+        for p in self.params:
+            n = p.numel()
+            p.grad = self.bucket[off:off + n].view_as(p)
+            off += n
         if self.world > 1:
             for p in self.params:          # identical start on every rank
                 dist.broadcast(p.data, src=0, group=process_group)
+
+    def zero_grad(self):
+        self.bucket.zero_()
+
+    def _check_views(self):
+        """The gradients must still be the bucket's views (an ``optimizer.zero_grad()`` by the caller would have replaced them)."""
+        base = self.bucket.data_ptr()
+        off = 0
+        for p in self.params:
+            if p.grad is None or p.grad.data_ptr() != base + off * self.bucket.element_size():
+                raise RuntimeError("DataParallelTrainer: a parameter's .grad is no longer a view of the flat bucket "
+                                   "(use trainer.zero_grad(), not optimizer.zero_grad())")
+            off += p.numel()
 
     def shard(self, batch):
         """Rank's slice of a global clip batch (B must divide evenly)."""
@@ -182,32 +240,180 @@ class DataParallelTrainer:
         return tuple(t[rank * per:(rank + 1) * per] for t in batch)
 
     def _allreduce_gradients(self):
-        off = 0
-        for p in self.params:
-            n = p.numel()
-            g = p.grad if p.grad is not None else torch.zeros_like(p)
-            self.bucket[off:off + n].copy_(g.reshape(-1))
-            off += n
         dist.all_reduce(self.bucket, op=dist.ReduceOp.SUM, group=self.group)
         self.bucket.div_(self.world)
-        off = 0
-        for p in self.params:
-            n = p.numel()
-            p.grad = self.bucket[off:off + n].view_as(p).clone() if p.grad is None else p.grad.copy_(self.bucket[off:off + n].view_as(p))
-            off += n
 
     def graphed(self, example_local_batch, **kw):
         """The data-parallel step captured in a HIP graph (``GraphedTrainStep``) with the flat-bucket all-reduce inside;
         needs the RCCL backend (gloo collectives cannot be captured) and an optimizer created with capturable=True."""
         return GraphedTrainStep(self.model, self.criterion, self.optimizer, example_local_batch,
-                                all_reduce=self._allreduce_gradients if self.world > 1 else None, **kw)
+                                all_reduce=self._allreduce_gradients if self.world > 1 else None,
+                                zero_grad=self.zero_grad, **kw)
 
     def step(self, local_batch, **kw):
         input, flow, target = local_batch
-        self.optimizer.zero_grad()
+        self._check_views()
+        self.zero_grad()
         loss, loss_sum = clip_loss(self.model, self.criterion, input, flow, target, **kw)
         backward(loss)
         if self.world > 1:
             self._allreduce_gradients()
         self.optimizer.step()
         return float(loss_sum.item()) / target.shape[1]
+
+
+# ---- the driver around the step: epochs, test pass, checkpoints, restore (mainVideoUnshaded.py:344-375, 397-473, 639-726,
+# 799-826) -------------------------------------------------------------------------------------------------------------
+def evaluate(model, criterion, loader, device, initial_image="zero", upscale=4, upsample="bilinear", disable_temporal=False):
+    """``test(epoch)`` of mainVideoUnshaded.py:639-726: the clip recurrence without gradients over the held-out
+    batches; returns ``{'total_loss', 'psnr', "('l1', 'mask')", ...}`` averaged over batches x frames, with
+    ``psnr = 10 log10(1 / max(1e-10, mse_color))`` per frame (``:693``).  The reference reads every term of every frame
+    back with ``.item()``; here everything is accumulated on the device and read once."""
+    was_training = model.training
+    model.eval()
+    lazy_before = getattr(criterion, 'lazy_values', None)
+    if lazy_before is not None:
+        criterion.lazy_values = True
+    feed_inputs = getattr(criterion, 'uses_input', True)
+    kw = dict(mode=upsample, **({"align_corners": False} if upsample in ("bilinear", "bicubic") else {}))
+    sums, frames = {}, 0
+
+    def add(key, value):
+        value = value.detach().double() if torch.is_tensor(value) else torch.tensor(float(value), dtype=torch.float64, device=device)
+        sums[key] = value if key not in sums else sums[key] + value
+    with torch.no_grad():
+        for batch in loader:
+            input, flow, target = (t.to(device) for t in batch)
+            B, T, Cout, Hh, Wh = target.shape
+            previous_output = previous_input = input_high = None
+            for j in range(T):
+                if j == 0 or disable_temporal:
+                    previous_warped = initialImage(input[:, 0], Cout, initial_image, False, upscale)
+                    previous_warped_loss = target[:, 0]
+                    if feed_inputs:
+                        previous_input = F.interpolate(input[:, 0], size=(Hh, Wh), **kw)
+                else:
+                    previous_warped = VideoTools.warp_upscale(previous_output, flow[:, j - 1], upscale, special_mask=True)
+                    previous_warped_loss = previous_warped
+                    if feed_inputs:
+                        previous_input = VideoTools.warp_upscale(F.interpolate(input[:, j - 1], size=(Hh, Wh), **kw),
+                                                                 flow[:, j - 1], upscale, special_mask=True)
+                single_input = torch.cat((input[:, j], VideoTools.flatten_high(previous_warped, upscale)), dim=1)
+                prediction, _ = model(single_input)
+                if feed_inputs:
+                    input_high = F.interpolate(input[:, j], size=(Hh, Wh), **kw)
+                loss0, values = criterion(target[:, j], prediction, input_high, previous_input, previous_warped_loss)
+                add('total_loss', loss0)
+                mse = values[('mse', 'color')]
+                mse = mse.detach().double() if torch.is_tensor(mse) else torch.tensor(float(mse), dtype=torch.float64, device=device)
+                add('psnr', 10.0 * torch.log10(1.0 / torch.clamp(mse, min=1e-10)))
+                for key, value in values.items():
+                    add(str(key), value)
+                previous_output = torch.cat([torch.clamp(prediction[:, 0:1], -1, +1),
+                                             ScreenSpaceShading.normalize(prediction[:, 1:4], dim=1),
+                                             torch.clamp(prediction[:, 4:5], 0, +1),
+                                             torch.clamp(prediction[:, 5:6], 0, +1)], dim=1)
+                frames += 1
+    if lazy_before is not None:
+        criterion.lazy_values = lazy_before
+    model.train(was_training)
+    if not frames:
+        return {}
+    keys = list(sums)
+    host = torch.stack([sums[k] for k in keys]).cpu().tolist()       # the one read-back
+    return {k: v / frames for k, v in zip(keys, host)}
+
+
+def checkpoint_path(modeldir, epoch):
+    return os.path.join(modeldir, "model_epoch_{}.pth".format(epoch))
+
+
+def save_checkpoint(modeldir, epoch, model, parameters, optimizer, scheduler):
+    """``checkpoint(epoch)`` of mainVideoUnshaded.py:799-811: the WHOLE model, optimizer and scheduler objects plus the
+    option dict, keyed as ``inference.LoadedModel`` (and the reference's restore) read them."""
+    os.makedirs(modeldir, exist_ok=True)
+    path = checkpoint_path(modeldir, epoch)
+    opt_dict = dict(parameters) if isinstance(parameters, dict) else dict(vars(parameters))      # `opt_dict = vars(opt)`, :167
+    state = {'epoch': epoch + 1, 'model': model, 'parameters': opt_dict, 'optimizer': optimizer, 'scheduler': scheduler}
+    torch.save(state, path)
+    return path
+
+
+def find_restore_epoch(modeldir, restore_epoch=-1):
+    """``--restoreEpoch -1``: the last consecutively numbered ``model_epoch_N.pth`` (mainVideoUnshaded.py:350-358)."""
+    if restore_epoch != -1:
+        return restore_epoch
+    n = 0
+    while os.path.exists(checkpoint_path(modeldir, n + 1)):
+        n += 1
+    return n
+
+
+def load_checkpoint(modeldir, restore_epoch=-1, device="cpu"):
+    """``--restore`` of mainVideoUnshaded.py:344-375 -> (checkpoint dict, start epoch).  The file is read through the
+    restricted unpickler of ``inference.loadedmodel``.  As in the reference the loop then starts AT the restored epoch
+    number (``startEpoch = restoreEpoch``), i.e. that epoch is run again on top of its own checkpoint."""
+    from .inference.loadedmodel import _CheckpointPickle
+    epoch = find_restore_epoch(modeldir, restore_epoch)
+    path = checkpoint_path(modeldir, epoch)
+    if epoch < 1 or not os.path.exists(path):
+        raise FileNotFoundError("no checkpoint to restore in %s (looked for %s)" % (modeldir, path))
+    return torch.load(path, map_location=device, weights_only=False, pickle_module=_CheckpointPickle), epoch
+
+
+def fit(model, criterion, train_loader, test_loader, modeldir, n_epochs, parameters, device=None, lr=1e-4, lr_step=500, lr_gamma=0.5,
+        restore=False, restore_epoch=-1, graphed=None, log=print, **kw):
+    """The epoch loop of mainVideoUnshaded.py:819-826 for the non-adversarial recipe:
+
+        for epoch in range(start, n_epochs + 1):  trainNormal(epoch); test(epoch); checkpoint(epoch)
+
+    ``trainNormal`` (:397-473) = ``scheduler.step()`` at the epoch's start, then one optimisation step per batch
+    (``train_step``; on the GPU the step of a full-size batch is captured once in a HIP graph, ``GraphedTrainStep``, and
+    replayed; a ragged last batch runs eagerly).  ``parameters``: the option dict / Namespace written into every
+    checkpoint (``initialImage``, ``upsample``, ...; ``inference.LoadedModel`` reads it).  ``restore``: continue from
+    the newest (or ``restore_epoch``) checkpoint of ``modeldir``, taking model, optimizer and scheduler from it.
+    Returns (model, history) -- history = one dict per epoch with the mean training loss, the learning rate, the test
+    dict of ``evaluate`` and the checkpoint path.  ``kw`` goes to ``clip_loss`` (initial_image, upscale, ...)."""
+    if device is None:
+        device = next(model.parameters()).device
+    on_gpu = str(device).startswith("cuda")
+    if graphed is None:
+        graphed = on_gpu
+    start = 1
+    if restore:
+        ckpt, start = load_checkpoint(modeldir, restore_epoch, device)
+        model, optimizer, scheduler = ckpt['model'].to(device), ckpt['optimizer'], ckpt['scheduler']
+        log("Restore training from %s and epoch %d" % (modeldir, start))
+    else:
+        model = model.to(device)
+        optimizer, scheduler = make_optimizer(model, lr, lr_step, lr_gamma, capturable=on_gpu and graphed, tensor_lr=on_gpu and graphed)
+    eval_kw = {k: v for k, v in kw.items() if k in ("initial_image", "upscale", "upsample", "disable_temporal")}
+    history = []
+    step_fn, step_shape = None, None
+    for epoch in range(start, n_epochs + 1):
+        lr_now = step_scheduler(optimizer, scheduler)
+        model.train()
+        total, batches = None, 0
+        for batch in train_loader:
+            batch = tuple(t.to(device, non_blocking=True) for t in batch)
+            shape = tuple(tuple(t.shape) for t in batch)
+            if graphed and on_gpu:
+                if step_fn is None:
+                    step_fn, step_shape = GraphedTrainStep(model, criterion, optimizer, batch, **kw), shape
+                if shape == step_shape:
+                    loss = step_fn(batch).detach().clone()
+                else:
+                    loss = torch.tensor(train_step(model, criterion, optimizer, batch, **kw), device=device)
+            else:
+                loss = torch.tensor(train_step(model, criterion, optimizer, batch, **kw))
+            total = loss if total is None else total + loss
+            batches += 1
+        train_loss = float(total.item()) / max(1, batches) if total is not None else float('nan')
+        log("===> Epoch {} Complete: Avg. Loss: {:.4f}, lr {:.3g}".format(epoch, train_loss, lr_now))
+        test = evaluate(model, criterion, test_loader, device, **eval_kw) if test_loader is not None else {}
+        if test:
+            log("===> Avg. PSNR: {:.4f} dB".format(test['psnr']))
+        path = save_checkpoint(modeldir, epoch, model, parameters, optimizer, scheduler)
+        log("Checkpoint saved to {}".format(path))
+        history.append({'epoch': epoch, 'train_loss': train_loss, 'lr': lr_now, 'test': test, 'checkpoint': path})
+    return model, history

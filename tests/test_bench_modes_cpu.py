@@ -13,13 +13,32 @@ from isosurfacesuperresolution_amd import volumes as V
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 REQUIRED = {"metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
-            "dtype", "data", "config", "roofline", "cpu_baseline", "rccl_ranks"}
+            "dtype", "data", "config", "roofline", "cpu_baseline", "rccl_ranks", "backend", "ranks_joined"}
+ROOFLINE = {"kernel", "bound", "achieved", "peak", "unit", "frac", "traffic"}
+
+
+def _check_line(d, world):
+    """Every mode's line is self-sufficient: the contract's keys, a non-null roofline, a cpu_baseline on the one-rank
+    run (rank 0 at N = 1 only, as the contract says), and an honest account of which backend joined how many ranks."""
+    assert REQUIRED <= set(d)
+    assert d["roofline"] is not None and ROOFLINE <= set(d["roofline"])
+    assert d["roofline"]["achieved"] > 0 and d["roofline"]["peak"] > 0
+    assert abs(d["roofline"]["frac"] - d["roofline"]["achieved"] / d["roofline"]["peak"]) < 1e-9
+    if world == 1:
+        assert d["cpu_baseline"] is not None and {"value", "unit", "cores", "kind", "sample"} <= set(d["cpu_baseline"])
+        assert d["cpu_baseline"]["value"] > 0 and d["cpu_baseline"]["kind"] in ("port", "reference")
+        assert d["backend"] is None and d["ranks_joined"] is None and d["rccl_ranks"] is None
+    else:
+        # these rehearsals run over gloo: the line must not claim that RCCL saw the ranks
+        assert d["backend"] == "gloo" and d["ranks_joined"] == world and d["rccl_ranks"] is None
 
 
 def _launch(script_args, port, tmp_path, nproc=2):
-    env = dict(os.environ, MASTER_ADDR="127.0.0.1", BENCH_DEVICE="cpu", BENCH_DIST_BACKEND="gloo", OMP_NUM_THREADS="2")
-    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=%d" % nproc,
-                          "--master-addr", "127.0.0.1", "--master-port", str(port)] + script_args,
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", BENCH_DEVICE="cpu", BENCH_DIST_BACKEND="gloo", OMP_NUM_THREADS="2",
+               BENCH_CPU_THREADS="2")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=%d" % nproc,
+           "--master-addr", "127.0.0.1", "--master-port", str(port)] if nproc > 1 else [sys.executable]
+    out = subprocess.run(cmd + script_args,
                          env=env, cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600, text=True)
     assert out.returncode == 0, out.stderr[-2000:]
     lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
@@ -30,12 +49,50 @@ def _launch(script_args, port, tmp_path, nproc=2):
 def test_train_mode_two_gloo_ranks(tmp_path):
     d = _launch([os.path.join(ROOT, "bench.py"), "--mode", "train", "--gpus", "2", "--steps", "2", "--warmup", "1",
                  "--train-batch", "2", "--train-frames", "2", "--train-crop", "16"], 29731, tmp_path)
-    assert REQUIRED <= set(d)
-    assert d["n_gpus"] == 2 and d["rccl_ranks"] == 2 and d["steps"] == 2 and d["scaling"] == "strong" and d["unit"] == "clips/s"
+    _check_line(d, 2)
+    assert d["n_gpus"] == 2 and d["steps"] == 2 and d["scaling"] == "strong" and d["unit"] == "clips/s"
     assert d["value"] > 0 and abs(d["value"] - 2 * 2 / (d["ms_per_step"] * 2 / 1e3)) < 1e-6 * d["value"]
     assert d["allreduce"]["bytes"] == 911046 * 4 and d["allreduce"]["buckets"] == 1 and d["allreduce"]["us"] > 0
     assert d["config"]["clips_per_rank"] == 1 and np.isfinite(d["loss"])
     assert d["roofline"]["bound"] == "mfma" and d["roofline"]["flops_per_step"] > 0
+    assert d["config"]["step"] == "eager"
+
+
+def test_train_mode_one_rank_line_is_self_sufficient(tmp_path):
+    d = _launch([os.path.join(ROOT, "bench.py"), "--mode", "train", "--gpus", "1", "--steps", "1", "--warmup", "1",
+                 "--train-batch", "1", "--train-frames", "2", "--train-crop", "16"], 0, tmp_path, nproc=1)
+    _check_line(d, 1)
+    assert d["allreduce"] is None and d["cpu_baseline"]["unit"] == "clips/s"
+
+
+def test_train_mode_capture_failure_falls_back_to_the_eager_step():
+    """If capturing the step (with its RCCL all-reduce) fails on the driver's node, the run goes on eagerly in the same
+    process and says so in the line -- never a re-exec of a process that has touched the GPU."""
+    sys.path.insert(0, ROOT)
+    import bench
+
+    class Trainer:
+        zeroed = steps = 0
+        def graphed(self, batch, **kw):
+            raise RuntimeError("hipErrorStreamCaptureUnsupported: operation not permitted when stream is capturing\nmore")
+        def zero_grad(self):
+            self.zeroed += 1
+        def step(self, batch, **kw):
+            self.steps += 1
+            return 1.5
+    t = Trainer()
+    synced = []
+    step, kind = bench.make_train_step(t, ("b",), True, sync=lambda: synced.append(1))
+    assert kind == "eager (capture failed: RuntimeError: hipErrorStreamCaptureUnsupported: operation not permitted when stream is capturing)"
+    assert t.zeroed == 1 and synced == [1] and step() == 1.5 and t.steps == 1
+    step2, kind2 = bench.make_train_step(t, ("b",), False)
+    assert kind2 == "eager" and step2() == 1.5
+
+    class Good(Trainer):
+        def graphed(self, batch, **kw):
+            return lambda b: 2.5
+    step3, kind3 = bench.make_train_step(Good(), ("b",), True)
+    assert kind3.startswith("one HIP graph") and step3() == 2.5
 
 
 def test_tiled_mode_two_gloo_ranks(tmp_path, oracle):
@@ -66,8 +123,8 @@ bench.main(sys.argv[1:], make_local_renderer=Local)
 ''' % ROOT)
     d = _launch([str(script), "--mode", "tiled", "--gpus", "2", "--steps", "2", "--warmup", "1", "--tiled-n", "64", "--low", "48x32"],
                 29733, tmp_path)
-    assert REQUIRED <= set(d)
-    assert d["n_gpus"] == 2 and d["rccl_ranks"] == 2 and d["scaling"] == "strong" and d["unit"] == "frames/s"
+    _check_line(d, 2)
+    assert d["n_gpus"] == 2 and d["scaling"] == "strong" and d["unit"] == "frames/s"
     assert set(d["phases_ms_max_over_ranks"]) == {"render", "allgather", "composite", "sr_strip_and_allgather"}
     assert all(v >= 0 for v in d["phases_ms_max_over_ranks"].values()) and d["value"] > 0
     assert d["tile"]["voxels"] == [64, 64, 40]                      # 32 owned + 8 halo along z, whole extent in x and y
@@ -77,3 +134,8 @@ bench.main(sys.argv[1:], make_local_renderer=Local)
     ref, _ = oracle.render(oracle.OracleVolume(vol), oracle.make_params(48, 32, origin=q, fov=30.0, isovalue=0.34, last_origin=last), threads=2)
     assert d["hit_pixels"] == int(ref[..., 3].sum()) > 50
     assert 0.0 < d["rgb_mean"] < 1.0
+    # one rank: the same line with a cpu_baseline (oracle tile render + CPU network on a bounded sample)
+    d1 = _launch([str(script), "--mode", "tiled", "--gpus", "1", "--steps", "1", "--warmup", "1", "--tiled-n", "64", "--low", "48x32"],
+                 0, tmp_path, nproc=1)
+    _check_line(d1, 1)
+    assert d1["hit_pixels"] > 50 and d1["cpu_baseline"]["unit"] == "frames/s"
