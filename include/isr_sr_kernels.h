@@ -223,6 +223,25 @@ int isrConvSmallFinishFrame(const float* x, const float* w8, const float* bias8,
                             int Cin, int h, int w, long long xPlane, const float* shading24, int exponent, float ao_strength,
                             int inverse_ao, int enable_specular, void* stream);
 
+/* The 1080p TAIL of the network in two launches (csrc/sr_conv_tail.hip): relu(conv3x3(x [64][4h][4w], 64 -> 64) + bias6)
+ * -> conv3x3(., 64 -> 6) + bias8 -> isrFinishFrame, i.e. models/enhancenet.py:119-125 (postblock.6 .. postblock.8) followed by
+ * _recon_image (:51-90) and the viewer's clamp / normalise / shading (mainGUI.py:594-603), on the split-operand arithmetic of
+ * isrConv3x3ForwardSplit.  The 64-channel tensor between the two convolutions never exists in memory: the last layer is
+ * evaluated per tap as a 1x1 product on the first convolution's accumulators (54 partial planes in `workspace`), and the second
+ * launch adds every pixel's nine shifted partials in a fixed order and finishes the frame.
+ *   wq6: isrConvSplitPrepare(w6 [64][64][3][3]); wz: isrConvTailPrepare(w8 [6][64][3][3]) into isrConvTailWeightBytes() bytes;
+ *   bias6 [64] (may be NULL), bias8 [6]: device; workspace: isrConvTailWorkspaceBytes(h, w) bytes of device memory;
+ *   x: 16-byte aligned, channel planes xPlane floats apart (a multiple of 4); w must be a multiple of 4.
+ * isrConvTailSupported(x, h, w, xPlane) -> 1 if the launch can take these tensors (else use isrConv3x3ForwardSplit +
+ * isrConvSmallFinishFrame).  Returns 0 ok, -1 bad arguments, -2 launch failure, -3 unsupported shape / alignment. */
+long long isrConvTailWeightBytes(void);
+long long isrConvTailWorkspaceBytes(int h, int w);
+int isrConvTailPrepare(const float* w8, void* wz, void* stream);
+int isrConvTailSupported(const float* x, int h, int w, long long xPlane);
+int isrConvTailFinishFrame(const float* x, const void* wq6, const float* bias6, const void* wz, const float* bias8, void* workspace,
+                           const float* net_input, float* next_prev, float* rgb, int h, int w, long long xPlane,
+                           const float* shading24, int exponent, float ao_strength, int inverse_ao, int enable_specular, void* stream);
+
 /* Optional per-dispatch timing of isrConv3x3Forward for benchmarks: while enabled, every forward
  * dispatch carries a start/stop event pair on its own packet (no extra stream operations).
  * isrProfileEnable(1) clears the records and starts recording, (0) stops.  After synchronising the

@@ -20,7 +20,7 @@ _cache = {}
 
 def build(force=False, verbose=False):
     """Compile every HIP extension for gfx950 (hipcc cross-compiles without a GPU)."""
-    cmd = ["make", "-C", CSRC, "all"]
+    cmd = ["make", "-j8", "-C", CSRC, "all"]
     if force:
         cmd.insert(1, "-B")
     out = None if verbose else subprocess.DEVNULL

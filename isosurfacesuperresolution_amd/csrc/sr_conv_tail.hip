@@ -1,0 +1,365 @@
+// The 1080p TAIL of EnhanceNet in two launches instead of three kernels and two 531 MB round trips:
+//     postblock.6 (conv3x3 64 -> 64 + ReLU)  ->  postblock.8 (conv3x3 64 -> 6)  ->  residual reconstruction, clamp /
+//     normalise, screen-space shading            (SuperresolutionNetwork/models/enhancenet.py:119-125,51-90; mainGUI.py:594-603)
+//
+// The 64-channel output y6 of postblock.6 never goes to memory.  The last convolution is linear in y6, so it is taken apart
+// by TAP:   out[c][q] = b[c] + sum_t z[t][c][q + d_t],     z[t][c][p] = sum_k W8[c][k][t] * y6[k][p]      (t = 3 dy + dx, d_t = (dy - 1, dx - 1))
+// -- z is a 1x1 convolution 64 -> 54 of y6, per pixel, with NO halo: it is computed where y6 is, in the registers of the
+// wave that has just finished the pixel's 64 accumulators.  The MFMA D layout (lane = pixel, 16 registers = 16 channels)
+// IS a B-operand layout for a following MFMA whose K index runs over those channels, provided the A operand (the
+// re-laid weights of the last layer) uses the same K order: the ReLU'd values are split into (hi, lo') fp16 pairs in
+// registers and 48 further MFMAs per wave (11 % on top of the layer's 432) produce the 54 tap-partials on the same
+// split-operand arithmetic (three products, fp32 accumulation) as every other layer.  Only z (54 fp32 planes) is
+// written; a second, streaming kernel adds each pixel's nine shifted partials in a FIXED order (bit-reproducible and
+// independent of the tiling) and finishes the frame.  Every z element is read exactly once.
+//
+// Against the three-kernel tail (conv3x3_split_stream_kernel, conv3x3_small_cout_kernel with its fused finish): the
+// fp32 4x4x1-MFMA kernel (0.20 ms, 72 TFLOP/s) and its 606 MB read are gone, the 531 MB write of y6 becomes 448 MB of z.
+#include "sr_split_common.h"
+
+namespace {
+
+constexpr int TZ_ROWS = 54;                                                  // 9 taps x 6 output channels
+constexpr int TZ_UNITS = 4 * 2 * 2 * 64;                                     // [k-step q][part][lane half][row m (64, >= 54 zero)] 16-byte units
+constexpr int SQ_QPR = (ST_W + 8) / 4;                                       // 10 quads per patch row
+constexpr int SQ_UNITS = 2 * SP_H * SQ_QPR;                                  // 200 (channel group, patch row, quad) units per k-step
+constexpr int SQ_SLOT = 2 * SP_PIX;                                          // 16-byte units of one k-step slot of the hi (or lo) patch
+constexpr int T_LDS_BYTES = S_LDS_BYTES + 256;                               // + postblock.6's bias: 80 640 B, two workgroups per CU
+
+struct TailParams {
+    SplitConvParams c;           // postblock.6: x, wq, bias, H, W, ... (y / residual unused)
+    const u32x4* wz;             // header {2^S, 2^-S, S, 0} + TZ_UNITS units: the last layer's weights by (tap, channel) row
+    float* z;                    // [54][zPlane] fp32 tap-partials
+    int zPlane;
+};
+
+// The streaming split-operand convolution of sr_conv_split.hip (persistent workgroups, 8 x 32-pixel x 64-channel tiles,
+// next k-step's operands in flight under the MFMAs) with the z stage between its last k-step and its epilogue.
+__global__ __launch_bounds__(S_THREADS, 2) void conv3x3_split_tail_kernel(const TailParams tp)
+{
+    const SplitConvParams& p = tp.c;
+    extern __shared__ u32x4 patch[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int j = lane & 31, h = lane >> 5;
+    u32x4* wbuf = patch + S_PUNITS;
+    const int ntiles = p.tilesY * p.tilesX;
+    const int xcd = blockIdx.x & 7, jw = blockIdx.x >> 3;
+    const int njw = ((int)gridDim.x >> 3) + (xcd < ((int)gridDim.x & 7) ? 1 : 0);
+    const int tq = ntiles >> 3, trm = ntiles & 7;
+    const int tstart = xcd < trm ? xcd * (tq + 1) : trm * (tq + 1) + (xcd - trm) * tq;
+    const int tcount = tq + (xcd < trm ? 1 : 0);
+    if (jw >= tcount) return;
+    const unsigned planeBytes = (unsigned)p.xPlane * 4u;
+
+    struct Tile { int oy0, ox0; };
+    auto decode = [&](int t) {
+        int b = tstart + t;
+        Tile r;
+        r.ox0 = (b % p.tilesX) * ST_W; b /= p.tilesX;
+        r.oy0 = b * ST_H;
+        return r;
+    };
+    const bool staging = tid < SQ_UNITS;
+    const int ug = tid / (SP_H * SQ_QPR), urem = tid - ug * (SP_H * SQ_QPR);
+    const int ur = urem / SQ_QPR, uq = urem - ur * SQ_QPR;
+    const rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.x), 0, (int)((size_t)64 * p.xPlane * 4), 0x00020000);
+    u32x4 v[8];
+    auto issue_loads = [&](const Tile& t, int ks) {
+        const int iy = t.oy0 + ur - 1, ix = t.ox0 - 4 + 4 * uq;
+        const bool ok = staging && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
+        const unsigned base = (unsigned)(ks * 16 + ug * 8) * planeBytes + (unsigned)(iy * p.W + ix) * 4u;
+#pragma unroll
+        for (int e = 0; e < 8; ++e)
+            v[e] = __builtin_amdgcn_raw_buffer_load_b128(xrs, (int)(ok ? base + (unsigned)e * planeBytes : BAD_OFFSET), 0, 0);
+    };
+    auto park_loads = [&](int slot) {
+        if (!staging) return;
+        f16x8 h0, h1, h2, h3, l0, l1, l2, l3;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const float4 f = __builtin_bit_cast(float4, v[e]);
+            _Float16 a, b;
+            split16x(f.x, a, b); h0[e] = a; l0[e] = b;
+            split16x(f.y, a, b); h1[e] = a; l1[e] = b;
+            split16x(f.z, a, b); h2[e] = a; l2[e] = b;
+            split16x(f.w, a, b); h3[e] = a; l3[e] = b;
+        }
+        u32x4* dst = patch + slot * SQ_SLOT + ug * SP_PIX + ur * SP_W + 4 * uq - 3;
+        if (uq > 0) { dst[0] = __builtin_bit_cast(u32x4, h0); dst[S_PART] = __builtin_bit_cast(u32x4, l0); }
+        if (uq > 0 && uq < SQ_QPR - 1) {
+            dst[1] = __builtin_bit_cast(u32x4, h1); dst[S_PART + 1] = __builtin_bit_cast(u32x4, l1);
+            dst[2] = __builtin_bit_cast(u32x4, h2); dst[S_PART + 2] = __builtin_bit_cast(u32x4, l2);
+        }
+        if (uq < SQ_QPR - 1) { dst[3] = __builtin_bit_cast(u32x4, h3); dst[S_PART + 3] = __builtin_bit_cast(u32x4, l3); }
+    };
+    u32x4 wreg[9];
+    auto wfetch = [&](int ks) {
+#pragma unroll
+        for (int i = 0; i < 9; ++i) {
+            const int q = tid + i * S_THREADS;
+            const int part = q / S_WPART, rem = q - part * S_WPART;
+            const int tap = rem >> 7, hh = (rem >> 6) & 1, c = rem & 63;
+            wreg[i] = p.wq[1 + (size_t)(((tap * 4 + ks) * 2 + part) * 2 + hh) * 64 + c];
+        }
+    };
+    auto wpark = [&]() {
+#pragma unroll
+        for (int i = 0; i < 9; ++i) wbuf[tid + i * S_THREADS] = wreg[i];
+    };
+    // constants of the z stage: bias of postblock.6 (64 floats in LDS behind the weight buffer), both output scales
+    const float unscale = reinterpret_cast<const float*>(p.wq)[1];
+    const float zunscale = reinterpret_cast<const float*>(tp.wz)[1];
+    float* bias_lds = reinterpret_cast<float*>(wbuf + S_WUNITS);
+    if (tid < 64) bias_lds[tid] = p.bias ? p.bias[tid] : 0.0f;
+    const rsrc_t zrs = __builtin_amdgcn_make_buffer_rsrc(tp.z, 0, (int)((size_t)TZ_ROWS * tp.zPlane * 4), 0x00020000);
+    u32x4 zw[4];                                                             // this thread's 4 of the 1024 units of the z weights
+
+    Tile cur = decode(jw);
+    issue_loads(cur, 0);
+    wfetch(0);
+    park_loads(0);
+    wpark();
+    __syncthreads();
+    int slot = 0;
+    for (int t = jw; t < tcount; t += njw) {
+        const bool more = t + njw < tcount;
+        Tile nxt = cur;
+        if (more) nxt = decode(t + njw);
+        f32x16 acc[2][2];
+#pragma unroll
+        for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+            for (int r = 0; r < 2; ++r)
+#pragma unroll
+                for (int i = 0; i < 16; ++i) acc[cb][r][i] = 0.0f;
+#pragma unroll 1
+        for (int ks = 0; ks < 3; ++ks) {
+            issue_loads(cur, ks + 1);
+            wfetch(ks + 1);
+            split_kstep(acc, wbuf + h * 64 + j, patch + slot * SQ_SLOT + h * SP_PIX + (wave * 2) * SP_W + j, true);
+            __syncthreads();
+            park_loads(slot ^ 1);
+            wpark();
+            __syncthreads();
+            slot ^= 1;
+        }
+        if (more) {
+            issue_loads(nxt, 0);
+            wfetch(0);
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) zw[i] = tp.wz[1 + tid + i * S_THREADS];   // in flight under the last k-step
+        split_kstep(acc, wbuf + h * 64 + j, patch + slot * SQ_SLOT + h * SP_PIX + (wave * 2) * SP_W + j, true);
+        __syncthreads();                                                     // weight buffer and patch idle
+#pragma unroll
+        for (int i = 0; i < 4; ++i) wbuf[tid + i * S_THREADS] = zw[i];
+        __syncthreads();
+        // ---- z stage, one output row at a time: y6 = relu(acc 2^-S + bias) as (hi, lo') B fragments straight from the D
+        // layout.  k-step q of the z product covers y6 channels 32 (q >> 1) + 16 (q & 1) + (e & 3) + 8 (e >> 2) + 4 h, e = 0..7:
+        // registers 8 (q & 1) .. + 7 of acc[q >> 1][r]; the prepared weights use the same order.
+        float* tr = reinterpret_cast<float*>(patch) + wave * (64 * 32);
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
+            f16x8 zh[4], zl[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const float4 b0 = *reinterpret_cast<const float4*>(bias_lds + 32 * (q >> 1) + 16 * (q & 1) + 4 * h);
+                const float4 b1 = *reinterpret_cast<const float4*>(bias_lds + 32 * (q >> 1) + 16 * (q & 1) + 8 + 4 * h);
+                const float bq[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    float val = acc[q >> 1][r][8 * (q & 1) + e] * unscale + bq[e];
+                    val = val > 0.f ? val : 0.f;
+                    _Float16 a, b;
+                    split16x(val, a, b);
+                    zh[q][e] = a; zl[q][e] = b;
+                }
+            }
+            const int oy = cur.oy0 + wave * 2 + r;
+#pragma unroll
+            for (int mb = 0; mb < 2; ++mb) {
+                f32x16 zacc;
+#pragma unroll
+                for (int i = 0; i < 16; ++i) zacc[i] = 0.0f;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const f16x8 ah = __builtin_bit_cast(f16x8, wbuf[((q * 2 + 0) * 2 + h) * 64 + mb * 32 + j]);
+                    const f16x8 al = __builtin_bit_cast(f16x8, wbuf[((q * 2 + 1) * 2 + h) * 64 + mb * 32 + j]);
+                    const f16x8 as = ah * (_Float16)0.00048828125f;          // w_hi 2^-11: partner of the scaled lo'
+                    zacc = mfma16(al, zh[q], zacc);
+                    zacc = mfma16(as, zl[q], zacc);
+                    zacc = mfma16(ah, zh[q], zacc);
+                }
+                // D row (z row within the block) = (i & 3) + 8 (i >> 2) + 4 h, column = pixel j: into this wave's slab
+#pragma unroll
+                for (int i = 0; i < 16; ++i) tr[(mb * 32 + (i & 3) + 8 * (i >> 2) + 4 * h) * 32 + j] = zacc[i] * zunscale;
+            }
+            __builtin_amdgcn_s_waitcnt(0xC07F);                              // lgkmcnt(0): same-wave hand-off through LDS
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const int qq = lane + 64 * k;                                // float4 index: z row = qq / 8, pixel group = qq % 8
+                const int m = qq >> 3, px = cur.ox0 + (qq & 7) * 4;
+                const bool ok = oy < p.H && px < p.W && m < TZ_ROWS;
+                const float4 val = reinterpret_cast<const float4*>(tr)[qq];
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, val), zrs,
+                                                       (int)(ok ? ((unsigned)m * (unsigned)tp.zPlane + (unsigned)(oy * p.W + px)) * 4u : BAD_OFFSET), 0, 0);
+            }
+            __builtin_amdgcn_s_waitcnt(0xC07F);                              // reads done before the next row overwrites the slab
+        }
+        __syncthreads();
+        if (more) {
+            park_loads(slot ^ 1);
+            wpark();
+            __syncthreads();
+        }
+        slot ^= 1;
+        cur = nxt;
+    }
+}
+
+// Second launch: out[c][q] = b[c] + sum over the nine taps, in tap order, of z[t][c][q + d_t]  (taps that fall outside the
+// image are the convolution's zero padding), then the frame's finishing code.  One thread per high-resolution pixel.
+struct TailFinishParams {
+    FinishParams fin;
+    const float* z;
+    int zPlane;
+    const float* bias8;          // the last layer's bias (6 floats, device)
+};
+
+__global__ __launch_bounds__(256) void tail_combine_finish_kernel(const TailFinishParams p)
+{
+    const int H = 4 * p.fin.h, W = 4 * p.fin.w;
+    const int X = blockIdx.x * blockDim.x + threadIdx.x, Y = blockIdx.y;
+    if (X >= W) return;
+    float v[6];
+#pragma unroll
+    for (int c = 0; c < 6; ++c) v[c] = p.bias8[c];
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+        const int py = Y + t / 3 - 1, px = X + t % 3 - 1;
+        if ((unsigned)py < (unsigned)H && (unsigned)px < (unsigned)W) {
+            const float* zp = p.z + (size_t)(t * 6) * p.zPlane + (size_t)py * W + px;
+#pragma unroll
+            for (int c = 0; c < 6; ++c) v[c] += zp[(size_t)c * p.zPlane];
+        }
+    }
+    isr_finish_pixel(p.fin, X, Y, v);
+}
+
+// w8 [6][64][3][3] fp32 -> header + [q][part][h][m] units: element e of (q, h) is y6 channel 32 (q >> 1) + 16 (q & 1) + (e & 3) +
+// 8 (e >> 2) + 4 h, row m = 6 t + c holds w8[c][.][t] 2^S (rows >= 54 zero); part 0 = hi, 1 = lo
+__global__ __launch_bounds__(256) void tail_prepare_kernel(const float* __restrict__ w8, u32x4* __restrict__ wz)
+{
+    __shared__ float red[256];
+    float m = 0.0f;
+    for (int i = threadIdx.x; i < 6 * 64 * 9; i += 256) m = fmaxf(m, fabsf(w8[i]));
+    red[threadIdx.x] = m;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if ((int)threadIdx.x < s) red[threadIdx.x] = fmaxf(red[threadIdx.x], red[threadIdx.x + s]);
+        __syncthreads();
+    }
+    int S = 0;
+    const float mx = red[0];
+    if (mx > 0.0f && mx < 3.0e38f) {
+        S = 13 - ilogbf(mx);
+        S = S < -100 ? -100 : (S > 100 ? 100 : S);
+    }
+    const float scale = ldexpf(1.0f, S);
+    if (threadIdx.x == 0) {
+        u32x4 hdr;
+        hdr.x = __builtin_bit_cast(unsigned, scale);
+        hdr.y = __builtin_bit_cast(unsigned, ldexpf(1.0f, -S));
+        hdr.z = (unsigned)S; hdr.w = 0u;
+        wz[0] = hdr;
+    }
+    for (int u = threadIdx.x; u < 4 * 2 * 64; u += 256) {                     // (q, h, m)
+        const int mrow = u & 63, hh = (u >> 6) & 1, q = u >> 7;
+        const int t = mrow / 6, c = mrow - t * 6;
+        f16x8 qh, ql;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const int k = 32 * (q >> 1) + 16 * (q & 1) + (e & 3) + 8 * (e >> 2) + 4 * hh;
+            _Float16 a, b;
+            split16(mrow < TZ_ROWS ? w8[((size_t)c * 64 + k) * 9 + t] * scale : 0.0f, a, b);
+            qh[e] = a; ql[e] = b;
+        }
+        wz[1 + ((q * 2 + 0) * 2 + hh) * 64 + mrow] = __builtin_bit_cast(u32x4, qh);
+        wz[1 + ((q * 2 + 1) * 2 + hh) * 64 + mrow] = __builtin_bit_cast(u32x4, ql);
+    }
+}
+
+} // namespace
+
+extern "C" {
+
+long long isrConvTailWeightBytes(void) { return 16 + (long long)TZ_UNITS * 16; }
+
+long long isrConvTailWorkspaceBytes(int h, int w)
+{
+    if (h <= 0 || w <= 0) return -1;
+    const long long H = 4LL * h, W = 4LL * w;
+    return (long long)TZ_ROWS * (H * W + W) * 4;                             // one extra row between planes (see ops.empty_planes)
+}
+
+int isrConvTailPrepare(const float* w8, void* wz, void* stream)
+{
+    if (!w8 || !wz) return -1;
+    hipLaunchKernelGGL(tail_prepare_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, w8, (u32x4*)wz);
+    return hipGetLastError() == hipSuccess ? 0 : -2;
+}
+
+int isrConvTailSupported(const float* x, int h, int w, long long xPlane)
+{
+    const long long H = 4LL * h, W = 4LL * w;
+    if (h <= 0 || w <= 0 || !x) return 0;
+    if (((uintptr_t)x & 15) != 0 || (xPlane & 3) != 0 || xPlane < H * W) return 0;
+    if (xPlane * 64 * 4 > 0x7fffffffLL || (H * W + W) * TZ_ROWS * 4 > 0x7fffffffLL) return 0;
+    return 1;
+}
+
+int isrConvTailFinishFrame(const float* x, const void* wq6, const float* bias6, const void* wz, const float* bias8, void* workspace,
+                           const float* net_input, float* next_prev, float* rgb, int h, int w, long long xPlane,
+                           const float* shading24, int exponent, float ao_strength, int inverse_ao, int enable_specular, void* stream)
+{
+    if (!x || !wq6 || !wz || !bias8 || !workspace || !net_input || !next_prev || (rgb && !shading24)) return -1;
+    if (!isrConvTailSupported(x, h, w, xPlane)) return -3;
+    const int H = 4 * h, W = 4 * w;
+    TailParams tp;
+    SplitConvParams& p = tp.c;
+    p.x = x; p.wq = (const u32x4*)wq6; p.bias = bias6; p.residual = nullptr; p.y = nullptr;
+    p.N = 1; p.Cin = 64; p.H = H; p.W = W; p.Cout = 64;
+    p.Hin = H; p.Win = W;
+    p.xPlane = (int)xPlane; p.yPlane = 0; p.rPlane = 0;
+    p.xImage = 64 * xPlane; p.yImage = 0; p.rImage = 0;
+    p.ksteps = 4; p.coutPad = 64; p.cgroups = 1;
+    p.tilesX = (W + ST_W - 1) / ST_W; p.tilesY = (H + ST_H - 1) / ST_H;
+    p.act = ISR_ACT_RELU; p.slope = 0.0f;
+    p.stamps = nullptr; p.dbg = 0; p.quads = 1;
+    tp.wz = (const u32x4*)wz;
+    tp.z = (float*)workspace;
+    tp.zPlane = H * W + W;
+    static int slots = 0;
+    if (!slots) {
+        int dev = 0, cus = 0;
+        (void)hipGetDevice(&dev);
+        if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
+        slots = 2 * cus;
+        (void)hipFuncSetAttribute((const void*)conv3x3_split_tail_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, T_LDS_BYTES);
+    }
+    const long long ntiles = (long long)p.tilesX * p.tilesY;
+    const long long want = ntiles < slots ? ((ntiles + 7) / 8) * 8 : slots;
+    hipStream_t s = (hipStream_t)stream;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    // algorithmic flops: postblock.6 and the final 64 -> 6 layer, whose arithmetic this launch carries
+    isr_profile_record(ISR_VARIANT_SPLIT_TAIL, 2.0 * 9 * 64 * (64 + 6) * (double)H * W, &e0, &e1);
+    if (e0 || e1) hipExtLaunchKernelGGL(conv3x3_split_tail_kernel, dim3((unsigned)want), dim3(S_THREADS), T_LDS_BYTES, s, e0, e1, 0, tp);
+    else hipLaunchKernelGGL(conv3x3_split_tail_kernel, dim3((unsigned)want), dim3(S_THREADS), T_LDS_BYTES, s, tp);
+    TailFinishParams fp;
+    isr_fill_finish_params(fp.fin, nullptr, net_input, next_prev, rgb, h, w, shading24, exponent, ao_strength, inverse_ao, enable_specular);
+    fp.z = tp.z; fp.zPlane = tp.zPlane; fp.bias8 = bias8;
+    hipLaunchKernelGGL(tail_combine_finish_kernel, dim3((W + 255) / 256, H), dim3(256), 0, s, fp);
+    return hipGetLastError() == hipSuccess ? 0 : -2;
+}
+
+} // extern "C"

@@ -1,0 +1,182 @@
+// Shared device code of the split-operand convolution kernels (sr_conv_split.hip, sr_conv_tail.hip): operand types, the
+// (hi, lo) split, the parameter block, one k-step of MFMAs and the common epilogue.  Every function is inline / static: each
+// translation unit gets its own copy, nothing is called across translation units (no relocatable device code).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
+#include <stdint.h>
+
+#include "../../include/isr_sr_kernels.h"
+#include "sr_finish.h"
+#include "sr_profile.h"
+
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef __amdgpu_buffer_rsrc_t rsrc_t;
+
+constexpr unsigned BAD_OFFSET = 0x80000000u;
+constexpr int ST_H = 8, ST_W = 32;
+constexpr int SP_H = ST_H + 2, SP_W = ST_W + 2, SP_PIX = SP_H * SP_W;       // 340 patch pixels
+constexpr int S_CHUNK = 32;                                                  // input channels per staging pass
+constexpr int S_GROUPS = S_CHUNK / 8;                                        // 8-channel groups per pass
+constexpr int S_PART = S_GROUPS * SP_PIX;                                    // 16-byte units of the hi (or lo) patch: 1360
+constexpr int S_PUNITS = 2 * S_PART;                                         // hi then lo
+constexpr int S_THREADS = 256;
+constexpr int S_WPART = 9 * 2 * 64;                                          // weights of one k-step, one part: [tap][lane half][64 couts]
+constexpr int S_WUNITS = 2 * S_WPART;                                        // hi then lo: 2304 units = 9 per thread
+constexpr int S_LDS_BYTES = (S_PUNITS + S_WUNITS) * 16;                      // 43520 + 36864 = 80384: two workgroups per CU
+
+struct SplitConvParams {
+    const float* x; const u32x4* wq; const float* bias; const float* residual; float* y;
+    int N, Cin, H, W, Cout;
+    int xPlane, yPlane, rPlane;
+    long long xImage, yImage, rImage;
+    int ksteps;          // ceil(Cin / 16)
+    int coutPad;         // Cout rounded up to 32
+    int cgroups;         // 64-channel output groups covered by the grid
+    int tilesX, tilesY;
+    int act; float slope;
+    int Hin, Win;                 // input size: (H, W), or (H / 2, W / 2) for the upsampling variant
+    int quads;                    // 1: W, the plane stride of x and its base address allow aligned dwordx4 staging
+    int dbg;                      // diagnostics: 1 skip the MFMAs, 2 skip the staging loads, 4 skip the stores
+    unsigned long long* stamps;   // diagnostics: per-workgroup s_memrealtime stamps (100 MHz, one clock for the whole chip), or NULL
+};
+
+// v = hi + lo (+ <= 2^-22 |v|): hi = RN16(v), lo = RN16(v - hi); the subtraction is exact in fp32
+__device__ __forceinline__ void split16(float v, _Float16& hi, _Float16& lo)
+{
+    hi = (_Float16)v;
+    lo = (_Float16)(v - (float)hi);
+}
+// activations: the low part scaled by 2^11 (exact), see the header comment
+__device__ __forceinline__ void split16x(float v, _Float16& hi, _Float16& lo)
+{
+    hi = (_Float16)v;
+    lo = (_Float16)((v - (float)hi) * 2048.0f);
+}
+
+__device__ __forceinline__ float buf_load(rsrc_t r, unsigned voff)
+{
+    return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, (int)voff, 0, 0));
+}
+
+__device__ __forceinline__ f32x16 mfma16(f16x8 a, f16x8 b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0); }
+
+// Epilogue shared by the split kernels: acc * 2^-S + bias, activation, residual / gate, store.  D row (cout) =
+// (reg & 3) + 8 * (reg >> 2) + 4 * h, column (pixel) = j.  The wide path transposes through the (idle) patch buffer.
+__device__ __forceinline__ void split_epilogue(const SplitConvParams& p, f32x16 (&acc)[2][2], u32x4* patch, int n, int oy0, int ox0, int co0,
+                                               bool second, int lane, int wave, int j, int h)
+{
+    const float unscale = reinterpret_cast<const float*>(p.wq)[1];          // 2^-S (header of the prepared weights)
+    const rsrc_t yrs = __builtin_amdgcn_make_buffer_rsrc(p.y + (size_t)n * p.yImage, 0, (int)((size_t)p.Cout * p.yPlane * 4), 0x00020000);
+    const rsrc_t rrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.residual ? p.residual + (size_t)n * p.rImage : p.y), 0,
+                                                         p.residual ? (int)((size_t)p.Cout * p.rPlane * 4) : 0, 0x00020000);
+    const int ox = ox0 + j;
+    float bv[2][16];                                                         // all bias values first: one latency, not 128
+#pragma unroll
+    for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+        for (int i = 0; i < 16; ++i)
+            bv[cb][i] = p.bias ? p.bias[min(co0 + cb * 32 + (i & 3) + 8 * (i >> 2) + 4 * h, p.Cout - 1)] : 0.0f;
+    if (p.dbg & 4) {
+    } else if (((p.W | p.yPlane | p.rPlane) & 3) == 0) {
+        // wide path: each wave transposes one output row (64 couts x 32 pixels) through 8 KB of the now idle patch, so
+        // that a lane owns 4 consecutive pixels of one channel and the stores are dwordx4 (4x fewer instructions)
+        float* tr = reinterpret_cast<float*>(patch) + wave * (64 * 32);
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
+            const int oy = oy0 + wave * 2 + r;
+#pragma unroll
+            for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    float v = acc[cb][r][i] * unscale + bv[cb][i];
+                    if (p.act == ISR_ACT_RELU) v = v > 0.f ? v : 0.f;
+                    else if (p.act == ISR_ACT_LEAKY) v = v > 0.f ? v : v * p.slope;
+                    tr[(cb * 32 + (i & 3) + 8 * (i >> 2) + 4 * h) * 32 + j] = v;
+                }
+            __builtin_amdgcn_s_waitcnt(0xC07F);                              // lgkmcnt(0): same-wave hand-off through LDS
+#pragma unroll
+            for (int t = 0; t < 8; ++t) {
+                const int q = lane + 64 * t;                                 // float4 index: cout = q / 8, pixel group = q % 8
+                const int co = co0 + (q >> 3), px = ox0 + (q & 7) * 4;
+                const bool ok = oy < p.H && px < p.W && co < p.Cout;
+                float4 v = reinterpret_cast<const float4*>(tr)[q];
+                const unsigned pixoff = (unsigned)(oy * p.W + px) * 4u;
+                if (p.residual) {
+                    const u32x4 rr = __builtin_amdgcn_raw_buffer_load_b128(rrs, (int)(ok ? pixoff + (unsigned)co * (unsigned)p.rPlane * 4u : BAD_OFFSET), 0, 0);
+                    const float4 rf = __builtin_bit_cast(float4, rr);
+                    if (p.act == ISR_ACT_GATE) {
+                        v.x = rf.x > 0.f ? v.x : 0.f; v.y = rf.y > 0.f ? v.y : 0.f;
+                        v.z = rf.z > 0.f ? v.z : 0.f; v.w = rf.w > 0.f ? v.w : 0.f;
+                    } else {
+                        v.x += rf.x; v.y += rf.y; v.z += rf.z; v.w += rf.w;
+                    }
+                }
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), yrs,
+                                                       (int)(ok ? pixoff + (unsigned)co * (unsigned)p.yPlane * 4u : BAD_OFFSET), 0, 0);
+            }
+            __builtin_amdgcn_s_waitcnt(0xC07F);                              // reads done before the next row overwrites the slab
+        }
+    } else {
+#pragma unroll
+    for (int cb = 0; cb < 2; ++cb) {
+        if (cb == 1 && !second) break;
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
+            const int oy = oy0 + wave * 2 + r;
+            const unsigned pix = (oy < p.H && ox < p.W) ? (unsigned)(oy * p.W + ox) * 4u : BAD_OFFSET;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const int co = co0 + cb * 32 + (i & 3) + 8 * (i >> 2) + 4 * h;
+                float v = acc[cb][r][i] * unscale + bv[cb][i];
+                if (p.act == ISR_ACT_RELU) v = v > 0.f ? v : 0.f;
+                else if (p.act == ISR_ACT_LEAKY) v = v > 0.f ? v : v * p.slope;
+                const bool ok = pix != BAD_OFFSET && co < p.Cout;
+                if (p.residual) {
+                    const float rv = buf_load(rrs, ok ? pix + (unsigned)co * (unsigned)p.rPlane * 4u : BAD_OFFSET);
+                    if (p.act == ISR_ACT_GATE) v = rv > 0.f ? v : 0.f; else v += rv;
+                }
+                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), yrs,
+                                                      ok ? (int)(pix + (unsigned)co * (unsigned)p.yPlane * 4u) : (int)BAD_OFFSET, 0, 0);
+            }
+        }
+    }
+    }
+}
+
+// One k-step of MFMAs: 16 input channels x 9 taps x (2 channel blocks x 2 rows) x 3 products.  wl: this lane's weight
+// units of the k-step in LDS (hi; lo at + S_WPART), bl: this lane's patch units (hi; lo at + S_PART).
+__device__ __forceinline__ void split_kstep(f32x16 (&acc)[2][2], const u32x4* wl, const u32x4* bl, bool second)
+{
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap) {
+        const int dy = tap / 3, dx = tap - dy * 3;
+        const f16x8 a0h = __builtin_bit_cast(f16x8, wl[tap * 128]);
+        const f16x8 a0l = __builtin_bit_cast(f16x8, wl[S_WPART + tap * 128]);
+        const f16x8 a1h = __builtin_bit_cast(f16x8, wl[tap * 128 + (second ? 32 : 0)]);
+        const f16x8 a1l = __builtin_bit_cast(f16x8, wl[S_WPART + tap * 128 + (second ? 32 : 0)]);
+        const f16x8 a0s = a0h * (_Float16)0.00048828125f;                   // w_hi 2^-11: partner of the scaled x_lo'
+        const f16x8 a1s = a1h * (_Float16)0.00048828125f;
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
+            const f16x8 bh = __builtin_bit_cast(f16x8, bl[(r + dy) * SP_W + dx]);
+            const f16x8 bo = __builtin_bit_cast(f16x8, bl[S_PART + (r + dy) * SP_W + dx]);
+            // the two small cross terms first, then the leading term
+            acc[0][r] = mfma16(a0l, bh, acc[0][r]);
+            acc[0][r] = mfma16(a0s, bo, acc[0][r]);
+            acc[0][r] = mfma16(a0h, bh, acc[0][r]);
+            if (second) {
+                acc[1][r] = mfma16(a1l, bh, acc[1][r]);
+                acc[1][r] = mfma16(a1s, bo, acc[1][r]);
+                acc[1][r] = mfma16(a1h, bh, acc[1][r]);
+            }
+        }
+    }
+}
+
+} // namespace

@@ -84,10 +84,11 @@ class EnhanceNet(nn.Module):
     def _fused_ok(self):
         return (not self.use_bn) and self.upsample == 'bilinear'
 
-    def forward_features(self, inputs, last_layer=True):
+    def forward_features(self, inputs, last_layer=True, last_two=True):
         """The convolutional trunk only: the tensor ``_recon_image`` receives (used by the fused
         frame pipeline, which folds the reconstruction into its finishing kernel).  ``last_layer=False`` stops
-        before the final 64 -> 6 convolution (``self.postblock[8]``), which the pipeline fuses with the finishing."""
+        before the final 64 -> 6 convolution (``self.postblock[8]``), which the pipeline fuses with the finishing;
+        ``last_two=False`` stops before ``self.postblock[6]`` as well (the fused 1080p tail, ``ops.tail_conv_finish``)."""
         assert self._fused_ok()
         c = ops.conv3x3
         pre = self.preblock[0]
@@ -97,6 +98,8 @@ class EnhanceNet(nn.Module):
         p = self.postblock
         f = c(f, p[1].weight, p[1].bias, act='relu', upsample2x=True)
         f = c(f, p[4].weight, p[4].bias, act='relu', upsample2x=True)
+        if not last_two:
+            return f
         f = c(f, p[6].weight, p[6].bias, act='relu')
         return c(f, p[8].weight, p[8].bias) if last_layer else f
 

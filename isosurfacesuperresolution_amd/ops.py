@@ -90,6 +90,12 @@ def _sr():
         lib.isrConvSplitPrepareManyMax.argtypes = []; lib.isrConvSplitPrepareManyMax.restype = ci
         lib.isrConvSplitPrepareMany.argtypes = [ci, vp, vp, vp, vp, vp, vp]; lib.isrConvSplitPrepareMany.restype = ci
         lib.isrConv3x3ForwardSplit.argtypes = lib.isrConv3x3ForwardF16.argtypes; lib.isrConv3x3ForwardSplit.restype = ci
+        lib.isrConvTailWeightBytes.argtypes = []; lib.isrConvTailWeightBytes.restype = ll
+        lib.isrConvTailWorkspaceBytes.argtypes = [ci, ci]; lib.isrConvTailWorkspaceBytes.restype = ll
+        lib.isrConvTailPrepare.argtypes = [vp, vp, vp]; lib.isrConvTailPrepare.restype = ci
+        lib.isrConvTailSupported.argtypes = [vp, ci, ci, ll]; lib.isrConvTailSupported.restype = ci
+        lib.isrConvTailFinishFrame.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, vp, ci, ci, ll, vp, ci, cf, ci, ci, vp]
+        lib.isrConvTailFinishFrame.restype = ci
         lib.isrProfileEnable.argtypes = [ci]; lib.isrProfileEnable.restype = ci
         lib.isrProfileCount.argtypes = []; lib.isrProfileCount.restype = ci
         lib.isrProfileGet.argtypes = [ci, vp, vp, vp]; lib.isrProfileGet.restype = ci
@@ -154,7 +160,8 @@ VARIANT_NAMES = {6: "conv3x3_small_cout_kernel", 2: "conv3x3_fwd_kernel<1,false>
                  8: "conv3x3_fwd2_kernel<false,4>", 9: "conv3x3_fwd2_kernel<true,4>",
                  10: "conv3x3_fwd2_kernel<false,1>", 11: "conv3x3_fwd2_kernel<true,1>", 12: "conv3x3_rowsplit_kernel",
                  13: "conv3x3_split_kernel<false>", 14: "conv3x3_split_kernel<true>",
-                 15: "conv3x3_split_stream_kernel", 16: "conv3x3_split_wide_kernel", 17: "conv3x3_split_rows2_kernel"}
+                 15: "conv3x3_split_stream_kernel", 16: "conv3x3_split_wide_kernel", 17: "conv3x3_split_rows2_kernel",
+                 18: "conv3x3_split_tail_kernel"}
 
 
 def profile_enable(on):
@@ -1004,6 +1011,77 @@ def final_conv_finish(features, weight, bias, net_input, shading=None):
                                      params, exponent, ao, inv, spec, _stream())
     if rc != 0:
         raise RuntimeError("isrConvSmallFinishFrame failed (%d)" % rc)
+    return nxt, rgb
+
+
+# ---- the fused 1080p tail (csrc/sr_conv_tail.hip): postblock.6 + postblock.8 + frame finish without the 64-channel round trip ----
+TAIL_FUSION = True
+_tail_cache = {}
+_tail_ws = {}
+
+
+def _prepare_tail(weight8):
+    """The last layer's weights [6, 64, 3, 3] by (tap, channel) row in the z stage's operand order, cached like ``prepare_weights``."""
+    lib = _sr()
+    key = id(weight8)
+    hit = _tail_cache.get(key)
+    if hit is not None:
+        ref, version, ptr, wz, epoch = hit
+        if ref() is weight8 and version == weight8._version and ptr == weight8.data_ptr() and epoch == _images_epoch:
+            return wz
+    wz = torch.empty(lib.isrConvTailWeightBytes(), dtype=torch.uint8, device=weight8.device)
+    rc = lib.isrConvTailPrepare(_ptr(weight8.detach().contiguous()), _ptr(wz), _stream())
+    if rc != 0:
+        raise RuntimeError("isrConvTailPrepare failed (%d)" % rc)
+    if len(_tail_cache) > 64:
+        _tail_cache.clear()
+    _tail_cache[key] = (weakref.ref(weight8), weight8._version, weight8.data_ptr(), wz, _images_epoch)
+    return wz
+
+
+def tail_supported(features, weight6, weight8):
+    """Can ``tail_conv_finish`` take this frame?  (64 -> 64 -> 6 channels, one image, 16-byte aligned rows; the default
+    split-operand inference mode.)"""
+    if not (TAIL_FUSION and SPLIT_F16 and not FAST_F16 and features.is_cuda and features.dtype == torch.float32):
+        return False
+    if features.dim() != 4 or features.shape[0] != 1 or features.shape[1] != 64 or features.shape[2] % 4 or features.shape[3] % 4:
+        return False
+    if tuple(weight6.shape) != (64, 64, 3, 3) or tuple(weight8.shape) != (6, 64, 3, 3):
+        return False
+    f, xp, _ = _plane_strides(features)
+    return f is features and bool(_sr().isrConvTailSupported(_ptr(features), features.shape[2] // 4, features.shape[3] // 4, xp))
+
+
+def tail_conv_finish(features, weight6, bias6, weight8, bias8, net_input, shading=None):
+    """features [1,64,4h,4w] (the output of postblock.4; channel planes may be padded) -> relu(conv3x3(., weight6) + bias6)
+    -> conv3x3(., weight8) + bias8 -> ``finish_frame``: (next_prev [1,6,4h,4w], rgb [1,3,4h,4w] or None) in two launches
+    (``isrConvTailFinishFrame``); the 64-channel tensor between the two convolutions never exists in memory."""
+    lib = _sr()
+    features, xp, _ = _plane_strides(features)
+    net_input = net_input.contiguous()
+    _, _, H, W = features.shape
+    h, w = H // 4, W // 4
+    wq6 = _prepare_split(weight6)
+    wz = _prepare_tail(weight8)
+    key = (features.device, h, w, torch.cuda.current_stream().cuda_stream)
+    ws = _tail_ws.get(key)
+    if ws is None:
+        ws = torch.empty(lib.isrConvTailWorkspaceBytes(h, w), dtype=torch.uint8, device=features.device)
+        _tail_ws[key] = ws
+    nxt = torch.empty((1, 6, H, W), dtype=torch.float32, device=features.device)
+    rgb, params = None, None
+    exponent, ao, inv, spec = 1, 0.0, 0, 0
+    if shading is not None:
+        rgb = torch.empty((1, 3, H, W), dtype=torch.float32, device=features.device)
+        params = (ctypes.c_float * 18)(*shading.packed_parameters())
+        exponent, ao = int(shading._specular_exponent), float(shading._ao)
+        inv, spec = int(bool(shading.inverse_ao)), int(bool(shading.enable_specular))
+    b6 = bias6.detach().contiguous() if bias6 is not None else None
+    b8 = bias8.detach().contiguous() if bias8 is not None else torch.zeros(6, dtype=torch.float32, device=features.device)
+    rc = lib.isrConvTailFinishFrame(_ptr(features), _ptr(wq6), _ptr(b6), _ptr(wz), _ptr(b8), _ptr(ws), _ptr(net_input), _ptr(nxt), _ptr(rgb),
+                                    h, w, xp, params, exponent, ao, inv, spec, _stream())
+    if rc != 0:
+        raise RuntimeError("isrConvTailFinishFrame failed (%d)" % rc)
     return nxt, rgb
 
 

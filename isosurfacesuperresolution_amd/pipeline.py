@@ -168,7 +168,18 @@ class SuperResolutionPipeline:
             net = self.model.model
             self.shading.inverse_ao = self.model.inverse_ao
             last = net.postblock[8]
-            if last.weight.shape[0] == 6:
+            six = net.postblock[6]
+            f4 = None
+            if last.weight.shape[0] == 6 and ops.TAIL_FUSION and ops.SPLIT_F16 and not ops.FAST_F16:
+                f4 = net.forward_features(x, last_two=False)
+            if f4 is not None and ops.tail_supported(f4, six.weight, last.weight):
+                # postblock.6, postblock.8 and the frame's finishing in two launches; the 64-channel 1080p tensor between the
+                # two convolutions never goes to memory (csrc/sr_conv_tail.hip)
+                raw, rgb = ops.tail_conv_finish(f4, six.weight, six.bias, last.weight, last.bias, x, self.shading)
+            elif f4 is not None:
+                f6 = ops.conv3x3(f4, six.weight, six.bias, act='relu')
+                raw, rgb = ops.final_conv_finish(f6, last.weight, last.bias, x, self.shading)
+            elif last.weight.shape[0] == 6:
                 # the last layer's epilogue finishes the frame (one launch, no [6,4h,4w] round trip)
                 raw, rgb = ops.final_conv_finish(net.forward_features(x, last_layer=False), last.weight, last.bias, x, self.shading)
             else:

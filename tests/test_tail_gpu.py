@@ -1,0 +1,126 @@
+"""The fused 1080p tail (csrc/sr_conv_tail.hip): postblock.6 + postblock.8 + frame finish without the 64-channel round trip,
+against the three-kernel path it replaces and against an fp64 CPU evaluation of
+SuperresolutionNetwork/models/enhancenet.py:119-125,51-90 + mainGUI.py:594-603."""
+import argparse
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+
+def _setup(h, w, seed, wscale=1.0, xscale=1.0):
+    from isosurfacesuperresolution_amd.pipeline import default_shading
+    g = torch.Generator().manual_seed(seed)
+    f4 = (torch.rand(1, 64, 4 * h, 4 * w, generator=g) * xscale).cuda()          # post-ReLU features: non-negative
+    w6 = ((torch.rand(64, 64, 3, 3, generator=g) - 0.5) * 0.08 * wscale).cuda()
+    b6 = ((torch.rand(64, generator=g) - 0.5) * 0.1).cuda()
+    w8 = ((torch.rand(6, 64, 3, 3, generator=g) - 0.5) * 0.08).cuda()
+    b8 = ((torch.rand(6, generator=g) - 0.5) * 0.1).cuda()
+    x = torch.rand(1, 101, h, w, generator=g).cuda()
+    x[:, 0] = x[:, 0] * 2 - 1
+    return f4, w6, b6, w8, b8, x, default_shading("cuda", 30.0)
+
+
+def _reference64(f4, w6, b6, w8, b8, x):
+    """fp64 on the CPU: the two convolutions, the residual reconstruction and the clamp / normalise of the viewer."""
+    d = lambda t: t.double().cpu()
+    y6 = F.relu(F.conv2d(d(f4), d(w6), d(b6), padding=1))
+    out = F.conv2d(y6, d(w8), d(b8), padding=1)
+    out[:, :5] += F.interpolate(d(x)[:, :5], size=out.shape[2:], mode='bilinear', align_corners=False)
+    n = out[:, 1:4]
+    n = n / torch.clamp(n.norm(dim=1, keepdim=True), min=1e-7)
+    return torch.cat([out[:, 0:1].clamp(-1, 1), n, out[:, 4:].clamp(0, 1)], dim=1), out
+
+
+@pytest.mark.parametrize("h,w", [(2, 8), (6, 8), (23, 37), (30, 52), (67, 120)])
+def test_tail_matches_the_three_kernel_path_and_fp64(h, w):
+    from isosurfacesuperresolution_amd import ops
+    f4, w6, b6, w8, b8, x, sh = _setup(h, w, seed=h * 100 + w)
+    assert ops.tail_supported(f4, w6, w8)
+    with torch.no_grad():
+        raw_t, rgb_t = ops.tail_conv_finish(f4, w6, b6, w8, b8, x, sh)
+        f6 = ops.conv3x3(f4, w6, b6, act='relu')
+        raw_s, rgb_s = ops.final_conv_finish(f6, w8, b8, x, sh)
+    torch.cuda.synchronize()
+    ref, pre = _reference64(f4, w6, b6, w8, b8, x)
+    scale = max(1.0, pre.abs().max().item())
+    err_t = (raw_t.double().cpu() - ref).abs().max().item()
+    err_s = (raw_s.double().cpu() - ref).abs().max().item()
+    # the normalised normal amplifies errors of short vectors: compare where the normal is not degenerate
+    assert err_s <= 2e-5 * scale, err_s
+    assert err_t <= 2e-5 * scale and err_t <= 4 * err_s + 2e-6, (err_t, err_s)
+    assert (raw_t - raw_s).abs().max().item() <= 2e-5 * scale
+    assert (rgb_t - rgb_s).abs().max().item() <= 2e-5
+    assert torch.isfinite(raw_t).all() and torch.isfinite(rgb_t).all()
+
+
+def test_tail_with_padded_planes_and_without_shading_or_bias():
+    from isosurfacesuperresolution_amd import ops
+    h, w = 12, 20
+    f4, w6, b6, w8, b8, x, sh = _setup(h, w, seed=5)
+    padded = torch.zeros(64 * (16 * h * w + 4 * w), device="cuda").as_strided((1, 64, 4 * h, 4 * w), (64 * (16 * h * w + 4 * w), 16 * h * w + 4 * w, 4 * w, 1))
+    padded.copy_(f4)
+    with torch.no_grad():
+        raw_a, rgb_a = ops.tail_conv_finish(f4, w6, b6, w8, b8, x, sh)
+        raw_b, rgb_b = ops.tail_conv_finish(padded, w6, b6, w8, b8, x, sh)
+        raw_c, rgb_c = ops.tail_conv_finish(f4, w6, None, w8, None, x, None)
+    assert torch.equal(raw_a, raw_b) and torch.equal(rgb_a, rgb_b)
+    assert rgb_c is None
+    ref, _ = _reference64(f4, w6, torch.zeros_like(b6), w8, torch.zeros_like(b8), x)
+    assert (raw_c.double().cpu() - ref).abs().max().item() <= 2e-5
+
+
+def test_tail_is_deterministic_and_independent_of_the_tile_origin():
+    """Every pixel's nine partials are added in a fixed order and each partial is a fixed-order MFMA chain over the
+    pixel's own 3x3 neighbourhood: the same pixels computed as part of a larger image (other tile boundaries, other
+    workgroups) come out bit for bit -- what the strip super-resolution of parallel_sr.py relies on."""
+    from isosurfacesuperresolution_amd import ops
+    h, w = 24, 32
+    f4, w6, b6, w8, b8, x, sh = _setup(h, w, seed=11)
+    with torch.no_grad():
+        raw_a, _ = ops.tail_conv_finish(f4, w6, b6, w8, b8, x, None)
+        raw_a2, _ = ops.tail_conv_finish(f4, w6, b6, w8, b8, x, None)
+        # a crop whose origin is not a multiple of the 8 x 32 tile: rows 12.., columns 20.. (high-res), interior compared
+        f4c = f4[:, :, 12:, 20:].contiguous()
+        xc = x[:, :, 3:, 5:].contiguous()
+        raw_c, _ = ops.tail_conv_finish(f4c, w6, b6, w8, b8, xc, None)
+    assert torch.equal(raw_a, raw_a2)
+    # the residual reconstruction resamples the low-res input (different at the crop's border) and the convolutions pad with
+    # zeros at the crop's border: compare channel 5 (no reconstruction) two pixels inside
+    assert torch.equal(raw_a[:, 5, 12 + 2:-2, 20 + 2:-2], raw_c[:, 5, 2:-2, 2:-2])
+
+
+def test_pipeline_uses_the_fused_tail_and_matches_the_unfused_frame():
+    from isosurfacesuperresolution_amd import models, ops, volumes as V
+    from isosurfacesuperresolution_amd.inference import DirectRenderer, LoadedModel
+    from isosurfacesuperresolution_amd.pipeline import SuperResolutionPipeline, default_shading
+    opt = argparse.Namespace(upsample='bilinear', reconType='residual', useBN=False, numResidualLayers=10)
+    torch.manual_seed(3)
+    net = models.createNetwork('EnhanceNet', 4, 101, [0, 1, 2, 3, 4], 6, opt)
+    lm = LoadedModel.from_model(net, "cuda", parameters={"initialImage": "zero"})
+    renderer = DirectRenderer()
+    renderer.load_dense(V.ejecta(64))
+    origins = [V.orbit_camera(k) for k in range(3)]
+    frames = {}
+    for fused in (True, False):
+        ops.TAIL_FUSION = fused
+        try:
+            pipe = SuperResolutionPipeline(renderer, lm, default_shading("cuda", 30.0), (96, 56))
+            pipe.set_static(fov=30.0, isovalue=0.34)
+            pipe.frame(origins[0])
+            pipe.reset()
+            ops.profile_enable(True)
+            out = [tuple(t.clone() for t in pipe.frame(o)) for o in origins]
+            torch.cuda.synchronize()
+            names = {n for n, _, _ in ops.profile_records()}
+            ops.profile_enable(False)
+        finally:
+            ops.TAIL_FUSION = True
+        assert ("conv3x3_split_tail_kernel" in names) == fused
+        assert ("conv3x3_small_cout_kernel" in names) == (not fused)
+        frames[fused] = out
+    for (rgb_a, raw_a), (rgb_b, raw_b) in zip(frames[True], frames[False]):
+        assert (raw_a - raw_b).abs().max().item() <= 1e-4 and (rgb_a - rgb_b).abs().max().item() <= 1e-4
+    assert (frames[True][0][1] - frames[False][0][1]).abs().max().item() <= 2e-5      # first frame: no recurrence yet
