@@ -223,6 +223,26 @@ int isrConvSmallFinishFrame(const float* x, const float* w8, const float* bias8,
                             int Cin, int h, int w, long long xPlane, const float* shading24, int exponent, float ao_strength,
                             int inverse_ao, int enable_specular, void* stream);
 
+/* isrConv3x3ForwardSplit for one image whose result is written PACKED-SPLIT instead of fp32: every output value already as
+ * the (hi, lo') fp16 pair the next split-operand layer multiplies, eight channels of a pixel per 16-byte unit,
+ * ps[part: hi | lo][Cout / 8][psPlane units] (unit index y W + x; Cout a multiple of 8; no residual).  The consumer
+ * (isrConvTailFinishFramePacked) stages it by LDS-DMA -- the numbers are those a consumer of the fp32 tensor would form on
+ * its way in, so results do not change.  ps: 2 * (Cout / 8) * psPlane * 16 bytes, 16-byte aligned.  Returns as above. */
+int isrConv3x3ForwardSplitPacked(const float* x, const void* wq, const float* bias, void* ps, int Cin, int H, int W, int Cout,
+                                 int act, float slope, int upsample2x, long long xPlane, long long psPlane, void* stream);
+
+/* One residual block of the trunk, y = x + conv2(relu(conv1(x) + bias1)) + bias2 (64 -> 64 -> 64 channels, one image;
+ * models/enhancenet.py:18-33,108-112,139-141), in ONE launch on the split-operand arithmetic: the same products in the same
+ * order as two calls of isrConv3x3ForwardSplit (bit-identical result).  The intermediate tensor stays in a per-workgroup
+ * scratch (`workspace`, isrResBlockSplitWorkspaceBytes() bytes) as LDS-ready (hi, lo) units and is streamed back by LDS-DMA.
+ *   x, y: [64][H][W] fp32, 16-byte aligned, planes xPlane / yPlane floats apart (multiples of 4), W a multiple of 4;
+ *   wq1 / wq2: isrConvSplitPrepare(w [64][64][3][3]); bias1 / bias2: [64] device (may be NULL).
+ * isrResBlockSplitSupported -> 1 if these tensors can be taken.  0 ok, -1 bad arguments, -2 launch failure, -3 unsupported. */
+long long isrResBlockSplitWorkspaceBytes(void);
+int isrResBlockSplitSupported(const float* x, int H, int W, long long xPlane, long long yPlane);
+int isrResBlockSplit(const float* x, const void* wq1, const float* bias1, const void* wq2, const float* bias2, float* y, void* workspace,
+                     int H, int W, long long xPlane, long long yPlane, void* stream);
+
 /* The 1080p TAIL of the network in two launches (csrc/sr_conv_tail.hip): relu(conv3x3(x [64][4h][4w], 64 -> 64) + bias6)
  * -> conv3x3(., 64 -> 6) + bias8 -> isrFinishFrame, i.e. models/enhancenet.py:119-125 (postblock.6 .. postblock.8) followed by
  * _recon_image (:51-90) and the viewer's clamp / normalise / shading (mainGUI.py:594-603), on the split-operand arithmetic of
@@ -241,6 +261,10 @@ int isrConvTailSupported(const float* x, int h, int w, long long xPlane);
 int isrConvTailFinishFrame(const float* x, const void* wq6, const float* bias6, const void* wz, const float* bias8, void* workspace,
                            const float* net_input, float* next_prev, float* rgb, int h, int w, long long xPlane,
                            const float* shading24, int exponent, float ao_strength, int inverse_ao, int enable_specular, void* stream);
+/* ... with the 64-channel input PACKED-SPLIT (isrConv3x3ForwardSplitPacked, 64 channels, [4h][4w], xpsPlane units per plane). */
+int isrConvTailFinishFramePacked(const void* xps, const void* wq6, const float* bias6, const void* wz, const float* bias8, void* workspace,
+                                 const float* net_input, float* next_prev, float* rgb, int h, int w, long long xpsPlane,
+                                 const float* shading24, int exponent, float ao_strength, int inverse_ao, int enable_specular, void* stream);
 
 /* Optional per-dispatch timing of isrConv3x3Forward for benchmarks: while enabled, every forward
  * dispatch carries a start/stop event pair on its own packet (no extra stream operations).

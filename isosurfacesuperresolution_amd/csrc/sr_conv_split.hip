@@ -68,9 +68,20 @@ __global__ __launch_bounds__(S_THREADS, 2) void conv3x3_split_kernel(const Split
     if (p.stamps) st0 = __builtin_amdgcn_s_memrealtime();
 
     // weights of k-step ks: 2304 units [part][tap][lane half][64 couts], 9 per thread, L2 -> registers -> LDS
+    // With 64 output channels (every layer of this network but the last) thread t moves unit (tap i, part t / 128, t % 128) of the
+    // k-step, i = 0..8: byte 16 t + 4096 ksteps i + 4096 ks of the prepared image -- ONE address register and scalar offsets
+    // instead of nine 64-bit pointers (which the register allocator spilled)
+    const bool w64 = p.coutPad == 64;
+    const rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<u32x4*>(p.wq + 1), 0, w64 ? 9 * p.ksteps * 4096 : 0, 0x00020000);
+    u32x4* wdst = wbuf + (tid >> 7) * S_WPART + (tid & 127);
     u32x4 wreg[9];
     auto wfetch = [&](int ks) {
         if (ks >= p.ksteps) return;
+        if (w64) {
+#pragma unroll
+            for (int i = 0; i < 9; ++i) wreg[i] = __builtin_amdgcn_raw_buffer_load_b128(wrs, tid * 16, (i * p.ksteps + ks) * 4096, 0);
+            return;
+        }
 #pragma unroll
         for (int i = 0; i < 9; ++i) {
             const int q = tid + i * S_THREADS;
@@ -80,6 +91,11 @@ __global__ __launch_bounds__(S_THREADS, 2) void conv3x3_split_kernel(const Split
         }
     };
     auto wpark = [&]() {
+        if (w64) {
+#pragma unroll
+            for (int i = 0; i < 9; ++i) wdst[i * 128] = wreg[i];
+            return;
+        }
 #pragma unroll
         for (int i = 0; i < 9; ++i) {
             const int q = tid + i * S_THREADS;
@@ -297,7 +313,8 @@ __global__ __launch_bounds__(S_THREADS, 2) void conv3x3_split_kernel(const Split
     }
 
     if (p.stamps) st2 = __builtin_amdgcn_s_memrealtime();
-    split_epilogue(p, acc, patch, n, oy0, ox0, co0, second, lane, wave, j, h);
+    if (p.ps) split_epilogue_ps(p, acc, oy0, ox0, co0, second, wave, j, h);
+    else split_epilogue(p, acc, patch, n, oy0, ox0, co0, second, lane, wave, j, h);
     if (p.stamps && tid == 0) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         const unsigned long long st3 = __builtin_amdgcn_s_memrealtime();
@@ -380,8 +397,16 @@ __global__ __launch_bounds__(S_THREADS, 2) void conv3x3_split_stream_kernel(cons
         }
         if (uq < SQ_QPR - 1) { dst[3] = __builtin_bit_cast(u32x4, h3); dst[S_PART + 3] = __builtin_bit_cast(u32x4, l3); }
     };
+    const bool w64 = p.coutPad == 64;                                        // see conv3x3_split_kernel: one address register for the weights
+    const rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<u32x4*>(p.wq + 1), 0, w64 ? 9 * p.ksteps * 4096 : 0, 0x00020000);
+    u32x4* wdst = wbuf + (tid >> 7) * S_WPART + (tid & 127);
     u32x4 wreg[9];
     auto wfetch = [&](int ks, int co0) {
+        if (w64) {
+#pragma unroll
+            for (int i = 0; i < 9; ++i) wreg[i] = __builtin_amdgcn_raw_buffer_load_b128(wrs, tid * 16, (i * p.ksteps + ks) * 4096, 0);
+            return;
+        }
         const int couts = min(64, p.coutPad - co0);
 #pragma unroll
         for (int i = 0; i < 9; ++i) {
@@ -392,6 +417,11 @@ __global__ __launch_bounds__(S_THREADS, 2) void conv3x3_split_stream_kernel(cons
         }
     };
     auto wpark = [&](int co0) {
+        if (w64) {
+#pragma unroll
+            for (int i = 0; i < 9; ++i) wdst[i * 128] = wreg[i];
+            return;
+        }
         const int couts = min(64, p.coutPad - co0);
 #pragma unroll
         for (int i = 0; i < 9; ++i) {
@@ -1040,6 +1070,7 @@ __global__ __launch_bounds__(256) void prepare_weights_split_many_kernel(const P
 
 } // namespace
 
+static bool g_ps_out = false;      // set around the launch by isrConv3x3ForwardSplitPacked (the library is single threaded by contract)
 static unsigned long long* g_split_stamps = nullptr;
 static int g_split_dbg = 0;
 static int g_split_small = 1;     // 2-row-tile kernel for small images (isrDebugSetSplitSmall)
@@ -1099,6 +1130,11 @@ int isrConv3x3ForwardSplit(const float* x, const void* wq, const float* bias, co
     p.stamps = g_split_stamps;
     p.dbg = g_split_dbg;
     p.quads = ((W & 3) == 0 && aligned) ? 1 : 0;
+    p.ps = nullptr; p.psPlane = 0;
+    if (g_ps_out) {            // isrConv3x3ForwardSplitPacked: `y` is the packed-split tensor, yPlane its plane stride in units
+        if (N != 1 || residual || (Cout & 7) || act == ISR_ACT_GATE || yPlane * 16 * 2 * (Cout / 8) > 0x7fffffffLL) return -1;
+        p.ps = (u32x4*)y; p.psPlane = (int)yPlane; p.y = nullptr;
+    }
     const long long nwg = (long long)N * p.tilesX * p.tilesY * p.cgroups;
     if (nwg > 0x7fffffffLL) return -1;
     static bool attr_done = false;
@@ -1144,16 +1180,21 @@ int isrConv3x3ForwardSplit(const float* x, const void* wq, const float* bias, co
         else hipLaunchKernelGGL(conv3x3_split_wide_kernel, pgrid, wblock, W_LDS_BYTES, s, p);
         return hipGetLastError() == hipSuccess ? 0 : -2;
     }
-    if (!upsample2x && p.quads && !g_split_stamps && g_split_algo == 1) {
-        // persistent form: two workgroups per CU walk the tile list with the next chunk's loads in flight under the MFMAs
-        static int slots = 0;
-        if (!slots) {
-            int dev = 0, cus = 0;
-            (void)hipGetDevice(&dev);
-            if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
-            slots = 2 * cus;
-            (void)hipFuncSetAttribute((const void*)conv3x3_split_stream_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, S_LDS_BYTES);
-        }
+    static int slots = 0;
+    if (!slots) {
+        int dev = 0, cus = 0;
+        (void)hipGetDevice(&dev);
+        if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
+        slots = 2 * cus;
+        (void)hipFuncSetAttribute((const void*)conv3x3_split_stream_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, S_LDS_BYTES);
+    }
+    // persistent form: two workgroups per CU walk the tile list with the next k-step's loads in flight under the MFMAs.  It pays
+    // when a workgroup has SEVERAL tiles to walk; a launch that fits in one round (the 480 x 270 trunk: 510 tiles on 512 slots)
+    // has nothing to stream into and runs faster on the one-workgroup-per-tile form with its 32-channel staging passes (half the
+    // barriers): 37.9 vs 42.5 us per layer in a chain of twenty (tools/bench_trunk_algos.py).  g_split_algo = 3 forces the
+    // persistent form for every size.
+    const bool one_round = nwg <= (g_split_slots > 0 ? g_split_slots : slots);
+    if (!upsample2x && p.quads && !g_split_stamps && (g_split_algo == 3 || (g_split_algo == 1 && !one_round))) {
         const int cap = g_split_slots > 0 ? g_split_slots : slots;
         const long long want = nwg < cap ? ((nwg + 7) / 8) * 8 : cap;
         isr_profile_record(ISR_VARIANT_SPLIT_STREAM, 2.0 * 9 * Cin * Cout * (double)N * H * W, &e0, &e1);
@@ -1172,6 +1213,19 @@ int isrConv3x3ForwardSplit(const float* x, const void* wq, const float* bias, co
         else hipLaunchKernelGGL((conv3x3_split_kernel<false>), grid, block, S_LDS_BYTES, s, p);
     }
     return hipGetLastError() == hipSuccess ? 0 : -2;
+}
+
+int isrConv3x3ForwardSplitPacked(const float* x, const void* wq, const float* bias, void* ps, int Cin, int H, int W, int Cout,
+                                 int act, float slope, int upsample2x, long long xPlane, long long psPlane, void* stream)
+{
+    // only the forms whose epilogue knows the packed-split layout: the one-workgroup-per-tile kernels (every upsampling layer;
+    // plain layers are forced onto it for this launch)
+    const int algo = g_split_algo, small = g_split_small;
+    g_ps_out = true; g_split_algo = 0; g_split_small = 0;
+    const int rc = isrConv3x3ForwardSplit(x, wq, bias, nullptr, (float*)ps, 1, Cin, H, W, Cout, act, slope, upsample2x,
+                                          xPlane, xPlane * Cin, psPlane, 0, 0, 0, stream);
+    g_ps_out = false; g_split_algo = algo; g_split_small = small;
+    return rc;
 }
 
 int isrConvSplitPrepareManyMax(void) { return PM_MAX; }

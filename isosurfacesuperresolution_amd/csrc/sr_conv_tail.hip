@@ -29,12 +29,49 @@ constexpr int T_LDS_BYTES = S_LDS_BYTES + 256;                               // 
 struct TailParams {
     SplitConvParams c;           // postblock.6: x, wq, bias, H, W, ... (y / residual unused)
     const u32x4* wz;             // header {2^S, 2^-S, S, 0} + TZ_UNITS units: the last layer's weights by (tap, channel) row
-    float* z;                    // [54][zPlane] fp32 tap-partials
+    float* z;                    // two-kernel form: [54][zPlane] fp32 tap-partials
     int zPlane;
+    // fused form (FUSED = true): pixels whose nine partials all lie in their own tile (or outside the image) are finished here;
+    // the others -- the SEAM pixels on the tiles' rims -- get their partials from up to four tiles, each of which writes the
+    // ones it owns into the pixel's record [9 taps][6 channels]; tail_seam_finish_kernel adds them in the same tap order
+    FinishParams fin;
+    const float* bias8;
+    float* rowrec;               // records of the pixels with Y % 8 in {0, 7}: [2 tilesY][W][54]
+    float* colrec;               // records of the other pixels with X % 32 in {0, 31}: [H][2 tilesX][54]
+    // PSIN = true: the input arrives PACKED-SPLIT (SplitConvParams::ps of the producing layer): xps[hi | lo][8 groups][xpsPlane
+    // units]; k-steps are staged by LDS-DMA, 22 wave-wide 1 KB pieces each, pixels outside the image from `zero` (16 zero bytes)
+    const u32x4* xps; int xpsPlane;
+    const u32x4* zero;
 };
+
+__device__ __forceinline__ bool tail_in_image(int x, int y, int W, int H) { return (unsigned)x < (unsigned)W && (unsigned)y < (unsigned)H; }
+
+// a pixel is finished by the tile that owns it iff none of its nine taps reads an in-image pixel of another tile
+__device__ __forceinline__ bool tail_is_seam(int x, int y, int W, int H)
+{
+    const int tx0 = x & ~(ST_W - 1), ty0 = y & ~(ST_H - 1);
+    bool seam = false;
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+        const int px = x + t % 3 - 1, py = y + t / 3 - 1;
+        seam = seam || (tail_in_image(px, py, W, H) && !(px >= tx0 && px < tx0 + ST_W && py >= ty0 && py < ty0 + ST_H));
+    }
+    return seam;
+}
+
+__device__ __forceinline__ float* tail_record(const TailParams& tp, int x, int y)
+{
+    const int W = tp.c.W;
+    if ((y & 7) == 0 || (y & 7) == 7)
+        return tp.rowrec + ((size_t)((y >> 3) * 2 + ((y & 7) == 7 ? 1 : 0)) * W + x) * TZ_ROWS;
+    return tp.colrec + ((size_t)y * (2 * tp.c.tilesX) + (x >> 5) * 2 + ((x & 31) == 31 ? 1 : 0)) * TZ_ROWS;
+}
 
 // The streaming split-operand convolution of sr_conv_split.hip (persistent workgroups, 8 x 32-pixel x 64-channel tiles,
 // next k-step's operands in flight under the MFMAs) with the z stage between its last k-step and its epilogue.
+constexpr int ZW_OFF = S_WUNITS - TZ_UNITS;                                  // the z weights sit at the END of the weight buffer: the fused
+                                                                             // form's z tile (54 x 8 x 32 fp32 = 55 296 B) grows from the patch into its start
+template <bool FUSED, bool PSIN>
 __global__ __launch_bounds__(S_THREADS, 2) void conv3x3_split_tail_kernel(const TailParams tp)
 {
     const SplitConvParams& p = tp.c;
@@ -62,49 +99,71 @@ __global__ __launch_bounds__(S_THREADS, 2) void conv3x3_split_tail_kernel(const 
     const bool staging = tid < SQ_UNITS;
     const int ug = tid / (SP_H * SQ_QPR), urem = tid - ug * (SP_H * SQ_QPR);
     const int ur = urem / SQ_QPR, uq = urem - ur * SQ_QPR;
-    const rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.x), 0, (int)((size_t)64 * p.xPlane * 4), 0x00020000);
-    u32x4 v[8];
-    auto issue_loads = [&](const Tile& t, int ks) {
-        const int iy = t.oy0 + ur - 1, ix = t.ox0 - 4 + 4 * uq;
-        const bool ok = staging && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
-        const unsigned base = (unsigned)(ks * 16 + ug * 8) * planeBytes + (unsigned)(iy * p.W + ix) * 4u;
+    const rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.x), 0, PSIN ? 0 : (int)((size_t)64 * p.xPlane * 4), 0x00020000);
+    u32x4 v[PSIN ? 1 : 8];
+    // packed-split input: k-step ks of tile t into slot `slot` -- per part (hi, lo) 680 units [2 groups][10 x 34 pixels] = 11 pieces
+    auto dma_kstep = [&](const Tile& t, int ks, int slot) {
 #pragma unroll
-        for (int e = 0; e < 8; ++e)
-            v[e] = __builtin_amdgcn_raw_buffer_load_b128(xrs, (int)(ok ? base + (unsigned)e * planeBytes : BAD_OFFSET), 0, 0);
+        for (int d = 0; d < 6; ++d) {
+            const int piece = wave + 4 * d;
+            const int part = piece / 11, pc = piece - part * 11, off = pc * 64 + lane;
+            if (piece < 22 && off < SQ_SLOT) {
+                const int gg = off / SP_PIX, pix = off - gg * SP_PIX;
+                const int r = pix / SP_W, c = pix - r * SP_W;
+                const int iy = t.oy0 + r - 1, ix = t.ox0 + c - 1;
+                const bool ok = (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
+                const u32x4* src = ok ? tp.xps + ((size_t)(part * 8 + 2 * ks + gg) * tp.xpsPlane + (size_t)iy * p.W + ix) : tp.zero;
+                isr_dma16(src, patch + part * S_PART + slot * SQ_SLOT + pc * 64);
+            }
+        }
+    };
+    // stage(t, ks, slot): start moving k-step ks of tile t towards patch slot `slot` -- fp32 input: loads into registers, parked
+    // (split, written to LDS) later by park_loads(slot); packed-split input: LDS-DMA straight into the slot
+    auto issue_loads = [&](const Tile& t, int ks, int slot) {
+        if constexpr (PSIN) {
+            dma_kstep(t, ks, slot);
+        } else {
+            const int iy = t.oy0 + ur - 1, ix = t.ox0 - 4 + 4 * uq;
+            const bool ok = staging && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
+            const unsigned base = (unsigned)(ks * 16 + ug * 8) * planeBytes + (unsigned)(iy * p.W + ix) * 4u;
+#pragma unroll
+            for (int e = 0; e < 8; ++e)
+                v[e] = __builtin_amdgcn_raw_buffer_load_b128(xrs, (int)(ok ? base : BAD_OFFSET), (int)((unsigned)e * planeBytes), 0);
+        }
     };
     auto park_loads = [&](int slot) {
-        if (!staging) return;
-        f16x8 h0, h1, h2, h3, l0, l1, l2, l3;
-#pragma unroll
-        for (int e = 0; e < 8; ++e) {
-            const float4 f = __builtin_bit_cast(float4, v[e]);
-            _Float16 a, b;
-            split16x(f.x, a, b); h0[e] = a; l0[e] = b;
-            split16x(f.y, a, b); h1[e] = a; l1[e] = b;
-            split16x(f.z, a, b); h2[e] = a; l2[e] = b;
-            split16x(f.w, a, b); h3[e] = a; l3[e] = b;
+        if constexpr (!PSIN) {
+            if (!staging) return;
+            f16x8 h0, h1, h2, h3, l0, l1, l2, l3;
+    #pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const float4 f = __builtin_bit_cast(float4, v[e]);
+                _Float16 a, b;
+                split16x(f.x, a, b); h0[e] = a; l0[e] = b;
+                split16x(f.y, a, b); h1[e] = a; l1[e] = b;
+                split16x(f.z, a, b); h2[e] = a; l2[e] = b;
+                split16x(f.w, a, b); h3[e] = a; l3[e] = b;
+            }
+            u32x4* dst = patch + slot * SQ_SLOT + ug * SP_PIX + ur * SP_W + 4 * uq - 3;
+            if (uq > 0) { dst[0] = __builtin_bit_cast(u32x4, h0); dst[S_PART] = __builtin_bit_cast(u32x4, l0); }
+            if (uq > 0 && uq < SQ_QPR - 1) {
+                dst[1] = __builtin_bit_cast(u32x4, h1); dst[S_PART + 1] = __builtin_bit_cast(u32x4, l1);
+                dst[2] = __builtin_bit_cast(u32x4, h2); dst[S_PART + 2] = __builtin_bit_cast(u32x4, l2);
+            }
+            if (uq < SQ_QPR - 1) { dst[3] = __builtin_bit_cast(u32x4, h3); dst[S_PART + 3] = __builtin_bit_cast(u32x4, l3); }
         }
-        u32x4* dst = patch + slot * SQ_SLOT + ug * SP_PIX + ur * SP_W + 4 * uq - 3;
-        if (uq > 0) { dst[0] = __builtin_bit_cast(u32x4, h0); dst[S_PART] = __builtin_bit_cast(u32x4, l0); }
-        if (uq > 0 && uq < SQ_QPR - 1) {
-            dst[1] = __builtin_bit_cast(u32x4, h1); dst[S_PART + 1] = __builtin_bit_cast(u32x4, l1);
-            dst[2] = __builtin_bit_cast(u32x4, h2); dst[S_PART + 2] = __builtin_bit_cast(u32x4, l2);
-        }
-        if (uq < SQ_QPR - 1) { dst[3] = __builtin_bit_cast(u32x4, h3); dst[S_PART + 3] = __builtin_bit_cast(u32x4, l3); }
     };
+    // weights of one k-step: thread t moves unit (tap i, part t / 128, t % 128), i = 0..8: byte 16 t + 16384 i + 4096 ks of the image
+    const rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<u32x4*>(p.wq + 1), 0, 9 * 4 * 256 * 16, 0x00020000);
     u32x4 wreg[9];
     auto wfetch = [&](int ks) {
 #pragma unroll
-        for (int i = 0; i < 9; ++i) {
-            const int q = tid + i * S_THREADS;
-            const int part = q / S_WPART, rem = q - part * S_WPART;
-            const int tap = rem >> 7, hh = (rem >> 6) & 1, c = rem & 63;
-            wreg[i] = p.wq[1 + (size_t)(((tap * 4 + ks) * 2 + part) * 2 + hh) * 64 + c];
-        }
+        for (int i = 0; i < 9; ++i) wreg[i] = __builtin_amdgcn_raw_buffer_load_b128(wrs, tid * 16, i * 16384 + ks * 4096, 0);
     };
+    u32x4* wdst = wbuf + (tid >> 7) * S_WPART + (tid & 127);
     auto wpark = [&]() {
 #pragma unroll
-        for (int i = 0; i < 9; ++i) wbuf[tid + i * S_THREADS] = wreg[i];
+        for (int i = 0; i < 9; ++i) wdst[i * 128] = wreg[i];
     };
     // constants of the z stage: bias of postblock.6 (64 floats in LDS behind the weight buffer), both output scales
     const float unscale = reinterpret_cast<const float*>(p.wq)[1];
@@ -115,7 +174,7 @@ __global__ __launch_bounds__(S_THREADS, 2) void conv3x3_split_tail_kernel(const 
     u32x4 zw[4];                                                             // this thread's 4 of the 1024 units of the z weights
 
     Tile cur = decode(jw);
-    issue_loads(cur, 0);
+    issue_loads(cur, 0, 0);
     wfetch(0);
     park_loads(0);
     wpark();
@@ -134,7 +193,7 @@ __global__ __launch_bounds__(S_THREADS, 2) void conv3x3_split_tail_kernel(const 
                 for (int i = 0; i < 16; ++i) acc[cb][r][i] = 0.0f;
 #pragma unroll 1
         for (int ks = 0; ks < 3; ++ks) {
-            issue_loads(cur, ks + 1);
+            issue_loads(cur, ks + 1, slot ^ 1);
             wfetch(ks + 1);
             split_kstep(acc, wbuf + h * 64 + j, patch + slot * SQ_SLOT + h * SP_PIX + (wave * 2) * SP_W + j, true);
             __syncthreads();
@@ -144,7 +203,7 @@ __global__ __launch_bounds__(S_THREADS, 2) void conv3x3_split_tail_kernel(const 
             slot ^= 1;
         }
         if (more) {
-            issue_loads(nxt, 0);
+            issue_loads(nxt, 0, slot ^ 1);
             wfetch(0);
         }
 #pragma unroll
@@ -152,12 +211,16 @@ __global__ __launch_bounds__(S_THREADS, 2) void conv3x3_split_tail_kernel(const 
         split_kstep(acc, wbuf + h * 64 + j, patch + slot * SQ_SLOT + h * SP_PIX + (wave * 2) * SP_W + j, true);
         __syncthreads();                                                     // weight buffer and patch idle
 #pragma unroll
-        for (int i = 0; i < 4; ++i) wbuf[tid + i * S_THREADS] = zw[i];
+        for (int i = 0; i < 4; ++i) wbuf[ZW_OFF + tid + i * S_THREADS] = zw[i];
         __syncthreads();
         // ---- z stage, one output row at a time: y6 = relu(acc 2^-S + bias) as (hi, lo') B fragments straight from the D
         // layout.  k-step q of the z product covers y6 channels 32 (q >> 1) + 16 (q & 1) + (e & 3) + 8 (e >> 2) + 4 h, e = 0..7:
         // registers 8 (q & 1) .. + 7 of acc[q >> 1][r]; the prepared weights use the same order.
-        float* tr = reinterpret_cast<float*>(patch) + wave * (64 * 32);
+        // transposition slab of this wave (8 KB).  With packed-split input the next tile's first k-step is landing in slot ^ 1 by DMA
+        // meanwhile: the slabs then live in the two halves of the slot just multiplied and in the front of the weight buffer
+        float* tr = PSIN ? reinterpret_cast<float*>(wave == 0 ? patch + slot * SQ_SLOT : wave == 1 ? patch + S_PART + slot * SQ_SLOT
+                                                              : wbuf + (wave - 2) * 512)
+                         : reinterpret_cast<float*>(patch) + wave * (64 * 32);
 #pragma unroll
         for (int r = 0; r < 2; ++r) {
             f16x8 zh[4], zl[4];
@@ -183,17 +246,27 @@ __global__ __launch_bounds__(S_THREADS, 2) void conv3x3_split_tail_kernel(const 
                 for (int i = 0; i < 16; ++i) zacc[i] = 0.0f;
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
-                    const f16x8 ah = __builtin_bit_cast(f16x8, wbuf[((q * 2 + 0) * 2 + h) * 64 + mb * 32 + j]);
-                    const f16x8 al = __builtin_bit_cast(f16x8, wbuf[((q * 2 + 1) * 2 + h) * 64 + mb * 32 + j]);
+                    const f16x8 ah = __builtin_bit_cast(f16x8, wbuf[ZW_OFF + ((q * 2 + 0) * 2 + h) * 64 + mb * 32 + j]);
+                    const f16x8 al = __builtin_bit_cast(f16x8, wbuf[ZW_OFF + ((q * 2 + 1) * 2 + h) * 64 + mb * 32 + j]);
                     const f16x8 as = ah * (_Float16)0.00048828125f;          // w_hi 2^-11: partner of the scaled lo'
                     zacc = mfma16(al, zh[q], zacc);
                     zacc = mfma16(as, zl[q], zacc);
                     zacc = mfma16(ah, zh[q], zacc);
                 }
-                // D row (z row within the block) = (i & 3) + 8 (i >> 2) + 4 h, column = pixel j: into this wave's slab
+                // D row (z row within the block) = (i & 3) + 8 (i >> 2) + 4 h, column = pixel j
+                if (FUSED) {                                                 // ... into the workgroup's z tile [54][8 rows][32 pixels]
+                    float* zt = reinterpret_cast<float*>(patch);
 #pragma unroll
-                for (int i = 0; i < 16; ++i) tr[(mb * 32 + (i & 3) + 8 * (i >> 2) + 4 * h) * 32 + j] = zacc[i] * zunscale;
+                    for (int i = 0; i < 16; ++i) {
+                        const int m = mb * 32 + (i & 3) + 8 * (i >> 2) + 4 * h;
+                        if (m < TZ_ROWS) zt[(m * ST_H + wave * 2 + r) * ST_W + j] = zacc[i] * zunscale;
+                    }
+                } else {                                                     // ... into this wave's transposition slab
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) tr[(mb * 32 + (i & 3) + 8 * (i >> 2) + 4 * h) * 32 + j] = zacc[i] * zunscale;
+                }
             }
+            if (FUSED) continue;
             __builtin_amdgcn_s_waitcnt(0xC07F);                              // lgkmcnt(0): same-wave hand-off through LDS
 #pragma unroll
             for (int k = 0; k < 8; ++k) {
@@ -207,6 +280,44 @@ __global__ __launch_bounds__(S_THREADS, 2) void conv3x3_split_tail_kernel(const 
             __builtin_amdgcn_s_waitcnt(0xC07F);                              // reads done before the next row overwrites the slab
         }
         __syncthreads();
+        if (FUSED) {
+            const float* zt = reinterpret_cast<const float*>(patch);
+            const int W = p.W, H = p.H;
+            {   // pixels this tile can finish on its own: bias, then the nine partials in tap order
+                const int row = tid >> 5, col = tid & 31;
+                const int X = cur.ox0 + col, Y = cur.oy0 + row;
+                if (X < W && Y < H && !tail_is_seam(X, Y, W, H)) {
+                    float v[6];
+#pragma unroll
+                    for (int c = 0; c < 6; ++c) v[c] = tp.bias8[c];
+#pragma unroll
+                    for (int t = 0; t < 9; ++t) {
+                        const int pc = col + t % 3 - 1, pr = row + t / 3 - 1;
+                        if (tail_in_image(cur.ox0 + pc, cur.oy0 + pr, W, H)) {        // in the image = in this tile, for these pixels
+#pragma unroll
+                            for (int c = 0; c < 6; ++c) v[c] += zt[((t * 6 + c) * ST_H + pr) * ST_W + pc];
+                        }
+                    }
+                    isr_finish_pixel(tp.fin, X, Y, v);
+                }
+            }
+            // seam pixels of this tile's rim and of the frame around it: the partials this tile owns go into their records
+            for (int u = tid; u < SP_PIX; u += S_THREADS) {
+                const int er = u / SP_W, ec = u - er * SP_W;
+                const int qx = cur.ox0 - 1 + ec, qy = cur.oy0 - 1 + er;
+                if (!tail_in_image(qx, qy, W, H) || !tail_is_seam(qx, qy, W, H)) continue;
+                float* rec = tail_record(tp, qx, qy);
+#pragma unroll
+                for (int t = 0; t < 9; ++t) {
+                    const int pc = ec - 1 + t % 3 - 1, pr = er - 1 + t / 3 - 1;     // the tap's pixel, tile relative
+                    if ((unsigned)pc < (unsigned)ST_W && (unsigned)pr < (unsigned)ST_H && tail_in_image(cur.ox0 + pc, cur.oy0 + pr, W, H)) {
+#pragma unroll
+                        for (int c = 0; c < 6; ++c) rec[t * 6 + c] = zt[((t * 6 + c) * ST_H + pr) * ST_W + pc];
+                    }
+                }
+            }
+            __syncthreads();
+        }
         if (more) {
             park_loads(slot ^ 1);
             wpark();
@@ -244,6 +355,39 @@ __global__ __launch_bounds__(256) void tail_combine_finish_kernel(const TailFini
         }
     }
     isr_finish_pixel(p.fin, X, Y, v);
+}
+
+// Fused form, second launch: the seam pixels (30 % of the image at 8 x 32 tiles) from their records, same order of additions.
+__global__ __launch_bounds__(256) void tail_seam_finish_kernel(const TailParams tp)
+{
+    const int W = tp.c.W, H = tp.c.H;
+    const int nrow = 2 * tp.c.tilesY * W, ncs = 2 * tp.c.tilesX;
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    int X, Y;
+    if (idx < nrow) {
+        const int rs = idx / W;
+        X = idx - rs * W; Y = (rs >> 1) * ST_H + (rs & 1) * (ST_H - 1);
+    } else {
+        const int k = idx - nrow;
+        if (k >= H * ncs) return;
+        Y = k / ncs;
+        const int cs = k - Y * ncs;
+        X = (cs >> 1) * ST_W + (cs & 1) * (ST_W - 1);
+        if ((Y & 7) == 0 || (Y & 7) == 7) return;                            // a row-seam pixel: handled above
+    }
+    if (!tail_in_image(X, Y, W, H) || !tail_is_seam(X, Y, W, H)) return;
+    const float* rec = tail_record(tp, X, Y);
+    float v[6];
+#pragma unroll
+    for (int c = 0; c < 6; ++c) v[c] = tp.bias8[c];
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+        if (tail_in_image(X + t % 3 - 1, Y + t / 3 - 1, W, H)) {
+#pragma unroll
+            for (int c = 0; c < 6; ++c) v[c] += rec[t * 6 + c];
+        }
+    }
+    isr_finish_pixel(tp.fin, X, Y, v);
 }
 
 // w8 [6][64][3][3] fp32 -> header + [q][part][h][m] units: element e of (q, h) is y6 channel 32 (q >> 1) + 16 (q & 1) + (e & 3) +
@@ -295,11 +439,25 @@ extern "C" {
 
 long long isrConvTailWeightBytes(void) { return 16 + (long long)TZ_UNITS * 16; }
 
+// 0 (default): 54 z planes + a streaming combine kernel.  1: the partials of a tile are combined in LDS, pixels whose nine
+// partials lie in their own tile are finished inside the convolution kernel, the tiles' rims go through per-pixel records and
+// tail_seam_finish_kernel -- bit-identical output, 0.9 GB less traffic per 1080p frame, and SLOWER: the convolution kernel
+// runs two 256-register waves per SIMD at the board's power limit, and 54 LDS reads + the finishing code's scattered loads,
+// divisions and nine stores per pixel inside it cost 0.25 ms where the streaming kernel needs 0.10 (0.75 vs 0.51 + 0.10 ms)
+static int g_tail_fused = 0;
+__device__ u32x4 g_tail_zero_unit[4];       // zero initialised: the source of out-of-image units of the LDS-DMA staging
+void isrDebugSetTailFused(int on) { g_tail_fused = on; }      // not part of the public header
+
+static long long tail_row_floats(int H, int W) { return 2LL * ((H + ST_H - 1) / ST_H) * W * TZ_ROWS; }
+static long long tail_col_floats(int H, int W) { return (long long)H * 2 * ((W + ST_W - 1) / ST_W) * TZ_ROWS; }
+
 long long isrConvTailWorkspaceBytes(int h, int w)
 {
     if (h <= 0 || w <= 0) return -1;
     const long long H = 4LL * h, W = 4LL * w;
-    return (long long)TZ_ROWS * (H * W + W) * 4;                             // one extra row between planes (see ops.empty_planes)
+    const long long planes = (long long)TZ_ROWS * (H * W + W) * 4;           // two-kernel form: one extra row between planes (see ops.empty_planes)
+    const long long records = (tail_row_floats((int)H, (int)W) + tail_col_floats((int)H, (int)W)) * 4;
+    return planes > records ? planes : records;
 }
 
 int isrConvTailPrepare(const float* w8, void* wz, void* stream)
@@ -318,13 +476,36 @@ int isrConvTailSupported(const float* x, int h, int w, long long xPlane)
     return 1;
 }
 
+static int tail_launch(const void* x, int packed, const void* wq6, const float* bias6, const void* wz, const float* bias8, void* workspace,
+                       const float* net_input, float* next_prev, float* rgb, int h, int w, long long xPlane,
+                       const float* shading24, int exponent, float ao_strength, int inverse_ao, int enable_specular, void* stream);
+
 int isrConvTailFinishFrame(const float* x, const void* wq6, const float* bias6, const void* wz, const float* bias8, void* workspace,
                            const float* net_input, float* next_prev, float* rgb, int h, int w, long long xPlane,
                            const float* shading24, int exponent, float ao_strength, int inverse_ao, int enable_specular, void* stream)
 {
+    return tail_launch(x, 0, wq6, bias6, wz, bias8, workspace, net_input, next_prev, rgb, h, w, xPlane, shading24, exponent, ao_strength,
+                       inverse_ao, enable_specular, stream);
+}
+
+int isrConvTailFinishFramePacked(const void* xps, const void* wq6, const float* bias6, const void* wz, const float* bias8, void* workspace,
+                                 const float* net_input, float* next_prev, float* rgb, int h, int w, long long xpsPlane,
+                                 const float* shading24, int exponent, float ao_strength, int inverse_ao, int enable_specular, void* stream)
+{
+    return tail_launch(xps, 1, wq6, bias6, wz, bias8, workspace, net_input, next_prev, rgb, h, w, xpsPlane, shading24, exponent, ao_strength,
+                       inverse_ao, enable_specular, stream);
+}
+
+static int tail_launch(const void* xin, int packed, const void* wq6, const float* bias6, const void* wz, const float* bias8, void* workspace,
+                       const float* net_input, float* next_prev, float* rgb, int h, int w, long long xPlane,
+                       const float* shading24, int exponent, float ao_strength, int inverse_ao, int enable_specular, void* stream)
+{
+    const float* x = (const float*)xin;
     if (!x || !wq6 || !wz || !bias8 || !workspace || !net_input || !next_prev || (rgb && !shading24)) return -1;
-    if (!isrConvTailSupported(x, h, w, xPlane)) return -3;
+    if (!packed && !isrConvTailSupported(x, h, w, xPlane)) return -3;
     const int H = 4 * h, W = 4 * w;
+    if (packed && (((uintptr_t)xin & 15) != 0 || xPlane < (long long)H * W || xPlane * 16 * 16 > 0x7fffffffLL
+                   || ((long long)H * W + W) * TZ_ROWS * 4 > 0x7fffffffLL)) return -3;
     TailParams tp;
     SplitConvParams& p = tp.c;
     p.x = x; p.wq = (const u32x4*)wq6; p.bias = bias6; p.residual = nullptr; p.y = nullptr;
@@ -339,26 +520,53 @@ int isrConvTailFinishFrame(const float* x, const void* wq6, const float* bias6, 
     tp.wz = (const u32x4*)wz;
     tp.z = (float*)workspace;
     tp.zPlane = H * W + W;
+    tp.xps = nullptr; tp.xpsPlane = 0; tp.zero = nullptr;
+    p.ps = nullptr; p.psPlane = 0;
+    if (packed) {
+        static u32x4* zero = nullptr;
+        if (!zero && hipGetSymbolAddress((void**)&zero, HIP_SYMBOL(g_tail_zero_unit)) != hipSuccess) return -2;
+        tp.xps = (const u32x4*)xin; tp.xpsPlane = (int)xPlane; tp.zero = zero;
+        p.x = nullptr; p.xPlane = 0; p.xImage = 0;
+    }
     static int slots = 0;
     if (!slots) {
         int dev = 0, cus = 0;
         (void)hipGetDevice(&dev);
         if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
         slots = 2 * cus;
-        (void)hipFuncSetAttribute((const void*)conv3x3_split_tail_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, T_LDS_BYTES);
+        (void)hipFuncSetAttribute((const void*)conv3x3_split_tail_kernel<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, T_LDS_BYTES);
+        (void)hipFuncSetAttribute((const void*)conv3x3_split_tail_kernel<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, T_LDS_BYTES);
+        (void)hipFuncSetAttribute((const void*)conv3x3_split_tail_kernel<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, T_LDS_BYTES);
     }
     const long long ntiles = (long long)p.tilesX * p.tilesY;
     const long long want = ntiles < slots ? ((ntiles + 7) / 8) * 8 : slots;
     hipStream_t s = (hipStream_t)stream;
     hipEvent_t e0 = nullptr, e1 = nullptr;
+    isr_fill_finish_params(tp.fin, nullptr, net_input, next_prev, rgb, h, w, shading24, exponent, ao_strength, inverse_ao, enable_specular);
+    tp.bias8 = bias8;
+    tp.rowrec = (float*)workspace;
+    tp.colrec = tp.rowrec + tail_row_floats(H, W);
+    const bool fused = g_tail_fused != 0 && !packed;
     // algorithmic flops: postblock.6 and the final 64 -> 6 layer, whose arithmetic this launch carries
     isr_profile_record(ISR_VARIANT_SPLIT_TAIL, 2.0 * 9 * 64 * (64 + 6) * (double)H * W, &e0, &e1);
-    if (e0 || e1) hipExtLaunchKernelGGL(conv3x3_split_tail_kernel, dim3((unsigned)want), dim3(S_THREADS), T_LDS_BYTES, s, e0, e1, 0, tp);
-    else hipLaunchKernelGGL(conv3x3_split_tail_kernel, dim3((unsigned)want), dim3(S_THREADS), T_LDS_BYTES, s, tp);
-    TailFinishParams fp;
-    isr_fill_finish_params(fp.fin, nullptr, net_input, next_prev, rgb, h, w, shading24, exponent, ao_strength, inverse_ao, enable_specular);
-    fp.z = tp.z; fp.zPlane = tp.zPlane; fp.bias8 = bias8;
-    hipLaunchKernelGGL(tail_combine_finish_kernel, dim3((W + 255) / 256, H), dim3(256), 0, s, fp);
+    if (fused) {
+        if (e0 || e1) hipExtLaunchKernelGGL((conv3x3_split_tail_kernel<true, false>), dim3((unsigned)want), dim3(S_THREADS), T_LDS_BYTES, s, e0, e1, 0, tp);
+        else hipLaunchKernelGGL((conv3x3_split_tail_kernel<true, false>), dim3((unsigned)want), dim3(S_THREADS), T_LDS_BYTES, s, tp);
+        const long long threads = 2LL * p.tilesY * W + (long long)H * 2 * p.tilesX;
+        hipLaunchKernelGGL(tail_seam_finish_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, s, tp);
+    } else {
+        if (packed) {
+            if (e0 || e1) hipExtLaunchKernelGGL((conv3x3_split_tail_kernel<false, true>), dim3((unsigned)want), dim3(S_THREADS), T_LDS_BYTES, s, e0, e1, 0, tp);
+            else hipLaunchKernelGGL((conv3x3_split_tail_kernel<false, true>), dim3((unsigned)want), dim3(S_THREADS), T_LDS_BYTES, s, tp);
+        } else {
+            if (e0 || e1) hipExtLaunchKernelGGL((conv3x3_split_tail_kernel<false, false>), dim3((unsigned)want), dim3(S_THREADS), T_LDS_BYTES, s, e0, e1, 0, tp);
+            else hipLaunchKernelGGL((conv3x3_split_tail_kernel<false, false>), dim3((unsigned)want), dim3(S_THREADS), T_LDS_BYTES, s, tp);
+        }
+        TailFinishParams fp;
+        fp.fin = tp.fin;
+        fp.z = tp.z; fp.zPlane = tp.zPlane; fp.bias8 = bias8;
+        hipLaunchKernelGGL(tail_combine_finish_kernel, dim3((W + 255) / 256, H), dim3(256), 0, s, fp);
+    }
     return hipGetLastError() == hipSuccess ? 0 : -2;
 }
 

@@ -44,7 +44,23 @@ struct SplitConvParams {
     int quads;                    // 1: W, the plane stride of x and its base address allow aligned dwordx4 staging
     int dbg;                      // diagnostics: 1 skip the MFMAs, 2 skip the staging loads, 4 skip the stores
     unsigned long long* stamps;   // diagnostics: per-workgroup s_memrealtime stamps (100 MHz, one clock for the whole chip), or NULL
+    // PACKED-SPLIT output (ps != NULL; y unused): the activations as the NEXT split-operand layer's LDS image, i.e. already
+    // split into (hi, lo') fp16 pairs, eight channels of one pixel per 16-byte unit: ps[part: hi | lo][Cout / 8 groups][psPlane
+    // units, pixel y W + x].  The consumer stages k-steps with plain 16-byte copies (LDS-DMA); same values as converting the
+    // fp32 tensor on the way in, so results do not change.  Single image, Cout a multiple of 8, no residual.
+    u32x4* ps; int psPlane;
 };
+
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+typedef __attribute__((address_space(1))) const void isr_gvoid_t;
+typedef __attribute__((address_space(3))) void isr_lvoid_t;
+
+// LDS-DMA (global_load_lds_dwordx4): 64 lanes x 16 bytes, lane l's bytes land at dst_wave_base + 16 l (dst is wave uniform,
+// src per lane).  The data is ordered for a ds_read by the next __syncthreads() (hipcc waits vmcnt(0) in front of it).
+__device__ __forceinline__ void isr_dma16(const u32x4* src, u32x4* dst_wave_base)
+{
+    __builtin_amdgcn_global_load_lds((isr_gvoid_t*)src, (isr_lvoid_t*)dst_wave_base, 16, 0, 0);
+}
 
 // v = hi + lo (+ <= 2^-22 |v|): hi = RN16(v), lo = RN16(v - hi); the subtraction is exact in fp32
 __device__ __forceinline__ void split16(float v, _Float16& hi, _Float16& lo)
@@ -68,6 +84,52 @@ __device__ __forceinline__ f32x16 mfma16(f16x8 a, f16x8 b, f32x16 c) { return __
 
 // Epilogue shared by the split kernels: acc * 2^-S + bias, activation, residual / gate, store.  D row (cout) =
 // (reg & 3) + 8 * (reg >> 2) + 4 * h, column (pixel) = j.  The wide path transposes through the (idle) patch buffer.
+// Packed-split epilogue: act(acc 2^-S + bias) of this wave's two rows as (hi, lo') units straight from the D layout -- lane (j, h)
+// holds channels 8 g + 4 h .. + 3 of pixel j for the four groups g of a 32-channel block: 8 bytes of the unit, the lane pair
+// (j, 0), (j, 1) writes the 16, a wave instruction 512 contiguous bytes.  No LDS transposition.
+__device__ __forceinline__ void split_epilogue_ps(const SplitConvParams& p, f32x16 (&acc)[2][2], int oy0, int ox0, int co0, bool second,
+                                                  int wave, int j, int h)
+{
+    const float unscale = reinterpret_cast<const float*>(p.wq)[1];
+    const int groups = p.Cout >> 3;
+    const rsrc_t prs = __builtin_amdgcn_make_buffer_rsrc(p.ps, 0, (int)((size_t)2 * groups * p.psPlane * 16), 0x00020000);
+    const int ox = ox0 + j;
+    float bv[2][16];                                                         // all bias values first: one latency, not 64
+#pragma unroll
+    for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+        for (int i = 0; i < 16; ++i)
+            bv[cb][i] = p.bias ? p.bias[min(co0 + cb * 32 + 8 * (i >> 2) + 4 * h + (i & 3), p.Cout - 1)] : 0.0f;
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+        const int oy = oy0 + wave * 2 + r;
+        const unsigned voff = (oy < p.H && ox < p.W) ? (unsigned)(oy * p.W + ox) * 16u + 8u * (unsigned)h : BAD_OFFSET;
+#pragma unroll
+        for (int cb = 0; cb < 2; ++cb) {
+            if (cb == 1 && !second) break;
+#pragma unroll
+            for (int gi = 0; gi < 4; ++gi) {
+                f16x4 th, tl;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    float v = acc[cb][r][4 * gi + e] * unscale + bv[cb][4 * gi + e];
+                    if (p.act == ISR_ACT_RELU) v = v > 0.f ? v : 0.f;
+                    else if (p.act == ISR_ACT_LEAKY) v = v > 0.f ? v : v * p.slope;
+                    _Float16 a, b;
+                    split16x(v, a, b);
+                    th[e] = a; tl[e] = b;
+                }
+                const int g = (co0 >> 3) + cb * 4 + gi;
+                const bool live = g < groups;
+                __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, th), prs, (int)(live ? voff : BAD_OFFSET), g * p.psPlane * 16, 0);
+                __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, tl), prs, (int)(live ? voff : BAD_OFFSET), (groups + g) * p.psPlane * 16, 0);
+            }
+        }
+    }
+}
+
+// WIDE_ONLY: the caller guarantees W and both plane strides are multiples of 4 (the per-element path is not compiled in).
+template <bool WIDE_ONLY = false>
 __device__ __forceinline__ void split_epilogue(const SplitConvParams& p, f32x16 (&acc)[2][2], u32x4* patch, int n, int oy0, int ox0, int co0,
                                                bool second, int lane, int wave, int j, int h)
 {
@@ -83,7 +145,7 @@ __device__ __forceinline__ void split_epilogue(const SplitConvParams& p, f32x16 
         for (int i = 0; i < 16; ++i)
             bv[cb][i] = p.bias ? p.bias[min(co0 + cb * 32 + (i & 3) + 8 * (i >> 2) + 4 * h, p.Cout - 1)] : 0.0f;
     if (p.dbg & 4) {
-    } else if (((p.W | p.yPlane | p.rPlane) & 3) == 0) {
+    } else if (WIDE_ONLY || ((p.W | p.yPlane | p.rPlane) & 3) == 0) {
         // wide path: each wave transposes one output row (64 couts x 32 pixels) through 8 KB of the now idle patch, so
         // that a lane owns 4 consecutive pixels of one channel and the stores are dwordx4 (4x fewer instructions)
         float* tr = reinterpret_cast<float*>(patch) + wave * (64 * 32);

@@ -84,11 +84,12 @@ class EnhanceNet(nn.Module):
     def _fused_ok(self):
         return (not self.use_bn) and self.upsample == 'bilinear'
 
-    def forward_features(self, inputs, last_layer=True, last_two=True):
+    def forward_features(self, inputs, last_layer=True, last_two=True, last_three=True):
         """The convolutional trunk only: the tensor ``_recon_image`` receives (used by the fused
         frame pipeline, which folds the reconstruction into its finishing kernel).  ``last_layer=False`` stops
         before the final 64 -> 6 convolution (``self.postblock[8]``), which the pipeline fuses with the finishing;
-        ``last_two=False`` stops before ``self.postblock[6]`` as well (the fused 1080p tail, ``ops.tail_conv_finish``)."""
+        ``last_two=False`` stops before ``self.postblock[6]`` as well (the fused 1080p tail, ``ops.tail_conv_finish``),
+        ``last_three=False`` before ``self.postblock[4]`` (whose output the pipeline hands to the tail packed-split)."""
         assert self._fused_ok()
         c = ops.conv3x3
         pre = self.preblock[0]
@@ -97,6 +98,8 @@ class EnhanceNet(nn.Module):
             f = ops.residual_block(f, block[0].weight, block[0].bias, block[2].weight, block[2].bias)
         p = self.postblock
         f = c(f, p[1].weight, p[1].bias, act='relu', upsample2x=True)
+        if not last_three:
+            return f
         f = c(f, p[4].weight, p[4].bias, act='relu', upsample2x=True)
         if not last_two:
             return f

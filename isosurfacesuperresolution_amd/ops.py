@@ -96,6 +96,13 @@ def _sr():
         lib.isrConvTailSupported.argtypes = [vp, ci, ci, ll]; lib.isrConvTailSupported.restype = ci
         lib.isrConvTailFinishFrame.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, vp, ci, ci, ll, vp, ci, cf, ci, ci, vp]
         lib.isrConvTailFinishFrame.restype = ci
+        lib.isrConv3x3ForwardSplitPacked.argtypes = [vp, vp, vp, vp, ci, ci, ci, ci, ci, cf, ci, ll, ll, vp]
+        lib.isrConv3x3ForwardSplitPacked.restype = ci
+        lib.isrConvTailFinishFramePacked.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, vp, ci, ci, ll, vp, ci, cf, ci, ci, vp]
+        lib.isrConvTailFinishFramePacked.restype = ci
+        lib.isrResBlockSplitWorkspaceBytes.argtypes = []; lib.isrResBlockSplitWorkspaceBytes.restype = ll
+        lib.isrResBlockSplitSupported.argtypes = [vp, ci, ci, ll, ll]; lib.isrResBlockSplitSupported.restype = ci
+        lib.isrResBlockSplit.argtypes = [vp, vp, vp, vp, vp, vp, vp, ci, ci, ll, ll, vp]; lib.isrResBlockSplit.restype = ci
         lib.isrProfileEnable.argtypes = [ci]; lib.isrProfileEnable.restype = ci
         lib.isrProfileCount.argtypes = []; lib.isrProfileCount.restype = ci
         lib.isrProfileGet.argtypes = [ci, vp, vp, vp]; lib.isrProfileGet.restype = ci
@@ -161,7 +168,7 @@ VARIANT_NAMES = {6: "conv3x3_small_cout_kernel", 2: "conv3x3_fwd_kernel<1,false>
                  10: "conv3x3_fwd2_kernel<false,1>", 11: "conv3x3_fwd2_kernel<true,1>", 12: "conv3x3_rowsplit_kernel",
                  13: "conv3x3_split_kernel<false>", 14: "conv3x3_split_kernel<true>",
                  15: "conv3x3_split_stream_kernel", 16: "conv3x3_split_wide_kernel", 17: "conv3x3_split_rows2_kernel",
-                 18: "conv3x3_split_tail_kernel"}
+                 18: "conv3x3_split_tail_kernel", 19: "resblock_split_kernel"}
 
 
 def profile_enable(on):
@@ -635,11 +642,49 @@ class _ResidualBlockFunction(torch.autograd.Function):
         return gx, gw1, gb1, gw2, gb2
 
 
+# Inference: the whole block in ONE launch (csrc/sr_conv_block.hip) -- bit-identical to the two split-operand launches
+BLOCK_FUSION = False
+BLOCK_FUSION_MIN_TILES = 256       # below that the persistent grid is not filled; the per-layer kernels' small-image forms take over
+_block_ws = {}
+
+
+def _block_supported(x, w1, w2):
+    if not (BLOCK_FUSION and SPLIT_F16 and not FAST_F16 and x.is_cuda and x.dtype == torch.float32 and x.dim() == 4 and x.shape[0] == 1):
+        return False
+    if tuple(w1.shape) != (64, 64, 3, 3) or tuple(w2.shape) != (64, 64, 3, 3) or x.shape[1] != 64:
+        return False
+    if ((x.shape[2] + 7) // 8) * ((x.shape[3] + 31) // 32) < BLOCK_FUSION_MIN_TILES:
+        return False
+    xs, xp, _ = _plane_strides(x)
+    return xs is x and bool(_sr().isrResBlockSplitSupported(_ptr(x), x.shape[2], x.shape[3], xp, x.shape[2] * x.shape[3] + plane_pad(x.shape[2], x.shape[3])))
+
+
+def residual_block_fused(x, w1, b1, w2, b2):
+    """x + conv3x3(relu(conv3x3(x, w1, b1)), w2, b2) for one [1, 64, H, W] image in one launch of ``isrResBlockSplit``."""
+    lib = _sr()
+    x, xp, _ = _plane_strides(x)
+    _, _, h, w = x.shape
+    key = (x.device, torch.cuda.current_stream().cuda_stream)
+    ws = _block_ws.get(key)
+    if ws is None:
+        ws = torch.empty(lib.isrResBlockSplitWorkspaceBytes(), dtype=torch.uint8, device=x.device)
+        _block_ws[key] = ws
+    y = empty_planes(1, 64, h, w, x.device)
+    rc = lib.isrResBlockSplit(_ptr(x), _ptr(_prepare_split(w1)), _ptr(b1.detach().contiguous() if b1 is not None else None),
+                              _ptr(_prepare_split(w2)), _ptr(b2.detach().contiguous() if b2 is not None else None), _ptr(y), _ptr(ws),
+                              h, w, xp, y.stride(1), _stream())
+    if rc != 0:
+        raise RuntimeError("isrResBlockSplit failed (%d)" % rc)
+    return y
+
+
 def residual_block(x, w1, b1, w2, b2):
     """x + conv3x3(relu(conv3x3(x, w1, b1)), w2, b2), 64 -> 64 -> 64 channels."""
     needs_grad = torch.is_grad_enabled() and any(t is not None and t.requires_grad for t in (x, w1, b1, w2, b2))
     if x.is_cuda and needs_grad and x.dtype == torch.float32 and w1.shape[0] == w1.shape[1] == w2.shape[0] == w2.shape[1]:
         return _ResidualBlockFunction.apply(x, w1, b1, w2, b2)
+    if not needs_grad and _block_supported(x, w1, w2):
+        return residual_block_fused(x, w1, b1, w2, b2)
     return conv3x3(conv3x3(x, w1, b1, act='relu'), w2, b2, residual=x)
 
 
@@ -1052,33 +1097,91 @@ def tail_supported(features, weight6, weight8):
     return f is features and bool(_sr().isrConvTailSupported(_ptr(features), features.shape[2] // 4, features.shape[3] // 4, xp))
 
 
+class PackedSplit:
+    """An activation tensor [1, C, H, W] in PACKED-SPLIT form: every value already split into the (hi, lo') fp16 pair the
+    split-operand kernels multiply, eight channels of one pixel per 16-byte unit, ``data[part: hi | lo][C / 8][plane units]``
+    (csrc/sr_split_common.h, SplitConvParams::ps).  Produced by ``conv3x3_split_packed``, consumed by ``tail_conv_finish``:
+    the consumer stages its k-steps with plain 16-byte copies (LDS-DMA) -- same numbers as converting an fp32 tensor on the
+    way in, without the conversions, the staging registers and the producer's LDS transposition."""
+
+    def __init__(self, data, channels, h, w, plane):
+        self.data, self.channels, self.h, self.w, self.plane = data, channels, h, w, plane
+
+    def to_float(self):
+        """The fp32 tensor this stands for, hi + lo' 2^-11 (tests)."""
+        u = self.data.view(torch.float16).view(2, self.channels // 8, self.plane, 8)[:, :, :self.h * self.w].float()
+        v = u[0] + u[1] * (2.0 ** -11)
+        return v.permute(0, 2, 1).reshape(1, self.channels, self.h, self.w)
+
+
+TAIL_PACKED = True       # hand postblock.4's output to the fused tail packed-split (frame pipeline)
+
+
+def conv3x3_split_packed(x, weight, bias=None, act='relu', slope=0.01, upsample2x=False):
+    """``conv3x3_split`` (no autograd, one image, Cout a multiple of 8) whose result is written PACKED-SPLIT."""
+    lib = _sr()
+    x, xp, _ = _plane_strides(x)
+    assert x.shape[0] == 1 and weight.shape[0] % 8 == 0
+    cin, cout = weight.shape[1], weight.shape[0]
+    h, w = (2 * x.shape[2], 2 * x.shape[3]) if upsample2x else (x.shape[2], x.shape[3])
+    if upsample2x and not lib.isrConvF16SupportsUpsample(x.data_ptr(), x.shape[3], xp, cin * xp):
+        raise ValueError("conv3x3_split_packed: the fused upsampling needs 16-byte aligned low-resolution rows")
+    plane = h * w + plane_pad(h, w)
+    data = torch.empty(2 * (cout // 8) * plane * 4, dtype=torch.int32, device=x.device)
+    rc = lib.isrConv3x3ForwardSplitPacked(_ptr(x), _ptr(_prepare_split(weight)), _ptr(bias.detach().contiguous() if bias is not None else None),
+                                          _ptr(data), cin, h, w, cout, ACT_CODES[act], float(slope), 1 if upsample2x else 0, xp, plane, _stream())
+    if rc != 0:
+        raise RuntimeError("isrConv3x3ForwardSplitPacked failed (%d)" % rc)
+    return PackedSplit(data, cout, h, w, plane)
+
+
+def packed_supported(x, weight, upsample2x):
+    """Can ``conv3x3_split_packed`` + the packed tail take this layer?"""
+    if not (TAIL_PACKED and x.is_cuda and x.dtype == torch.float32 and x.shape[0] == 1 and weight.shape[0] == 64):
+        return False
+    x2, xp, _ = _plane_strides(x)
+    if x2 is not x:
+        return False
+    h, w = (2 * x.shape[2], 2 * x.shape[3]) if upsample2x else (x.shape[2], x.shape[3])
+    if h % 4 or w % 4 or 16 * 16 * (h * w + plane_pad(h, w)) >= 2 ** 31:
+        return False
+    return (not upsample2x) or bool(_sr().isrConvF16SupportsUpsample(x.data_ptr(), x.shape[3], xp, x.shape[1] * xp))
+
+
 def tail_conv_finish(features, weight6, bias6, weight8, bias8, net_input, shading=None):
     """features [1,64,4h,4w] (the output of postblock.4; channel planes may be padded) -> relu(conv3x3(., weight6) + bias6)
     -> conv3x3(., weight8) + bias8 -> ``finish_frame``: (next_prev [1,6,4h,4w], rgb [1,3,4h,4w] or None) in two launches
     (``isrConvTailFinishFrame``); the 64-channel tensor between the two convolutions never exists in memory."""
     lib = _sr()
-    features, xp, _ = _plane_strides(features)
+    packed = isinstance(features, PackedSplit)
+    if packed:
+        H, W, xp, dev = features.h, features.w, features.plane, features.data.device
+        assert features.channels == 64
+    else:
+        features, xp, _ = _plane_strides(features)
+        _, _, H, W = features.shape
+        dev = features.device
     net_input = net_input.contiguous()
-    _, _, H, W = features.shape
     h, w = H // 4, W // 4
     wq6 = _prepare_split(weight6)
     wz = _prepare_tail(weight8)
-    key = (features.device, h, w, torch.cuda.current_stream().cuda_stream)
+    key = (dev, h, w, torch.cuda.current_stream().cuda_stream)
     ws = _tail_ws.get(key)
     if ws is None:
-        ws = torch.empty(lib.isrConvTailWorkspaceBytes(h, w), dtype=torch.uint8, device=features.device)
+        ws = torch.empty(lib.isrConvTailWorkspaceBytes(h, w), dtype=torch.uint8, device=dev)
         _tail_ws[key] = ws
-    nxt = torch.empty((1, 6, H, W), dtype=torch.float32, device=features.device)
+    nxt = torch.empty((1, 6, H, W), dtype=torch.float32, device=dev)
     rgb, params = None, None
     exponent, ao, inv, spec = 1, 0.0, 0, 0
     if shading is not None:
-        rgb = torch.empty((1, 3, H, W), dtype=torch.float32, device=features.device)
+        rgb = torch.empty((1, 3, H, W), dtype=torch.float32, device=dev)
         params = (ctypes.c_float * 18)(*shading.packed_parameters())
         exponent, ao = int(shading._specular_exponent), float(shading._ao)
         inv, spec = int(bool(shading.inverse_ao)), int(bool(shading.enable_specular))
     b6 = bias6.detach().contiguous() if bias6 is not None else None
-    b8 = bias8.detach().contiguous() if bias8 is not None else torch.zeros(6, dtype=torch.float32, device=features.device)
-    rc = lib.isrConvTailFinishFrame(_ptr(features), _ptr(wq6), _ptr(b6), _ptr(wz), _ptr(b8), _ptr(ws), _ptr(net_input), _ptr(nxt), _ptr(rgb),
+    b8 = bias8.detach().contiguous() if bias8 is not None else torch.zeros(6, dtype=torch.float32, device=dev)
+    fn = lib.isrConvTailFinishFramePacked if packed else lib.isrConvTailFinishFrame
+    rc = fn(_ptr(features.data if packed else features), _ptr(wq6), _ptr(b6), _ptr(wz), _ptr(b8), _ptr(ws), _ptr(net_input), _ptr(nxt), _ptr(rgb),
                                     h, w, xp, params, exponent, ao, inv, spec, _stream())
     if rc != 0:
         raise RuntimeError("isrConvTailFinishFrame failed (%d)" % rc)

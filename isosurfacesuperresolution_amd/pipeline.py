@@ -170,9 +170,19 @@ class SuperResolutionPipeline:
             last = net.postblock[8]
             six = net.postblock[6]
             f4 = None
-            if last.weight.shape[0] == 6 and ops.TAIL_FUSION and ops.SPLIT_F16 and not ops.FAST_F16:
+            tail = last.weight.shape[0] == 6 and ops.TAIL_FUSION and ops.SPLIT_F16 and not ops.FAST_F16
+            four = net.postblock[4]
+            if tail and ops.TAIL_PACKED and tuple(six.weight.shape) == (64, 64, 3, 3) and tuple(last.weight.shape) == (6, 64, 3, 3):
+                f2 = net.forward_features(x, last_three=False)
+                if ops.packed_supported(f2, four.weight, True):
+                    # postblock.4 writes its output packed-split (already the (hi, lo') units postblock.6 multiplies), the tail
+                    # stages them by LDS-DMA: no conversion on the way in, no LDS transposition on the way out
+                    f4 = ops.conv3x3_split_packed(f2, four.weight, four.bias, act='relu', upsample2x=True)
+                else:
+                    f4 = ops.conv3x3(f2, four.weight, four.bias, act='relu', upsample2x=True)
+            elif tail:
                 f4 = net.forward_features(x, last_two=False)
-            if f4 is not None and ops.tail_supported(f4, six.weight, last.weight):
+            if isinstance(f4, ops.PackedSplit) or (f4 is not None and ops.tail_supported(f4, six.weight, last.weight)):
                 # postblock.6, postblock.8 and the frame's finishing in two launches; the 64-channel 1080p tensor between the
                 # two convolutions never goes to memory (csrc/sr_conv_tail.hip)
                 raw, rgb = ops.tail_conv_finish(f4, six.weight, six.bias, last.weight, last.bias, x, self.shading)

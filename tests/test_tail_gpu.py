@@ -56,6 +56,65 @@ def test_tail_matches_the_three_kernel_path_and_fp64(h, w):
     assert torch.isfinite(raw_t).all() and torch.isfinite(rgb_t).all()
 
 
+@pytest.mark.parametrize("h,w", [(2, 8), (6, 8), (23, 37), (30, 52), (67, 120), (270, 480)])
+def test_fused_form_equals_the_two_kernel_form_bit_for_bit(h, w):
+    """The default form finishes every pixel whose nine partials lie in its own tile inside the convolution kernel and
+    assembles the others (the tiles' rims) from per-pixel records; the two-kernel form writes all 54 partial planes and adds
+    them in a streaming kernel.  Same partials, same order of additions: equal outputs, at ragged and full sizes."""
+    import ctypes
+    from isosurfacesuperresolution_amd import ops
+    lib = ops._sr()
+    lib.isrDebugSetTailFused.argtypes = [ctypes.c_int]
+    f4, w6, b6, w8, b8, x, sh = _setup(h, w, seed=h * 31 + w)
+    out = {}
+    try:
+        for fused in (0, 1, 0, 1):
+            lib.isrDebugSetTailFused(fused)
+            with torch.no_grad():
+                raw, rgb = ops.tail_conv_finish(f4, w6, b6, w8, b8, x, sh)
+            torch.cuda.synchronize()
+            if fused in out:
+                assert torch.equal(out[fused][0], raw) and torch.equal(out[fused][1], rgb)      # and deterministic
+            out[fused] = (raw, rgb)
+    finally:
+        lib.isrDebugSetTailFused(0)
+    assert torch.equal(out[1][0], out[0][0]), (out[1][0] - out[0][0]).abs().max().item()
+    # (the shading arithmetic is inlined into different kernels, where the compiler may contract different multiply-adds)
+    assert (out[1][1] - out[0][1]).abs().max().item() <= 1e-6
+
+
+@pytest.mark.parametrize("h,w", [(4, 8), (11, 20), (30, 52), (135, 240)])
+def test_packed_split_producer_and_packed_tail(h, w):
+    """postblock.4 can write its output PACKED-SPLIT (the (hi, lo') fp16 units the next layer multiplies) and the tail stages that
+    by LDS-DMA: the units are the split of exactly the fp32 values the ordinary launch stores, and the tail's output is bit for
+    bit the one it computes from the fp32 tensor."""
+    from isosurfacesuperresolution_amd import ops
+    g = torch.Generator().manual_seed(h * 13 + w)
+    f2 = torch.rand(1, 64, 2 * h, 2 * w, generator=g).cuda()
+    w4 = ((torch.rand(64, 64, 3, 3, generator=g) - 0.5) * 0.08).cuda()
+    b4 = ((torch.rand(64, generator=g) - 0.5) * 0.1).cuda()
+    _, w6, b6, w8, b8, x, sh = _setup(h, w, seed=3)
+    assert ops.packed_supported(f2, w4, True)
+    with torch.no_grad():
+        f4 = ops.conv3x3_split(f2, w4, b4, act='relu', upsample2x=True)
+        f4p = ops.conv3x3_split_packed(f2, w4, b4, act='relu', upsample2x=True)
+        back = f4p.to_float()
+        # hi + lo' 2^-11 carries 22 significand bits of the fp32 value (and is exactly it for most values)
+        assert (back - f4).abs().max().item() <= 2.0 ** -21 * max(1.0, f4.abs().max().item())
+        hi = f4p.data.view(torch.float16).view(2, 8, f4p.plane, 8)[0, :, :16 * h * w].float().permute(0, 2, 1).reshape(1, 64, 4 * h, 4 * w)
+        assert torch.equal(hi, f4.half().float())                                      # hi = RN16(value), bit for bit
+        raw_a, rgb_a = ops.tail_conv_finish(f4, w6, b6, w8, b8, x, sh)
+        raw_b, rgb_b = ops.tail_conv_finish(f4p, w6, b6, w8, b8, x, sh)
+        raw_c, _ = ops.tail_conv_finish(f4p, w6, b6, w8, b8, x, sh)
+    torch.cuda.synchronize()
+    assert torch.equal(raw_a, raw_b) and torch.equal(rgb_a, rgb_b) and torch.equal(raw_b, raw_c)
+    # plain (non-upsampling) producer as well
+    with torch.no_grad():
+        f5 = ops.conv3x3_split(f4, w6, b6, act='relu')
+        f5p = ops.conv3x3_split_packed(f4, w6, b6, act='relu')
+    assert (f5p.to_float() - f5).abs().max().item() <= 2.0 ** -21 * max(1.0, f5.abs().max().item())
+
+
 def test_tail_with_padded_planes_and_without_shading_or_bias():
     from isosurfacesuperresolution_amd import ops
     h, w = 12, 20
@@ -104,8 +163,9 @@ def test_pipeline_uses_the_fused_tail_and_matches_the_unfused_frame():
     renderer.load_dense(V.ejecta(64))
     origins = [V.orbit_camera(k) for k in range(3)]
     frames = {}
-    for fused in (True, False):
-        ops.TAIL_FUSION = fused
+    for fused in (True, False, "unpacked"):
+        ops.TAIL_FUSION = bool(fused)
+        ops.TAIL_PACKED = fused is True
         try:
             pipe = SuperResolutionPipeline(renderer, lm, default_shading("cuda", 30.0), (96, 56))
             pipe.set_static(fov=30.0, isovalue=0.34)
@@ -118,9 +178,12 @@ def test_pipeline_uses_the_fused_tail_and_matches_the_unfused_frame():
             ops.profile_enable(False)
         finally:
             ops.TAIL_FUSION = True
-        assert ("conv3x3_split_tail_kernel" in names) == fused
+            ops.TAIL_PACKED = True
+        assert ("conv3x3_split_tail_kernel" in names) == bool(fused)
         assert ("conv3x3_small_cout_kernel" in names) == (not fused)
         frames[fused] = out
+    for (rgb_a, raw_a), (rgb_b, raw_b) in zip(frames[True], frames["unpacked"]):
+        assert torch.equal(raw_a, raw_b) and torch.equal(rgb_a, rgb_b)               # packed-split hand-over: nothing changes
     for (rgb_a, raw_a), (rgb_b, raw_b) in zip(frames[True], frames[False]):
         assert (raw_a - raw_b).abs().max().item() <= 1e-4 and (rgb_a - rgb_b).abs().max().item() <= 1e-4
     assert (frames[True][0][1] - frames[False][0][1]).abs().max().item() <= 2e-5      # first frame: no recurrence yet
