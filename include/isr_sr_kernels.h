@@ -231,6 +231,13 @@ int isrConvSmallFinishFrame(const float* x, const float* w8, const float* bias8,
 int isrConv3x3ForwardSplitPacked(const float* x, const void* wq, const float* bias, void* ps, int Cin, int H, int W, int Cout,
                                  int act, float slope, int upsample2x, long long xPlane, long long psPlane, void* stream);
 
+/* ... and the consumer side for plain layers: the split-operand convolution of a PACKED-SPLIT input xps (Cin / 8 groups, xpsPlane
+ * units per plane, one image), result as isrConv3x3ForwardSplit (y fp32, planes yPlane floats apart, optional residual with rPlane)
+ * or, with packed_out != 0, packed-split again (y = ps, yPlane = its plane stride in units, no residual). */
+int isrConv3x3ForwardSplitFromPacked(const void* xps, const void* wq, const float* bias, const float* residual, void* y, int packed_out,
+                                     int Cin, int H, int W, int Cout, int act, float slope, long long xpsPlane, long long yPlane, long long rPlane,
+                                     void* stream);
+
 /* One residual block of the trunk, y = x + conv2(relu(conv1(x) + bias1)) + bias2 (64 -> 64 -> 64 channels, one image;
  * models/enhancenet.py:18-33,108-112,139-141), in ONE launch on the split-operand arithmetic: the same products in the same
  * order as two calls of isrConv3x3ForwardSplit (bit-identical result).  The intermediate tensor stays in a per-workgroup

@@ -43,6 +43,7 @@ struct BlockParams {
     const float* bias1; const float* bias2;
     u32x4* scratch;               // gridDim.x * SCR_UNITS units
     int H, W, xPlane, yPlane, tilesX, tilesY;
+    unsigned* absmax;             // range guard (SplitConvParams::absmax): over the intermediate t AND the output
     unsigned long long* stamps;   // diagnostics: 8 s_memrealtime stamps (100 MHz, chip-wide clock) per workgroup, first tile; or NULL
     int dbg;                      // diagnostics: 1 skip conv1's MFMAs, 2 skip conv2's MFMAs, 4 skip the scratch stores, 8 skip the DMA
 };
@@ -148,7 +149,7 @@ __global__ __launch_bounds__(B_THREADS, 2) void resblock_split_kernel(const Bloc
     p2.xPlane = p.xPlane; p2.yPlane = p.yPlane; p2.rPlane = p.xPlane;
     p2.xImage = 0; p2.yImage = 0; p2.rImage = 0;
     p2.ksteps = 4; p2.coutPad = 64; p2.cgroups = 1; p2.tilesX = p.tilesX; p2.tilesY = p.tilesY;
-    p2.act = ISR_ACT_NONE; p2.slope = 0.0f; p2.Hin = p.H; p2.Win = p.W; p2.quads = 1; p2.dbg = 0; p2.stamps = nullptr; p2.ps = nullptr; p2.psPlane = 0;
+    p2.act = ISR_ACT_NONE; p2.slope = 0.0f; p2.Hin = p.H; p2.Win = p.W; p2.quads = 1; p2.dbg = 0; p2.stamps = nullptr; p2.ps = nullptr; p2.psPlane = 0; p2.xps = nullptr; p2.xpsPlane = 0; p2.zero = nullptr; p2.absmax = p.absmax;
 
     // The two workgroups of a CU share its SIMDs, and issue arbitration prefers the OLDER wave: the first-dispatched workgroup
     // of a CU runs near full speed, the second (in practice blockIdx >= half the grid) gets the leftovers and finishes ~20 us
@@ -215,6 +216,7 @@ __global__ __launch_bounds__(B_THREADS, 2) void resblock_split_kernel(const Bloc
         if (p.stamps && t == jw) st[2] = __builtin_amdgcn_s_memrealtime();
         wpark();                                                             // conv2 k-step 0 weights
         const rsrc_t srs = __builtin_amdgcn_make_buffer_rsrc(scr, 0, SCR_UNITS * 16, 0x00020000);
+        unsigned tmag = 0u;
 #pragma unroll
         for (int b = 0; b < B_BLOCKS; ++b) {
             const int q = (wave * B_BLOCKS + b) * 32 + j;
@@ -241,6 +243,7 @@ __global__ __launch_bounds__(B_THREADS, 2) void resblock_split_kernel(const Bloc
                         _Float16 a, bo;
                         split16x(val, a, bo);
                         th[e] = a; tl[e] = bo;
+                        tmag = isr_umax(tmag, isr_mag(val));
                     }
                     const int g = cb * 4 + gi;
                     __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(uint2_t, th), srs, (int)voff, g * R1_PIX * 16, 0);
@@ -251,6 +254,7 @@ __global__ __launch_bounds__(B_THREADS, 2) void resblock_split_kernel(const Bloc
                     }
                 }
         }
+        isr_range_note(p.absmax, tmag);
         __syncthreads();                                                     // scratch stores done and visible to the workgroup; slot 0 and weights in place
         if (p.stamps && t == jw) st[3] = __builtin_amdgcn_s_memrealtime();
         // ================= conv2 on the 8 x 32 tile, k-steps streamed from the scratch ==========================================
@@ -336,6 +340,7 @@ int isrResBlockSplit(const float* x, const void* wq1, const float* bias1, const 
     p.H = H; p.W = W; p.xPlane = (int)xPlane; p.yPlane = (int)yPlane;
     p.tilesX = (W + ST_W - 1) / ST_W; p.tilesY = (H + ST_H - 1) / ST_H;
     p.stamps = g_block_stamps; p.dbg = g_block_dbg;
+    p.absmax = isr_take_range_flag();
     const int slots = block_slots();
     const long long ntiles = (long long)p.tilesX * p.tilesY;
     const long long want = ntiles < slots ? ((ntiles + 7) / 8) * 8 : slots;

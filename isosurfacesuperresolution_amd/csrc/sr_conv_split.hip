@@ -199,6 +199,23 @@ __global__ __launch_bounds__(S_THREADS, 2) void conv3x3_split_kernel(const Split
             }
             __syncthreads();                                                 // tmp is free: the weights may land on it
         } else if (p.dbg & 2) {
+        } else if (p.xps) {
+            // packed-split input: the chunk's units are already what the slot holds -- 2 parts x 1360 units = 44 wave-wide 1 KB
+            // pieces, 11 per wave, by LDS-DMA (no registers, no conversion; they land before the barrier below)
+            const int groups = p.Cin >> 3;
+#pragma unroll
+            for (int d = 0; d < 11; ++d) {
+                const int piece = wave + 4 * d;                              // 0 .. 43: 22 pieces per part
+                const int part = piece / 22, pc = piece - part * 22, off = pc * 64 + lane;
+                if (off < S_PART) {
+                    const int g = off / SP_PIX, pix = off - g * SP_PIX;
+                    const int r = pix / SP_W, c = pix - r * SP_W;
+                    const int iy = oy0 + r - 1, ix = ox0 + c - 1, gg = (cin0 >> 3) + g;
+                    const bool ok = gg < groups && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
+                    const u32x4* src = ok ? p.xps + ((size_t)(part * groups + gg) * p.xpsPlane + (size_t)iy * p.W + ix) : p.zero;
+                    isr_dma16(src, patch + part * S_PART + pc * 64);
+                }
+            }
         } else if (p.quads) {
             // rows of 4-pixel groups aligned to 16 bytes (W, plane stride and tile origin are multiples of 4): one
             // dwordx4 per channel covers 4 pixels.  Unit = (channel group g, patch row r, quad q); quad q holds
@@ -588,6 +605,7 @@ __global__ __launch_bounds__(W_THREADS, 1) void conv3x3_split_wide_kernel(const 
     };
 
     f32x16 acc[4];
+    unsigned wmag = 0u;
     // one k-step of this wave: 9 taps x 4 rows x 3 products, fragments double-buffered by hand; `mid` runs after two
     // thirds of the steps (the parking of the next k-step's operands)
     auto kstep = [&](int slot, int buf, bool active, auto&& mid) {
@@ -697,6 +715,7 @@ __global__ __launch_bounds__(W_THREADS, 1) void conv3x3_split_wide_kernel(const 
                                 val.x += rf.x; val.y += rf.y; val.z += rf.z; val.w += rf.w;
                             }
                         }
+                        if (ok) wmag = isr_umax(isr_umax(wmag, isr_umax(isr_mag(val.x), isr_mag(val.y))), isr_umax(isr_mag(val.z), isr_mag(val.w)));
                         __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, val), yrs,
                                                                (int)(ok ? pixoff + (unsigned)co * (unsigned)p.yPlane * 4u : BAD_OFFSET), 0, 0);
                     }
@@ -715,12 +734,15 @@ __global__ __launch_bounds__(W_THREADS, 1) void conv3x3_split_wide_kernel(const 
                             const float rv = buf_load(rrs, ok ? pix + (unsigned)co * (unsigned)p.rPlane * 4u : BAD_OFFSET);
                             if (p.act == ISR_ACT_GATE) val = rv > 0.f ? val : 0.f; else val += rv;
                         }
+                        if (ok) wmag = isr_umax(wmag, isr_mag(val));
                         __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, val), yrs,
                                                               ok ? (int)(pix + (unsigned)co * (unsigned)p.yPlane * 4u) : (int)BAD_OFFSET, 0, 0);
                     }
                 }
             }
         }
+        isr_range_note(p.absmax, wmag);
+        wmag = 0u;
         __syncthreads();                                                     // the scratch is a patch slot: done before the next k-step parks into it
         slot ^= 1;
         cur = nxt;
@@ -878,6 +900,7 @@ __global__ __launch_bounds__(S_THREADS, 1) void conv3x3_split_rows2_kernel(const
     const int oy = oy0 + row;
     float* tr = reinterpret_cast<float*>(patch) + wave * (32 * 32);
     const bool wide = ((p.W | p.yPlane | p.rPlane) & 3) == 0;
+    unsigned rmag = 0u;
     if (wide) {
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
@@ -905,6 +928,7 @@ __global__ __launch_bounds__(S_THREADS, 1) void conv3x3_split_rows2_kernel(const
                     val.x += rf.x; val.y += rf.y; val.z += rf.z; val.w += rf.w;
                 }
             }
+            if (ok) rmag = isr_umax(isr_umax(rmag, isr_umax(isr_mag(val.x), isr_mag(val.y))), isr_umax(isr_mag(val.z), isr_mag(val.w)));
             __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, val), yrs,
                                                    (int)(ok ? pixoff + (unsigned)co * (unsigned)p.yPlane * 4u : BAD_OFFSET), 0, 0);
         }
@@ -922,10 +946,12 @@ __global__ __launch_bounds__(S_THREADS, 1) void conv3x3_split_rows2_kernel(const
                 const float rv = buf_load(rrs, ok ? pix + (unsigned)co * (unsigned)p.rPlane * 4u : BAD_OFFSET);
                 if (p.act == ISR_ACT_GATE) val = rv > 0.f ? val : 0.f; else val += rv;
             }
+            if (ok) rmag = isr_umax(rmag, isr_mag(val));
             __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, val), yrs,
                                                   ok ? (int)(pix + (unsigned)co * (unsigned)p.yPlane * 4u) : (int)BAD_OFFSET, 0, 0);
         }
     }
+    isr_range_note(p.absmax, rmag);
 }
 
 // header unit of the prepared weights: { 2^S, 2^-S, S (int), 0 } with max |w| 2^S in [2^13, 2^14)
@@ -1070,6 +1096,10 @@ __global__ __launch_bounds__(256) void prepare_weights_split_many_kernel(const P
 
 } // namespace
 
+__device__ u32x4 g_split_zero_unit[4];      // zero initialised: source of the zero-padding units of the LDS-DMA staging
+static unsigned* g_range_flag = nullptr;
+unsigned* isr_take_range_flag() { unsigned* f = g_range_flag; g_range_flag = nullptr; return f; }
+static bool g_ps_in = false;       // set around the launch by isrConv3x3ForwardSplitFromPacked
 static bool g_ps_out = false;      // set around the launch by isrConv3x3ForwardSplitPacked (the library is single threaded by contract)
 static unsigned long long* g_split_stamps = nullptr;
 static int g_split_dbg = 0;
@@ -1079,6 +1109,7 @@ static int g_split_algo = 1;      // plain layers: 1 persistent streaming kernel
 
 extern "C" {
 
+void isrSetRangeFlag(unsigned* flag) { g_range_flag = flag; }
 void isrDebugSetSplitStampBuffer(unsigned long long* buf) { g_split_stamps = buf; }   // not part of the public header
 void isrDebugSetSplitAblation(int bits) { g_split_dbg = bits; }
 void isrDebugSetSplitAlgo(int a) { g_split_algo = a; }
@@ -1131,6 +1162,14 @@ int isrConv3x3ForwardSplit(const float* x, const void* wq, const float* bias, co
     p.dbg = g_split_dbg;
     p.quads = ((W & 3) == 0 && aligned) ? 1 : 0;
     p.ps = nullptr; p.psPlane = 0;
+    p.xps = nullptr; p.xpsPlane = 0; p.zero = nullptr;
+    p.absmax = isr_take_range_flag();
+    if (g_ps_in) {             // isrConv3x3ForwardSplitFromPacked: `x` is a packed-split tensor, xPlane its plane stride in units
+        static u32x4* zero = nullptr;
+        if (!zero && hipGetSymbolAddress((void**)&zero, HIP_SYMBOL(g_split_zero_unit)) != hipSuccess) return -2;
+        if (N != 1 || upsample2x || (Cin & 7) || xPlane * 16 * 2 * (Cin / 8) > 0x7fffffffLL || ((uintptr_t)x & 15)) return -1;
+        p.xps = (const u32x4*)x; p.xpsPlane = (int)xPlane; p.zero = zero; p.x = nullptr;
+    }
     if (g_ps_out) {            // isrConv3x3ForwardSplitPacked: `y` is the packed-split tensor, yPlane its plane stride in units
         if (N != 1 || residual || (Cout & 7) || act == ISR_ACT_GATE || yPlane * 16 * 2 * (Cout / 8) > 0x7fffffffLL) return -1;
         p.ps = (u32x4*)y; p.psPlane = (int)yPlane; p.y = nullptr;
@@ -1225,6 +1264,19 @@ int isrConv3x3ForwardSplitPacked(const float* x, const void* wq, const float* bi
     const int rc = isrConv3x3ForwardSplit(x, wq, bias, nullptr, (float*)ps, 1, Cin, H, W, Cout, act, slope, upsample2x,
                                           xPlane, xPlane * Cin, psPlane, 0, 0, 0, stream);
     g_ps_out = false; g_split_algo = algo; g_split_small = small;
+    return rc;
+}
+
+int isrConv3x3ForwardSplitFromPacked(const void* xps, const void* wq, const float* bias, const float* residual, void* y, int packed_out,
+                                     int Cin, int H, int W, int Cout, int act, float slope, long long xpsPlane, long long yPlane, long long rPlane,
+                                     void* stream)
+{
+    // the one-workgroup-per-tile kernel knows the packed-split layouts; `packed_out`: y is a packed-split tensor as well
+    const int algo = g_split_algo, small = g_split_small;
+    g_ps_in = true; g_ps_out = packed_out != 0; g_split_algo = 0; g_split_small = 0;
+    const int rc = isrConv3x3ForwardSplit((const float*)xps, wq, bias, residual, (float*)y, 1, Cin, H, W, Cout, act, slope, 0,
+                                          xpsPlane, xpsPlane * Cin, yPlane, yPlane * Cout, rPlane, rPlane * Cout, stream);
+    g_ps_in = false; g_ps_out = false; g_split_algo = algo; g_split_small = small;
     return rc;
 }
 

@@ -218,6 +218,7 @@ __global__ __launch_bounds__(S_THREADS, 2) void conv3x3_split_tail_kernel(const 
         // registers 8 (q & 1) .. + 7 of acc[q >> 1][r]; the prepared weights use the same order.
         // transposition slab of this wave (8 KB).  With packed-split input the next tile's first k-step is landing in slot ^ 1 by DMA
         // meanwhile: the slabs then live in the two halves of the slot just multiplied and in the front of the weight buffer
+        unsigned ymag = 0u;
         float* tr = PSIN ? reinterpret_cast<float*>(wave == 0 ? patch + slot * SQ_SLOT : wave == 1 ? patch + S_PART + slot * SQ_SLOT
                                                               : wbuf + (wave - 2) * 512)
                          : reinterpret_cast<float*>(patch) + wave * (64 * 32);
@@ -236,6 +237,7 @@ __global__ __launch_bounds__(S_THREADS, 2) void conv3x3_split_tail_kernel(const 
                     _Float16 a, b;
                     split16x(val, a, b);
                     zh[q][e] = a; zl[q][e] = b;
+                    ymag = isr_umax(ymag, isr_mag(val));
                 }
             }
             const int oy = cur.oy0 + wave * 2 + r;
@@ -279,6 +281,7 @@ __global__ __launch_bounds__(S_THREADS, 2) void conv3x3_split_tail_kernel(const 
             }
             __builtin_amdgcn_s_waitcnt(0xC07F);                              // reads done before the next row overwrites the slab
         }
+        isr_range_note(p.absmax, ymag);
         __syncthreads();
         if (FUSED) {
             const float* zt = reinterpret_cast<const float*>(patch);
@@ -521,7 +524,8 @@ static int tail_launch(const void* xin, int packed, const void* wq6, const float
     tp.z = (float*)workspace;
     tp.zPlane = H * W + W;
     tp.xps = nullptr; tp.xpsPlane = 0; tp.zero = nullptr;
-    p.ps = nullptr; p.psPlane = 0;
+    p.ps = nullptr; p.psPlane = 0; p.xps = nullptr; p.xpsPlane = 0; p.zero = nullptr;
+    p.absmax = isr_take_range_flag();      // here: the largest |y6|, the 64-channel intermediate that is split in registers
     if (packed) {
         static u32x4* zero = nullptr;
         if (!zero && hipGetSymbolAddress((void**)&zero, HIP_SYMBOL(g_tail_zero_unit)) != hipSuccess) return -2;

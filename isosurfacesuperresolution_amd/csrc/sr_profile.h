@@ -14,3 +14,7 @@ constexpr int ISR_VARIANT_SPLIT_BLOCK = 19;    // resblock_split_kernel (sr_conv
 
 // Sets *e0 / *e1 to an event pair (and records the launch) when profiling is on, leaves them untouched otherwise.
 void isr_profile_record(int variant, double flops, hipEvent_t* e0, hipEvent_t* e1);
+
+// Range guard (SplitConvParams::absmax): isrSetRangeFlag(ptr) arms the NEXT launch of a split-operand kernel (any translation
+// unit) with a device word that receives the bit pattern of the largest |value| it stores; the launcher takes (and clears) it.
+unsigned* isr_take_range_flag();

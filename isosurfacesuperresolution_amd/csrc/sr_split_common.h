@@ -49,7 +49,27 @@ struct SplitConvParams {
     // units, pixel y W + x].  The consumer stages k-steps with plain 16-byte copies (LDS-DMA); same values as converting the
     // fp32 tensor on the way in, so results do not change.  Single image, Cout a multiple of 8, no residual.
     u32x4* ps; int psPlane;
+    // PACKED-SPLIT input (xps != NULL; x unused): the same layout, Cin / 8 groups, xpsPlane units per plane; staged by LDS-DMA,
+    // units outside the image (zero padding) and beyond the last group from `zero` (16 zero bytes).  Plain layers, one image.
+    const u32x4* xps; int xpsPlane;
+    const u32x4* zero;
+    // RANGE GUARD (may be NULL): atomic maximum, as the bit pattern of |v|, over every value this launch stores.  The split of an
+    // activation overflows fp16 at |x| >= 65520; the host reads the producers' maxima now and then and routes the CONSUMER of a
+    // tensor that came close (>= 3e4) to the exact fp32 kernels (ops.RANGE_GUARD) -- no cliff, no host read inside a frame.
+    unsigned* absmax;
 };
+
+// bit pattern of |v|: unsigned order = order of the magnitudes, inf above every finite value, NaN above inf (never lost)
+__device__ __forceinline__ unsigned isr_mag(float v) { return __builtin_bit_cast(unsigned, v) & 0x7fffffffu; }
+__device__ __forceinline__ unsigned isr_umax(unsigned a, unsigned b) { return a > b ? a : b; }
+// one atomic per wave: lane maxima combined by butterfly shuffles
+__device__ __forceinline__ void isr_range_note(unsigned* flag, unsigned m)
+{
+    if (!flag) return;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m = isr_umax(m, (unsigned)__shfl_xor((int)m, o, 64));
+    if ((threadIdx.x & 63) == 0) atomicMax(flag, m);
+}
 
 typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 typedef __attribute__((address_space(1))) const void isr_gvoid_t;
@@ -100,6 +120,7 @@ __device__ __forceinline__ void split_epilogue_ps(const SplitConvParams& p, f32x
 #pragma unroll
         for (int i = 0; i < 16; ++i)
             bv[cb][i] = p.bias ? p.bias[min(co0 + cb * 32 + 8 * (i >> 2) + 4 * h + (i & 3), p.Cout - 1)] : 0.0f;
+    unsigned mag = 0u;
 #pragma unroll
     for (int r = 0; r < 2; ++r) {
         const int oy = oy0 + wave * 2 + r;
@@ -118,6 +139,7 @@ __device__ __forceinline__ void split_epilogue_ps(const SplitConvParams& p, f32x
                     _Float16 a, b;
                     split16x(v, a, b);
                     th[e] = a; tl[e] = b;
+                    mag = isr_umax(mag, isr_mag(v));
                 }
                 const int g = (co0 >> 3) + cb * 4 + gi;
                 const bool live = g < groups;
@@ -126,6 +148,7 @@ __device__ __forceinline__ void split_epilogue_ps(const SplitConvParams& p, f32x
             }
         }
     }
+    isr_range_note(p.absmax, mag);
 }
 
 // WIDE_ONLY: the caller guarantees W and both plane strides are multiples of 4 (the per-element path is not compiled in).
@@ -138,6 +161,7 @@ __device__ __forceinline__ void split_epilogue(const SplitConvParams& p, f32x16 
     const rsrc_t rrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.residual ? p.residual + (size_t)n * p.rImage : p.y), 0,
                                                          p.residual ? (int)((size_t)p.Cout * p.rPlane * 4) : 0, 0x00020000);
     const int ox = ox0 + j;
+    unsigned mag = 0u;
     float bv[2][16];                                                         // all bias values first: one latency, not 128
 #pragma unroll
     for (int cb = 0; cb < 2; ++cb)
@@ -179,6 +203,7 @@ __device__ __forceinline__ void split_epilogue(const SplitConvParams& p, f32x16 
                         v.x += rf.x; v.y += rf.y; v.z += rf.z; v.w += rf.w;
                     }
                 }
+                if (ok) mag = isr_umax(isr_umax(mag, isr_umax(isr_mag(v.x), isr_mag(v.y))), isr_umax(isr_mag(v.z), isr_mag(v.w)));
                 __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), yrs,
                                                        (int)(ok ? pixoff + (unsigned)co * (unsigned)p.yPlane * 4u : BAD_OFFSET), 0, 0);
             }
@@ -203,12 +228,14 @@ __device__ __forceinline__ void split_epilogue(const SplitConvParams& p, f32x16 
                     const float rv = buf_load(rrs, ok ? pix + (unsigned)co * (unsigned)p.rPlane * 4u : BAD_OFFSET);
                     if (p.act == ISR_ACT_GATE) v = rv > 0.f ? v : 0.f; else v += rv;
                 }
+                if (ok) mag = isr_umax(mag, isr_mag(v));
                 __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), yrs,
                                                       ok ? (int)(pix + (unsigned)co * (unsigned)p.yPlane * 4u) : (int)BAD_OFFSET, 0, 0);
             }
         }
     }
     }
+    isr_range_note(p.absmax, mag);
 }
 
 // One k-step of MFMAs: 16 input channels x 9 taps x (2 channel blocks x 2 rows) x 3 products.  wl: this lane's weight

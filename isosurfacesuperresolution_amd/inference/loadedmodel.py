@@ -138,6 +138,9 @@ class LoadedModel:
             raise NotImplementedError("only the unshaded (mask/normal/depth/ao) networks are on the hot path")
         self.initial_image_mode = self.parameters.get('initialImage', 'input')
         self.inverse_ao = self.parameters.get('aoInverted', False)
+        if str(self.device).startswith("cuda"):
+            from .. import ops
+            ops.range_reset()             # range guard of the split-operand kernels: a new model starts unflagged
 
     def inference(self, current_low, prev_high):
         """current_low [1,12,h,w] renderer output (r,g,b,mask,nx,ny,nz,depth,fx,fy,ao,shadow);
@@ -153,5 +156,10 @@ class LoadedModel:
                 previous_warped = VideoTools.warp_upscale(prev_high.to(self.device), flow,
                                                           self.upscale_factor, special_mask=True)
             flat = VideoTools.flatten_high(previous_warped, self.upscale_factor)
-            prediction, _ = self.model(torch.cat((inp, flat), dim=1))
+            net_in = torch.cat((inp, flat), dim=1)
+            prediction, _ = self.model(net_in)
+            if net_in.is_cuda:
+                from .. import ops
+                if ops.range_check_due(net_in.device) and ops.refresh_range_flags(net_in.device):
+                    prediction, _ = self.model(net_in)      # a layer came close to the split operands' fp16 range: exact routing from now on
         return prediction

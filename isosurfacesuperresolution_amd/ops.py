@@ -98,11 +98,14 @@ def _sr():
         lib.isrConvTailFinishFrame.restype = ci
         lib.isrConv3x3ForwardSplitPacked.argtypes = [vp, vp, vp, vp, ci, ci, ci, ci, ci, cf, ci, ll, ll, vp]
         lib.isrConv3x3ForwardSplitPacked.restype = ci
+        lib.isrConv3x3ForwardSplitFromPacked.argtypes = [vp, vp, vp, vp, vp, ci, ci, ci, ci, ci, ci, cf, ll, ll, ll, vp]
+        lib.isrConv3x3ForwardSplitFromPacked.restype = ci
         lib.isrConvTailFinishFramePacked.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, vp, ci, ci, ll, vp, ci, cf, ci, ci, vp]
         lib.isrConvTailFinishFramePacked.restype = ci
         lib.isrResBlockSplitWorkspaceBytes.argtypes = []; lib.isrResBlockSplitWorkspaceBytes.restype = ll
         lib.isrResBlockSplitSupported.argtypes = [vp, ci, ci, ll, ll]; lib.isrResBlockSplitSupported.restype = ci
         lib.isrResBlockSplit.argtypes = [vp, vp, vp, vp, vp, vp, vp, ci, ci, ll, ll, vp]; lib.isrResBlockSplit.restype = ci
+        lib.isrSetRangeFlag.argtypes = [vp]; lib.isrSetRangeFlag.restype = None
         lib.isrProfileEnable.argtypes = [ci]; lib.isrProfileEnable.restype = ci
         lib.isrProfileCount.argtypes = []; lib.isrProfileCount.restype = ci
         lib.isrProfileGet.argtypes = [ci, vp, vp, vp]; lib.isrProfileGet.restype = ci
@@ -351,6 +354,92 @@ def conv3x3_f16(x, weight, bias=None, act='none', slope=0.01, residual=None, ups
                           act, slope, upsample2x, False)
 
 
+# ---- range guard of the split-operand path ---------------------------------------------------------------------------------
+# The split of an ACTIVATION into (hi, lo') fp16 numbers overflows at |x| >= 65520 (inf / NaN downstream: loud, not silent).  With
+# the reference's networks and G-buffer inputs in [-1, 5] this cannot happen; a user's checkpoint is one badly scaled layer away.
+# So every split-operand launch leaves the largest |value| it stored in a device word (SplitConvParams::absmax, one atomic per
+# wave), tensors remember which word describes them, and ``refresh_range_flags()`` -- one host read, done by the frame pipeline
+# / LoadedModel after the FIRST frame of a model and then every RANGE_CHECK_EVERY frames, never inside a frame -- marks the
+# producers whose output came within a factor two of the limit as HOT.  The CONSUMER of a hot tensor (and, conservatively,
+# everything downstream of it in that frame) runs on the exact fp32 kernels (sr_conv3x3.hip), which have the full fp32 range.
+RANGE_GUARD = True
+RANGE_LIMIT = 3.0e4
+RANGE_CHECK_EVERY = 256
+_RANGE_SLOTS = 512
+HOT = "hot"                      # range key of a tensor of unknown / large range (e.g. produced by an exact kernel on the guarded path)
+_range = {}                      # device -> {"buf": uint32 tensor, "slots": {key: index}, "hot": set(keys), "frames": int}
+
+
+def _range_state(device):
+    st = _range.get(device)
+    if st is None:
+        st = {"buf": torch.zeros(_RANGE_SLOTS, dtype=torch.int32, device=device), "slots": {}, "hot": set(), "frames": 0}
+        _range[device] = st
+    return st
+
+
+def _arm_range(key, device):
+    """Arm the NEXT split-operand launch with the flag word of producer ``key`` (no-op when the guard is off)."""
+    if not RANGE_GUARD:
+        return None
+    st = _range_state(device)
+    idx = st["slots"].get(key)
+    if idx is None:
+        if len(st["slots"]) >= _RANGE_SLOTS:
+            return None
+        idx = st["slots"][key] = len(st["slots"])
+    _sr().isrSetRangeFlag(ctypes.c_void_p(st["buf"].data_ptr() + 4 * idx))
+    return key
+
+
+def range_is_hot(key, device):
+    """Must a consumer of the tensor tagged ``key`` avoid the split kernels?"""
+    if key is None or not RANGE_GUARD:
+        return False
+    return key == HOT or key in _range_state(device)["hot"]
+
+
+def any_hot(device):
+    return RANGE_GUARD and device in _range and bool(_range[device]["hot"])
+
+
+def refresh_range_flags(device=None):
+    """Read the producers' maxima (ONE host synchronisation), mark producers at or above RANGE_LIMIT (or non-finite) hot,
+    reset the words.  Returns the set of producers that became hot in this call."""
+    new = set()
+    for dev, st in list(_range.items()):
+        if device is not None and torch.device(dev) != torch.device(device):
+            continue
+        if not st["slots"]:
+            continue
+        vals = st["buf"].cpu().view(torch.float32)
+        for key, idx in st["slots"].items():
+            v = float(vals[idx])
+            if not (v < RANGE_LIMIT) and key not in st["hot"]:       # NaN compares false: hot
+                st["hot"].add(key)
+                new.add(key)
+        st["buf"].zero_()
+    return new
+
+
+def range_reset():
+    """Forget every maximum and every hot producer (a new model was loaded)."""
+    for st in _range.values():
+        st["buf"].zero_()
+        st["hot"].clear()
+        st["frames"] = 0
+
+
+def range_check_due(device):
+    """Frame pipelines call this once per frame: True after the first frame since the last reset and then every
+    RANGE_CHECK_EVERY frames."""
+    if not RANGE_GUARD:
+        return False
+    st = _range_state(device)
+    st["frames"] += 1
+    return st["frames"] == 1 or st["frames"] % RANGE_CHECK_EVERY == 0
+
+
 # ---- split-operand mode: fp32-equivalent accuracy on the fp16 matrix pipe (inference; THE default parity path) ----------
 # SPLIT_F16 = True routes the no-grad ``conv3x3`` of layers with more than 8 output channels through
 # ``isrConv3x3ForwardSplit`` (csrc/sr_conv_split.hip): every operand is split into two fp16 numbers (22 significand
@@ -431,8 +520,11 @@ def conv3x3_split(x, weight, bias=None, act='none', slope=0.01, residual=None, u
     if act not in ('none', 'relu', 'leaky'):
         raise ValueError("unknown activation %r" % (act,))
     with torch.no_grad():
-        return _launch_split(x, _prepare_split(weight), bias.contiguous() if bias is not None else None, residual, weight.shape[0],
-                             act, slope, upsample2x)
+        key = _arm_range(id(weight), x.device)
+        y = _launch_split(x, _prepare_split(weight), bias.contiguous() if bias is not None else None, residual, weight.shape[0],
+                          act, slope, upsample2x)
+        y._isr_range_key = key
+        return y
 
 
 def _launch_split(x, wq, bias, residual, cout, act, slope, upsample2x, packed=False):
@@ -644,12 +736,16 @@ class _ResidualBlockFunction(torch.autograd.Function):
 
 # Inference: the whole block in ONE launch (csrc/sr_conv_block.hip) -- bit-identical to the two split-operand launches
 BLOCK_FUSION = False
+BLOCK_PACKED = True                # two launches per block, the intermediate packed-split (see residual_block)
+BLOCK_PACKED_MIN_TILES = 256
 BLOCK_FUSION_MIN_TILES = 256       # below that the persistent grid is not filled; the per-layer kernels' small-image forms take over
 _block_ws = {}
 
 
 def _block_supported(x, w1, w2):
     if not (BLOCK_FUSION and SPLIT_F16 and not FAST_F16 and x.is_cuda and x.dtype == torch.float32 and x.dim() == 4 and x.shape[0] == 1):
+        return False
+    if any_hot(x.device):
         return False
     if tuple(w1.shape) != (64, 64, 3, 3) or tuple(w2.shape) != (64, 64, 3, 3) or x.shape[1] != 64:
         return False
@@ -670,6 +766,7 @@ def residual_block_fused(x, w1, b1, w2, b2):
         ws = torch.empty(lib.isrResBlockSplitWorkspaceBytes(), dtype=torch.uint8, device=x.device)
         _block_ws[key] = ws
     y = empty_planes(1, 64, h, w, x.device)
+    y._isr_range_key = _arm_range(("block", id(w1)), x.device)      # covers the intermediate and the output
     rc = lib.isrResBlockSplit(_ptr(x), _ptr(_prepare_split(w1)), _ptr(b1.detach().contiguous() if b1 is not None else None),
                               _ptr(_prepare_split(w2)), _ptr(b2.detach().contiguous() if b2 is not None else None), _ptr(y), _ptr(ws),
                               h, w, xp, y.stride(1), _stream())
@@ -685,6 +782,13 @@ def residual_block(x, w1, b1, w2, b2):
         return _ResidualBlockFunction.apply(x, w1, b1, w2, b2)
     if not needs_grad and _block_supported(x, w1, w2):
         return residual_block_fused(x, w1, b1, w2, b2)
+    if not needs_grad and BLOCK_PACKED and SPLIT_F16 and not FAST_F16 and x.is_cuda and x.dtype == torch.float32 and x.shape[0] == 1 \
+            and tuple(w1.shape) == (64, 64, 3, 3) == tuple(w2.shape) and x.shape[3] % 4 == 0 \
+            and ((x.shape[2] + 7) // 8) * ((x.shape[3] + 31) // 32) >= BLOCK_PACKED_MIN_TILES and packed_supported(x, w1, False):
+        # the intermediate of the block travels packed-split: conv1 stores (hi, lo') units straight from its accumulators (no LDS
+        # transposition), conv2 stages them by LDS-DMA (no conversion) -- the same numbers, bit-identical output
+        t = conv3x3_split_packed(x, w1, b1, act='relu')
+        return conv3x3_split_from_packed(t, w2, b2, residual=x)
     return conv3x3(conv3x3(x, w1, b1, act='relu'), w2, b2, residual=x)
 
 
@@ -771,8 +875,17 @@ def conv3x3(x, weight, bias=None, act='none', slope=0.01, residual=None, upsampl
         cout, cin = weight.shape[0], weight.shape[1]
         if FAST_F16 and cout > 8:
             return conv3x3_f16(x, weight, bias, act, slope, residual, upsample2x)
-        if SPLIT_F16 and cout > 8 and _split_fits(x, cout, upsample2x):
+        hot_in = range_is_hot(getattr(x, '_isr_range_key', None), x.device) or \
+            (residual is not None and getattr(residual, '_isr_range_key', None) == HOT)
+        if SPLIT_F16 and cout > 8 and _split_fits(x, cout, upsample2x) and not hot_in:
             return conv3x3_split(x, weight, bias, act, slope, residual, upsample2x)
+        if hot_in and cout > 8:
+            # the input (or something upstream of it) came close to the fp16 range of the split: exact fp32 kernel, and whatever
+            # consumes ITS output stays exact too (its range is not tracked)
+            y = _launch_forward(x, prepare_weights(weight), bias.contiguous() if bias is not None else None, residual,
+                                cin, cout, act, slope, upsample2x)
+            y._isr_range_key = HOT
+            return y
         if cout <= 8 and not upsample2x and cin * x.shape[2] * x.shape[3] * 4 < 2 ** 31:
             return _launch_small(x, weight, bias, residual.contiguous() if residual is not None else None, act, slope)
         if cout <= 8 and not upsample2x:
@@ -1089,6 +1202,8 @@ def tail_supported(features, weight6, weight8):
     split-operand inference mode.)"""
     if not (TAIL_FUSION and SPLIT_F16 and not FAST_F16 and features.is_cuda and features.dtype == torch.float32):
         return False
+    if any_hot(features.device):          # range guard: a layer of this model needs the exact kernels -- per-layer routing only
+        return False
     if features.dim() != 4 or features.shape[0] != 1 or features.shape[1] != 64 or features.shape[2] % 4 or features.shape[3] % 4:
         return False
     if tuple(weight6.shape) != (64, 64, 3, 3) or tuple(weight8.shape) != (6, 64, 3, 3):
@@ -1106,6 +1221,7 @@ class PackedSplit:
 
     def __init__(self, data, channels, h, w, plane):
         self.data, self.channels, self.h, self.w, self.plane = data, channels, h, w, plane
+        self.range_key = None      # range guard: the producer whose flag word describes these values
 
     def to_float(self):
         """The fp32 tensor this stands for, hi + lo' 2^-11 (tests)."""
@@ -1128,16 +1244,53 @@ def conv3x3_split_packed(x, weight, bias=None, act='relu', slope=0.01, upsample2
         raise ValueError("conv3x3_split_packed: the fused upsampling needs 16-byte aligned low-resolution rows")
     plane = h * w + plane_pad(h, w)
     data = torch.empty(2 * (cout // 8) * plane * 4, dtype=torch.int32, device=x.device)
+    key = _arm_range(id(weight), x.device)
     rc = lib.isrConv3x3ForwardSplitPacked(_ptr(x), _ptr(_prepare_split(weight)), _ptr(bias.detach().contiguous() if bias is not None else None),
                                           _ptr(data), cin, h, w, cout, ACT_CODES[act], float(slope), 1 if upsample2x else 0, xp, plane, _stream())
     if rc != 0:
         raise RuntimeError("isrConv3x3ForwardSplitPacked failed (%d)" % rc)
-    return PackedSplit(data, cout, h, w, plane)
+    out = PackedSplit(data, cout, h, w, plane)
+    out.range_key = key
+    return out
+
+
+def conv3x3_split_from_packed(xp, weight, bias=None, act='none', slope=0.01, residual=None, packed_out=False):
+    """The split-operand convolution of a PACKED-SPLIT input (``PackedSplit``, staged by LDS-DMA): act(conv3x3(x) + bias)
+    + residual as an fp32 tensor, or (``packed_out``, no residual) packed-split again."""
+    lib = _sr()
+    cout, cin = weight.shape[0], weight.shape[1]
+    assert isinstance(xp, PackedSplit) and xp.channels == cin and cin % 8 == 0
+    h, w = xp.h, xp.w
+    rp = 0
+    if residual is not None:
+        residual, rp, _ = _plane_strides(residual)
+    if packed_out:
+        assert residual is None and cout % 8 == 0
+        plane = h * w + plane_pad(h, w)
+        out = torch.empty(2 * (cout // 8) * plane * 4, dtype=torch.int32, device=xp.data.device)
+        yplane = plane
+    else:
+        out = empty_planes(1, cout, h, w, xp.data.device)
+        yplane = out.stride(1)
+    key = _arm_range(id(weight), xp.data.device)
+    rc = lib.isrConv3x3ForwardSplitFromPacked(_ptr(xp.data), _ptr(_prepare_split(weight)), _ptr(bias.detach().contiguous() if bias is not None else None),
+                                              _ptr(residual), _ptr(out), 1 if packed_out else 0, cin, h, w, cout, ACT_CODES[act], float(slope),
+                                              xp.plane, yplane, rp, _stream())
+    if rc != 0:
+        raise RuntimeError("isrConv3x3ForwardSplitFromPacked failed (%d)" % rc)
+    if packed_out:
+        out = PackedSplit(out, cout, h, w, yplane)
+        out.range_key = key
+    else:
+        out._isr_range_key = key
+    return out
 
 
 def packed_supported(x, weight, upsample2x):
     """Can ``conv3x3_split_packed`` + the packed tail take this layer?"""
     if not (TAIL_PACKED and x.is_cuda and x.dtype == torch.float32 and x.shape[0] == 1 and weight.shape[0] == 64):
+        return False
+    if any_hot(x.device):
         return False
     x2, xp, _ = _plane_strides(x)
     if x2 is not x:
@@ -1180,6 +1333,7 @@ def tail_conv_finish(features, weight6, bias6, weight8, bias8, net_input, shadin
         inv, spec = int(bool(shading.inverse_ao)), int(bool(shading.enable_specular))
     b6 = bias6.detach().contiguous() if bias6 is not None else None
     b8 = bias8.detach().contiguous() if bias8 is not None else torch.zeros(6, dtype=torch.float32, device=dev)
+    _arm_range(("tail", id(weight6)), dev)         # the largest |y6|: the intermediate is split in registers inside the kernel
     fn = lib.isrConvTailFinishFramePacked if packed else lib.isrConvTailFinishFrame
     rc = fn(_ptr(features.data if packed else features), _ptr(wq6), _ptr(b6), _ptr(wz), _ptr(b8), _ptr(ws), _ptr(net_input), _ptr(nxt), _ptr(rgb),
                                     h, w, xp, params, exponent, ao, inv, spec, _stream())

@@ -148,6 +148,39 @@ class SuperResolutionPipeline:
         self.previous = raw
         return raw
 
+    def _network(self, x):
+        """Network input [1,101,h,w] -> (raw [1,6,4h,4w] clamped / normalised, rgb [1,3,4h,4w])."""
+        net = self.model.model
+        self.shading.inverse_ao = self.model.inverse_ao
+        last = net.postblock[8]
+        six = net.postblock[6]
+        f4 = None
+        tail = last.weight.shape[0] == 6 and ops.TAIL_FUSION and ops.SPLIT_F16 and not ops.FAST_F16 and not ops.any_hot(x.device)
+        four = net.postblock[4]
+        if tail and ops.TAIL_PACKED and tuple(six.weight.shape) == (64, 64, 3, 3) and tuple(last.weight.shape) == (6, 64, 3, 3):
+            f2 = net.forward_features(x, last_three=False)
+            if ops.packed_supported(f2, four.weight, True):
+                # postblock.4 writes its output packed-split (already the (hi, lo') units postblock.6 multiplies), the tail
+                # stages them by LDS-DMA: no conversion on the way in, no LDS transposition on the way out
+                f4 = ops.conv3x3_split_packed(f2, four.weight, four.bias, act='relu', upsample2x=True)
+            else:
+                f4 = ops.conv3x3(f2, four.weight, four.bias, act='relu', upsample2x=True)
+        elif tail:
+            f4 = net.forward_features(x, last_two=False)
+        if isinstance(f4, ops.PackedSplit) or (f4 is not None and ops.tail_supported(f4, six.weight, last.weight)):
+            # postblock.6, postblock.8 and the frame's finishing in two launches; the 64-channel 1080p tensor between the
+            # two convolutions never goes to memory (csrc/sr_conv_tail.hip)
+            raw, rgb = ops.tail_conv_finish(f4, six.weight, six.bias, last.weight, last.bias, x, self.shading)
+        elif f4 is not None:
+            f6 = ops.conv3x3(f4, six.weight, six.bias, act='relu')
+            raw, rgb = ops.final_conv_finish(f6, last.weight, last.bias, x, self.shading)
+        elif last.weight.shape[0] == 6:
+            # the last layer's epilogue finishes the frame (one launch, no [6,4h,4w] round trip)
+            raw, rgb = ops.final_conv_finish(net.forward_features(x, last_layer=False), last.weight, last.bias, x, self.shading)
+        else:
+            raw, rgb = ops.finish_frame(net.forward_features(x), x, self.shading)
+        return raw, rgb
+
     def frame_fused(self, origin, next_origin=None):
         with torch.no_grad():
             if next_origin is not None:
@@ -165,35 +198,11 @@ class SuperResolutionPipeline:
                 flow = self._flows[self._slot] if self._flow_ready[self._slot] else ops.fill_flow_gbuffer(g)
             x = ops.assemble_input(g, flow, prev, self.model.initial_image_mode, self.model.inverse_ao)
             self._consumed[self._slot].record(torch.cuda.current_stream())   # G-buffer no longer needed
-            net = self.model.model
-            self.shading.inverse_ao = self.model.inverse_ao
-            last = net.postblock[8]
-            six = net.postblock[6]
-            f4 = None
-            tail = last.weight.shape[0] == 6 and ops.TAIL_FUSION and ops.SPLIT_F16 and not ops.FAST_F16
-            four = net.postblock[4]
-            if tail and ops.TAIL_PACKED and tuple(six.weight.shape) == (64, 64, 3, 3) and tuple(last.weight.shape) == (6, 64, 3, 3):
-                f2 = net.forward_features(x, last_three=False)
-                if ops.packed_supported(f2, four.weight, True):
-                    # postblock.4 writes its output packed-split (already the (hi, lo') units postblock.6 multiplies), the tail
-                    # stages them by LDS-DMA: no conversion on the way in, no LDS transposition on the way out
-                    f4 = ops.conv3x3_split_packed(f2, four.weight, four.bias, act='relu', upsample2x=True)
-                else:
-                    f4 = ops.conv3x3(f2, four.weight, four.bias, act='relu', upsample2x=True)
-            elif tail:
-                f4 = net.forward_features(x, last_two=False)
-            if isinstance(f4, ops.PackedSplit) or (f4 is not None and ops.tail_supported(f4, six.weight, last.weight)):
-                # postblock.6, postblock.8 and the frame's finishing in two launches; the 64-channel 1080p tensor between the
-                # two convolutions never goes to memory (csrc/sr_conv_tail.hip)
-                raw, rgb = ops.tail_conv_finish(f4, six.weight, six.bias, last.weight, last.bias, x, self.shading)
-            elif f4 is not None:
-                f6 = ops.conv3x3(f4, six.weight, six.bias, act='relu')
-                raw, rgb = ops.final_conv_finish(f6, last.weight, last.bias, x, self.shading)
-            elif last.weight.shape[0] == 6:
-                # the last layer's epilogue finishes the frame (one launch, no [6,4h,4w] round trip)
-                raw, rgb = ops.final_conv_finish(net.forward_features(x, last_layer=False), last.weight, last.bias, x, self.shading)
-            else:
-                raw, rgb = ops.finish_frame(net.forward_features(x), x, self.shading)
+            raw, rgb = self._network(x)
+            if ops.range_check_due(x.device) and ops.refresh_range_flags(x.device):
+                # range guard (ops.RANGE_GUARD): a layer's output came close to the fp16 range of the split operands -- from now on
+                # its consumers run on the exact fp32 kernels; this frame is computed again with that routing
+                raw, rgb = self._network(x)
             self.previous = raw
         return rgb, raw
 

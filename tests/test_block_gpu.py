@@ -30,6 +30,26 @@ def test_fused_block_is_bit_identical_to_two_launches(h, w):
     assert torch.equal(y_f, y_f2)
 
 
+@pytest.mark.parametrize("h,w", [(8, 32), (9, 36), (23, 52), (270, 480)])
+def test_packed_split_intermediate_is_bit_identical(h, w):
+    """The two launches of a block with the intermediate handed over packed-split (conv1 stores (hi, lo') units from its
+    accumulators, conv2 stages them by LDS-DMA) compute exactly what they compute through an fp32 tensor."""
+    from isosurfacesuperresolution_amd import ops
+    x, w1, b1, w2, b2 = _case(h, w, seed=h * 5 + w)
+    with torch.no_grad():
+        t = ops.conv3x3_split(x, w1, b1, act='relu')
+        tp = ops.conv3x3_split_packed(x, w1, b1, act='relu')
+        assert (tp.to_float() - t).abs().max().item() <= 2.0 ** -21 * max(1.0, t.abs().max().item())
+        y_r = ops.conv3x3_split(t, w2, b2, residual=x)
+        y_p = ops.conv3x3_split_from_packed(tp, w2, b2, residual=x)
+        # packed in, packed out (no residual): the units are the split of the fp32 result
+        u = ops.conv3x3_split(t, w2, b2, act='relu')
+        up = ops.conv3x3_split_from_packed(tp, w2, b2, act='relu', packed_out=True)
+    torch.cuda.synchronize()
+    assert torch.equal(y_p, y_r), (y_p - y_r).abs().max().item()
+    assert (up.to_float() - u).abs().max().item() <= 2.0 ** -21 * max(1.0, u.abs().max().item())
+
+
 def test_fused_block_without_bias_and_with_padded_planes():
     from isosurfacesuperresolution_amd import ops
     h, w = 40, 96
@@ -53,8 +73,9 @@ def test_trunk_runs_on_the_fused_block_and_matches():
     net = models.createNetwork('EnhanceNet', 4, 101, [0, 1, 2, 3, 4], 6, opt).cuda().eval()
     x = torch.rand(1, 101, 270, 480, device="cuda")
     outs = {}
-    for fused in (True, False):
-        ops.BLOCK_FUSION = fused
+    for fused in (True, False, "plain"):
+        ops.BLOCK_FUSION = fused is True
+        ops.BLOCK_PACKED = fused is not "plain"
         try:
             ops.profile_enable(True)
             with torch.no_grad():
@@ -63,6 +84,7 @@ def test_trunk_runs_on_the_fused_block_and_matches():
             names = [n for n, _, _ in ops.profile_records()]
             ops.profile_enable(False)
         finally:
-            ops.BLOCK_FUSION = True
-        assert (names.count("resblock_split_kernel") == 10) == fused
-    assert torch.equal(outs[True], outs[False])
+            ops.BLOCK_FUSION = False
+            ops.BLOCK_PACKED = True
+        assert (names.count("resblock_split_kernel") == 10) == (fused is True)
+    assert torch.equal(outs[True], outs[False]) and torch.equal(outs[False], outs["plain"])

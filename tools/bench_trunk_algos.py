@@ -21,6 +21,14 @@ def chain():
     return f
 
 
+def packed():
+    f = x
+    for k in range(10):
+        t = ops.conv3x3_split_packed(f, ws[2 * k], b, act='relu')
+        f = ops.conv3x3_split_from_packed(t, ws[2 * k + 1], b, residual=f)
+    return f
+
+
 def fused():
     f = x
     for k in range(10):
@@ -48,7 +56,7 @@ with torch.no_grad():
     ref = chain()
     timed(chain, 200)
     forms = [(1, "default (per tile when one round)", chain), (3, "persistent streaming", chain), (0, "one workgroup per tile", chain),
-             (2, "wide, pipelined reads", chain), (1, "fused blocks", fused)]
+             (2, "wide, pipelined reads", chain), (1, "fused blocks", fused), (1, "per tile, packed intermediate", packed)]
     results = {name: [] for _, name, _ in forms}
     for rnd in range(3):
         for algo, name, fn in forms:
