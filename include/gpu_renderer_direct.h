@@ -102,6 +102,12 @@ int isoProfileGet(int i, float* ms);
  * lets the next SR conv workgroup land on every CU while a frame renders on a side stream.
  * Returns 0, or -1 for a negative cap. */
 int isoSetWaveCap(int waves);
+/* Additive: cost-ordered dispatch of the default kernel (variant 0) for images of at most 4096 tiles of 8x8 pixels.  The waves
+ * of a frame record their clock cycles, one workgroup sorts the tiles on the render's stream, and the NEXT frame dispatches its
+ * tiles in that order: 1 = heaviest first, 2 = heaviest first for the first 4 x #CUs workgroups, then the lightest (a SIMD's
+ * second wave is light where its first is heavy).  A pure permutation of the work: the G-buffer does not change.  0 = off
+ * (default: the XCD-aware scan order).  Returns 0, or -1 for an unknown mode. */
+int isoSetTileOrderMode(int mode);
 
 /* Enqueues a one-wave kernel on `stream` that returns once every wave of the most recently launched variant-2
  * render has started (or after `timeoutUs`).  Put on the stream of the SR network right after the render was

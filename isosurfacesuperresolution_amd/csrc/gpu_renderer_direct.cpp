@@ -79,6 +79,12 @@ struct State {
     unsigned* tileQueue = nullptr;   // 8 per-XCD work counters of kernel variant 2 (+ 1 resident-wave counter)
     unsigned residentTarget = 0;     // waves launched by all variant-2 renders so far (what the counter will reach)
     unsigned gatedTarget = 0;        // residentTarget at the last isoGateResident: a gate with nothing new to wait for is a no-op
+    // cost-ordered dispatch of the default kernel (isoSetTileOrderMode): the waves of frame t write their clock cycles, one
+    // workgroup sorts them on the render's stream, frame t + 1 dispatches its tiles in that order (same pixels, other order)
+    int orderMode = 0;               // 0 off, 1 heaviest first, 2 heaviest first then the lightest as the SIMDs' second waves
+    unsigned* tileCost = nullptr;    // [ISO_ORDER_MAX_TILES]
+    unsigned short* tileOrder = nullptr;   // [ISO_ORDER_MAX_TILES]
+    int orderW = 0, orderH = 0;      // resolution the stored order belongs to (0: none yet)
     long long* statsOut = nullptr;   // diagnostics: isoDebugSetStatsBuffer
     bool profile = false;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> events;   // one pair per profiled frame
@@ -681,6 +687,16 @@ bool launchFrame(float* out, hipStream_t stream)
     p.aoHemi = g.aoHemi; p.aoRot = g.aoRot;
     p.tileQueue = g.tileQueue;
     p.resident = g.tileQueue + 8;
+    const int tiles_all = ((p.W + 7) >> 3) * ((p.H + 7) >> 3);
+    const bool ordering = g.orderMode > 0 && g.variant == 0 && g.semantics != 1 && !g.statsOut && tiles_all <= ISO_ORDER_MAX_TILES;
+    if (ordering) {
+        if (!g.tileCost) {
+            HIP_OK(hipMalloc(&g.tileCost, ISO_ORDER_MAX_TILES * sizeof(unsigned)));
+            HIP_OK(hipMalloc(&g.tileOrder, ISO_ORDER_MAX_TILES * sizeof(unsigned short)));
+        }
+        p.tileCost = g.tileCost;
+        p.tileOrder = (g.orderW == p.W && g.orderH == p.H) ? g.tileOrder : nullptr;
+    }
     hipEvent_t e0 = nullptr, e1 = nullptr;
     if (g.profile) {
         if (hipEventCreate(&e0) == hipSuccess && hipEventCreate(&e1) == hipSuccess) g.events.emplace_back(e0, e1);
@@ -695,6 +711,13 @@ bool launchFrame(float* out, hipStream_t stream)
         iso_launch_render_stats(p, g.variant, g.statsOut, stream);
     } else {
         iso_launch_render(p, g.variant, stream, e0, e1, g.waveCap);
+        if (ordering) {
+            int dev = 0, cus = 256;
+            (void)hipGetDevice(&dev);
+            if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
+            iso_launch_tile_order(g.tileCost, g.tileOrder, tiles_all, g.orderMode, 4 * cus, stream);
+            g.orderW = p.W; g.orderH = p.H;
+        }
         if (g.variant == 2) {
             const int tiles = ((p.W + 7) >> 3) * ((p.H + 7) >> 3);
             g.residentTarget += unsigned(g.waveCap > 0 && g.waveCap < tiles ? (g.waveCap + 7) & ~7 : (tiles + 7) & ~7);
@@ -715,6 +738,14 @@ bool endsWith(const std::string& s, const char* suffix)
 }  // namespace
 
 extern "C" {
+
+int isoSetTileOrderMode(int mode)
+{
+    if (mode < 0 || mode > 2) return -1;
+    g.orderMode = mode;
+    g.orderW = g.orderH = 0;
+    return 0;
+}
 
 int initGVDB(void)
 {
@@ -981,6 +1012,9 @@ void isoShutdown(void)
     if (g.aoRot) (void)hipFree(g.aoRot);
     if (g.tileQueue) (void)hipFree(g.tileQueue);
     g.tileQueue = nullptr;
+    if (g.tileCost) (void)hipFree(g.tileCost);
+    if (g.tileOrder) (void)hipFree(g.tileOrder);
+    g.tileCost = nullptr; g.tileOrder = nullptr; g.orderW = g.orderH = 0;
     g.aoHemi = g.aoRot = nullptr;
     g.initialised = false;
 }

@@ -747,7 +747,9 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg)
 template <bool AO, int FLAT = 3>
 __device__ __forceinline__ void render_gather_tile(const IsoRenderParams& P, int vb, int tiles_x, int ntiles, int lane, bool remap = true)
 {
-    const int tile = remap ? xcd_remap(vb, ntiles) : vb;
+    const bool ordered = remap && P.tileOrder != nullptr;
+    const long long c0 = P.tileCost ? (long long)__builtin_amdgcn_s_memtime() : 0;
+    const int tile = ordered ? (int)P.tileOrder[vb] : (remap ? xcd_remap(vb, ntiles) : vb);
     const int i = (tile % tiles_x) * 8 + (lane & 7);
     const int j = (tile / tiles_x) * 8 + (lane >> 3);
     if (i >= P.W || j >= P.H) return;
@@ -766,6 +768,38 @@ __device__ __forceinline__ void render_gather_tile(const IsoRenderParams& P, int
         if (hit) shade_hit<AO, FLAT>(P, r, it, wdx, wdy, wdz, i, j, o);
     }
     store_pixel(P, i, j, o);
+    // the wave's cost for the next frame's dispatch order: its lanes leave the traversal together, any lane may write
+    if (P.tileCost && remap && lane == 0)
+        P.tileCost[tile] = (unsigned)((long long)__builtin_amdgcn_s_memtime() - c0);
+}
+
+// ---- cost-ordered dispatch: one workgroup sorts the (cost, tile) pairs of the previous frame (bitonic, in LDS) -------------
+__global__ __launch_bounds__(1024) void iso_tile_order_kernel(const unsigned* __restrict__ cost, unsigned short* __restrict__ order,
+                                                               int n, int mode, int slots)
+{
+    __shared__ unsigned long long key[ISO_ORDER_MAX_TILES];
+    const int tid = threadIdx.x;
+    // key = (cost + 1) << 16 | tile; the padding (key 0) sorts behind every real tile
+    for (int k = tid; k < ISO_ORDER_MAX_TILES; k += 1024)
+        key[k] = k < n ? ((((unsigned long long)cost[k] + 1ull) << 16) | (unsigned)k) : 0ull;
+    __syncthreads();
+    for (int size = 2; size <= ISO_ORDER_MAX_TILES; size <<= 1)
+        for (int stride = size >> 1; stride > 0; stride >>= 1) {
+            for (int k = tid; k < ISO_ORDER_MAX_TILES / 2; k += 1024) {
+                const int lo = 2 * k - (k & (stride - 1)), hi = lo + stride;
+                const bool desc = (lo & size) == 0;                          // overall descending
+                const unsigned long long a = key[lo], b = key[hi];
+                if ((a < b) == desc) { key[lo] = b; key[hi] = a; }
+            }
+            __syncthreads();
+        }
+    // key[0 .. n) now holds the real tiles, heaviest first
+    for (int k = tid; k < n; k += 1024) {
+        int src = k;
+        if (mode == 2 && k >= slots) src = n - 1 - (k - slots);             // second waves: lightest first
+        if (mode == 2 && k < slots) src = k;
+        order[k] = (unsigned short)(key[src] & 0xffffu);
+    }
 }
 
 template <bool AO, int FLAT>
@@ -1250,6 +1284,12 @@ void iso_launch_render(const IsoRenderParams& p, int variant, void* stream, void
         if (p.aoSamples > 0) hipExtLaunchKernelGGL((iso_render_gather<true, 3>), grid, block, 0, st, e0, e1, 0, p);
         else hipExtLaunchKernelGGL((iso_render_gather<false, 3>), grid, block, 0, st, e0, e1, 0, p);
     }
+}
+
+void iso_launch_tile_order(const unsigned* cost, unsigned short* order, int n, int mode, int slots, void* stream)
+{
+    if (n <= 0 || n > ISO_ORDER_MAX_TILES) return;
+    hipLaunchKernelGGL(iso_tile_order_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, cost, order, n, mode, slots);
 }
 
 void iso_launch_render_stats(const IsoRenderParams& p, int variant, long long* out, void* stream)

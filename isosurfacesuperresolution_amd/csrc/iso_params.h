@@ -48,7 +48,13 @@ struct IsoRenderParams {
     const float* aoRot;          // [16][4] per-pixel (x%4, y%4) rotation vectors
     unsigned* tileQueue;         // variant 2: 8 per-XCD tile counters, zeroed before the launch
     unsigned* resident;          // variant 2: every wave adds 1 when it starts (never reset; see iso_launch_gate)
+    // cost-ordered dispatch (variant 0, at most ISO_ORDER_MAX_TILES tiles): tileCost[tile] receives the wave's clock cycles,
+    // tileOrder[block] (or NULL: the XCD-aware scan order) says which tile a workgroup renders -- a permutation built from the
+    // PREVIOUS frame's costs (iso_launch_tile_order), so the output is unchanged bit for bit
+    unsigned* tileCost;
+    const unsigned short* tileOrder;
 };
+constexpr int ISO_ORDER_MAX_TILES = 4096;
 
 // Per-frame constants of the `semantics=gvdb` kernel (iso_gvdb.hip), prepared in double and narrowed to float
 struct IsoGvdbFrame {
@@ -69,6 +75,9 @@ struct IsoGvdbFrame {
 // waveCap: variant 2 only -- launch at most this many one-wave workgroups (0 = one per 8x8 tile)
 void iso_launch_render(const IsoRenderParams& p, int variant, void* stream, void* startEvent, void* stopEvent, int waveCap);
 void iso_launch_render_gvdb(const IsoRenderParams& p, const IsoGvdbFrame& f, void* stream, void* startEvent, void* stopEvent);
+// order[0 .. n) = a permutation of the tiles from cost[0 .. n): mode 1 heaviest first; mode 2 heaviest first for the first
+// `slots` workgroups (one per SIMD), then the LIGHTEST first, so that a SIMD's second wave is light where its first is heavy
+void iso_launch_tile_order(const unsigned* cost, unsigned short* order, int n, int mode, int slots, void* stream);
 // diagnostics: variant 0 with per-tile clocks and step counts, out[tiles][6] (see iso_render_stats)
 void iso_launch_render_stats(const IsoRenderParams& p, int variant, long long* out, void* stream);
 // One wave on `stream` that spins until *resident has reached `target` (wrap-safe) or `timeoutUs` have passed.

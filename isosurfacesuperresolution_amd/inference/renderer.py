@@ -64,6 +64,8 @@ class DirectRenderer:
         lib.isoGateResident.restype = ctypes.c_int
         lib.isoSetWaveCap.argtypes = [ctypes.c_int]
         lib.isoSetWaveCap.restype = ctypes.c_int
+        lib.isoSetTileOrderMode.argtypes = [ctypes.c_int]
+        lib.isoSetTileOrderMode.restype = ctypes.c_int
         lib.isoProfileEnable.argtypes = [ctypes.c_int]
         lib.isoProfileEnable.restype = ctypes.c_int
         lib.isoProfileCount.argtypes = []
@@ -157,6 +159,10 @@ class DirectRenderer:
     def gate_resident(self, stream, timeout_us=100):
         """Additive: see isoGateResident.  ``stream``: a torch.cuda.Stream."""
         return self.lib.isoGateResident(ctypes.c_void_p(stream.cuda_stream), int(timeout_us))
+
+    def set_tile_order_mode(self, mode):
+        """Additive: see isoSetTileOrderMode (cost-ordered dispatch of the default kernel from the previous frame's tile costs)."""
+        return self.lib.isoSetTileOrderMode(int(mode))
 
     def set_wave_cap(self, waves):
         """Additive: see isoSetWaveCap (variant 2, side-stream rendering under the SR network)."""
