@@ -33,7 +33,7 @@ sys.path.insert(0, ROOT)
 MFMA_F32_PEAK_TFLOPS = 157.3      # /opt/skills/guides/MI355X_MICROARCH.md, chip-level parameters
 MFMA_F16_PEAK_TFLOPS = 2500.0     # dense fp16/bf16 MFMA (same table)
 HBM_PEAK_GBS = 8000.0
-PMC_TRAFFIC_FILES = ("r02_pmc_traffic.json", "r01_pmc_traffic.json")   # committed rocprofv3 --pmc passes of this command
+PMC_TRAFFIC_FILES = ("r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json")   # committed rocprofv3 --pmc passes of this command
 
 
 def parse(argv=None):
@@ -260,7 +260,7 @@ def run_infer(args, job):
     # Roofline of the dominant kernel.  `achieved` is always ALGORITHMIC: 2*9*Cin*Cout flops per output pixel.  The exact
     # kernels spend one fp32 MFMA multiply-accumulate per algorithmic one (peak 157.3); the split-operand kernels spend
     # three fp16 ones (x_hi*w_hi + x_hi*w_lo + x_lo*w_hi), so their ceiling is a third of the dense fp16 MFMA peak.
-    split = dom_name.startswith("conv3x3_split")
+    split = dom_name.startswith("conv3x3_split") or dom_name.startswith("resblock_split")
     peak = MFMA_F16_PEAK_TFLOPS / 3.0 if split else MFMA_F32_PEAK_TFLOPS
 
     result = {
@@ -280,7 +280,8 @@ def run_infer(args, job):
             "overlap": ("render(t+1) on a side HIP stream || SR(t)" + (", kernel variant %d capped at %d ray-march waves" % (pipe.side_variant, pipe.side_waves)
                                                                        if pipe.side_variant == 2 else "")) if overlap else "off",
             "conv_kernels": "exact fp32 fmaf chain (v_mfma_f32_32x32x2_f32)" if args.exact else
-                            "split-operand: 3 x v_mfma_f32_32x32x16_f16 per product, fp32 accumulation (bench.py --exact = fp32 MFMA kernels)"},
+                            "split-operand: 3 x v_mfma_f32_32x32x16_f16 per product, fp32 accumulation (bench.py --exact = fp32 MFMA kernels); "
+                            "1080p tail fused (postblock.6 + postblock.8 + finish), packed-split hand-over postblock.4 -> tail and inside the blocks"},
         **rank_keys,
         "roofline": {"kernel": dom_name, "bound": "mfma", "achieved": achieved, "peak": peak,
                      "unit": "TFLOP/s", "frac": achieved / peak, "traffic": traffic,
@@ -290,9 +291,12 @@ def run_infer(args, job):
                      "traffic_source": ("profiles/%s (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, bytes per launch)" % traffic_file) if traffic else None,
                      "avg_launch_ms": dom_time / dom_launches * 1e3, "launches_per_frame": dom_launches / K,
                      "flops_per_launch": dom_flops / dom_launches},
-        "kernels": {n: {"tflops": v[0] / v[1] / 1e12, "ms_per_frame": v[1] / K * 1e3, "launches_per_frame": v[2] / K}
+        # every profiled kernel with ITS OWN roofline fraction (the 1080p kernels and the 480 x 270 trunk are bound differently)
+        "kernels": {n: {"tflops": v[0] / v[1] / 1e12, "ms_per_frame": v[1] / K * 1e3, "launches_per_frame": v[2] / K,
+                        "frac": v[0] / v[1] / 1e12 / ((MFMA_F16_PEAK_TFLOPS / 3.0) if (n.startswith("conv3x3_split") or n.startswith("resblock_split"))
+                                                      else MFMA_F32_PEAK_TFLOPS)}
                     for n, v in per.items()},
-        "raymarch": {"kernel": "iso_render_gather_slim (under the network)" if overlap else "iso_render_gather",
+        "raymarch": {"kernel": "iso_render_gather (on a side stream under the network)" if overlap else "iso_render_gather",
                      "ms_per_frame": rm_time * 1e3, "alone_ms_per_frame": rm_alone * 1e3},
     }
 

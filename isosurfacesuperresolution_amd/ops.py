@@ -12,6 +12,7 @@
 * CPU tensors: the reference's own CPU path, i.e. plain PyTorch ops (BASELINE config #1).
 """
 import ctypes
+import os
 import warnings
 import weakref
 
@@ -107,6 +108,9 @@ def _sr():
         lib.isrResBlockSplit.argtypes = [vp, vp, vp, vp, vp, vp, vp, ci, ci, ll, ll, vp]; lib.isrResBlockSplit.restype = ci
         lib.isrSetRangeFlag.argtypes = [vp]; lib.isrSetRangeFlag.restype = None
         lib.isrProfileEnable.argtypes = [ci]; lib.isrProfileEnable.restype = ci
+        lib.isrDebugSetSplitAlgo.argtypes = [ci]
+        if os.environ.get("ISR_SPLIT_ALGO"):          # experiments: force a kernel form of the plain split layers (see sr_conv_split.hip)
+            lib.isrDebugSetSplitAlgo(int(os.environ["ISR_SPLIT_ALGO"]))
         lib.isrProfileCount.argtypes = []; lib.isrProfileCount.restype = ci
         lib.isrProfileGet.argtypes = [ci, vp, vp, vp]; lib.isrProfileGet.restype = ci
         _lib = lib
@@ -735,8 +739,8 @@ class _ResidualBlockFunction(torch.autograd.Function):
 
 
 # Inference: the whole block in ONE launch (csrc/sr_conv_block.hip) -- bit-identical to the two split-operand launches
-BLOCK_FUSION = False
-BLOCK_PACKED = True                # two launches per block, the intermediate packed-split (see residual_block)
+BLOCK_FUSION = os.environ.get("ISR_BLOCK_FUSION", "0") == "1"
+BLOCK_PACKED = os.environ.get("ISR_BLOCK_PACKED", "1") != "0"       # two launches per block, the intermediate packed-split (see residual_block)
 BLOCK_PACKED_MIN_TILES = 256
 BLOCK_FUSION_MIN_TILES = 256       # below that the persistent grid is not filled; the per-layer kernels' small-image forms take over
 _block_ws = {}
@@ -1230,7 +1234,7 @@ class PackedSplit:
         return v.permute(0, 2, 1).reshape(1, self.channels, self.h, self.w)
 
 
-TAIL_PACKED = True       # hand postblock.4's output to the fused tail packed-split (frame pipeline)
+TAIL_PACKED = os.environ.get("ISR_TAIL_PACKED", "1") != "0"       # hand postblock.4's output to the fused tail packed-split (frame pipeline)
 
 
 def conv3x3_split_packed(x, weight, bias=None, act='relu', slope=0.01, upsample2x=False):

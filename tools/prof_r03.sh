@@ -7,13 +7,13 @@ cd $GRAFT_REPO_ROOT
 export TMPDIR=/tmp
 OUT=gpurun_out/r03_prof
 rm -rf $OUT; mkdir -p $OUT
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -o bench -- python3 bench.py --no-cpu-baseline --no-fast-mode > $OUT/stats.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -o bench -- python3 bench.py --no-cpu-baseline --no-fast-mode --no-exact-leg > $OUT/stats.log 2>&1
 echo "stats done"
-rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/fetch -o run -- python3 bench.py --no-cpu-baseline --no-fast-mode --steps 5 --warmup 2 > $OUT/fetch.log 2>&1
+rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/fetch -o run -- python3 bench.py --no-cpu-baseline --no-fast-mode --no-exact-leg --steps 5 --warmup 2 > $OUT/fetch.log 2>&1
 echo "fetch done"
-rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/write -o run -- python3 bench.py --no-cpu-baseline --no-fast-mode --steps 5 --warmup 2 > $OUT/write.log 2>&1
+rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/write -o run -- python3 bench.py --no-cpu-baseline --no-fast-mode --no-exact-leg --steps 5 --warmup 2 > $OUT/write.log 2>&1
 echo "write done"
-rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F16 SQ_LDS_BANK_CONFLICT SQ_BUSY_CYCLES --output-format csv -d $OUT/sq -o run -- python3 bench.py --no-cpu-baseline --no-fast-mode --steps 5 --warmup 2 > $OUT/sq.log 2>&1
+rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F16 SQ_LDS_BANK_CONFLICT SQ_BUSY_CYCLES --output-format csv -d $OUT/sq -o run -- python3 bench.py --no-cpu-baseline --no-fast-mode --no-exact-leg --steps 5 --warmup 2 > $OUT/sq.log 2>&1
 echo "sq done"
 python3 - <<'PY'
 import csv, glob
