@@ -341,7 +341,8 @@ def run_train(args, job):
     with contextlib.redirect_stdout(sys.stderr):
         net = models.createNetwork('EnhanceNet', 4, 101, [0, 1, 2, 3, 4], 6, opt).to(dev)
         crit = losses.LossNetUnshaded(dev, 5, 6, 4 * crop, crop // 2, opt).to(dev)
-    optim, _ = train.make_optimizer(net, capturable=(dev == "cuda"))
+    # FlatAdam: torch.optim.Adam's update over one flat buffer in one launch; its gradient buffer is the all-reduce bucket
+    optim, _ = train.make_optimizer(net, capturable=(dev == "cuda"), flat=True)
     trainer = train.DataParallelTrainer(net, crit, optim)
     batch = _clip_batch(torch, per, T, crop, 1000 + rank, dev)
     from isosurfacesuperresolution_amd import ops

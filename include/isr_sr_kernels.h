@@ -185,6 +185,12 @@ int isrRecurrentInputForward(const float* prev_raw, const float* input, const fl
 int isrRecurrentInputBackward(const float* prev_raw, const float* flow, const float* g_net_input, const float* g_warped,
                               float* scratch, float* g_prev_raw, int B, int h, int w, long long flowBatchStride, void* stream);
 
+/* One step of Adam (torch.optim.Adam as mainVideoUnshaded.py:287-289 uses it: betas (0.9, 0.999), eps 1e-8, no weight decay) over
+ * FLAT buffers of n floats: params -= lr / (1 - b1^t) * m / (sqrt(v) / sqrt(1 - b2^t) + eps) with the moments updated first;
+ * step[0] (device float) = steps taken so far, incremented by the call.  lr_dev (device, may be NULL) overrides lr. */
+int isrAdamFlatStep(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, long long n, const float* lr_dev, float lr,
+                    float beta1, float beta2, float eps, float* step, void* stream);
+
 /* gz = gy * act'(y) for the activations above (y is the post-activation output, before the residual add). */
 int isrActBackward(const float* gy, const float* y, float* gz, long long count, int act, float slope, void* stream);
 

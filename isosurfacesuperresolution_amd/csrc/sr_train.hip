@@ -631,7 +631,41 @@ __global__ __launch_bounds__(256) void recurrent_input_post_kernel(const RecurPa
 
 } // namespace
 
+// One Adam step (torch.optim.Adam: no weight decay, no amsgrad) over FLAT parameter / gradient / moment buffers: the whole
+// network's 911 046 parameters in one launch instead of ~100 per-tensor launches of the framework's optimizer.  `step` holds the
+// number of steps taken so far (device, so that a HIP graph replays the right bias corrections); it is read here and
+// incremented by adam_flat_count_kernel afterwards.  lr_dev (may be NULL) overrides lr: a learning rate a scheduler changes
+// between graph replays.
+__global__ __launch_bounds__(256) void adam_flat_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                                                         float* __restrict__ v, long long n, const float* lr_dev, float lr, float b1, float b2,
+                                                         float eps, const float* __restrict__ step)
+{
+    const float t = step[0] + 1.0f;
+    const float bc1 = 1.0f - powf(b1, t), bc2s = sqrtf(1.0f - powf(b2, t));
+    const float step_size = (lr_dev ? lr_dev[0] : lr) / bc1;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+        const float gi = g[i];
+        const float mi = m[i] + (gi - m[i]) * (1.0f - b1);                  // exp_avg.lerp_(grad, 1 - beta1)
+        const float vi = v[i] * b2 + (1.0f - b2) * gi * gi;                // exp_avg_sq.mul_(beta2).addcmul_(grad, grad, value = 1 - beta2)
+        m[i] = mi; v[i] = vi;
+        p[i] -= step_size * (mi / (sqrtf(vi) / bc2s + eps));
+    }
+}
+
+__global__ void adam_flat_count_kernel(float* step) { step[0] += 1.0f; }
+
 extern "C" {
+
+int isrAdamFlatStep(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, long long n, const float* lr_dev, float lr,
+                    float beta1, float beta2, float eps, float* step, void* stream)
+{
+    if (!params || !grads || !exp_avg || !exp_avg_sq || !step || n <= 0) return -1;
+    const long long blocks = (n + 255) / 256;
+    hipLaunchKernelGGL(adam_flat_kernel, dim3((unsigned)(blocks > 4096 ? 4096 : blocks)), dim3(256), 0, (hipStream_t)stream,
+                       params, grads, exp_avg, exp_avg_sq, n, lr_dev, lr, beta1, beta2, eps, (const float*)step);
+    hipLaunchKernelGGL(adam_flat_count_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, step);
+    return hipGetLastError() == hipSuccess ? 0 : -2;
+}
 
 int isrUpsample2xForward(const float* x, float* y, long long planes, int h, int w, void* stream)
 {

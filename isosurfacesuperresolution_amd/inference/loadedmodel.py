@@ -55,7 +55,7 @@ class _CheckpointPickle:
     _STORAGE = re.compile(r"^(Float|Double|Half|BFloat16|Long|Int|Short|Char|Byte|Bool)Storage$")
     # packages whose CLASSES (checked below) may be named freely
     _CLASS_PACKAGES = ("torch.nn.modules.", "torch.optim.", "isosurfacesuperresolution_amd.models", "isosurfacesuperresolution_amd.utils",
-                       "isosurfacesuperresolution_amd.losses")
+                       "isosurfacesuperresolution_amd.losses", "isosurfacesuperresolution_amd.train")
 
     class Unpickler(pickle.Unpickler):
         def find_class(self, module, name):

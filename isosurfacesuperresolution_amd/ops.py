@@ -106,6 +106,7 @@ def _sr():
         lib.isrResBlockSplitWorkspaceBytes.argtypes = []; lib.isrResBlockSplitWorkspaceBytes.restype = ll
         lib.isrResBlockSplitSupported.argtypes = [vp, ci, ci, ll, ll]; lib.isrResBlockSplitSupported.restype = ci
         lib.isrResBlockSplit.argtypes = [vp, vp, vp, vp, vp, vp, vp, ci, ci, ll, ll, vp]; lib.isrResBlockSplit.restype = ci
+        lib.isrAdamFlatStep.argtypes = [vp, vp, vp, vp, ll, vp, cf, cf, cf, cf, vp, vp]; lib.isrAdamFlatStep.restype = ci
         lib.isrSetRangeFlag.argtypes = [vp]; lib.isrSetRangeFlag.restype = None
         lib.isrProfileEnable.argtypes = [ci]; lib.isrProfileEnable.restype = ci
         lib.isrDebugSetSplitAlgo.argtypes = [ci]
@@ -1102,6 +1103,25 @@ def loss_unshaded_config(weight_dict, padding, shading):
 def loss_unshaded(gt, pred, prev, cfg):
     """-> values[16] (differentiable w.r.t. pred and prev through values[15], the weighted total)."""
     return _LossUnshadedFunction.apply(gt, pred, prev, cfg)
+
+
+def adam_flat_step(params, grads, exp_avg, exp_avg_sq, step, lr, beta1, beta2, eps):
+    """One Adam step over flat fp32 buffers (``isrAdamFlatStep``); ``lr``: float or one-element device tensor; ``step``: one-element
+    float32 device tensor counting the steps taken (incremented).  CPU tensors: the same arithmetic with PyTorch ops."""
+    if not params.is_cuda:
+        t = float(step.item()) + 1.0
+        lr_v = float(lr.item()) if torch.is_tensor(lr) else float(lr)
+        exp_avg.lerp_(grads, 1.0 - beta1)
+        exp_avg_sq.mul_(beta2).addcmul_(grads, grads, value=1.0 - beta2)
+        denom = (exp_avg_sq.sqrt() / (1.0 - beta2 ** t) ** 0.5).add_(eps)
+        params.addcdiv_(exp_avg, denom, value=-lr_v / (1.0 - beta1 ** t))
+        step.add_(1.0)
+        return
+    lr_dev = lr if torch.is_tensor(lr) else None
+    rc = _sr().isrAdamFlatStep(_ptr(params), _ptr(grads), _ptr(exp_avg), _ptr(exp_avg_sq), params.numel(), _ptr(lr_dev),
+                               0.0 if lr_dev is not None else float(lr), float(beta1), float(beta2), float(eps), _ptr(step), _stream())
+    if rc != 0:
+        raise RuntimeError("isrAdamFlatStep failed (%d)" % rc)
 
 
 # ---- fused frame assembly (inference) ---------------------------------------------------------

@@ -101,15 +101,72 @@ def clip_loss(model, criterion, input, flow, target, initial_image="zero", upsca
     return loss, loss_sum
 
 
-def make_optimizer(model, lr=1e-4, lr_step=500, lr_gamma=0.5, capturable=False, tensor_lr=False):
+def make_optimizer(model, lr=1e-4, lr_step=500, lr_gamma=0.5, capturable=False, tensor_lr=False, flat=False):
     """Adam + StepLR of mainVideoUnshaded.py:287-300.  ``tensor_lr``: the learning rate lives in a device tensor, so that
-    a scheduler step is seen by an optimizer step captured in a HIP graph (needs ``capturable``)."""
+    a scheduler step is seen by an optimizer step captured in a HIP graph (needs ``capturable``).  ``flat``: ``FlatAdam`` -- the
+    same update over one flat buffer in one launch (parameters and gradients become views of it)."""
     params = list(model.parameters())
+    if flat:
+        opt = FlatAdam(params, lr=lr, tensor_lr=tensor_lr)
+        return opt, torch.optim.lr_scheduler.StepLR(opt, lr_step, lr_gamma)
     if tensor_lr:
         lr = torch.tensor(float(lr), dtype=torch.float32, device=params[0].device)
     opt = torch.optim.Adam(params, lr=lr, capturable=capturable)
     sched = torch.optim.lr_scheduler.StepLR(opt, lr_step, lr_gamma)
     return opt, sched
+
+
+class FlatAdam(torch.optim.Optimizer):
+    """``torch.optim.Adam`` (the reference's optimizer, mainVideoUnshaded.py:287-289: lr 1e-4, betas (0.9, 0.999), eps 1e-8, no
+    weight decay) over ONE flat buffer: every parameter of the model becomes a view of ``self.flat`` and every gradient a view of
+    ``self.bucket``, so a step is one launch (``isrAdamFlatStep``) instead of ~100 per-tensor launches, zeroing the gradients one
+    ``zero_``, and the data-parallel exchange one all-reduce of ``self.bucket`` (``DataParallelTrainer`` adopts it).  The step
+    counter and (optionally) the learning rate live on the device, so a HIP graph of the step replays correctly.
+
+    Build it AFTER ``model.to(device)`` (moving the model afterwards would detach the views).  A step writes the parameters'
+    memory without advancing ``Parameter._version``: it declares the cached kernel-layout weight images stale itself."""
+
+    def __init__(self, params, lr=1e-4, betas=(0.9, 0.999), eps=1e-8, tensor_lr=False):
+        params = [p for p in params if p.requires_grad]
+        n = sum(p.numel() for p in params)
+        dev, dt = params[0].device, params[0].dtype
+        flat = torch.empty(n, dtype=dt, device=dev)
+        bucket = torch.zeros(n, dtype=dt, device=dev)
+        off = 0
+        with torch.no_grad():
+            for p in params:
+                k = p.numel()
+                flat[off:off + k].copy_(p.detach().reshape(-1))
+                p.data = flat[off:off + k].view_as(p)
+                p.grad = bucket[off:off + k].view_as(p)
+                off += k
+        self.members = params
+        self.flat = torch.nn.Parameter(flat)
+        self.flat.grad = bucket
+        self.bucket = bucket
+        if tensor_lr and not torch.is_tensor(lr):
+            lr = torch.tensor(float(lr), dtype=torch.float32, device=dev)
+        super().__init__([self.flat], dict(lr=lr, betas=betas, eps=eps))
+        self.exp_avg = torch.zeros_like(flat)
+        self.exp_avg_sq = torch.zeros_like(flat)
+        self.steps = torch.zeros(1, dtype=torch.float32, device=dev)
+
+    def zero_grad(self, set_to_none=False):
+        self.bucket.zero_()
+
+    def check_views(self):
+        base, esz, off = self.bucket.data_ptr(), self.bucket.element_size(), 0
+        for p in self.members:
+            if p.grad is None or p.grad.data_ptr() != base + off * esz or p.data_ptr() != self.flat.data_ptr() + off * esz:
+                raise RuntimeError("FlatAdam: a parameter or its .grad is no longer a view of the flat buffers "
+                                   "(model.to() after construction, or an optimizer.zero_grad(set_to_none=True) elsewhere)")
+            off += p.numel()
+
+    @torch.no_grad()
+    def step(self, closure=None):
+        g = self.param_groups[0]
+        ops.adam_flat_step(self.flat.data, self.bucket, self.exp_avg, self.exp_avg_sq, self.steps, g['lr'], g['betas'][0], g['betas'][1], g['eps'])
+        ops.invalidate_weight_images()
 
 
 def step_scheduler(optimizer, scheduler):
@@ -130,7 +187,7 @@ def step_scheduler(optimizer, scheduler):
 def train_step(model, criterion, optimizer, batch, **kw):
     """One optimisation step on a clip batch (single process)."""
     input, flow, target = batch
-    optimizer.zero_grad()
+    optimizer.zero_grad()          # (FlatAdam: one zero_ of its flat gradient buffer, the views stay)
     loss, loss_sum = clip_loss(model, criterion, input, flow, target, **kw)
     backward(loss)
     optimizer.step()
@@ -155,7 +212,9 @@ class GraphedTrainStep:
     def __init__(self, model, criterion, optimizer, example_batch, all_reduce=None, zero_grad=None, warmup=3, **kw):
         self.model, self.criterion, self.optimizer, self.kw = model, criterion, optimizer, kw
         self.all_reduce = all_reduce
-        self.zero_grad = zero_grad if zero_grad is not None else (lambda: self.optimizer.zero_grad(set_to_none=True))
+        if zero_grad is None:
+            zero_grad = self.optimizer.zero_grad if isinstance(self.optimizer, FlatAdam) else (lambda: self.optimizer.zero_grad(set_to_none=True))
+        self.zero_grad = zero_grad
         self.static = tuple(torch.empty_like(t) for t in example_batch)
         for dst, src in zip(self.static, example_batch):
             dst.copy_(src)
@@ -206,12 +265,16 @@ class DataParallelTrainer:
         self.params = [p for p in model.parameters() if p.requires_grad]
         self.numel = sum(p.numel() for p in self.params)
         first = self.params[0]
-        self.bucket = torch.zeros(self.numel, dtype=first.dtype, device=first.device)
-        off = 0
-        for p in self.params:
-            n = p.numel()
-            p.grad = self.bucket[off:off + n].view_as(p)
-            off += n
+        if isinstance(optimizer, FlatAdam) and optimizer.bucket.numel() == self.numel:
+            optimizer.check_views()
+            self.bucket = optimizer.bucket         # the optimizer's flat gradient buffer IS the all-reduce bucket
+        else:
+            self.bucket = torch.zeros(self.numel, dtype=first.dtype, device=first.device)
+            off = 0
+            for p in self.params:
+                n = p.numel()
+                p.grad = self.bucket[off:off + n].view_as(p)
+                off += n
         if self.world > 1:
             for p in self.params:          # identical start on every rank
                 dist.broadcast(p.data, src=0, group=process_group)
@@ -362,7 +425,7 @@ def load_checkpoint(modeldir, restore_epoch=-1, device="cpu"):
 
 
 def fit(model, criterion, train_loader, test_loader, modeldir, n_epochs, parameters, device=None, lr=1e-4, lr_step=500, lr_gamma=0.5,
-        restore=False, restore_epoch=-1, graphed=None, log=print, **kw):
+        restore=False, restore_epoch=-1, graphed=None, flat_adam=False, log=print, **kw):
     """The epoch loop of mainVideoUnshaded.py:819-826 for the non-adversarial recipe:
 
         for epoch in range(start, n_epochs + 1):  trainNormal(epoch); test(epoch); checkpoint(epoch)
@@ -386,7 +449,8 @@ def fit(model, criterion, train_loader, test_loader, modeldir, n_epochs, paramet
         log("Restore training from %s and epoch %d" % (modeldir, start))
     else:
         model = model.to(device)
-        optimizer, scheduler = make_optimizer(model, lr, lr_step, lr_gamma, capturable=on_gpu and graphed, tensor_lr=on_gpu and graphed)
+        optimizer, scheduler = make_optimizer(model, lr, lr_step, lr_gamma, capturable=on_gpu and graphed, tensor_lr=on_gpu and graphed,
+                                              flat=flat_adam)
     eval_kw = {k: v for k, v in kw.items() if k in ("initial_image", "upscale", "upsample", "disable_temporal")}
     history = []
     step_fn, step_shape = None, None

@@ -135,3 +135,58 @@ def test_recurrent_frames_stay_within_the_parity_bound_with_a_contracting_networ
         prev_cpu = rc
         errs.append((raw.cpu() - rc).abs().max().item())
     assert max(errs) <= 1e-4, errs
+
+
+def test_flat_adam_matches_torch_adam_on_the_network():
+    """train.FlatAdam (one launch over the flat parameter buffer) against torch.optim.Adam after three training steps of
+    the same network on the same clips; and as a captured HIP graph (device-side step counter and learning rate)."""
+    from isosurfacesuperresolution_amd import losses, models, train
+    g = torch.Generator().manual_seed(2)
+    inp = torch.rand(2, 2, 5, 32, 32, generator=g); inp[:, :, 0] = inp[:, :, 0] * 2 - 1
+    flow = (torch.rand(2, 2, 2, 32, 32, generator=g) - 0.5) * 0.05
+    tgt = torch.rand(2, 2, 6, 128, 128, generator=g); tgt[:, :, 0] = tgt[:, :, 0] * 2 - 1
+    batch = tuple(t.cuda() for t in (inp, flow, tgt))
+    nets, hist = [], []
+    for kind in ("torch", "flat", "flat-graph"):
+        torch.manual_seed(124)
+        net = models.createNetwork('EnhanceNet', 4, 101, [0, 1, 2, 3, 4], 6, OPT).cuda()
+        crit = losses.LossNetUnshaded('cuda', 5, 6, 128, 16, OPT).cuda()
+        optim, sched = train.make_optimizer(net, lr=1e-3, lr_step=2, capturable=True, tensor_lr=(kind != "torch"), flat=(kind != "torch"))
+        if kind == "flat-graph":
+            step = train.GraphedTrainStep(net, crit, optim, batch, warmup=0, initial_image="zero")
+            ls = []
+            for k in range(3):
+                if k == 2:
+                    train.step_scheduler(optim, sched); train.step_scheduler(optim, sched)      # lr halves: seen by the replay
+                ls.append(float(step(batch)))
+        else:
+            ls = []
+            for k in range(3):
+                if k == 2:
+                    train.step_scheduler(optim, sched); train.step_scheduler(optim, sched)
+                ls.append(train.train_step(net, crit, optim, batch, initial_image="zero"))
+        nets.append(net); hist.append(ls)
+        if kind != "torch":
+            optim.check_views()
+    for other, name in ((1, "flat"), (2, "graph")):
+        assert np.allclose(hist[0], hist[other], rtol=2e-4), (name, hist)
+        # Adam normalises every gradient element by its own magnitude, so elements whose gradient is rounding noise (the warp's
+        # backward adds with float atomics) move by up to lr per step in either run: the parameters agree to a fraction of the
+        # three steps' movement, the exact comparison is the synthetic one below
+        for p, q in zip(nets[0].parameters(), nets[other].parameters()):
+            assert (p - q).abs().max().item() <= 1.5e-3, name
+            assert (p - q).abs().mean().item() <= 5e-5, name
+    # the update itself, on identical gradients: FlatAdam's kernel against torch.optim.Adam, five steps with a changing lr
+    torch.manual_seed(3)
+    a = torch.nn.Parameter(torch.randn(100003, device="cuda"))
+    b = torch.nn.Parameter(a.detach().clone())
+    oa = torch.optim.Adam([a], lr=3e-3)
+    ob = train.FlatAdam([b], lr=3e-3)
+    for k in range(5):
+        grad = torch.randn(100003, device="cuda") * (10.0 ** (k - 3))
+        a.grad = grad.clone()
+        ob.zero_grad(); b.grad.copy_(grad)
+        for o in (oa, ob):
+            o.param_groups[0]['lr'] = 3e-3 / (k + 1)
+            o.step()
+    assert (a - b).abs().max().item() <= 1e-6
