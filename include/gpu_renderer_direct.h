@@ -69,7 +69,8 @@ int isoLoadDenseDevice(unsigned long long devicePtr, int nx, int ny, int nz);
  * leaves inside [clipLo, clipHi) (global index coordinates, clipLo a multiple of 8), so the pixels it
  * produces are bit for bit those of the unsplit render wherever its leaves hold the first crossing, and
  * the nearest-hit composite of all tiles equals the unsplit image.  An all-zero tile is valid.  Ray-cast
- * AO sees only the tile's own leaves (use aosamples=0); semantics=gvdb is not available for tiles.
+ * AO inside render() sees only the tile's own leaves: render with aosamples=0 and use the exact tiled-AO passes
+ * (isoSetHitStateBuffer / isoAoDistancesAsync / isoAoFinishAsync below); semantics=gvdb is not available for tiles.
  * 0 ok, -2 on failure (misaligned origin / clipLo, region outside the stored data, no memory). */
 int isoLoadDenseTileHost(const float* hostData, int nx, int ny, int nz, const int origin[3],
                          const int globalActiveMin[3], const int globalActiveMax[3], float globalMax,
@@ -108,6 +109,23 @@ int isoSetWaveCap(int waves);
  * second wave is light where its first is heavy).  A pure permutation of the work: the G-buffer does not change.  0 = off
  * (default: the XCD-aware scan order).  Returns 0, or -1 for an unknown mode. */
 int isoSetTileOrderMode(int mode);
+
+/* Additive: EXACT ray-cast ambient occlusion for a volume split into tiles (isoLoadDenseTileHost).  An AO ray ends at its first
+ * hit anywhere in the volume (render_kernel.cu:109-146: computeAmbientOcclusion calls rayCast without a range), so no halo makes a
+ * tile's own AO right.  Instead, per frame:
+ *   1. every tile renders with aosamples = 0 and isoSetHitStateBuffer(ptr): besides the G-buffer it exports, per pixel it hits,
+ *      the AO rays' origin and the viewer-facing normal in double precision ([H][W][6] doubles, caller-owned device memory;
+ *      0 switches the export off);
+ *   2. the tiles' G-buffers AND hit states are composited by nearest hit (the winner's values are the unsplit pixel's);
+ *   3. with aosamples = n set, every tile runs isoAoDistancesAsync(hitState, gbuf, dist): each hit pixel's n rays against the
+ *      tile's OWN leaves, dist[H][W][n] doubles = distance to the first hit there or +inf;
+ *   4. the element-wise MINIMUM of the tiles' dist arrays (one all-reduce) is each ray's distance in the unsplit volume;
+ *   5. isoAoFinishAsync(dist, gbuf) writes channel 10 = mean of smoothstep(1, 0, aoradius / dist) in sample order.
+ * Same frame, directions, traversal and arithmetic as the unsplit kernel: the result equals it bit for bit.  0 ok, -1 on
+ * missing volume / null pointers / aosamples = 0 / semantics = gvdb. */
+int isoSetHitStateBuffer(unsigned long long devicePtr);
+int isoAoDistancesAsync(unsigned long long hitStatePtr, unsigned long long gbufPtr, unsigned long long distPtr, void* stream);
+int isoAoFinishAsync(unsigned long long distPtr, unsigned long long gbufPtr, void* stream);
 
 /* Enqueues a one-wave kernel on `stream` that returns once every wave of the most recently launched variant-2
  * render has started (or after `timeoutUs`).  Put on the stream of the SR network right after the render was

@@ -85,6 +85,7 @@ struct State {
     unsigned* tileCost = nullptr;    // [ISO_ORDER_MAX_TILES]
     unsigned short* tileOrder = nullptr;   // [ISO_ORDER_MAX_TILES]
     int orderW = 0, orderH = 0;      // resolution the stored order belongs to (0: none yet)
+    double* hitState = nullptr;      // isoSetHitStateBuffer: caller-owned [H][W][6] doubles the renders export their AO ray set-up to
     long long* statsOut = nullptr;   // diagnostics: isoDebugSetStatsBuffer
     bool profile = false;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> events;   // one pair per profiled frame
@@ -641,12 +642,12 @@ bool updateMarchFlags(Volume& v, double iso, hipStream_t stream)
     return true;
 }
 
-bool launchFrame(float* out, hipStream_t stream)
+// Everything a kernel needs to know about the volume, the camera and the shading, from the current Args (launchFrame, AO passes)
+bool buildParams(IsoRenderParams& p, float* out, hipStream_t stream)
 {
     const Args& a = g.args;
     const Volume& v = g.vol;
     if (!g.initialised || !v.loaded || !out || a.resolutionX <= 0 || a.resolutionY <= 0) return false;
-    IsoRenderParams p;
     std::memset(&p, 0, sizeof(p));
     IsoCamera last;
     buildCamera(p.cam, a.cameraOrigin, a.cameraLookAt, a.cameraUp, a.cameraFov, a.resolutionX, a.resolutionY);
@@ -687,6 +688,16 @@ bool launchFrame(float* out, hipStream_t stream)
     p.aoHemi = g.aoHemi; p.aoRot = g.aoRot;
     p.tileQueue = g.tileQueue;
     p.resident = g.tileQueue + 8;
+    p.hitState = g.hitState;
+    return true;
+}
+
+bool launchFrame(float* out, hipStream_t stream)
+{
+    IsoRenderParams p;
+    if (!buildParams(p, out, stream)) return false;
+    const Args& a = g.args;
+    const Volume& v = g.vol;
     const int tiles_all = ((p.W + 7) >> 3) * ((p.H + 7) >> 3);
     const bool ordering = g.orderMode > 0 && g.variant == 0 && g.semantics != 1 && !g.statsOut && tiles_all <= ISO_ORDER_MAX_TILES;
     if (ordering) {
@@ -738,6 +749,34 @@ bool endsWith(const std::string& s, const char* suffix)
 }  // namespace
 
 extern "C" {
+
+int isoSetHitStateBuffer(unsigned long long devicePtr)
+{
+    g.hitState = reinterpret_cast<double*>(devicePtr);
+    return 0;
+}
+
+int isoAoDistancesAsync(unsigned long long hitStatePtr, unsigned long long gbufPtr, unsigned long long distPtr, void* stream)
+{
+    if (!g.initialised || !g.vol.loaded || !hitStatePtr || !gbufPtr || !distPtr || g.semantics == 1) return -1;
+    IsoRenderParams p;
+    if (!buildParams(p, reinterpret_cast<float*>(gbufPtr), static_cast<hipStream_t>(stream))) return -1;
+    if (p.aoSamples <= 0) return -1;
+    p.hitState = nullptr;
+    iso_launch_ao_distances(p, reinterpret_cast<const double*>(hitStatePtr), reinterpret_cast<const float*>(gbufPtr),
+                            reinterpret_cast<double*>(distPtr), stream);
+    return hipGetLastError() == hipSuccess ? 0 : -1;
+}
+
+int isoAoFinishAsync(unsigned long long distPtr, unsigned long long gbufPtr, void* stream)
+{
+    if (!g.initialised || !g.vol.loaded || !gbufPtr || !distPtr) return -1;
+    IsoRenderParams p;
+    if (!buildParams(p, reinterpret_cast<float*>(gbufPtr), static_cast<hipStream_t>(stream))) return -1;
+    if (p.aoSamples <= 0) return -1;
+    iso_launch_ao_finish(p, reinterpret_cast<const double*>(distPtr), reinterpret_cast<float*>(gbufPtr), stream);
+    return hipGetLastError() == hipSuccess ? 0 : -1;
+}
 
 int isoSetTileOrderMode(int mode)
 {

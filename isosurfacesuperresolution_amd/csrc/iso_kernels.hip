@@ -634,33 +634,51 @@ __device__ bool cast_world(const IsoRenderParams& P, double ox, double oy, doubl
     return true;
 }
 
-template <int FLAT>
-__device__ double ambient_occlusion(const IsoRenderParams& P, double px, double py, double pz,
-                                    double nx, double ny, double nz, int x, int y)
+// the hemisphere frame of a pixel: tangent and bitangent around the normal from the 4 x 4-tiled rotation table
+struct AoFrame { double tx, ty, tz, bx, by, bz; };
+__device__ __forceinline__ AoFrame ao_frame(const IsoRenderParams& P, double nx, double ny, double nz, int x, int y)
 {
     const float* rot = P.aoRot + 4 * ((x % 4) + 4 * (y % 4));
     const double qx = rot[0], qy = rot[1], qz = rot[2];
     const double dn = qx * nx + qy * ny + qz * nz;
-    double tx = qx - nx * dn, ty = qy - ny * dn, tz = qz - nz * dn;
-    normalize3(tx, ty, tz);
-    const double bx = ny * tz - nz * ty, by = nz * tx - nx * tz, bz = nx * ty - ny * tx;
+    AoFrame f;
+    f.tx = qx - nx * dn; f.ty = qy - ny * dn; f.tz = qz - nz * dn;
+    normalize3(f.tx, f.ty, f.tz);
+    f.bx = ny * f.tz - nz * f.ty; f.by = nz * f.tx - nx * f.tz; f.bz = nx * f.ty - ny * f.tx;
+    return f;
+}
+// world direction of hemisphere sample i
+__device__ __forceinline__ void ao_direction(const IsoRenderParams& P, const AoFrame& f, double nx, double ny, double nz, int i,
+                                             double& wx, double& wy, double& wz)
+{
+    double sx = P.aoHemi[4 * i], sy = P.aoHemi[4 * i + 1], sz = P.aoHemi[4 * i + 2];
+    normalize3(sx, sy, sz);
+    wx = f.tx * sx + f.bx * sy + nx * sz;
+    wy = f.ty * sx + f.by * sy + ny * sz;
+    wz = f.tz * sx + f.bz * sy + nz * sz;
+    normalize3(wx, wy, wz);
+}
+// contribution of a sample whose ray hit at distance dist: smoothstep(1, 0, r / d)
+__device__ __forceinline__ double ao_value(const IsoRenderParams& P, double dist)
+{
+    double yv = 1.0 - P.aoRadius / dist;
+    yv = yv < 0.0 ? 0.0 : (yv > 1.0 ? 1.0 : yv);
+    return yv * yv * (3.0 - (2.0 * yv));
+}
+
+template <int FLAT>
+__device__ double ambient_occlusion(const IsoRenderParams& P, double px, double py, double pz,
+                                    double nx, double ny, double nz, int x, int y)
+{
+    const AoFrame f = ao_frame(P, nx, ny, nz, x, y);
     double ao = 0.0;
     const int n = P.aoSamples > 512 ? 512 : P.aoSamples;
     for (int i = 0; i < n; ++i) {
-        double sx = P.aoHemi[4 * i], sy = P.aoHemi[4 * i + 1], sz = P.aoHemi[4 * i + 2];
-        normalize3(sx, sy, sz);
-        double wx = tx * sx + bx * sy + nx * sz;
-        double wy = ty * sx + by * sy + ny * sz;
-        double wz = tz * sx + bz * sy + nz * sz;
-        normalize3(wx, wy, wz);
+        double wx, wy, wz;
+        ao_direction(P, f, nx, ny, nz, i, wx, wy, wz);
         double hx, hy, hz;
         double value = 1.0;
-        if (cast_world<FLAT>(P, px, py, pz, wx, wy, wz, hx, hy, hz)) {
-            const double dist = len3(px - hx, py - hy, pz - hz);
-            double yv = 1.0 - P.aoRadius / dist;                 // smoothstep(1, 0, r/d)
-            yv = yv < 0.0 ? 0.0 : (yv > 1.0 ? 1.0 : yv);
-            value = yv * yv * (3.0 - (2.0 * yv));
-        }
+        if (cast_world<FLAT>(P, px, py, pz, wx, wy, wz, hx, hy, hz)) value = ao_value(P, len3(px - hx, py - hy, pz - hz));
         ao += value;
     }
     return ao / n;
@@ -717,11 +735,16 @@ __device__ __forceinline__ void shade_hit(const IsoRenderParams& P, const Ray& r
         const double lw = wx * L[0][3] + wy * L[1][3] + wz * L[2][3] + 1.0 * L[3][3];
         o[8] = -(float)(lx / lw - cx / cw);
         o[9] = -(float)(ly / lw - cy / cw);
-        if (AO && P.aoSamples > 0) {
+        if ((AO && P.aoSamples > 0) || P.hitState) {
             // hemisphere around the normal that faces the viewer, origin pulled back by aoBias = 1e-3
             double ax = nx, ay = ny, az = nz;
             if (nx * wdx + ny * wdy + nz * wdz > 0) { ax = -ax; ay = -ay; az = -az; }
-            o[10] = (float)ambient_occlusion<FLAT>(P, wx - 1e-3 * wdx, wy - 1e-3 * wdy, wz - 1e-3 * wdz, ax, ay, az, px_, py_);
+            const double ox = wx - 1e-3 * wdx, oy = wy - 1e-3 * wdy, oz = wz - 1e-3 * wdz;
+            if (P.hitState) {            // tiled AO: the rays are cast later, by every tile (iso_ao_dist_kernel)
+                double* hs = P.hitState + ((size_t)py_ * P.W + px_) * 6;
+                hs[0] = ox; hs[1] = oy; hs[2] = oz; hs[3] = ax; hs[4] = ay; hs[5] = az;
+            }
+            if (AO && P.aoSamples > 0) o[10] = (float)ambient_occlusion<FLAT>(P, ox, oy, oz, ax, ay, az, px_, py_);
         }
     }
 }
@@ -771,6 +794,46 @@ __device__ __forceinline__ void render_gather_tile(const IsoRenderParams& P, int
     // the wave's cost for the next frame's dispatch order: its lanes leave the traversal together, any lane may write
     if (P.tileCost && remap && lane == 0)
         P.tileCost[tile] = (unsigned)((long long)__builtin_amdgcn_s_memtime() - c0);
+}
+
+// ---- ray-cast AO of a tiled volume, exactly ------------------------------------------------------------------------
+// One wave per 8 x 8 pixels; a lane casts the aoSamples rays of its pixel (origin and normal from the composite of the tiles'
+// hit-state exports) against THIS tile's leaves and writes each ray's hit distance (+inf: none here).  Same frame, directions,
+// traversal and distance arithmetic as ambient_occlusion(); the first hit of a ray in the unsplit volume lies in a leaf that
+// exactly one tile owns, which computes it bit for bit, every other tile a later one: min over the tiles = the unsplit distance.
+__global__ __launch_bounds__(64) void iso_ao_dist_kernel(const IsoRenderParams P, const double* __restrict__ hitState,
+                                                          const float* __restrict__ gbuf, double* __restrict__ dist)
+{
+    const int tiles_x = (P.W + 7) >> 3, ntiles = tiles_x * ((P.H + 7) >> 3);
+    const int tile = xcd_remap(blockIdx.x, ntiles), lane = threadIdx.x;
+    const int i = (tile % tiles_x) * 8 + (lane & 7), j = (tile / tiles_x) * 8 + (lane >> 3);
+    if (i >= P.W || j >= P.H) return;
+    const size_t pix = (size_t)j * P.W + i;
+    if (gbuf[pix * 12 + 3] != 1.0f) return;
+    const double* hs = hitState + pix * 6;
+    const double px = hs[0], py = hs[1], pz = hs[2], nx = hs[3], ny = hs[4], nz = hs[5];
+    const AoFrame f = ao_frame(P, nx, ny, nz, i, j);
+    const int n = P.aoSamples > 512 ? 512 : P.aoSamples;
+    for (int s = 0; s < n; ++s) {
+        double wx, wy, wz, hx, hy, hz;
+        ao_direction(P, f, nx, ny, nz, s, wx, wy, wz);
+        double d = __builtin_huge_val();
+        if (cast_world<3>(P, px, py, pz, wx, wy, wz, hx, hy, hz)) d = len3(px - hx, py - hy, pz - hz);
+        dist[pix * n + s] = d;
+    }
+}
+
+__global__ __launch_bounds__(256) void iso_ao_finish_kernel(const IsoRenderParams P, const double* __restrict__ dist, float* __restrict__ gbuf)
+{
+    const size_t pix = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (pix >= (size_t)P.W * P.H || gbuf[pix * 12 + 3] != 1.0f) return;
+    const int n = P.aoSamples > 512 ? 512 : P.aoSamples;
+    double ao = 0.0;
+    for (int s = 0; s < n; ++s) {
+        const double d = dist[pix * n + s];
+        ao += d == __builtin_huge_val() ? 1.0 : ao_value(P, d);
+    }
+    gbuf[pix * 12 + 10] = (float)(ao / n);
 }
 
 // ---- cost-ordered dispatch: one workgroup sorts the (cost, tile) pairs of the previous frame (bitonic, in LDS) -------------
@@ -1284,6 +1347,18 @@ void iso_launch_render(const IsoRenderParams& p, int variant, void* stream, void
         if (p.aoSamples > 0) hipExtLaunchKernelGGL((iso_render_gather<true, 3>), grid, block, 0, st, e0, e1, 0, p);
         else hipExtLaunchKernelGGL((iso_render_gather<false, 3>), grid, block, 0, st, e0, e1, 0, p);
     }
+}
+
+void iso_launch_ao_distances(const IsoRenderParams& p, const double* hitState, const float* gbuf, double* dist, void* stream)
+{
+    const int tiles = ((p.W + 7) >> 3) * ((p.H + 7) >> 3);
+    hipLaunchKernelGGL(iso_ao_dist_kernel, dim3(tiles), dim3(64), 0, (hipStream_t)stream, p, hitState, gbuf, dist);
+}
+
+void iso_launch_ao_finish(const IsoRenderParams& p, const double* dist, float* gbuf, void* stream)
+{
+    const size_t n = (size_t)p.W * p.H;
+    hipLaunchKernelGGL(iso_ao_finish_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, p, dist, gbuf);
 }
 
 void iso_launch_tile_order(const unsigned* cost, unsigned short* order, int n, int mode, int slots, void* stream)

@@ -53,6 +53,10 @@ struct IsoRenderParams {
     // PREVIOUS frame's costs (iso_launch_tile_order), so the output is unchanged bit for bit
     unsigned* tileCost;
     const unsigned short* tileOrder;
+    // exact ray-cast AO of an object-space TILED volume (iso_launch_ao_*): the render exports, per hit pixel, the AO
+    // rays' origin and the viewer-facing normal in double precision, every tile then casts every pixel's AO rays against its
+    // OWN leaves and writes the hit distances, the minimum over the tiles is the unsplit ray's distance
+    double* hitState;            // [H][W][6] or NULL: (origin xyz, normal xyz) exactly as ambient_occlusion() receives them
 };
 constexpr int ISO_ORDER_MAX_TILES = 4096;
 
@@ -78,6 +82,11 @@ void iso_launch_render_gvdb(const IsoRenderParams& p, const IsoGvdbFrame& f, voi
 // order[0 .. n) = a permutation of the tiles from cost[0 .. n): mode 1 heaviest first; mode 2 heaviest first for the first
 // `slots` workgroups (one per SIMD), then the LIGHTEST first, so that a SIMD's second wave is light where its first is heavy
 void iso_launch_tile_order(const unsigned* cost, unsigned short* order, int n, int mode, int slots, void* stream);
+// dist[H][W][aoSamples] (double): distance of AO sample s of pixel (i, j) to its first hit among this volume's (tile's) leaves,
+// +inf if none; pixels with gbuf mask != 1 are left untouched.  hitState: composite of the tiles' exports (P.hitState layout)
+void iso_launch_ao_distances(const IsoRenderParams& p, const double* hitState, const float* gbuf, double* dist, void* stream);
+// gbuf[.][10] = mean over the samples of smoothstep(1, 0, aoRadius / dist) (1 for +inf), summed in sample order as ambient_occlusion() does
+void iso_launch_ao_finish(const IsoRenderParams& p, const double* dist, float* gbuf, void* stream);
 // diagnostics: variant 0 with per-tile clocks and step counts, out[tiles][6] (see iso_render_stats)
 void iso_launch_render_stats(const IsoRenderParams& p, int variant, long long* out, void* stream);
 // One wave on `stream` that spins until *resident has reached `target` (wrap-safe) or `timeoutUs` have passed.

@@ -66,6 +66,12 @@ class DirectRenderer:
         lib.isoSetWaveCap.restype = ctypes.c_int
         lib.isoSetTileOrderMode.argtypes = [ctypes.c_int]
         lib.isoSetTileOrderMode.restype = ctypes.c_int
+        lib.isoSetHitStateBuffer.argtypes = [ctypes.c_ulonglong]
+        lib.isoSetHitStateBuffer.restype = ctypes.c_int
+        lib.isoAoDistancesAsync.argtypes = [ctypes.c_ulonglong, ctypes.c_ulonglong, ctypes.c_ulonglong, ctypes.c_void_p]
+        lib.isoAoDistancesAsync.restype = ctypes.c_int
+        lib.isoAoFinishAsync.argtypes = [ctypes.c_ulonglong, ctypes.c_ulonglong, ctypes.c_void_p]
+        lib.isoAoFinishAsync.restype = ctypes.c_int
         lib.isoProfileEnable.argtypes = [ctypes.c_int]
         lib.isoProfileEnable.restype = ctypes.c_int
         lib.isoProfileCount.argtypes = []
@@ -159,6 +165,28 @@ class DirectRenderer:
     def gate_resident(self, stream, timeout_us=100):
         """Additive: see isoGateResident.  ``stream``: a torch.cuda.Stream."""
         return self.lib.isoGateResident(ctypes.c_void_p(stream.cuda_stream), int(timeout_us))
+
+    # ---- exact AO of a tiled volume (include/gpu_renderer_direct.h: isoSetHitStateBuffer ...) ------------------------------
+    def set_hit_state_buffer(self, tensor):
+        """tensor: [H, W, 6] float64 on the device (the renders export their AO ray set-up into it), or None to switch it off."""
+        if tensor is not None:
+            assert tensor.is_cuda and tensor.is_contiguous() and tensor.dtype.is_floating_point and tensor.element_size() == 8
+        return self.lib.isoSetHitStateBuffer(ctypes.c_ulonglong(tensor.data_ptr() if tensor is not None else 0))
+
+    def ao_distances(self, hit_state, gbuffer, dist, stream=None):
+        """dist [H, W, aosamples] float64 <- distance of every hit pixel's AO rays to their first hit among THIS volume's leaves."""
+        handle = ctypes.c_void_p(stream.cuda_stream) if stream is not None else None
+        rc = self.lib.isoAoDistancesAsync(ctypes.c_ulonglong(hit_state.data_ptr()), ctypes.c_ulonglong(gbuffer.data_ptr()),
+                                          ctypes.c_ulonglong(dist.data_ptr()), handle)
+        if rc != 0:
+            raise RuntimeError("isoAoDistancesAsync failed (aosamples must be > 0, a volume loaded)")
+
+    def ao_finish(self, dist, gbuffer, stream=None):
+        """gbuffer[..., 10] <- the ambient occlusion from the (tile-minimum) distances."""
+        handle = ctypes.c_void_p(stream.cuda_stream) if stream is not None else None
+        rc = self.lib.isoAoFinishAsync(ctypes.c_ulonglong(dist.data_ptr()), ctypes.c_ulonglong(gbuffer.data_ptr()), handle)
+        if rc != 0:
+            raise RuntimeError("isoAoFinishAsync failed")
 
     def set_tile_order_mode(self, mode):
         """Additive: see isoSetTileOrderMode (cost-ordered dispatch of the default kernel from the previous frame's tile costs)."""

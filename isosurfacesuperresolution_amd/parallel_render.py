@@ -118,14 +118,18 @@ def assemble(tiles, shape):
     return vol
 
 
-def composite(gbuffers):
-    """Nearest-hit composite of per-tile G-buffers [T, H, W, 12] -> [H, W, 12] (mask ch 3, depth ch 7)."""
+def composite(gbuffers, extra=None):
+    """Nearest-hit composite of per-tile G-buffers [T, H, W, 12] -> [H, W, 12] (mask ch 3, depth ch 7).  ``extra`` [T, H, W, C]
+    (any dtype, e.g. the tiles' hit-state exports) is composited with the same per-pixel winner: returns (out, extra_out)."""
     mask = gbuffers[..., 3] > 0
     depth = torch.where(mask, gbuffers[..., 7], torch.full_like(gbuffers[..., 7], float("inf")))
     win = depth.argmin(dim=0)                                        # [H, W]
     idx = win.unsqueeze(0).unsqueeze(-1).expand(1, *gbuffers.shape[1:])
     out = torch.gather(gbuffers, 0, idx)[0]
-    return out
+    if extra is None:
+        return out
+    eidx = win.unsqueeze(0).unsqueeze(-1).expand(1, *extra.shape[1:])
+    return out, torch.gather(extra, 0, eidx)[0]
 
 
 class TiledRenderer:
@@ -141,7 +145,11 @@ class TiledRenderer:
         if renderer is not None:
             renderer.load_tile(tile)
 
-    def render(self, width, height, device="cuda"):
+    def render(self, width, height, device="cuda", ao_samples=0):
+        """The composited frame.  ``ao_samples > 0``: channel 10 is the ray-cast ambient occlusion of the WHOLE volume, exactly
+        (``render_with_ao``); 0: AO == 1 as in SR mode."""
+        if ao_samples > 0 and self.renderer is not None:
+            return self.render_with_ao(width, height, ao_samples, device)
         local = torch.empty((height, width, 12), dtype=torch.float32, device=device)
         if self.render_fn is not None:
             self.render_fn(local)
@@ -152,3 +160,35 @@ class TiledRenderer:
         gathered = torch.empty((self.world * height, width, 12), dtype=torch.float32, device=device)
         dist.all_gather_into_tensor(gathered, local, group=self.group)       # concatenated along dim 0
         return composite(gathered.view(self.world, height, width, 12))
+
+    def render_with_ao(self, width, height, ao_samples, device="cuda"):
+        """Ray-cast AO across tiles, bit-identical to the unsplit render.  An AO ray ends at its first hit ANYWHERE in the volume
+        (``render_kernel.cu:109-146``), so no halo makes a tile's own AO right; instead every tile casts every hit pixel's rays
+        against its own leaves and the minimum over the tiles is each ray's true distance (``gpu_renderer_direct.h``,
+        isoSetHitStateBuffer ...).  Per frame: all-gather of the G-buffers and of the hit states (48 B / pixel), one all-reduce
+        (MIN) of width x height x ao_samples doubles."""
+        r = self.renderer
+        local = torch.empty((height, width, 12), dtype=torch.float32, device=device)
+        state = torch.zeros((height, width, 6), dtype=torch.float64, device=device)
+        r.send_command("aosamples", "0")
+        r.set_hit_state_buffer(state)
+        try:
+            r.render_direct(local)
+        finally:
+            r.set_hit_state_buffer(None)
+        if self.world > 1:
+            g = torch.empty((self.world * height, width, 12), dtype=torch.float32, device=device)
+            h = torch.empty((self.world * height, width, 6), dtype=torch.float64, device=device)
+            dist.all_gather_into_tensor(g, local, group=self.group)
+            dist.all_gather_into_tensor(h, state, group=self.group)
+            local, state = composite(g.view(self.world, height, width, 12), h.view(self.world, height, width, 6))
+            local, state = local.contiguous(), state.contiguous()
+        r.send_command("aosamples", "%d" % ao_samples)
+        d = torch.empty((height, width, ao_samples), dtype=torch.float64, device=device)
+        r.ao_distances(state, local, d)
+        if self.world > 1:
+            torch.cuda.synchronize()
+            dist.all_reduce(d, op=dist.ReduceOp.MIN, group=self.group)
+        r.ao_finish(d, local)
+        torch.cuda.synchronize()
+        return local
