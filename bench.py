@@ -215,6 +215,10 @@ def run_infer(args, job):
     sync()
     elapsed = time.perf_counter() - t0
     records = ops.profile_records()
+    switches = ops.debug_switches()
+    # an ablation (MFMAs skipped, stores skipped, stamp buffers) must never be behind a reported number; a forced kernel form
+    # (ISR_SPLIT_ALGO, an experiment switch) is allowed and shows up in the line
+    assert not (switches & ~2), "diagnostic switches of libisr_sr.so are set (mask %#x): not a measurement" % switches
     rm_ms = renderer.profile_times_ms()
     ops.profile_enable(False)
     renderer.profile_enable(False)
@@ -283,6 +287,7 @@ def run_infer(args, job):
                             "split-operand: 3 x v_mfma_f32_32x32x16_f16 per product, fp32 accumulation (bench.py --exact = fp32 MFMA kernels); "
                             "1080p tail fused (postblock.6 + postblock.8 + finish), packed-split hand-over postblock.4 -> tail and inside the blocks"},
         **rank_keys,
+        "debug_switches": switches,
         "roofline": {"kernel": dom_name, "bound": "mfma", "achieved": achieved, "peak": peak,
                      "unit": "TFLOP/s", "frac": achieved / peak, "traffic": traffic,
                      "peak_source": ("dense fp16 MFMA %.0f TFLOP/s / 3 matrix products per algorithmic multiply-accumulate" % MFMA_F16_PEAK_TFLOPS)

@@ -304,6 +304,7 @@ static unsigned long long* g_block_stamps = nullptr;
 static int g_block_dbg = 0;
 void isrDebugSetBlockStampBuffer(unsigned long long* buf) { g_block_stamps = buf; }   // not part of the public header
 void isrDebugSetBlockAblation(int bits) { g_block_dbg = bits; }
+int isrDebugBlockState(void) { return (g_block_stamps ? 1 : 0) | (g_block_dbg ? 2 : 0); }
 
 static int block_slots()
 {

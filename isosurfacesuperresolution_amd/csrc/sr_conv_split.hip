@@ -1110,6 +1110,13 @@ static int g_split_algo = 1;      // plain layers: 1 persistent streaming kernel
 extern "C" {
 
 void isrSetRangeFlag(unsigned* flag) { g_range_flag = flag; }
+// bit mask of the process-global diagnostic switches of this translation unit that are NOT in their default position
+// (bench.py refuses to report a number measured with any of them set): 1 ablation, 2 kernel form, 4 grid cap, 8 small-image
+// form off, 16 stamp buffer
+int isrDebugSplitState(void)
+{
+    return (g_split_dbg ? 1 : 0) | (g_split_algo != 1 ? 2 : 0) | (g_split_slots ? 4 : 0) | (g_split_small != 1 ? 8 : 0) | (g_split_stamps ? 16 : 0);
+}
 void isrDebugSetSplitStampBuffer(unsigned long long* buf) { g_split_stamps = buf; }   // not part of the public header
 void isrDebugSetSplitAblation(int bits) { g_split_dbg = bits; }
 void isrDebugSetSplitAlgo(int a) { g_split_algo = a; }

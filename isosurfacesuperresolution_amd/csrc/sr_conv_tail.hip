@@ -450,6 +450,7 @@ long long isrConvTailWeightBytes(void) { return 16 + (long long)TZ_UNITS * 16; }
 static int g_tail_fused = 0;
 __device__ u32x4 g_tail_zero_unit[4];       // zero initialised: the source of out-of-image units of the LDS-DMA staging
 void isrDebugSetTailFused(int on) { g_tail_fused = on; }      // not part of the public header
+int isrDebugTailState(void) { return g_tail_fused ? 1 : 0; }
 
 static long long tail_row_floats(int H, int W) { return 2LL * ((H + ST_H - 1) / ST_H) * W * TZ_ROWS; }
 static long long tail_col_floats(int H, int W) { return (long long)H * 2 * ((W + ST_W - 1) / ST_W) * TZ_ROWS; }

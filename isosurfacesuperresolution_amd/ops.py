@@ -179,6 +179,14 @@ VARIANT_NAMES = {6: "conv3x3_small_cout_kernel", 2: "conv3x3_fwd_kernel<1,false>
                  18: "conv3x3_split_tail_kernel", 19: "resblock_split_kernel"}
 
 
+def debug_switches():
+    """Bit mask of the libraries' process-global diagnostic switches (``isrDebugSet*``: ablations that skip MFMAs, forced kernel
+    forms, grid caps, stamp buffers) that are not in their default position; 0 on a clean process.  bench.py reports it and
+    refuses to print a headline measured with an ablation active."""
+    lib = _sr()
+    return int(lib.isrDebugSplitState()) | (int(lib.isrDebugTailState()) << 8) | (int(lib.isrDebugBlockState()) << 12)
+
+
 def profile_enable(on):
     _sr().isrProfileEnable(1 if on else 0)
 
