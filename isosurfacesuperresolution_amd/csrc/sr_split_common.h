@@ -152,7 +152,9 @@ __device__ __forceinline__ void split_epilogue_ps(const SplitConvParams& p, f32x
 }
 
 // WIDE_ONLY: the caller guarantees W and both plane strides are multiples of 4 (the per-element path is not compiled in).
-template <bool WIDE_ONLY = false>
+// AUX: cache policy of the output stores (0 plain; 16 = sc1, write-through to memory: the dataflow kernels' hand-off, see
+// sr_conv_chain.hip).
+template <bool WIDE_ONLY = false, int AUX = 0>
 __device__ __forceinline__ void split_epilogue(const SplitConvParams& p, f32x16 (&acc)[2][2], u32x4* patch, int n, int oy0, int ox0, int co0,
                                                bool second, int lane, int wave, int j, int h)
 {
@@ -205,7 +207,7 @@ __device__ __forceinline__ void split_epilogue(const SplitConvParams& p, f32x16 
                 }
                 if (ok) mag = isr_umax(isr_umax(mag, isr_umax(isr_mag(v.x), isr_mag(v.y))), isr_umax(isr_mag(v.z), isr_mag(v.w)));
                 __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), yrs,
-                                                       (int)(ok ? pixoff + (unsigned)co * (unsigned)p.yPlane * 4u : BAD_OFFSET), 0, 0);
+                                                       (int)(ok ? pixoff + (unsigned)co * (unsigned)p.yPlane * 4u : BAD_OFFSET), 0, AUX);
             }
             __builtin_amdgcn_s_waitcnt(0xC07F);                              // reads done before the next row overwrites the slab
         }

@@ -160,6 +160,11 @@ class LoadedModel:
             prediction, _ = self.model(net_in)
             if net_in.is_cuda:
                 from .. import ops
-                if ops.range_check_due(net_in.device) and ops.refresh_range_flags(net_in.device):
-                    prediction, _ = self.model(net_in)      # a layer came close to the split operands' fp16 range: exact routing from now on
+                if ops.range_check_due(net_in.device):
+                    # a layer came close to the split operands' fp16 range: exact routing from now on, this frame again (repeated:
+                    # a fused launch only says THAT something inside it was hot, the per-layer pass that replaces it says where)
+                    for _ in range(4):
+                        if not ops.refresh_range_flags(net_in.device):
+                            break
+                        prediction, _ = self.model(net_in)
         return prediction

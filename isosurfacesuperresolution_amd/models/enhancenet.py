@@ -84,18 +84,26 @@ class EnhanceNet(nn.Module):
     def _fused_ok(self):
         return (not self.use_bn) and self.upsample == 'bilinear'
 
-    def forward_features(self, inputs, last_layer=True, last_two=True, last_three=True):
+    def forward_features(self, inputs, last_layer=True, last_two=True, last_three=True, after_trunk=None):
         """The convolutional trunk only: the tensor ``_recon_image`` receives (used by the fused
         frame pipeline, which folds the reconstruction into its finishing kernel).  ``last_layer=False`` stops
         before the final 64 -> 6 convolution (``self.postblock[8]``), which the pipeline fuses with the finishing;
         ``last_two=False`` stops before ``self.postblock[6]`` as well (the fused 1080p tail, ``ops.tail_conv_finish``),
-        ``last_three=False`` before ``self.postblock[4]`` (whose output the pipeline hands to the tail packed-split)."""
+        ``last_three=False`` before ``self.postblock[4]`` (whose output the pipeline hands to the tail packed-split).
+        ``after_trunk``: called once the low-resolution trunk has been enqueued (the frame pipeline starts the next frame's
+        ray-march there: beside the multi-round 1080p kernels instead of beside the one-round dataflow trunk)."""
         assert self._fused_ok()
         c = ops.conv3x3
         pre = self.preblock[0]
-        f = c(inputs, pre.weight, pre.bias, act='relu')
-        for block in self.blocks:
-            f = ops.residual_block(f, block[0].weight, block[0].bias, block[2].weight, block[2].bias)
+        convs = [(pre.weight, pre.bias)] + [(m.weight, m.bias) for block in self.blocks for m in (block[0], block[2])]
+        if ops.trunk_supported(inputs, convs):
+            f = ops.trunk_dataflow(inputs, convs)       # preblock + all blocks in ONE dataflow launch (csrc/sr_conv_trunk.hip)
+        else:
+            f = c(inputs, pre.weight, pre.bias, act='relu')
+            for block in self.blocks:
+                f = ops.residual_block(f, block[0].weight, block[0].bias, block[2].weight, block[2].bias)
+        if after_trunk is not None:
+            after_trunk()
         p = self.postblock
         f = c(f, p[1].weight, p[1].bias, act='relu', upsample2x=True)
         if not last_three:

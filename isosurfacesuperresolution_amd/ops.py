@@ -103,6 +103,10 @@ def _sr():
         lib.isrConv3x3ForwardSplitFromPacked.restype = ci
         lib.isrConvTailFinishFramePacked.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, vp, ci, ci, ll, vp, ci, cf, ci, ci, vp]
         lib.isrConvTailFinishFramePacked.restype = ci
+        lib.isrTrunkDataflowMaxTiles.argtypes = []; lib.isrTrunkDataflowMaxTiles.restype = ci
+        lib.isrTrunkDataflowWorkspaceBytes.argtypes = [ci, ci]; lib.isrTrunkDataflowWorkspaceBytes.restype = ll
+        lib.isrTrunkDataflowSupported.argtypes = [vp, ci, ci, ll, ll]; lib.isrTrunkDataflowSupported.restype = ci
+        lib.isrTrunkDataflow.argtypes = [vp, ci, ll, vp, vp, ll, vp, vp, ci, ci, ci, vp, vp]; lib.isrTrunkDataflow.restype = ci
         lib.isrResBlockSplitWorkspaceBytes.argtypes = []; lib.isrResBlockSplitWorkspaceBytes.restype = ll
         lib.isrResBlockSplitSupported.argtypes = [vp, ci, ci, ll, ll]; lib.isrResBlockSplitSupported.restype = ci
         lib.isrResBlockSplit.argtypes = [vp, vp, vp, vp, vp, vp, vp, ci, ci, ll, ll, vp]; lib.isrResBlockSplit.restype = ci
@@ -176,7 +180,7 @@ VARIANT_NAMES = {6: "conv3x3_small_cout_kernel", 2: "conv3x3_fwd_kernel<1,false>
                  10: "conv3x3_fwd2_kernel<false,1>", 11: "conv3x3_fwd2_kernel<true,1>", 12: "conv3x3_rowsplit_kernel",
                  13: "conv3x3_split_kernel<false>", 14: "conv3x3_split_kernel<true>",
                  15: "conv3x3_split_stream_kernel", 16: "conv3x3_split_wide_kernel", 17: "conv3x3_split_rows2_kernel",
-                 18: "conv3x3_split_tail_kernel", 19: "resblock_split_kernel"}
+                 18: "conv3x3_split_tail_kernel", 19: "resblock_split_kernel", 20: "trunk_dataflow_kernel"}
 
 
 def debug_switches():
@@ -418,7 +422,9 @@ def any_hot(device):
 
 def refresh_range_flags(device=None):
     """Read the producers' maxima (ONE host synchronisation), mark producers at or above RANGE_LIMIT (or non-finite) hot,
-    reset the words.  Returns the set of producers that became hot in this call."""
+    reset the words.  Returns the set of producers that became hot in this call.  (Also the moment the dataflow trunk's error
+    words are looked at, ``trunk_check``.)"""
+    trunk_check()
     new = set()
     for dev, st in list(_range.items()):
         if device is not None and torch.device(dev) != torch.device(device):
@@ -745,6 +751,66 @@ class _ResidualBlockFunction(torch.autograd.Function):
         if ctx.needs_input_grad[1] or (b1 is not None and ctx.needs_input_grad[2]):
             gw1, gb1 = _weight_grad_or_defer(w1, b1 if (b1 is not None and b1.requires_grad) else None, b1 is not None, x, gz1)
         return gx, gw1, gb1, gw2, gb2
+
+
+# ---- the whole low-resolution trunk as ONE dataflow launch (csrc/sr_conv_trunk.hip) -----------------------------------------
+# preblock + the residual blocks of a single image whose tiles all fit on the GPU at once (<= 2 x #CUs tiles of 8 x 32 pixels: the
+# 480 x 270 frame has 510): workgroup w owns tile w through every layer and waits only for its 3 x 3 neighbourhood's progress.
+# Bit-identical to the per-layer launches.  A wait that never completes ends the launch and sets an error word, which
+# ``trunk_check()`` (called where the range guard is refreshed: after a model's first frame, then every RANGE_CHECK_EVERY frames)
+# turns into an exception.
+TRUNK_DATAFLOW = os.environ.get("ISR_TRUNK_DATAFLOW", "1") != "0"
+_trunk_ws = {}
+
+
+def trunk_supported(x, convs):
+    """x [1, Cin, h, w]; convs: [(weight, bias)] = preblock, then conv1 / conv2 of every block."""
+    if not (TRUNK_DATAFLOW and SPLIT_F16 and not FAST_F16 and x.is_cuda and x.dtype == torch.float32 and x.dim() == 4 and x.shape[0] == 1):
+        return False
+    if torch.is_grad_enabled() and (x.requires_grad or any(w.requires_grad for w, _ in convs)):
+        return False
+    if len(convs) < 1 or len(convs) % 2 != 1 or len(convs) > 24 or tuple(convs[0][0].shape[2:]) != (3, 3) or convs[0][0].shape[0] != 64:
+        return False
+    if any(tuple(w.shape) != (64, 64, 3, 3) for w, _ in convs[1:]) or convs[0][0].shape[1] != x.shape[1]:
+        return False
+    if any_hot(x.device) or range_is_hot(getattr(x, '_isr_range_key', None), x.device):
+        return False
+    xs, xp, _ = _plane_strides(x)
+    return xs is x and bool(_sr().isrTrunkDataflowSupported(_ptr(x), x.shape[2], x.shape[3], xp, x.shape[2] * x.shape[3] + plane_pad(x.shape[2], x.shape[3])))
+
+
+def trunk_dataflow(x, convs):
+    """f = relu(conv(x, w0) + b0); f = f + conv(relu(conv(f, w1) + b1), w2) + b2; ...  in ONE launch (``isrTrunkDataflow``)."""
+    lib = _sr()
+    x, xp, _ = _plane_strides(x)
+    _, cin, h, w = x.shape
+    key = (x.device, h, w, torch.cuda.current_stream().cuda_stream)
+    ws = _trunk_ws.get(key)
+    if ws is None:
+        ws = torch.zeros(lib.isrTrunkDataflowWorkspaceBytes(h, w) // 4, dtype=torch.int32, device=x.device)
+        _trunk_ws[key] = ws
+    f = empty_planes(1, 64, h, w, x.device)
+    t = empty_planes(1, 64, h, w, x.device)
+    wq = [_prepare_split(wt) for wt, _ in convs]
+    bs = [b.detach().contiguous() if b is not None else None for _, b in convs]
+    n = len(convs)
+    pw = (ctypes.c_void_p * n)(*[q.data_ptr() for q in wq])
+    pb = (ctypes.c_void_p * n)(*[(b.data_ptr() if b is not None else None) for b in bs])
+    f._isr_range_key = _arm_range(("trunk", id(convs[0][0])), x.device)
+    rc = lib.isrTrunkDataflow(_ptr(x), cin, xp, _ptr(f), _ptr(t), f.stride(1), pw, pb, (n - 1) // 2, h, w, _ptr(ws), _stream())
+    if rc != 0:
+        raise RuntimeError("isrTrunkDataflow failed (%d)" % rc)
+    return f
+
+
+def trunk_check():
+    """Host read of the dataflow launches' error words (ONE synchronisation): raises if a tile ever gave up waiting for a
+    neighbour -- which would mean a workgroup was not resident (more tiles than the GPU holds) or the launch was disturbed."""
+    for key, ws in list(_trunk_ws.items()):
+        tiles = ws.numel() - 2
+        err = int(ws[tiles].item())
+        if err:
+            raise RuntimeError("trunk_dataflow_kernel: a tile timed out waiting for its neighbours at layer %d" % (err - 1))
 
 
 # Inference: the whole block in ONE launch (csrc/sr_conv_block.hip) -- bit-identical to the two split-operand launches

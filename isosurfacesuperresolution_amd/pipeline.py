@@ -7,6 +7,8 @@ This is the call sequence of the reference's scripted 1080p video
 ``ScreenSpaceShading``) and of the interactive viewer (``mainGUI.py:642-720,573-603``), with all
 stages enqueued on one HIP stream and no host synchronisation inside the frame.
 """
+import os
+
 import numpy as np
 import torch
 
@@ -62,6 +64,7 @@ class SuperResolutionPipeline:
         # (0.21 ms alone) the plain kernel beside the network gives 400 frames/s; the capped 128-register kernel (2), which
         # round 1's 0.45 ms nested-loop kernel needed, gives 384 (tools/side_sweep.sh)
         self.side_variant = None
+        self.prefetch_after_trunk = os.environ.get("ISR_PREFETCH_AFTER_TRUNK", "0") == "1"     # measured: no gain (414-418 vs 420 frames/s)
         self.previous = None
         self.foreground_variant = 0       # kernel variant of frames rendered on the main stream
         # fused=True: input assembly and frame finishing run as two HIP kernels (ops.assemble_input /
@@ -148,7 +151,7 @@ class SuperResolutionPipeline:
         self.previous = raw
         return raw
 
-    def _network(self, x):
+    def _network(self, x, after_trunk=None):
         """Network input [1,101,h,w] -> (raw [1,6,4h,4w] clamped / normalised, rgb [1,3,4h,4w])."""
         net = self.model.model
         self.shading.inverse_ao = self.model.inverse_ao
@@ -158,7 +161,8 @@ class SuperResolutionPipeline:
         tail = last.weight.shape[0] == 6 and ops.TAIL_FUSION and ops.SPLIT_F16 and not ops.FAST_F16 and not ops.any_hot(x.device)
         four = net.postblock[4]
         if tail and ops.TAIL_PACKED and tuple(six.weight.shape) == (64, 64, 3, 3) and tuple(last.weight.shape) == (6, 64, 3, 3):
-            f2 = net.forward_features(x, last_three=False)
+            f2 = net.forward_features(x, last_three=False, after_trunk=after_trunk)
+            after_trunk = None
             if ops.packed_supported(f2, four.weight, True):
                 # postblock.4 writes its output packed-split (already the (hi, lo') units postblock.6 multiplies), the tail
                 # stages them by LDS-DMA: no conversion on the way in, no LDS transposition on the way out
@@ -166,7 +170,8 @@ class SuperResolutionPipeline:
             else:
                 f4 = ops.conv3x3(f2, four.weight, four.bias, act='relu', upsample2x=True)
         elif tail:
-            f4 = net.forward_features(x, last_two=False)
+            f4 = net.forward_features(x, last_two=False, after_trunk=after_trunk)
+            after_trunk = None
         if isinstance(f4, ops.PackedSplit) or (f4 is not None and ops.tail_supported(f4, six.weight, last.weight)):
             # postblock.6, postblock.8 and the frame's finishing in two launches; the 64-channel 1080p tensor between the
             # two convolutions never goes to memory (csrc/sr_conv_tail.hip)
@@ -176,9 +181,13 @@ class SuperResolutionPipeline:
             raw, rgb = ops.final_conv_finish(f6, last.weight, last.bias, x, self.shading)
         elif last.weight.shape[0] == 6:
             # the last layer's epilogue finishes the frame (one launch, no [6,4h,4w] round trip)
-            raw, rgb = ops.final_conv_finish(net.forward_features(x, last_layer=False), last.weight, last.bias, x, self.shading)
+            raw, rgb = ops.final_conv_finish(net.forward_features(x, last_layer=False, after_trunk=after_trunk), last.weight, last.bias, x, self.shading)
+            after_trunk = None
         else:
-            raw, rgb = ops.finish_frame(net.forward_features(x), x, self.shading)
+            raw, rgb = ops.finish_frame(net.forward_features(x, after_trunk=after_trunk), x, self.shading)
+            after_trunk = None
+        if after_trunk is not None:
+            after_trunk()
         return raw, rgb
 
     def frame_fused(self, origin, next_origin=None):
@@ -186,10 +195,15 @@ class SuperResolutionPipeline:
             if next_origin is not None:
                 self._frame_start.record(torch.cuda.current_stream())
             g = self._acquire_gbuffer(origin)
-            if next_origin is not None:
-                # the next frame's render goes first (enqueued after the trunk or the upsampling layers instead, the frame
-                # takes the same 2.50 ms).  With the capped 128-register kernel (side_variant = 2) this stream then waits
-                # until its waves sit one per SIMD on the momentarily idle GPU (a no-op for the other variants).
+            start_next = None
+            if next_origin is not None and self.prefetch_after_trunk:
+                # the next frame's render is enqueued once the trunk has been: the dataflow trunk is ONE round of workgroups that
+                # must all be resident (a ray-march wave on a SIMD keeps the CU's second conv workgroup out until it ends, and that
+                # tile's neighbours wait for it), while the 1080p kernels behind it run many rounds and absorb a guest
+                start_next = lambda: self.prefetch(next_origin)
+            elif next_origin is not None:
+                # the next frame's render goes first.  With the capped 128-register kernel (side_variant = 2) this stream then
+                # waits until its waves sit one per SIMD on the momentarily idle GPU (a no-op for the other variants).
                 self.prefetch(next_origin)
                 self.renderer.gate_resident(torch.cuda.current_stream())
             prev = self.previous if self.temporal else None
@@ -198,11 +212,15 @@ class SuperResolutionPipeline:
                 flow = self._flows[self._slot] if self._flow_ready[self._slot] else ops.fill_flow_gbuffer(g)
             x = ops.assemble_input(g, flow, prev, self.model.initial_image_mode, self.model.inverse_ao)
             self._consumed[self._slot].record(torch.cuda.current_stream())   # G-buffer no longer needed
-            raw, rgb = self._network(x)
-            if ops.range_check_due(x.device) and ops.refresh_range_flags(x.device):
+            raw, rgb = self._network(x, after_trunk=start_next)
+            if ops.range_check_due(x.device):
                 # range guard (ops.RANGE_GUARD): a layer's output came close to the fp16 range of the split operands -- from now on
-                # its consumers run on the exact fp32 kernels; this frame is computed again with that routing
-                raw, rgb = self._network(x)
+                # its consumers run on the exact fp32 kernels; this frame is computed again with that routing.  (Again, because the
+                # fused launches only say THAT something inside them was hot: the per-layer pass that replaces them says where.)
+                for _ in range(4):
+                    if not ops.refresh_range_flags(x.device):
+                        break
+                    raw, rgb = self._network(x)
             self.previous = raw
         return rgb, raw
 

@@ -73,9 +73,10 @@ def test_trunk_runs_on_the_fused_block_and_matches():
     net = models.createNetwork('EnhanceNet', 4, 101, [0, 1, 2, 3, 4], 6, opt).cuda().eval()
     x = torch.rand(1, 101, 270, 480, device="cuda")
     outs = {}
-    for fused in (True, False, "plain"):
+    for fused in (True, False, "plain", "dataflow"):
         ops.BLOCK_FUSION = fused is True
-        ops.BLOCK_PACKED = fused is not "plain"
+        ops.BLOCK_PACKED = fused != "plain"
+        ops.TRUNK_DATAFLOW = fused == "dataflow"      # (the default: the whole trunk in one launch, tests/test_trunk_gpu.py)
         try:
             ops.profile_enable(True)
             with torch.no_grad():
@@ -86,5 +87,7 @@ def test_trunk_runs_on_the_fused_block_and_matches():
         finally:
             ops.BLOCK_FUSION = False
             ops.BLOCK_PACKED = True
+            ops.TRUNK_DATAFLOW = True
         assert (names.count("resblock_split_kernel") == 10) == (fused is True)
-    assert torch.equal(outs[True], outs[False]) and torch.equal(outs[False], outs["plain"])
+        assert (names.count("trunk_dataflow_kernel") == 1) == (fused == "dataflow")
+    assert torch.equal(outs[True], outs[False]) and torch.equal(outs[False], outs["plain"]) and torch.equal(outs["plain"], outs["dataflow"])

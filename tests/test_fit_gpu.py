@@ -174,7 +174,7 @@ def test_flat_adam_matches_torch_adam_on_the_network():
         # backward adds with float atomics) move by up to lr per step in either run: the parameters agree to a fraction of the
         # three steps' movement, the exact comparison is the synthetic one below
         for p, q in zip(nets[0].parameters(), nets[other].parameters()):
-            assert (p - q).abs().max().item() <= 1.5e-3, name
+            assert (p - q).abs().max().item() <= 6.1e-3, name      # at most lr per step in opposite directions
             assert (p - q).abs().mean().item() <= 5e-5, name
     # the update itself, on identical gradients: FlatAdam's kernel against torch.optim.Adam, five steps with a changing lr
     torch.manual_seed(3)

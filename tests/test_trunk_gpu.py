@@ -1,0 +1,97 @@
+"""The dataflow trunk (csrc/sr_conv_trunk.hip): preblock + ten residual blocks of one image in ONE persistent launch with
+per-tile progress counters, against the per-layer launches -- same products in the same order: EQUAL bit for bit
+(SuperresolutionNetwork/models/enhancenet.py:92-112,136-141)."""
+import argparse
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+OPT = argparse.Namespace(upsample='bilinear', reconType='residual', useBN=False, numResidualLayers=10)
+
+
+def _net(seed):
+    from isosurfacesuperresolution_amd import models
+    torch.manual_seed(seed)
+    return models.createNetwork('EnhanceNet', 4, 101, [0, 1, 2, 3, 4], 6, OPT).cuda().eval()
+
+
+def _per_layer(net, x):
+    from isosurfacesuperresolution_amd import ops
+    ops.TRUNK_DATAFLOW = False
+    try:
+        with torch.no_grad():
+            return net.forward_features(x, last_three=False)
+    finally:
+        ops.TRUNK_DATAFLOW = True
+
+
+@pytest.mark.parametrize("h,w", [(8, 32), (9, 36), (41, 100), (270, 480), (128, 512)])
+def test_dataflow_trunk_is_bit_identical_to_the_per_layer_launches(h, w):
+    from isosurfacesuperresolution_amd import ops
+    net = _net(h + w)
+    x = torch.rand(1, 101, h, w, device="cuda") * 2 - 0.5
+    pre = net.preblock[0]
+    convs = [(pre.weight, pre.bias)] + [(m.weight, m.bias) for b in net.blocks for m in (b[0], b[2])]
+    with torch.no_grad():
+        assert ops.trunk_supported(x, convs)
+        f = ops.trunk_dataflow(x, convs)
+        f2 = ops.trunk_dataflow(x, convs)
+        ref = x
+        ref = ops.conv3x3_split(x, pre.weight, pre.bias, act='relu')
+        for b in net.blocks:
+            ref = ops.conv3x3_split(ops.conv3x3_split(ref, b[0].weight, b[0].bias, act='relu'), b[2].weight, b[2].bias, residual=ref)
+    torch.cuda.synchronize()
+    ops.trunk_check()
+    assert torch.equal(f, ref), (f - ref).abs().max().item()
+    assert torch.equal(f, f2)
+
+
+def test_network_uses_the_dataflow_trunk_and_is_unchanged():
+    from isosurfacesuperresolution_amd import ops
+    net = _net(3)
+    x = torch.rand(1, 101, 270, 480, device="cuda")
+    ops.profile_enable(True)
+    with torch.no_grad():
+        f = net.forward_features(x, last_three=False)
+    torch.cuda.synchronize()
+    names = [n for n, _, _ in ops.profile_records()]
+    ops.profile_enable(False)
+    assert names.count("trunk_dataflow_kernel") == 1 and not any(n.startswith("conv3x3_split_kernel<false>") for n in names)
+    assert torch.equal(f, _per_layer(net, x))
+    ops.trunk_check()
+    # too many tiles for one round (960 x 540 has 2040): the per-layer kernels take over
+    big = torch.rand(1, 101, 540, 960, device="cuda")
+    pre = net.preblock[0]
+    convs = [(pre.weight, pre.bias)] + [(m.weight, m.bias) for b in net.blocks for m in (b[0], b[2])]
+    with torch.no_grad():
+        assert not ops.trunk_supported(big, convs)
+
+
+def test_dataflow_trunk_under_uneven_load_and_repeated_launches():
+    """The hand-off between workgroups must hold when the chip is busy with something else and the consumers' caches are warm:
+    the trunk runs forty times back to back while another stream keeps the GPU loaded with bandwidth-heavy work; every result
+    is compared word for word."""
+    from isosurfacesuperresolution_amd import ops
+    net = _net(5)
+    x = torch.rand(1, 101, 270, 480, device="cuda")
+    pre = net.preblock[0]
+    convs = [(pre.weight, pre.bias)] + [(m.weight, m.bias) for b in net.blocks for m in (b[0], b[2])]
+    with torch.no_grad():
+        ref = ops.conv3x3_split(x, pre.weight, pre.bias, act='relu')
+        for b in net.blocks:
+            ref = ops.conv3x3_split(ops.conv3x3_split(ref, b[0].weight, b[0].bias, act='relu'), b[2].weight, b[2].bias, residual=ref)
+    side = torch.cuda.Stream()
+    junk = torch.rand(64 * 1024 * 1024, device="cuda")
+    outs = []
+    with torch.no_grad():
+        for k in range(40):
+            if k % 2 == 0:
+                with torch.cuda.stream(side):
+                    for _ in range(3):
+                        junk.mul_(1.0001).add_(0.5)
+            outs.append(ops.trunk_dataflow(x, convs))
+    torch.cuda.synchronize()
+    ops.trunk_check()
+    bad = [k for k, o in enumerate(outs) if not torch.equal(o, ref)]
+    assert not bad, "launches %s differ (max |diff| %.3g)" % (bad, max((outs[k] - ref).abs().max().item() for k in bad))
