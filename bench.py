@@ -30,6 +30,15 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
+SPLIT_KERNEL_PREFIXES = ("conv3x3_split", "resblock_split", "trunk_dataflow")      # three fp16 MFMAs per product
+
+
+def is_split_kernel(name):
+    """Kernel families of libisr_sr.so that compute each fp32 product as three fp16 MFMAs on split operands: their MFMA
+    ceiling is a third of the dense fp16 peak; every other profiled convolution runs on fp32 MFMA."""
+    return name.startswith(SPLIT_KERNEL_PREFIXES)
+
+
 MFMA_F32_PEAK_TFLOPS = 157.3      # /opt/skills/guides/MI355X_MICROARCH.md, chip-level parameters
 MFMA_F16_PEAK_TFLOPS = 2500.0     # dense fp16/bf16 MFMA (same table)
 HBM_PEAK_GBS = 8000.0
@@ -264,7 +273,7 @@ def run_infer(args, job):
     # Roofline of the dominant kernel.  `achieved` is always ALGORITHMIC: 2*9*Cin*Cout flops per output pixel.  The exact
     # kernels spend one fp32 MFMA multiply-accumulate per algorithmic one (peak 157.3); the split-operand kernels spend
     # three fp16 ones (x_hi*w_hi + x_hi*w_lo + x_lo*w_hi), so their ceiling is a third of the dense fp16 MFMA peak.
-    split = dom_name.startswith("conv3x3_split") or dom_name.startswith("resblock_split")
+    split = is_split_kernel(dom_name)
     peak = MFMA_F16_PEAK_TFLOPS / 3.0 if split else MFMA_F32_PEAK_TFLOPS
 
     result = {
@@ -298,7 +307,7 @@ def run_infer(args, job):
                      "flops_per_launch": dom_flops / dom_launches},
         # every profiled kernel with ITS OWN roofline fraction (the 1080p kernels and the 480 x 270 trunk are bound differently)
         "kernels": {n: {"tflops": v[0] / v[1] / 1e12, "ms_per_frame": v[1] / K * 1e3, "launches_per_frame": v[2] / K,
-                        "frac": v[0] / v[1] / 1e12 / ((MFMA_F16_PEAK_TFLOPS / 3.0) if (n.startswith("conv3x3_split") or n.startswith("resblock_split"))
+                        "frac": v[0] / v[1] / 1e12 / ((MFMA_F16_PEAK_TFLOPS / 3.0) if is_split_kernel(n)
                                                       else MFMA_F32_PEAK_TFLOPS)}
                     for n, v in per.items()},
         "raymarch": {"kernel": "iso_render_gather (on a side stream under the network)" if overlap else "iso_render_gather",
@@ -573,7 +582,7 @@ def run_tiled(args, job, make_local_renderer=None):
             d[0] += flops; d[1] += kms * 1e-3; d[2] += 1
         ops.profile_enable(False)
         dom_name, (dom_flops, dom_time, dom_launches) = max(per.items(), key=lambda kv: kv[1][1])
-        split = dom_name.startswith("conv3x3_split")
+        split = is_split_kernel(dom_name)
         peak = MFMA_F16_PEAK_TFLOPS / 3.0 if split else MFMA_F32_PEAK_TFLOPS
         achieved = dom_flops / dom_time / 1e12
         roofline = {"kernel": dom_name, "bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak,

@@ -247,17 +247,19 @@ int isrConv3x3ForwardSplitFromPacked(const void* xps, const void* wq, const floa
 /* The whole low-resolution trunk of one image as ONE persistent dataflow launch (csrc/sr_conv_trunk.hip):
  *   F = relu(conv3x3(x [cin0][H][W], w[0]) + b[0]);  nblocks times  F += conv3x3(relu(conv3x3(F, w[2k+1]) + b[2k+1]), w[2k+2]) + b[2k+2]
  * (models/enhancenet.py:92-112,136-141), split-operand arithmetic, bit-identical to the per-layer launches of
- * isrConv3x3ForwardSplit.  Workgroup w owns tile w of 8 x 32 pixels through all layers and starts a layer when its 3 x 3
- * neighbourhood has finished the previous one; every tile must be resident at once: at most isrTrunkDataflowMaxTiles() tiles
- * (isrTrunkDataflowSupported says whether these tensors qualify; larger images use the per-layer kernels).
- *   x: planes xPlane floats apart; F (result), T (scratch): [64][H][W], planes `plane` floats apart, 16-byte aligned;
- *   wq[l]: isrConvSplitPrepare images, bias[l]: [64] device or NULL, l = 0 .. 2 nblocks; workspace: isrTrunkDataflowWorkspaceBytes
- *   bytes of device memory (progress counters; word [tiles] is an error word: 1 + layer if a tile's wait timed out after 50 ms).
+ * isrConv3x3ForwardSplit.  Workgroup w owns tile w of 16 x 32 pixels through all layers and starts a layer when its 3 x 3
+ * neighbourhood has finished the previous one; every tile must be resident at once, one workgroup per CU: at most
+ * isrTrunkDataflowMaxTiles() tiles (isrTrunkDataflowSupported says whether these tensors qualify; larger images use the per-layer
+ * kernels).  Between the layers the activations live in the workspace in the packed-split format, the residual stream in registers.
+ *   x: planes xPlane floats apart (rows contiguous); y (the result F): [64][H][W], planes `plane` floats apart;
+ *   wq[l]: isrConvSplitPrepare images, bias[l]: [64] device or NULL, l = 0 .. 2 nblocks;
+ *   workspace: isrTrunkDataflowWorkspaceBytes(cin0, H, W) bytes of device memory, 256-byte aligned.  Bytes 16 .. hold the tiles'
+ *   progress counters and then an error word: 1 + layer if a tile's wait timed out after 50 ms (0 after a good launch).
  * 0 ok, -1 bad arguments, -2 launch failure, -3 unsupported shape / alignment / too many tiles. */
 int isrTrunkDataflowMaxTiles(void);
-long long isrTrunkDataflowWorkspaceBytes(int H, int W);
-int isrTrunkDataflowSupported(const float* x, int H, int W, long long xPlane, long long plane);
-int isrTrunkDataflow(const float* x, int cin0, long long xPlane, float* F, float* T, long long plane, const void* const* wq,
+long long isrTrunkDataflowWorkspaceBytes(int cin0, int H, int W);
+int isrTrunkDataflowSupported(const float* x, int cin0, int H, int W, long long xPlane, long long plane);
+int isrTrunkDataflow(const float* x, int cin0, long long xPlane, float* y, long long plane, const void* const* wq,
                      const float* const* bias, int nblocks, int H, int W, void* workspace, void* stream);
 
 /* One residual block of the trunk, y = x + conv2(relu(conv1(x) + bias1)) + bias2 (64 -> 64 -> 64 channels, one image;

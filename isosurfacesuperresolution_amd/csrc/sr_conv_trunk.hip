@@ -1,62 +1,173 @@
 // The low-resolution TRUNK of EnhanceNet -- preblock (conv3x3 101 -> 64 + ReLU) and the ten residual blocks
 // (SuperresolutionNetwork/models/enhancenet.py:92-112,136-141: f = relu(pre(x)); f = f + conv2(relu(conv1(f))) x 10) -- as ONE persistent
-// launch with tile-level DATAFLOW instead of 21 dependent launches.  Same split-operand products in the same order as the
-// per-layer kernels of sr_conv_split.hip: the output is bit-identical to them.
+// launch with tile-level DATAFLOW: workgroup w owns tile w through all 21 layers, and layer l of a tile starts as soon as its
+// 3 x 3 neighbourhood has finished layer l - 1 (one progress counter per tile, no grid barrier).  Same split-operand products in
+// the same order as the per-layer kernels of sr_conv_split.hip: the output is bit-identical to them.
 //
-// Why.  At 480 x 270 a trunk layer is ONE round of 510 workgroups on 512 slots.  Every workgroup stages, multiplies and stores in
-// step with every other one, so the memory system idles while the matrix pipes work and vice versa; every layer pays a launch
-// boundary, an exposed first staging, a chip-wide store burst and a tail: 37-50 us per layer for 11.5 us of matrix issue, 40 % of
-// the frame.  Round 2 ruled out a persistent trunk with GRID barriers (62 us per barrier: 512 concurrent L2 write-back fences
-// serialise).  Here there is no global barrier at all: workgroup w owns tile w through all 21 layers, and layer l of a tile starts
-// as soon as its 3 x 3 neighbourhood has finished layer l - 1 (one progress counter per tile).  Neighbours stay within one layer
-// of each other, the chip as a whole de-phases -- some workgroups store while others multiply -- and nothing is launched in between.
-// Measured on a chain of 20 plain layers (tools/bench_chain.py): 34 us per layer against 51 for dependent launches on the same box.
+// Second form of the idea (the first, in the history of this file, kept the per-layer kernel's
+// shape: 8 x 32 tiles, two workgroups per CU, staging through registers).  Its phase stamps showed a workgroup's four phases --
+// wait 8 us, staging 8, MFMAs 12, epilogue 6..12 per layer -- running strictly one after the other, AND the two workgroups of a CU
+// doing so in step (they are near neighbours in the image, the dataflow keeps them within a layer of each other): nothing
+// overlapped, 40 us per layer for 11.5 us of matrix issue.  This form overlaps inside the workgroup instead:
 //
-// Storage: the carried feature tensor F is updated IN PLACE and one intermediate tensor T is reused by every block.  A tile
-// overwrites its region of a tensor only after all its neighbours -- the only other readers of that region -- have finished the
-// layer that read it: conv2 of tile t (writes F[t], reads T with halo) needs its neighbours' conv1 of the same block done, which
-// was their last read of F[t]'s halo before the next block; conv1 of the next block (writes T[t]) needs their conv2 done.
+//   * tile 16 x 32, 512 threads, ONE workgroup per CU (480 x 270 = 255 tiles on 256 CUs), 152 KB of LDS:
+//     two patch buffers (one k-step = 16 channels of the 18 x 34 patch, hi and lo') and two weight buffers (one k-step);
+//   * every byte that enters LDS comes by LDS-DMA (global_load_lds_dwordx4): activations travel between layers in the PACKED-SPLIT
+//     format (sr_split_common.h: already split into fp16 pairs, 8 channels of a pixel per 16-byte unit), so staging is a copy --
+//     no registers, no conversion, no ds_write.  While k-step s multiplies, k-step s + 1's patch and weights land in the other
+//     buffers: ONE barrier per k-step;
+//   * the tile's own centre of the next layer's first k-step is requested BEFORE the wait for the neighbours (it is the tile's own
+//     output), only the one-pixel halo after it; the next layer's first weights travel under the last k-step;
+//   * the epilogue stores straight from the MFMA result layout (8 bytes per lane, a wave instruction = 512 contiguous bytes): no
+//     transposition through LDS;
+//   * the residual stream F never leaves the registers: each lane keeps its 64 values of the tile across the ten blocks
+//     (F += conv2(...) is an add between two register arrays); memory only ever sees the packed-split copy the next conv1 reads;
+//   * the range guard (SplitConvParams::absmax) is ONE atomic per wave per launch: one per layer (2040 atomics on one address,
+//     each waited for by the publish) cost the first form 20 us per layer when nothing else did.
 //
-// Visibility across CUs / XCDs (MI355X_MICROARCH.md, "inter-workgroup visibility": producer with drained write-through stores,
-// consumer with one agent-scope acquire):
-//   producer: every output store is `sc1` (write-through), every wave drains its stores (s_waitcnt vmcnt(0)), the workgroup meets
-//             at a barrier, ONE lane publishes the tile's progress with an agent-scope store;
-//   consumer: lanes 0..8 of wave 0 poll the neighbours' counters (relaxed agent-scope loads, s_sleep between polls, a deadline
-//             on the chip's 100 MHz clock: a neighbour that never arrives ends the launch with an error word -- never a hang),
-//             then ONE agent-scope acquire (buffer_inv sc1) + s_waitcnt vmcnt(0) + barrier, then plain loads.
-// Every workgroup must be resident at once: the host refuses images of more than 2 x #CUs tiles (the per-layer kernels take those).
+// Visibility across CUs / XCDs (MI355X_MICROARCH.md, "inter-workgroup visibility"): producer stores are `sc1` (write-through), every
+// wave drains its stores (s_waitcnt vmcnt(0)), barrier, ONE lane publishes the tile's progress with an agent-scope store; the
+// consumer polls the eight neighbours' counters (relaxed agent-scope loads, s_sleep, a deadline on the chip's 100 MHz clock: a
+// neighbour that never arrives ends the launch with an error word -- never a hang), then ONE agent-scope acquire + barrier.
+// Every workgroup must be resident at once: the host refuses images of more than #CUs tiles (the per-layer kernels take those).
 #include <cstring>
 
 #include "sr_split_common.h"
 
 namespace {
 
-constexpr int TK_MAX_LAYERS = 24;
-constexpr int TK_QPR = (ST_W + 8) / 4;
-constexpr int TK_QUNITS = S_GROUPS * SP_H * TK_QPR;                           // 400 staging units per 32-channel chunk
-constexpr int TK_LDS_BYTES = S_LDS_BYTES + 64;
+constexpr int T16_H = 16, T16_W = 32, T16_THREADS = 512, T16_WAVES = 8;
+constexpr int P16_H = T16_H + 2, P16_W = T16_W + 2, P16_PIX = P16_H * P16_W;          // 612 patch pixels
+constexpr int P16_PART = 2 * P16_PIX;                                                 // one k-step: 2 channel groups; hi, then lo at + P16_PART
+constexpr int P16_UNITS = 2 * P16_PART;                                               // 2448 units = 39168 bytes
+constexpr int P16_SUBS = (P16_PIX + 63) / 64;                                         // 10 wave-wide DMA pieces per (part, group)
+constexpr int T16_LDS_UNITS = 2 * P16_UNITS + 2 * S_WUNITS;                           // 2 patch + 2 weight buffers
+constexpr int T16_LDS_BYTES = T16_LDS_UNITS * 16 + 64 * 4 + 64;                       // + bias + flags = 152384
+constexpr int T16_MAX_LAYERS = 24;
 
-struct TrunkLayer {
-    const float* in; const float* residual; float* out;
-    const u32x4* wq; const float* bias;
-    int cin, inPlane, act;
-};
-
-struct TrunkParams {
-    TrunkLayer layer[TK_MAX_LAYERS];
+// The layers are regular: layer 0 is the preblock (x -> F, ReLU), odd layers are a block's first convolution (F -> T, ReLU), even
+// layers its second (F += conv(T)); only the weights and biases differ.
+struct Trunk16Params {
+    const u32x4* wq[T16_MAX_LAYERS]; const float* bias[T16_MAX_LAYERS];
+    const char* ws;                  // the workspace; its first 16 bytes are zero: source of the padding units
+    unsigned xpsOff, fpsOff, tpsOff; // byte offsets in the workspace of the packed-split tensors [hi | lo][groups][plane units]: input, F, T
+    int groups0;                     // channel groups of 8 of the input (a multiple of 2: 14 for 101 channels); F and T have 8
+    float* y; int yPlane;            // the trunk's result, fp32 planes [64][yPlane]
     unsigned* done;                  // [tiles] layers finished by each tile (zeroed before the launch)
     unsigned* error;                 // 1 + the layer at which a wait timed out (0: none)
     unsigned* absmax;                // range guard over every value stored (may be NULL)
     int H, W, plane, tilesX, tilesY, layers;
+    int dbg;                         // diagnostics (isrDebugSetTrunkAblation): 1 no MFMAs, 2 no activation DMA, 4 no stores, 8 no waits, 16 no weight DMA
     unsigned long long timeoutTicks; // of the chip's 100 MHz clock
+    unsigned long long* stamps;      // diagnostics: [tile][layer][8] = start, then ticks spent in wait | first staging | MFMA | epilogue | drain
 };
 
-__global__ __launch_bounds__(S_THREADS, 2) void trunk_dataflow_kernel(const TrunkParams p)
+// a wave-uniform pointer, held in scalar registers
+template <typename T>
+__device__ __forceinline__ T* trunk16_uniform(T* q)
 {
-    extern __shared__ u32x4 patch[];
-    u32x4* wbuf = patch + S_PUNITS;
-    int* flags = reinterpret_cast<int*>(wbuf + S_WUNITS);
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const unsigned long long v = (unsigned long long)q;
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v), hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
+    return (T*)(((unsigned long long)hi << 32) | lo);
+}
+
+int g_trunk_dbg = 0;
+unsigned long long* g_trunk_stamps = nullptr;
+
+// One k-step of MFMAs on this form's LDS geometry: the arithmetic of split_kstep (sr_split_common.h), tap for tap, product for product.
+__device__ __forceinline__ void trunk16_kstep(f32x16 (&acc)[2][2], const u32x4* wl, const u32x4* bl)
+{
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap) {
+        const int dy = tap / 3, dx = tap - dy * 3;
+        const f16x8 a0h = __builtin_bit_cast(f16x8, wl[tap * 128]);
+        const f16x8 a0l = __builtin_bit_cast(f16x8, wl[S_WPART + tap * 128]);
+        const f16x8 a1h = __builtin_bit_cast(f16x8, wl[tap * 128 + 32]);
+        const f16x8 a1l = __builtin_bit_cast(f16x8, wl[S_WPART + tap * 128 + 32]);
+        const f16x8 a0s = a0h * (_Float16)0.00048828125f;                   // w_hi 2^-11: partner of the scaled x_lo'
+        const f16x8 a1s = a1h * (_Float16)0.00048828125f;
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
+            const f16x8 bh = __builtin_bit_cast(f16x8, bl[(r + dy) * P16_W + dx]);
+            const f16x8 bo = __builtin_bit_cast(f16x8, bl[P16_PART + (r + dy) * P16_W + dx]);
+            acc[0][r] = mfma16(a0l, bh, acc[0][r]);
+            acc[0][r] = mfma16(a0s, bo, acc[0][r]);
+            acc[0][r] = mfma16(a0h, bh, acc[0][r]);
+            acc[1][r] = mfma16(a1l, bh, acc[1][r]);
+            acc[1][r] = mfma16(a1s, bo, acc[1][r]);
+            acc[1][r] = mfma16(a1h, bh, acc[1][r]);
+        }
+    }
+}
+
+// Where this lane's unit of DMA piece d of a patch buffer comes from.  The 40 wave-wide pieces of a k-step (2 parts x 2 channel
+// groups x 10 runs of 64 patch pixels) go 5 to a wave: piece wave + 8 d.  Its patch pixel -- hence `off` below -- is the same for
+// every k-step of every layer: computed once per launch, 5 registers + 1 of flags.
+struct Trunk16Lane {
+    int poff[5];                     // byte offset of the pixel's unit inside a plane, or -1: padding (zero unit)
+    unsigned live, centre;           // bit d: the lane takes part in piece d / its pixel belongs to the tile's own 16 x 32 centre
+};
+
+__device__ __forceinline__ Trunk16Lane trunk16_lane_setup(const Trunk16Params& p, int oy0, int ox0, int wave, int lane)
+{
+    Trunk16Lane t;
+    t.live = 0u; t.centre = 0u;
+#pragma unroll
+    for (int d = 0; d < 5; ++d) {
+        const int piece = wave + T16_WAVES * d;
+        const int sub = piece % P16_SUBS, off = sub * 64 + lane;
+        const int r = off / P16_W, c = off - r * P16_W;
+        const int iy = oy0 + r - 1, ix = ox0 + c - 1;
+        t.poff[d] = ((unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W) ? (iy * p.W + ix) * 16 : -1;
+        if (off < P16_PIX) t.live |= 1u << d;
+        if (r >= 1 && r <= T16_H && c >= 1 && c <= T16_W) t.centre |= 1u << d;
+    }
+    return t;
+}
+
+// The 18 x 34 patch of k-step ks (channel groups 2 ks, 2 ks + 1; hi and lo') into one patch buffer.
+// WHICH: 0 every unit, 1 only the tile's own 16 x 32 centre, 2 only the one-pixel halo.
+template <int WHICH>
+__device__ __forceinline__ void trunk16_stage_patch(const char* ws, unsigned inOff, int groups, unsigned planeBytes, int ks, u32x4* pbuf,
+                                                    const Trunk16Lane& t, int wave)
+{
+    const unsigned take = WHICH == 0 ? t.live : WHICH == 1 ? (t.live & t.centre) : (t.live & ~t.centre);
+#pragma unroll
+    for (int d = 0; d < 5; ++d) {
+        const int piece = wave + T16_WAVES * d;                              // 0 .. 39
+        const int pg = piece / P16_SUBS, sub = piece - pg * P16_SUBS;        // pg = part * 2 + group
+        if (take & (1u << d)) {
+            // one scalar base (the workspace) + a 32-bit lane offset: the padding unit is the workspace's first 16 bytes
+            const unsigned plane = inOff + (unsigned)((pg >> 1) * groups + 2 * ks + (pg & 1)) * planeBytes;
+            const unsigned voff = t.poff[d] >= 0 ? plane + (unsigned)t.poff[d] : 0u;
+            isr_dma16(reinterpret_cast<const u32x4*>(ws + voff), pbuf + pg * P16_PIX + sub * 64);
+        }
+    }
+}
+
+// The weights of k-step ks (9 taps x [hi | lo] x 128 units) into one weight buffer: 36 wave-wide pieces.
+__device__ __forceinline__ void trunk16_stage_weights(const u32x4* wq, int ksteps, int ks, u32x4* wbuf, int wave, int lane)
+{
+#pragma unroll
+    for (int d = 0; d < 5; ++d) {
+        const int piece = wave + T16_WAVES * d;                              // 0 .. 35 live
+        if (piece < 36) {
+            const int part = piece / 18, rem = piece - part * 18, tap = rem >> 1, half = rem & 1;
+            const char* base = reinterpret_cast<const char*>(wq + 1 + (size_t)(tap * ksteps + ks) * 256 + part * 128 + half * 64);
+            isr_dma16(reinterpret_cast<const u32x4*>(base + (unsigned)lane * 16u), wbuf + part * S_WPART + tap * 128 + half * 64);
+        }
+    }
+}
+
+__global__ __launch_bounds__(T16_THREADS) void trunk_dataflow_kernel(const Trunk16Params p)
+{
+    extern __shared__ u32x4 lds[];
+    u32x4* const pbuf0 = lds;                                                // patch buffers at + P16_UNITS
+    u32x4* const wbuf0 = lds + 2 * P16_UNITS;                                // weight buffers at + S_WUNITS
+    float* const biasl = reinterpret_cast<float*>(lds + T16_LDS_UNITS);
+    int* const flags = reinterpret_cast<int*>(biasl + 64);
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);      // in a scalar register: everything derived from it is scalar work
     const int j = lane & 31, h = lane >> 5;
     const int ntiles = p.tilesX * p.tilesY;
     int tile;
@@ -66,51 +177,71 @@ __global__ __launch_bounds__(S_THREADS, 2) void trunk_dataflow_kernel(const Trun
     }
     if (tile >= ntiles) return;
     const int tx = tile % p.tilesX, ty = tile / p.tilesX;
-    const int oy0 = ty * ST_H, ox0 = tx * ST_W;
+    const int oy0 = ty * T16_H, ox0 = tx * T16_W;
     const unsigned long long deadline = __builtin_amdgcn_s_memrealtime() + p.timeoutTicks;
-    u32x4* wdst = wbuf + (tid >> 7) * S_WPART + (tid & 127);
-    u32x4 wreg[9];
+    const Trunk16Lane lanes = trunk16_lane_setup(p, oy0, ox0, wave, lane);
+
+    f32x16 F[2][2];                                                          // the residual stream of this lane's 2 rows x 64 channels
+#pragma unroll
+    for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+        for (int r = 0; r < 2; ++r)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) F[cb][r][i] = 0.0f;
+    unsigned mag = 0u;
+    int gk = 0;                                                              // k-steps done so far, all layers: k-step gk uses buffers gk & 1
+
+    // the first layer's first k-step: nothing to wait for
+    const char* const ws = trunk16_uniform(p.ws);
+    const unsigned planeBytes = (unsigned)p.plane * 16u;
+    const bool dmaX = !(p.dbg & 2), dmaW = !(p.dbg & 16);
+    const u32x4* wq = trunk16_uniform(p.wq[0]);
+    if (dmaW) trunk16_stage_weights(wq, p.groups0 >> 1, 0, wbuf0, wave, lane);
+    if (dmaX) trunk16_stage_patch<0>(ws, p.xpsOff, p.groups0, planeBytes, 0, pbuf0, lanes, wave);
 
 #pragma unroll 1
     for (int l = 0; l < p.layers; ++l) {
-        const TrunkLayer& L = p.layer[l];
-        // ---- wait for the 3 x 3 neighbourhood to have finished layer l - 1 ------------------------------------------------
+        const int kind = l == 0 ? 0 : (l & 1) ? 1 : 2;
+        const int groups = l == 0 ? p.groups0 : 8, ksteps = groups >> 1;
+        const unsigned inOff = l == 0 ? p.xpsOff : (l & 1) ? p.fpsOff : p.tpsOff;
+        const unsigned nextOff = (l & 1) ? p.tpsOff : p.fpsOff;              // this layer's output = the next layer's input
+        const bool last = l + 1 == p.layers;
+        const float* const bias = trunk16_uniform(p.bias[l]);
+        const u32x4* const wqNext = last ? nullptr : trunk16_uniform(p.wq[l + 1]);
+        unsigned long long tstart = 0, tprev = 0, tWait = 0, tStage = 0, tMfma = 0, tEpi = 0;
+        if (p.stamps) tstart = tprev = __builtin_amdgcn_s_memrealtime();
+        auto lap = [&](unsigned long long& slot) {
+            if (p.stamps) { const unsigned long long t = __builtin_amdgcn_s_memrealtime(); slot += t - tprev; tprev = t; }
+        };
+        if (tid < 64) biasl[tid] = bias ? bias[tid] : 0.0f;              // read by the epilogue, many barriers from here
+        // ---- wait for the 3 x 3 neighbourhood to have finished layer l - 1, then fetch the halo of the first k-step ---------------
         if (l > 0) {
-            if (tid == 0) flags[0] = 0;
-            __syncthreads();
-            if (tid < 9 && tid != 4) {
-                const int ny = ty + tid / 3 - 1, nx = tx + tid % 3 - 1;
-                if ((unsigned)ny < (unsigned)p.tilesY && (unsigned)nx < (unsigned)p.tilesX) {
-                    const unsigned* f = p.done + ny * p.tilesX + nx;
-                    while (__hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (unsigned)l) {
-                        __builtin_amdgcn_s_sleep(4);
-                        if (__builtin_amdgcn_s_memrealtime() > deadline) { flags[0] = 1; break; }
+            if (!(p.dbg & 8)) {
+                if (tid == 0) flags[0] = 0;
+                __syncthreads();
+                if (tid < 9 && tid != 4) {
+                    const int ny = ty + tid / 3 - 1, nx = tx + tid % 3 - 1;
+                    if ((unsigned)ny < (unsigned)p.tilesY && (unsigned)nx < (unsigned)p.tilesX) {
+                        const unsigned* f = p.done + ny * p.tilesX + nx;
+                        while (__hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (unsigned)l) {
+                            __builtin_amdgcn_s_sleep(2);
+                            if (__builtin_amdgcn_s_memrealtime() > deadline) { flags[0] = 1; break; }
+                        }
                     }
                 }
+                if (wave == 0) {
+                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                }
+                __syncthreads();
+                if (flags[0]) {                                              // a neighbour never arrived: give up, loudly
+                    if (tid == 0) atomicMax(p.error, (unsigned)(1 + l));
+                    return;
+                }
             }
-            if (wave == 0) {
-                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            }
-            __syncthreads();
-            if (flags[0]) {                                                  // a neighbour never arrived: give up, loudly
-                if (tid == 0) atomicMax(p.error, (unsigned)(1 + l));
-                return;
-            }
+            lap(tWait);
+            if (dmaX) trunk16_stage_patch<2>(ws, inOff, groups, planeBytes, 0, pbuf0 + (gk & 1) * P16_UNITS, lanes, wave);
         }
-        const int ksteps = (L.cin + 15) >> 4;
-        const unsigned planeBytes = (unsigned)L.inPlane * 4u;
-        const rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(L.in), 0, (int)((size_t)L.cin * L.inPlane * 4), 0x00020000);
-        const rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<u32x4*>(L.wq + 1), 0, 9 * ksteps * 4096, 0x00020000);
-        auto wfetch = [&](int ks) {
-            if (ks >= ksteps) return;
-#pragma unroll
-            for (int i = 0; i < 9; ++i) wreg[i] = __builtin_amdgcn_raw_buffer_load_b128(wrs, tid * 16, (i * ksteps + ks) * 4096, 0);
-        };
-        auto wpark = [&]() {
-#pragma unroll
-            for (int i = 0; i < 9; ++i) wdst[i * 128] = wreg[i];
-        };
         f32x16 acc[2][2];
 #pragma unroll
         for (int cb = 0; cb < 2; ++cb)
@@ -118,138 +249,202 @@ __global__ __launch_bounds__(S_THREADS, 2) void trunk_dataflow_kernel(const Trun
             for (int r = 0; r < 2; ++r)
 #pragma unroll
                 for (int i = 0; i < 16; ++i) acc[cb][r][i] = 0.0f;
-        wfetch(0);
 #pragma unroll 1
-        for (int cin0 = 0; cin0 < L.cin; cin0 += S_CHUNK) {
-            const int ks0 = cin0 >> 4;
-            const int nks = min(2, ksteps - ks0);
-            // the 32-channel chunk of the patch, split into (hi, lo'): unit = (channel group, patch row, aligned quad of 4 pixels);
-            // channels beyond cin fall behind the descriptor's range and read as zero
-            for (int u0 = tid; u0 < TK_QUNITS; u0 += 2 * S_THREADS) {
-                u32x4 v[2][8];
-#pragma unroll
-                for (int k = 0; k < 2; ++k) {
-                    const int u = u0 + k * S_THREADS;
-                    const int g = u / (SP_H * TK_QPR), rem = u - g * (SP_H * TK_QPR);
-                    const int r = rem / TK_QPR, q = rem - r * TK_QPR;
-                    const int iy = oy0 + r - 1, ix = ox0 - 4 + 4 * q;
-                    const bool ok = u < TK_QUNITS && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
-                    const unsigned base = (unsigned)(cin0 + g * 8) * planeBytes + (unsigned)(iy * p.W + ix) * 4u;
-#pragma unroll
-                    for (int e = 0; e < 8; ++e)
-                        v[k][e] = __builtin_amdgcn_raw_buffer_load_b128(xrs, (int)(ok ? base + (unsigned)e * planeBytes : BAD_OFFSET), 0, 0);
-                }
-#pragma unroll
-                for (int k = 0; k < 2; ++k) {
-                    const int u = u0 + k * S_THREADS;
-                    if (u >= TK_QUNITS) continue;
-                    const int g = u / (SP_H * TK_QPR), rem = u - g * (SP_H * TK_QPR);
-                    const int r = rem / TK_QPR, q = rem - r * TK_QPR;
-                    f16x8 h0, h1, h2, h3, l0, l1, l2, l3;
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) {
-                        const float4 f = __builtin_bit_cast(float4, v[k][e]);
-                        _Float16 a, b;
-                        split16x(f.x, a, b); h0[e] = a; l0[e] = b;
-                        split16x(f.y, a, b); h1[e] = a; l1[e] = b;
-                        split16x(f.z, a, b); h2[e] = a; l2[e] = b;
-                        split16x(f.w, a, b); h3[e] = a; l3[e] = b;
-                    }
-                    u32x4* dst = patch + g * SP_PIX + r * SP_W + 4 * q - 3;
-                    if (q > 0) { dst[0] = __builtin_bit_cast(u32x4, h0); dst[S_PART] = __builtin_bit_cast(u32x4, l0); }
-                    if (q > 0 && q < TK_QPR - 1) {
-                        dst[1] = __builtin_bit_cast(u32x4, h1); dst[S_PART + 1] = __builtin_bit_cast(u32x4, l1);
-                        dst[2] = __builtin_bit_cast(u32x4, h2); dst[S_PART + 2] = __builtin_bit_cast(u32x4, l2);
-                    }
-                    if (q < TK_QPR - 1) { dst[3] = __builtin_bit_cast(u32x4, h3); dst[S_PART + 3] = __builtin_bit_cast(u32x4, l3); }
-                }
-            }
-            wpark();
+        for (int ks = 0; ks < ksteps; ++ks, ++gk) {
+            // k-step gk's patch and weights have landed (this wave's DMA: vmcnt(0) inside the barrier; everyone's: the barrier), and
+            // every wave is done with k-step gk - 1: the other buffers are free
             __syncthreads();
+            if (ks == 0) lap(tStage);
+            u32x4* const pcur = pbuf0 + (gk & 1) * P16_UNITS;
+            u32x4* const wcur = wbuf0 + (gk & 1) * S_WUNITS;
+            u32x4* const pnxt = pbuf0 + ((gk + 1) & 1) * P16_UNITS;
+            u32x4* const wnxt = wbuf0 + ((gk + 1) & 1) * S_WUNITS;
+            if (ks + 1 < ksteps) {
+                if (dmaW) trunk16_stage_weights(wq, ksteps, ks + 1, wnxt, wave, lane);
+                if (dmaX) trunk16_stage_patch<0>(ws, inOff, groups, planeBytes, ks + 1, pnxt, lanes, wave);
+            } else if (!last) {
+                if (dmaW) trunk16_stage_weights(wqNext, 4, 0, wnxt, wave, lane);
+            }
+            if (p.dbg & 32) {                                                // diagnostics: the k-step's 108 MFMAs on operands read once
+                const f16x8 a = __builtin_bit_cast(f16x8, wcur[h * 64 + j]), b = __builtin_bit_cast(f16x8, pcur[h * P16_PIX + j]);
 #pragma unroll
-            for (int S = 0; S < 2; ++S) {
-                if (S < nks) {
-                    wfetch(ks0 + S + 1);
-                    split_kstep(acc, wbuf + h * 64 + j, patch + (2 * S + h) * SP_PIX + (wave * 2) * SP_W + j, true);
-                    __syncthreads();
-                    if (S + 1 < nks) { wpark(); __syncthreads(); }
+                for (int t = 0; t < 27; ++t)
+#pragma unroll
+                    for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+                        for (int r = 0; r < 2; ++r) acc[cb][r] = mfma16(a, b, acc[cb][r]);
+            } else if (!(p.dbg & 1)) trunk16_kstep(acc, wcur + h * 64 + j, pcur + h * P16_PIX + (wave * 2) * P16_W + j);
+        }
+        lap(tMfma);
+        // ---- epilogue, straight from the D layout: lane (j, h) holds pixel j, channels 32 cb + 8 gi + 4 h + e -----------------------
+        {
+            const float unscale = reinterpret_cast<const float*>(wq)[1];
+            const rsrc_t prs = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(ws) + nextOff, 0, last ? 0 : (int)(16u * planeBytes), 0x00020000);
+            const rsrc_t yrs = __builtin_amdgcn_make_buffer_rsrc(p.y, 0, (int)((size_t)64 * p.yPlane * 4), 0x00020000);
+            const int ox = ox0 + j;
+#pragma unroll
+            for (int r = 0; r < 2; ++r) {
+                const int oy = oy0 + wave * 2 + r;
+                const bool inside = oy < p.H && ox < p.W && !(p.dbg & 4);
+                const unsigned voff = inside ? (unsigned)(oy * p.W + ox) * 16u + 8u * (unsigned)h : BAD_OFFSET;
+                const unsigned yoff = inside ? (unsigned)(oy * p.W + ox + 4 * h * p.yPlane) * 4u : BAD_OFFSET;     // the lane half's 4 channels: in the lane offset
+#pragma unroll
+                for (int cb = 0; cb < 2; ++cb) {
+#pragma unroll
+                    for (int gi = 0; gi < 4; ++gi) {
+                        const float4 b4 = *reinterpret_cast<const float4*>(biasl + cb * 32 + 8 * gi + 4 * h);
+                        const float bv[4] = {b4.x, b4.y, b4.z, b4.w};
+                        f16x4 th, tl;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            float v = acc[cb][r][4 * gi + e] * unscale + bv[e];
+                            if (kind != 2) v = v > 0.f ? v : 0.f;
+                            else v += F[cb][r][4 * gi + e];
+                            if (kind != 1) F[cb][r][4 * gi + e] = v;
+                            _Float16 a, b;
+                            split16x(v, a, b);
+                            th[e] = a; tl[e] = b;
+                            if (inside) mag = isr_umax(mag, isr_mag(v));
+                            if (last)
+                                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), yrs, (int)yoff,
+                                                                      (cb * 32 + 8 * gi + e) * p.yPlane * 4, 0);
+                        }
+                        if (!last) {
+                            const int g = cb * 4 + gi;
+                            __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, th), prs, (int)voff, g * planeBytes, 16);
+                            __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, tl), prs, (int)voff, (8 + g) * planeBytes, 16);
+                        }
+                    }
                 }
             }
         }
-        SplitConvParams q;
-        q.x = nullptr; q.wq = L.wq; q.bias = L.bias; q.residual = L.residual; q.y = L.out;
-        q.N = 1; q.Cin = L.cin; q.H = p.H; q.W = p.W; q.Cout = 64;
-        q.xPlane = L.inPlane; q.yPlane = p.plane; q.rPlane = p.plane; q.xImage = 0; q.yImage = 0; q.rImage = 0;
-        q.ksteps = ksteps; q.coutPad = 64; q.cgroups = 1; q.tilesX = p.tilesX; q.tilesY = p.tilesY;
-        q.act = L.act; q.slope = 0.f; q.Hin = p.H; q.Win = p.W; q.quads = 1; q.dbg = 0; q.stamps = nullptr;
-        q.ps = nullptr; q.psPlane = 0; q.xps = nullptr; q.xpsPlane = 0; q.zero = nullptr; q.absmax = p.absmax;
-        split_epilogue<true, 16>(q, acc, patch, 0, oy0, ox0, 0, true, lane, wave, j, h);      // sc1: write-through stores
+        lap(tEpi);
         // ---- publish: every wave's stores drained, then one agent-scope store of the tile's progress -------------------------
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         if (tid == 0) __hip_atomic_store(p.done + tile, (unsigned)(l + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        // the tile's own centre of the next layer's first k-step travels while the neighbours are waited for
+        if (!last && dmaX) trunk16_stage_patch<1>(ws, nextOff, 8, planeBytes, 0, pbuf0 + (gk & 1) * P16_UNITS, lanes, wave);
+        wq = wqNext;
+        if (p.stamps && tid == 0) {
+            unsigned long long* s = p.stamps + ((size_t)tile * p.layers + l) * 8;
+            s[0] = tstart; s[1] = tWait; s[2] = tStage; s[3] = tMfma; s[4] = tEpi; s[5] = __builtin_amdgcn_s_memrealtime() - tprev;
+            s[6] = blockIdx.x; s[7] = 0;
+        }
     }
+    isr_range_note(p.absmax, mag);
+}
+
+// x fp32 planes [cin][xPlane] -> packed-split [hi | lo][groups][plane] (channels beyond cin are zero)
+__global__ __launch_bounds__(256) void trunk_pack_input_kernel(const float* __restrict__ x, int cin, long long xPlane, int npix, u32x4* __restrict__ ps,
+                                                               int groups, int plane)
+{
+    const int pix = blockIdx.x * 256 + threadIdx.x, g = blockIdx.y;
+    if (pix >= npix) return;
+    f16x8 hi, lo;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const int c = g * 8 + e;
+        const float v = c < cin ? x[(size_t)c * xPlane + pix] : 0.0f;
+        _Float16 a, b;
+        split16x(v, a, b);
+        hi[e] = a; lo[e] = b;
+    }
+    ps[(size_t)g * plane + pix] = __builtin_bit_cast(u32x4, hi);
+    ps[(size_t)(groups + g) * plane + pix] = __builtin_bit_cast(u32x4, lo);
+}
+
+inline long long align256(long long v) { return (v + 255) & ~255LL; }
+
+struct Trunk16Layout { long long header, xps, fps, tps, total; int tiles, groups0; };
+
+Trunk16Layout trunk16_layout(int cin0, int H, int W)
+{
+    Trunk16Layout o;
+    o.tiles = ((W + T16_W - 1) / T16_W) * ((H + T16_H - 1) / T16_H);
+    o.groups0 = 2 * ((cin0 + 15) / 16);
+    const long long plane = (long long)H * W;
+    o.header = 0;                                                            // [16 zero bytes][done: tiles][error]
+    o.xps = align256(16 + (long long)(o.tiles + 1) * 4);
+    o.fps = o.xps + align256(2LL * o.groups0 * plane * 16);
+    o.tps = o.fps + align256(2LL * 8 * plane * 16);
+    o.total = o.tps + align256(2LL * 8 * plane * 16);
+    return o;
 }
 
 } // namespace
 
 extern "C" {
 
+/* Diagnostics only (tools/bench_trunk.py): bit 0 skip the MFMAs, 1 skip the activation DMA, 2 skip the stores, 3 skip the waits on
+ * the neighbours, 4 skip the weight DMA, 5 the MFMAs on operands read once per k-step (no LDS traffic).  Results are wrong with any bit set; bench.py refuses to report with a non-zero
+ * isrDebugTrunkState(). */
+void isrDebugSetTrunkAblation(int mask) { g_trunk_dbg = mask & 63; }
+/* [tiles][layers][8] unsigned long long of device memory (or NULL): per tile and layer the start tick (100 MHz) and the ticks spent
+ * waiting | until the first k-step is staged | in the MFMA phase | in the epilogue | draining the stores, then blockIdx. */
+void isrDebugSetTrunkStampBuffer(unsigned long long* stamps) { g_trunk_stamps = stamps; }
+int isrDebugTrunkState(void) { return g_trunk_dbg | (g_trunk_stamps ? 64 : 0); }
+
 int isrTrunkDataflowMaxTiles(void)
 {
     int dev = 0, cus = 0;
     (void)hipGetDevice(&dev);
     if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
-    return 2 * cus;
+    return cus;
 }
 
-long long isrTrunkDataflowWorkspaceBytes(int H, int W)
+long long isrTrunkDataflowWorkspaceBytes(int cin0, int H, int W)
 {
-    if (H <= 0 || W <= 0) return -1;
-    const long long tiles = (long long)((W + ST_W - 1) / ST_W) * ((H + ST_H - 1) / ST_H);
-    return (tiles + 2) * 4;
+    if (H <= 0 || W <= 0 || cin0 <= 0) return -1;
+    return trunk16_layout(cin0, H, W).total;
 }
 
-int isrTrunkDataflowSupported(const float* x, int H, int W, long long xPlane, long long plane)
+int isrTrunkDataflowSupported(const float* x, int cin0, int H, int W, long long xPlane, long long plane)
 {
-    if (!x || H <= 0 || W <= 0 || (W & 3) || (xPlane & 3) || (plane & 3) || ((uintptr_t)x & 15)) return 0;
-    if (xPlane < (long long)H * W || plane < (long long)H * W || xPlane * 101 * 4 > 0x7fffffffLL || plane * 64 * 4 > 0x7fffffffLL) return 0;
-    return ((W + ST_W - 1) / ST_W) * ((H + ST_H - 1) / ST_H) <= isrTrunkDataflowMaxTiles() ? 1 : 0;
+    if (!x || H <= 0 || W <= 0 || cin0 <= 0 || cin0 > 1024) return 0;
+    if (xPlane < (long long)H * W || plane < (long long)H * W || plane * 64 * 4 > 0x7fffffffLL) return 0;
+    if (trunk16_layout(cin0, H, W).total > 0xffffffffLL || (long long)H * W * 16 * 16 > 0x7fffffffLL) return 0;   // 32-bit offsets into the workspace
+    return ((W + T16_W - 1) / T16_W) * ((H + T16_H - 1) / T16_H) <= isrTrunkDataflowMaxTiles() ? 1 : 0;
 }
 
-/* x [cin0][H][W] -> F = relu(conv(x, w[0]) + b[0]); then nblocks times F += conv(relu(conv(F, w[2k+1]) + b[2k+1]), w[2k+2]) + b[2k+2]
- * (F updated in place, T the intermediate; both [64][H][W] with `plane` floats per channel).  wq[l]: isrConvSplitPrepare images. */
-int isrTrunkDataflow(const float* x, int cin0, long long xPlane, float* F, float* T, long long plane, const void* const* wq,
+/* x [cin0][H][W] -> y = F after: F = relu(conv(x, w[0]) + b[0]); nblocks times F += conv(relu(conv(F, w[2k+1]) + b[2k+1]), w[2k+2]) + b[2k+2]
+ * (y [64][H][W] with `plane` floats per channel).  wq[l]: isrConvSplitPrepare images. */
+int isrTrunkDataflow(const float* x, int cin0, long long xPlane, float* y, long long plane, const void* const* wq,
                      const float* const* bias, int nblocks, int H, int W, void* workspace, void* stream)
 {
-    if (!x || !F || !T || !wq || !bias || !workspace || nblocks < 0 || 1 + 2 * nblocks > TK_MAX_LAYERS || cin0 <= 0) return -1;
-    if (!isrTrunkDataflowSupported(x, H, W, xPlane, plane) || ((uintptr_t)F & 15) || ((uintptr_t)T & 15)) return -3;
-    TrunkParams p;
+    if (!x || !y || !wq || !bias || !workspace || nblocks < 0 || 1 + 2 * nblocks > T16_MAX_LAYERS || cin0 <= 0) return -1;
+    if (!isrTrunkDataflowSupported(x, cin0, H, W, xPlane, plane) || ((uintptr_t)workspace & 255)) return -3;
+    const Trunk16Layout lay = trunk16_layout(cin0, H, W);
+    char* ws = (char*)workspace;
+    u32x4* xps = (u32x4*)(ws + lay.xps);
+    Trunk16Params p;
     std::memset(&p, 0, sizeof(p));
     const int layers = 1 + 2 * nblocks;
     for (int l = 0; l < layers; ++l) {
-        TrunkLayer& L = p.layer[l];
         if (!wq[l]) return -1;
-        L.wq = (const u32x4*)wq[l]; L.bias = bias[l];
-        if (l == 0) { L.in = x; L.cin = cin0; L.inPlane = (int)xPlane; L.out = F; L.residual = nullptr; L.act = ISR_ACT_RELU; }
-        else if (l & 1) { L.in = F; L.cin = 64; L.inPlane = (int)plane; L.out = T; L.residual = nullptr; L.act = ISR_ACT_RELU; }
-        else { L.in = T; L.cin = 64; L.inPlane = (int)plane; L.out = F; L.residual = F; L.act = ISR_ACT_NONE; }
+        p.wq[l] = (const u32x4*)wq[l]; p.bias[l] = bias[l];
     }
-    p.H = H; p.W = W; p.plane = (int)plane; p.layers = layers;
-    p.tilesX = (W + ST_W - 1) / ST_W; p.tilesY = (H + ST_H - 1) / ST_H;
+    p.xpsOff = (unsigned)lay.xps; p.fpsOff = (unsigned)lay.fps; p.tpsOff = (unsigned)lay.tps; p.groups0 = lay.groups0;
+    p.y = y; p.yPlane = (int)plane;
+    p.H = H; p.W = W; p.plane = H * W; p.layers = layers;
+    p.tilesX = (W + T16_W - 1) / T16_W; p.tilesY = (H + T16_H - 1) / T16_H;
     const int ntiles = p.tilesX * p.tilesY;
-    p.done = (unsigned*)workspace; p.error = p.done + ntiles;
+    p.ws = ws; p.done = (unsigned*)(ws + 16); p.error = p.done + ntiles;
     p.absmax = isr_take_range_flag();
+    p.dbg = g_trunk_dbg; p.stamps = g_trunk_stamps;
     p.timeoutTicks = 5000000ull;                                             // 50 ms: a frame is 2 ms
     hipStream_t s = (hipStream_t)stream;
-    if (hipMemsetAsync(workspace, 0, (size_t)(ntiles + 1) * sizeof(unsigned), s) != hipSuccess) return -2;
+    if (hipMemsetAsync(workspace, 0, 16 + (size_t)(ntiles + 1) * sizeof(unsigned), s) != hipSuccess) return -2;
     static bool attr = false;
-    if (!attr) { (void)hipFuncSetAttribute((const void*)trunk_dataflow_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, TK_LDS_BYTES); attr = true; }
+    if (!attr) { (void)hipFuncSetAttribute((const void*)trunk_dataflow_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, T16_LDS_BYTES); attr = true; }
+    const int npix = H * W;
+    hipLaunchKernelGGL(trunk_pack_input_kernel, dim3((unsigned)((npix + 255) / 256), (unsigned)lay.groups0), dim3(256), 0, s,
+                       x, cin0, xPlane, npix, xps, lay.groups0, npix);
     hipEvent_t e0 = nullptr, e1 = nullptr;
     isr_profile_record(ISR_VARIANT_SPLIT_TRUNK, 2.0 * 9 * 64 * ((double)cin0 + 2.0 * nblocks * 64) * (double)H * W, &e0, &e1);
-    const dim3 grid((unsigned)(((ntiles + 7) / 8) * 8)), block(S_THREADS);
-    if (e0 || e1) hipExtLaunchKernelGGL(trunk_dataflow_kernel, grid, block, TK_LDS_BYTES, s, e0, e1, 0, p);
-    else hipLaunchKernelGGL(trunk_dataflow_kernel, grid, block, TK_LDS_BYTES, s, p);
+    const dim3 grid((unsigned)(((ntiles + 7) / 8) * 8)), block(T16_THREADS);
+    if (e0 || e1) hipExtLaunchKernelGGL(trunk_dataflow_kernel, grid, block, T16_LDS_BYTES, s, e0, e1, 0, p);
+    else hipLaunchKernelGGL(trunk_dataflow_kernel, grid, block, T16_LDS_BYTES, s, p);
     return hipGetLastError() == hipSuccess ? 0 : -2;
 }
 

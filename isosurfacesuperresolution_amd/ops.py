@@ -104,9 +104,9 @@ def _sr():
         lib.isrConvTailFinishFramePacked.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, vp, ci, ci, ll, vp, ci, cf, ci, ci, vp]
         lib.isrConvTailFinishFramePacked.restype = ci
         lib.isrTrunkDataflowMaxTiles.argtypes = []; lib.isrTrunkDataflowMaxTiles.restype = ci
-        lib.isrTrunkDataflowWorkspaceBytes.argtypes = [ci, ci]; lib.isrTrunkDataflowWorkspaceBytes.restype = ll
-        lib.isrTrunkDataflowSupported.argtypes = [vp, ci, ci, ll, ll]; lib.isrTrunkDataflowSupported.restype = ci
-        lib.isrTrunkDataflow.argtypes = [vp, ci, ll, vp, vp, ll, vp, vp, ci, ci, ci, vp, vp]; lib.isrTrunkDataflow.restype = ci
+        lib.isrTrunkDataflowWorkspaceBytes.argtypes = [ci, ci, ci]; lib.isrTrunkDataflowWorkspaceBytes.restype = ll
+        lib.isrTrunkDataflowSupported.argtypes = [vp, ci, ci, ci, ll, ll]; lib.isrTrunkDataflowSupported.restype = ci
+        lib.isrTrunkDataflow.argtypes = [vp, ci, ll, vp, ll, vp, vp, ci, ci, ci, vp, vp]; lib.isrTrunkDataflow.restype = ci
         lib.isrResBlockSplitWorkspaceBytes.argtypes = []; lib.isrResBlockSplitWorkspaceBytes.restype = ll
         lib.isrResBlockSplitSupported.argtypes = [vp, ci, ci, ll, ll]; lib.isrResBlockSplitSupported.restype = ci
         lib.isrResBlockSplit.argtypes = [vp, vp, vp, vp, vp, vp, vp, ci, ci, ll, ll, vp]; lib.isrResBlockSplit.restype = ci
@@ -188,7 +188,7 @@ def debug_switches():
     forms, grid caps, stamp buffers) that are not in their default position; 0 on a clean process.  bench.py reports it and
     refuses to print a headline measured with an ablation active."""
     lib = _sr()
-    return int(lib.isrDebugSplitState()) | (int(lib.isrDebugTailState()) << 8) | (int(lib.isrDebugBlockState()) << 12)
+    return int(lib.isrDebugSplitState()) | (int(lib.isrDebugTailState()) << 8) | (int(lib.isrDebugBlockState()) << 12) | (int(lib.isrDebugTrunkState()) << 16)
 
 
 def profile_enable(on):
@@ -776,7 +776,7 @@ def trunk_supported(x, convs):
     if any_hot(x.device) or range_is_hot(getattr(x, '_isr_range_key', None), x.device):
         return False
     xs, xp, _ = _plane_strides(x)
-    return xs is x and bool(_sr().isrTrunkDataflowSupported(_ptr(x), x.shape[2], x.shape[3], xp, x.shape[2] * x.shape[3] + plane_pad(x.shape[2], x.shape[3])))
+    return xs is x and bool(_sr().isrTrunkDataflowSupported(_ptr(x), x.shape[1], x.shape[2], x.shape[3], xp, x.shape[2] * x.shape[3] + plane_pad(x.shape[2], x.shape[3])))
 
 
 def trunk_dataflow(x, convs):
@@ -784,20 +784,20 @@ def trunk_dataflow(x, convs):
     lib = _sr()
     x, xp, _ = _plane_strides(x)
     _, cin, h, w = x.shape
-    key = (x.device, h, w, torch.cuda.current_stream().cuda_stream)
+    key = (x.device, cin, h, w, torch.cuda.current_stream().cuda_stream)
     ws = _trunk_ws.get(key)
     if ws is None:
-        ws = torch.zeros(lib.isrTrunkDataflowWorkspaceBytes(h, w) // 4, dtype=torch.int32, device=x.device)
+        # header (zero unit, the tiles' progress counters, error word) + the packed-split input, F and T tensors of the launch
+        ws = torch.zeros(lib.isrTrunkDataflowWorkspaceBytes(cin, h, w) // 4, dtype=torch.int32, device=x.device)
         _trunk_ws[key] = ws
     f = empty_planes(1, 64, h, w, x.device)
-    t = empty_planes(1, 64, h, w, x.device)
     wq = [_prepare_split(wt) for wt, _ in convs]
     bs = [b.detach().contiguous() if b is not None else None for _, b in convs]
     n = len(convs)
     pw = (ctypes.c_void_p * n)(*[q.data_ptr() for q in wq])
     pb = (ctypes.c_void_p * n)(*[(b.data_ptr() if b is not None else None) for b in bs])
     f._isr_range_key = _arm_range(("trunk", id(convs[0][0])), x.device)
-    rc = lib.isrTrunkDataflow(_ptr(x), cin, xp, _ptr(f), _ptr(t), f.stride(1), pw, pb, (n - 1) // 2, h, w, _ptr(ws), _stream())
+    rc = lib.isrTrunkDataflow(_ptr(x), cin, xp, _ptr(f), f.stride(1), pw, pb, (n - 1) // 2, h, w, _ptr(ws), _stream())
     if rc != 0:
         raise RuntimeError("isrTrunkDataflow failed (%d)" % rc)
     return f
@@ -807,8 +807,8 @@ def trunk_check():
     """Host read of the dataflow launches' error words (ONE synchronisation): raises if a tile ever gave up waiting for a
     neighbour -- which would mean a workgroup was not resident (more tiles than the GPU holds) or the launch was disturbed."""
     for key, ws in list(_trunk_ws.items()):
-        tiles = ws.numel() - 2
-        err = int(ws[tiles].item())
+        tiles = ((key[2] + 15) // 16) * ((key[3] + 31) // 32)
+        err = int(ws[4 + tiles].item())
         if err:
             raise RuntimeError("trunk_dataflow_kernel: a tile timed out waiting for its neighbours at layer %d" % (err - 1))
 
