@@ -42,7 +42,7 @@ constexpr int P16_PART = 2 * P16_PIX;                                           
 constexpr int P16_UNITS = 2 * P16_PART;                                               // 2448 units = 39168 bytes
 constexpr int P16_SUBS = (P16_PIX + 63) / 64;                                         // 10 wave-wide DMA pieces per (part, group)
 constexpr int T16_LDS_UNITS = 2 * P16_UNITS + 2 * S_WUNITS;                           // 2 patch + 2 weight buffers
-constexpr int T16_LDS_BYTES = T16_LDS_UNITS * 16 + 64 * 4 + 64;                       // + bias + flags = 152384
+constexpr int T16_LDS_BYTES = T16_LDS_UNITS * 16 + 2 * 64 * 4 + 64;                   // + two bias buffers + flags = 152640
 constexpr int T16_MAX_LAYERS = 24;
 
 // The layers are regular: layer 0 is the preblock (x -> F, ReLU), odd layers are a block's first convolution (F -> T, ReLU), even
@@ -59,7 +59,7 @@ struct Trunk16Params {
     int H, W, plane, tilesX, tilesY, layers;
     int dbg;                         // diagnostics (isrDebugSetTrunkAblation): 1 no MFMAs, 2 no activation DMA, 4 no stores, 8 no waits, 16 no weight DMA
     unsigned long long timeoutTicks; // of the chip's 100 MHz clock
-    unsigned long long* stamps;      // diagnostics: [tile][layer][8] = start, then ticks spent in wait | first staging | MFMA | epilogue | drain
+    unsigned long long* stamps;      // diagnostics: [tile][layer][8] = ticks at: layer start | neighbours there | first k-step staged | MFMAs done | epilogue done | stores drained
 };
 
 // a wave-uniform pointer, held in scalar registers
@@ -74,37 +74,79 @@ __device__ __forceinline__ T* trunk16_uniform(T* q)
 int g_trunk_dbg = 0;
 unsigned long long* g_trunk_stamps = nullptr;
 
-// One k-step of MFMAs on this form's LDS geometry: the arithmetic of split_kstep (sr_split_common.h), tap for tap, product for product.
-__device__ __forceinline__ void trunk16_kstep(f32x16 (&acc)[2][2], const u32x4* wl, const u32x4* bl)
+typedef __attribute__((address_space(3))) char t16_lds_char;
+
+// (No "memory" clobber on these: the requests land in LDS buffers nobody reads before the next barrier, which is preceded by an
+// explicit s_waitcnt vmcnt(0) that does carry one; with it every request would pin the k-step's operand reads in place and the
+// compiler could no longer fetch a tap's operands under the MFMAs of the tap before.)
+// LDS-DMA with a SCALAR base and a 32-bit lane offset (the builtin only produces the 64-bit-lane-address form, which costs a 64-bit
+// vector add per request): lane l's 16 bytes at base + voff land at LDS address ldsaddr + 16 l.
+#pragma clang diagnostic push
+#pragma clang diagnostic ignored "-Winline-asm"
+// COHERENT: an agent-scope load (sc1): served past this XCD's L2, which may hold a stale copy of a line another XCD has rewritten.
+template <bool COHERENT = false>
+__device__ __forceinline__ void trunk16_dma16(const void* base, unsigned voff, unsigned ldsaddr)
+{
+    if (COHERENT)
+        asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2 sc1" :: "s"(ldsaddr), "v"(voff), "s"(base) : "m0");
+    else
+        asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" :: "s"(ldsaddr), "v"(voff), "s"(base) : "m0");
+}
+// ... and 64 floats (lane l's dword to ldsaddr + 4 l)
+__device__ __forceinline__ void trunk16_dma4(const void* base, unsigned voff, unsigned ldsaddr)
+{
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dword %1, %2" :: "s"(ldsaddr), "v"(voff), "s"(base) : "m0");
+}
+#pragma clang diagnostic pop
+
+// One k-step of MFMAs on this form's LDS geometry: the arithmetic of split_kstep (sr_split_common.h), tap for tap, product for
+// product.  `between(tap)` runs after each tap's MFMAs are issued: the caller spreads its DMA requests over the k-step there, so
+// that a request that has to queue for the memory pipeline does so behind 12 MFMAs of cover instead of in front of the k-step.
+struct Trunk16Operands { f16x8 a0h, a0l, a1h, a1l, bh[2], bo[2]; };
+
+__device__ __forceinline__ Trunk16Operands trunk16_operands(const u32x4* wl, const u32x4* bl, int tap)
+{
+    const int dy = tap / 3, dx = tap - dy * 3;
+    Trunk16Operands o;
+    o.a0h = __builtin_bit_cast(f16x8, wl[tap * 128]);
+    o.a0l = __builtin_bit_cast(f16x8, wl[S_WPART + tap * 128]);
+    o.a1h = __builtin_bit_cast(f16x8, wl[tap * 128 + 32]);
+    o.a1l = __builtin_bit_cast(f16x8, wl[S_WPART + tap * 128 + 32]);
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+        o.bh[r] = __builtin_bit_cast(f16x8, bl[(r + dy) * P16_W + dx]);
+        o.bo[r] = __builtin_bit_cast(f16x8, bl[P16_PART + (r + dy) * P16_W + dx]);
+    }
+    return o;
+}
+
+template <typename Between>
+__device__ __forceinline__ void trunk16_kstep(f32x16 (&acc)[2][2], const u32x4* wl, const u32x4* bl, Between between)
 {
 #pragma unroll
     for (int tap = 0; tap < 9; ++tap) {
-        const int dy = tap / 3, dx = tap - dy * 3;
-        const f16x8 a0h = __builtin_bit_cast(f16x8, wl[tap * 128]);
-        const f16x8 a0l = __builtin_bit_cast(f16x8, wl[S_WPART + tap * 128]);
-        const f16x8 a1h = __builtin_bit_cast(f16x8, wl[tap * 128 + 32]);
-        const f16x8 a1l = __builtin_bit_cast(f16x8, wl[S_WPART + tap * 128 + 32]);
-        const f16x8 a0s = a0h * (_Float16)0.00048828125f;                   // w_hi 2^-11: partner of the scaled x_lo'
-        const f16x8 a1s = a1h * (_Float16)0.00048828125f;
+        const Trunk16Operands cur = trunk16_operands(wl, bl, tap);
+        const f16x8 a0s = cur.a0h * (_Float16)0.00048828125f;               // w_hi 2^-11: partner of the scaled x_lo'
+        const f16x8 a1s = cur.a1h * (_Float16)0.00048828125f;
 #pragma unroll
         for (int r = 0; r < 2; ++r) {
-            const f16x8 bh = __builtin_bit_cast(f16x8, bl[(r + dy) * P16_W + dx]);
-            const f16x8 bo = __builtin_bit_cast(f16x8, bl[P16_PART + (r + dy) * P16_W + dx]);
-            acc[0][r] = mfma16(a0l, bh, acc[0][r]);
-            acc[0][r] = mfma16(a0s, bo, acc[0][r]);
-            acc[0][r] = mfma16(a0h, bh, acc[0][r]);
-            acc[1][r] = mfma16(a1l, bh, acc[1][r]);
-            acc[1][r] = mfma16(a1s, bo, acc[1][r]);
-            acc[1][r] = mfma16(a1h, bh, acc[1][r]);
+            acc[0][r] = mfma16(cur.a0l, cur.bh[r], acc[0][r]);
+            acc[0][r] = mfma16(a0s, cur.bo[r], acc[0][r]);
+            acc[0][r] = mfma16(cur.a0h, cur.bh[r], acc[0][r]);
+            acc[1][r] = mfma16(cur.a1l, cur.bh[r], acc[1][r]);
+            acc[1][r] = mfma16(a1s, cur.bo[r], acc[1][r]);
+            acc[1][r] = mfma16(cur.a1h, cur.bh[r], acc[1][r]);
         }
+        between(tap);
     }
 }
 
 // Where this lane's unit of DMA piece d of a patch buffer comes from.  The 40 wave-wide pieces of a k-step (2 parts x 2 channel
-// groups x 10 runs of 64 patch pixels) go 5 to a wave: piece wave + 8 d.  Its patch pixel -- hence `off` below -- is the same for
-// every k-step of every layer: computed once per launch, 5 registers + 1 of flags.
+// groups x 10 runs of 64 patch pixels) go 5 to a wave: piece wave + 8 d.  Its patch pixel is the same for every k-step of every
+// layer: computed once per launch, 5 registers + 2 of flags.  Every plane of a packed-split tensor ends in one zero unit (unit H W):
+// that is where padding pixels read, so the lane offset needs no select.
 struct Trunk16Lane {
-    int poff[5];                     // byte offset of the pixel's unit inside a plane, or -1: padding (zero unit)
+    unsigned poff[5];                // byte offset of the pixel's unit inside a plane (padding: the plane's zero unit)
     unsigned live, centre;           // bit d: the lane takes part in piece d / its pixel belongs to the tile's own 16 x 32 centre
 };
 
@@ -118,43 +160,105 @@ __device__ __forceinline__ Trunk16Lane trunk16_lane_setup(const Trunk16Params& p
         const int sub = piece % P16_SUBS, off = sub * 64 + lane;
         const int r = off / P16_W, c = off - r * P16_W;
         const int iy = oy0 + r - 1, ix = ox0 + c - 1;
-        t.poff[d] = ((unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W) ? (iy * p.W + ix) * 16 : -1;
+        t.poff[d] = (unsigned)(((unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W) ? iy * p.W + ix : p.H * p.W) * 16u;
         if (off < P16_PIX) t.live |= 1u << d;
         if (r >= 1 && r <= T16_H && c >= 1 && c <= T16_W) t.centre |= 1u << d;
     }
     return t;
 }
 
-// The 18 x 34 patch of k-step ks (channel groups 2 ks, 2 ks + 1; hi and lo') into one patch buffer.
-// WHICH: 0 every unit, 1 only the tile's own 16 x 32 centre, 2 only the one-pixel halo.
+// Piece d (0 .. 4) of this wave's share of the 18 x 34 patch of k-step ks (channel groups 2 ks, 2 ks + 1; hi and lo') into the patch
+// buffer at LDS address pbuf.  WHICH: 0 every unit, 1 only the tile's own 16 x 32 centre, 2 only the one-pixel halo.
 template <int WHICH>
-__device__ __forceinline__ void trunk16_stage_patch(const char* ws, unsigned inOff, int groups, unsigned planeBytes, int ks, u32x4* pbuf,
-                                                    const Trunk16Lane& t, int wave)
+__device__ __forceinline__ void trunk16_patch_piece(int d, const char* tensor, int groups, unsigned planeBytes, int ks, unsigned pbuf,
+                                                    const Trunk16Lane& t, int wave, bool p_allCoherent = false)
 {
-    const unsigned take = WHICH == 0 ? t.live : WHICH == 1 ? (t.live & t.centre) : (t.live & ~t.centre);
-#pragma unroll
-    for (int d = 0; d < 5; ++d) {
-        const int piece = wave + T16_WAVES * d;                              // 0 .. 39
-        const int pg = piece / P16_SUBS, sub = piece - pg * P16_SUBS;        // pg = part * 2 + group
-        if (take & (1u << d)) {
-            // one scalar base (the workspace) + a 32-bit lane offset: the padding unit is the workspace's first 16 bytes
-            const unsigned plane = inOff + (unsigned)((pg >> 1) * groups + 2 * ks + (pg & 1)) * planeBytes;
-            const unsigned voff = t.poff[d] >= 0 ? plane + (unsigned)t.poff[d] : 0u;
-            isr_dma16(reinterpret_cast<const u32x4*>(ws + voff), pbuf + pg * P16_PIX + sub * 64);
-        }
+    const int piece = wave + T16_WAVES * d;                                  // 0 .. 39
+    const int pg = piece / P16_SUBS, sub = piece - pg * P16_SUBS;            // pg = part * 2 + group
+    const char* const plane = tensor + (size_t)((pg >> 1) * groups + 2 * ks + (pg & 1)) * planeBytes;
+    const unsigned dst = pbuf + (unsigned)(pg * P16_PIX + sub * 64) * 16u;
+    // the centre is this workgroup's own output of the layer before: its L2 has it.  The halo was written by other CUs, possibly
+    // behind another L2: read coherently (no L2 invalidation anywhere in this kernel: the weights and the centres stay cached)
+    if (WHICH == 0 && (p_allCoherent)) {
+        if (t.live & (1u << d)) trunk16_dma16<true>(plane, t.poff[d], dst);
+        return;
+    }
+    if (WHICH != 2 && (t.live & t.centre & (1u << d))) trunk16_dma16<false>(plane, t.poff[d], dst);
+    if (WHICH != 1 && (t.live & ~t.centre & (1u << d))) trunk16_dma16<true>(plane, t.poff[d], dst);
+}
+
+// Piece d (0 .. 4) of this wave's share of the weights of k-step ks (9 taps x [hi | lo] x 128 units: 36 wave-wide pieces).
+__device__ __forceinline__ void trunk16_weight_piece(int d, const u32x4* wq, int ksteps, int ks, unsigned wbuf, int wave, int lane)
+{
+    const int piece = wave + T16_WAVES * d;                                  // 0 .. 35 live
+    if (piece < 36) {
+        const int part = piece / 18, rem = piece - part * 18, tap = rem >> 1, half = rem & 1;
+        trunk16_dma16(wq + 1 + (size_t)(tap * ksteps + ks) * 256 + part * 128 + half * 64, (unsigned)lane * 16u,
+                      wbuf + (unsigned)(part * S_WPART + tap * 128 + half * 64) * 16u);
     }
 }
 
-// The weights of k-step ks (9 taps x [hi | lo] x 128 units) into one weight buffer: 36 wave-wide pieces.
-__device__ __forceinline__ void trunk16_stage_weights(const u32x4* wq, int ksteps, int ks, u32x4* wbuf, int wave, int lane)
+// The epilogue of one layer, straight from the D layout: lane (j, h) holds pixel j, channels 32 cb + 8 gi + 4 h + e.
+// KIND 0: F = relu(conv + b); 1: T = relu(conv + b); 2: F += conv + b.  LAST: the result goes to y (fp32 planes), else to the
+// packed-split tensor `out` (write-through stores: other CUs read it after the publish).
+// Not LAST: channels 0 .. 31 -- the next layer's first two k-steps -- go straight into the two patch buffers (pk0, pk1: LDS, this
+// tile's centre; pixels outside the image as zeros) and to memory only where a neighbour will read them (the tile's outermost
+// ring); channels 32 .. 63 go to memory whole and come back by DMA under those two k-steps.
+template <int KIND, bool LAST>
+__device__ __forceinline__ void trunk16_epilogue(const Trunk16Params& p, f32x16 (&acc)[2][2], f32x16 (&F)[2][2], unsigned& mag, float unscale,
+                                                 const float* biasl, const char* out, unsigned planeBytes, int oy0, int ox0, int wave, int j, int h,
+                                                 u32x4* pk0, u32x4* pk1)
 {
+    const rsrc_t prs = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(LAST ? reinterpret_cast<const char*>(p.y) : out), 0,
+                                                         LAST ? (int)((size_t)64 * p.yPlane * 4) : (int)(16u * planeBytes), 0x00020000);
+    const int ox = ox0 + j;
 #pragma unroll
-    for (int d = 0; d < 5; ++d) {
-        const int piece = wave + T16_WAVES * d;                              // 0 .. 35 live
-        if (piece < 36) {
-            const int part = piece / 18, rem = piece - part * 18, tap = rem >> 1, half = rem & 1;
-            const char* base = reinterpret_cast<const char*>(wq + 1 + (size_t)(tap * ksteps + ks) * 256 + part * 128 + half * 64);
-            isr_dma16(reinterpret_cast<const u32x4*>(base + (unsigned)lane * 16u), wbuf + part * S_WPART + tap * 128 + half * 64);
+    for (int r = 0; r < 2; ++r) {
+        const int oy = oy0 + wave * 2 + r;
+        const bool inside = oy < p.H && ox < p.W && !(p.dbg & 4);
+        const unsigned voff = !inside ? BAD_OFFSET : LAST ? (unsigned)(oy * p.W + ox + 4 * h * p.yPlane) * 4u      // the lane half's 4 channels: in the lane offset
+                                                          : (unsigned)(oy * p.W + ox) * 16u + 8u * (unsigned)h;
+        const int row = wave * 2 + r;
+        const bool ring = row == 0 || row == T16_H - 1 || j == 0 || j == T16_W - 1;
+        const unsigned voffRing = ring ? voff : BAD_OFFSET;
+        const bool live = oy < p.H && ox < p.W;                              // (the stores' ablation switch does not touch the LDS hand-over)
+        u32x2* const c0 = reinterpret_cast<u32x2*>(pk0 + (row + 1) * P16_W + j + 1) + h;     // this lane's 8 bytes of the pixel's unit
+        u32x2* const c1 = reinterpret_cast<u32x2*>(pk1 + (row + 1) * P16_W + j + 1) + h;
+#pragma unroll
+        for (int cb = 0; cb < 2; ++cb) {
+#pragma unroll
+            for (int gi = 0; gi < 4; ++gi) {
+                const float4 b4 = *reinterpret_cast<const float4*>(biasl + cb * 32 + 8 * gi + 4 * h);
+                const float bv[4] = {b4.x, b4.y, b4.z, b4.w};
+                f16x4 th, tl;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    float v = acc[cb][r][4 * gi + e] * unscale + bv[e];
+                    if (KIND != 2) v = v > 0.f ? v : 0.f;
+                    else v += F[cb][r][4 * gi + e];
+                    if (KIND != 1) F[cb][r][4 * gi + e] = v;
+                    if (inside) mag = isr_umax(mag, isr_mag(v));
+                    if (LAST) {
+                        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), prs, (int)voff, (cb * 32 + 8 * gi + e) * p.yPlane * 4, 0);
+                    } else {
+                        _Float16 a, b;
+                        split16x(v, a, b);
+                        th[e] = a; tl[e] = b;
+                    }
+                }
+                if (!LAST) {
+                    const int g = cb * 4 + gi;
+                    const unsigned vo = cb == 0 ? voffRing : voff;
+                    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, th), prs, (int)vo, g * planeBytes, 16);
+                    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, tl), prs, (int)vo, (8 + g) * planeBytes, 16);
+                    if (cb == 0) {
+                        const u32x2 zero2 = {0u, 0u};
+                        u32x2* const c = (gi < 2 ? c0 : c1) + (gi & 1) * (P16_PIX * 2);          // channel group of the k-step; lo' at + P16_PART units
+                        c[0] = live ? __builtin_bit_cast(u32x2, th) : zero2;
+                        c[P16_PART * 2] = live ? __builtin_bit_cast(u32x2, tl) : zero2;
+                    }
+                }
+            }
         }
     }
 }
@@ -164,8 +268,10 @@ __global__ __launch_bounds__(T16_THREADS) void trunk_dataflow_kernel(const Trunk
     extern __shared__ u32x4 lds[];
     u32x4* const pbuf0 = lds;                                                // patch buffers at + P16_UNITS
     u32x4* const wbuf0 = lds + 2 * P16_UNITS;                                // weight buffers at + S_WUNITS
-    float* const biasl = reinterpret_cast<float*>(lds + T16_LDS_UNITS);
-    int* const flags = reinterpret_cast<int*>(biasl + 64);
+    float* const biasl0 = reinterpret_cast<float*>(lds + T16_LDS_UNITS);     // two bias buffers of 64 floats
+    int* const flags = reinterpret_cast<int*>(biasl0 + 128);
+    const unsigned ldsBase = (unsigned)(uintptr_t)(t16_lds_char*)lds;        // LDS byte addresses for the DMA
+    const unsigned pAddr = ldsBase, wAddr = ldsBase + 2 * P16_UNITS * 16, bAddr = ldsBase + T16_LDS_UNITS * 16;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);      // in a scalar register: everything derived from it is scalar work
     const int j = lane & 31, h = lane >> 5;
@@ -191,29 +297,38 @@ __global__ __launch_bounds__(T16_THREADS) void trunk_dataflow_kernel(const Trunk
     unsigned mag = 0u;
     int gk = 0;                                                              // k-steps done so far, all layers: k-step gk uses buffers gk & 1
 
-    // the first layer's first k-step: nothing to wait for
     const char* const ws = trunk16_uniform(p.ws);
-    const unsigned planeBytes = (unsigned)p.plane * 16u;
+    const unsigned planeBytes = (unsigned)p.plane * 16u;                     // H W units + the plane's zero unit, rounded up to whole cache lines
     const bool dmaX = !(p.dbg & 2), dmaW = !(p.dbg & 16);
     const u32x4* wq = trunk16_uniform(p.wq[0]);
-    if (dmaW) trunk16_stage_weights(wq, p.groups0 >> 1, 0, wbuf0, wave, lane);
-    if (dmaX) trunk16_stage_patch<0>(ws, p.xpsOff, p.groups0, planeBytes, 0, pbuf0, lanes, wave);
+    // bias of layer l into bias buffer l & 1: one dword-wide DMA (64 floats) by the last wave; a layer without bias reads zeros
+    auto stage_bias = [&](int l) {
+        const float* b = trunk16_uniform(p.bias[l]);
+        if (wave != T16_WAVES - 1) return;
+        if (b) trunk16_dma4(b, (unsigned)lane * 4u, bAddr + (unsigned)(l & 1) * 256u);
+        else biasl0[(l & 1) * 64 + lane] = 0.0f;
+    };
+    // the first layer's first k-step: nothing to wait for
+    stage_bias(0);
+#pragma unroll
+    for (int d = 0; d < 5; ++d) {
+        if (dmaW) trunk16_weight_piece(d, wq, p.groups0 >> 1, 0, wAddr, wave, lane);
+        if (dmaX) trunk16_patch_piece<0>(d, ws + p.xpsOff, p.groups0, planeBytes, 0, pAddr, lanes, wave);
+    }
 
 #pragma unroll 1
     for (int l = 0; l < p.layers; ++l) {
         const int kind = l == 0 ? 0 : (l & 1) ? 1 : 2;
         const int groups = l == 0 ? p.groups0 : 8, ksteps = groups >> 1;
-        const unsigned inOff = l == 0 ? p.xpsOff : (l & 1) ? p.fpsOff : p.tpsOff;
-        const unsigned nextOff = (l & 1) ? p.tpsOff : p.fpsOff;              // this layer's output = the next layer's input
+        const char* const tin = ws + (l == 0 ? p.xpsOff : (l & 1) ? p.fpsOff : p.tpsOff);
+        const char* const tout = ws + ((l & 1) ? p.tpsOff : p.fpsOff);       // this layer's output = the next layer's input
         const bool last = l + 1 == p.layers;
-        const float* const bias = trunk16_uniform(p.bias[l]);
         const u32x4* const wqNext = last ? nullptr : trunk16_uniform(p.wq[l + 1]);
-        unsigned long long tstart = 0, tprev = 0, tWait = 0, tStage = 0, tMfma = 0, tEpi = 0;
-        if (p.stamps) tstart = tprev = __builtin_amdgcn_s_memrealtime();
-        auto lap = [&](unsigned long long& slot) {
-            if (p.stamps) { const unsigned long long t = __builtin_amdgcn_s_memrealtime(); slot += t - tprev; tprev = t; }
+        // diagnostics: raw ticks at the phase boundaries, straight to memory (no registers held for it)
+        auto lap = [&](int slot) {
+            if (p.stamps && tid == 0) p.stamps[((size_t)tile * p.layers + l) * 8 + slot] = __builtin_amdgcn_s_memrealtime();
         };
-        if (tid < 64) biasl[tid] = bias ? bias[tid] : 0.0f;              // read by the epilogue, many barriers from here
+        lap(0);
         // ---- wait for the 3 x 3 neighbourhood to have finished layer l - 1, then fetch the halo of the first k-step ---------------
         if (l > 0) {
             if (!(p.dbg & 8)) {
@@ -229,18 +344,17 @@ __global__ __launch_bounds__(T16_THREADS) void trunk_dataflow_kernel(const Trunk
                         }
                     }
                 }
-                if (wave == 0) {
-                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                }
                 __syncthreads();
                 if (flags[0]) {                                              // a neighbour never arrived: give up, loudly
                     if (tid == 0) atomicMax(p.error, (unsigned)(1 + l));
                     return;
                 }
             }
-            lap(tWait);
-            if (dmaX) trunk16_stage_patch<2>(ws, inOff, groups, planeBytes, 0, pbuf0 + (gk & 1) * P16_UNITS, lanes, wave);
+            lap(1);
+            if (dmaX) {
+#pragma unroll
+                for (int d = 0; d < 5; ++d) trunk16_patch_piece<2>(d, tin, groups, planeBytes, 0, pAddr + (unsigned)(gk & 1) * (P16_UNITS * 16), lanes, wave);
+            }
         }
         f32x16 acc[2][2];
 #pragma unroll
@@ -251,20 +365,32 @@ __global__ __launch_bounds__(T16_THREADS) void trunk_dataflow_kernel(const Trunk
                 for (int i = 0; i < 16; ++i) acc[cb][r][i] = 0.0f;
 #pragma unroll 1
         for (int ks = 0; ks < ksteps; ++ks, ++gk) {
-            // k-step gk's patch and weights have landed (this wave's DMA: vmcnt(0) inside the barrier; everyone's: the barrier), and
-            // every wave is done with k-step gk - 1: the other buffers are free
+            // k-step gk's patch and weights have landed (this wave's DMA: the explicit vmcnt(0) -- the compiler does not count the
+            // requests issued from inline assembly; everyone's: the barrier), and every wave is done with k-step gk - 1: the other
+            // buffers are free
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();
-            if (ks == 0) lap(tStage);
-            u32x4* const pcur = pbuf0 + (gk & 1) * P16_UNITS;
-            u32x4* const wcur = wbuf0 + (gk & 1) * S_WUNITS;
-            u32x4* const pnxt = pbuf0 + ((gk + 1) & 1) * P16_UNITS;
-            u32x4* const wnxt = wbuf0 + ((gk + 1) & 1) * S_WUNITS;
-            if (ks + 1 < ksteps) {
-                if (dmaW) trunk16_stage_weights(wq, ksteps, ks + 1, wnxt, wave, lane);
-                if (dmaX) trunk16_stage_patch<0>(ws, inOff, groups, planeBytes, ks + 1, pnxt, lanes, wave);
-            } else if (!last) {
-                if (dmaW) trunk16_stage_weights(wqNext, 4, 0, wnxt, wave, lane);
-            }
+            if (ks == 0) lap(2);
+            const int cur = gk & 1, nxt = cur ^ 1;
+            const u32x4* const pcur = pbuf0 + cur * P16_UNITS;
+            const u32x4* const wcur = wbuf0 + cur * S_WUNITS;
+            const unsigned pnxt = pAddr + (unsigned)nxt * (P16_UNITS * 16), wnxt = wAddr + (unsigned)nxt * (S_WUNITS * 16);
+            const bool more = ks + 1 < ksteps;
+            // the next k-step's patch and weights (or, under the layer's last k-step, the next layer's first weights and its bias):
+            // one or two requests after each of the first taps' MFMAs
+            auto between = [&](int tap) {
+                if (more) {
+                    if (tap < 5) {
+                        // k-step 1 of a layer fed by this kernel: the centre is in LDS already (the epilogue put it there)
+                        if (dmaX && l > 0 && ks == 0) trunk16_patch_piece<2>(tap, tin, groups, planeBytes, 1, pnxt, lanes, wave);
+                        else if (dmaX) trunk16_patch_piece<0>(tap, tin, groups, planeBytes, ks + 1, pnxt, lanes, wave, (p.dbg & 64) != 0);
+                        if (dmaW) trunk16_weight_piece(tap, wq, ksteps, ks + 1, wnxt, wave, lane);
+                    }
+                } else if (!last) {
+                    if (tap < 5) { if (dmaW) trunk16_weight_piece(tap, wqNext, 4, 0, wnxt, wave, lane); }
+                    else if (tap == 5) stage_bias(l + 1);
+                }
+            };
             if (p.dbg & 32) {                                                // diagnostics: the k-step's 108 MFMAs on operands read once
                 const f16x8 a = __builtin_bit_cast(f16x8, wcur[h * 64 + j]), b = __builtin_bit_cast(f16x8, pcur[h * P16_PIX + j]);
 #pragma unroll
@@ -273,74 +399,56 @@ __global__ __launch_bounds__(T16_THREADS) void trunk_dataflow_kernel(const Trunk
                     for (int cb = 0; cb < 2; ++cb)
 #pragma unroll
                         for (int r = 0; r < 2; ++r) acc[cb][r] = mfma16(a, b, acc[cb][r]);
-            } else if (!(p.dbg & 1)) trunk16_kstep(acc, wcur + h * 64 + j, pcur + h * P16_PIX + (wave * 2) * P16_W + j);
-        }
-        lap(tMfma);
-        // ---- epilogue, straight from the D layout: lane (j, h) holds pixel j, channels 32 cb + 8 gi + 4 h + e -----------------------
-        {
-            const float unscale = reinterpret_cast<const float*>(wq)[1];
-            const rsrc_t prs = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(ws) + nextOff, 0, last ? 0 : (int)(16u * planeBytes), 0x00020000);
-            const rsrc_t yrs = __builtin_amdgcn_make_buffer_rsrc(p.y, 0, (int)((size_t)64 * p.yPlane * 4), 0x00020000);
-            const int ox = ox0 + j;
 #pragma unroll
-            for (int r = 0; r < 2; ++r) {
-                const int oy = oy0 + wave * 2 + r;
-                const bool inside = oy < p.H && ox < p.W && !(p.dbg & 4);
-                const unsigned voff = inside ? (unsigned)(oy * p.W + ox) * 16u + 8u * (unsigned)h : BAD_OFFSET;
-                const unsigned yoff = inside ? (unsigned)(oy * p.W + ox + 4 * h * p.yPlane) * 4u : BAD_OFFSET;     // the lane half's 4 channels: in the lane offset
+                for (int t = 0; t < 9; ++t) between(t);
+            } else if (!(p.dbg & 1)) {
+                trunk16_kstep(acc, wcur + h * 64 + j, pcur + h * P16_PIX + (wave * 2) * P16_W + j, between);
+            } else {
 #pragma unroll
-                for (int cb = 0; cb < 2; ++cb) {
-#pragma unroll
-                    for (int gi = 0; gi < 4; ++gi) {
-                        const float4 b4 = *reinterpret_cast<const float4*>(biasl + cb * 32 + 8 * gi + 4 * h);
-                        const float bv[4] = {b4.x, b4.y, b4.z, b4.w};
-                        f16x4 th, tl;
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) {
-                            float v = acc[cb][r][4 * gi + e] * unscale + bv[e];
-                            if (kind != 2) v = v > 0.f ? v : 0.f;
-                            else v += F[cb][r][4 * gi + e];
-                            if (kind != 1) F[cb][r][4 * gi + e] = v;
-                            _Float16 a, b;
-                            split16x(v, a, b);
-                            th[e] = a; tl[e] = b;
-                            if (inside) mag = isr_umax(mag, isr_mag(v));
-                            if (last)
-                                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), yrs, (int)yoff,
-                                                                      (cb * 32 + 8 * gi + e) * p.yPlane * 4, 0);
-                        }
-                        if (!last) {
-                            const int g = cb * 4 + gi;
-                            __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, th), prs, (int)voff, g * planeBytes, 16);
-                            __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, tl), prs, (int)voff, (8 + g) * planeBytes, 16);
-                        }
-                    }
-                }
+                for (int t = 0; t < 9; ++t) between(t);
             }
         }
-        lap(tEpi);
+        __syncthreads();                                                     // both patch buffers are free: the epilogue fills them
+        lap(3);
+        {
+            const float unscale = reinterpret_cast<const float*>(wq)[1];
+            const float* const biasl = biasl0 + (l & 1) * 64;
+            u32x4* const pk0 = pbuf0 + (gk & 1) * P16_UNITS;                 // the next layer's k-steps 0 and 1
+            u32x4* const pk1 = pbuf0 + ((gk + 1) & 1) * P16_UNITS;
+            if (last) {
+                if (kind == 0) trunk16_epilogue<0, true>(p, acc, F, mag, unscale, biasl, tout, planeBytes, oy0, ox0, wave, j, h, pk0, pk1);
+                else trunk16_epilogue<2, true>(p, acc, F, mag, unscale, biasl, tout, planeBytes, oy0, ox0, wave, j, h, pk0, pk1);
+            } else if (kind == 0) trunk16_epilogue<0, false>(p, acc, F, mag, unscale, biasl, tout, planeBytes, oy0, ox0, wave, j, h, pk0, pk1);
+            else if (kind == 1) trunk16_epilogue<1, false>(p, acc, F, mag, unscale, biasl, tout, planeBytes, oy0, ox0, wave, j, h, pk0, pk1);
+            else trunk16_epilogue<2, false>(p, acc, F, mag, unscale, biasl, tout, planeBytes, oy0, ox0, wave, j, h, pk0, pk1);
+        }
+        lap(4);
         // ---- publish: every wave's stores drained, then one agent-scope store of the tile's progress -------------------------
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         if (tid == 0) __hip_atomic_store(p.done + tile, (unsigned)(l + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        // the tile's own centre of the next layer's first k-step travels while the neighbours are waited for
-        if (!last && dmaX) trunk16_stage_patch<1>(ws, nextOff, 8, planeBytes, 0, pbuf0 + (gk & 1) * P16_UNITS, lanes, wave);
         wq = wqNext;
-        if (p.stamps && tid == 0) {
-            unsigned long long* s = p.stamps + ((size_t)tile * p.layers + l) * 8;
-            s[0] = tstart; s[1] = tWait; s[2] = tStage; s[3] = tMfma; s[4] = tEpi; s[5] = __builtin_amdgcn_s_memrealtime() - tprev;
-            s[6] = blockIdx.x; s[7] = 0;
-        }
+        lap(5);
     }
     isr_range_note(p.absmax, mag);
 }
 
-// x fp32 planes [cin][xPlane] -> packed-split [hi | lo][groups][plane] (channels beyond cin are zero)
+// x fp32 planes [cin][xPlane] -> packed-split [hi | lo][groups][npix + 1 units] (channels beyond cin are zero), and the zero unit
+// that ends every plane of the three packed-split tensors of the launch (the padding pixels of the LDS-DMA staging read it)
 __global__ __launch_bounds__(256) void trunk_pack_input_kernel(const float* __restrict__ x, int cin, long long xPlane, int npix, u32x4* __restrict__ ps,
-                                                               int groups, int plane)
+                                                               int groups, u32x4* __restrict__ fps, u32x4* __restrict__ tps)
 {
     const int pix = blockIdx.x * 256 + threadIdx.x, g = blockIdx.y;
-    if (pix >= npix) return;
+    const size_t plane = ((size_t)npix + 8) & ~(size_t)7;
+    const u32x4 zero = {0u, 0u, 0u, 0u};
+    if (blockIdx.x == 0 && threadIdx.x < 2) {
+        if (g < groups) ps[(size_t)(threadIdx.x * groups + g) * plane + npix] = zero;
+        if (g < 8) {
+            fps[(size_t)(threadIdx.x * 8 + g) * plane + npix] = zero;
+            tps[(size_t)(threadIdx.x * 8 + g) * plane + npix] = zero;
+        }
+    }
+    if (pix >= npix || g >= groups) return;
     f16x8 hi, lo;
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
@@ -363,7 +471,7 @@ Trunk16Layout trunk16_layout(int cin0, int H, int W)
     Trunk16Layout o;
     o.tiles = ((W + T16_W - 1) / T16_W) * ((H + T16_H - 1) / T16_H);
     o.groups0 = 2 * ((cin0 + 15) / 16);
-    const long long plane = (long long)H * W;
+    const long long plane = ((long long)H * W + 8) & ~7LL;                   // + the zero unit that ends every plane, whole 128-byte lines
     o.header = 0;                                                            // [16 zero bytes][done: tiles][error]
     o.xps = align256(16 + (long long)(o.tiles + 1) * 4);
     o.fps = o.xps + align256(2LL * o.groups0 * plane * 16);
@@ -379,11 +487,12 @@ extern "C" {
 /* Diagnostics only (tools/bench_trunk.py): bit 0 skip the MFMAs, 1 skip the activation DMA, 2 skip the stores, 3 skip the waits on
  * the neighbours, 4 skip the weight DMA, 5 the MFMAs on operands read once per k-step (no LDS traffic).  Results are wrong with any bit set; bench.py refuses to report with a non-zero
  * isrDebugTrunkState(). */
-void isrDebugSetTrunkAblation(int mask) { g_trunk_dbg = mask & 63; }
-/* [tiles][layers][8] unsigned long long of device memory (or NULL): per tile and layer the start tick (100 MHz) and the ticks spent
- * waiting | until the first k-step is staged | in the MFMA phase | in the epilogue | draining the stores, then blockIdx. */
+void isrDebugSetTrunkAblation(int mask) { g_trunk_dbg = mask & 127; }
+/* [tiles][layers][8] unsigned long long of ZEROED device memory (or NULL): per tile and layer the tick (100 MHz, one clock for the
+ * chip) at the layer's start | the neighbours' arrival | the first k-step staged | the MFMAs done | the epilogue done | the stores
+ * drained (slot 1 stays 0 for the first layer). */
 void isrDebugSetTrunkStampBuffer(unsigned long long* stamps) { g_trunk_stamps = stamps; }
-int isrDebugTrunkState(void) { return g_trunk_dbg | (g_trunk_stamps ? 64 : 0); }
+int isrDebugTrunkState(void) { return g_trunk_dbg | (g_trunk_stamps ? 128 : 0); }
 
 int isrTrunkDataflowMaxTiles(void)
 {
@@ -403,7 +512,7 @@ int isrTrunkDataflowSupported(const float* x, int cin0, int H, int W, long long 
 {
     if (!x || H <= 0 || W <= 0 || cin0 <= 0 || cin0 > 1024) return 0;
     if (xPlane < (long long)H * W || plane < (long long)H * W || plane * 64 * 4 > 0x7fffffffLL) return 0;
-    if (trunk16_layout(cin0, H, W).total > 0xffffffffLL || (long long)H * W * 16 * 16 > 0x7fffffffLL) return 0;   // 32-bit offsets into the workspace
+    if (trunk16_layout(cin0, H, W).total > 0xffffffffLL || ((long long)H * W + 8) * 16 * 16 > 0x7fffffffLL) return 0;   // 32-bit offsets into the workspace
     return ((W + T16_W - 1) / T16_W) * ((H + T16_H - 1) / T16_H) <= isrTrunkDataflowMaxTiles() ? 1 : 0;
 }
 
@@ -426,7 +535,7 @@ int isrTrunkDataflow(const float* x, int cin0, long long xPlane, float* y, long 
     }
     p.xpsOff = (unsigned)lay.xps; p.fpsOff = (unsigned)lay.fps; p.tpsOff = (unsigned)lay.tps; p.groups0 = lay.groups0;
     p.y = y; p.yPlane = (int)plane;
-    p.H = H; p.W = W; p.plane = H * W; p.layers = layers;
+    p.H = H; p.W = W; p.plane = (int)(((long long)H * W + 8) & ~7LL); p.layers = layers;
     p.tilesX = (W + T16_W - 1) / T16_W; p.tilesY = (H + T16_H - 1) / T16_H;
     const int ntiles = p.tilesX * p.tilesY;
     p.ws = ws; p.done = (unsigned*)(ws + 16); p.error = p.done + ntiles;
@@ -438,8 +547,8 @@ int isrTrunkDataflow(const float* x, int cin0, long long xPlane, float* y, long 
     static bool attr = false;
     if (!attr) { (void)hipFuncSetAttribute((const void*)trunk_dataflow_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, T16_LDS_BYTES); attr = true; }
     const int npix = H * W;
-    hipLaunchKernelGGL(trunk_pack_input_kernel, dim3((unsigned)((npix + 255) / 256), (unsigned)lay.groups0), dim3(256), 0, s,
-                       x, cin0, xPlane, npix, xps, lay.groups0, npix);
+    hipLaunchKernelGGL(trunk_pack_input_kernel, dim3((unsigned)((npix + 255) / 256), (unsigned)(lay.groups0 > 8 ? lay.groups0 : 8)), dim3(256), 0, s,
+                       x, cin0, xPlane, npix, xps, lay.groups0, (u32x4*)(ws + lay.fps), (u32x4*)(ws + lay.tps));
     hipEvent_t e0 = nullptr, e1 = nullptr;
     isr_profile_record(ISR_VARIANT_SPLIT_TRUNK, 2.0 * 9 * 64 * ((double)cin0 + 2.0 * nblocks * 64) * (double)H * W, &e0, &e1);
     const dim3 grid((unsigned)(((ntiles + 7) / 8) * 8)), block(T16_THREADS);

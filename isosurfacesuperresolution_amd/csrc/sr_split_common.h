@@ -62,13 +62,16 @@ struct SplitConvParams {
 // bit pattern of |v|: unsigned order = order of the magnitudes, inf above every finite value, NaN above inf (never lost)
 __device__ __forceinline__ unsigned isr_mag(float v) { return __builtin_bit_cast(unsigned, v) & 0x7fffffffu; }
 __device__ __forceinline__ unsigned isr_umax(unsigned a, unsigned b) { return a > b ? a : b; }
-// one atomic per wave: lane maxima combined by butterfly shuffles
+// At most one atomic per wave: lane maxima combined by butterfly shuffles, and the atomic only if the wave would raise the flag.
+// (32 000 waves of a 1080p launch hammering one address are a queue the last workgroups of the launch wait behind; the flag
+// reaches its final value within the first few waves, everyone after that reads it -- a cached line -- and moves on.  A stale
+// read can only be too LOW, i.e. cost a superfluous atomic, never lose a maximum.)
 __device__ __forceinline__ void isr_range_note(unsigned* flag, unsigned m)
 {
     if (!flag) return;
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) m = isr_umax(m, (unsigned)__shfl_xor((int)m, o, 64));
-    if ((threadIdx.x & 63) == 0) atomicMax(flag, m);
+    if ((threadIdx.x & 63) == 0 && m > __hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(flag, m);
 }
 
 typedef unsigned u32x2 __attribute__((ext_vector_type(2)));

@@ -27,9 +27,10 @@ with torch.no_grad():
     lib.isrDebugSetTrunkStampBuffer(None)
 s = stamps.cpu().numpy().reshape(tiles, L, 8).astype(np.float64)
 t0 = s[:, :, 0].min()
+s[:, 0, 1] = s[:, 0, 0]                             # the first layer waits for nobody
 start = (s[:, :, 0] - t0) / 100.0                  # us
-ph = s[:, :, 1:6] / 100.0                           # us: wait, stage, mfma, epilogue, drain
-end = start + ph.sum(axis=2)
+ph = np.diff(s[:, :, 0:6], axis=2) / 100.0          # us: wait, stage, mfma, epilogue, drain
+end = (s[:, :, 5] - t0) / 100.0
 print("launch span %.0f us (first layer start -> last layer end)" % end.max())
 names = ["wait", "stage", "mfma", "epilogue", "drain"]
 print("mean per tile over the launch: " + ", ".join("%s %.0f us" % (n, ph[:, :, i].sum(axis=1).mean()) for i, n in enumerate(names)),
