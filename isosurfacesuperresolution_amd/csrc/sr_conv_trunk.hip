@@ -4,32 +4,41 @@
 // 3 x 3 neighbourhood has finished layer l - 1 (one progress counter per tile, no grid barrier).  Same split-operand products in
 // the same order as the per-layer kernels of sr_conv_split.hip: the output is bit-identical to them.
 //
-// Second form of the idea (the first, in the history of this file, kept the per-layer kernel's
-// shape: 8 x 32 tiles, two workgroups per CU, staging through registers).  Its phase stamps showed a workgroup's four phases --
-// wait 8 us, staging 8, MFMAs 12, epilogue 6..12 per layer -- running strictly one after the other, AND the two workgroups of a CU
-// doing so in step (they are near neighbours in the image, the dataflow keeps them within a layer of each other): nothing
-// overlapped, 40 us per layer for 11.5 us of matrix issue.  This form overlaps inside the workgroup instead:
+// Second form of the idea (the first, in the history of this file, kept the per-layer kernel's shape: 8 x 32 tiles, two workgroups
+// per CU, staging through registers).  Its phase stamps showed a workgroup's four phases -- wait 8 us, staging 8, MFMAs 12,
+// epilogue 6..12 per layer -- running strictly one after the other, AND the two workgroups of a CU doing so in step (they are near
+// neighbours in the image, the dataflow keeps them within a layer of each other): nothing overlapped, 40 us per layer for 11.5 us
+// of matrix issue.  This form overlaps inside the workgroup instead:
 //
 //   * tile 16 x 32, 512 threads, ONE workgroup per CU (480 x 270 = 255 tiles on 256 CUs), 152 KB of LDS:
 //     two patch buffers (one k-step = 16 channels of the 18 x 34 patch, hi and lo') and two weight buffers (one k-step);
-//   * every byte that enters LDS comes by LDS-DMA (global_load_lds_dwordx4): activations travel between layers in the PACKED-SPLIT
-//     format (sr_split_common.h: already split into fp16 pairs, 8 channels of a pixel per 16-byte unit), so staging is a copy --
-//     no registers, no conversion, no ds_write.  While k-step s multiplies, k-step s + 1's patch and weights land in the other
-//     buffers: ONE barrier per k-step;
-//   * the tile's own centre of the next layer's first k-step is requested BEFORE the wait for the neighbours (it is the tile's own
-//     output), only the one-pixel halo after it; the next layer's first weights travel under the last k-step;
-//   * the epilogue stores straight from the MFMA result layout (8 bytes per lane, a wave instruction = 512 contiguous bytes): no
-//     transposition through LDS;
+//   * every byte that enters LDS from memory comes by LDS-DMA (global_load_lds_dwordx4, scalar base + 32-bit lane offset, issued
+//     from inline assembly): activations travel between layers in the PACKED-SPLIT format (sr_split_common.h: already split into
+//     fp16 pairs, 8 channels of a pixel per 16-byte unit; every plane ends in a zero unit that padding pixels read), so staging is
+//     a copy -- no registers, no conversion.  While k-step s multiplies, k-step s + 1's patch and weights land in the other
+//     buffers, one or two requests after each tap's MFMAs: ONE barrier per k-step;
+//   * the epilogue works straight from the MFMA result layout (no transposition through LDS).  Channels 0 .. 31 of the tile -- the
+//     next layer's first two k-steps -- are written INTO the two patch buffers (the centre never leaves the CU) and to memory only
+//     on the tile's outermost ring (what the neighbours read); channels 32 .. 63 go to memory (8 bytes per lane, a wave instruction
+//     = 512 contiguous bytes) and return by DMA under those two k-steps.  Per tile and layer 77 KB are stored and 91 KB fetched
+//     instead of 131 + 157: an XCD's 32 tiles fit its 4 MB L2;
 //   * the residual stream F never leaves the registers: each lane keeps its 64 values of the tile across the ten blocks
 //     (F += conv2(...) is an add between two register arrays); memory only ever sees the packed-split copy the next conv1 reads;
+//   * the next layer's first weights and its bias travel under the last k-step;
 //   * the range guard (SplitConvParams::absmax) is ONE atomic per wave per launch: one per layer (2040 atomics on one address,
 //     each waited for by the publish) cost the first form 20 us per layer when nothing else did.
 //
 // Visibility across CUs / XCDs (MI355X_MICROARCH.md, "inter-workgroup visibility"): producer stores are `sc1` (write-through), every
 // wave drains its stores (s_waitcnt vmcnt(0)), barrier, ONE lane publishes the tile's progress with an agent-scope store; the
 // consumer polls the eight neighbours' counters (relaxed agent-scope loads, s_sleep, a deadline on the chip's 100 MHz clock: a
-// neighbour that never arrives ends the launch with an error word -- never a hang), then ONE agent-scope acquire + barrier.
+// neighbour that never arrives ends the launch with an error word -- never a hang) and then reads the halo -- the only bytes other
+// CUs wrote -- with agent-scope (sc1) DMA loads, which are served past this XCD's L2.  No cache is ever invalidated: the weights
+// and the tile's own centre stay in L2.
 // Every workgroup must be resident at once: the host refuses images of more than #CUs tiles (the per-layer kernels take those).
+//
+// Measured (tools/bench_trunk.py, tools/trunk_timeline.py; 480 x 270, 21 layers): 0.58-0.65 ms against 0.84 for the first form and
+// 0.83-1.15 for 21 launches.  Per layer ~29 us: MFMA phase 22 (the 108 x 4 MFMAs of a wave take 17 at the 1.6 GHz the chip holds
+// under this load -- 11 with operands read once, i.e. at full clock), epilogue 2.2, drain 1.4, wait 2.5, halo fetch 1.8.
 #include <cstring>
 
 #include "sr_split_common.h"
@@ -171,7 +180,7 @@ __device__ __forceinline__ Trunk16Lane trunk16_lane_setup(const Trunk16Params& p
 // buffer at LDS address pbuf.  WHICH: 0 every unit, 1 only the tile's own 16 x 32 centre, 2 only the one-pixel halo.
 template <int WHICH>
 __device__ __forceinline__ void trunk16_patch_piece(int d, const char* tensor, int groups, unsigned planeBytes, int ks, unsigned pbuf,
-                                                    const Trunk16Lane& t, int wave, bool p_allCoherent = false)
+                                                    const Trunk16Lane& t, int wave)
 {
     const int piece = wave + T16_WAVES * d;                                  // 0 .. 39
     const int pg = piece / P16_SUBS, sub = piece - pg * P16_SUBS;            // pg = part * 2 + group
@@ -179,10 +188,6 @@ __device__ __forceinline__ void trunk16_patch_piece(int d, const char* tensor, i
     const unsigned dst = pbuf + (unsigned)(pg * P16_PIX + sub * 64) * 16u;
     // the centre is this workgroup's own output of the layer before: its L2 has it.  The halo was written by other CUs, possibly
     // behind another L2: read coherently (no L2 invalidation anywhere in this kernel: the weights and the centres stay cached)
-    if (WHICH == 0 && (p_allCoherent)) {
-        if (t.live & (1u << d)) trunk16_dma16<true>(plane, t.poff[d], dst);
-        return;
-    }
     if (WHICH != 2 && (t.live & t.centre & (1u << d))) trunk16_dma16<false>(plane, t.poff[d], dst);
     if (WHICH != 1 && (t.live & ~t.centre & (1u << d))) trunk16_dma16<true>(plane, t.poff[d], dst);
 }
@@ -383,7 +388,7 @@ __global__ __launch_bounds__(T16_THREADS) void trunk_dataflow_kernel(const Trunk
                     if (tap < 5) {
                         // k-step 1 of a layer fed by this kernel: the centre is in LDS already (the epilogue put it there)
                         if (dmaX && l > 0 && ks == 0) trunk16_patch_piece<2>(tap, tin, groups, planeBytes, 1, pnxt, lanes, wave);
-                        else if (dmaX) trunk16_patch_piece<0>(tap, tin, groups, planeBytes, ks + 1, pnxt, lanes, wave, (p.dbg & 64) != 0);
+                        else if (dmaX) trunk16_patch_piece<0>(tap, tin, groups, planeBytes, ks + 1, pnxt, lanes, wave);
                         if (dmaW) trunk16_weight_piece(tap, wq, ksteps, ks + 1, wnxt, wave, lane);
                     }
                 } else if (!last) {
@@ -487,12 +492,12 @@ extern "C" {
 /* Diagnostics only (tools/bench_trunk.py): bit 0 skip the MFMAs, 1 skip the activation DMA, 2 skip the stores, 3 skip the waits on
  * the neighbours, 4 skip the weight DMA, 5 the MFMAs on operands read once per k-step (no LDS traffic).  Results are wrong with any bit set; bench.py refuses to report with a non-zero
  * isrDebugTrunkState(). */
-void isrDebugSetTrunkAblation(int mask) { g_trunk_dbg = mask & 127; }
+void isrDebugSetTrunkAblation(int mask) { g_trunk_dbg = mask & 63; }
 /* [tiles][layers][8] unsigned long long of ZEROED device memory (or NULL): per tile and layer the tick (100 MHz, one clock for the
  * chip) at the layer's start | the neighbours' arrival | the first k-step staged | the MFMAs done | the epilogue done | the stores
  * drained (slot 1 stays 0 for the first layer). */
 void isrDebugSetTrunkStampBuffer(unsigned long long* stamps) { g_trunk_stamps = stamps; }
-int isrDebugTrunkState(void) { return g_trunk_dbg | (g_trunk_stamps ? 128 : 0); }
+int isrDebugTrunkState(void) { return g_trunk_dbg | (g_trunk_stamps ? 64 : 0); }
 
 int isrTrunkDataflowMaxTiles(void)
 {

@@ -64,7 +64,8 @@ class SuperResolutionPipeline:
         # (0.21 ms alone) the plain kernel beside the network gives 400 frames/s; the capped 128-register kernel (2), which
         # round 1's 0.45 ms nested-loop kernel needed, gives 384 (tools/side_sweep.sh)
         self.side_variant = None
-        self.prefetch_after_trunk = os.environ.get("ISR_PREFETCH_AFTER_TRUNK", "0") == "1"     # measured: no gain (414-418 vs 420 frames/s)
+        self.prefetch_after_trunk = os.environ.get("ISR_PREFETCH_AFTER_TRUNK", "1") != "0"     # measured: 516-519 against 497-505 frames/s with the render beside the trunk
+        self._trunk_done = torch.cuda.Event() if torch.cuda.is_available() else None
         self.previous = None
         self.foreground_variant = 0       # kernel variant of frames rendered on the main stream
         # fused=True: input assembly and frame finishing run as two HIP kernels (ops.assemble_input /
@@ -98,10 +99,13 @@ class SuperResolutionPipeline:
             if self._displayed is not None:
                 self.renderer.set_last_camera(self._displayed, self._lookat)
 
-    def prefetch(self, origin):
-        """Start rendering the G-buffer of ``origin`` on the side stream (used by ``frame(..., next_origin=)``)."""
+    def prefetch(self, origin, after=None):
+        """Start rendering the G-buffer of ``origin`` on the side stream (used by ``frame(..., next_origin=)``).
+        ``after``: an event the render waits for on top of the buffer hand-over (e.g. the end of the trunk)."""
         slot = self._slot ^ 1
         rs = self._render_stream
+        if after is not None:
+            rs.wait_event(after)
         rs.wait_event(self._consumed[slot])              # the network has finished reading that buffer ...
         rs.wait_event(self._frame_start)                 # ... and so has anything the caller enqueued before this frame()
                                                          # (``pipe.gbuffer`` stays valid until the next frame() call)
@@ -197,10 +201,12 @@ class SuperResolutionPipeline:
             g = self._acquire_gbuffer(origin)
             start_next = None
             if next_origin is not None and self.prefetch_after_trunk:
-                # the next frame's render is enqueued once the trunk has been: the dataflow trunk is ONE round of workgroups that
-                # must all be resident (a ray-march wave on a SIMD keeps the CU's second conv workgroup out until it ends, and that
-                # tile's neighbours wait for it), while the 1080p kernels behind it run many rounds and absorb a guest
-                start_next = lambda: self.prefetch(next_origin)
+                # the next frame's render starts when the trunk has ENDED (an event): the dataflow trunk is ONE round of workgroups, one
+                # per CU, that must all be resident and wait for each other tile by tile -- a guest that delays one tile delays its
+                # neighbours -- while the 1080p kernels behind it run many rounds and absorb a guest
+                def start_next():
+                    self._trunk_done.record(torch.cuda.current_stream())
+                    self.prefetch(next_origin, after=self._trunk_done)
             elif next_origin is not None:
                 # the next frame's render goes first.  With the capped 128-register kernel (side_variant = 2) this stream then
                 # waits until its waves sit one per SIMD on the momentarily idle GPU (a no-op for the other variants).

@@ -95,3 +95,26 @@ def test_dataflow_trunk_under_uneven_load_and_repeated_launches():
     ops.trunk_check()
     bad = [k for k, o in enumerate(outs) if not torch.equal(o, ref)]
     assert not bad, "launches %s differ (max |diff| %.3g)" % (bad, max((outs[k] - ref).abs().max().item() for k in bad))
+
+
+@pytest.mark.parametrize("cin,nblocks,h,w", [(5, 1, 33, 70), (16, 0, 16, 32), (40, 2, 50, 64), (101, 3, 270, 480)])
+def test_dataflow_trunk_with_other_depths_and_input_widths(cin, nblocks, h, w):
+    """Fewer input channel groups than the 8 of the inner tensors (the packing kernel still has to end every plane of all three
+    packed-split tensors with its zero unit), no blocks at all (the preblock's result goes straight to y), and consecutive launches
+    on DIFFERENT inputs through the same workspace (nothing of the previous launch may survive in it)."""
+    from isosurfacesuperresolution_amd import ops
+    g = torch.Generator().manual_seed(cin * 100 + nblocks)
+    convs = [(((torch.rand(64, cin if k == 0 else 64, 3, 3, generator=g) - 0.5) * 0.15).cuda(), ((torch.rand(64, generator=g) - 0.5) * 0.2).cuda())
+             for k in range(1 + 2 * nblocks)]
+    with torch.no_grad():
+        for trial in range(3):
+            x = ((torch.rand(1, cin, h, w, generator=g) - 0.4) * (1 + trial)).cuda()
+            assert ops.trunk_supported(x, convs)
+            f = ops.trunk_dataflow(x, convs)
+            ref = ops.conv3x3_split(x, convs[0][0], convs[0][1], act='relu')
+            for k in range(nblocks):
+                t = ops.conv3x3_split(ref, convs[2 * k + 1][0], convs[2 * k + 1][1], act='relu')
+                ref = ops.conv3x3_split(t, convs[2 * k + 2][0], convs[2 * k + 2][1], residual=ref)
+            torch.cuda.synchronize()
+            ops.trunk_check()
+            assert torch.equal(f, ref), (trial, (f - ref).abs().max().item())
