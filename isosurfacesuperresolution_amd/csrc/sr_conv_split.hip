@@ -173,13 +173,13 @@ __global__ __launch_bounds__(S_THREADS, 2) void conv3x3_split_kernel(const Split
                 for (int e = 0; e < 4; ++e) {
                     const float a0 = ta[e * LR_CS + x0], a1 = ta[e * LR_CS + x1];
                     const float b0 = tb[e * LR_CS + x0], b1 = tb[e * LR_CS + x1];
-                    const float al = hxl * a0 + lxl * a1, ar = hxr * a0 + lxr * a1;
-                    const float bl = hxl * b0 + lxl * b1, br = hxr * b0 + lxr * b1;
+                    const float al = isr_blend(hxl, a0, lxl, a1), ar = isr_blend(hxr, a0, lxr, a1);
+                    const float bl = isr_blend(hxl, b0, lxl, b1), br = isr_blend(hxr, b0, lxr, b1);
                     _Float16 vh, vl;
-                    split16x(hyu * al + lyu * bl, vh, vl); h00[e] = vh; l00[e] = vl;
-                    split16x(hyu * ar + lyu * br, vh, vl); h01[e] = vh; l01[e] = vl;
-                    split16x(hyd * al + lyd * bl, vh, vl); h10[e] = vh; l10[e] = vl;
-                    split16x(hyd * ar + lyd * br, vh, vl); h11[e] = vh; l11[e] = vl;
+                    split16x(isr_blend(hyu, al, lyu, bl), vh, vl); h00[e] = vh; l00[e] = vl;
+                    split16x(isr_blend(hyu, ar, lyu, br), vh, vl); h01[e] = vh; l01[e] = vl;
+                    split16x(isr_blend(hyd, al, lyd, bl), vh, vl); h10[e] = vh; l10[e] = vl;
+                    split16x(isr_blend(hyd, ar, lyd, br), vh, vl); h11[e] = vh; l11[e] = vl;
                 }
                 const f16x4 z = {(_Float16)0.0f, (_Float16)0.0f, (_Float16)0.0f, (_Float16)0.0f};
                 if (!(oku && okl)) { h00 = z; l00 = z; }

@@ -98,6 +98,10 @@ __device__ __forceinline__ void split16x(float v, _Float16& hi, _Float16& lo)
     lo = (_Float16)((v - (float)hi) * 2048.0f);
 }
 
+// h a + l b with the roundings spelled out -- round(l b), then one fused multiply-add -- so that every kernel that interpolates (the
+// two upsampling kernels must agree bit for bit) gets the same bits whatever the optimiser would have contracted on its own
+__device__ __forceinline__ float isr_blend(float h, float a, float l, float b) { return __builtin_fmaf(h, a, l * b); }
+
 __device__ __forceinline__ float buf_load(rsrc_t r, unsigned voff)
 {
     return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, (int)voff, 0, 0));

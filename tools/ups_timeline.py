@@ -8,7 +8,7 @@ from isosurfacesuperresolution_amd import ops
 lib = ops._sr()
 lib.isrDebugSetSplitStampBuffer.argtypes = [ctypes.c_void_p]
 with torch.no_grad():
-    for (h, w), packed in (((540, 960), False), ((540, 960), True), ((270, 480), False)):
+    for (h, w), packed in (((540, 960), True), ((540, 960), False), ((270, 480), False)):
         x = torch.rand(1, 64, h, w, device='cuda') - 0.5
         wt = (torch.rand(64, 64, 3, 3, device='cuda') - 0.5) * 0.1
         b = torch.rand(64, device='cuda')
