@@ -65,6 +65,9 @@ class SuperResolutionPipeline:
         # round 1's 0.45 ms nested-loop kernel needed, gives 384 (tools/side_sweep.sh)
         self.side_variant = None
         self.prefetch_after_trunk = os.environ.get("ISR_PREFETCH_AFTER_TRUNK", "1") != "0"     # measured: 516-519 against 497-505 frames/s with the render beside the trunk
+        # where in the network the next frame's render is released (experiment switch): trunk | ups1 | ups2 | tail = when the trunk,
+        # the first / second upsampling layer, or everything but the last launch has ended
+        self.prefetch_point = os.environ.get("ISR_PREFETCH_POINT", "trunk")
         self._trunk_done = torch.cuda.Event() if torch.cuda.is_available() else None
         self.previous = None
         self.foreground_variant = 0       # kernel variant of frames rendered on the main stream
@@ -165,8 +168,12 @@ class SuperResolutionPipeline:
         tail = last.weight.shape[0] == 6 and ops.TAIL_FUSION and ops.SPLIT_F16 and not ops.FAST_F16 and not ops.any_hot(x.device)
         four = net.postblock[4]
         if tail and ops.TAIL_PACKED and tuple(six.weight.shape) == (64, 64, 3, 3) and tuple(last.weight.shape) == (6, 64, 3, 3):
-            f2 = net.forward_features(x, last_three=False, after_trunk=after_trunk)
-            after_trunk = None
+            at = self.prefetch_point
+            f2 = net.forward_features(x, last_three=False, after_trunk=after_trunk if at == "trunk" else None)
+            if at == "trunk":
+                after_trunk = None
+            if at == "ups1" and after_trunk is not None:
+                after_trunk(); after_trunk = None
             if ops.packed_supported(f2, four.weight, True):
                 # postblock.4 writes its output packed-split (already the (hi, lo') units postblock.6 multiplies), the tail
                 # stages them by LDS-DMA: no conversion on the way in, no LDS transposition on the way out
@@ -176,6 +183,8 @@ class SuperResolutionPipeline:
         elif tail:
             f4 = net.forward_features(x, last_two=False, after_trunk=after_trunk)
             after_trunk = None
+        if f4 is not None and after_trunk is not None and self.prefetch_point != "tail":
+            after_trunk(); after_trunk = None                # "ups2": beside the fused tail
         if isinstance(f4, ops.PackedSplit) or (f4 is not None and ops.tail_supported(f4, six.weight, last.weight)):
             # postblock.6, postblock.8 and the frame's finishing in two launches; the 64-channel 1080p tensor between the
             # two convolutions never goes to memory (csrc/sr_conv_tail.hip)
