@@ -31,9 +31,13 @@
 // Visibility across CUs / XCDs (MI355X_MICROARCH.md, "inter-workgroup visibility"): producer stores are `sc1` (write-through), every
 // wave drains its stores (s_waitcnt vmcnt(0)), barrier, ONE lane publishes the tile's progress with an agent-scope store; the
 // consumer polls the eight neighbours' counters (relaxed agent-scope loads, s_sleep, a deadline on the chip's 100 MHz clock: a
-// neighbour that never arrives ends the launch with an error word -- never a hang) and then reads the halo -- the only bytes other
-// CUs wrote -- with agent-scope (sc1) DMA loads, which are served past this XCD's L2.  No cache is ever invalidated: the weights
-// and the tile's own centre stay in L2.
+// neighbour that never arrives ends the launch with an error word -- never a hang), the other waves follow behind a workgroup
+// barrier, and every activation byte is then loaded `sc1` (past the CU's L1).  That is the guide's hand-off "one lane of each storing
+// workgroup signals with an sc1 flag store for all its stores / sc1 poll / sc1 stores / sc1 loads, one workgroup per CU" with its
+// four conditions met; the one difference is that the loads are LDS-DMA (global_load_lds_dwordx4 sc1) instead of loads to registers,
+// which the guide's table does not list -- the bit-exactness tests (tests/test_trunk_gpu.py, also under a second stream's load and
+// forty launches back to back) are what covers it.  No cache is ever invalidated: an acquire per layer and CU cost more than it
+// saved (the weights stay in L2).
 // Every workgroup must be resident at once: the host refuses images of more than #CUs tiles (the per-layer kernels take those).
 //
 // Measured (tools/bench_trunk.py, tools/trunk_timeline.py; 480 x 270, 21 layers): 0.58-0.65 ms against 0.84 for the first form and
@@ -177,8 +181,11 @@ __device__ __forceinline__ Trunk16Lane trunk16_lane_setup(const Trunk16Params& p
 }
 
 // Piece d (0 .. 4) of this wave's share of the 18 x 34 patch of k-step ks (channel groups 2 ks, 2 ks + 1; hi and lo') into the patch
-// buffer at LDS address pbuf.  WHICH: 0 every unit, 1 only the tile's own 16 x 32 centre, 2 only the one-pixel halo.
-template <int WHICH>
+// buffer at LDS address pbuf.  HALO_ONLY: only the one-pixel halo (the centre is in LDS already).  Every activation byte is loaded
+// `sc1` (agent scope: past this CU's L1) -- the halo because other CUs wrote it, the centre because this CU's L1 may still hold
+// the line from two layers ago, when the same buffer held the previous block's tensor (MI355X_MICROARCH.md: every load of handed-off
+// bytes must be such a load; the producer's `sc1` stores drop the line from L2 anyway, so nothing is lost).
+template <bool HALO_ONLY>
 __device__ __forceinline__ void trunk16_patch_piece(int d, const char* tensor, int groups, unsigned planeBytes, int ks, unsigned pbuf,
                                                     const Trunk16Lane& t, int wave)
 {
@@ -186,10 +193,8 @@ __device__ __forceinline__ void trunk16_patch_piece(int d, const char* tensor, i
     const int pg = piece / P16_SUBS, sub = piece - pg * P16_SUBS;            // pg = part * 2 + group
     const char* const plane = tensor + (size_t)((pg >> 1) * groups + 2 * ks + (pg & 1)) * planeBytes;
     const unsigned dst = pbuf + (unsigned)(pg * P16_PIX + sub * 64) * 16u;
-    // the centre is this workgroup's own output of the layer before: its L2 has it.  The halo was written by other CUs, possibly
-    // behind another L2: read coherently (no L2 invalidation anywhere in this kernel: the weights and the centres stay cached)
-    if (WHICH != 2 && (t.live & t.centre & (1u << d))) trunk16_dma16<false>(plane, t.poff[d], dst);
-    if (WHICH != 1 && (t.live & ~t.centre & (1u << d))) trunk16_dma16<true>(plane, t.poff[d], dst);
+    const unsigned take = HALO_ONLY ? (t.live & ~t.centre) : t.live;
+    if (take & (1u << d)) trunk16_dma16<true>(plane, t.poff[d], dst);
 }
 
 // Piece d (0 .. 4) of this wave's share of the weights of k-step ks (9 taps x [hi | lo] x 128 units: 36 wave-wide pieces).
@@ -318,7 +323,7 @@ __global__ __launch_bounds__(T16_THREADS) void trunk_dataflow_kernel(const Trunk
 #pragma unroll
     for (int d = 0; d < 5; ++d) {
         if (dmaW) trunk16_weight_piece(d, wq, p.groups0 >> 1, 0, wAddr, wave, lane);
-        if (dmaX) trunk16_patch_piece<0>(d, ws + p.xpsOff, p.groups0, planeBytes, 0, pAddr, lanes, wave);
+        if (dmaX) trunk16_patch_piece<false>(d, ws + p.xpsOff, p.groups0, planeBytes, 0, pAddr, lanes, wave);
     }
 
 #pragma unroll 1
@@ -358,7 +363,7 @@ __global__ __launch_bounds__(T16_THREADS) void trunk_dataflow_kernel(const Trunk
             lap(1);
             if (dmaX) {
 #pragma unroll
-                for (int d = 0; d < 5; ++d) trunk16_patch_piece<2>(d, tin, groups, planeBytes, 0, pAddr + (unsigned)(gk & 1) * (P16_UNITS * 16), lanes, wave);
+                for (int d = 0; d < 5; ++d) trunk16_patch_piece<true>(d, tin, groups, planeBytes, 0, pAddr + (unsigned)(gk & 1) * (P16_UNITS * 16), lanes, wave);
             }
         }
         f32x16 acc[2][2];
@@ -387,8 +392,8 @@ __global__ __launch_bounds__(T16_THREADS) void trunk_dataflow_kernel(const Trunk
                 if (more) {
                     if (tap < 5) {
                         // k-step 1 of a layer fed by this kernel: the centre is in LDS already (the epilogue put it there)
-                        if (dmaX && l > 0 && ks == 0) trunk16_patch_piece<2>(tap, tin, groups, planeBytes, 1, pnxt, lanes, wave);
-                        else if (dmaX) trunk16_patch_piece<0>(tap, tin, groups, planeBytes, ks + 1, pnxt, lanes, wave);
+                        if (dmaX && l > 0 && ks == 0) trunk16_patch_piece<true>(tap, tin, groups, planeBytes, 1, pnxt, lanes, wave);
+                        else if (dmaX) trunk16_patch_piece<false>(tap, tin, groups, planeBytes, ks + 1, pnxt, lanes, wave);
                         if (dmaW) trunk16_weight_piece(tap, wq, ksteps, ks + 1, wnxt, wave, lane);
                     }
                 } else if (!last) {
