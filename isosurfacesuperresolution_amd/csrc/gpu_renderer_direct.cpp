@@ -114,6 +114,20 @@ void freeVolume(Volume& v)
     v = Volume();
 }
 
+// A volume under construction and the upload's device temporaries: released on every early return (HIP_OK returns false from the
+// middle of an upload; a sparse or hostile .vbx that fails half way must not leak device memory on each loadGrid that reports -2).
+// handOver(): the volume is complete and finalizeVolume -- which frees it itself when it fails -- takes it from here.
+struct UploadGuard {
+    Volume& v;
+    void** tmp[4] = { nullptr, nullptr, nullptr, nullptr };
+    bool armed = true;
+    explicit UploadGuard(Volume& vol) : v(vol) {}
+    void watch(int i, void** q) { tmp[i] = q; }
+    void freeTemporaries() { for (void**& q : tmp) if (q && *q) { (void)hipFree(*q); *q = nullptr; } }
+    void handOver() { freeTemporaries(); armed = false; }
+    ~UploadGuard() { freeTemporaries(); if (armed) freeVolume(v); }
+};
+
 // ---- "a,b,c" parsing (GPURendererDirect.cpp:60-85); strict arity, no exceptions ------------
 bool splitNumbers(const char* s, int n, double* out)
 {
@@ -337,6 +351,8 @@ bool uploadFromDevice(const float* dense, int nx, int ny, int nz, const TileInfo
     uint8_t *dFlag9 = nullptr;
     int* dBBox = nullptr;
     unsigned int* dMax = nullptr;
+    UploadGuard guard(v);
+    guard.watch(0, (void**)&dFlag9); guard.watch(1, (void**)&dBBox); guard.watch(2, (void**)&dMax);
     HIP_OK(hipMalloc(&dFlag9, nb));
     HIP_OK(hipMalloc(&v.leaf, nb));
     HIP_OK(hipMalloc(&dBBox, 6 * sizeof(int)));
@@ -354,7 +370,7 @@ bool uploadFromDevice(const float* dense, int nx, int ny, int nz, const TileInfo
     HIP_OK(hipMemcpy(leaf.data(), v.leaf, nb, hipMemcpyDeviceToHost));
     HIP_OK(hipMemcpy(bbox, dBBox, sizeof(bbox), hipMemcpyDeviceToHost));
     HIP_OK(hipMemcpy(&maxbits, dMax, sizeof(maxbits), hipMemcpyDeviceToHost));
-    (void)hipFree(dFlag9); (void)hipFree(dBBox); (void)hipFree(dMax);
+    guard.freeTemporaries();
 
     // slot table (exclusive scan of flag9), leaf-level bbox, 128^3 node occupancy
     std::vector<int32_t> slot(nb);
@@ -380,10 +396,7 @@ bool uploadFromDevice(const float* dense, int nx, int ny, int nz, const TileInfo
                     if (z < lmin[2]) lmin[2] = z; if (z > lmax[2]) lmax[2] = z;
                 }
             }
-    if (nleaf == 0 && !tile) {   // the reference throws on empty grids (IsoVolumeRayTracer.h:188-190)
-        freeVolume(v);
-        return false;
-    }
+    if (nleaf == 0 && !tile) return false;   // the reference throws on empty grids (IsoVolumeRayTracer.h:188-190); the guard frees
     if (nleaf == 0) {            // an empty tile of a larger volume renders nothing
         for (int k = 0; k < 3; ++k) { lmin[k] = 0; lmax[k] = -1; }
     }
@@ -399,6 +412,7 @@ bool uploadFromDevice(const float* dense, int nx, int ny, int nz, const TileInfo
     iso_launch_leaf_range(dense, nx, ny, nz, v.nbx, v.nby, v.nbz, v.leafRange, nullptr);
     HIP_OK(hipGetLastError());
     HIP_OK(hipDeviceSynchronize());
+    guard.handOver();
     return finalizeVolume(v, bbox, orderBitsToFloat(maxbits), lmin, lmax, tile);
 }
 
@@ -519,6 +533,9 @@ bool uploadFromBricks(const VbxBricks& vb)
     }
     if (nleaf == 0) return false;
     v.nslots = nslots; v.nleaf = nleaf;
+    long long* dIndex = nullptr; int32_t* dSlot = nullptr; uint8_t* dLeaf = nullptr; float* dRange = nullptr;
+    UploadGuard guard(v);
+    guard.watch(0, (void**)&dIndex); guard.watch(1, (void**)&dSlot); guard.watch(2, (void**)&dLeaf); guard.watch(3, (void**)&dRange);
     HIP_OK(hipMalloc(&v.slot, nb * sizeof(int32_t)));
     HIP_OK(hipMalloc(&v.leaf, nb));
     HIP_OK(hipMalloc(&v.leafRange, nb * 2 * sizeof(float)));
@@ -530,7 +547,6 @@ bool uploadFromBricks(const VbxBricks& vb)
     HIP_OK(hipMemcpy(v.node1, node1.data(), node1.size(), hipMemcpyHostToDevice));
     if (nslots > 0) HIP_OK(hipMemcpy(v.bricks, bricks.data(), bricks.size() * sizeof(float), hipMemcpyHostToDevice));
     const int n = int(index.size());
-    long long* dIndex = nullptr; int32_t* dSlot = nullptr; uint8_t* dLeaf = nullptr; float* dRange = nullptr;
     HIP_OK(hipMalloc(&dIndex, size_t(n) * sizeof(long long)));
     HIP_OK(hipMalloc(&dSlot, size_t(n) * sizeof(int32_t)));
     HIP_OK(hipMalloc(&dLeaf, size_t(n)));
@@ -542,7 +558,7 @@ bool uploadFromBricks(const VbxBricks& vb)
     iso_launch_scatter_tables(n, dIndex, dSlot, dLeaf, dRange, v.slot, v.leaf, v.leafRange, nullptr);
     HIP_OK(hipGetLastError());
     HIP_OK(hipDeviceSynchronize());
-    (void)hipFree(dIndex); (void)hipFree(dSlot); (void)hipFree(dLeaf); (void)hipFree(dRange);
+    guard.handOver();
     return finalizeVolume(v, bbox, maxv, lmin, lmax, nullptr);
 }
 

@@ -126,6 +126,19 @@ bool read_bricks(const char* path, VbxBricks& out, std::string& err)
     }
     out.bd = bd;
     const size_t per = (size_t)bd * bd * bd;
+    // Every node is validated BEFORE any memory proportional to the node count is taken: atlas offsets inside the atlas, positions
+    // on the brick grid, and no more bricks than the atlas has room for (many nodes may name the same atlas brick: without the cap
+    // a small file could ask for thousands of times its size)
+    if (used > atlas_count / per) { err = "more bricks than the atlas holds"; return false; }
+    for (const VbxNode& nd : nodes) {
+        if (!nd.flags) continue;
+        const int64_t ax = nd.value[0], ay = nd.value[1], az = nd.value[2];
+        if (ax < 0 || ay < 0 || az < 0 || ax + bd > axisres[0] || ay + bd > axisres[1] || az + bd > axisres[2]) {
+            err = "brick outside atlas"; return false;
+        }
+        for (int a = 0; a < 3; ++a)
+            if (((int64_t)nd.pos[a] - mn[a]) % bd) { err = "brick off the brick grid"; return false; }
+    }
     out.pos.clear(); out.data.clear();
     out.pos.reserve(used * 3);
     out.data.resize(used * per);

@@ -581,7 +581,9 @@ TRAIN_BF16 = False
 # all weight gradients stay on the exact fp32 MFMA kernels.
 TRAIN_SPLIT = True
 # GATE_FUSION: a conv3x3 whose input is the output of a ReLU conv3x3 applies that ReLU's backward in the epilogue of its own
-# data gradient (one isrActBackward launch and a 3-tensor round trip less per such pair)
+# data gradient (one isrActBackward launch and a 3-tensor round trip less per such pair).  Parameter and input gradients are
+# bit-identical either way; the gradient of the INTERMEDIATE activation is then the post-gate value -- a tensor hook or
+# retain_grad() on it switches the fusion off for that pair (tests/test_train_kernels_gpu.py), torch.autograd.grad on it does not.
 GATE_FUSION = True
 TRAIN_SPLIT_MIN_TILES = 256
 TRAIN_SPLIT_MIN_TILES2 = 128      # small images: 2-row tiles (the library picks that form below 256 tiles of 8x32 pixels)
@@ -916,7 +918,9 @@ class _Conv3x3Function(torch.autograd.Function):
         gx = gw = gb = gres = None
         if ctx.needs_input_grad[0]:
             # data gradient = the same fused kernel on flipped / transposed weights
-            if ctx.x_relu and GATE_FUSION:
+            # (a hook or retain_grad() on x wants dL/dx itself, not dL/dx already multiplied by (x > 0): no fusion then.  What
+            # cannot be seen from here -- torch.autograd.grad(loss, x) on the intermediate activation -- gets the gated value)
+            if ctx.x_relu and GATE_FUSION and not _has_grad_hooks(x) and not x.retains_grad:
                 gx = _train_conv(gz, weight, True, None, x, 'gate')
                 gx._isr_gated_by = (x.data_ptr(), x._version, gx._version)   # read by the backward of the layer that produced x
             else:

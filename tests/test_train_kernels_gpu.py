@@ -528,6 +528,45 @@ def test_relu_backward_folded_into_the_consumers_data_gradient():
         ops.GATE_FUSION = old
 
 
+def test_gate_fusion_steps_aside_when_the_intermediate_gradient_is_observed():
+    """A tensor hook or retain_grad() on the ReLU output between two fused convolutions must see dL/dy itself -- the gradient of
+    the unfused graph -- not dL/dy already multiplied by (y > 0): the fusion is skipped for that pair, every other gradient stays
+    bit-identical."""
+    from isosurfacesuperresolution_amd import ops
+    g = torch.Generator().manual_seed(78)
+    x0 = (torch.rand(1, 64, 32, 64, generator=g) - 0.5).cuda()
+    ws = [((torch.rand(64, 64, 3, 3, generator=g) - 0.5) * 0.1).cuda() for _ in range(2)]
+    tgt = torch.rand(1, 64, 32, 64, generator=g).cuda()
+
+    def run(fuse, how):
+        ops.GATE_FUSION = fuse
+        x = x0.clone().requires_grad_(True)
+        w = [t.clone().requires_grad_(True) for t in ws]
+        y1 = ops.conv3x3(x, w[0], None, act='relu')
+        seen = {}
+        if how == "hook":
+            y1.register_hook(lambda gr: seen.setdefault("g", gr.clone()))
+        elif how == "retain":
+            y1.retain_grad()
+        y2 = ops.conv3x3(y1, w[1], None)
+        ((y2 - tgt) ** 2).mean().backward()
+        if how == "retain":
+            seen["g"] = y1.grad.clone()
+        return seen.get("g"), [x.grad] + [t.grad for t in w], y1.detach()
+
+    old = ops.GATE_FUSION
+    try:
+        for how in ("hook", "retain"):
+            gref, ref, y1 = run(False, how)
+            gfus, got, _ = run(True, how)
+            assert torch.equal(gref, gfus), how
+            assert (gref[y1 <= 0] != 0).any(), "the true gradient is non-zero where the ReLU is closed: the comparison means something"
+            for a, c in zip(ref, got):
+                assert torch.equal(a, c), how
+    finally:
+        ops.GATE_FUSION = old
+
+
 @pytest.mark.parametrize("shape", [(2, 6, 101, 5, 32, 32), (1, 6, 5, 5, 9, 7), (3, 6, 8, 6, 5, 12), (1, 4, 7, 2, 1, 1)])
 def test_residual_reconstruction_kernel_matches_interpolate_add_cat(shape):
     """isrReconResidualForward / Backward against the reference's slice + F.interpolate(x4, bilinear) + add + cat
