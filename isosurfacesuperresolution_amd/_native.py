@@ -13,7 +13,8 @@ _PKG = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_PKG, "csrc")
 LIBDIR = os.path.join(_PKG, "lib")
 RENDERER_LIB = os.path.join(LIBDIR, "libGPURendererDirect.so")
-SR_LIB = os.path.join(LIBDIR, "libisr_sr.so")
+# ISR_SR_LIB: another build of the same library (A/B measurements of kernel changes on one box: tools/ab_bench.sh)
+SR_LIB = os.environ.get("ISR_SR_LIB") or os.path.join(LIBDIR, "libisr_sr.so")
 
 _cache = {}
 
