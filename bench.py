@@ -224,6 +224,7 @@ def run_infer(args, job):
     sync()
     elapsed = time.perf_counter() - t0
     records = ops.profile_records()
+    ops.trunk_check()                     # no dataflow launch of the timed region gave up on a neighbour (the error word is sticky)
     switches = ops.debug_switches()
     # an ablation (MFMAs skipped, stores skipped, stamp buffers) must never be behind a reported number; a forced kernel form
     # (ISR_SPLIT_ALGO, an experiment switch) is allowed and shows up in the line

@@ -253,8 +253,9 @@ int isrConv3x3ForwardSplitFromPacked(const void* xps, const void* wq, const floa
  * kernels).  Between the layers the activations live in the workspace in the packed-split format, the residual stream in registers.
  *   x: planes xPlane floats apart (rows contiguous); y (the result F): [64][H][W], planes `plane` floats apart;
  *   wq[l]: isrConvSplitPrepare images, bias[l]: [64] device or NULL, l = 0 .. 2 nblocks;
- *   workspace: isrTrunkDataflowWorkspaceBytes(cin0, H, W) bytes of device memory, 256-byte aligned.  Bytes 16 .. hold the tiles'
- *   progress counters and then an error word: 1 + layer if a tile's wait timed out after 50 ms (0 after a good launch).
+ *   workspace: isrTrunkDataflowWorkspaceBytes(cin0, H, W) bytes of device memory, 256-byte aligned, ZERO-FILLED by the caller before
+ *   its first use.  Bytes 16 .. hold the tiles' progress counters and then an error word: 1 + layer if a tile's wait timed out after
+ *   50 ms in ANY launch since the caller last reset it (the launches never clear it).
  * 0 ok, -1 bad arguments, -2 launch failure, -3 unsupported shape / alignment / too many tiles. */
 int isrTrunkDataflowMaxTiles(void);
 long long isrTrunkDataflowWorkspaceBytes(int cin0, int H, int W);

@@ -553,7 +553,9 @@ int isrTrunkDataflow(const float* x, int cin0, long long xPlane, float* y, long 
     p.dbg = g_trunk_dbg; p.stamps = g_trunk_stamps;
     p.timeoutTicks = 5000000ull;                                             // 50 ms: a frame is 2 ms
     hipStream_t s = (hipStream_t)stream;
-    if (hipMemsetAsync(workspace, 0, 16 + (size_t)(ntiles + 1) * sizeof(unsigned), s) != hipSuccess) return -2;
+    // the progress counters start at zero every launch; the error word behind them is STICKY (the caller zero-fills the workspace
+    // once, reads the word when it likes and resets it then): an error of any launch since the last look stays visible
+    if (hipMemsetAsync(workspace, 0, 16 + (size_t)ntiles * sizeof(unsigned), s) != hipSuccess) return -2;
     static bool attr = false;
     if (!attr) { (void)hipFuncSetAttribute((const void*)trunk_dataflow_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, T16_LDS_BYTES); attr = true; }
     const int npix = H * W;

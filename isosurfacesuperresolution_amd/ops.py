@@ -812,7 +812,9 @@ def trunk_check():
         tiles = ((key[2] + 15) // 16) * ((key[3] + 31) // 32)
         err = int(ws[4 + tiles].item())
         if err:
-            raise RuntimeError("trunk_dataflow_kernel: a tile timed out waiting for its neighbours at layer %d" % (err - 1))
+            ws[4 + tiles] = 0          # sticky on the device: an error of ANY launch since the last look is still there
+            raise RuntimeError("trunk_dataflow_kernel: a tile timed out waiting for its neighbours at layer %d in a launch since the last "
+                               "check (its output is incomplete)" % (err - 1))
 
 
 # Inference: the whole block in ONE launch (csrc/sr_conv_block.hip) -- bit-identical to the two split-operand launches

@@ -118,3 +118,25 @@ def test_dataflow_trunk_with_other_depths_and_input_widths(cin, nblocks, h, w):
             torch.cuda.synchronize()
             ops.trunk_check()
             assert torch.equal(f, ref), (trial, (f - ref).abs().max().item())
+
+
+def test_error_word_of_the_dataflow_trunk_is_sticky():
+    """A tile that gives up on a neighbour leaves 1 + layer in the workspace's error word; later launches must not clear it (the
+    host looks only now and then: ops.trunk_check, bench.py after its timed region), the check that reports it does."""
+    from isosurfacesuperresolution_amd import ops
+    g = torch.Generator().manual_seed(9)
+    convs = [(((torch.rand(64, 16 if k == 0 else 64, 3, 3, generator=g) - 0.5) * 0.1).cuda(), None) for k in range(3)]
+    x = torch.rand(1, 16, 40, 70, generator=g).cuda()
+    with torch.no_grad():
+        ops.trunk_dataflow(x, convs)
+        torch.cuda.synchronize()
+        ops.trunk_check()
+        (key, ws), = [(k, w) for k, w in ops._trunk_ws.items() if k[1:4] == (16, 40, 70)]
+        tiles = ((40 + 15) // 16) * ((70 + 31) // 32)
+        ws[4 + tiles] = 7                      # as if layer 6 had timed out in some earlier launch
+        ops.trunk_dataflow(x, convs)
+        ops.trunk_dataflow(x, convs)
+        torch.cuda.synchronize()
+        with pytest.raises(RuntimeError, match="layer 6"):
+            ops.trunk_check()
+        ops.trunk_check()                      # reported once, then reset
