@@ -16,7 +16,8 @@
 //     from inline assembly): activations travel between layers in the PACKED-SPLIT format (sr_split_common.h: already split into
 //     fp16 pairs, 8 channels of a pixel per 16-byte unit; every plane ends in a zero unit that padding pixels read), so staging is
 //     a copy -- no registers, no conversion.  While k-step s multiplies, k-step s + 1's patch and weights land in the other
-//     buffers, one or two requests after each tap's MFMAs: ONE barrier per k-step;
+//     buffers, one request after each tap's MFMAs, waves 0..3 fetching weights and waves 4..7 the patch (Trunk16Lane): ONE barrier
+//     per k-step;
 //   * the epilogue works straight from the MFMA result layout (no transposition through LDS).  Channels 0 .. 31 of the tile -- the
 //     next layer's first two k-steps -- are written INTO the two patch buffers (the centre never leaves the CU) and to memory only
 //     on the tile's outermost ring (what the neighbours read); channels 32 .. 63 go to memory (8 bytes per lane, a wave instruction
@@ -154,58 +155,43 @@ __device__ __forceinline__ void trunk16_kstep(f32x16 (&acc)[2][2], const u32x4* 
     }
 }
 
-// Where this lane's unit of DMA piece d of a patch buffer comes from.  The 40 wave-wide pieces of a k-step (2 parts x 2 channel
-// groups x 10 runs of 64 patch pixels) go 5 to a wave: piece wave + 8 d.  Its patch pixel is the same for every k-step of every
-// layer: computed once per launch, 5 registers + 2 of flags.  Every plane of a packed-split tensor ends in one zero unit (unit H W):
-// that is where padding pixels read, so the lane offset needs no select.
+// DMA ROLES.  The 76 wave-wide requests of a k-step (40 patch pieces: 2 parts x 2 channel groups x 10 runs of 64 patch pixels; 36
+// weight pieces: 2 parts x 9 taps x 2 halves) are dealt by kind: waves 0..3 fetch weights -- wave w the nine taps of (part w / 2,
+// half w % 2): one source pointer and one LDS address that advance by a constant per tap -- and waves 4..7 fetch the patch -- wave
+// 4 + q the ten runs of (part q / 2, group q % 2): one plane pointer per k-step and this table of ten lane offsets, the same for
+// every k-step of every layer.  A SIMD holds waves w and w + 4, i.e. one of each kind.  (The first form dealt both kinds to every
+// wave: twice the scalar bookkeeping per request and ~250 scalar registers spilled.)
 struct Trunk16Lane {
-    unsigned poff[5];                // byte offset of the pixel's unit inside a plane (padding: the plane's zero unit)
-    unsigned live, centre;           // bit d: the lane takes part in piece d / its pixel belongs to the tile's own 16 x 32 centre
+    unsigned poff[P16_SUBS];         // byte offset of the pixel's unit inside a plane (padding: the plane's zero unit), per run
+    unsigned live, centre;           // bit s: the lane takes part in run s / its pixel belongs to the tile's own 16 x 32 centre
 };
 
-__device__ __forceinline__ Trunk16Lane trunk16_lane_setup(const Trunk16Params& p, int oy0, int ox0, int wave, int lane)
+__device__ __forceinline__ Trunk16Lane trunk16_lane_setup(const Trunk16Params& p, int oy0, int ox0, int lane)
 {
     Trunk16Lane t;
     t.live = 0u; t.centre = 0u;
 #pragma unroll
-    for (int d = 0; d < 5; ++d) {
-        const int piece = wave + T16_WAVES * d;
-        const int sub = piece % P16_SUBS, off = sub * 64 + lane;
+    for (int sub = 0; sub < P16_SUBS; ++sub) {
+        const int off = sub * 64 + lane;
         const int r = off / P16_W, c = off - r * P16_W;
         const int iy = oy0 + r - 1, ix = ox0 + c - 1;
-        t.poff[d] = (unsigned)(((unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W) ? iy * p.W + ix : p.H * p.W) * 16u;
-        if (off < P16_PIX) t.live |= 1u << d;
-        if (r >= 1 && r <= T16_H && c >= 1 && c <= T16_W) t.centre |= 1u << d;
+        t.poff[sub] = (unsigned)(((unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W) ? iy * p.W + ix : p.H * p.W) * 16u;
+        if (off < P16_PIX) t.live |= 1u << sub;
+        if (r >= 1 && r <= T16_H && c >= 1 && c <= T16_W) t.centre |= 1u << sub;
     }
     return t;
 }
 
-// Piece d (0 .. 4) of this wave's share of the 18 x 34 patch of k-step ks (channel groups 2 ks, 2 ks + 1; hi and lo') into the patch
-// buffer at LDS address pbuf.  HALO_ONLY: only the one-pixel halo (the centre is in LDS already).  Every activation byte is loaded
-// `sc1` (agent scope: past this CU's L1) -- the halo because other CUs wrote it, the centre because this CU's L1 may still hold
-// the line from two layers ago, when the same buffer held the previous block's tensor (MI355X_MICROARCH.md: every load of handed-off
-// bytes must be such a load; the producer's `sc1` stores drop the line from L2 anyway, so nothing is lost).
+// Run `sub` (0 .. 9) of the patch wave's (part, group) of k-step ks into the patch buffer at LDS address pbuf.  HALO_ONLY: only the
+// one-pixel halo (the centre is in LDS already).  Every activation byte is loaded `sc1` (agent scope: past this CU's L1) -- the
+// halo because other CUs wrote it, the centre because this CU's L1 may still hold the line from two layers ago, when the same
+// buffer held the previous block's tensor (MI355X_MICROARCH.md: every load of handed-off bytes must be such a load; the
+// producer's `sc1` stores drop the line from L2 anyway, so nothing is lost).
 template <bool HALO_ONLY>
-__device__ __forceinline__ void trunk16_patch_piece(int d, const char* tensor, int groups, unsigned planeBytes, int ks, unsigned pbuf,
-                                                    const Trunk16Lane& t, int wave)
+__device__ __forceinline__ void trunk16_patch_run(int sub, const char* plane, unsigned pbufRole, const Trunk16Lane& t)
 {
-    const int piece = wave + T16_WAVES * d;                                  // 0 .. 39
-    const int pg = piece / P16_SUBS, sub = piece - pg * P16_SUBS;            // pg = part * 2 + group
-    const char* const plane = tensor + (size_t)((pg >> 1) * groups + 2 * ks + (pg & 1)) * planeBytes;
-    const unsigned dst = pbuf + (unsigned)(pg * P16_PIX + sub * 64) * 16u;
     const unsigned take = HALO_ONLY ? (t.live & ~t.centre) : t.live;
-    if (take & (1u << d)) trunk16_dma16<true>(plane, t.poff[d], dst);
-}
-
-// Piece d (0 .. 4) of this wave's share of the weights of k-step ks (9 taps x [hi | lo] x 128 units: 36 wave-wide pieces).
-__device__ __forceinline__ void trunk16_weight_piece(int d, const u32x4* wq, int ksteps, int ks, unsigned wbuf, int wave, int lane)
-{
-    const int piece = wave + T16_WAVES * d;                                  // 0 .. 35 live
-    if (piece < 36) {
-        const int part = piece / 18, rem = piece - part * 18, tap = rem >> 1, half = rem & 1;
-        trunk16_dma16(wq + 1 + (size_t)(tap * ksteps + ks) * 256 + part * 128 + half * 64, (unsigned)lane * 16u,
-                      wbuf + (unsigned)(part * S_WPART + tap * 128 + half * 64) * 16u);
-    }
+    if (take & (1u << sub)) trunk16_dma16<true>(plane, t.poff[sub], pbufRole + (unsigned)sub * 1024u);
 }
 
 // The epilogue of one layer, straight from the D layout: lane (j, h) holds pixel j, channels 32 cb + 8 gi + 4 h + e.
@@ -295,7 +281,7 @@ __global__ __launch_bounds__(T16_THREADS) void trunk_dataflow_kernel(const Trunk
     const int tx = tile % p.tilesX, ty = tile / p.tilesX;
     const int oy0 = ty * T16_H, ox0 = tx * T16_W;
     const unsigned long long deadline = __builtin_amdgcn_s_memrealtime() + p.timeoutTicks;
-    const Trunk16Lane lanes = trunk16_lane_setup(p, oy0, ox0, wave, lane);
+    const Trunk16Lane lanes = trunk16_lane_setup(p, oy0, ox0, lane);
 
     f32x16 F[2][2];                                                          // the residual stream of this lane's 2 rows x 64 channels
 #pragma unroll
@@ -318,12 +304,30 @@ __global__ __launch_bounds__(T16_THREADS) void trunk_dataflow_kernel(const Trunk
         if (b) trunk16_dma4(b, (unsigned)lane * 4u, bAddr + (unsigned)(l & 1) * 256u);
         else biasl0[(l & 1) * 64 + lane] = 0.0f;
     };
+    // this wave's role (see Trunk16Lane): weights (waves 0..3: part, half) or patch (waves 4..7: part, group)
+    const bool wrole = wave < 4;
+    const int rpart = (wave & 3) >> 1, rsel = wave & 1;
+    const unsigned wdstRole = (unsigned)(rpart * S_WPART + rsel * 64) * 16u;             // + the weight buffer + tap * 2048
+    const unsigned pdstRole = (unsigned)((rpart * 2 + rsel) * P16_PIX) * 16u;            // + the patch buffer + run * 1024
+    const unsigned wlane = (unsigned)lane * 16u;
+    // tap `tap` of this wave's (part, half) of k-step ks of a weight image, into the weight buffer at LDS address wbuf
+    auto weight_tap = [&](int tap, const u32x4* image, int ksteps_, int ks, unsigned wbuf) {
+        trunk16_dma16(image + 1 + (size_t)(tap * ksteps_ + ks) * 256 + rpart * 128 + rsel * 64, wlane, wbuf + wdstRole + (unsigned)tap * 2048u);
+    };
+    auto patch_plane = [&](const char* tensor, int groups_, int ks) {
+        return tensor + (size_t)(rpart * groups_ + 2 * ks + rsel) * planeBytes;
+    };
     // the first layer's first k-step: nothing to wait for
     stage_bias(0);
+    if (wrole) {
+        if (dmaW) {
 #pragma unroll
-    for (int d = 0; d < 5; ++d) {
-        if (dmaW) trunk16_weight_piece(d, wq, p.groups0 >> 1, 0, wAddr, wave, lane);
-        if (dmaX) trunk16_patch_piece<false>(d, ws + p.xpsOff, p.groups0, planeBytes, 0, pAddr, lanes, wave);
+            for (int tap = 0; tap < 9; ++tap) weight_tap(tap, wq, p.groups0 >> 1, 0, wAddr);
+        }
+    } else if (dmaX) {
+        const char* const plane = patch_plane(ws + p.xpsOff, p.groups0, 0);
+#pragma unroll
+        for (int sub = 0; sub < P16_SUBS; ++sub) trunk16_patch_run<false>(sub, plane, pAddr + pdstRole, lanes);
     }
 
 #pragma unroll 1
@@ -361,9 +365,10 @@ __global__ __launch_bounds__(T16_THREADS) void trunk_dataflow_kernel(const Trunk
                 }
             }
             lap(1);
-            if (dmaX) {
+            if (dmaX && !wrole) {
+                const char* const plane = patch_plane(tin, groups, 0);
 #pragma unroll
-                for (int d = 0; d < 5; ++d) trunk16_patch_piece<true>(d, tin, groups, planeBytes, 0, pAddr + (unsigned)(gk & 1) * (P16_UNITS * 16), lanes, wave);
+                for (int sub = 0; sub < P16_SUBS; ++sub) trunk16_patch_run<true>(sub, plane, pAddr + (unsigned)(gk & 1) * (P16_UNITS * 16) + pdstRole, lanes);
             }
         }
         f32x16 acc[2][2];
@@ -386,19 +391,26 @@ __global__ __launch_bounds__(T16_THREADS) void trunk_dataflow_kernel(const Trunk
             const u32x4* const wcur = wbuf0 + cur * S_WUNITS;
             const unsigned pnxt = pAddr + (unsigned)nxt * (P16_UNITS * 16), wnxt = wAddr + (unsigned)nxt * (S_WUNITS * 16);
             const bool more = ks + 1 < ksteps;
-            // the next k-step's patch and weights (or, under the layer's last k-step, the next layer's first weights and its bias):
-            // one or two requests after each of the first taps' MFMAs
+            // the next k-step's weights (weight waves: one tap's piece after each tap's MFMAs) and patch (patch waves: one run after
+            // each tap, two after the last) -- or, under the layer's last k-step, the next layer's first weights and its bias
+            const u32x4* const wimg = more ? wq : wqNext;
+            const int wks = more ? ks + 1 : 0, wksteps = more ? ksteps : 4;
+            const bool wany = dmaW && (more || !last), pany = dmaX && more;
+            const bool haloOnly = l > 0 && ks == 0;                          // k-step 1 of a layer fed by this kernel: its centre is in LDS
+            const char* const pplane = patch_plane(tin, groups, ks + 1);
             auto between = [&](int tap) {
-                if (more) {
-                    if (tap < 5) {
-                        // k-step 1 of a layer fed by this kernel: the centre is in LDS already (the epilogue put it there)
-                        if (dmaX && l > 0 && ks == 0) trunk16_patch_piece<true>(tap, tin, groups, planeBytes, 1, pnxt, lanes, wave);
-                        else if (dmaX) trunk16_patch_piece<false>(tap, tin, groups, planeBytes, ks + 1, pnxt, lanes, wave);
-                        if (dmaW) trunk16_weight_piece(tap, wq, ksteps, ks + 1, wnxt, wave, lane);
-                    }
-                } else if (!last) {
-                    if (tap < 5) { if (dmaW) trunk16_weight_piece(tap, wqNext, 4, 0, wnxt, wave, lane); }
-                    else if (tap == 5) stage_bias(l + 1);
+                if (wrole) {
+                    if (wany) weight_tap(tap, wimg, wksteps, wks, wnxt);
+                } else {
+                    if (pany) {
+                        if (haloOnly) {
+                            trunk16_patch_run<true>(tap, pplane, pnxt + pdstRole, lanes);
+                            if (tap == 8) trunk16_patch_run<true>(9, pplane, pnxt + pdstRole, lanes);
+                        } else {
+                            trunk16_patch_run<false>(tap, pplane, pnxt + pdstRole, lanes);
+                            if (tap == 8) trunk16_patch_run<false>(9, pplane, pnxt + pdstRole, lanes);
+                        }
+                    } else if (!more && !last && tap == 0) stage_bias(l + 1);
                 }
             };
             if (p.dbg & 32) {                                                // diagnostics: the k-step's 108 MFMAs on operands read once
