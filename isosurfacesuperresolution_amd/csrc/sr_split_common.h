@@ -160,7 +160,7 @@ __device__ __forceinline__ void split_epilogue_ps(const SplitConvParams& p, f32x
 
 // WIDE_ONLY: the caller guarantees W and both plane strides are multiples of 4 (the per-element path is not compiled in).
 // AUX: cache policy of the output stores (0 plain; 16 = sc1, write-through to memory: the dataflow kernels' hand-off, see
-// sr_conv_chain.hip).
+// sr_conv_trunk.hip).
 template <bool WIDE_ONLY = false, int AUX = 0>
 __device__ __forceinline__ void split_epilogue(const SplitConvParams& p, f32x16 (&acc)[2][2], u32x4* patch, int n, int oy0, int ox0, int co0,
                                                bool second, int lane, int wave, int j, int h)

@@ -15,3 +15,8 @@ for r in rows[:22]:
     print("%-100s calls %6s  avg %8.1f us  %5.1f%%" % (r['Name'][:100], r['Calls'], float(r['AverageNs']) / 1e3, float(r['Percentage'])))
 PY
 find $OUT -name "*kernel_trace.csv" -size +8M -delete
+# one PMC pass per counter over the same command (MI355X_MICROARCH.md: separate --pmc runs, no other trace domains)
+rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/fetch -o run -- python3 bench.py --mode train --steps 3 --warmup 1 --no-cpu-baseline > $OUT/fetch.log 2>&1
+rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/write -o run -- python3 bench.py --mode train --steps 3 --warmup 1 --no-cpu-baseline > $OUT/write.log 2>&1
+find $OUT -name "*kernel_trace.csv" -size +8M -delete
+du -sh $OUT
