@@ -118,10 +118,10 @@ __global__ __launch_bounds__(S_THREADS, 2) void conv3x3_split_kernel(const Split
             constexpr int LR_CS = 113;                                       // channel stride (108 used): ds_read_b32 banks = dword mod 32, a half-wave = 8 four-channel groups x 4 quads -> 4 * 113 = 4 (mod 32) apart
             float* tmp = reinterpret_cast<float*>(wbuf);                     // [32][113] fp32 = 14.5 KB of the 36.9 KB weight buffer
             const int ly0 = oy0 / 2 - 1, lx0 = ox0 / 2 - 1;
-            for (int u0 = tid; u0 < LUNITS; u0 += 5 * S_THREADS) {
-                u32x4 v[5];
+            for (int u0 = tid; u0 < LUNITS; u0 += 3 * S_THREADS) {
+                u32x4 v[3];
 #pragma unroll
-                for (int k = 0; k < 5; ++k) {
+                for (int k = 0; k < 3; ++k) {
                     const int u = u0 + k * S_THREADS;
                     const int c = u / (LR_H * LQ), rem = u - c * (LR_H * LQ);
                     const int r = rem / LQ, q = rem - r * LQ;
@@ -131,7 +131,7 @@ __global__ __launch_bounds__(S_THREADS, 2) void conv3x3_split_kernel(const Split
                                                                                : BAD_OFFSET), 0, 0);
                 }
 #pragma unroll
-                for (int k = 0; k < 5; ++k) {
+                for (int k = 0; k < 3; ++k) {
                     const int u = u0 + k * S_THREADS;
                     if (u >= LUNITS) continue;
                     const int c = u / (LR_H * LQ), rem = u - c * (LR_H * LQ);
@@ -321,6 +321,7 @@ __global__ __launch_bounds__(S_THREADS, 2) void conv3x3_split_kernel(const Split
                                 acc[1][r] = mfma16(a1h, bh, acc[1][r]);
                             }
                         }
+                        if (UPS) __builtin_amdgcn_sched_barrier(0);
                     }
                 }
                 __syncthreads();                                             // weight buffer (and, after the last k-step, the patch) free

@@ -61,9 +61,14 @@ class SuperResolutionPipeline:
         # SIMD, so that it sits beside the conv waves instead of displacing them (csrc/iso_kernels.hip)
         self.side_waves = 4 * torch.cuda.get_device_properties(device).multi_processor_count if self._render_stream else 0
         # kernel variant of the render that runs under the network.  None = the foreground variant: since the flat traversal
-        # (0.21 ms alone) the plain kernel beside the network gives 400 frames/s; the capped 128-register kernel (2), which
-        # round 1's 0.45 ms nested-loop kernel needed, gives 384 (tools/side_sweep.sh)
-        self.side_variant = None
+        # (0.21 ms alone) the plain kernel beside the network gave 400 frames/s in round 2; the capped 128-register kernel (2), which
+        # round 1's 0.45 ms nested-loop kernel needed, gave 384 (tools/side_sweep.sh)
+        # (round 3) 5 = the flat traversal with one sample per iteration: 124 registers.  A SIMD has 512; beside two upsampling waves of
+        # 184 each it FITS, where the 168-register default variant takes the place of one of them -- and with it of a whole workgroup of
+        # the CU: 533-535 against 524 frames/s (ISR_SIDE_VARIANT=0 restores the foreground variant)
+        self.side_variant = int(os.environ.get("ISR_SIDE_VARIANT", "5"))
+        if self.side_variant == 0:
+            self.side_variant = None
         self.prefetch_after_trunk = os.environ.get("ISR_PREFETCH_AFTER_TRUNK", "1") != "0"     # measured: 516-519 against 497-505 frames/s with the render beside the trunk
         # where in the network the next frame's render is released (experiment switch): trunk | ups1 | ups2 | tail = when the trunk,
         # the first / second upsampling layer, or everything but the last launch has ended
