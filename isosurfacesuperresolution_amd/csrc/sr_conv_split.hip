@@ -27,6 +27,8 @@
 // shift = +16 bytes); the weights [hi|lo][tap][lane half][cout][8 x fp16] of one 16-channel k-step pass through LDS,
 // fetched from L2 into registers under the previous k-step's MFMAs; 80 KB of LDS -> two workgroups per CU, one's
 // staging and barriers under the other's MFMAs.  Per tap and k-step: 8 ds_read_b128 feed 12 MFMAs.
+#include <cstdlib>
+
 #include "sr_split_common.h"
 
 namespace {
@@ -1097,6 +1099,8 @@ __global__ __launch_bounds__(256) void prepare_weights_split_many_kernel(const P
 
 } // namespace
 
+#include "sr_conv_ups3.h"       // the three-workgroups-per-CU upsampling kernel: same translation unit, same parameter block
+
 __device__ u32x4 g_split_zero_unit[4];      // zero initialised: source of the zero-padding units of the LDS-DMA staging
 static unsigned* g_range_flag = nullptr;
 unsigned* isr_take_range_flag() { unsigned* f = g_range_flag; g_range_flag = nullptr; return f; }
@@ -1106,6 +1110,8 @@ static unsigned long long* g_split_stamps = nullptr;
 static int g_split_dbg = 0;
 static int g_split_small = 1;     // 2-row-tile kernel for small images (isrDebugSetSplitSmall)
 static int g_split_slots = 0;     // tests: cap on the persistent kernels' grid (0 = two / one workgroup per CU)
+// upsampling layers: 3 = sr_conv_ups3.h (three workgroups per CU; default), 0 = the tile kernel (two); ISR_UPS_FORM overrides
+static int g_split_ups_form = getenv("ISR_UPS_FORM") ? atoi(getenv("ISR_UPS_FORM")) : 3;
 static int g_split_algo = 1;      // plain layers: 1 persistent streaming kernel (default), 2 wide 512-thread kernel, 0 one workgroup per tile
 
 extern "C" {
@@ -1116,11 +1122,13 @@ void isrSetRangeFlag(unsigned* flag) { g_range_flag = flag; }
 // form off, 16 stamp buffer
 int isrDebugSplitState(void)
 {
-    return (g_split_dbg ? 1 : 0) | (g_split_algo != 1 ? 2 : 0) | (g_split_slots ? 4 : 0) | (g_split_small != 1 ? 8 : 0) | (g_split_stamps ? 16 : 0);
+    return (g_split_dbg ? 1 : 0) | (g_split_algo != 1 ? 2 : 0) | (g_split_slots ? 4 : 0) | (g_split_small != 1 ? 8 : 0) | (g_split_stamps ? 16 : 0) | (g_split_ups_form != 3 ? 2 : 0);
 }
 void isrDebugSetSplitStampBuffer(unsigned long long* buf) { g_split_stamps = buf; }   // not part of the public header
 void isrDebugSetSplitAblation(int bits) { g_split_dbg = bits; }
 void isrDebugSetSplitAlgo(int a) { g_split_algo = a; }
+void isrDebugSetSplitUpsForm(int f) { g_split_ups_form = f; }       // not part of the public header
+int isrDebugSplitUpsForm(void) { return g_split_ups_form; }
 void isrDebugSetSplitSlots(int n) { g_split_slots = n; }
 void isrDebugSetSplitSmall(int on) { g_split_small = on; }
 
@@ -1251,7 +1259,12 @@ int isrConv3x3ForwardSplit(const float* x, const void* wq, const float* bias, co
         return hipGetLastError() == hipSuccess ? 0 : -2;
     }
     // algorithmic flops of the convolution (2 * 9 * Cin * Cout per output pixel), not the 3x matrix flops spent on it
-    isr_profile_record(upsample2x ? ISR_VARIANT_SPLIT_UPS : ISR_VARIANT_SPLIT, 2.0 * 9 * Cin * Cout * (double)N * H * W, &e0, &e1);
+    const bool ups3 = upsample2x && g_split_ups_form == 3 && Cin > 0 && !(Cin & 15) && p.coutPad == 64 && Cout == 64 && p.cgroups == 1 && !p.xps;
+    isr_profile_record(ups3 ? ISR_VARIANT_SPLIT_UPS3 : upsample2x ? ISR_VARIANT_SPLIT_UPS : ISR_VARIANT_SPLIT, 2.0 * 9 * Cin * Cout * (double)N * H * W, &e0, &e1);
+    if (ups3) {
+        const int rc = isr_launch_split_ups3(p, (unsigned)nwg, s, e0, e1);
+        if (rc != -1) return rc;
+    }
     if (upsample2x) {
         if (e0 || e1) hipExtLaunchKernelGGL((conv3x3_split_kernel<true>), grid, block, S_LDS_BYTES, s, e0, e1, 0, p);
         else hipLaunchKernelGGL((conv3x3_split_kernel<true>), grid, block, S_LDS_BYTES, s, p);

@@ -1,0 +1,55 @@
+"""The three-workgroups-per-CU upsampling kernel (csrc/sr_conv_ups3.h) against the tile kernel (conv3x3_split_kernel<true>) -- the
+same interpolation and products in the same order: EQUAL bit for bit -- and against torch
+(SuperresolutionNetwork/models/enhancenet.py:113-124)."""
+import ctypes
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+
+def _forms(fn):
+    from isosurfacesuperresolution_amd import ops
+    lib = ops._sr()
+    lib.isrDebugSetSplitUpsForm.argtypes = [ctypes.c_int]
+    lib.isrDebugSplitUpsForm.restype = ctypes.c_int
+    default = lib.isrDebugSplitUpsForm()
+    try:
+        lib.isrDebugSetSplitUpsForm(0)
+        tile = fn()
+        lib.isrDebugSetSplitUpsForm(3)
+        three = fn()
+    finally:
+        lib.isrDebugSetSplitUpsForm(default)
+    torch.cuda.synchronize()
+    return tile, three
+
+
+@pytest.mark.parametrize("h,w,cin", [(4, 16, 64), (5, 18, 64), (17, 34, 64), (135, 240, 64), (270, 480, 64), (30, 50, 32), (9, 10, 16)])
+def test_three_per_cu_upsampling_kernel_is_bit_identical_to_the_tile_kernel(h, w, cin):
+    from isosurfacesuperresolution_amd import ops
+    g = torch.Generator().manual_seed(h * 1000 + w)
+    x = ((torch.rand(1, cin, h, w, generator=g) - 0.4) * 3).cuda()
+    wt = ((torch.rand(64, cin, 3, 3, generator=g) - 0.5) * 0.2).cuda()
+    b = ((torch.rand(64, generator=g) - 0.5) * 0.3).cuda()
+    with torch.no_grad():
+        tile, three = _forms(lambda: ops.conv3x3_split(x, wt, b, act='relu', upsample2x=True))
+        assert torch.equal(tile, three), (tile - three).abs().max().item()
+        ref = F.relu(F.conv2d(F.interpolate(x.double(), scale_factor=2, mode='bilinear', align_corners=False), wt.double(), b.double(), padding=1))
+        err = (three.double() - ref).abs().max().item()
+        assert err <= 2e-6 * max(1.0, ref.abs().max().item()), err
+        if ops.packed_supported(x, wt, True):
+            pt, p3 = _forms(lambda: ops.conv3x3_split_packed(x, wt, b, act='relu', upsample2x=True).data.clone())
+            assert torch.equal(pt, p3)
+
+
+def test_three_per_cu_upsampling_kernel_takes_batches_and_residuals():
+    from isosurfacesuperresolution_amd import ops
+    g = torch.Generator().manual_seed(11)
+    x = (torch.rand(3, 64, 20, 36, generator=g) - 0.5).cuda()
+    wt = ((torch.rand(64, 64, 3, 3, generator=g) - 0.5) * 0.2).cuda()
+    with torch.no_grad():
+        tile, three = _forms(lambda: ops.conv3x3_split(x, wt, None, act='none', upsample2x=True))
+    assert torch.equal(tile, three)

@@ -1,0 +1,35 @@
+"""The two upsampling layers of the frame (270x480 -> 540x960 fp32 out, 540x960 -> 1080x1920 packed-split out) on the tile kernel
+(two workgroups per CU) and on csrc/sr_conv_ups3.h (three), interleaved.  PYTHONPATH=. python tools/bench_ups_forms.py"""
+import ctypes
+import torch
+from isosurfacesuperresolution_amd import ops
+
+lib = ops._sr()
+lib.isrDebugSetSplitUpsForm.argtypes = [ctypes.c_int]
+ops.RANGE_GUARD = False
+wt = (torch.rand(64, 64, 3, 3, device='cuda') - 0.5) * 0.1
+b = torch.rand(64, device='cuda')
+x1 = torch.rand(1, 64, 270, 480, device='cuda') - 0.5
+x2 = torch.rand(1, 64, 540, 960, device='cuda') - 0.5
+
+
+def timed(fn, n=12):
+    for _ in range(3):
+        fn()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(n):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / n * 1e3
+
+
+with torch.no_grad():
+    for rnd in range(3):
+        for form in (0, 3):
+            lib.isrDebugSetSplitUpsForm(form)
+            t1 = timed(lambda: ops.conv3x3_split(x1, wt, b, act='relu', upsample2x=True))
+            t2 = timed(lambda: ops.conv3x3_split_packed(x2, wt, b, act='relu', upsample2x=True))
+            print("round %d form %d: 540p layer %.0f us, 1080p layer %.0f us" % (rnd, form, t1, t2), flush=True)
+lib.isrDebugSetSplitUpsForm(0)
