@@ -293,7 +293,7 @@ def run_infer(args, job):
             "frames_per_rank": K, "sharding": "contiguous frame chunks per rank, no collective",
             "overlap": ("render(t+1) on a side HIP stream || SR(t), released when the trunk has ended" +
                         (", kernel variant %d capped at %d ray-march waves" % (pipe.side_variant, pipe.side_waves) if pipe.side_variant == 2 else
-                         ", ray-march kernel variant %d (124 registers: fits beside two upsampling waves of a SIMD)" % pipe.side_variant if pipe.side_variant == 5 else
+                         ", ray-march kernel variant %d (124 registers)" % pipe.side_variant if pipe.side_variant == 5 else
                          "")) if overlap else "off",
             "conv_kernels": "exact fp32 fmaf chain (v_mfma_f32_32x32x2_f32)" if args.exact else
                             "split-operand: 3 x v_mfma_f32_32x32x16_f16 per product, fp32 accumulation (bench.py --exact = fp32 MFMA kernels); "

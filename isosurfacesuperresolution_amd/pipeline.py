@@ -63,10 +63,12 @@ class SuperResolutionPipeline:
         # kernel variant of the render that runs under the network.  None = the foreground variant: since the flat traversal
         # (0.21 ms alone) the plain kernel beside the network gave 400 frames/s in round 2; the capped 128-register kernel (2), which
         # round 1's 0.45 ms nested-loop kernel needed, gave 384 (tools/side_sweep.sh)
-        # (round 3) 5 = the flat traversal with one sample per iteration: 124 registers.  A SIMD has 512; beside two upsampling waves of
-        # 184 each it FITS, where the 168-register default variant takes the place of one of them -- and with it of a whole workgroup of
-        # the CU: 533-535 against 524 frames/s (ISR_SIDE_VARIANT=0 restores the foreground variant)
-        self.side_variant = int(os.environ.get("ISR_SIDE_VARIANT", "5"))
+        # (round 3) A ray-march wave shares a SIMD's 512 registers with the convolution waves.  Beside the TILE upsampling kernel (two
+        # waves of 184) the 124-register one-sample traversal (variant 5) fits where the 168-register default takes the place of one of
+        # them: 503-508 against 491-497 frames/s.  Beside the three-workgroups-per-CU upsampling kernel (3 x 168, the default since)
+        # nothing fits either way and the faster default variant wins: 505-510 against 502-504.  ISR_SIDE_VARIANT picks one (0 / unset:
+        # the foreground variant).
+        self.side_variant = int(os.environ.get("ISR_SIDE_VARIANT", "0"))
         if self.side_variant == 0:
             self.side_variant = None
         self.prefetch_after_trunk = os.environ.get("ISR_PREFETCH_AFTER_TRUNK", "1") != "0"     # measured: 516-519 against 497-505 frames/s with the render beside the trunk
