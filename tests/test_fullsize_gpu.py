@@ -7,6 +7,7 @@ the CPU path (oracle ray-marcher + CPU PyTorch network with identical weights). 
 statement: with random-init weights the recurrence amplifies rounding differences ~2.4x per frame.
 """
 import argparse
+import os
 
 import numpy as np
 import pytest
@@ -242,3 +243,31 @@ def test_config3_b16_t10_training_step_matches_cpu():
     assert abs(lossg - loss64) <= 1e-5 * abs(loss64), (lossg, loss64)
     e32, eg = rel(grad64, grad32), rel(grad64, gradg)
     assert max(eg) <= 3 * max(e32) + 1e-4, (max(eg), max(e32))
+
+
+def test_tiled_ray_cast_ao_two_ranks_real_collectives():
+    """parallel_render.TiledRenderer.render_with_ao with real collectives: two processes (gloo; both on this one GPU), each
+    generating and loading only its own tile, all-gather G-buffers and hit states, all-reduce (MIN) the AO distances; rank 0
+    checks the result against the unsplit render bit for bit (tests/helpers/tiled_ao_rank.py)."""
+    import socket
+    import subprocess
+    import sys
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    helper = os.path.join(os.path.dirname(os.path.abspath(__file__)), "helpers", "tiled_ao_rank.py")
+    procs = []
+    for rank in range(2):
+        env = dict(os.environ, RANK=str(rank), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+        procs.append(subprocess.Popen([sys.executable, helper], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
+    outs = []
+    for p in procs:
+        try:
+            outs.append(p.communicate(timeout=240)[0])
+        except subprocess.TimeoutExpired:
+            for q in procs:
+                q.kill()
+            raise
+    assert all(p.returncode == 0 for p in procs), "\n".join(outs)
+    assert "0 of" in outs[0], outs[0]
