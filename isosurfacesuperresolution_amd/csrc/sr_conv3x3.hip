@@ -917,6 +917,7 @@ struct WGradParams {
     int ci0, co0;       // channel group handled by this launch
     int tilesX, tilesY, ntiles;
     const float* scale; // split-operand kernel only: { 2^S, 2^-S } with max |gz| 2^S in [2^13, 2^14)
+    int dbg;            // diagnostics (isrDebugSetAblation; conv3x3_wgrad_split2_kernel): 1 no MFMAs, 2 no split / park, 4 no fetch
 };
 
 // Staging is branch-free and software pipelined: the next tile's 8 + 51 elements per thread are fetched through
@@ -1365,6 +1366,202 @@ __global__ __launch_bounds__(NTHREADS, 1) void conv3x3_wgrad_split_kernel(const 
     }
 }
 
+// ---- the same sums with the staging on its own waves ----------------------------------------------------------------------
+// conv3x3_wgrad_split_kernel runs ONE wave per SIMD (144 accumulator registers + 92 of staging: 507 registers), so the split of the
+// next tile (a few hundred VALU instructions per thread), its LDS writes and the latency of every operand read sit in series with
+// the MFMAs: 8.7 us per 128-pixel tile for 3.4 us of matrix work.  Here a workgroup is EIGHT waves, two per SIMD: waves 0..3 own the
+// accumulators and do nothing but read operands and issue MFMAs, waves 4..7 fetch, split and park -- the matrix pipe and the vector
+// pipe of a SIMD work for different waves at the same time.  Both roles fit 256 registers (accumulators + operands | two register
+// sets of staging).  LDS is double buffered, which a 4-row tile does not fit twice: the unit of the pipeline is HALF a tile (2 rows
+// x 32 pixels, 61 KB per buffer); a workgroup walks the tiles of conv3x3_wgrad_split_kernel in the same order, each as its two
+// halves, so every accumulator sees the same products in the same order -- slabs and weight gradients are bit-identical.  (The bias
+// sums are grouped differently per thread: equal to rounding.)  One barrier per half-tile.
+constexpr int W2_THREADS = 512;
+constexpr int W2_TH = 2;
+constexpr int W2_GP = W2_TH * WG_TW * 2 + 16;                 // bytes per gz channel: 64 pixels x 2 + 16 (bank spread: 36 dwords)
+constexpr int W2_XP = (W2_TH + 2) * BX_ROW + 16;              // bytes per x channel: 4 patch rows + 16 (84 dwords)
+constexpr int W2_GZ = 64 * W2_GP, W2_X = 64 * W2_XP;
+constexpr int W2_BUF = 2 * W2_GZ + 2 * W2_X;                  // hi and lo planes of gz and x: 61 440 B
+constexpr int W2_LDS_BYTES = 2 * W2_BUF;                      // 122 880 B
+constexpr int W2_NGQ = 64 * W2_TH * WG_TW / 4 / 256;          // 4 gz quads per staging thread and half-tile
+constexpr int W2_NXP = 64 * (W2_TH + 2) * BX_PAIRS / 256;     // 17 x pairs (4352 = 17 x 256 exactly)
+static_assert(64 * (W2_TH + 2) * BX_PAIRS == W2_NXP * 256, "x pairs divide evenly over the staging threads");
+
+struct W2Stage { u32x4 gq[W2_NGQ]; float xlo[W2_NXP], xhi[W2_NXP]; };
+
+__global__ __launch_bounds__(W2_THREADS, 1) void conv3x3_wgrad_split2_kernel(const WGradParams p)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char w2l[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const bool consumer = wave < 4;
+    const int m = (wave >> 1) & 1, nn = wave & 1;
+    const int j = lane & 31, kh = lane >> 5;
+    const int pt = tid & 255;                                                  // staging thread
+    const int g = blockIdx.x, nslab = gridDim.x;
+    const int nhalf = g < p.ntiles ? 2 * ((p.ntiles - g + nslab - 1) / nslab) : 0;
+    const float gscale = p.scale[0];
+
+    const size_t planeBytes = (size_t)p.H * p.W * 4;
+    const int tilesPerImage = p.tilesX * p.tilesY;
+
+    auto fetch = [&](W2Stage& st, int it) {
+        const int tile = g + (it >> 1) * nslab;
+        const int ng = tile / tilesPerImage;
+        const int t2 = tile - ng * tilesPerImage;
+        const int seg = ng / p.N, n = ng - seg * p.N;
+        const int ty = t2 / p.tilesX, tx = t2 - ty * p.tilesX;
+        const int oy0 = ty * WG_TH + (it & 1) * W2_TH, ox0 = tx * WG_TW;
+        const int gzc = p.Cout - p.co0, xc = p.Cin - p.ci0;
+        const rsrc_t grs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.gz[seg] + ((size_t)n * p.Cout + p.co0) * p.H * p.W), 0,
+                                                             (int)((gzc < 64 ? gzc : 64) * planeBytes), 0x00020000);
+        const rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.x[seg] + ((size_t)n * p.Cin + p.ci0) * p.H * p.W), 0,
+                                                             (int)((xc < 64 ? xc : 64) * planeBytes), 0x00020000);
+#pragma unroll
+        for (int i = 0; i < W2_NGQ; ++i) {                                     // quad q = (channel q / 16, row, 4 pixels)
+            const int q = pt + i * 256;
+            const int c = q >> 4, ry = (q >> 3) & 1, rx = (q & 7) * 4;
+            const int gy = oy0 + ry, gx = ox0 + rx;
+            const bool ok = gy < p.H && gx < p.W;                              // W % 4 == 0: a quad is inside or outside as a whole
+            st.gq[i] = __builtin_amdgcn_raw_buffer_load_b128(grs, (int)(ok ? (unsigned)((c * p.H + gy) * p.W + gx) * 4u : BAD_OFFSET), 0, 0);
+        }
+#pragma unroll
+        for (int i = 0; i < W2_NXP; ++i) {                                     // pair e = (channel, patch row, patch columns 2 pr, 2 pr + 1)
+            const int e = pt + i * 256;
+            const int c = e / ((W2_TH + 2) * BX_PAIRS), rem = e - c * ((W2_TH + 2) * BX_PAIRS);
+            const int r = rem / BX_PAIRS, pr = rem - r * BX_PAIRS;
+            const int gy = oy0 + r - 1, gx = ox0 + 2 * pr - 1;
+            const bool in = (unsigned)gy < (unsigned)p.H;
+            const unsigned off = (unsigned)((c * p.H + gy) * p.W + gx) * 4u;
+            st.xlo[i] = buf_load(xrs, (in && (unsigned)gx < (unsigned)p.W) ? off : BAD_OFFSET);
+            st.xhi[i] = buf_load(xrs, (in && (unsigned)(gx + 1) < (unsigned)p.W) ? off + 4u : BAD_OFFSET);
+        }
+    };
+    auto park = [&](const W2Stage& st, float (&bs)[W2_NGQ], int buf) {
+        unsigned char* gzh = w2l + buf * W2_BUF;
+        unsigned char* gzl = gzh + W2_GZ;
+        unsigned char* xph = gzl + W2_GZ;
+        unsigned char* xpl = xph + W2_X;
+#pragma unroll
+        for (int i = 0; i < W2_NGQ; ++i) {
+            const int q = pt + i * 256;
+            const float4 f = __builtin_bit_cast(float4, st.gq[i]);
+            bs[i] += (f.x + f.y) + (f.z + f.w);
+            uint2 vh, vl;
+            split_pair(f.x * gscale, f.y * gscale, 1.0f, vh.x, vl.x);
+            split_pair(f.z * gscale, f.w * gscale, 1.0f, vh.y, vl.y);
+            *reinterpret_cast<uint2*>(gzh + (q >> 4) * W2_GP + (q & 15) * 8) = vh;
+            *reinterpret_cast<uint2*>(gzl + (q >> 4) * W2_GP + (q & 15) * 8) = vl;
+        }
+#pragma unroll
+        for (int i = 0; i < W2_NXP; ++i) {
+            const int e = pt + i * 256;
+            const int c = e / ((W2_TH + 2) * BX_PAIRS), rem = e - c * ((W2_TH + 2) * BX_PAIRS);
+            const int r = rem / BX_PAIRS, pr = rem - r * BX_PAIRS;
+            unsigned vh, vl;
+            split_pair(st.xlo[i], st.xhi[i], 2048.0f, vh, vl);
+            *reinterpret_cast<unsigned*>(xph + c * W2_XP + r * BX_ROW + pr * 4) = vh;
+            *reinterpret_cast<unsigned*>(xpl + c * W2_XP + r * BX_ROW + pr * 4) = vl;
+        }
+    };
+    auto compute = [&](f32x16 (&acc)[9], int buf) {
+        const unsigned char* gzh = w2l + buf * W2_BUF;
+        const unsigned char* gzl = gzh + W2_GZ;
+        const unsigned char* xph = gzl + W2_GZ;
+        const unsigned char* xpl = xph + W2_X;
+        const int ga = (m * 32 + j) * W2_GP + kh * 16;
+        const int xb = (nn * 32 + j) * W2_XP + kh * 16;
+#pragma unroll
+        for (int ry = 0; ry < W2_TH; ++ry) {
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {                                   // k-step = 16 pixels of the row: columns 16 ks + 8 kh ..
+                const wf16x8 ah = __builtin_bit_cast(wf16x8, *reinterpret_cast<const u32x4*>(gzh + ga + (ry * 32 + ks * 16) * 2));
+                const wf16x8 al = __builtin_bit_cast(wf16x8, *reinterpret_cast<const u32x4*>(gzl + ga + (ry * 32 + ks * 16) * 2));
+                const wf16x8 as = ah * (_Float16)0.00048828125f;              // gz_hi 2^-11: partner of the scaled x_lo'
+#pragma unroll
+                for (int dy = 0; dy < 3; ++dy) {
+                    const int row = xb + (ry + dy) * BX_ROW + ks * 32;
+                    const u32x4 dh = *reinterpret_cast<const u32x4*>(xph + row);
+                    const unsigned dh4 = *reinterpret_cast<const unsigned*>(xph + row + 16);
+                    const u32x4 dl = *reinterpret_cast<const u32x4*>(xpl + row);
+                    const unsigned dl4 = *reinterpret_cast<const unsigned*>(xpl + row + 16);
+                    u32x4 h1, h2, l1, l2;
+                    h1.x = __builtin_amdgcn_alignbit(dh.y, dh.x, 16); h1.y = __builtin_amdgcn_alignbit(dh.z, dh.y, 16);
+                    h1.z = __builtin_amdgcn_alignbit(dh.w, dh.z, 16); h1.w = __builtin_amdgcn_alignbit(dh4, dh.w, 16);
+                    h2.x = dh.y; h2.y = dh.z; h2.z = dh.w; h2.w = dh4;
+                    l1.x = __builtin_amdgcn_alignbit(dl.y, dl.x, 16); l1.y = __builtin_amdgcn_alignbit(dl.z, dl.y, 16);
+                    l1.z = __builtin_amdgcn_alignbit(dl.w, dl.z, 16); l1.w = __builtin_amdgcn_alignbit(dl4, dl.w, 16);
+                    l2.x = dl.y; l2.y = dl.z; l2.z = dl.w; l2.w = dl4;
+#define ISR_WS3(T, BH, BL)                                                                                              \
+                    acc[T] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, __builtin_bit_cast(wf16x8, BH), acc[T], 0, 0, 0);   \
+                    acc[T] = __builtin_amdgcn_mfma_f32_32x32x16_f16(as, __builtin_bit_cast(wf16x8, BL), acc[T], 0, 0, 0);   \
+                    acc[T] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, __builtin_bit_cast(wf16x8, BH), acc[T], 0, 0, 0);
+                    ISR_WS3(dy * 3 + 0, dh, dl)
+                    ISR_WS3(dy * 3 + 1, h1, l1)
+                    ISR_WS3(dy * 3 + 2, h2, l2)
+#undef ISR_WS3
+                }
+                __builtin_amdgcn_sched_barrier(0);                             // operands are fetched one k-step ahead at most (256 registers)
+            }
+        }
+    };
+
+    // half-tile `it` is computed from buffer it & 1 while the staging waves park half-tile it + 1 (requested one iteration ago) into
+    // the other buffer and then request half-tile it + 2: ONE register set, the requests fly while the staging waves wait at the
+    // barrier for the MFMAs.  The two roles are separate loops (same number of barriers in each: nhalf + 1), so that the register
+    // allocation is the larger of the two roles and not their sum.
+    if (consumer) {
+        f32x16 acc[9];
+#pragma unroll
+        for (int t = 0; t < 9; ++t)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[t][i] = 0.0f;
+        __syncthreads();
+        for (int it = 0; it < nhalf; ++it) {
+            if (!(p.dbg & 1)) compute(acc, it & 1);
+            __syncthreads();
+        }
+        float* slab = p.slabs + (size_t)g * 9 * 64 * 64;
+#pragma unroll
+        for (int t = 0; t < 9; ++t)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const int co = m * 32 + (i & 3) + 8 * (i >> 2) + 4 * kh;
+                slab[((size_t)t * 64 + co) * 64 + nn * 32 + j] = acc[t][i];
+            }
+    } else {
+        // one register set (a second one, requests two iterations ahead, measured the same: the staging waves are bound by their
+        // own work -- 900 vector instructions and 38 memory requests per thread and half-tile -- not by the latency)
+        W2Stage st;
+        float bs[W2_NGQ];                                                      // fp32 sums of gz (channel pt / 16 + 16 i)
+#pragma unroll
+        for (int i = 0; i < W2_NGQ; ++i) bs[i] = 0.0f;
+        const bool doPark = !(p.dbg & 2), doFetch = !(p.dbg & 4);
+        if (nhalf > 0) {
+            fetch(st, 0);
+            park(st, bs, 0);
+            fetch(st, 1);                                                      // nhalf is even
+        }
+        __syncthreads();
+        for (int it = 0; it < nhalf; ++it) {
+            if (it + 1 < nhalf) {
+                if (doPark) park(st, bs, (it + 1) & 1);
+                if (it + 2 < nhalf && doFetch) fetch(st, it + 2);
+            }
+            __syncthreads();
+        }
+        // bias gradient from the fp32 values: staging thread t's sum i belongs to channel t / 16 + 16 i; reduce over the 16 lanes
+        if (p.bslabs) {
+#pragma unroll
+            for (int i = 0; i < W2_NGQ; ++i) {
+                float v = bs[i];
+#pragma unroll
+                for (int off = 8; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+                if ((lane & 15) == 0) p.bslabs[(size_t)g * 64 + (pt >> 4) + 16 * i] = v;
+            }
+        }
+    }
+}
+
 // max |gz| over the tensors of a launch: one partial per workgroup, then { 2^S, 2^-S } with max |gz| 2^S in [2^13, 2^14)
 struct AbsMaxParams { const float* t[WG_MAX_SEG]; int segments; long long count; };
 __global__ __launch_bounds__(256) void wgrad_absmax_kernel(const AbsMaxParams p, float* __restrict__ partial)
@@ -1474,6 +1671,7 @@ void isr_profile_record(int variant, double flops, hipEvent_t* e0, hipEvent_t* e
 }
 
 static int g_conv_dbg = 0;
+static int g_wgrad_split_form = [] { const char* e = getenv("ISR_WGRAD_FORM"); return (e && e[0] == '1') ? 1 : 2; }();
 static int g_conv_tile = 0;   // 0: automatic, 1: always 4x32 tiles, 2: always 16x32 tiles, 3: one row per workgroup (tools / tests)
 static long long g_row_threshold = 160;   // automatic: rows when the 4x32 tiling has at most this many workgroups
                                           // (HIP-graph chain of 64 -> 64 layers on N crops of 32x32, rows vs 4x32 tiles:
@@ -1505,6 +1703,9 @@ int isrProfileGet(int i, int* variant, double* flops, float* ms)
 }
 
 void isrDebugSetAblation(int bits) { g_conv_dbg = bits; }
+// split-operand weight gradient: 2 = staging on its own waves (conv3x3_wgrad_split2_kernel, the default), 1 = one wave per SIMD
+void isrDebugSetWgradSplitForm(int form) { g_wgrad_split_form = form == 1 ? 1 : 2; }
+int isrDebugWgradSplitForm(void) { return g_wgrad_split_form; }
 void isrDebugSetForwardAlgo(int a) { g_conv_algo = a; }
 void isrDebugSetForwardTile(int t) { g_conv_tile = t; }   // not part of the public header
 void isrDebugSetRowThreshold(long long n) { g_row_threshold = n; }
@@ -1679,6 +1880,7 @@ int isrConv3x3WeightGradSegments(const float* const* xs, const float* const* gzs
         return -1;
     hipStream_t s = (hipStream_t)stream;
     WGradParams p;
+    p.dbg = g_conv_dbg;
     for (int k = 0; k < WG_MAX_SEG; ++k) {
         p.x[k] = k < segments ? xs[k] : nullptr;
         p.gz[k] = k < segments ? gzs[k] : nullptr;
@@ -1718,6 +1920,7 @@ int isrConv3x3WeightGradSegmentsBf16(const float* const* xs, const float* const*
     if (W & 3) return -3;                          // the gz tile is fetched as aligned groups of four pixels
     hipStream_t s = (hipStream_t)stream;
     WGradParams p;
+    p.dbg = g_conv_dbg;
     for (int k = 0; k < WG_MAX_SEG; ++k) {
         p.x[k] = k < segments ? xs[k] : nullptr;
         p.gz[k] = k < segments ? gzs[k] : nullptr;
@@ -1752,6 +1955,7 @@ int isrConv3x3WeightGradSegmentsSplit(const float* const* xs, const float* const
     if (W & 3) return -3;                          // the gz tile is fetched as aligned groups of four pixels
     hipStream_t s = (hipStream_t)stream;
     WGradParams p;
+    p.dbg = g_conv_dbg;
     AbsMaxParams ap;
     for (int k = 0; k < WG_MAX_SEG; ++k) {
         p.x[k] = k < segments ? xs[k] : nullptr;
@@ -1775,6 +1979,7 @@ int isrConv3x3WeightGradSegmentsSplit(const float* const* xs, const float* const
     static bool attr_done = false;
     if (!attr_done) {
         (void)hipFuncSetAttribute((const void*)conv3x3_wgrad_split_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, WS_LDS_BYTES);
+        (void)hipFuncSetAttribute((const void*)conv3x3_wgrad_split2_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, W2_LDS_BYTES);
         attr_done = true;
     }
     const long long quads = ap.count >> 2;
@@ -1786,7 +1991,8 @@ int isrConv3x3WeightGradSegmentsSplit(const float* const* xs, const float* const
         for (int ci0 = 0; ci0 < Cin; ci0 += 64) {
             p.co0 = co0; p.ci0 = ci0;
             p.bslabs = (db && ci0 == 0) ? bslabs : nullptr;
-            hipLaunchKernelGGL(conv3x3_wgrad_split_kernel, dim3(G), dim3(NTHREADS), WS_LDS_BYTES, s, p);
+            if (g_wgrad_split_form == 2) hipLaunchKernelGGL(conv3x3_wgrad_split2_kernel, dim3(G), dim3(W2_THREADS), W2_LDS_BYTES, s, p);
+            else hipLaunchKernelGGL(conv3x3_wgrad_split_kernel, dim3(G), dim3(NTHREADS), WS_LDS_BYTES, s, p);
             hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(9 * 64 + 1), dim3(256), 0, s,
                                p.slabs, G, dw, Cout, Cin, co0, ci0, (const float*)p.bslabs, db, (const float*)scale);
         }

@@ -469,6 +469,47 @@ def test_split_operand_weight_gradient_matches_fp64(case, gz_scale):
     assert err[True] <= 1e-5, err
 
 
+@pytest.mark.parametrize("case", [(10, 16, 64, 64, 32, 32), (3, 12, 101, 64, 64, 64), (2, 16, 64, 64, 128, 128), (2, 16, 64, 6, 128, 128),
+                                  (5, 7, 64, 64, 36, 40), (1, 3, 64, 64, 130, 68)])
+def test_staged_weight_gradient_kernel_is_bit_identical_to_the_one_wave_form(case):
+    """conv3x3_wgrad_split2_kernel (staging on its own waves, half-tile pipeline) walks the tiles of conv3x3_wgrad_split_kernel in
+    the same order: the weight gradients are EQUAL bit for bit (odd tile counts, ragged rows and columns, partial channel groups
+    included); the bias gradient groups its fp32 sums differently and is equal to rounding."""
+    import ctypes
+    from isosurfacesuperresolution_amd import ops
+    lib = ops._sr()
+    lib.isrDebugSetWgradSplitForm.argtypes = [ctypes.c_int]
+    lib.isrDebugWgradSplitForm.restype = ctypes.c_int
+    segs, n, cin, cout, h, w = case
+    g = torch.Generator().manual_seed(segs * 7 + h)
+    xs = [torch.relu(torch.randn(n, cin, h, w, generator=g)).cuda() for _ in range(segs)]
+    gzs = [(torch.randn(n, cout, h, w, generator=g) * 1e-3).cuda() for _ in range(segs)]
+    weight = torch.zeros(cout, cin, 3, 3).cuda()
+    default = lib.isrDebugWgradSplitForm()
+    old = ops.TRAIN_SPLIT
+    out = {}
+    try:
+        ops.TRAIN_SPLIT = True
+        for form in (1, 2):
+            lib.isrDebugSetWgradSplitForm(form)
+            fn = lib.isrConv3x3WeightGradSegmentsSplit
+            dw = torch.full_like(weight, 7.0)
+            db = torch.full((cout,), 7.0, device="cuda")
+            ws = ops._wgrad_workspace(weight.device, lib.isrConvWeightGradWorkspace(n, cin, h, w, cout))
+            px = (ctypes.c_void_p * segs)(*[t.data_ptr() for t in xs])
+            pg = (ctypes.c_void_p * segs)(*[t.data_ptr() for t in gzs])
+            assert fn(px, pg, segs, ops._ptr(dw), ops._ptr(db), ops._ptr(ws), n, cin, h, w, cout, ops._stream()) == 0
+            torch.cuda.synchronize()
+            out[form] = (dw.clone(), db.clone())
+    finally:
+        lib.isrDebugSetWgradSplitForm(default)
+        ops.TRAIN_SPLIT = old
+    assert default == 2
+    assert torch.equal(out[1][0], out[2][0]), (out[1][0] - out[2][0]).abs().max().item()
+    assert out[1][0].abs().max().item() > 0
+    assert (out[1][1] - out[2][1]).abs().max().item() <= 1e-5 * out[1][1].abs().max().item()
+
+
 def test_relu_backward_folded_into_the_consumers_data_gradient():
     """conv(relu) -> conv(relu) -> conv: with ops.GATE_FUSION the data gradient of a layer whose input is a ReLU conv3x3's
     output applies that ReLU's backward in its epilogue and the producer skips its isrActBackward; every gradient must be
