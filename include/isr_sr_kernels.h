@@ -270,6 +270,18 @@ int isrTrunkDataflow(const float* x, int cin0, long long xPlane, float* y, long 
  *   x, y: [64][H][W] fp32, 16-byte aligned, planes xPlane / yPlane floats apart (multiples of 4), W a multiple of 4;
  *   wq1 / wq2: isrConvSplitPrepare(w [64][64][3][3]); bias1 / bias2: [64] device (may be NULL).
  * isrResBlockSplitSupported -> 1 if these tensors can be taken.  0 ok, -1 bad arguments, -2 launch failure, -3 unsupported. */
+/* Two chained 64 -> 64 convolutions of a BATCH OF SMALL IMAGES (W <= 32, e.g. the 32 x 32 crops of mainVideoUnshaded.py's training
+ * step) in ONE launch -- a residual block, z = relu(conv(x, wa) + ba), y = conv(z, wb) + bb + x (models/enhancenet.py:18-33,139-141;
+ * gate == NULL), or its data gradient, z = gate > 0 ? conv(x, wa) : 0, y = conv(z, wb) + x (x = the gradient of the block's output,
+ * gate = the saved relu output, wa / wb = the flipped / transposed images of the block's second / first convolution).  Bit-identical
+ * to two isrConv3x3ForwardSplit launches (the intermediate's halo rows are recomputed per 2-row tile).
+ *   x, gate, z, y: packed [N][64][H][W] fp32, x and y 16-byte aligned, W a multiple of 4; wa / wb: isrConvSplitPrepare(w [64][64][3][3]);
+ *   ba / bb: [64] device or NULL.  isrResBlockSmallSupported -> 1 for shapes this takes (at least 64 two-row tiles).
+ * 0 ok, -1 bad arguments, -2 launch failure, -3 unsupported shape. */
+int isrResBlockSmallSupported(int N, int H, int W);
+int isrResBlockSmall(const float* x, const void* wa, const float* ba, const float* gate, const void* wb, const float* bb, float* z, float* y,
+                     int N, int H, int W, void* stream);
+
 long long isrResBlockSplitWorkspaceBytes(void);
 int isrResBlockSplitSupported(const float* x, int H, int W, long long xPlane, long long yPlane);
 int isrResBlockSplit(const float* x, const void* wq1, const float* bias1, const void* wq2, const float* bias2, float* y, void* workspace,

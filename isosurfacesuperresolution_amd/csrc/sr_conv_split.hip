@@ -1100,6 +1100,7 @@ __global__ __launch_bounds__(256) void prepare_weights_split_many_kernel(const P
 } // namespace
 
 #include "sr_conv_ups3.h"       // the three-workgroups-per-CU upsampling kernel: same translation unit, same parameter block
+#include "sr_conv_block2.h"     // two chained convolutions of a batch of small images in one launch (training trunk)
 
 __device__ u32x4 g_split_zero_unit[4];      // zero initialised: source of the zero-padding units of the LDS-DMA staging
 static unsigned* g_range_flag = nullptr;
@@ -1324,6 +1325,35 @@ int isrConvSplitPrepareMany(int n, const float* const* w, void* const* wqForward
     p.n = n;
     hipLaunchKernelGGL(split_scale_many_kernel, dim3(n), dim3(1024), 0, (hipStream_t)stream, p);
     hipLaunchKernelGGL(prepare_weights_split_many_kernel, dim3((most + 255) / 256, 2 * n), dim3(256), 0, (hipStream_t)stream, p);
+    return hipGetLastError() == hipSuccess ? 0 : -2;
+}
+
+int isrResBlockSmallSupported(int N, int H, int W)
+{
+    if (N <= 0 || H <= 0 || W <= 0 || (W & 3) || W > ST_W) return 0;
+    const long long tiles = (long long)N * ((H + R2_H - 1) / R2_H);
+    return tiles >= 64 && tiles <= 0x7fffffffLL && (long long)64 * H * W * 4 <= 0x7fffffffLL;
+}
+
+int isrResBlockSmall(const float* x, const void* wa, const float* ba, const float* gate, const void* wb, const float* bb, float* z, float* y,
+                     int N, int H, int W, void* stream)
+{
+    if (!x || !wa || !wb || !z || !y) return -1;
+    if (!isrResBlockSmallSupported(N, H, W)) return -3;
+    if (((uintptr_t)x & 15) || ((uintptr_t)y & 15) || ((uintptr_t)wa & 15) || ((uintptr_t)wb & 15)) return -1;
+    Block2Params p;
+    p.x = x; p.wa = (const u32x4*)wa; p.ba = ba; p.gate = gate; p.wb = (const u32x4*)wb; p.bb = bb; p.z = z; p.y = y;
+    p.N = N; p.H = H; p.W = W; p.tilesY = (H + R2_H - 1) / R2_H;
+    p.absmax = isr_take_range_flag();
+    p.dbg = g_split_dbg;
+    static bool attr = false;
+    if (!attr) { (void)hipFuncSetAttribute((const void*)conv3x3_split_block2_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, B2_LDS_BYTES); attr = true; }
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    isr_profile_record(ISR_VARIANT_SPLIT_BLOCK2, 2.0 * 2.0 * 9 * 64 * 64 * (double)N * H * W, &e0, &e1);
+    const dim3 grid((unsigned)(N * p.tilesY)), block(S_THREADS);
+    hipStream_t s = (hipStream_t)stream;
+    if (e0 || e1) hipExtLaunchKernelGGL(conv3x3_split_block2_kernel, grid, block, B2_LDS_BYTES, s, e0, e1, 0, p);
+    else hipLaunchKernelGGL(conv3x3_split_block2_kernel, grid, block, B2_LDS_BYTES, s, p);
     return hipGetLastError() == hipSuccess ? 0 : -2;
 }
 

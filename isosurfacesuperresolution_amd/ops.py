@@ -55,6 +55,8 @@ def _sr():
         lib.isrConv3x3WeightGradSegmentsSplit.argtypes = lib.isrConv3x3WeightGradSegments.argtypes
         lib.isrConv3x3WeightGradSegmentsSplit.restype = ci
         lib.isrActBackward.argtypes = [vp, vp, vp, ll, ci, cf, vp]; lib.isrActBackward.restype = ci
+        lib.isrResBlockSmallSupported.argtypes = [ci, ci, ci]; lib.isrResBlockSmallSupported.restype = ci
+        lib.isrResBlockSmall.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, ci, ci, ci, vp]; lib.isrResBlockSmall.restype = ci
         lib.isrAssembleInput.argtypes = [vp, vp, vp, vp, ci, ci, ci, ci, vp]; lib.isrAssembleInput.restype = ci
         lib.isrConvSmallCinPad.argtypes = [ci]; lib.isrConvSmallCinPad.restype = ci
         lib.isrConvSmallWeightFloats.argtypes = [ci]; lib.isrConvSmallWeightFloats.restype = ll
@@ -181,7 +183,7 @@ VARIANT_NAMES = {6: "conv3x3_small_cout_kernel", 2: "conv3x3_fwd_kernel<1,false>
                  13: "conv3x3_split_kernel<false>", 14: "conv3x3_split_kernel<true>",
                  15: "conv3x3_split_stream_kernel", 16: "conv3x3_split_wide_kernel", 17: "conv3x3_split_rows2_kernel",
                  18: "conv3x3_split_tail_kernel", 19: "resblock_split_kernel", 20: "trunk_dataflow_kernel",
-                 21: "conv3x3_split_ups3_kernel"}
+                 21: "conv3x3_split_ups3_kernel", 22: "conv3x3_split_block2_kernel"}
 
 
 def debug_switches():
@@ -722,6 +724,34 @@ def _weight_grad_or_defer(weight, bias, has_bias, x, gz):
     return _weight_grad([x], [gz], weight, has_bias)
 
 
+# A residual block of a batch of SMALL images (the 32 x 32 training crops: too few 8 x 32 tiles for the streaming kernel) as ONE
+# launch forward and ONE backward (csrc/sr_conv_block2.h: both convolutions, the intermediate's halo rows recomputed per 2-row
+# tile) instead of two each: bit-identical tensors, one chain of launch latencies instead of two.
+TRAIN_BLOCK2 = os.environ.get("ISR_TRAIN_BLOCK2", "1") != "0"
+
+
+def _block2_supported(x, w1, w2):
+    n, c, h, w = x.shape
+    if not (TRAIN_BLOCK2 and TRAIN_SPLIT and not TRAIN_BF16 and c == 64 and tuple(w1.shape) == (64, 64, 3, 3) and tuple(w2.shape) == (64, 64, 3, 3)):
+        return False
+    if n * ((h + 7) // 8) * ((w + 31) // 32) >= TRAIN_SPLIT_MIN_TILES or n * ((h + 1) // 2) < TRAIN_SPLIT_MIN_TILES2:
+        return False                        # enough 8 x 32 tiles for the streaming kernel / too few rows to fill the GPU
+    return bool(_sr().isrResBlockSmallSupported(n, h, w))
+
+
+def _block2(x, wa, ba, gate, wb, bb, transpose_flip):
+    """(z, y): z = relu(conv(x, wa) + ba) (or, with ``gate``: conv(x, wa) where gate > 0, else 0), y = conv(z, wb) + bb + x;
+    x, gate: packed [N, 64, H, W]."""
+    n, _, h, w = x.shape
+    z, y = torch.empty_like(x), torch.empty_like(x)
+    _tally("split", 2 * 2.0 * 9 * 64 * 64 * n * h * w)
+    rc = _sr().isrResBlockSmall(_ptr(x), _ptr(_prepare_split(wa, transpose_flip)), _ptr(ba), _ptr(gate), _ptr(_prepare_split(wb, transpose_flip)),
+                                _ptr(bb), _ptr(z), _ptr(y), n, h, w, _stream())
+    if rc != 0:
+        raise RuntimeError("isrResBlockSmall failed (%d)" % rc)
+    return z, y
+
+
 class _ResidualBlockFunction(torch.autograd.Function):
     """y = x + conv2(relu(conv1(x))) -- EnhanceNet's residual block (enhancenet.py:18-33,141) as ONE autograd node of
     two fused launches forward and two backward: the data gradient of conv2 is gated by relu's output in its epilogue
@@ -731,9 +761,11 @@ class _ResidualBlockFunction(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, w1, b1, w2, b2):
         x = x.contiguous()
-        c = w1.shape[0]
-        t = _train_conv(x, w1, False, b1.contiguous() if b1 is not None else None, None, 'relu')
-        y = _train_conv(t, w2, False, b2.contiguous() if b2 is not None else None, x, 'none')
+        if _block2_supported(x, w1, w2):
+            t, y = _block2(x, w1, b1.contiguous() if b1 is not None else None, None, w2, b2.contiguous() if b2 is not None else None, False)
+        else:
+            t = _train_conv(x, w1, False, b1.contiguous() if b1 is not None else None, None, 'relu')
+            y = _train_conv(t, w2, False, b2.contiguous() if b2 is not None else None, x, 'none')
         ctx.params = (w1, b1, w2, b2)
         ctx.save_for_backward(x, t)
         return y
@@ -743,11 +775,13 @@ class _ResidualBlockFunction(torch.autograd.Function):
         x, t = ctx.saved_tensors
         w1, b1, w2, b2 = ctx.params
         gy = gy.contiguous()
-        c = w1.shape[0]
-        gz1 = _train_conv(gy, w2, True, None, t, 'gate')
         gx = None
-        if ctx.needs_input_grad[0]:
-            gx = _train_conv(gz1, w1, True, None, gy, 'none')
+        if ctx.needs_input_grad[0] and _block2_supported(gy, w1, w2):
+            gz1, gx = _block2(gy, w2, None, t, w1, None, True)
+        else:
+            gz1 = _train_conv(gy, w2, True, None, t, 'gate')
+            if ctx.needs_input_grad[0]:
+                gx = _train_conv(gz1, w1, True, None, gy, 'none')
         gw1 = gb1 = gw2 = gb2 = None
         if ctx.needs_input_grad[3] or (b2 is not None and ctx.needs_input_grad[4]):
             gw2, gb2 = _weight_grad_or_defer(w2, b2 if (b2 is not None and b2.requires_grad) else None, b2 is not None, t, gy)

@@ -510,6 +510,42 @@ def test_staged_weight_gradient_kernel_is_bit_identical_to_the_one_wave_form(cas
     assert (out[1][1] - out[2][1]).abs().max().item() <= 1e-5 * out[1][1].abs().max().item()
 
 
+@pytest.mark.parametrize("shape", [(16, 32, 32), (16, 31, 32), (40, 9, 28), (130, 2, 4), (8, 32, 32)])
+def test_fused_small_image_residual_block_is_bit_identical_to_two_launches(shape):
+    """csrc/sr_conv_block2.h (one launch for both convolutions of a residual block of a batch of small images, forward and data
+    gradient; the intermediate's halo rows recomputed) against the two-launch path: output, input gradient, and -- through the
+    tensors handed to the deferred weight gradients -- every parameter gradient EQUAL bit for bit; and close to a float64 block."""
+    from isosurfacesuperresolution_amd import ops
+    n, h, w = shape
+    g = torch.Generator().manual_seed(n * 100 + h)
+    x0 = ((torch.rand(n, 64, h, w, generator=g) - 0.3) * 2).cuda()
+    ws = [((torch.rand(64, 64, 3, 3, generator=g) - 0.5) * 0.1).cuda().requires_grad_() for _ in range(2)]
+    bs = [((torch.rand(64, generator=g) - 0.5) * 0.2).cuda().requires_grad_() for _ in range(2)]
+    gy = ((torch.rand(n, 64, h, w, generator=g) - 0.5) * 1e-2).cuda()
+    assert ops._block2_supported(x0, ws[0], ws[1])
+    out = {}
+    old = ops.TRAIN_BLOCK2
+    try:
+        for mode in (True, False):
+            ops.TRAIN_BLOCK2 = mode
+            x = x0.clone().requires_grad_()
+            y = ops.residual_block(x, ws[0], bs[0], ws[1], bs[1])
+            grads = torch.autograd.grad(y, [x] + ws + bs, gy)
+            out[mode] = [y.detach()] + [t.detach() for t in grads]
+    finally:
+        ops.TRAIN_BLOCK2 = old
+    names = ["y", "gx", "gw1", "gw2", "gb1", "gb2"]
+    for name, a, b in zip(names, out[True], out[False]):
+        assert torch.equal(a, b), "%s: %g" % (name, (a - b).abs().max().item())
+    xd = x0.double().requires_grad_()
+    wd = [t.detach().double().requires_grad_() for t in ws]
+    bd = [t.detach().double().requires_grad_() for t in bs]
+    yd = xd + F.conv2d(F.relu(F.conv2d(xd, wd[0], bd[0], padding=1)), wd[1], bd[1], padding=1)
+    gd = torch.autograd.grad(yd, [xd] + wd + bd, gy.double())
+    for name, a, ref in zip(names, out[True], [yd.detach()] + list(gd)):
+        assert (a.double() - ref).abs().max().item() <= 2e-5 * max(1e-3, ref.abs().max().item()), name
+
+
 def test_relu_backward_folded_into_the_consumers_data_gradient():
     """conv(relu) -> conv(relu) -> conv: with ops.GATE_FUSION the data gradient of a layer whose input is a ReLU conv3x3's
     output applies that ReLU's backward in its epilogue and the producer skips its isrActBackward; every gradient must be
