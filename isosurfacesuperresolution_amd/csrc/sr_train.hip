@@ -8,6 +8,7 @@
 //    sum, backward = ONE pass that writes d loss / d pred and d loss / d prev.  The module path
 //    (losses/lossnet_unshaded.py in this package) issues ~150 launches forward and ~200 backward per frame.
 #include <hip/hip_runtime.h>
+#include <stdint.h>
 #include "../../include/isr_sr_kernels.h"
 #include "sr_finish.h"
 
@@ -81,6 +82,70 @@ __global__ __launch_bounds__(256) void upsample2x_bwd_kernel(const float* __rest
         }
         gx[i] = acc;
     }
+}
+
+// The same two maps for the shapes of a training step (w a multiple of 4, fewer than 2^31 elements), laid out for the memory system:
+// no 64-bit divisions, the x2 weights in closed form (0.25 / 0.75, 1 at the borders -- what up2_weight evaluates to), a thread per
+// 2 x 4 output block (forward: 12 loads for 8 outputs) / per 4 input pixels (backward: the 4 x 10 window as 8 quad + 8 single loads
+// instead of 64 single ones).  Every output is the same expression in the same order as in the kernels above: same bits.
+__global__ __launch_bounds__(256) void upsample2x_fwd4_kernel(const float* __restrict__ x, float* __restrict__ y, int h, int w, unsigned count)
+{
+    const unsigned W = 2u * w, QW = W / 4u;
+    const unsigned t = blockIdx.x * 256u + threadIdx.x;                      // (plane, iy, qx)
+    if (t >= count) return;
+    const unsigned qx = t % QW, r = t / QW, iy = r % (unsigned)h, plane = r / (unsigned)h;
+    const float* src = x + (size_t)plane * h * w;
+    float* dst = y + ((size_t)plane * 2 * h + 2 * iy) * W + 4 * qx;
+    int x0[4], x1[4]; float lx[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) isr_src_index((int)(4 * qx) + k, 0.5f, w, x0[k], x1[k], lx[k]);
+#pragma unroll
+    for (int d = 0; d < 2; ++d) {
+        int y0, y1; float ly;
+        isr_src_index((int)(2 * iy) + d, 0.5f, h, y0, y1, ly);
+        const float hy = 1.f - ly;
+        const float* r0 = src + (size_t)y0 * w;
+        const float* r1 = src + (size_t)y1 * w;
+        float o[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const float hx = 1.f - lx[k];
+            o[k] = hy * (hx * r0[x0[k]] + lx[k] * r0[x1[k]]) + ly * (hx * r1[x0[k]] + lx[k] * r1[x1[k]]);
+        }
+        *reinterpret_cast<float4*>(dst + (size_t)d * W) = make_float4(o[0], o[1], o[2], o[3]);
+    }
+}
+
+__global__ __launch_bounds__(256) void upsample2x_bwd4_kernel(const float* __restrict__ gy, float* __restrict__ gx, int h, int w, unsigned count)
+{
+    const unsigned W = 2u * w, H = 2u * h, qw = (unsigned)w / 4u;
+    const unsigned t = blockIdx.x * 256u + threadIdx.x;                      // (plane, iy, 4 input pixels)
+    if (t >= count) return;
+    const unsigned q = t % qw, r = t / qw, iy = r % (unsigned)h, plane = r / (unsigned)h;
+    const int ix0 = (int)(4 * q);
+    float acc[4] = { 0.f, 0.f, 0.f, 0.f };
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int Y = 2 * (int)iy - 1 + j;
+        if (Y < 0 || Y >= (int)H) continue;
+        // output row Y reads input row iy with 0.25 (the far rows), 0.75 (the near ones), 1 where the other tap is clamped onto it
+        const float wy = (j == 0 || j == 3) ? 0.25f : ((j == 1 && iy == 0) || (j == 2 && iy == (unsigned)h - 1)) ? 1.0f : 0.75f;
+        const float* row = gy + ((size_t)plane * H + Y) * W + 2 * ix0;      // row[-1 .. 8] are this thread's ten columns
+        const float4 a = *reinterpret_cast<const float4*>(row), b = *reinterpret_cast<const float4*>(row + 4);
+        const float left = ix0 > 0 ? row[-1] : 0.f, right = ix0 + 4 < w ? row[8] : 0.f;
+        const float v[10] = { left, a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w, right };
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int ix = ix0 + e;
+            float s = 0.f;
+            if (ix > 0) s += 0.25f * v[2 * e];
+            s += (ix == 0 ? 1.0f : 0.75f) * v[2 * e + 1];
+            s += (ix == w - 1 ? 1.0f : 0.75f) * v[2 * e + 2];
+            if (ix < w - 1) s += 0.25f * v[2 * e + 3];
+            acc[e] += wy * s;
+        }
+    }
+    *reinterpret_cast<float4*>(gx + ((size_t)plane * h + iy) * w + ix0) = make_float4(acc[0], acc[1], acc[2], acc[3]);
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -671,6 +736,11 @@ int isrUpsample2xForward(const float* x, float* y, long long planes, int h, int 
 {
     if (!x || !y || planes <= 0 || h <= 0 || w <= 0 || (w & 1)) return -1;
     const long long quads = planes * (2LL * h) * (2 * w / 4);
+    if (!(w & 1) && quads < 0x7fffffffLL && !(((uintptr_t)y) & 15)) {         // 2 w a multiple of 4: whole output quads
+        const unsigned count = (unsigned)(quads / 2);
+        hipLaunchKernelGGL(upsample2x_fwd4_kernel, dim3((count + 255) / 256), dim3(256), 0, (hipStream_t)stream, x, y, h, w, count);
+        return hipGetLastError() == hipSuccess ? 0 : -2;
+    }
     long long blocks = (quads + 255) / 256;
     if (blocks > 8192) blocks = 8192;
     hipLaunchKernelGGL(upsample2x_fwd_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, x, y, h, w, quads);
@@ -681,6 +751,11 @@ int isrUpsample2xBackward(const float* gy, float* gx, long long planes, int h, i
 {
     if (!gy || !gx || planes <= 0 || h <= 0 || w <= 0) return -1;
     const long long count = planes * h * w;
+    if (!(w & 3) && count < 0x7fffffffLL && !(((uintptr_t)gy | (uintptr_t)gx) & 15)) {
+        const unsigned n4 = (unsigned)(count / 4);
+        hipLaunchKernelGGL(upsample2x_bwd4_kernel, dim3((n4 + 255) / 256), dim3(256), 0, (hipStream_t)stream, gy, gx, h, w, n4);
+        return hipGetLastError() == hipSuccess ? 0 : -2;
+    }
     long long blocks = (count + 255) / 256;
     if (blocks > 16384) blocks = 16384;
     hipLaunchKernelGGL(upsample2x_bwd_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, gy, gx, h, w, count);

@@ -10,7 +10,7 @@ import torch.nn.functional as F
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("shape", [(2, 3, 5, 6), (1, 64, 32, 32), (3, 1, 1, 2), (1, 2, 7, 10), (16, 64, 16, 16)])
+@pytest.mark.parametrize("shape", [(2, 3, 5, 6), (1, 64, 32, 32), (3, 1, 1, 2), (1, 2, 7, 10), (16, 64, 16, 16), (2, 5, 3, 4), (3, 2, 1, 8), (2, 3, 9, 12)])
 def test_upsample2x_forward_backward_match_torch(shape):
     from isosurfacesuperresolution_amd import ops
     g = torch.Generator().manual_seed(7)
