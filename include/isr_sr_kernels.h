@@ -136,6 +136,17 @@ int isrConv3x3WeightGradSegments(const float* const* xs, const float* const* gzs
  * weight-gradient half of the opt-in mixed-precision training mode.  W % 4 == 0 and 16-byte aligned gzs[k] (else -3 / -1). */
 int isrConv3x3WeightGradSegmentsSplit(const float* const* xs, const float* const* gzs, int segments, float* dw, float* db, void* workspace,
                                       int N, int Cin, int H, int W, int Cout, void* stream);
+/* Per-wave maxima of the NEXT isrConv3x3ForwardSplit launch (training: a data gradient that will be a weight gradient's gz operand):
+ * `words` -> a zeroed device array of `capacity` words; the launch, if its kernel form supports it and 4 x its workgroups fit, leaves in
+ * word 4 w + v the bit pattern of the largest |value| wave v of workgroup w stored.  isrTakeMaxSlotWords() -> the number of words the
+ * last armed launch used (0: not supported / did not fit -- make the pass over the tensor instead). */
+void isrSetMaxSlots(void* words, int capacity);
+int isrTakeMaxSlotWords(void);
+/* ...SplitMax: as ...Split, with the maxima of the gz tensors supplied: gzmax[k] (HOST array of device pointers) -> maxWords words
+ * whose maximum is the bit pattern of max |gzs[k]|, as left by the kernel that produced the tensor (isrResBlockSmall's zmax /
+ * ymax, isrSetMaxSlots: one word per wave); the pass over gz that ...Split makes to find its scale is skipped.  gzmax == NULL: exactly ...Split. */
+int isrConv3x3WeightGradSegmentsSplitMax(const float* const* xs, const float* const* gzs, const void* const* gzmax, int maxWords, int segments,
+                                         float* dw, float* db, void* workspace, int N, int Cin, int H, int W, int Cout, void* stream);
 int isrConv3x3WeightGradSegmentsBf16(const float* const* xs, const float* const* gzs, int segments, float* dw, float* db, void* workspace,
                                      int N, int Cin, int H, int W, int Cout, void* stream);
 
@@ -277,10 +288,12 @@ int isrTrunkDataflow(const float* x, int cin0, long long xPlane, float* y, long 
  * to two isrConv3x3ForwardSplit launches (the intermediate's halo rows are recomputed per 2-row tile).
  *   x, gate, z, y: packed [N][64][H][W] fp32, x and y 16-byte aligned, W a multiple of 4; wa / wb: isrConvSplitPrepare(w [64][64][3][3]);
  *   ba / bb: [64] device or NULL.  isrResBlockSmallSupported -> 1 for shapes this takes (at least 64 two-row tiles).
+ *   zmax / ymax (both or neither): device arrays of 4 N ceil(H / 2) words that receive, per wave, the bit pattern of max |z| / max |y| --
+ *   what isrConv3x3WeightGradSegmentsSplitMax wants for a gz operand.
  * 0 ok, -1 bad arguments, -2 launch failure, -3 unsupported shape. */
 int isrResBlockSmallSupported(int N, int H, int W);
 int isrResBlockSmall(const float* x, const void* wa, const float* ba, const float* gate, const void* wb, const float* bb, float* z, float* y,
-                     int N, int H, int W, void* stream);
+                     int N, int H, int W, void* zmax, void* ymax, void* stream);
 
 long long isrResBlockSplitWorkspaceBytes(void);
 int isrResBlockSplitSupported(const float* x, int H, int W, long long xPlane, long long yPlane);

@@ -1607,6 +1607,34 @@ __global__ __launch_bounds__(256) void wgrad_scale_kernel(const float* __restric
     }
 }
 
+// ... the same pair from maxima the PRODUCERS of the gz tensors left behind (bit patterns of max |gz|, one word per tensor: the
+// split-operand convolutions note it in their epilogues -- SplitConvParams::absmax, Block2Params::zmax / ymax): no pass over gz
+struct MaxFlagParams { const unsigned* f[WG_MAX_SEG]; int segments, words; };
+__global__ __launch_bounds__(1024) void wgrad_scale_flags_kernel(const MaxFlagParams p, float* __restrict__ scale)
+{
+    __shared__ unsigned red[16];
+    unsigned m = 0u;
+    for (int i = threadIdx.x; i < p.words; i += 1024) {
+#pragma unroll 8
+        for (int s = 0; s < p.segments; ++s) { const unsigned t = p.f[s][i]; m = t > m ? t : m; }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { const unsigned t = (unsigned)__shfl_xor((int)m, o, 64); m = t > m ? t : m; }
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int k = 1; k < 16; ++k) m = red[k] > m ? red[k] : m;
+        const float mx = __builtin_bit_cast(float, m);
+        int S = 0;
+        if (mx > 0.0f && mx < 3.0e38f) {
+            S = 13 - ilogbf(mx);
+            S = S < -100 ? -100 : (S > 100 ? 100 : S);
+        }
+        scale[0] = ldexpf(1.0f, S);
+        scale[1] = ldexpf(1.0f, -S);
+    }
+}
+
 // dw[co][ci][tap] = sum over the G slabs, in a fixed order (bitwise reproducible run to run).  A workgroup owns 64
 // consecutive slab elements; its four waves take the slabs g % 4 == wave with four loads in flight each and the
 // four partial sums are combined through LDS -- 576 workgroups x 16 independent loads instead of 144 x 8, the
@@ -1950,6 +1978,12 @@ int isrConv3x3WeightGradSegmentsBf16(const float* const* xs, const float* const*
 int isrConv3x3WeightGradSegmentsSplit(const float* const* xs, const float* const* gzs, int segments, float* dw, float* db, void* workspace,
                                       int N, int Cin, int H, int W, int Cout, void* stream)
 {
+    return isrConv3x3WeightGradSegmentsSplitMax(xs, gzs, nullptr, 0, segments, dw, db, workspace, N, Cin, H, W, Cout, stream);
+}
+
+int isrConv3x3WeightGradSegmentsSplitMax(const float* const* xs, const float* const* gzs, const void* const* gzmax, int maxWords, int segments,
+                                         float* dw, float* db, void* workspace, int N, int Cin, int H, int W, int Cout, void* stream)
+{
     if (!xs || !gzs || segments <= 0 || segments > WG_MAX_SEG || !dw || !workspace || N <= 0 || Cin <= 0 || Cout <= 0 || H <= 0 || W <= 0)
         return -1;
     if (W & 3) return -3;                          // the gz tile is fetched as aligned groups of four pixels
@@ -1984,8 +2018,19 @@ int isrConv3x3WeightGradSegmentsSplit(const float* const* xs, const float* const
     }
     const long long quads = ap.count >> 2;
     const int AB = (int)(quads < 512LL * 256 ? (quads + 255) / 256 > 0 ? (quads + 255) / 256 : 1 : 512);
-    hipLaunchKernelGGL(wgrad_absmax_kernel, dim3(AB), dim3(256), 0, s, ap, partial);
-    hipLaunchKernelGGL(wgrad_scale_kernel, dim3(1), dim3(256), 0, s, (const float*)partial, AB, scale);
+    if (gzmax) {
+        MaxFlagParams mp;
+        for (int k = 0; k < WG_MAX_SEG; ++k) {
+            mp.f[k] = k < segments ? (const unsigned*)gzmax[k] : nullptr;
+            if (k < segments && !gzmax[k]) return -1;
+        }
+        if (maxWords <= 0) return -1;
+        mp.segments = segments; mp.words = maxWords;
+        hipLaunchKernelGGL(wgrad_scale_flags_kernel, dim3(1), dim3(1024), 0, s, mp, scale);
+    } else {
+        hipLaunchKernelGGL(wgrad_absmax_kernel, dim3(AB), dim3(256), 0, s, ap, partial);
+        hipLaunchKernelGGL(wgrad_scale_kernel, dim3(1), dim3(256), 0, s, (const float*)partial, AB, scale);
+    }
     const int G = p.ntiles >= 512 ? 256 : (p.ntiles < WGRAD_MAX_SLABS ? p.ntiles : WGRAD_MAX_SLABS);
     for (int co0 = 0; co0 < Cout; co0 += 64)
         for (int ci0 = 0; ci0 < Cin; ci0 += 64) {

@@ -53,6 +53,9 @@ struct Block2Params {
     float* z; float* y;              // [N][64][H][W] each
     int N, H, W, tilesY;
     unsigned* absmax;                // range guard over z and y (may be NULL)
+    unsigned* zmax; unsigned* ymax;  // [4 x workgroups] bit patterns of max |z| / max |y| per WAVE (plain stores, may be NULL): the
+                                     // weight-gradient kernels scale their gz operand by the maximum (isrConv3x3WeightGradSegmentsSplitMax).
+                                     // (One word and atomics: 1024 waves on one address per launch cost 4.5 us per word.)
     int dbg;                         // diagnostics: 1 skip the MFMAs, 4 skip the stores
 };
 
@@ -215,7 +218,7 @@ __global__ __launch_bounds__(S_THREADS, 1) void conv3x3_split_block2_kernel(cons
         __syncthreads();
     }
     // ---- z: own rows to memory, all four rows into LDS as the second convolution's operand image (rows2 geometry) ------------------
-    unsigned mag = 0u;
+    unsigned mag = 0u, ymag = 0u;
     {
         const float unscale = reinterpret_cast<const float*>(p.wa)[1];
         const rsrc_t zrs = __builtin_amdgcn_make_buffer_rsrc(p.z + (size_t)n * image, 0, (int)(64u * planeBytes), 0x00020000);
@@ -313,12 +316,21 @@ __global__ __launch_bounds__(S_THREADS, 1) void conv3x3_split_block2_kernel(cons
             float4 val = reinterpret_cast<const float4*>(tr)[q];
             const float4 rf = __builtin_bit_cast(float4, rq[k]);
             val.x += rf.x; val.y += rf.y; val.z += rf.z; val.w += rf.w;
-            if (ok) mag = isr_umax(isr_umax(mag, isr_umax(isr_mag(val.x), isr_mag(val.y))), isr_umax(isr_mag(val.z), isr_mag(val.w)));
+            if (ok) ymag = isr_umax(isr_umax(ymag, isr_umax(isr_mag(val.x), isr_mag(val.y))), isr_umax(isr_mag(val.z), isr_mag(val.w)));
             __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, val), yrs,
                                                    (int)(ok ? (unsigned)co * planeBytes + (unsigned)(oy * p.W + px) * 4u : BAD_OFFSET), 0, 0);
         }
     }
-    isr_range_note(p.absmax, mag);
+    if (p.zmax) {
+        unsigned a = mag, b = ymag;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            a = isr_umax(a, (unsigned)__shfl_xor((int)a, o, 64));
+            b = isr_umax(b, (unsigned)__shfl_xor((int)b, o, 64));
+        }
+        if (lane == 0) { p.zmax[blockIdx.x * 4 + wave] = a; p.ymax[blockIdx.x * 4 + wave] = b; }
+    }
+    isr_range_note(p.absmax, isr_umax(mag, ymag));
 }
 
 } // namespace

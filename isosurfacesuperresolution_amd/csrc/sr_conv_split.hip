@@ -1104,6 +1104,8 @@ __global__ __launch_bounds__(256) void prepare_weights_split_many_kernel(const P
 
 __device__ u32x4 g_split_zero_unit[4];      // zero initialised: source of the zero-padding units of the LDS-DMA staging
 static unsigned* g_range_flag = nullptr;
+static unsigned* g_max_slots = nullptr;   // isrSetMaxSlots: per-wave maxima of the NEXT isrConv3x3ForwardSplit launch
+static int g_max_slot_cap = 0, g_max_slot_used = 0;
 unsigned* isr_take_range_flag() { unsigned* f = g_range_flag; g_range_flag = nullptr; return f; }
 static bool g_ps_in = false;       // set around the launch by isrConv3x3ForwardSplitFromPacked
 static bool g_ps_out = false;      // set around the launch by isrConv3x3ForwardSplitPacked (the library is single threaded by contract)
@@ -1118,6 +1120,8 @@ static int g_split_algo = 1;      // plain layers: 1 persistent streaming kernel
 extern "C" {
 
 void isrSetRangeFlag(unsigned* flag) { g_range_flag = flag; }
+void isrSetMaxSlots(void* words, int capacity) { g_max_slots = (unsigned*)words; g_max_slot_cap = capacity; g_max_slot_used = 0; }
+int isrTakeMaxSlotWords(void) { const int n = g_max_slot_used; g_max_slot_used = 0; return n; }
 // bit mask of the process-global diagnostic switches of this translation unit that are NOT in their default position
 // (bench.py refuses to report a number measured with any of them set): 1 ablation, 2 kernel form, 4 grid cap, 8 small-image
 // form off, 16 stamp buffer
@@ -1181,6 +1185,10 @@ int isrConv3x3ForwardSplit(const float* x, const void* wq, const float* bias, co
     p.ps = nullptr; p.psPlane = 0;
     p.xps = nullptr; p.xpsPlane = 0; p.zero = nullptr;
     p.absmax = isr_take_range_flag();
+    p.slotmax = nullptr;
+    unsigned* const maxSlots = g_max_slots;
+    const int maxCap = g_max_slot_cap;
+    g_max_slots = nullptr; g_max_slot_cap = 0; g_max_slot_used = 0;
     if (g_ps_in) {             // isrConv3x3ForwardSplitFromPacked: `x` is a packed-split tensor, xPlane its plane stride in units
         static u32x4* zero = nullptr;
         if (!zero && hipGetSymbolAddress((void**)&zero, HIP_SYMBOL(g_split_zero_unit)) != hipSuccess) return -2;
@@ -1255,6 +1263,7 @@ int isrConv3x3ForwardSplit(const float* x, const void* wq, const float* bias, co
         const long long want = nwg < cap ? ((nwg + 7) / 8) * 8 : cap;
         isr_profile_record(ISR_VARIANT_SPLIT_STREAM, 2.0 * 9 * Cin * Cout * (double)N * H * W, &e0, &e1);
         const dim3 pgrid((unsigned)want);
+        if (maxSlots && 4 * want <= maxCap) { p.slotmax = maxSlots; g_max_slot_used = (int)(4 * want); }
         if (e0 || e1) hipExtLaunchKernelGGL(conv3x3_split_stream_kernel, pgrid, block, S_LDS_BYTES, s, e0, e1, 0, p);
         else hipLaunchKernelGGL(conv3x3_split_stream_kernel, pgrid, block, S_LDS_BYTES, s, p);
         return hipGetLastError() == hipSuccess ? 0 : -2;
@@ -1336,15 +1345,16 @@ int isrResBlockSmallSupported(int N, int H, int W)
 }
 
 int isrResBlockSmall(const float* x, const void* wa, const float* ba, const float* gate, const void* wb, const float* bb, float* z, float* y,
-                     int N, int H, int W, void* stream)
+                     int N, int H, int W, void* zmax, void* ymax, void* stream)
 {
-    if (!x || !wa || !wb || !z || !y) return -1;
+    if (!x || !wa || !wb || !z || !y || (!zmax) != (!ymax)) return -1;
     if (!isrResBlockSmallSupported(N, H, W)) return -3;
     if (((uintptr_t)x & 15) || ((uintptr_t)y & 15) || ((uintptr_t)wa & 15) || ((uintptr_t)wb & 15)) return -1;
     Block2Params p;
     p.x = x; p.wa = (const u32x4*)wa; p.ba = ba; p.gate = gate; p.wb = (const u32x4*)wb; p.bb = bb; p.z = z; p.y = y;
     p.N = N; p.H = H; p.W = W; p.tilesY = (H + R2_H - 1) / R2_H;
     p.absmax = isr_take_range_flag();
+    p.zmax = (unsigned*)zmax; p.ymax = (unsigned*)ymax;
     p.dbg = g_split_dbg;
     static bool attr = false;
     if (!attr) { (void)hipFuncSetAttribute((const void*)conv3x3_split_block2_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, B2_LDS_BYTES); attr = true; }

@@ -57,6 +57,10 @@ struct SplitConvParams {
     // activation overflows fp16 at |x| >= 65520; the host reads the producers' maxima now and then and routes the CONSUMER of a
     // tensor that came close (>= 3e4) to the exact fp32 kernels (ops.RANGE_GUARD) -- no cliff, no host read inside a frame.
     unsigned* absmax;
+    // per-WAVE maxima (may be NULL; kernels that end in split_epilogue): word 4 blockIdx.x + wave of a zeroed array receives the bit
+    // pattern of the largest |value| the wave stores (an atomic maximum on an address nobody else touches).  Training: the weight-gradient
+    // kernels scale their gz operand by the tensor's maximum (isrConv3x3WeightGradSegmentsSplitMax) without a pass over it.
+    unsigned* slotmax;
 };
 
 // bit pattern of |v|: unsigned order = order of the magnitudes, inf above every finite value, NaN above inf (never lost)
@@ -243,6 +247,12 @@ __device__ __forceinline__ void split_epilogue(const SplitConvParams& p, f32x16 
             }
         }
     }
+    }
+    if (p.slotmax) {
+        unsigned m = mag;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) m = isr_umax(m, (unsigned)__shfl_xor((int)m, o, 64));
+        if (lane == 0) atomicMax(p.slotmax + blockIdx.x * 4 + wave, m);
     }
     isr_range_note(p.absmax, mag);
 }

@@ -56,7 +56,11 @@ def _sr():
         lib.isrConv3x3WeightGradSegmentsSplit.restype = ci
         lib.isrActBackward.argtypes = [vp, vp, vp, ll, ci, cf, vp]; lib.isrActBackward.restype = ci
         lib.isrResBlockSmallSupported.argtypes = [ci, ci, ci]; lib.isrResBlockSmallSupported.restype = ci
-        lib.isrResBlockSmall.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, ci, ci, ci, vp]; lib.isrResBlockSmall.restype = ci
+        lib.isrResBlockSmall.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, ci, ci, ci, vp, vp, vp]; lib.isrResBlockSmall.restype = ci
+        lib.isrConv3x3WeightGradSegmentsSplitMax.argtypes = [vp, vp, vp, ci, ci, vp, vp, vp, ci, ci, ci, ci, ci, vp]
+        lib.isrConv3x3WeightGradSegmentsSplitMax.restype = ci
+        lib.isrSetMaxSlots.argtypes = [vp, ci]; lib.isrSetMaxSlots.restype = None
+        lib.isrTakeMaxSlotWords.argtypes = []; lib.isrTakeMaxSlotWords.restype = ci
         lib.isrAssembleInput.argtypes = [vp, vp, vp, vp, ci, ci, ci, ci, vp]; lib.isrAssembleInput.restype = ci
         lib.isrConvSmallCinPad.argtypes = [ci]; lib.isrConvSmallCinPad.restype = ci
         lib.isrConvSmallWeightFloats.argtypes = [ci]; lib.isrConvSmallWeightFloats.restype = ll
@@ -589,6 +593,7 @@ TRAIN_SPLIT = True
 # retain_grad() on it switches the fusion off for that pair (tests/test_train_kernels_gpu.py), torch.autograd.grad on it does not.
 GATE_FUSION = True
 TRAIN_SPLIT_MIN_TILES = 256
+TRAIN_SPLIT_FEW_INPUTS = os.environ.get("ISR_TRAIN_SPLIT_FEW_INPUTS", "1") != "0"
 TRAIN_SPLIT_MIN_TILES2 = 128      # small images: 2-row tiles (the library picks that form below 256 tiles of 8x32 pixels)
 
 
@@ -608,10 +613,20 @@ def _train_conv(x, weight, transpose_flip, bias, residual, act):
     # tiles to fill the persistent grid: the 64^2 / 128^2 post-block layers of a crop batch, 54 % of the step's flops
     # ... or, for a batch of small crops, enough 2-row tiles for the small-image form (conv3x3_split_rows2_kernel)
     tiles2 = x.shape[0] * ((x.shape[2] + 1) // 2) * ((x.shape[3] + 31) // 32)
-    if TRAIN_SPLIT and cout > 8 and cin > 8 and (tiles >= TRAIN_SPLIT_MIN_TILES or tiles2 >= TRAIN_SPLIT_MIN_TILES2) \
+    # (few INPUT channels are fine -- the 6 -> 64 data gradient of the output layer is one k-step of mostly zero padding, a store-bound
+    # launch -- few OUTPUT channels are not: the 32-row MFMA tile would be mostly padding, conv3x3_small_cout_kernel takes those)
+    if TRAIN_SPLIT and cout > 8 and (cin > 8 or TRAIN_SPLIT_FEW_INPUTS) and (tiles >= TRAIN_SPLIT_MIN_TILES or tiles2 >= TRAIN_SPLIT_MIN_TILES2) \
             and x.shape[3] % 4 == 0 and _split_fits(x, cout, False):
         _tally("split", flops)
-        return _launch_split(x, _prepare_split(weight, transpose_flip), bias, residual, cout, act, 0.0, False, packed=True)
+        slot = _gmax_slot(x.device, _GMAX_CONV_WORDS) if transpose_flip else None    # a data gradient: some layer's gz later on
+        if slot is not None:
+            _sr().isrSetMaxSlots(ctypes.c_void_p(slot), _GMAX_CONV_WORDS)
+        y = _launch_split(x, _prepare_split(weight, transpose_flip), bias, residual, cout, act, 0.0, False, packed=True)
+        if slot is not None:
+            words = _sr().isrTakeMaxSlotWords()
+            if words > 0:
+                _gmax_tag(y, slot, words)
+        return y
     _tally("exact", flops)
     return _launch_forward(x, prepare_weights(weight, transpose_flip=transpose_flip), bias, residual, cin, cout, act, 0.0, False,
                            packed=True)
@@ -661,7 +676,12 @@ def _weight_grad(xs, gzs, weight, has_bias):
             lib.isrConv3x3WeightGradSegmentsSplit if (TRAIN_SPLIT and big) else lib.isrConv3x3WeightGradSegments)
         _tally("bf16" if (TRAIN_BF16 and big and cout > 8) else ("split" if (TRAIN_SPLIT and big) else "exact"),
                2.0 * 9 * cin * cout * n * len(part_x) * h * w)
-        rc = fn(px, pg, len(part_x), _ptr(dw), _ptr(db), _ptr(ws), n, cin, h, w, cout, _stream())
+        maxima = [_gmax_of(t) for t in part_g] if fn is lib.isrConv3x3WeightGradSegmentsSplit else [None]
+        if all(m is not None for m in maxima) and len(set(m[1] for m in maxima)) == 1:
+            pm = (ctypes.c_void_p * len(part_g))(*[m[0] for m in maxima])
+            rc = lib.isrConv3x3WeightGradSegmentsSplitMax(px, pg, pm, maxima[0][1], len(part_x), _ptr(dw), _ptr(db), _ptr(ws), n, cin, h, w, cout, _stream())
+        else:
+            rc = fn(px, pg, len(part_x), _ptr(dw), _ptr(db), _ptr(ws), n, cin, h, w, cout, _stream())
         if rc != 0:
             raise RuntimeError("isrConv3x3WeightGradSegments failed (%d)" % rc)
         gw = dw if gw is None else gw + dw
@@ -676,19 +696,60 @@ def _weight_grad(xs, gzs, weight, has_bias):
 # weight gradient; leaving the context runs ONE weight-gradient pass per layer over all recorded frames and adds the
 # result to ``weight.grad`` / ``bias.grad`` -- the same sums in another order.
 _deferred = None
+# The split-operand weight gradient scales gz by a power of two taken from max |gz| over the launch's tensors: a pass over every
+# gradient tensor.  Inside deferred_weight_gradients() the kernels that PRODUCE those tensors -- the fused small-image block
+# (isrResBlockSmall, backward direction: both outputs) and the persistent split-operand convolution (isrSetMaxSlots) -- leave the
+# maxima of their outputs in words of a per-step pool instead (one word per wave, no contention), the tensors are tagged with the words' address, and a layer whose gz tensors all carry a valid tag skips the pass
+# (isrConv3x3WeightGradSegmentsSplitMax).  The same maxima, the same scale: bit-identical gradients.
+GMAX_FROM_PRODUCERS = os.environ.get("ISR_GMAX_FROM_PRODUCERS", "1") != "0"
+_GMAX_WORDS = 1 << 20
+_GMAX_CONV_WORDS = 2048    # isrSetMaxSlots capacity: 4 words per workgroup of the persistent split kernel (2 per CU)
+_gmax = None              # {"pool": int32 tensor, "next": int} of the active deferred_weight_gradients() context
+
+
+def _gmax_slot(device, words):
+    """Address of `words` zeroed words for the maxima of a gradient tensor, or None (outside the context / switched off / pool used up)."""
+    global _gmax
+    if _deferred is None or not GMAX_FROM_PRODUCERS:
+        return None
+    if _gmax is None:
+        _gmax = {"pool": torch.zeros(_GMAX_WORDS, dtype=torch.int32, device=device), "next": 0}
+    if _gmax["pool"].device != device or _gmax["next"] + words > _GMAX_WORDS:
+        return None
+    _gmax["next"] += words
+    return _gmax["pool"].data_ptr() + 4 * (_gmax["next"] - words)
+
+
+def _gmax_tag(t, slot, words):
+    t._isr_gmax = (slot, words, t.data_ptr(), t._version, _gmax["pool"])      # the pool lives as long as a tag points into it
+
+
+def _gmax_of(t):
+    tag = getattr(t, '_isr_gmax', None)
+    if tag is None or tag[2] != t.data_ptr() or tag[3] != t._version or _gmax is None or tag[4] is not _gmax["pool"]:
+        return None
+    return tag[0], tag[1]
 
 
 class deferred_weight_gradients:
     def __enter__(self):
-        global _deferred
+        global _deferred, _gmax
         if _deferred is not None:
             raise RuntimeError("deferred_weight_gradients() does not nest")
         _deferred = {}
+        _gmax = None
         return self
 
     def __exit__(self, exc_type, exc, tb):
-        global _deferred
+        global _deferred, _gmax
         pending, _deferred = _deferred, None
+        try:
+            return self._finish(pending, exc_type)
+        finally:
+            _gmax = None
+
+    @staticmethod
+    def _finish(pending, exc_type):
         if exc_type is not None:
             return False
         for (_, shape), (weight, bias, xs, gzs) in pending.items():
@@ -745,10 +806,18 @@ def _block2(x, wa, ba, gate, wb, bb, transpose_flip):
     n, _, h, w = x.shape
     z, y = torch.empty_like(x), torch.empty_like(x)
     _tally("split", 2 * 2.0 * 9 * 64 * 64 * n * h * w)
+    words = 4 * n * ((h + 1) // 2)                                     # one per wave of the launch
+    zs = _gmax_slot(x.device, words) if transpose_flip else None      # data gradients: both outputs are some layer's gz
+    ys = _gmax_slot(x.device, words) if (transpose_flip and zs is not None) else None
+    if ys is None:
+        zs = None
     rc = _sr().isrResBlockSmall(_ptr(x), _ptr(_prepare_split(wa, transpose_flip)), _ptr(ba), _ptr(gate), _ptr(_prepare_split(wb, transpose_flip)),
-                                _ptr(bb), _ptr(z), _ptr(y), n, h, w, _stream())
+                                _ptr(bb), _ptr(z), _ptr(y), n, h, w, ctypes.c_void_p(zs), ctypes.c_void_p(ys), _stream())
     if rc != 0:
         raise RuntimeError("isrResBlockSmall failed (%d)" % rc)
+    if zs is not None:
+        _gmax_tag(z, zs, words)
+        _gmax_tag(y, ys, words)
     return z, y
 
 

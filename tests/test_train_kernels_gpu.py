@@ -546,6 +546,61 @@ def test_fused_small_image_residual_block_is_bit_identical_to_two_launches(shape
         assert (a.double() - ref).abs().max().item() <= 2e-5 * max(1e-3, ref.abs().max().item()), name
 
 
+def test_weight_gradient_scale_from_the_producers_maxima_is_bit_identical():
+    """Inside deferred_weight_gradients() the fused small-image block leaves max |output| of its two data gradients in pool words
+    (one per wave) and the split-operand weight gradient takes its gz scale from those words instead of a pass over gz
+    (ops.GMAX_FROM_PRODUCERS): every parameter gradient of a ten-frame clip through conv(relu) -> three residual blocks ->
+    conv(relu) -> conv EQUAL bit for bit with the switch off, and the tagged route did run."""
+    from isosurfacesuperresolution_amd import ops
+    g = torch.Generator().manual_seed(5)
+    mk = lambda *s, k=0.1: ((torch.rand(*s, generator=g) - 0.5) * k).cuda().requires_grad_()
+    w0, b0 = mk(64, 12, 3, 3), mk(64, k=0.2)
+    blocks = [(mk(64, 64, 3, 3), mk(64, k=0.2), mk(64, 64, 3, 3), mk(64, k=0.2)) for _ in range(3)]
+    w3, b3, w4, b4 = mk(64, 64, 3, 3), mk(64, k=0.2), mk(64, 64, 3, 3), mk(64, k=0.2)
+    params = [w0, b0] + [t for blk in blocks for t in blk] + [w3, b3, w4, b4]
+    frames = [((torch.rand(16, 12, 32, 32, generator=g) - 0.4)).cuda() for _ in range(10)]
+    calls = {"max": 0}
+    lib = ops._sr()
+    real = lib.isrConv3x3WeightGradSegmentsSplitMax
+
+    def counted(*a):
+        calls["max"] += 1
+        return real(*a)
+
+    out = {}
+    old = ops.GMAX_FROM_PRODUCERS
+    try:
+        for mode in (True, False):
+            ops.GMAX_FROM_PRODUCERS = mode
+            for t in params:
+                t.grad = None
+            lib.isrConv3x3WeightGradSegmentsSplitMax = counted
+            try:
+                with ops.deferred_weight_gradients():
+                    total = 0.0
+                    for x in frames:
+                        f = ops.conv3x3(x, w0, b0, act='relu')
+                        for blk in blocks:
+                            f = ops.residual_block(f, *blk)
+                        f = ops.conv3x3(ops.conv3x3(f, w3, b3, act='relu'), w4, b4)
+                        total = total + (f * f).sum() * 1e-4
+                    total.backward()
+            finally:
+                lib.isrConv3x3WeightGradSegmentsSplitMax = real
+            torch.cuda.synchronize()
+            out[mode] = [t.grad.clone() for t in params]
+            if mode:
+                assert calls["max"] == 5, calls          # conv1 of every block, conv2 of all but the last (whose gz is a plain layer's data gradient)
+                calls["max"] = 0
+            else:
+                assert calls["max"] == 0
+    finally:
+        ops.GMAX_FROM_PRODUCERS = old
+    for k, (a, b) in enumerate(zip(out[True], out[False])):
+        assert torch.equal(a, b), "parameter %d: %g" % (k, (a - b).abs().max().item())
+        assert a.abs().max().item() > 0
+
+
 def test_relu_backward_folded_into_the_consumers_data_gradient():
     """conv(relu) -> conv(relu) -> conv: with ops.GATE_FUSION the data gradient of a layer whose input is a ReLU conv3x3's
     output applies that ReLU's backward in its epilogue and the producer skips its isrActBackward; every gradient must be
