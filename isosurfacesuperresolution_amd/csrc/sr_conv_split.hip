@@ -1115,7 +1115,7 @@ static int g_split_small = 1;     // 2-row-tile kernel for small images (isrDebu
 static int g_split_slots = 0;     // tests: cap on the persistent kernels' grid (0 = two / one workgroup per CU)
 // upsampling layers: 3 = sr_conv_ups3.h (three workgroups per CU; default), 0 = the tile kernel (two); ISR_UPS_FORM overrides
 static int g_split_ups_form = getenv("ISR_UPS_FORM") ? atoi(getenv("ISR_UPS_FORM")) : 3;
-static int g_split_algo = 1;      // plain layers: 1 persistent streaming kernel (default), 2 wide 512-thread kernel, 0 one workgroup per tile
+static int g_split_algo = getenv("ISR_SPLIT_ALGO") ? atoi(getenv("ISR_SPLIT_ALGO")) : 1;      // (ISR_SPLIT_ALGO overrides) plain layers: 1 persistent streaming kernel (default), 2 wide 512-thread kernel, 0 one workgroup per tile
 
 extern "C" {
 
@@ -1257,7 +1257,9 @@ int isrConv3x3ForwardSplit(const float* x, const void* wq, const float* bias, co
     // has nothing to stream into and runs faster on the one-workgroup-per-tile form with its 32-channel staging passes (half the
     // barriers): 37.9 vs 42.5 us per layer in a chain of twenty (tools/bench_trunk_algos.py).  g_split_algo = 3 forces the
     // persistent form for every size.
-    const bool one_round = nwg <= (g_split_slots > 0 ? g_split_slots : slots);
+    // (Two rounds do not pay either: the 1024 tiles of a 16 x 64 x 128 x 128 training layer take 66-95 us on the persistent form and
+    // the step is 0.35 ms shorter with them on the one-workgroup-per-tile form; from three rounds on the persistent form stays.)
+    const bool one_round = nwg <= (g_split_slots > 0 ? g_split_slots : 2 * slots);
     if (!upsample2x && p.quads && !g_split_stamps && (g_split_algo == 3 || (g_split_algo == 1 && !one_round))) {
         const int cap = g_split_slots > 0 ? g_split_slots : slots;
         const long long want = nwg < cap ? ((nwg + 7) / 8) * 8 : cap;
@@ -1279,6 +1281,7 @@ int isrConv3x3ForwardSplit(const float* x, const void* wq, const float* bias, co
         if (e0 || e1) hipExtLaunchKernelGGL((conv3x3_split_kernel<true>), grid, block, S_LDS_BYTES, s, e0, e1, 0, p);
         else hipLaunchKernelGGL((conv3x3_split_kernel<true>), grid, block, S_LDS_BYTES, s, p);
     } else {
+        if (maxSlots && !p.ps && 4 * nwg <= maxCap) { p.slotmax = maxSlots; g_max_slot_used = (int)(4 * nwg); }
         if (e0 || e1) hipExtLaunchKernelGGL((conv3x3_split_kernel<false>), grid, block, S_LDS_BYTES, s, e0, e1, 0, p);
         else hipLaunchKernelGGL((conv3x3_split_kernel<false>), grid, block, S_LDS_BYTES, s, p);
     }

@@ -703,7 +703,7 @@ _deferred = None
 # (isrConv3x3WeightGradSegmentsSplitMax).  The same maxima, the same scale: bit-identical gradients.
 GMAX_FROM_PRODUCERS = os.environ.get("ISR_GMAX_FROM_PRODUCERS", "1") != "0"
 _GMAX_WORDS = 1 << 20
-_GMAX_CONV_WORDS = 2048    # isrSetMaxSlots capacity: 4 words per workgroup of the persistent split kernel (2 per CU)
+_GMAX_CONV_WORDS = 8192    # isrSetMaxSlots capacity: 4 words per workgroup (up to four per CU on the one-workgroup-per-tile form)
 _gmax = None              # {"pool": int32 tensor, "next": int} of the active deferred_weight_gradients() context
 
 
