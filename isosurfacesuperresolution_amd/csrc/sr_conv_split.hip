@@ -334,7 +334,8 @@ __global__ __launch_bounds__(S_THREADS, 2) void conv3x3_split_kernel(const Split
 
     if (p.stamps) st2 = __builtin_amdgcn_s_memrealtime();
     if (p.ps) split_epilogue_ps(p, acc, oy0, ox0, co0, second, wave, j, h);
-    else split_epilogue(p, acc, patch, n, oy0, ox0, co0, second, lane, wave, j, h);
+    else if (UPS) split_epilogue(p, acc, patch, n, oy0, ox0, co0, second, lane, wave, j, h);
+    else split_epilogue<false, 0, true>(p, acc, patch, n, oy0, ox0, co0, second, lane, wave, j, h);
     if (p.stamps && tid == 0) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         const unsigned long long st3 = __builtin_amdgcn_s_memrealtime();

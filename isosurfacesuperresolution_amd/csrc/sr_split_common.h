@@ -165,7 +165,7 @@ __device__ __forceinline__ void split_epilogue_ps(const SplitConvParams& p, f32x
 // WIDE_ONLY: the caller guarantees W and both plane strides are multiples of 4 (the per-element path is not compiled in).
 // AUX: cache policy of the output stores (0 plain; 16 = sc1, write-through to memory: the dataflow kernels' hand-off, see
 // sr_conv_trunk.hip).
-template <bool WIDE_ONLY = false, int AUX = 0>
+template <bool WIDE_ONLY = false, int AUX = 0, bool RES_AHEAD = false>
 __device__ __forceinline__ void split_epilogue(const SplitConvParams& p, f32x16 (&acc)[2][2], u32x4* patch, int n, int oy0, int ox0, int co0,
                                                bool second, int lane, int wave, int j, int h)
 {
@@ -186,6 +186,22 @@ __device__ __forceinline__ void split_epilogue(const SplitConvParams& p, f32x16 
         // wide path: each wave transposes one output row (64 couts x 32 pixels) through 8 KB of the now idle patch, so
         // that a lane owns 4 consecutive pixels of one channel and the stores are dwordx4 (4x fewer instructions)
         float* tr = reinterpret_cast<float*>(patch) + wave * (64 * 32);
+        // the residual / gate operand of both rows up front: behind the first store the compiler may not move a load any more (it
+        // cannot know that y and the residual do not overlap), and sixteen load -> use -> store round trips in a row cost a gated
+        // data gradient a third of its launch
+        // (RES_AHEAD: 64 registers -- only where the register budget has them: the one-workgroup-per-tile plain kernel)
+        u32x4 rq[2][8];
+        if (RES_AHEAD && p.residual) {
+#pragma unroll
+            for (int r = 0; r < 2; ++r)
+#pragma unroll
+                for (int t = 0; t < 8; ++t) {
+                    const int q = lane + 64 * t, oy = oy0 + wave * 2 + r;
+                    const int co = co0 + (q >> 3), px = ox0 + (q & 7) * 4;
+                    const bool ok = oy < p.H && px < p.W && co < p.Cout;
+                    rq[r][t] = __builtin_amdgcn_raw_buffer_load_b128(rrs, (int)(ok ? (unsigned)(oy * p.W + px) * 4u + (unsigned)co * (unsigned)p.rPlane * 4u : BAD_OFFSET), 0, 0);
+                }
+        }
 #pragma unroll
         for (int r = 0; r < 2; ++r) {
             const int oy = oy0 + wave * 2 + r;
@@ -207,8 +223,8 @@ __device__ __forceinline__ void split_epilogue(const SplitConvParams& p, f32x16 
                 float4 v = reinterpret_cast<const float4*>(tr)[q];
                 const unsigned pixoff = (unsigned)(oy * p.W + px) * 4u;
                 if (p.residual) {
-                    const u32x4 rr = __builtin_amdgcn_raw_buffer_load_b128(rrs, (int)(ok ? pixoff + (unsigned)co * (unsigned)p.rPlane * 4u : BAD_OFFSET), 0, 0);
-                    const float4 rf = __builtin_bit_cast(float4, rr);
+                    if (!RES_AHEAD) rq[r][t] = __builtin_amdgcn_raw_buffer_load_b128(rrs, (int)(ok ? pixoff + (unsigned)co * (unsigned)p.rPlane * 4u : BAD_OFFSET), 0, 0);
+                    const float4 rf = __builtin_bit_cast(float4, rq[r][t]);
                     if (p.act == ISR_ACT_GATE) {
                         v.x = rf.x > 0.f ? v.x : 0.f; v.y = rf.y > 0.f ? v.y : 0.f;
                         v.z = rf.z > 0.f ? v.z : 0.f; v.w = rf.w > 0.f ? v.w : 0.f;
