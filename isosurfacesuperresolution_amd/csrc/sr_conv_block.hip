@@ -149,7 +149,7 @@ __global__ __launch_bounds__(B_THREADS, 2) void resblock_split_kernel(const Bloc
     p2.xPlane = p.xPlane; p2.yPlane = p.yPlane; p2.rPlane = p.xPlane;
     p2.xImage = 0; p2.yImage = 0; p2.rImage = 0;
     p2.ksteps = 4; p2.coutPad = 64; p2.cgroups = 1; p2.tilesX = p.tilesX; p2.tilesY = p.tilesY;
-    p2.act = ISR_ACT_NONE; p2.slope = 0.0f; p2.Hin = p.H; p2.Win = p.W; p2.quads = 1; p2.dbg = 0; p2.stamps = nullptr; p2.ps = nullptr; p2.psPlane = 0; p2.xps = nullptr; p2.xpsPlane = 0; p2.zero = nullptr; p2.absmax = p.absmax;
+    p2.act = ISR_ACT_NONE; p2.slope = 0.0f; p2.Hin = p.H; p2.Win = p.W; p2.quads = 1; p2.dbg = 0; p2.stamps = nullptr; p2.ps = nullptr; p2.psPlane = 0; p2.xps = nullptr; p2.xpsPlane = 0; p2.zero = nullptr; p2.absmax = p.absmax; p2.slotmax = nullptr;
 
     // The two workgroups of a CU share its SIMDs, and issue arbitration prefers the OLDER wave: the first-dispatched workgroup
     // of a CU runs near full speed, the second (in practice blockIdx >= half the grid) gets the leftovers and finishes ~20 us

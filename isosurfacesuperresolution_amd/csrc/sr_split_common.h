@@ -60,7 +60,7 @@ struct SplitConvParams {
     // per-WAVE maxima (may be NULL; kernels that end in split_epilogue): word 4 blockIdx.x + wave of a zeroed array receives the bit
     // pattern of the largest |value| the wave stores (an atomic maximum on an address nobody else touches).  Training: the weight-gradient
     // kernels scale their gz operand by the tensor's maximum (isrConv3x3WeightGradSegmentsSplitMax) without a pass over it.
-    unsigned* slotmax;
+    unsigned* slotmax = nullptr;     // (default: parameter blocks filled field by field elsewhere -- sr_conv_block.hip, sr_conv_tail.hip -- leave it off)
 };
 
 // bit pattern of |v|: unsigned order = order of the magnitudes, inf above every finite value, NaN above inf (never lost)
