@@ -20,3 +20,7 @@ rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/fetch -o r
 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/write -o run -- python3 bench.py --mode train --steps 3 --warmup 1 --no-cpu-baseline > $OUT/write.log 2>&1
 find $OUT -name "*kernel_trace.csv" -size +8M -delete
 du -sh $OUT
+# condensed tables for profiles/ (copy what you want judged): kernel stats csv + the PMC summary
+cp $(find $OUT/stats -name "*kernel_stats.csv" | head -1) $OUT/r03_train_kernel_stats.csv
+python3 tools/pmc_summary.py r03_train $OUT/fetch $OUT/write > $OUT/pmc_summary.log 2>&1
+ls profiles/ | grep r03_train
