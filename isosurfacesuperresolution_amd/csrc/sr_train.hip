@@ -90,29 +90,44 @@ __global__ __launch_bounds__(256) void upsample2x_bwd_kernel(const float* __rest
 // instead of 64 single ones).  Every output is the same expression in the same order as in the kernels above: same bits.
 __global__ __launch_bounds__(256) void upsample2x_fwd4_kernel(const float* __restrict__ x, float* __restrict__ y, int h, int w, unsigned count)
 {
-    const unsigned W = 2u * w, QW = W / 4u;
-    const unsigned t = blockIdx.x * 256u + threadIdx.x;                      // (plane, iy, qx)
+    // a thread = input row iy, input columns 4 q .. 4 q + 3 -> the 2 x 8 output block below them: the 3 x 6 input window is read as
+    // three quads + six border values (18 loads for 16 outputs, four quad stores)
+    const unsigned W = 2u * w, qw = (unsigned)w / 4u;
+    const unsigned t = blockIdx.x * 256u + threadIdx.x;
     if (t >= count) return;
-    const unsigned qx = t % QW, r = t / QW, iy = r % (unsigned)h, plane = r / (unsigned)h;
+    const unsigned q = t % qw, r = t / qw, iy = r % (unsigned)h, plane = r / (unsigned)h;
+    const int ix0 = (int)(4 * q);
     const float* src = x + (size_t)plane * h * w;
-    float* dst = y + ((size_t)plane * 2 * h + 2 * iy) * W + 4 * qx;
-    int x0[4], x1[4]; float lx[4];
+    float* dst = y + ((size_t)plane * 2 * h + 2 * iy) * W + 2 * ix0;
+    const int ym = iy > 0 ? (int)iy - 1 : 0, yp = (int)iy < h - 1 ? (int)iy + 1 : (int)iy;
+    const int xm = ix0 > 0 ? ix0 - 1 : 0, xp = ix0 + 4 < w ? ix0 + 4 : w - 1;
+    float v[3][6];
+    const int rows[3] = { ym, (int)iy, yp };
 #pragma unroll
-    for (int k = 0; k < 4; ++k) isr_src_index((int)(4 * qx) + k, 0.5f, w, x0[k], x1[k], lx[k]);
+    for (int k = 0; k < 3; ++k) {
+        const float* row = src + (size_t)rows[k] * w;
+        const float4 c = *reinterpret_cast<const float4*>(row + ix0);
+        v[k][0] = row[xm]; v[k][1] = c.x; v[k][2] = c.y; v[k][3] = c.z; v[k][4] = c.w; v[k][5] = row[xp];
+    }
 #pragma unroll
     for (int d = 0; d < 2; ++d) {
+        // output row 2 iy + d blends window rows (d, d + 1), output column 2 ix0 + e window columns ((e + 1) / 2, (e + 1) / 2 + 1): what
+        // isr_src_index returns, except at the image border, where it clamps both taps onto the border pixel and returns weight 0 for
+        // the second -- the window holds the border pixel in both slots there, so the value is the same (finite inputs)
         int y0, y1; float ly;
         isr_src_index((int)(2 * iy) + d, 0.5f, h, y0, y1, ly);
         const float hy = 1.f - ly;
-        const float* r0 = src + (size_t)y0 * w;
-        const float* r1 = src + (size_t)y1 * w;
-        float o[4];
+        float o[8];
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const float hx = 1.f - lx[k];
-            o[k] = hy * (hx * r0[x0[k]] + lx[k] * r0[x1[k]]) + ly * (hx * r1[x0[k]] + lx[k] * r1[x1[k]]);
+        for (int e = 0; e < 8; ++e) {
+            int x0, x1; float lx;
+            isr_src_index(2 * ix0 + e, 0.5f, w, x0, x1, lx);
+            const float hx = 1.f - lx;
+            const int c0 = (e + 1) >> 1, c1 = c0 + 1;
+            o[e] = hy * (hx * v[d][c0] + lx * v[d][c1]) + ly * (hx * v[d + 1][c0] + lx * v[d + 1][c1]);
         }
         *reinterpret_cast<float4*>(dst + (size_t)d * W) = make_float4(o[0], o[1], o[2], o[3]);
+        *reinterpret_cast<float4*>(dst + (size_t)d * W + 4) = make_float4(o[4], o[5], o[6], o[7]);
     }
 }
 
@@ -736,8 +751,8 @@ int isrUpsample2xForward(const float* x, float* y, long long planes, int h, int 
 {
     if (!x || !y || planes <= 0 || h <= 0 || w <= 0 || (w & 1)) return -1;
     const long long quads = planes * (2LL * h) * (2 * w / 4);
-    if (!(w & 1) && quads < 0x7fffffffLL && !(((uintptr_t)y) & 15)) {         // 2 w a multiple of 4: whole output quads
-        const unsigned count = (unsigned)(quads / 2);
+    if (!(w & 3) && quads < 0x7fffffffLL && !(((uintptr_t)y | (uintptr_t)x) & 15)) {
+        const unsigned count = (unsigned)(quads / 4);                         // a thread per four input pixels
         hipLaunchKernelGGL(upsample2x_fwd4_kernel, dim3((count + 255) / 256), dim3(256), 0, (hipStream_t)stream, x, y, h, w, count);
         return hipGetLastError() == hipSuccess ? 0 : -2;
     }
