@@ -1258,9 +1258,10 @@ int isrConv3x3ForwardSplit(const float* x, const void* wq, const float* bias, co
     // has nothing to stream into and runs faster on the one-workgroup-per-tile form with its 32-channel staging passes (half the
     // barriers): 37.9 vs 42.5 us per layer in a chain of twenty (tools/bench_trunk_algos.py).  g_split_algo = 3 forces the
     // persistent form for every size.
-    // (Two rounds do not pay either: the 1024 tiles of a 16 x 64 x 128 x 128 training layer take 66-95 us on the persistent form and
-    // the step is 0.35 ms shorter with them on the one-workgroup-per-tile form; from three rounds on the persistent form stays.)
-    const bool one_round = nwg <= (g_split_slots > 0 ? g_split_slots : 2 * slots);
+    // (A few rounds do not pay either: the 1024 tiles of a 16 x 64 x 128 x 128 training layer take 66-95 us on the persistent form and
+    // the step is 0.35 ms shorter with them on the one-workgroup-per-tile form; the 2040 tiles of a 960 x 540 layer of the tiled 4K
+    // mode 124 against 129 us.  Beyond four rounds the persistent form stays.)
+    const bool one_round = nwg <= (g_split_slots > 0 ? g_split_slots : 4 * slots);
     if (!upsample2x && p.quads && !g_split_stamps && (g_split_algo == 3 || (g_split_algo == 1 && !one_round))) {
         const int cap = g_split_slots > 0 ? g_split_slots : slots;
         const long long want = nwg < cap ? ((nwg + 7) / 8) * 8 : cap;
