@@ -57,6 +57,8 @@ struct Block2Params {
                                      // weight-gradient kernels scale their gz operand by the maximum (isrConv3x3WeightGradSegmentsSplitMax).
                                      // (One word and atomics: 1024 waves on one address per launch cost 4.5 us per word.)
     int dbg;                         // diagnostics: 1 skip the MFMAs, 4 skip the stores
+    unsigned long long* stamps;      // diagnostics: [workgroup][8] s_memrealtime ticks (100 MHz): entry | x patch parked | stage 1 done |
+                                     // z image written | stage 2 done | stores issued | stores drained
 };
 
 // the fragments of one tap: stage 1 (two z rows share the weights) / stage 2
@@ -99,6 +101,9 @@ __global__ __launch_bounds__(S_THREADS, 1) void conv3x3_split_block2_kernel(cons
         const int nwg = gridDim.x, q = nwg >> 3, r = nwg & 7, xcd = blockIdx.x & 7;
         bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (blockIdx.x >> 3);
     }
+    auto lap = [&](int slot) { if (p.stamps && tid == 0) p.stamps[(size_t)blockIdx.x * 8 + slot] = __builtin_amdgcn_s_memrealtime(); };
+    unsigned long long clk1 = 0;       // shader-clock ticks over stage 1 (slot 7): the clock the kernel runs at = ticks / (10 ns x real-time ticks)
+    lap(0);
     // the biases travel with the first staging pass (a global load per channel in the epilogues would queue behind their stores)
     float bval = 0.0f;
     if (tid < 128) {
@@ -166,6 +171,8 @@ __global__ __launch_bounds__(S_THREADS, 1) void conv3x3_split_block2_kernel(cons
     if (tid < 128) biases[tid] = bval;
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
+    lap(1);
+    if (p.stamps) clk1 = __builtin_amdgcn_s_memtime();
 
     // ---- stage 1: z rows `row` and `row + 2` of the four (image rows oy0 - 1 + tr), 32 channels each --------------------------------
     const rsrc_t grs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.gate ? p.gate + (size_t)n * image : p.x), 0,
@@ -217,6 +224,8 @@ __global__ __launch_bounds__(S_THREADS, 1) void conv3x3_split_block2_kernel(cons
         else asm volatile("s_waitcnt vmcnt(9)" ::: "memory");
         __syncthreads();
     }
+    lap(2);
+    if (p.stamps && tid == 0) p.stamps[(size_t)blockIdx.x * 8 + 7] = __builtin_amdgcn_s_memtime() - clk1;
     // ---- z: own rows to memory, all four rows into LDS as the second convolution's operand image (rows2 geometry) ------------------
     unsigned mag = 0u, ymag = 0u;
     {
@@ -227,11 +236,17 @@ __global__ __launch_bounds__(S_THREADS, 1) void conv3x3_split_block2_kernel(cons
             const int part = tid >> 6, g = (tid >> 3) & 7, r4 = (tid >> 1) & 3;
             patch[part * R2_PART + g * R2_PIX + r4 * SP_W + ((tid & 1) ? SP_W - 1 : 0)] = zero;
         }
+        // this lane's sixteen bias values (the same channels for both rows) in one batch: a ds_read per value between the stores cost
+        // the forward launch a microsecond
+        float bz[16];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) bz[i] = p.gate ? 0.0f : biases[cb * 32 + (i & 3) + 8 * (i >> 2) + 4 * h];
+        const bool track = p.absmax != nullptr || p.zmax != nullptr;
 #pragma unroll
         for (int s = 0; s < 2; ++s) {
             const int tr = row + 2 * s, iy = oy0 - 1 + tr;
             const bool in = (unsigned)iy < (unsigned)p.H && j < p.W;
-            const bool own = in && (tr == 1 || tr == 2) && !(p.dbg & 4);
+            const bool ownRow = (tr == 1 || tr == 2) && !(p.dbg & 4);         // wave uniform: the halo rows are not stored at all
             const unsigned pix = (unsigned)(iy * p.W + j) * 4u;
 #pragma unroll
             for (int g4 = 0; g4 < 4; ++g4) {
@@ -243,10 +258,10 @@ __global__ __launch_bounds__(S_THREADS, 1) void conv3x3_split_block2_kernel(cons
                     const int c = cb * 32 + e + 8 * g4 + 4 * h;
                     float val = (s ? zb[i] : za[i]) * unscale;
                     if (p.gate) val = gv[s][i] > 0.f ? val : 0.f;
-                    else { val += biases[c]; val = val > 0.f ? val : 0.f; }
+                    else { val += bz[i]; val = val > 0.f ? val : 0.f; }
                     if (!in) val = 0.0f;
-                    mag = isr_umax(mag, isr_mag(val));
-                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, val), zrs, own ? (int)((unsigned)c * planeBytes + pix) : (int)BAD_OFFSET, 0, 0);
+                    if (track) mag = isr_umax(mag, isr_mag(val));
+                    if (ownRow) __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, val), zrs, in ? (int)((unsigned)c * planeBytes + pix) : (int)BAD_OFFSET, 0, 0);
                     _Float16 a, b;
                     split16x(val, a, b);
                     vh[e] = a; vl[e] = b;
@@ -268,6 +283,7 @@ __global__ __launch_bounds__(S_THREADS, 1) void conv3x3_split_block2_kernel(cons
         rq[k] = __builtin_amdgcn_raw_buffer_load_b128(xrs, (int)(ok ? (unsigned)co * planeBytes + (unsigned)(oy * p.W + px) * 4u : BAD_OFFSET), 0, 0);
     }
     __syncthreads();
+    lap(3);
 
     // ---- stage 2: output row `row`, 32 channels (conv3x3_split_rows2_kernel's loop on the z image) ----------------------------------
     f32x16 acc;
@@ -297,6 +313,7 @@ __global__ __launch_bounds__(S_THREADS, 1) void conv3x3_split_block2_kernel(cons
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
     }
+    lap(4);
     // ---- y = conv + bias + x: one output row x 32 channels per wave, transposed through 4 KB of the idle patch -----------------------
     if (!(p.dbg & 4)) {
         const float unscale = reinterpret_cast<const float*>(p.wb)[1];
@@ -321,6 +338,8 @@ __global__ __launch_bounds__(S_THREADS, 1) void conv3x3_split_block2_kernel(cons
                                                    (int)(ok ? (unsigned)co * planeBytes + (unsigned)(oy * p.W + px) * 4u : BAD_OFFSET), 0, 0);
         }
     }
+    lap(5);
+    if (p.stamps) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); lap(6); }
     if (p.zmax) {
         unsigned a = mag, b = ymag;
 #pragma unroll

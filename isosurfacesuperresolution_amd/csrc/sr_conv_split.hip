@@ -1360,7 +1360,7 @@ int isrResBlockSmall(const float* x, const void* wa, const float* ba, const floa
     p.N = N; p.H = H; p.W = W; p.tilesY = (H + R2_H - 1) / R2_H;
     p.absmax = isr_take_range_flag();
     p.zmax = (unsigned*)zmax; p.ymax = (unsigned*)ymax;
-    p.dbg = g_split_dbg;
+    p.dbg = g_split_dbg; p.stamps = g_split_stamps;
     static bool attr = false;
     if (!attr) { (void)hipFuncSetAttribute((const void*)conv3x3_split_block2_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, B2_LDS_BYTES); attr = true; }
     hipEvent_t e0 = nullptr, e1 = nullptr;
