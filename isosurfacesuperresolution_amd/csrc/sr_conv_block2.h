@@ -56,7 +56,7 @@ struct Block2Params {
     unsigned* zmax; unsigned* ymax;  // [4 x workgroups] bit patterns of max |z| / max |y| per WAVE (plain stores, may be NULL): the
                                      // weight-gradient kernels scale their gz operand by the maximum (isrConv3x3WeightGradSegmentsSplitMax).
                                      // (One word and atomics: 1024 waves on one address per launch cost 4.5 us per word.)
-    int dbg;                         // diagnostics: 1 skip the MFMAs, 4 skip the stores
+    int dbg;                         // diagnostics: 1 skip the MFMAs, 4 skip the stores, 8 stage 1 on operands read once per k-step, 16 no weight DMA, 32 stage 1 eight times
     unsigned long long* stamps;      // diagnostics: [workgroup][8] s_memrealtime ticks (100 MHz): entry | x patch parked | stage 1 done |
                                      // z image written | stage 2 done | stores issued | stores drained
 };
@@ -133,6 +133,7 @@ __global__ __launch_bounds__(S_THREADS, 1) void conv3x3_split_block2_kernel(cons
     // k-step gk (0..3: wa, 4..7: wb) into ring buffer gk % 3: 36 pieces of 64 units (part, tap, lane half; the 64 couts contiguous in
     // the prepared image), nine per wave
     auto wdma = [&](int gk) {
+        if (p.dbg & 16) return;                                              // diagnostics: no weight traffic
         const char* img = reinterpret_cast<const char*>(gk < 4 ? p.wa : p.wb) + 16;
         const unsigned dst = wAddr + (unsigned)(gk % B2_WRING) * (S_WUNITS * 16);
 #pragma unroll
@@ -181,8 +182,10 @@ __global__ __launch_bounds__(S_THREADS, 1) void conv3x3_split_block2_kernel(cons
     f32x16 za, zb;
 #pragma unroll
     for (int i = 0; i < 16; ++i) { za[i] = 0.0f; zb[i] = 0.0f; }
+    const int reps1 = (p.dbg & 32) ? 32 : 4;                                // diagnostics: stage 1 eight times over (with 16: steady-state rate)
 #pragma unroll 1
-    for (int gk = 0; gk < 4; ++gk) {
+    for (int gq = 0; gq < reps1; ++gq) {
+        const int gk = gq & 3;
         wdma(gk + 2);                                                        // two k-steps ahead (gk = 2, 3: the second stage's first two)
         if (gk == 2 && p.gate) {                                             // the gate operand of the epilogue: in flight under two k-steps
 #pragma unroll
@@ -202,6 +205,14 @@ __global__ __launch_bounds__(S_THREADS, 1) void conv3x3_split_block2_kernel(cons
             // the operands of tap t + 1 are requested BEFORE the six MFMAs of tap t are issued (left to itself the compiler reads
             // each fragment right in front of its MFMA and waits for it: one wave per SIMD, nothing else to run meanwhile)
             B2Taps1 cur = b2_taps1(wl, bl, 0);
+            if (p.dbg & 8) {                                                 // diagnostics: the k-step's 54 MFMAs on operands read once
+                const f16x8 as = cur.ah * (_Float16)0.00048828125f;
+#pragma unroll
+                for (int t = 0; t < 9; ++t) {
+                    za = mfma16(cur.al, cur.bh0, za); za = mfma16(as, cur.bo0, za); za = mfma16(cur.ah, cur.bh0, za);
+                    zb = mfma16(cur.al, cur.bh1, zb); zb = mfma16(as, cur.bo1, zb); zb = mfma16(cur.ah, cur.bh1, zb);
+                }
+            } else
 #pragma unroll
             for (int tap = 0; tap < 9; ++tap) {
                 B2Taps1 nxt = cur;

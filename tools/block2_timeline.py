@@ -7,9 +7,15 @@ from isosurfacesuperresolution_amd import ops
 
 lib = ops._sr()
 lib.isrDebugSetSplitStampBuffer.argtypes = [ctypes.c_void_p]
+lib.isrDebugSetSplitAblation.argtypes = [ctypes.c_int]
+import os
+lib.isrDebugSetSplitAblation(int(os.environ.get("ISR_SPLIT_ABLATE", "0")))
 n, h, w = 16, 32, 32
-x = (torch.rand(n, 64, h, w, device="cuda") - 0.3)
+zero = os.environ.get("ISR_ZERO_DATA", "0") == "1"        # all-zero activations and weights: the matrix pipe at its lowest power
+x = (torch.rand(n, 64, h, w, device="cuda") - 0.3) * (0.0 if zero else 1.0)
 ws = [((torch.rand(64, 64, 3, 3, device="cuda") - 0.5) * 0.1) for _ in range(2)]
+if zero:
+    ws = [torch.full((64, 64, 3, 3), 1e-30, device="cuda") for _ in range(2)]
 bs = [((torch.rand(64, device="cuda") - 0.5) * 0.2) for _ in range(2)]
 t = torch.relu(torch.randn(n, 64, h, w, device="cuda"))
 nwg = n * ((h + 1) // 2)
@@ -36,5 +42,5 @@ for name, fn in (("forward", lambda v: ops._block2(v, ws[0], bs[0], None, ws[1],
         print("   %-40s median %5.2f  90%% %5.2f" % (names[k], np.median(a), np.percentile(a, 90)))
         prev = st[:, k]
     raw = buf.cpu().numpy().reshape(-1, 8).astype(np.float64)
-    print("   shader clock over stage 1: %.2f GHz (median), %.0f cycles per MFMA" % (np.median(raw[:, 7] / ((raw[:, 2] - raw[:, 1]) * 10.0)), np.median(raw[:, 7]) / 216))
+    print("   shader clock over stage 1: %.2f GHz (median), %.0f cycles per MFMA" % (np.median(raw[:, 7] / ((raw[:, 2] - raw[:, 1]) * 10.0)), np.median(raw[:, 7]) / (216 * (8 if int(os.environ.get('ISR_SPLIT_ABLATE', '0')) & 32 else 1))))
     print("   life median %.2f us, span of the launch (first entry -> last drain) %.2f us" % (np.median(st[:, 6] - st[:, 0]), st[:, 6].max() - t0))
