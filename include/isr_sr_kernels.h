@@ -147,15 +147,9 @@ int isrTakeMaxSlotWords(void);
  * ymax, isrSetMaxSlots: one word per wave); the pass over gz that ...Split makes to find its scale is skipped.  gzmax == NULL: exactly ...Split. */
 int isrConv3x3WeightGradSegmentsSplitMax(const float* const* xs, const float* const* gzs, const void* const* gzmax, int maxWords, int segments,
                                          float* dw, float* db, void* workspace, int N, int Cin, int H, int W, int Cout, void* stream);
-/* The deferred form for a training step's many layers: ...SplitDeferred launches the scale and the weight-gradient kernel of ONE
- * layer (Cin, Cout <= 64) into ITS OWN workspace (isrConvWeightGradWorkspace bytes, kept until the flush) and returns the number of
- * slabs (> 0) or an error (< 0); isrWeightGradReduceMany then reduces the slabs of up to 32 such layers in one launch and writes --
- * or, per layer, accumulate bit 0 (dw) / bit 1 (db), ADDS -- the gradients: the same values as ...SplitMax followed by `grad += dw`.
- * HOST arrays of n entries; db[l] may be NULL; split_scaled = 1 for workspaces filled by ...SplitDeferred. */
-int isrConv3x3WeightGradSplitDeferred(const float* const* xs, const float* const* gzs, const void* const* gzmax, int maxWords, int segments,
-                                      int want_bias, void* workspace, int N, int Cin, int H, int W, int Cout, void* stream);
-int isrWeightGradReduceMany(int n, const void* const* workspaces, const int* G, float* const* dw, float* const* db, const int* cout, const int* cin,
-                            const int* accumulate, int split_scaled, void* stream);
+/* isrSetWeightGradAccumulate(bits) arms the NEXT ...SegmentsSplit / ...SplitMax call: bit 0 -> dw += the gradient, bit 1 -> db += (instead
+ * of =), i.e. the slab reduction adds straight into a parameter's .grad; the same bits as the call followed by `grad += dw`. */
+void isrSetWeightGradAccumulate(int bits);
 int isrConv3x3WeightGradSegmentsBf16(const float* const* xs, const float* const* gzs, int segments, float* dw, float* db, void* workspace,
                                      int N, int Cin, int H, int W, int Cout, void* stream);
 

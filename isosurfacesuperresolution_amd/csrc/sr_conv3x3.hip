@@ -1641,7 +1641,8 @@ __global__ __launch_bounds__(1024) void wgrad_scale_flags_kernel(const MaxFlagPa
 // reduction of 256 slabs (38 MB) is latency bound otherwise.  Workgroup 576 reduces the 64 bias sums the same way.
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ slabs, int G, float* __restrict__ dw,
                                     int Cout, int Cin, int co0, int ci0, const float* __restrict__ bslabs, float* __restrict__ db,
-                                    const float* __restrict__ scale = nullptr)      // split kernel: slabs hold sums scaled by scale[0]
+                                    const float* __restrict__ scale = nullptr,      // split kernel: slabs hold sums scaled by scale[0]
+                                    int accumulate = 0)                             // bit 0: dw += (bit 1: db +=) instead of = : straight into .grad
 {
     __shared__ float part[4][64];
     const int lane = threadIdx.x & 63, q = threadIdx.x >> 6;
@@ -1661,57 +1662,16 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
     if (q != 0) return;
     const float total = (part[0][lane] + part[1][lane]) + (part[2][lane] + part[3][lane]);
     if (isBias) {
-        if (co0 + lane < Cout) db[co0 + lane] = total;
+        if (co0 + lane < Cout) db[co0 + lane] = (accumulate & 2) ? __fadd_rn(db[co0 + lane], total) : total;
         return;
     }
     const int e = blockIdx.x * 64 + lane;                    // over [9][64][64]
     const int ci = e & 63, co = (e >> 6) & 63, tap = e >> 12;
     if (co0 + co >= Cout || ci0 + ci >= Cin) return;
-    dw[((size_t)(co0 + co) * Cin + (ci0 + ci)) * 9 + tap] = scale ? total * scale[1] : total;
-}
-
-// The slab reductions of up to 32 layers in ONE launch (blockIdx.y = layer), optionally ADDING to dw / db: the deferred weight
-// gradients of a training step are 26 layers -- 26 reductions of 8 us and 48 `grad += dw` launches of 5 us otherwise.  Same sums
-// in the same order as wgrad_reduce_kernel, the product with 2^-S and the addition rounded separately (as the two launches did).
-constexpr int WGRAD_MANY = 32;
-struct ReduceManyParams {
-    const float* slabs[WGRAD_MANY]; const float* bslabs[WGRAD_MANY]; const float* scale[WGRAD_MANY];
-    float* dw[WGRAD_MANY]; float* db[WGRAD_MANY];
-    int G[WGRAD_MANY], cout[WGRAD_MANY], cin[WGRAD_MANY], accumulate[WGRAD_MANY];     // accumulate: bit 0 dw, bit 1 db
-};
-__global__ __launch_bounds__(256) void wgrad_reduce_many_kernel(const ReduceManyParams p)
-{
-    __shared__ float part[4][64];
-    const int L = blockIdx.y;
-    const int lane = threadIdx.x & 63, q = threadIdx.x >> 6;
-    const bool isBias = blockIdx.x == 9 * 64;
-    const float* bslabs = p.bslabs[L];
-    if (isBias && (!bslabs || !p.db[L])) return;
-    const int G = p.G[L];
-    const size_t stride = isBias ? 64 : (size_t)9 * 64 * 64;
-    const float* src = (isBias ? bslabs : p.slabs[L] + (size_t)blockIdx.x * 64) + lane;
-    float s[4] = { 0.f, 0.f, 0.f, 0.f };
-    int g = q;
-    for (; g + 12 < G; g += 16) {
-#pragma unroll
-        for (int k = 0; k < 4; ++k) s[k] += src[(size_t)(g + 4 * k) * stride];
-    }
-    for (int k = 0; g < G; g += 4, ++k) s[k] += src[(size_t)g * stride];
-    part[q][lane] = (s[0] + s[1]) + (s[2] + s[3]);
-    __syncthreads();
-    if (q != 0) return;
-    const float total = (part[0][lane] + part[1][lane]) + (part[2][lane] + part[3][lane]);
-    const int Cout = p.cout[L], Cin = p.cin[L], acc = p.accumulate[L];
-    if (isBias) {
-        if (lane < Cout) p.db[L][lane] = (acc & 2) ? __fadd_rn(p.db[L][lane], total) : total;
-        return;
-    }
-    const int e = blockIdx.x * 64 + lane;                    // over [9][64][64]
-    const int ci = e & 63, co = (e >> 6) & 63, tap = e >> 12;
-    if (co >= Cout || ci >= Cin) return;
-    const float gval = p.scale[L] ? __fmul_rn(total, p.scale[L][1]) : total;
-    float* dst = p.dw[L] + ((size_t)co * Cin + ci) * 9 + tap;
-    *dst = (acc & 1) ? __fadd_rn(*dst, gval) : gval;
+    // (product and sum rounded separately: the same bits as this kernel followed by `grad += dw`)
+    const float gval = scale ? __fmul_rn(total, scale[1]) : total;
+    float* dst = dw + ((size_t)(co0 + co) * Cin + (ci0 + ci)) * 9 + tap;
+    *dst = (accumulate & 1) ? __fadd_rn(*dst, gval) : gval;
 }
 
 constexpr int WGRAD_MAX_SLABS = 512;
@@ -2025,44 +1985,16 @@ int isrConv3x3WeightGradSegmentsSplit(const float* const* xs, const float* const
     return isrConv3x3WeightGradSegmentsSplitMax(xs, gzs, nullptr, 0, segments, dw, db, workspace, N, Cin, H, W, Cout, stream);
 }
 
-static bool g_wgrad_skip_reduce = false;   // set around the launch by isrConv3x3WeightGradSplitDeferred
-static int g_wgrad_last_slabs = 0;
-
-int isrConv3x3WeightGradSplitDeferred(const float* const* xs, const float* const* gzs, const void* const* gzmax, int maxWords, int segments,
-                                      int want_bias, void* workspace, int N, int Cin, int H, int W, int Cout, void* stream)
-{
-    if (Cin > 64 || Cout > 64) return -3;                // one channel group: the slabs of a second one would overwrite the first's
-    float dummy = 0.0f;                                  // dw / db are only checked for NULL when the reduction is skipped
-    g_wgrad_skip_reduce = true; g_wgrad_last_slabs = 0;
-    const int rc = isrConv3x3WeightGradSegmentsSplitMax(xs, gzs, gzmax, maxWords, segments, &dummy, want_bias ? &dummy : nullptr, workspace, N, Cin, H, W, Cout, stream);
-    g_wgrad_skip_reduce = false;
-    return rc != 0 ? rc : g_wgrad_last_slabs;
-}
-
-int isrWeightGradReduceMany(int n, const void* const* workspaces, const int* G, float* const* dw, float* const* db, const int* cout, const int* cin,
-                            const int* accumulate, int split_scaled, void* stream)
-{
-    if (n <= 0 || n > WGRAD_MANY || !workspaces || !G || !dw || !db || !cout || !cin || !accumulate) return -1;
-    ReduceManyParams p;
-    for (int l = 0; l < WGRAD_MANY; ++l) {
-        const bool on = l < n;
-        if (on && (!workspaces[l] || !dw[l] || G[l] <= 0 || G[l] > WGRAD_MAX_SLABS || cout[l] <= 0 || cout[l] > 64 || cin[l] <= 0 || cin[l] > 64)) return -1;
-        const float* slabs = on ? (const float*)workspaces[l] : nullptr;
-        const float* bslabs = on ? slabs + (size_t)WGRAD_MAX_SLABS * 9 * 64 * 64 : nullptr;
-        p.slabs[l] = slabs; p.bslabs[l] = on && db[l] ? bslabs : nullptr;
-        p.scale[l] = on && split_scaled ? bslabs + (size_t)WGRAD_MAX_SLABS * 64 + 512 : nullptr;      // the layout of ...SegmentsSplit's workspace
-        p.dw[l] = on ? dw[l] : nullptr; p.db[l] = on ? db[l] : nullptr;
-        p.G[l] = on ? G[l] : 0; p.cout[l] = on ? cout[l] : 0; p.cin[l] = on ? cin[l] : 0; p.accumulate[l] = on ? accumulate[l] : 0;
-    }
-    hipLaunchKernelGGL(wgrad_reduce_many_kernel, dim3(9 * 64 + 1, n), dim3(256), 0, (hipStream_t)stream, p);
-    return hipGetLastError() == hipSuccess ? 0 : -2;
-}
+static int g_wgrad_accumulate = 0;      // isrSetWeightGradAccumulate: taken (and cleared) by the next ...SegmentsSplit[Max] call
+void isrSetWeightGradAccumulate(int bits) { g_wgrad_accumulate = bits & 3; }
 
 int isrConv3x3WeightGradSegmentsSplitMax(const float* const* xs, const float* const* gzs, const void* const* gzmax, int maxWords, int segments,
                                          float* dw, float* db, void* workspace, int N, int Cin, int H, int W, int Cout, void* stream)
 {
     if (!xs || !gzs || segments <= 0 || segments > WG_MAX_SEG || !dw || !workspace || N <= 0 || Cin <= 0 || Cout <= 0 || H <= 0 || W <= 0)
         return -1;
+    const int accumulate = g_wgrad_accumulate;
+    g_wgrad_accumulate = 0;
     if (W & 3) return -3;                          // the gz tile is fetched as aligned groups of four pixels
     hipStream_t s = (hipStream_t)stream;
     WGradParams p;
@@ -2115,9 +2047,8 @@ int isrConv3x3WeightGradSegmentsSplitMax(const float* const* xs, const float* co
             p.bslabs = (db && ci0 == 0) ? bslabs : nullptr;
             if (g_wgrad_split_form == 2) hipLaunchKernelGGL(conv3x3_wgrad_split2_kernel, dim3(G), dim3(W2_THREADS), W2_LDS_BYTES, s, p);
             else hipLaunchKernelGGL(conv3x3_wgrad_split_kernel, dim3(G), dim3(NTHREADS), WS_LDS_BYTES, s, p);
-            if (g_wgrad_skip_reduce) { g_wgrad_last_slabs = G; continue; }       // isrWeightGradReduceMany will
             hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(9 * 64 + 1), dim3(256), 0, s,
-                               p.slabs, G, dw, Cout, Cin, co0, ci0, (const float*)p.bslabs, db, (const float*)scale);
+                               p.slabs, G, dw, Cout, Cin, co0, ci0, (const float*)p.bslabs, db, (const float*)scale, accumulate);
         }
     return hipGetLastError() == hipSuccess ? 0 : -2;
 }

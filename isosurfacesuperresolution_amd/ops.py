@@ -60,9 +60,7 @@ def _sr():
         lib.isrConv3x3WeightGradSegmentsSplitMax.argtypes = [vp, vp, vp, ci, ci, vp, vp, vp, ci, ci, ci, ci, ci, vp]
         lib.isrConv3x3WeightGradSegmentsSplitMax.restype = ci
         lib.isrSetMaxSlots.argtypes = [vp, ci]; lib.isrSetMaxSlots.restype = None
-        lib.isrConv3x3WeightGradSplitDeferred.argtypes = [vp, vp, vp, ci, ci, ci, vp, ci, ci, ci, ci, ci, vp]
-        lib.isrConv3x3WeightGradSplitDeferred.restype = ci
-        lib.isrWeightGradReduceMany.argtypes = [ci, vp, vp, vp, vp, vp, vp, vp, ci, vp]; lib.isrWeightGradReduceMany.restype = ci
+        lib.isrSetWeightGradAccumulate.argtypes = [ci]; lib.isrSetWeightGradAccumulate.restype = None
         lib.isrTakeMaxSlotWords.argtypes = []; lib.isrTakeMaxSlotWords.restype = ci
         lib.isrAssembleInput.argtypes = [vp, vp, vp, vp, ci, ci, ci, ci, vp]; lib.isrAssembleInput.restype = ci
         lib.isrConvSmallCinPad.argtypes = [ci]; lib.isrConvSmallCinPad.restype = ci
@@ -755,9 +753,8 @@ class deferred_weight_gradients:
     def _finish(pending, exc_type):
         if exc_type is not None:
             return False
-        batch = []
         for (_, shape), (weight, bias, xs, gzs) in pending.items():
-            if _weight_grad_batched(xs, gzs, weight, bias, batch):
+            if _weight_grad_into_grad(xs, gzs, weight, bias):
                 continue
             gw, gb = _weight_grad(xs, gzs, weight, bias is not None)
             for param, g in ((weight, gw), (bias, gb)):
@@ -767,41 +764,37 @@ class deferred_weight_gradients:
                     param.grad = g.view_as(param)
                 else:
                     param.grad.add_(g.view_as(param))
-        _weight_grad_flush(batch)
         return False
 
 
-# The deferred pass over a step's layers, batched: every layer that takes the split-operand kernel in one piece (<= 32 frames, one
-# 64-channel group) launches its weight-gradient kernel into its OWN slab workspace, and ONE launch then reduces the slabs of all of
-# them straight into (+=) the parameters' .grad -- instead of a reduction launch per layer and a `grad += dw` launch per parameter
-# (26 + 48 launches of 5-8 us).  Same sums, same roundings (tests/test_train_kernels_gpu.py).
-WGRAD_BATCHED = os.environ.get("ISR_WGRAD_BATCHED", "1") != "0"
+# The deferred pass writes straight into .grad: a layer that takes the split-operand kernel in one piece (<= 32 frames) has its slab
+# reduction ADD to the parameters' gradients (isrSetWeightGradAccumulate) instead of producing dw / db for a `grad += dw` launch per
+# parameter (47 launches per step).  Same sums, same roundings (tests/test_train_kernels_gpu.py).  (Tried: the weight-gradient kernels
+# of all layers back to back and ONE reduction launch at the end -- 71 launches fewer, the same step time: the slabs, 38 MB per layer,
+# then come back from memory instead of the caches.)
+WGRAD_INTO_GRAD = os.environ.get("ISR_WGRAD_INTO_GRAD", "1") != "0"
 
 
-def _weight_grad_batched(xs, gzs, weight, bias, batch):
-    """Launch this layer's weight-gradient kernel for the batched reduction and append its record to ``batch``; False: not eligible."""
+def _weight_grad_into_grad(xs, gzs, weight, bias):
+    """The layer's weight (and bias) gradient added to ``weight.grad`` / ``bias.grad`` by the reduction itself; False: not eligible."""
     lib = _sr()
     cout, cin = weight.shape[0], weight.shape[1]
     n, _, h, w = xs[0].shape
     tiles = n * len(xs) * ((h + 3) // 4) * ((w + 31) // 32)
-    if not (WGRAD_BATCHED and TRAIN_SPLIT and not TRAIN_BF16 and len(batch) < 32 and len(xs) <= lib.isrConvWeightGradMaxSegments()
-            and cin <= 64 and cout <= 64 and w % 4 == 0 and tiles >= 1024 and all(t.data_ptr() % 16 == 0 for t in gzs)):
+    if not (WGRAD_INTO_GRAD and TRAIN_SPLIT and not TRAIN_BF16 and len(xs) <= lib.isrConvWeightGradMaxSegments()
+            and w % 4 == 0 and tiles >= 1024 and all(t.data_ptr() % 16 == 0 for t in gzs)):
         return False
-    if any(b[2][0] is weight.grad and weight.grad is not None for b in batch) or any(b[6] is weight for b in batch):
-        return False                        # a second use of the same weights: its `+=` must not run beside the first one's
-    targets = []
-    for param in (weight, bias):
+    bits = 0
+    for k, param in enumerate((weight, bias)):
         if param is None:
-            targets.append((None, 0))
             continue
         if not param.requires_grad or (param.grad is not None and not param.grad.is_contiguous()):
             return False
         if param.grad is None:
             param.grad = torch.empty_like(param, memory_format=torch.contiguous_format)
-            targets.append((param.grad, 0))
         else:
-            targets.append((param.grad, 1))
-    ws = torch.empty(lib.isrConvWeightGradWorkspace(n, cin, h, w, cout), dtype=torch.uint8, device=weight.device)
+            bits |= 1 << k
+    ws = _wgrad_workspace(weight.device, lib.isrConvWeightGradWorkspace(n, cin, h, w, cout))
     px = (ctypes.c_void_p * len(xs))(*[t.data_ptr() for t in xs])
     pg = (ctypes.c_void_p * len(gzs))(*[t.data_ptr() for t in gzs])
     maxima = [_gmax_of(t) for t in gzs]
@@ -810,25 +803,12 @@ def _weight_grad_batched(xs, gzs, weight, bias, batch):
     else:
         pm, words = None, 0
     _tally("split", 2.0 * 9 * cin * cout * n * len(xs) * h * w)
-    slabs = lib.isrConv3x3WeightGradSplitDeferred(px, pg, pm, words, len(xs), 1 if bias is not None else 0, _ptr(ws), n, cin, h, w, cout, _stream())
-    if slabs <= 0:
-        raise RuntimeError("isrConv3x3WeightGradSplitDeferred failed (%d)" % slabs)
-    batch.append((ws, slabs, targets[0], targets[1], cout, cin, weight))
-    return True
-
-
-def _weight_grad_flush(batch):
-    if not batch:
-        return
-    n = len(batch)
-    vp, ci = ctypes.c_void_p, ctypes.c_int
-    rc = _sr().isrWeightGradReduceMany(
-        n, (vp * n)(*[b[0].data_ptr() for b in batch]), (ci * n)(*[b[1] for b in batch]),
-        (vp * n)(*[b[2][0].data_ptr() for b in batch]), (vp * n)(*[(b[3][0].data_ptr() if b[3][0] is not None else None) for b in batch]),
-        (ci * n)(*[b[4] for b in batch]), (ci * n)(*[b[5] for b in batch]), (ci * n)(*[b[2][1] | (b[3][1] << 1) for b in batch]), 1, _stream())
+    lib.isrSetWeightGradAccumulate(bits)
+    rc = lib.isrConv3x3WeightGradSegmentsSplitMax(px, pg, pm, words, len(xs), _ptr(weight.grad), _ptr(bias.grad if bias is not None else None),
+                                                  _ptr(ws), n, cin, h, w, cout, _stream())
     if rc != 0:
-        raise RuntimeError("isrWeightGradReduceMany failed (%d)" % rc)
-    batch.clear()
+        raise RuntimeError("isrConv3x3WeightGradSegmentsSplitMax failed (%d)" % rc)
+    return True
 
 
 def _has_grad_hooks(p):

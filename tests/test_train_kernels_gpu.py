@@ -561,7 +561,7 @@ def test_weight_gradient_scale_from_the_producers_maxima_is_bit_identical():
     frames = [((torch.rand(16, 12, 32, 32, generator=g) - 0.4)).cuda() for _ in range(10)]
     calls = {"max": 0}
     lib = ops._sr()
-    real = lib.isrConv3x3WeightGradSplitDeferred
+    real = lib.isrConv3x3WeightGradSegmentsSplitMax
 
     def counted(*a):
         calls["max"] += 1 if a[2] is not None else 0        # a[2]: the maxima's addresses
@@ -574,7 +574,7 @@ def test_weight_gradient_scale_from_the_producers_maxima_is_bit_identical():
             ops.GMAX_FROM_PRODUCERS = mode
             for t in params:
                 t.grad = None
-            lib.isrConv3x3WeightGradSplitDeferred = counted
+            lib.isrConv3x3WeightGradSegmentsSplitMax = counted
             try:
                 with ops.deferred_weight_gradients():
                     total = 0.0
@@ -586,7 +586,7 @@ def test_weight_gradient_scale_from_the_producers_maxima_is_bit_identical():
                         total = total + (f * f).sum() * 1e-4
                     total.backward()
             finally:
-                lib.isrConv3x3WeightGradSplitDeferred = real
+                lib.isrConv3x3WeightGradSegmentsSplitMax = real
             torch.cuda.synchronize()
             out[mode] = [t.grad.clone() for t in params]
             if mode:
@@ -601,9 +601,9 @@ def test_weight_gradient_scale_from_the_producers_maxima_is_bit_identical():
         assert a.abs().max().item() > 0
 
 
-def test_batched_slab_reduction_into_grad_is_bit_identical():
-    """ops.WGRAD_BATCHED: the deferred layers' slabs reduced in ONE launch straight into (+=) .grad, against a reduction launch per
-    layer and `grad += dw` per parameter -- with gradients already present (second clip accumulates onto the first) and absent."""
+def test_slab_reduction_into_grad_is_bit_identical():
+    """ops.WGRAD_INTO_GRAD: the deferred layers' slab reductions add straight into .grad (isrSetWeightGradAccumulate), against
+    `grad += dw` per parameter -- with gradients already present (second clip accumulates onto the first) and absent."""
     from isosurfacesuperresolution_amd import ops
     g = torch.Generator().manual_seed(9)
     mk = lambda *s, k=0.1: ((torch.rand(*s, generator=g) - 0.5) * k).cuda().requires_grad_()
@@ -613,10 +613,10 @@ def test_batched_slab_reduction_into_grad_is_bit_identical():
     params = [w0, b0] + [t for blk in blocks for t in blk if t is not None] + [w3]
     clips = [[((torch.rand(16, 12, 32, 32, generator=g) - 0.4)).cuda() for _ in range(10)] for _ in range(2)]
     out = {}
-    old = ops.WGRAD_BATCHED
+    old = ops.WGRAD_INTO_GRAD
     try:
         for mode in (True, False):
-            ops.WGRAD_BATCHED = mode
+            ops.WGRAD_INTO_GRAD = mode
             for t in params:
                 t.grad = None
             for frames in clips:                                        # no zero_grad in between: the second pass accumulates
@@ -632,7 +632,7 @@ def test_batched_slab_reduction_into_grad_is_bit_identical():
             torch.cuda.synchronize()
             out[mode] = [t.grad.clone() for t in params]
     finally:
-        ops.WGRAD_BATCHED = old
+        ops.WGRAD_INTO_GRAD = old
     for k, (a, b) in enumerate(zip(out[True], out[False])):
         assert torch.equal(a, b), "parameter %d: %g" % (k, (a - b).abs().max().item())
         assert a.abs().max().item() > 0
