@@ -75,6 +75,9 @@ class SuperResolutionPipeline:
         # where in the network the next frame's render is released (experiment switch): trunk | ups1 | ups2 | tail = when the trunk,
         # the first / second upsampling layer, or everything but the last launch has ended
         self.prefetch_point = os.environ.get("ISR_PREFETCH_POINT", "trunk")
+        # the flow hole filling of the prefetched frame: on the side stream behind its render (1), or on the main stream in front of the
+        # next frame's input assembly (0)
+        self.flow_fill_on_side = os.environ.get("ISR_FLOW_FILL_ON_SIDE", "1") != "0"
         self._trunk_done = torch.cuda.Event() if torch.cuda.is_available() else None
         self.previous = None
         self.foreground_variant = 0       # kernel variant of frames rendered on the main stream
@@ -125,7 +128,7 @@ class SuperResolutionPipeline:
             self.renderer.set_wave_cap(self.side_waves)
         self.renderer.render_async(self._gbuffers[slot], rs)
         self.renderer.set_kernel_variant(self.foreground_variant)
-        self._flow_ready[slot] = self.fused and self.temporal
+        self._flow_ready[slot] = self.fused and self.temporal and self.flow_fill_on_side
         if self._flow_ready[slot]:
             ops.fill_flow_gbuffer(self._gbuffers[slot], out=self._flows[slot], stream=rs, threads=256)
         self._ready[slot].record(rs)
