@@ -458,9 +458,14 @@ __global__ __launch_bounds__(T16_THREADS) void trunk_dataflow_kernel(const Trunk
 // x fp32 planes [cin][xPlane] -> packed-split [hi | lo][groups][npix + 1 units] (channels beyond cin are zero), and the zero unit
 // that ends every plane of the three packed-split tensors of the launch (the padding pixels of the LDS-DMA staging read it)
 __global__ __launch_bounds__(256) void trunk_pack_input_kernel(const float* __restrict__ x, int cin, long long xPlane, int npix, u32x4* __restrict__ ps,
-                                                               int groups, u32x4* __restrict__ fps, u32x4* __restrict__ tps)
+                                                               int groups, u32x4* __restrict__ fps, u32x4* __restrict__ tps,
+                                                               unsigned* __restrict__ done, int ntiles)
 {
     const int pix = blockIdx.x * 256 + threadIdx.x, g = blockIdx.y;
+    // ... and the tiles' progress counters back to zero for the launch that follows (a hipMemsetAsync of 1 036 bytes was two fill
+    // kernels and two more kernel boundaries per frame)
+    if (blockIdx.x == 0 && g == 0)
+        for (int i = threadIdx.x; i < ntiles; i += 256) done[i] = 0u;
     const size_t plane = ((size_t)npix + 8) & ~(size_t)7;
     const u32x4 zero = {0u, 0u, 0u, 0u};
     if (blockIdx.x == 0 && threadIdx.x < 2) {
@@ -567,12 +572,12 @@ int isrTrunkDataflow(const float* x, int cin0, long long xPlane, float* y, long 
     hipStream_t s = (hipStream_t)stream;
     // the progress counters start at zero every launch; the error word behind them is STICKY (the caller zero-fills the workspace
     // once, reads the word when it likes and resets it then): an error of any launch since the last look stays visible
-    if (hipMemsetAsync(workspace, 0, 16 + (size_t)ntiles * sizeof(unsigned), s) != hipSuccess) return -2;
+    // (trunk_pack_input_kernel zeroes the counters; the 16-byte zero unit in front of them is never written)
     static bool attr = false;
     if (!attr) { (void)hipFuncSetAttribute((const void*)trunk_dataflow_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, T16_LDS_BYTES); attr = true; }
     const int npix = H * W;
     hipLaunchKernelGGL(trunk_pack_input_kernel, dim3((unsigned)((npix + 255) / 256), (unsigned)(lay.groups0 > 8 ? lay.groups0 : 8)), dim3(256), 0, s,
-                       x, cin0, xPlane, npix, xps, lay.groups0, (u32x4*)(ws + lay.fps), (u32x4*)(ws + lay.tps));
+                       x, cin0, xPlane, npix, xps, lay.groups0, (u32x4*)(ws + lay.fps), (u32x4*)(ws + lay.tps), p.done, ntiles);
     hipEvent_t e0 = nullptr, e1 = nullptr;
     isr_profile_record(ISR_VARIANT_SPLIT_TRUNK, 2.0 * 9 * 64 * ((double)cin0 + 2.0 * nblocks * 64) * (double)H * W, &e0, &e1);
     const dim3 grid((unsigned)(((ntiles + 7) / 8) * 8)), block(T16_THREADS);
