@@ -1,6 +1,6 @@
 // Micro-benchmark: cycles per v_mfma_f32_32x32x16_f16 on one SIMD (one wave per SIMD, 256 workgroups of 4 waves), as a function of the
 // number of INDEPENDENT accumulators the MFMAs rotate over (1: one dependent chain; 2, 4, 8), with constant operands in registers.
-// s_memtime ticks / MFMAs.   hipcc -O3 --offload-arch=gfx950 tools/mfma_f16_rate.hip -o gpurun_out/mfma_f16_rate && ./gpurun_out/mfma_f16_rate
+// s_memtime ticks / MFMAs.   hipcc -O3 --offload-arch=gfx950 tools/mfma_f16_rate.hip -o tools/bin/mfma_f16_rate (git-ignored; it travels with gpurun) && ./tools/bin/mfma_f16_rate
 #include <hip/hip_runtime.h>
 #include <cstdio>
 typedef float f32x16 __attribute__((ext_vector_type(16)));
