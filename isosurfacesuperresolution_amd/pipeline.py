@@ -78,6 +78,7 @@ class SuperResolutionPipeline:
         # the flow hole filling of the prefetched frame: on the side stream behind its render (1), or on the main stream in front of the
         # next frame's input assembly (0)
         self.flow_fill_on_side = os.environ.get("ISR_FLOW_FILL_ON_SIDE", "1") != "0"
+        self.flow_fill_threads = int(os.environ.get("ISR_FLOW_FILL_THREADS", "1024"))     # workgroup size of its two full-grid passes (1024: 541-544 against 536-541 frames/s with 256)
         self._trunk_done = torch.cuda.Event() if torch.cuda.is_available() else None
         self.previous = None
         self.foreground_variant = 0       # kernel variant of frames rendered on the main stream
@@ -130,7 +131,7 @@ class SuperResolutionPipeline:
         self.renderer.set_kernel_variant(self.foreground_variant)
         self._flow_ready[slot] = self.fused and self.temporal and self.flow_fill_on_side
         if self._flow_ready[slot]:
-            ops.fill_flow_gbuffer(self._gbuffers[slot], out=self._flows[slot], stream=rs, threads=256)
+            ops.fill_flow_gbuffer(self._gbuffers[slot], out=self._flows[slot], stream=rs, threads=self.flow_fill_threads)
         self._ready[slot].record(rs)
         self._prefetched = (tuple(origin), slot)
 
