@@ -78,7 +78,7 @@ class SuperResolutionPipeline:
         # the flow hole filling of the prefetched frame: on the side stream behind its render (1), or on the main stream in front of the
         # next frame's input assembly (0)
         self.flow_fill_on_side = os.environ.get("ISR_FLOW_FILL_ON_SIDE", "1") != "0"
-        self.flow_fill_threads = int(os.environ.get("ISR_FLOW_FILL_THREADS", "1024"))     # workgroup size of its two full-grid passes (1024: 541-544 against 536-541 frames/s with 256)
+        self.flow_fill_threads = int(os.environ.get("ISR_FLOW_FILL_THREADS", "256"))      # workgroup size of its two full-grid passes (1024: +0.6 % on one box, nothing on another and one 2.4 ms outlier run: a 1024-thread workgroup has to find 16 free wave slots on ONE CU beside the convolutions)
         self._trunk_done = torch.cuda.Event() if torch.cuda.is_available() else None
         self.previous = None
         self.foreground_variant = 0       # kernel variant of frames rendered on the main stream
