@@ -5,10 +5,11 @@ shading) at a 256^3 volume, 480x270 -> 1920x1080 (BASELINE.json configs[1]).
     python bench.py --gpus N --steps K --warmup W
 
 A "step" is one frame of the orbit camera path of SURVEY.md 8(d) on synthetic data (V256-ejecta
-stand-in volume, seeded random-init EnhanceNet weights).  With N > 1 (launched by
-torch.distributed.run, one rank per GPU) every rank renders its own contiguous chunk of the
-sequence, started with ``initialImage``: weak scaling, no data-path collective.
-Rank 0 prints ONE JSON line.
+stand-in volume, seeded random-init EnhanceNet weights).  With N > 1 there is one rank per GPU: either
+torch.distributed.run launched them (WORLD_SIZE is set), or this process starts them itself
+(``launch_ranks``: N fresh children before anything touches a GPU) -- every rank renders its own
+contiguous chunk of the sequence, started with ``initialImage``: weak scaling, no
+data-path collective.  Rank 0 prints ONE JSON line.
 
 Two further modes time the collectives SURVEY.md 8(e) defines (each prints its own JSON line, with its own metric):
 
@@ -151,8 +152,75 @@ class Job:
             dist.destroy_process_group()
 
 
+def launch_ranks(args, argv):
+    """``python bench.py --gpus N`` WITHOUT a launcher (no WORLD_SIZE in the environment): this process becomes the launcher.
+    It starts N fresh child processes of the same script and arguments -- one rank per GPU, RANK / LOCAL_RANK / WORLD_SIZE /
+    MASTER_ADDR / MASTER_PORT set the way torch.distributed.run sets them -- relays rank 0's stdout (the ONE JSON line),
+    sends the other ranks' stdout to stderr, and returns the first non-zero exit code (ending the remaining ranks by their
+    exact PIDs when one fails, so that a dead rank cannot leave the others in a collective forever).  The launcher never
+    imports torch and never touches a GPU; the children are ordinary processes, nothing is exec'd over an initialised
+    runtime.  Under torch.distributed.run (WORLD_SIZE set) this function is not reached."""
+    import socket
+    import subprocess
+    import threading
+    n = args.gpus
+    port = os.environ.get("MASTER_PORT")
+    if not port:
+        with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
+            s.bind(("127.0.0.1", 0))
+            port = str(s.getsockname()[1])
+    script = os.path.abspath(sys.argv[0])
+    children = []
+    for rank in range(n):
+        env = dict(os.environ, RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR=os.environ.get("MASTER_ADDR", "127.0.0.1"), MASTER_PORT=port)
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or n) // n)))
+        children.append(subprocess.Popen([sys.executable, script] + list(argv), env=env,
+                                         stdout=None if rank == 0 else subprocess.PIPE, stderr=None))
+
+    def to_stderr(rank, pipe):
+        for line in iter(pipe.readline, b""):
+            sys.stderr.write("[rank %d] %s" % (rank, line.decode(errors="replace")))
+        pipe.close()
+    relays = [threading.Thread(target=to_stderr, args=(r, c.stdout), daemon=True) for r, c in enumerate(children) if r > 0]
+    for t in relays:
+        t.start()
+    code = 0
+    live = set(range(n))
+    while live:
+        for r in sorted(live):
+            rc = children[r].poll()
+            if rc is None:
+                continue
+            live.discard(r)
+            if rc != 0 and code == 0:
+                code = rc if rc > 0 else 1
+                sys.stderr.write("bench.py launcher: rank %d exited with %d; ending the other ranks\n" % (r, rc))
+                deadline = time.time() + 20.0          # the others may be on their way out with the same error
+                while time.time() < deadline and any(children[o].poll() is None for o in live):
+                    time.sleep(0.2)
+                for o in live:
+                    if children[o].poll() is None:
+                        children[o].terminate()
+                for o in live:
+                    try:
+                        children[o].wait(timeout=15)
+                    except subprocess.TimeoutExpired:
+                        children[o].kill()
+        time.sleep(0.05)
+    for t in relays:
+        t.join(timeout=5)
+    return code
+
+
 def main(argv=None, **hooks):
     args = parse(argv)
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        code = launch_ranks(args, sys.argv[1:] if argv is None else argv)
+        if code != 0:
+            sys.exit(code)
+        return None
     job = Job(args)
     try:
         if args.mode == "train":

@@ -33,13 +33,19 @@ def _check_line(d, world):
         assert d["backend"] == "gloo" and d["ranks_joined"] == world and d["rccl_ranks"] is None
 
 
-def _launch(script_args, port, tmp_path, nproc=2):
+def _launch(script_args, port, tmp_path, nproc=2, launcher=True, expect_ok=True):
+    """``launcher``: start the ranks with torch.distributed.run (what the driver does for N > 1); False = plain
+    ``python bench.py --gpus N``, which must start its N ranks itself (bench.launch_ranks)."""
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", BENCH_DEVICE="cpu", BENCH_DIST_BACKEND="gloo", OMP_NUM_THREADS="2",
                BENCH_CPU_THREADS="2")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT"):
+        env.pop(k, None)
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=%d" % nproc,
-           "--master-addr", "127.0.0.1", "--master-port", str(port)] if nproc > 1 else [sys.executable]
+           "--master-addr", "127.0.0.1", "--master-port", str(port)] if (nproc > 1 and launcher) else [sys.executable]
     out = subprocess.run(cmd + script_args,
                          env=env, cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600, text=True)
+    if not expect_ok:
+        return out
     assert out.returncode == 0, out.stderr[-2000:]
     lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1, "exactly ONE JSON line, from rank 0"
@@ -56,6 +62,25 @@ def test_train_mode_two_gloo_ranks(tmp_path):
     assert d["config"]["clips_per_rank"] == 1 and np.isfinite(d["loss"])
     assert d["roofline"]["bound"] == "mfma" and d["roofline"]["flops_per_step"] > 0
     assert d["config"]["step"] == "eager"
+
+
+def test_train_mode_starts_its_own_ranks_without_a_launcher(tmp_path):
+    """``python bench.py --gpus 2 --mode train`` with no WORLD_SIZE in the environment: the process starts two ranks itself,
+    relays rank 0's ONE line, and the collective really joined two ranks."""
+    d = _launch([os.path.join(ROOT, "bench.py"), "--mode", "train", "--gpus", "2", "--steps", "1", "--warmup", "1",
+                 "--train-batch", "2", "--train-frames", "2", "--train-crop", "16"], 0, tmp_path, launcher=False)
+    _check_line(d, 2)
+    assert d["n_gpus"] == 2 and d["ranks_joined"] == 2 and d["config"]["clips_per_rank"] == 1
+    assert d["allreduce"]["bytes"] == 911046 * 4
+
+
+def test_self_launched_ranks_that_fail_give_a_nonzero_exit_and_no_line(tmp_path):
+    """A rank that dies must fail the whole run: batch 3 over 2 ranks trips every rank's divisibility assert."""
+    out = _launch([os.path.join(ROOT, "bench.py"), "--mode", "train", "--gpus", "2", "--steps", "1", "--warmup", "0",
+                   "--train-batch", "3", "--train-frames", "2", "--train-crop", "16"], 0, tmp_path, launcher=False, expect_ok=False)
+    assert out.returncode != 0
+    assert not [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert "launcher: rank" in out.stderr
 
 
 def test_train_mode_one_rank_line_is_self_sufficient(tmp_path):
@@ -134,6 +159,11 @@ bench.main(sys.argv[1:], make_local_renderer=Local)
     ref, _ = oracle.render(oracle.OracleVolume(vol), oracle.make_params(48, 32, origin=q, fov=30.0, isovalue=0.34, last_origin=last), threads=2)
     assert d["hit_pixels"] == int(ref[..., 3].sum()) > 50
     assert 0.0 < d["rgb_mean"] < 1.0
+    # the same two ranks started by bench.py itself (no torch.distributed.run): the same composite
+    d2 = _launch([str(script), "--mode", "tiled", "--gpus", "2", "--steps", "1", "--warmup", "1", "--tiled-n", "64", "--low", "48x32"],
+                 0, tmp_path, launcher=False)
+    _check_line(d2, 2)
+    assert d2["ranks_joined"] == 2 and d2["tile"]["voxels"] == [64, 64, 40] and d2["hit_pixels"] > 50
     # one rank: the same line with a cpu_baseline (oracle tile render + CPU network on a bounded sample)
     d1 = _launch([str(script), "--mode", "tiled", "--gpus", "1", "--steps", "1", "--warmup", "1", "--tiled-n", "64", "--low", "48x32"],
                  0, tmp_path, nproc=1)
