@@ -11,6 +11,7 @@
   gradient is ``isrConv3x3WeightGrad``.  There is no fallback: if the library is missing this raises.
 * CPU tensors: the reference's own CPU path, i.e. plain PyTorch ops (BASELINE config #1).
 """
+import contextlib
 import ctypes
 import os
 import warnings
@@ -1334,6 +1335,32 @@ def loss_unshaded_config(weight_dict, padding, shading):
 def loss_unshaded(gt, pred, prev, cfg):
     """-> values[16] (differentiable w.r.t. pred and prev through values[15], the weighted total)."""
     return _LossUnshadedFunction.apply(gt, pred, prev, cfg)
+
+
+@contextlib.contextmanager
+def graph_capture(graph, **kw):
+    """``torch.cuda.graph(graph, **kw)`` with the cyclic garbage collector out of the way.
+
+    A global-mode stream capture makes most HIP calls illegal on every thread until it ends.  If a cyclic collection runs
+    INSIDE the capture and finalises GPU objects that an earlier caller dropped in a reference cycle (a HIP graph, a
+    stream or event of a SuperResolutionPipeline, a cached workspace), their destructors call hipFree / hipEventDestroy /
+    hipGraphDestroy from C++ ``noexcept`` code while the capture is open: the runtime reports an error, the destructor
+    throws, ``std::terminate`` -- "Fatal Python error: Aborted" with the main thread "Garbage-collecting" (one full GPU
+    test run of round 3 died exactly there, in ``GraphedTrainStep.__init__``).  torch 2.10's ``graph.__enter__`` does not
+    collect by itself any more.  So: drain the device, collect NOW (destructors run at a quiescent point), and keep the
+    collector off until the capture has ended."""
+    import gc
+    torch.cuda.synchronize()
+    gc.collect()
+    torch.cuda.synchronize()
+    was_enabled = gc.isenabled()
+    gc.disable()
+    try:
+        with torch.cuda.graph(graph, **kw):
+            yield graph
+    finally:
+        if was_enabled:
+            gc.enable()
 
 
 def adam_flat_step(params, grads, exp_avg, exp_avg_sq, step, lr, beta1, beta2, eps):

@@ -123,11 +123,30 @@ class FlatAdam(torch.optim.Optimizer):
     ``zero_``, and the data-parallel exchange one all-reduce of ``self.bucket`` (``DataParallelTrainer`` adopts it).  The step
     counter and (optionally) the learning rate live on the device, so a HIP graph of the step replays correctly.
 
-    Build it AFTER ``model.to(device)`` (moving the model afterwards would detach the views).  A step writes the parameters'
-    memory without advancing ``Parameter._version``: it declares the cached kernel-layout weight images stale itself."""
+    Build it AFTER ``model.to(device)`` (moving the model afterwards detaches the views: call ``rebind()``).  A step writes the
+    parameters' memory without advancing ``Parameter._version``: it declares the cached kernel-layout weight images stale itself.
+
+    State: the moments and the step counter live in ``self.state[self.flat]`` under torch.optim.Adam's keys (``step``, ``exp_avg``,
+    ``exp_avg_sq``), so ``state_dict()`` / ``load_state_dict()`` and pickling the optimizer object -- what the reference's
+    checkpoints do (mainVideoUnshaded.py:799-811) -- carry them; the member parameters travel with the pickle and are re-pointed
+    at the flat buffers when it is loaded (``__setstate__`` -> ``rebind``).  ``load_state_dict`` copies INTO the existing state
+    tensors, so a HIP graph captured before it keeps updating the live ones."""
 
     def __init__(self, params, lr=1e-4, betas=(0.9, 0.999), eps=1e-8, tensor_lr=False):
         params = [p for p in params if p.requires_grad]
+        dev = params[0].device
+        self.members = params
+        self.flat = self.bucket = None
+        flat = self._bind()
+        if tensor_lr and not torch.is_tensor(lr):
+            lr = torch.tensor(float(lr), dtype=torch.float32, device=dev)
+        super().__init__([flat], dict(lr=lr, betas=betas, eps=eps, capturable=True))
+        self.state[flat] = dict(step=torch.zeros(1, dtype=torch.float32, device=dev), exp_avg=torch.zeros_like(flat.data),
+                                exp_avg_sq=torch.zeros_like(flat.data))
+
+    def _bind(self):
+        """(Re)build the flat parameter / gradient buffers from the members' current values and point the members at them."""
+        params = self.members
         n = sum(p.numel() for p in params)
         dev, dt = params[0].device, params[0].dtype
         flat = torch.empty(n, dtype=dt, device=dev)
@@ -140,27 +159,78 @@ class FlatAdam(torch.optim.Optimizer):
                 p.data = flat[off:off + k].view_as(p)
                 p.grad = bucket[off:off + k].view_as(p)
                 off += k
-        self.members = params
         self.flat = torch.nn.Parameter(flat)
         self.flat.grad = bucket
         self.bucket = bucket
-        if tensor_lr and not torch.is_tensor(lr):
-            lr = torch.tensor(float(lr), dtype=torch.float32, device=dev)
-        super().__init__([self.flat], dict(lr=lr, betas=betas, eps=eps))
-        self.exp_avg = torch.zeros_like(flat)
-        self.exp_avg_sq = torch.zeros_like(flat)
-        self.steps = torch.zeros(1, dtype=torch.float32, device=dev)
+        return self.flat
+
+    # the moments under their old attribute names (kernel launch, tests)
+    exp_avg = property(lambda self: self.state[self.flat]['exp_avg'])
+    exp_avg_sq = property(lambda self: self.state[self.flat]['exp_avg_sq'])
+    steps = property(lambda self: self.state[self.flat]['step'])
+
+    def views_intact(self):
+        if self.flat is None or self.bucket is None or self.flat.grad is not self.bucket:
+            return False
+        base, pbase, esz, off = self.bucket.data_ptr(), self.flat.data_ptr(), self.bucket.element_size(), 0
+        for p in self.members:
+            if p.grad is None or p.grad.data_ptr() != base + off * esz or p.data_ptr() != pbase + off * esz or p.device != self.flat.device:
+                return False
+            off += p.numel()
+        return True
+
+    def rebind(self):
+        """After the members moved (``model.to(device)``) or the optimizer was unpickled: make parameters and gradients views of
+        the flat buffers again, keeping the parameters' CURRENT values and the optimizer's moments / step count / learning rate."""
+        if self.views_intact():
+            return self
+        old = self.flat
+        st = self.state.pop(old) if old is not None and old in self.state else None
+        flat = self._bind()
+        self.param_groups[0]['params'] = [flat]
+        if st is None:
+            st = dict(step=torch.zeros(1), exp_avg=torch.zeros(flat.numel()), exp_avg_sq=torch.zeros(flat.numel()))
+        self.state[flat] = {k: (v.to(device=flat.device, dtype=torch.float32 if k == 'step' else flat.dtype) if torch.is_tensor(v) else v)
+                            for k, v in st.items()}
+        g = self.param_groups[0]
+        if torch.is_tensor(g['lr']) and g['lr'].device != flat.device:
+            g['lr'] = g['lr'].to(flat.device)
+        return self
+
+    def __getstate__(self):
+        st = dict(super().__getstate__())
+        st['members'] = self.members
+        return st
+
+    def __setstate__(self, state):
+        members = state.pop('members', None) if isinstance(state, dict) else None
+        super().__setstate__(state)
+        if members is not None:                    # unpickled (load_state_dict comes through here too, without members)
+            self.members = members
+            self.flat = self.param_groups[0]['params'][0]
+            self.bucket = None                     # gradients are not pickled
+            self.rebind()
+
+    def load_state_dict(self, state_dict):
+        live = self.state[self.flat]
+        lr_live = self.param_groups[0]['lr']
+        super().load_state_dict(state_dict)
+        loaded = self.state[self.flat]
+        with torch.no_grad():
+            for k in ('step', 'exp_avg', 'exp_avg_sq'):
+                live[k].copy_(loaded[k].reshape(live[k].shape))
+        self.state[self.flat] = live
+        if torch.is_tensor(lr_live):               # a captured step reads THIS tensor
+            lr_live.fill_(float(self.param_groups[0]['lr']))
+            self.param_groups[0]['lr'] = lr_live
 
     def zero_grad(self, set_to_none=False):
         self.bucket.zero_()
 
     def check_views(self):
-        base, esz, off = self.bucket.data_ptr(), self.bucket.element_size(), 0
-        for p in self.members:
-            if p.grad is None or p.grad.data_ptr() != base + off * esz or p.data_ptr() != self.flat.data_ptr() + off * esz:
-                raise RuntimeError("FlatAdam: a parameter or its .grad is no longer a view of the flat buffers "
-                                   "(model.to() after construction, or an optimizer.zero_grad(set_to_none=True) elsewhere)")
-            off += p.numel()
+        if not self.views_intact():
+            raise RuntimeError("FlatAdam: a parameter or its .grad is no longer a view of the flat buffers "
+                               "(model.to() after construction -- call rebind() -- or an optimizer.zero_grad(set_to_none=True) elsewhere)")
 
     @torch.no_grad()
     def step(self, closure=None):
@@ -194,6 +264,36 @@ def train_step(model, criterion, optimizer, batch, **kw):
     return float(loss_sum.item()) / target.shape[1]
 
 
+def _optimizer_state_tensors(optimizer):
+    for group in optimizer.param_groups:
+        for p in group['params']:
+            st = optimizer.state.get(p)
+            if st:
+                for k, v in st.items():
+                    if torch.is_tensor(v):
+                        yield (id(p), k), v
+
+
+def _snapshot_training_state(model, optimizer):
+    """Copies of everything an optimisation step changes: the model's parameters and buffers, the optimizer's state tensors."""
+    return ({k: v.detach().clone() for k, v in model.state_dict().items()},
+            {key: v.detach().clone() for key, v in _optimizer_state_tensors(optimizer)})
+
+
+@torch.no_grad()
+def _restore_training_state(model, optimizer, snapshot):
+    """Put model and optimizer back IN PLACE (tensors keep their addresses); optimizer state that did not exist at the
+    snapshot (a fresh optimizer creates it in its first step) is zeroed, which is what a first step starts from."""
+    weights, opt = snapshot
+    for k, v in model.state_dict().items():
+        v.copy_(weights[k])
+    for key, v in _optimizer_state_tensors(optimizer):
+        if key in opt:
+            v.copy_(opt[key])
+        else:
+            v.zero_()
+
+
 class GraphedTrainStep:
     """The whole optimisation step (T frames forward with the recurrence, backward through time, Adam) captured ONCE in
     a HIP graph and replayed: at the per-GPU batch of BASELINE config #3 (2 clips) a step is ~1500 small launches and the
@@ -218,6 +318,11 @@ class GraphedTrainStep:
         self.static = tuple(torch.empty_like(t) for t in example_batch)
         for dst, src in zip(self.static, example_batch):
             dst.copy_(src)
+        # The warm-up steps are REAL optimisation steps on the example batch (they create the optimizer's state tensors and
+        # every cached buffer the capture must find in place); the reference takes one step per batch (trainNormal,
+        # mainVideoUnshaded.py:397-473), so model and optimizer are put back to where they were -- in place, the graph
+        # holds these very tensors -- before the first replay.
+        before = _snapshot_training_state(model, optimizer) if warmup > 0 else None
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):                      # PyTorch's capture recipe: warm up on a side stream
@@ -227,8 +332,11 @@ class GraphedTrainStep:
         torch.cuda.synchronize()
         self.graph = torch.cuda.CUDAGraph()
         self.zero_grad()
-        with torch.cuda.graph(self.graph):
+        with ops.graph_capture(self.graph):
             self.loss = self._eager()
+        if before is not None:
+            _restore_training_state(model, optimizer, before)
+            self.zero_grad()
         ops.invalidate_weight_images()
 
     def _eager(self):
@@ -446,6 +554,8 @@ def fit(model, criterion, train_loader, test_loader, modeldir, n_epochs, paramet
     if restore:
         ckpt, start = load_checkpoint(modeldir, restore_epoch, device)
         model, optimizer, scheduler = ckpt['model'].to(device), ckpt['optimizer'], ckpt['scheduler']
+        if isinstance(optimizer, FlatAdam):
+            optimizer.rebind()                 # parameters and gradients as views of the flat buffers again (no-op if they still are)
         log("Restore training from %s and epoch %d" % (modeldir, start))
     else:
         model = model.to(device)

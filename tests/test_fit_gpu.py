@@ -192,3 +192,62 @@ def test_flat_adam_matches_torch_adam_on_the_network():
             o.param_groups[0]['lr'] = 3e-3 / (k + 1)
             o.step()
     assert (a - b).abs().max().item() <= 1e-6
+
+
+@pytest.mark.keep_garbage
+def test_capture_survives_uncollected_gpu_garbage():
+    """Round 3's abort (``Fatal Python error: Aborted``, main thread ``Garbage-collecting`` inside ``GraphedTrainStep.__init__``): a
+    cyclic collection ran while the global-mode stream capture was open and finalised HIP graphs / streams / events that an
+    earlier caller had dropped in a reference cycle.  Here exactly that garbage exists -- a frame pipeline (side stream, events,
+    workspaces) and a captured training step in a cycle, dropped and NOT collected, this test opts out of the suite's collecting
+    teardown -- and the collector is set to run at every allocation; ``ops.graph_capture`` must collect BEFORE the capture and
+    keep the collector off inside it."""
+    import gc
+    from isosurfacesuperresolution_amd import losses, models, train, volumes as V
+    from isosurfacesuperresolution_amd.inference import DirectRenderer, LoadedModel
+    from isosurfacesuperresolution_amd.pipeline import SuperResolutionPipeline, default_shading
+    g = torch.Generator().manual_seed(3)
+    inp = torch.rand(2, 2, 5, 32, 32, generator=g); inp[:, :, 0] = inp[:, :, 0] * 2 - 1
+    flow = (torch.rand(2, 2, 2, 32, 32, generator=g) - 0.5) * 0.05
+    tgt = torch.rand(2, 2, 6, 128, 128, generator=g); tgt[:, :, 0] = tgt[:, :, 0] * 2 - 1
+    batch = tuple(t.cuda() for t in (inp, flow, tgt))
+    crit = losses.LossNetUnshaded('cuda', 5, 6, 128, 16, OPT).cuda()
+
+    def make():
+        torch.manual_seed(124)
+        net = models.createNetwork('EnhanceNet', 4, 101, [0, 1, 2, 3, 4], 6, OPT).cuda()
+        optim, _ = train.make_optimizer(net, lr=1e-4, capturable=True)
+        return net, optim
+
+    class Holder:
+        pass
+    gc.collect()
+    gc.disable()
+    try:
+        h = Holder()
+        h.me = h                                                     # the cycle: only the cyclic collector can free what hangs off it
+        r = DirectRenderer()
+        r.load_dense(V.sphere64())
+        inf_net = models.createNetwork('EnhanceNet', 4, 101, [0, 1, 2, 3, 4], 6, OPT)
+        h.pipe = SuperResolutionPipeline(r, LoadedModel.from_model(inf_net, "cuda", parameters={"initialImage": "zero"}),
+                                         default_shading("cuda", 30.0), (64, 48))
+        h.pipe.set_static(fov=30.0, isovalue=0.5)
+        h.pipe.frame(V.orbit_camera(0), V.orbit_camera(1))
+        h.pipe.frame(V.orbit_camera(1))
+        net, optim = make()
+        h.step = train.GraphedTrainStep(net, crit, optim, batch, warmup=1, initial_image="zero")
+        h.step(batch)
+        torch.cuda.synchronize()
+        del h, net, optim, inf_net
+    finally:
+        gc.enable()
+    old = gc.get_threshold()
+    gc.set_threshold(1, 1, 1)                                        # a collection at (nearly) every container allocation
+    try:
+        net2, optim2 = make()
+        step2 = train.GraphedTrainStep(net2, crit, optim2, batch, warmup=1, initial_image="zero")
+        assert gc.isenabled()                                        # the guard gives the collector back
+        loss = float(step2(batch))
+    finally:
+        gc.set_threshold(*old)
+    assert np.isfinite(loss)

@@ -588,3 +588,59 @@ def test_fit_driver_epochs_checkpoint_restore_and_loadedmodel(tmp_path):
     assert any("Restore training" in str(l) for l in logs)
     with pytest.raises(FileNotFoundError):
         train.load_checkpoint(str(tmp_path / "nothing"))
+
+
+def test_flat_adam_checkpoint_restore_continues_like_an_uninterrupted_run(tmp_path):
+    """``fit(flat_adam=True)`` checkpoints pickle the optimizer OBJECT (mainVideoUnshaded.py:799-811).  FlatAdam's
+    moments and step count live in ``optimizer.state`` under Adam's keys and its member parameters travel with the pickle, so
+    a restored run takes exactly the steps the uninterrupted run takes; ``state_dict`` / ``load_state_dict`` carry them too."""
+    g = torch.Generator().manual_seed(4)
+    inp = torch.rand(1, 2, 5, 16, 16, generator=g); inp[:, :, 0] = inp[:, :, 0] * 2 - 1
+    flow = (torch.rand(1, 2, 2, 16, 16, generator=g) - 0.5) * 0.05
+    tgt = torch.rand(1, 2, 6, 64, 64, generator=g); tgt[:, :, 0] = tgt[:, :, 0] * 2 - 1
+    loader = [(inp, flow, tgt)]
+    opt2 = argparse.Namespace(**dict(vars(OPT), numResidualLayers=10))
+    crit = losses.LossNetUnshaded('cpu', 5, 6, 64, 8, opt2)
+    params = dict(vars(opt2), initialImage="zero", upscale_factor=4)
+
+    def fresh():
+        torch.manual_seed(124)
+        return models.createNetwork('EnhanceNet', 4, 101, [0, 1, 2, 3, 4], 6, opt2)
+    # uninterrupted: three epochs of one step each
+    ref, _ = train.fit(fresh(), crit, loader, None, str(tmp_path / "a"), 3, params, device="cpu", lr=1e-3, flat_adam=True,
+                       initial_image="zero", log=lambda *_: None)
+    # interrupted after two epochs; the checkpoint of epoch 2 holds the model and the optimizer OBJECT
+    run_b = str(tmp_path / "b")
+    train.fit(fresh(), crit, loader, None, run_b, 2, params, device="cpu", lr=1e-3, flat_adam=True, initial_image="zero", log=lambda *_: None)
+    ck, start = train.load_checkpoint(run_b)
+    opt = ck['optimizer']
+    assert isinstance(opt, train.FlatAdam) and start == 2
+    opt.check_views()                                              # parameters AND gradients are views of the flat buffers again
+    assert float(opt.steps.item()) == 2.0 and opt.exp_avg.abs().max().item() > 0 and opt.exp_avg_sq.abs().max().item() > 0
+    assert all(p is q for p, q in zip(opt.members, ck['model'].parameters()))
+    # one more step from the restored state == the third step of the uninterrupted run (same batch, same lr: lr_step 500)
+    train.train_step(ck['model'], crit, opt, loader[0], initial_image="zero")
+    for p, q in zip(ref.parameters(), ck['model'].parameters()):
+        assert torch.allclose(p, q, rtol=0, atol=1e-7), (p - q).abs().max().item()
+    # fit(restore=True) takes the same route (and would have raised AttributeError before)
+    net_c, hist = train.fit(None, crit, loader, None, run_b, 3, params, device="cpu", restore=True, initial_image="zero", log=lambda *_: None)
+    assert [h['epoch'] for h in hist] == [2, 3] and all(np.isfinite(h['train_loss']) for h in hist)
+    # state_dict round trip into a fresh FlatAdam: moments, step count, lr
+    sd = opt.state_dict()
+    other = train.FlatAdam(list(fresh().parameters()), lr=5e-4)
+    live_avg = other.exp_avg
+    other.load_state_dict(sd)
+    assert other.exp_avg is live_avg and torch.equal(other.exp_avg, opt.exp_avg) and torch.equal(other.exp_avg_sq, opt.exp_avg_sq)
+    assert float(other.steps.item()) == float(opt.steps.item()) and other.param_groups[0]['lr'] == pytest.approx(opt.param_groups[0]['lr'])
+    other.check_views()
+    # a model moved after construction: rebind() keeps values and moments
+    net_d = fresh()
+    od = train.FlatAdam(list(net_d.parameters()), lr=1e-3)
+    train.train_step(net_d, crit, od, loader[0], initial_image="zero")
+    w = [p.detach().clone() for p in net_d.parameters()]
+    m = od.exp_avg.clone()
+    for p in net_d.parameters():
+        p.data = p.data.clone()                                     # what model.to(other device) does to the views
+    assert not od.views_intact()
+    od.rebind().check_views()
+    assert all(torch.equal(a, b) for a, b in zip(w, net_d.parameters())) and torch.equal(m, od.exp_avg) and float(od.steps.item()) == 1.0

@@ -265,7 +265,7 @@ def test_clip_gradients_inside_a_hip_graph_are_reproduced_by_every_replay():
     """Forward + backward of a clip captured in a HIP graph: every replay (not only the first) must give the eager
     gradients.  Guards state carried between replays -- a captured hipMemsetAsync that did not take effect on replay
     once left the scatter buffer of the recurrent input's backward un-zeroed from the second replay on."""
-    from isosurfacesuperresolution_amd import models, losses as L, train
+    from isosurfacesuperresolution_amd import models, losses as L, ops, train
     opt = argparse.Namespace(upsample='bilinear', reconType='residual', useBN=False, numResidualLayers=3, losses=RECIPE,
                              lossAO=0.0, lossAmbient=0.1, lossDiffuse=0.9, lossSpecular=0.0)
     B, T = 2, 5                                           # 5 frames of 128^2: the K-split weight gradient of the output layer
@@ -293,7 +293,7 @@ def test_clip_gradients_inside_a_hip_graph_are_reproduced_by_every_replay():
     torch.cuda.synchronize()
     graph = torch.cuda.CUDAGraph()
     net.zero_grad(set_to_none=True)
-    with torch.cuda.graph(graph):
+    with ops.graph_capture(graph):
         total = grads()
     for replay in range(3):
         graph.replay()

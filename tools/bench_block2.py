@@ -47,7 +47,7 @@ for name, fn in (("two launches, forward", two_fwd), ("fused, forward", fused_fw
     with torch.cuda.stream(s):
         fn()
         g = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(g, stream=s):
+        with ops.graph_capture(g, stream=s):
             for _ in range(40):
                 y = fn()
         g.replay()

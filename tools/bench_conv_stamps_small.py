@@ -30,7 +30,7 @@ with torch.no_grad():
             y = ops.conv3x3(x, wt, b, act='relu')
         torch.cuda.current_stream().wait_stream(side); torch.cuda.synchronize()
         graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(graph):
+        with ops.graph_capture(graph):
             y = x
             for _ in range(200): y = ops.conv3x3(y, wt, b, act='relu')
         graph.replay(); torch.cuda.synchronize()

@@ -21,7 +21,7 @@ with torch.no_grad():
             g = torch.cuda.CUDAGraph()
             y = ops.conv3x3(x, wt, b, act='relu')
             torch.cuda.synchronize()
-            with torch.cuda.graph(g, stream=side):
+            with ops.graph_capture(g, stream=side):
                 y = x
                 for _ in range(100):
                     y = ops.conv3x3(y, wt, b, act='relu')
@@ -51,7 +51,7 @@ with torch.no_grad():
             g = torch.cuda.CUDAGraph()
             y = ops.conv3x3(x, wt, b, residual=r)
             torch.cuda.synchronize()
-            with torch.cuda.graph(g, stream=side):
+            with ops.graph_capture(g, stream=side):
                 y = x
                 for _ in range(100):
                     y = ops.conv3x3(y, wt, b, residual=r)

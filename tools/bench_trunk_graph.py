@@ -34,7 +34,7 @@ with torch.no_grad():
         trunk()
     torch.cuda.current_stream().wait_stream(s)
     g = torch.cuda.CUDAGraph()
-    with torch.cuda.graph(g):
+    with ops.graph_capture(g):
         out = trunk()
     g.replay(); torch.cuda.synchronize()
     e0.record()
