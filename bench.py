@@ -248,6 +248,8 @@ def run_infer(args, job):
 
     if args.exact:
         ops.SPLIT_F16 = False
+    if os.environ.get("BENCH_SHARE_DEVICE") == "1":
+        ops.TRUNK_DATAFLOW = False          # several ranks on ONE device (a rehearsal): the dataflow trunk needs every tile resident
     low_w, low_h = (int(v) for v in (args.low or "480x270").split("x"))
     iso = {"ejecta256": 0.34, "ejecta128": 0.34, "sphere64": 0.5}[args.volume]
     vol = V.VOLUMES[args.volume][0]()

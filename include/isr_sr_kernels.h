@@ -276,6 +276,10 @@ long long isrTrunkDataflowWorkspaceBytes(int cin0, int H, int W);
 int isrTrunkDataflowSupported(const float* x, int cin0, int H, int W, long long xPlane, long long plane);
 int isrTrunkDataflow(const float* x, int cin0, long long xPlane, float* y, long long plane, const void* const* wq,
                      const float* const* bias, int nblocks, int H, int W, void* workspace, void* stream);
+/* Where every LATER isrTrunkDataflow launch reports a timed-out wait instead of the workspace's own word (same encoding, sticky until
+ * the caller clears it; NULL restores the workspace word): one device word the caller can mirror to the host once per frame together
+ * with the range-guard words (isrSetRangeFlag), so that a disturbed launch is noticed a frame later, not whenever somebody looks. */
+void isrSetTrunkErrorWord(unsigned* word);
 
 /* One residual block of the trunk, y = x + conv2(relu(conv1(x) + bias1)) + bias2 (64 -> 64 -> 64 channels, one image;
  * models/enhancenet.py:18-33,108-112,139-141), in ONE launch on the split-operand arithmetic: the same products in the same

@@ -333,6 +333,7 @@ int isrResBlockSplitSupported(const float* x, int H, int W, long long xPlane, lo
 int isrResBlockSplit(const float* x, const void* wq1, const float* bias1, const void* wq2, const float* bias2, float* y, void* workspace,
                      int H, int W, long long xPlane, long long yPlane, void* stream)
 {
+    unsigned* const rangeFlag = isr_take_range_flag();       // taken first: an error return must not leave it armed
     if (!x || !wq1 || !wq2 || !y || !workspace) return -1;
     if (!isrResBlockSplitSupported(x, H, W, xPlane, yPlane) || ((uintptr_t)y & 15) != 0) return -3;
     BlockParams p;
@@ -341,7 +342,7 @@ int isrResBlockSplit(const float* x, const void* wq1, const float* bias1, const 
     p.H = H; p.W = W; p.xPlane = (int)xPlane; p.yPlane = (int)yPlane;
     p.tilesX = (W + ST_W - 1) / ST_W; p.tilesY = (H + ST_H - 1) / ST_H;
     p.stamps = g_block_stamps; p.dbg = g_block_dbg;
-    p.absmax = isr_take_range_flag();
+    p.absmax = rangeFlag;
     const int slots = block_slots();
     const long long ntiles = (long long)p.tilesX * p.tilesY;
     const long long want = ntiles < slots ? ((ntiles + 7) / 8) * 8 : slots;

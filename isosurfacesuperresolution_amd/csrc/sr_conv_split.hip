@@ -1160,6 +1160,7 @@ int isrConv3x3ForwardSplit(const float* x, const void* wq, const float* bias, co
                            long long xPlane, long long xImage, long long yPlane, long long yImage,
                            long long rPlane, long long rImage, void* stream)
 {
+    unsigned* const rangeFlag = isr_take_range_flag();       // taken FIRST: an early error return must not leave it armed for the next launch
     if (!x || !wq || !y || N <= 0 || Cin <= 0 || Cout <= 0 || H <= 0 || W <= 0) return -1;
     if (act < ISR_ACT_NONE || act > ISR_ACT_GATE) return -1;
     if (act == ISR_ACT_GATE && !residual) return -1;
@@ -1185,7 +1186,7 @@ int isrConv3x3ForwardSplit(const float* x, const void* wq, const float* bias, co
     p.quads = ((W & 3) == 0 && aligned) ? 1 : 0;
     p.ps = nullptr; p.psPlane = 0;
     p.xps = nullptr; p.xpsPlane = 0; p.zero = nullptr;
-    p.absmax = isr_take_range_flag();
+    p.absmax = rangeFlag;
     p.slotmax = nullptr;
     unsigned* const maxSlots = g_max_slots;
     const int maxCap = g_max_slot_cap;
@@ -1352,13 +1353,14 @@ int isrResBlockSmallSupported(int N, int H, int W)
 int isrResBlockSmall(const float* x, const void* wa, const float* ba, const float* gate, const void* wb, const float* bb, float* z, float* y,
                      int N, int H, int W, void* zmax, void* ymax, void* stream)
 {
+    unsigned* const rangeFlag = isr_take_range_flag();       // taken first (see isrConv3x3ForwardSplit)
     if (!x || !wa || !wb || !z || !y || (!zmax) != (!ymax)) return -1;
     if (!isrResBlockSmallSupported(N, H, W)) return -3;
     if (((uintptr_t)x & 15) || ((uintptr_t)y & 15) || ((uintptr_t)wa & 15) || ((uintptr_t)wb & 15)) return -1;
     Block2Params p;
     p.x = x; p.wa = (const u32x4*)wa; p.ba = ba; p.gate = gate; p.wb = (const u32x4*)wb; p.bb = bb; p.z = z; p.y = y;
     p.N = N; p.H = H; p.W = W; p.tilesY = (H + R2_H - 1) / R2_H;
-    p.absmax = isr_take_range_flag();
+    p.absmax = rangeFlag;
     p.zmax = (unsigned*)zmax; p.ymax = (unsigned*)ymax;
     p.dbg = g_split_dbg; p.stamps = g_split_stamps;
     static bool attr = false;

@@ -505,6 +505,7 @@ static int tail_launch(const void* xin, int packed, const void* wq6, const float
                        const float* shading24, int exponent, float ao_strength, int inverse_ao, int enable_specular, void* stream)
 {
     const float* x = (const float*)xin;
+    unsigned* const rangeFlag = isr_take_range_flag();       // taken first: an error return must not leave it armed
     if (!x || !wq6 || !wz || !bias8 || !workspace || !net_input || !next_prev || (rgb && !shading24)) return -1;
     if (!packed && !isrConvTailSupported(x, h, w, xPlane)) return -3;
     const int H = 4 * h, W = 4 * w;
@@ -526,7 +527,7 @@ static int tail_launch(const void* xin, int packed, const void* wq6, const float
     tp.zPlane = H * W + W;
     tp.xps = nullptr; tp.xpsPlane = 0; tp.zero = nullptr;
     p.ps = nullptr; p.psPlane = 0; p.xps = nullptr; p.xpsPlane = 0; p.zero = nullptr;
-    p.absmax = isr_take_range_flag();      // here: the largest |y6|, the 64-channel intermediate that is split in registers
+    p.absmax = rangeFlag;                  // here: the largest |y6|, the 64-channel intermediate that is split in registers
     if (packed) {
         static u32x4* zero = nullptr;
         if (!zero && hipGetSymbolAddress((void**)&zero, HIP_SYMBOL(g_tail_zero_unit)) != hipSuccess) return -2;

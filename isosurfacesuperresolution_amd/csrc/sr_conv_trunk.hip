@@ -72,6 +72,7 @@ struct Trunk16Params {
     unsigned* absmax;                // range guard over every value stored (may be NULL)
     int H, W, plane, tilesX, tilesY, layers;
     int dbg;                         // diagnostics (isrDebugSetTrunkAblation): 1 no MFMAs, 2 no activation DMA, 4 no stores, 8 no waits, 16 no weight DMA
+    int faultTile;                   // diagnostics (isrDebugSetTrunkFault): the tile that never publishes, or -1
     unsigned long long timeoutTicks; // of the chip's 100 MHz clock
     unsigned long long* stamps;      // diagnostics: [tile][layer][8] = ticks at: layer start | neighbours there | first k-step staged | MFMAs done | epilogue done | stores drained
 };
@@ -87,6 +88,9 @@ __device__ __forceinline__ T* trunk16_uniform(T* q)
 
 int g_trunk_dbg = 0;
 unsigned long long* g_trunk_stamps = nullptr;
+unsigned* g_trunk_error_word = nullptr;          // isrSetTrunkErrorWord: where launches report a timed-out wait (NULL: the workspace's own word)
+int g_trunk_fault_tile = -1;                     // isrDebugSetTrunkFault: this tile never publishes its progress (tests of the timeout path)
+unsigned long long g_trunk_timeout_ticks = 5000000ull;     // 50 ms of the chip's 100 MHz clock: a frame is 2 ms
 
 typedef __attribute__((address_space(3))) char t16_lds_char;
 
@@ -448,7 +452,7 @@ __global__ __launch_bounds__(T16_THREADS) void trunk_dataflow_kernel(const Trunk
         // ---- publish: every wave's stores drained, then one agent-scope store of the tile's progress -------------------------
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
-        if (tid == 0) __hip_atomic_store(p.done + tile, (unsigned)(l + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (tid == 0 && tile != p.faultTile) __hip_atomic_store(p.done + tile, (unsigned)(l + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         wq = wqNext;
         lap(5);
     }
@@ -519,7 +523,18 @@ void isrDebugSetTrunkAblation(int mask) { g_trunk_dbg = mask & 63; }
  * chip) at the layer's start | the neighbours' arrival | the first k-step staged | the MFMAs done | the epilogue done | the stores
  * drained (slot 1 stays 0 for the first layer). */
 void isrDebugSetTrunkStampBuffer(unsigned long long* stamps) { g_trunk_stamps = stamps; }
-int isrDebugTrunkState(void) { return g_trunk_dbg | (g_trunk_stamps ? 64 : 0); }
+int isrDebugTrunkState(void) { return g_trunk_dbg | (g_trunk_stamps ? 64 : 0) | ((g_trunk_fault_tile >= 0 || g_trunk_timeout_ticks != 5000000ull) ? 128 : 0); }
+/* Tests of the timeout path: tile `tile` (>= 0) never publishes its progress, so its neighbours' waits run into the deadline, which
+ * is `timeoutTicks` of the 100 MHz clock after the kernel's start (0: the default 50 ms); tile < 0 switches the fault off.  The launch
+ * then ends with the error word set BY THE KERNEL and an incomplete output. */
+void isrDebugSetTrunkFault(int tile, unsigned long long timeoutTicks)
+{
+    g_trunk_fault_tile = tile;
+    g_trunk_timeout_ticks = timeoutTicks ? timeoutTicks : 5000000ull;
+}
+/* Where every later isrTrunkDataflow launch reports a timed-out wait (atomic maximum of 1 + layer; sticky until the caller clears
+ * it): a device word the caller mirrors to the host once per frame (ops.guards_publish), or NULL for the workspace's own word. */
+void isrSetTrunkErrorWord(unsigned* word) { g_trunk_error_word = word; }
 
 int isrTrunkDataflowMaxTiles(void)
 {
@@ -548,6 +563,7 @@ int isrTrunkDataflowSupported(const float* x, int cin0, int H, int W, long long 
 int isrTrunkDataflow(const float* x, int cin0, long long xPlane, float* y, long long plane, const void* const* wq,
                      const float* const* bias, int nblocks, int H, int W, void* workspace, void* stream)
 {
+    unsigned* const rangeFlag = isr_take_range_flag();       // taken first: an error return must not leave it armed
     if (!x || !y || !wq || !bias || !workspace || nblocks < 0 || 1 + 2 * nblocks > T16_MAX_LAYERS || cin0 <= 0) return -1;
     if (!isrTrunkDataflowSupported(x, cin0, H, W, xPlane, plane) || ((uintptr_t)workspace & 255)) return -3;
     const Trunk16Layout lay = trunk16_layout(cin0, H, W);
@@ -565,10 +581,11 @@ int isrTrunkDataflow(const float* x, int cin0, long long xPlane, float* y, long 
     p.H = H; p.W = W; p.plane = (int)(((long long)H * W + 8) & ~7LL); p.layers = layers;
     p.tilesX = (W + T16_W - 1) / T16_W; p.tilesY = (H + T16_H - 1) / T16_H;
     const int ntiles = p.tilesX * p.tilesY;
-    p.ws = ws; p.done = (unsigned*)(ws + 16); p.error = p.done + ntiles;
-    p.absmax = isr_take_range_flag();
+    p.ws = ws; p.done = (unsigned*)(ws + 16); p.error = g_trunk_error_word ? g_trunk_error_word : p.done + ntiles;
+    p.absmax = rangeFlag;
     p.dbg = g_trunk_dbg; p.stamps = g_trunk_stamps;
-    p.timeoutTicks = 5000000ull;                                             // 50 ms: a frame is 2 ms
+    p.timeoutTicks = g_trunk_timeout_ticks;                                  // 50 ms unless a test shortened it: a frame is 2 ms
+    p.faultTile = g_trunk_fault_tile;
     hipStream_t s = (hipStream_t)stream;
     // the progress counters start at zero every launch; the error word behind them is STICKY (the caller zero-fills the workspace
     // once, reads the word when it likes and resets it then): an error of any launch since the last look stays visible

@@ -157,14 +157,18 @@ class LoadedModel:
                                                           self.upscale_factor, special_mask=True)
             flat = VideoTools.flatten_high(previous_warped, self.upscale_factor)
             net_in = torch.cat((inp, flat), dim=1)
-            prediction, _ = self.model(net_in)
             if net_in.is_cuda:
                 from .. import ops
+                ops.guards_poll(net_in.device)       # what the previous frame's kernels reported (plain read of pinned memory, one frame late)
+            prediction, _ = self.model(net_in)
+            if net_in.is_cuda:
                 if ops.range_check_due(net_in.device):
-                    # a layer came close to the split operands' fp16 range: exact routing from now on, this frame again (repeated:
-                    # a fused launch only says THAT something inside it was hot, the per-layer pass that replaces it says where)
+                    # FIRST frame of a model -- a layer came close to the split operands' fp16 range: exact routing from now on, this
+                    # frame again (repeated: a fused launch only says THAT something inside it was hot, the per-layer pass that
+                    # replaces it says where).  Later frames: guards_publish here, guards_poll at the next frame's start.
                     for _ in range(4):
                         if not ops.refresh_range_flags(net_in.device):
                             break
                         prediction, _ = self.model(net_in)
+                ops.guards_publish(net_in.device)
         return prediction

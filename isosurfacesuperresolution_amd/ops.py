@@ -120,6 +120,8 @@ def _sr():
         lib.isrResBlockSplit.argtypes = [vp, vp, vp, vp, vp, vp, vp, ci, ci, ll, ll, vp]; lib.isrResBlockSplit.restype = ci
         lib.isrAdamFlatStep.argtypes = [vp, vp, vp, vp, ll, vp, cf, cf, cf, cf, vp, vp]; lib.isrAdamFlatStep.restype = ci
         lib.isrSetRangeFlag.argtypes = [vp]; lib.isrSetRangeFlag.restype = None
+        lib.isrSetTrunkErrorWord.argtypes = [vp]; lib.isrSetTrunkErrorWord.restype = None
+        lib.isrDebugSetTrunkFault.argtypes = [ci, ctypes.c_ulonglong]; lib.isrDebugSetTrunkFault.restype = None
         lib.isrProfileEnable.argtypes = [ci]; lib.isrProfileEnable.restype = ci
         lib.isrDebugSetSplitAlgo.argtypes = [ci]
         if os.environ.get("ISR_SPLIT_ALGO"):          # experiments: force a kernel form of the plain split layers (see sr_conv_split.hip)
@@ -380,40 +382,60 @@ def conv3x3_f16(x, weight, bias=None, act='none', slope=0.01, residual=None, ups
                           act, slope, upsample2x, False)
 
 
-# ---- range guard of the split-operand path ---------------------------------------------------------------------------------
+# ---- range guard of the split-operand path, and the per-frame guard words ---------------------------------------------------
 # The split of an ACTIVATION into (hi, lo') fp16 numbers overflows at |x| >= 65520 (inf / NaN downstream: loud, not silent).  With
-# the reference's networks and G-buffer inputs in [-1, 5] this cannot happen; a user's checkpoint is one badly scaled layer away.
-# So every split-operand launch leaves the largest |value| it stored in a device word (SplitConvParams::absmax, one atomic per
-# wave), tensors remember which word describes them, and ``refresh_range_flags()`` -- one host read, done by the frame pipeline
-# / LoadedModel after the FIRST frame of a model and then every RANGE_CHECK_EVERY frames, never inside a frame -- marks the
-# producers whose output came within a factor two of the limit as HOT.  The CONSUMER of a hot tensor (and, conservatively,
-# everything downstream of it in that frame) runs on the exact fp32 kernels (sr_conv3x3.hip), which have the full fp32 range.
+# the reference's networks and G-buffer inputs in [-1, 5] this cannot happen; a user's checkpoint is one badly scaled layer away
+# (inference/loadedmodel.py:70-120 of the reference: arbitrary checkpoints, arbitrary sequences).  So every split-operand launch
+# leaves the largest |value| it stored in a device word (SplitConvParams::absmax, one atomic per wave) and tensors remember which
+# word describes them.  Producers whose output came within a factor two of the limit are HOT: the CONSUMER of a hot tensor (and,
+# conservatively, everything downstream of it in that frame) runs on the exact fp32 kernels (sr_conv3x3.hip), which have the full
+# fp32 range.  Two ways the host learns about it, neither a synchronisation inside a frame:
+#   * a model's FIRST frame: ``range_check_due`` -> ``refresh_range_flags`` reads the words (one synchronisation) and the frame is
+#     computed again with the routing -- repeated, because a fused launch only says THAT something inside it was hot and the
+#     per-layer pass that replaces it says where: the first frame of any checkpoint is right;
+#   * EVERY later frame, one frame late (``guards_publish`` / ``guards_poll``): the frame ends with an asynchronous copy of the
+#     words into pinned host memory, the next frame starts by reading that copy -- a plain load.  A layer that turns hot at frame t
+#     is routed from frame t + 1 on (a fused segment is then taken apart conservatively: all its layers count as hot).  The
+#     threshold (3e4) is a factor two below the overflow, so values that GROW into the limit are caught while they are still exact.
+# The last word of the buffer is the dataflow trunk's error word (``isrSetTrunkErrorWord``): a launch that gave up waiting for a
+# neighbour raises at the start of the NEXT frame and switches the dataflow form off for the process.
 RANGE_GUARD = True
 RANGE_LIMIT = 3.0e4
-RANGE_CHECK_EVERY = 256
 _RANGE_SLOTS = 512
+_TRUNK_ERROR_SLOT = _RANGE_SLOTS - 1
 HOT = "hot"                      # range key of a tensor of unknown / large range (e.g. produced by an exact kernel on the guarded path)
-_range = {}                      # device -> {"buf": uint32 tensor, "slots": {key: index}, "hot": set(keys), "frames": int}
+_range = {}                      # device -> state, see _range_state
 
 
 def _range_state(device):
+    device = torch.device(device)
+    if device.index is None:
+        device = torch.device(device.type, torch.cuda.current_device())
     st = _range.get(device)
     if st is None:
-        st = {"buf": torch.zeros(_RANGE_SLOTS, dtype=torch.int32, device=device), "slots": {}, "hot": set(), "frames": 0}
+        st = {"buf": torch.zeros(_RANGE_SLOTS, dtype=torch.int32, device=device), "slots": {}, "hot": set(), "frames": 0,
+              "members": {},                # fused segment key -> keys of the layers it covers
+              "mirror": torch.zeros(_RANGE_SLOTS, dtype=torch.int32).pin_memory(), "event": torch.cuda.Event(), "pending": False}
         _range[device] = st
     return st
 
 
-def _arm_range(key, device):
-    """Arm the NEXT split-operand launch with the flag word of producer ``key`` (no-op when the guard is off)."""
+def _arm_range(key, device, members=None):
+    """Arm the NEXT split-operand launch with the flag word of producer ``key`` (no-op when the guard is off).  ``members``: the
+    per-layer keys a fused launch stands for.  Out of words: the tensor counts as HOT (its consumer takes the exact kernel) -- an
+    unguarded launch is never silently accepted."""
     if not RANGE_GUARD:
         return None
     st = _range_state(device)
     idx = st["slots"].get(key)
     if idx is None:
-        if len(st["slots"]) >= _RANGE_SLOTS:
-            return None
+        if len(st["slots"]) >= _TRUNK_ERROR_SLOT:
+            _warn_once("range_slots", "range guard: all %d flag words are in use (models loaded without ops.range_reset()?); "
+                       "further layers' consumers run on the exact fp32 kernels" % _TRUNK_ERROR_SLOT)
+            return HOT
         idx = st["slots"][key] = len(st["slots"])
+    if members is not None:
+        st["members"][key] = tuple(members)
     _sr().isrSetRangeFlag(ctypes.c_void_p(st["buf"].data_ptr() + 4 * idx))
     return key
 
@@ -426,46 +448,111 @@ def range_is_hot(key, device):
 
 
 def any_hot(device):
-    return RANGE_GUARD and device in _range and bool(_range[device]["hot"])
+    if not RANGE_GUARD:
+        return False
+    device = torch.device(device)
+    if device.index is None:
+        device = torch.device(device.type, torch.cuda.current_device())
+    return device in _range and bool(_range[device]["hot"])
+
+
+def _mark_hot(st, words, conservative):
+    """``words``: the guard words as a float32 view (host).  -> the producers that became hot.  ``conservative``: a fused segment
+    that is hot makes every layer it covers hot at once (nobody recomputes the frame to find out which one it was)."""
+    new = set()
+    n = len(st["slots"])
+    words = words.numpy() if torch.is_tensor(words) else words
+    if n == 0 or bool((words[:n] < RANGE_LIMIT).all()):              # the common case in one vector compare (slots are handed out 0, 1, 2, ...)
+        return new
+    for key, idx in st["slots"].items():
+        v = float(words[idx])
+        if not (v < RANGE_LIMIT) and key not in st["hot"]:           # NaN compares false: hot
+            st["hot"].add(key)
+            new.add(key)
+            if conservative:
+                for m in st["members"].get(key, ()):
+                    if m not in st["hot"]:
+                        st["hot"].add(m)
+                        new.add(m)
+    return new
 
 
 def refresh_range_flags(device=None):
-    """Read the producers' maxima (ONE host synchronisation), mark producers at or above RANGE_LIMIT (or non-finite) hot,
-    reset the words.  Returns the set of producers that became hot in this call.  (Also the moment the dataflow trunk's error
-    words are looked at, ``trunk_check``.)"""
+    """Read the producers' maxima (ONE host synchronisation), mark producers at or above RANGE_LIMIT (or non-finite) hot (the
+    words are running maxima and stay: hot is a one-way state until ``range_reset``).  Returns the set of producers that became hot in this call.  (Also a moment the dataflow trunk's error
+    word is looked at, ``trunk_check``.)"""
     trunk_check()
     new = set()
     for dev, st in list(_range.items()):
-        if device is not None and torch.device(dev) != torch.device(device):
+        if device is not None and dev != _range_device(device):
             continue
         if not st["slots"]:
             continue
         vals = st["buf"].cpu().view(torch.float32)
-        for key, idx in st["slots"].items():
-            v = float(vals[idx])
-            if not (v < RANGE_LIMIT) and key not in st["hot"]:       # NaN compares false: hot
-                st["hot"].add(key)
-                new.add(key)
-        st["buf"].zero_()
+        new |= _mark_hot(st, vals, conservative=False)
+        st["pending"] = False
     return new
 
 
+def _range_device(device):
+    device = torch.device(device)
+    return device if device.index is not None else torch.device(device.type, torch.cuda.current_device())
+
+
+def guards_publish(device, record=True):
+    """End of a frame: copy the guard words (range maxima + the trunk's error word) into pinned host memory, asynchronously on
+    the current stream.  ``record=False`` inside a stream capture (an event recorded there is a graph node, not something the host
+    can query): the caller marks the replay's end with ``guards_mark``."""
+    if not RANGE_GUARD:
+        return
+    st = _range_state(device)
+    st["mirror"].copy_(st["buf"], non_blocking=True)
+    if record:
+        guards_mark(device)
+
+
+def guards_mark(device):
+    st = _range_state(device)
+    st["event"].record(torch.cuda.current_stream())
+    st["pending"] = True
+
+
+def guards_poll(device):
+    """Start of a frame: look at what the PREVIOUS frame published -- a plain read of pinned memory, no synchronisation (if that
+    copy has not landed yet it is looked at a frame later).  Marks new hot producers (returned) and raises if a dataflow-trunk
+    launch timed out."""
+    if not RANGE_GUARD:
+        return set()
+    st = _range_state(device)
+    if not st["pending"] or not st["event"].query():
+        return set()
+    st["pending"] = False
+    words = st["mirror"]
+    err = int(words[_TRUNK_ERROR_SLOT])
+    if err:
+        _trunk_failed(st, err)
+    return _mark_hot(st, words.view(torch.float32), conservative=True)
+
+
 def range_reset():
-    """Forget every maximum and every hot producer (a new model was loaded)."""
+    """Forget every maximum, every hot producer and every producer's word (a new model was loaded)."""
     for st in _range.values():
-        st["buf"].zero_()
+        st["buf"][:_TRUNK_ERROR_SLOT].zero_()
         st["hot"].clear()
+        st["slots"].clear()
+        st["members"].clear()
         st["frames"] = 0
+        st["pending"] = False
 
 
 def range_check_due(device):
-    """Frame pipelines call this once per frame: True after the first frame since the last reset and then every
-    RANGE_CHECK_EVERY frames."""
+    """Frame pipelines call this once per frame: True for the FIRST frame since the last reset (the synchronous check that makes a
+    checkpoint's first frame right); every later frame is covered by ``guards_publish`` / ``guards_poll``."""
     if not RANGE_GUARD:
         return False
     st = _range_state(device)
     st["frames"] += 1
-    return st["frames"] == 1 or st["frames"] % RANGE_CHECK_EVERY == 0
+    return st["frames"] == 1
 
 
 # ---- split-operand mode: fp32-equivalent accuracy on the fp16 matrix pipe (inference; THE default parity path) ----------
@@ -908,11 +995,13 @@ class _ResidualBlockFunction(torch.autograd.Function):
 
 
 # ---- the whole low-resolution trunk as ONE dataflow launch (csrc/sr_conv_trunk.hip) -----------------------------------------
-# preblock + the residual blocks of a single image whose tiles all fit on the GPU at once (<= 2 x #CUs tiles of 8 x 32 pixels: the
-# 480 x 270 frame has 510): workgroup w owns tile w through every layer and waits only for its 3 x 3 neighbourhood's progress.
-# Bit-identical to the per-layer launches.  A wait that never completes ends the launch and sets an error word, which
-# ``trunk_check()`` (called where the range guard is refreshed: after a model's first frame, then every RANGE_CHECK_EVERY frames)
-# turns into an exception.
+# preblock + the residual blocks of a single image whose tiles all fit on the GPU at once (<= #CUs tiles of 16 x 32 pixels, one
+# workgroup per CU: the 480 x 270 frame has 255): workgroup w owns tile w through every layer and waits only for its 3 x 3
+# neighbourhood's progress.  Bit-identical to the per-layer launches.  Every tile must be RESIDENT: a co-runner that holds a CU (a
+# second process on the device, another stream's kernel) can keep a tile out, its neighbours' waits then run into the 50 ms
+# deadline, the launch ends with an incomplete output and the error word set.  That word is one of the per-frame guard words:
+# ``guards_poll`` at the start of the next frame raises and switches the dataflow form off for the process (``trunk_check()`` is the
+# synchronous look: bench.py after its timed region, tests).  Do not use it on a shared device (bench.py: BENCH_SHARE_DEVICE).
 TRUNK_DATAFLOW = os.environ.get("ISR_TRUNK_DATAFLOW", "1") != "0"
 _trunk_ws = {}
 
@@ -950,23 +1039,31 @@ def trunk_dataflow(x, convs):
     n = len(convs)
     pw = (ctypes.c_void_p * n)(*[q.data_ptr() for q in wq])
     pb = (ctypes.c_void_p * n)(*[(b.data_ptr() if b is not None else None) for b in bs])
-    f._isr_range_key = _arm_range(("trunk", id(convs[0][0])), x.device)
+    st = _range_state(x.device)
+    lib.isrSetTrunkErrorWord(ctypes.c_void_p(st["buf"].data_ptr() + 4 * _TRUNK_ERROR_SLOT))
+    f._isr_range_key = _arm_range(("trunk", id(convs[0][0])), x.device, members=[id(wt) for wt, _ in convs])
     rc = lib.isrTrunkDataflow(_ptr(x), cin, xp, _ptr(f), f.stride(1), pw, pb, (n - 1) // 2, h, w, _ptr(ws), _stream())
     if rc != 0:
         raise RuntimeError("isrTrunkDataflow failed (%d)" % rc)
     return f
 
 
+def _trunk_failed(st, err):
+    global TRUNK_DATAFLOW
+    st["buf"][_TRUNK_ERROR_SLOT] = 0           # sticky on the device: an error of ANY launch since the last look was still there
+    TRUNK_DATAFLOW = False                      # whoever catches this goes on with the per-layer kernels
+    raise RuntimeError("trunk_dataflow_kernel: a tile timed out waiting for its neighbours at layer %d in a launch since the last "
+                       "look (that launch's output is incomplete; a workgroup was not resident -- is the device shared?).  The "
+                       "dataflow trunk is now off for this process (ops.TRUNK_DATAFLOW)" % (err - 1))
+
+
 def trunk_check():
-    """Host read of the dataflow launches' error words (ONE synchronisation): raises if a tile ever gave up waiting for a
+    """Host read of the dataflow launches' error word (ONE synchronisation): raises if a tile ever gave up waiting for a
     neighbour -- which would mean a workgroup was not resident (more tiles than the GPU holds) or the launch was disturbed."""
-    for key, ws in list(_trunk_ws.items()):
-        tiles = ((key[2] + 15) // 16) * ((key[3] + 31) // 32)
-        err = int(ws[4 + tiles].item())
+    for st in list(_range.values()):
+        err = int(st["buf"][_TRUNK_ERROR_SLOT].item())
         if err:
-            ws[4 + tiles] = 0          # sticky on the device: an error of ANY launch since the last look is still there
-            raise RuntimeError("trunk_dataflow_kernel: a tile timed out waiting for its neighbours at layer %d in a launch since the last "
-                               "check (its output is incomplete)" % (err - 1))
+            _trunk_failed(st, err)
 
 
 # Inference: the whole block in ONE launch (csrc/sr_conv_block.hip) -- bit-identical to the two split-operand launches
@@ -1001,7 +1098,7 @@ def residual_block_fused(x, w1, b1, w2, b2):
         ws = torch.empty(lib.isrResBlockSplitWorkspaceBytes(), dtype=torch.uint8, device=x.device)
         _block_ws[key] = ws
     y = empty_planes(1, 64, h, w, x.device)
-    y._isr_range_key = _arm_range(("block", id(w1)), x.device)      # covers the intermediate and the output
+    y._isr_range_key = _arm_range(("block", id(w1)), x.device, members=[id(w1), id(w2)])      # covers the intermediate and the output
     rc = lib.isrResBlockSplit(_ptr(x), _ptr(_prepare_split(w1)), _ptr(b1.detach().contiguous() if b1 is not None else None),
                               _ptr(_prepare_split(w2)), _ptr(b2.detach().contiguous() if b2 is not None else None), _ptr(y), _ptr(ws),
                               h, w, xp, y.stride(1), _stream())
@@ -1615,7 +1712,7 @@ def tail_conv_finish(features, weight6, bias6, weight8, bias8, net_input, shadin
         inv, spec = int(bool(shading.inverse_ao)), int(bool(shading.enable_specular))
     b6 = bias6.detach().contiguous() if bias6 is not None else None
     b8 = bias8.detach().contiguous() if bias8 is not None else torch.zeros(6, dtype=torch.float32, device=dev)
-    _arm_range(("tail", id(weight6)), dev)         # the largest |y6|: the intermediate is split in registers inside the kernel
+    _arm_range(("tail", id(weight6)), dev, members=[id(weight6)])         # the largest |y6|: the intermediate is split in registers inside the kernel
     fn = lib.isrConvTailFinishFramePacked if packed else lib.isrConvTailFinishFrame
     rc = fn(_ptr(features.data if packed else features), _ptr(wq6), _ptr(b6), _ptr(wz), _ptr(b8), _ptr(ws), _ptr(net_input), _ptr(nxt), _ptr(rgb),
                                     h, w, xp, params, exponent, ao, inv, spec, _stream())

@@ -23,6 +23,7 @@ import torch.distributed as dist
 from . import ops
 from .inference.flowfill import fill_flow
 from .models import VideoTools
+from .pipeline import fused_path_ok, run_network
 from .utils import ScreenSpaceShading, initialImage
 
 HALO = 24
@@ -77,11 +78,27 @@ class StripSuperResolution:
         e0, e1 = max(0, y0 - self.halo), min(h, y1 + self.halo)
         xs = x[:, :, e0:e1]
         net = self.model.model
+        u = self.upscale
+        if x.is_cuda and fused_path_ok(self.model, u):
+            # the frame pipeline's network path on the strip (``pipeline.run_network``): dataflow trunk when the strip's tiles fit
+            # the CUs, three-workgroup upsampling layers, packed-split hand-over, fused 1080p tail + finish -- one code path for a
+            # whole frame and for a strip; per-pixel arithmetic does not depend on the tiling, so strips stay bit-identical to the
+            # unsplit frame (tests/test_conv_gpu.py)
+            xs = xs if (e0 == 0 and e1 == h) else xs.contiguous()
+            ops.guards_poll(xs.device)                     # the previous frame's guard words (pipeline.frame_fused)
+            raw, rgb = run_network(self.model, self.shading, xs)
+            if ops.range_check_due(xs.device):
+                for _ in range(4):                         # range guard, first frame: a hot layer reroutes its consumers; recompute
+                    if not ops.refresh_range_flags(xs.device):
+                        break
+                    raw, rgb = run_network(self.model, self.shading, xs)
+            ops.guards_publish(xs.device)
+            a, b = (y0 - e0) * u, (y1 - e0) * u
+            return raw[:, :, a:b], rgb[:, :, a:b]
         raw, _ = net._recon_image(xs, net.forward_features(xs))
         raw = torch.cat([torch.clamp(raw[:, 0:1], -1, +1),
                          ScreenSpaceShading.normalize(raw[:, 1:4], dim=1),
                          torch.clamp(raw[:, 4:], 0, 1)], dim=1)
-        u = self.upscale
         raw = raw[:, :, (y0 - e0) * u:(y1 - e0) * u]
         self.shading.inverse_ao = self.model.inverse_ao
         return raw, self.shading(raw)

@@ -33,6 +33,62 @@ def default_shading(device, fov=30.0):
     return sh
 
 
+def run_network(model, shading, x, after_trunk=None, prefetch_point="trunk"):
+    """The network and the frame's finishing on the fused HIP path: input [1,101,h,w] -> (raw [1,6,4h,4w] clamped / normalised,
+    rgb [1,3,4h,4w]).  ``model``: inference.LoadedModel; ``after_trunk``: callable run once at ``prefetch_point`` (the frame
+    pipeline releases the next frame's ray-march there).  Used by ``SuperResolutionPipeline`` for whole frames and by
+    ``parallel_sr.StripSuperResolution`` for a rank's strip (``enhancenet.py:92-144`` + ``mainGUI.py:594-603``)."""
+    net = model.model
+    shading.inverse_ao = model.inverse_ao
+    last = net.postblock[8]
+    six = net.postblock[6]
+    f4 = None
+    tail = last.weight.shape[0] == 6 and ops.TAIL_FUSION and ops.SPLIT_F16 and not ops.FAST_F16 and not ops.any_hot(x.device)
+    four = net.postblock[4]
+    if tail and ops.TAIL_PACKED and tuple(six.weight.shape) == (64, 64, 3, 3) and tuple(last.weight.shape) == (6, 64, 3, 3):
+        at = prefetch_point
+        f2 = net.forward_features(x, last_three=False, after_trunk=after_trunk if at == "trunk" else None)
+        if at == "trunk":
+            after_trunk = None
+        if at == "ups1" and after_trunk is not None:
+            after_trunk(); after_trunk = None
+        if ops.packed_supported(f2, four.weight, True):
+            # postblock.4 writes its output packed-split (already the (hi, lo') units postblock.6 multiplies), the tail
+            # stages them by LDS-DMA: no conversion on the way in, no LDS transposition on the way out
+            f4 = ops.conv3x3_split_packed(f2, four.weight, four.bias, act='relu', upsample2x=True)
+        else:
+            f4 = ops.conv3x3(f2, four.weight, four.bias, act='relu', upsample2x=True)
+    elif tail:
+        f4 = net.forward_features(x, last_two=False, after_trunk=after_trunk)
+        after_trunk = None
+    if f4 is not None and after_trunk is not None and prefetch_point != "tail":
+        after_trunk(); after_trunk = None                # "ups2": beside the fused tail
+    if isinstance(f4, ops.PackedSplit) or (f4 is not None and ops.tail_supported(f4, six.weight, last.weight)):
+        # postblock.6, postblock.8 and the frame's finishing in two launches; the 64-channel 1080p tensor between the
+        # two convolutions never goes to memory (csrc/sr_conv_tail.hip)
+        raw, rgb = ops.tail_conv_finish(f4, six.weight, six.bias, last.weight, last.bias, x, shading)
+    elif f4 is not None:
+        f6 = ops.conv3x3(f4, six.weight, six.bias, act='relu')
+        raw, rgb = ops.final_conv_finish(f6, last.weight, last.bias, x, shading)
+    elif last.weight.shape[0] == 6:
+        # the last layer's epilogue finishes the frame (one launch, no [6,4h,4w] round trip)
+        raw, rgb = ops.final_conv_finish(net.forward_features(x, last_layer=False, after_trunk=after_trunk), last.weight, last.bias, x, shading)
+        after_trunk = None
+    else:
+        raw, rgb = ops.finish_frame(net.forward_features(x, after_trunk=after_trunk), x, shading)
+        after_trunk = None
+    if after_trunk is not None:
+        after_trunk()
+    return raw, rgb
+
+
+def fused_path_ok(model, upscale=4):
+    """The fused frame kernels take this network: 4x, residual reconstruction over the five input channels."""
+    net = model.model
+    return upscale == 4 and getattr(net, 'recon_type', None) == 'residual' \
+        and getattr(net, 'channel_mask', None) is not None and len(net.channel_mask) == 5
+
+
 class SuperResolutionPipeline:
     def __init__(self, renderer, model, shading, low_res, upscale=4, temporal=True, device="cuda", fused=True):
         self.renderer = renderer
@@ -84,8 +140,7 @@ class SuperResolutionPipeline:
         self.foreground_variant = 0       # kernel variant of frames rendered on the main stream
         # fused=True: input assembly and frame finishing run as two HIP kernels (ops.assemble_input /
         # ops.finish_frame); fused=False: the module-level PyTorch path (LoadedModel.inference etc.)
-        self.fused = fused and upscale == 4 and getattr(model.model, 'recon_type', None) == 'residual' \
-            and getattr(model.model, 'channel_mask', None) is not None and len(model.model.channel_mask) == 5
+        self.fused = fused and fused_path_ok(model, upscale)
         self.set_static(fov=shading.get_fov(), isovalue=0.5)
 
     def set_static(self, fov, isovalue, lookat=(0.0, 0.0, 0.0), up=(0.0, 1.0, 0.0)):
@@ -171,51 +226,13 @@ class SuperResolutionPipeline:
 
     def _network(self, x, after_trunk=None):
         """Network input [1,101,h,w] -> (raw [1,6,4h,4w] clamped / normalised, rgb [1,3,4h,4w])."""
-        net = self.model.model
-        self.shading.inverse_ao = self.model.inverse_ao
-        last = net.postblock[8]
-        six = net.postblock[6]
-        f4 = None
-        tail = last.weight.shape[0] == 6 and ops.TAIL_FUSION and ops.SPLIT_F16 and not ops.FAST_F16 and not ops.any_hot(x.device)
-        four = net.postblock[4]
-        if tail and ops.TAIL_PACKED and tuple(six.weight.shape) == (64, 64, 3, 3) and tuple(last.weight.shape) == (6, 64, 3, 3):
-            at = self.prefetch_point
-            f2 = net.forward_features(x, last_three=False, after_trunk=after_trunk if at == "trunk" else None)
-            if at == "trunk":
-                after_trunk = None
-            if at == "ups1" and after_trunk is not None:
-                after_trunk(); after_trunk = None
-            if ops.packed_supported(f2, four.weight, True):
-                # postblock.4 writes its output packed-split (already the (hi, lo') units postblock.6 multiplies), the tail
-                # stages them by LDS-DMA: no conversion on the way in, no LDS transposition on the way out
-                f4 = ops.conv3x3_split_packed(f2, four.weight, four.bias, act='relu', upsample2x=True)
-            else:
-                f4 = ops.conv3x3(f2, four.weight, four.bias, act='relu', upsample2x=True)
-        elif tail:
-            f4 = net.forward_features(x, last_two=False, after_trunk=after_trunk)
-            after_trunk = None
-        if f4 is not None and after_trunk is not None and self.prefetch_point != "tail":
-            after_trunk(); after_trunk = None                # "ups2": beside the fused tail
-        if isinstance(f4, ops.PackedSplit) or (f4 is not None and ops.tail_supported(f4, six.weight, last.weight)):
-            # postblock.6, postblock.8 and the frame's finishing in two launches; the 64-channel 1080p tensor between the
-            # two convolutions never goes to memory (csrc/sr_conv_tail.hip)
-            raw, rgb = ops.tail_conv_finish(f4, six.weight, six.bias, last.weight, last.bias, x, self.shading)
-        elif f4 is not None:
-            f6 = ops.conv3x3(f4, six.weight, six.bias, act='relu')
-            raw, rgb = ops.final_conv_finish(f6, last.weight, last.bias, x, self.shading)
-        elif last.weight.shape[0] == 6:
-            # the last layer's epilogue finishes the frame (one launch, no [6,4h,4w] round trip)
-            raw, rgb = ops.final_conv_finish(net.forward_features(x, last_layer=False, after_trunk=after_trunk), last.weight, last.bias, x, self.shading)
-            after_trunk = None
-        else:
-            raw, rgb = ops.finish_frame(net.forward_features(x, after_trunk=after_trunk), x, self.shading)
-            after_trunk = None
-        if after_trunk is not None:
-            after_trunk()
-        return raw, rgb
+        return run_network(self.model, self.shading, x, after_trunk=after_trunk, prefetch_point=self.prefetch_point)
 
     def frame_fused(self, origin, next_origin=None):
         with torch.no_grad():
+            # what the previous frame's kernels reported (a plain read of pinned memory): a layer that came close to the split
+            # operands' range is routed to the exact kernels from THIS frame on; a dataflow-trunk launch that timed out raises
+            ops.guards_poll(self.device)
             if next_origin is not None:
                 self._frame_start.record(torch.cuda.current_stream())
             g = self._acquire_gbuffer(origin)
@@ -240,13 +257,15 @@ class SuperResolutionPipeline:
             self._consumed[self._slot].record(torch.cuda.current_stream())   # G-buffer no longer needed
             raw, rgb = self._network(x, after_trunk=start_next)
             if ops.range_check_due(x.device):
-                # range guard (ops.RANGE_GUARD): a layer's output came close to the fp16 range of the split operands -- from now on
-                # its consumers run on the exact fp32 kernels; this frame is computed again with that routing.  (Again, because the
-                # fused launches only say THAT something inside them was hot: the per-layer pass that replaces them says where.)
+                # range guard (ops.RANGE_GUARD), a model's FIRST frame: a layer's output came close to the fp16 range of the split
+                # operands -- its consumers run on the exact fp32 kernels from now on; this frame is computed again with that routing.
+                # (Again, because the fused launches only say THAT something inside them was hot: the per-layer pass that replaces
+                # them says where.)  Every later frame is watched one frame late: guards_publish here, guards_poll at the next start.
                 for _ in range(4):
                     if not ops.refresh_range_flags(x.device):
                         break
                     raw, rgb = self._network(x)
+            ops.guards_publish(x.device)
             self.previous = raw
         return rgb, raw
 

@@ -3,9 +3,10 @@
 An activation is split into (hi, lo') fp16 numbers; |x| >= 65520 overflows that split (csrc/sr_conv_split.hip, header).  The
 reference's networks never get there (G-buffer inputs in [-1, 5], small weights), but ``inference.LoadedModel`` takes arbitrary
 user checkpoints (SuperresolutionNetwork/inference/loadedmodel.py:16-68), so: (1) the overflow is LOUD (inf / NaN, never a
-plausible number), (2) every launch records the largest magnitude it stored, and after the first frame of a model (then every
-``ops.RANGE_CHECK_EVERY`` frames) the producers that came close are marked hot and their consumers run on the exact fp32
-kernels -- a checkpoint with a badly scaled layer still matches the fp64 CPU network."""
+plausible number), (2) every launch records the largest magnitude it stored, and after the first frame of a model the producers that came close are marked hot and their consumers run on the exact fp32
+kernels -- a checkpoint with a badly scaled layer still matches the fp64 CPU network; (3) every LATER frame mirrors the words
+into pinned host memory and the next frame reads them at its start: a layer that turns hot in mid-sequence is rerouted one frame
+later, without a synchronisation.  (``ops.RANGE_CHECK_EVERY`` is gone.)"""
 import argparse
 
 import pytest
@@ -108,4 +109,73 @@ def test_checkpoint_with_a_badly_scaled_layer_still_matches_the_fp64_network(tmp
     assert ops.any_hot(raw.device) and torch.isfinite(raw).all() and torch.isfinite(rgb).all()
     rgb2, raw2 = pipe.frame(V.orbit_camera(1))
     assert torch.isfinite(raw2).all()
+    ops.range_reset()
+
+
+def test_a_layer_that_turns_hot_after_the_first_frame_is_rerouted_one_frame_later():
+    """the range guard is continuous.  A network whose activations stay small for frames 0-2 and reach ~4.5e4
+    (above the 3e4 threshold, below the fp16 overflow at 65520) from frame 3 on: frame 3 still runs on the split kernels -- and is
+    right, that is what the factor-two margin is for -- its guard words travel to pinned memory with the frame, frame 4 STARTS by
+    reading them (no synchronisation) and runs every layer of the fused trunk on the exact kernels.  Every frame matches the fp64
+    network to 1e-4 of the output scale -- frames 5-6, whose activations (1.35e5) would overflow the split, included; nothing reads the
+    device between frames."""
+    from isosurfacesuperresolution_amd import models, ops
+    from isosurfacesuperresolution_amd.inference import LoadedModel
+    opt = argparse.Namespace(upsample='bilinear', reconType='residual', useBN=False, numResidualLayers=10)
+    torch.manual_seed(15)
+    net = models.createNetwork('EnhanceNet', 4, 101, [0, 1, 2, 3, 4], 6, opt)
+    with torch.no_grad():
+        net.blocks[2][0].weight.mul_(300.0)                       # one badly scaled layer inside the fused trunk
+        net.postblock[1].weight.mul_(0.02)                        # ... and nothing larger downstream: the trunk holds the maximum
+    ref_net = models.createNetwork('EnhanceNet', 4, 101, [0, 1, 2, 3, 4], 6, opt).double()
+    ref_net.load_state_dict({k: v.double() for k, v in net.state_dict().items()})
+    lm = LoadedModel.from_model(net, "cuda", parameters={"initialImage": "zero"})
+    dev = torch.device("cuda", torch.cuda.current_device())
+    g = torch.Generator().manual_seed(16)
+    base = torch.rand(1, 12, 40, 64, generator=g)
+    base[:, 3] = (base[:, 3] > 0.3).float()
+
+    def low(amp):
+        v = base.clone()
+        v[:, 4:8] *= amp                                          # normals / depth: the network is (nearly) homogeneous in them
+        return v
+
+    def reference(v):
+        inp = torch.cat((v[:, 3:4] * 2 - 1, v[:, 4:8], torch.zeros(1, 96, 40, 64)), dim=1)
+        with torch.no_grad():
+            return ref_net(inp.double())[0]
+
+    def largest_stored():
+        st = ops._range_state(dev)
+        words = st["buf"][:len(st["slots"])].view(torch.float32)
+        trunk, = [i for k, i in st["slots"].items() if isinstance(k, tuple) and k[0] == "trunk"]
+        assert float(words.max().item()) <= 1.05 * float(words[trunk].item())      # the trunk's word is the network's maximum
+        return float(words[trunk].item())
+    # calibrate the amplitudes on the device itself: largest |value| any layer stores at amplitude 1
+    with torch.no_grad():
+        lm.inference(low(1.0).cuda(), None)
+    m1 = largest_stored()
+    ops.range_reset()
+    small, big = 1.0e3 / m1, 4.5e4 / m1
+    assert not ops.any_hot(dev)
+    hot_after = []
+    for t in range(7):
+        # frames 0-2 small; 3-4 hot but representable; 5-6 beyond the fp16 range of the split operands: loud NaN unless rerouted
+        v = low(small if t < 3 else big if t < 5 else 3.0 * big)
+        with torch.no_grad():
+            out = lm.inference(v.cuda(), None)
+        torch.cuda.synchronize()                                  # (so that "one frame late" is deterministic in this test)
+        hot_after.append(ops.any_hot(dev))
+        ref = reference(v)
+        scale = ref.abs().max().item()
+        assert torch.isfinite(out).all(), t
+        assert (out.double().cpu() - ref).abs().max().item() <= 1e-4 * scale, (t, scale)
+        if t == 3:
+            peak = largest_stored()
+            assert 3.2e4 < peak < 6.4e4, peak                     # hot, not yet overflowing: the margin the guard relies on
+    # frames 0-3 ran unflagged (3 produced the hot values), frame 4 read frame 3's words at its start
+    assert hot_after == [False, False, False, False, True, True, True], hot_after
+    st = ops._range_state(dev)
+    trunk_keys = [k for k in st["hot"] if isinstance(k, tuple) and k[0] == "trunk"]
+    assert trunk_keys and all(id(m.weight) in st["hot"] for b in lm.model.blocks for m in (b[0], b[2]))      # the segment, taken apart conservatively
     ops.range_reset()

@@ -121,22 +121,66 @@ def test_dataflow_trunk_with_other_depths_and_input_widths(cin, nblocks, h, w):
 
 
 def test_error_word_of_the_dataflow_trunk_is_sticky():
-    """A tile that gives up on a neighbour leaves 1 + layer in the workspace's error word; later launches must not clear it (the
-    host looks only now and then: ops.trunk_check, bench.py after its timed region), the check that reports it does."""
+    """A tile that gives up on a neighbour leaves 1 + layer in the error word (the last of the per-frame guard words,
+    isrSetTrunkErrorWord); later launches must not clear it, the check that reports it does -- and switches the dataflow form off."""
     from isosurfacesuperresolution_amd import ops
     g = torch.Generator().manual_seed(9)
     convs = [(((torch.rand(64, 16 if k == 0 else 64, 3, 3, generator=g) - 0.5) * 0.1).cuda(), None) for k in range(3)]
     x = torch.rand(1, 16, 40, 70, generator=g).cuda()
-    with torch.no_grad():
-        ops.trunk_dataflow(x, convs)
-        torch.cuda.synchronize()
-        ops.trunk_check()
-        (key, ws), = [(k, w) for k, w in ops._trunk_ws.items() if k[1:4] == (16, 40, 70)]
-        tiles = ((40 + 15) // 16) * ((70 + 31) // 32)
-        ws[4 + tiles] = 7                      # as if layer 6 had timed out in some earlier launch
-        ops.trunk_dataflow(x, convs)
-        ops.trunk_dataflow(x, convs)
-        torch.cuda.synchronize()
-        with pytest.raises(RuntimeError, match="layer 6"):
+    try:
+        with torch.no_grad():
+            ops.trunk_dataflow(x, convs)
+            torch.cuda.synchronize()
             ops.trunk_check()
-        ops.trunk_check()                      # reported once, then reset
+            st = ops._range_state(x.device)
+            st["buf"][ops._TRUNK_ERROR_SLOT] = 7   # as if layer 6 had timed out in some earlier launch
+            ops.trunk_dataflow(x, convs)
+            ops.trunk_dataflow(x, convs)
+            torch.cuda.synchronize()
+            with pytest.raises(RuntimeError, match="layer 6"):
+                ops.trunk_check()
+            assert ops.TRUNK_DATAFLOW is False     # whoever catches the error continues on the per-layer kernels
+            ops.trunk_check()                      # reported once, then reset
+    finally:
+        ops.TRUNK_DATAFLOW = True
+
+
+def test_a_timeout_induced_on_the_device_raises_at_the_start_of_the_next_frame():
+    """the timeout path itself (deadline -> LDS flag -> atomicMax(error) -> early return), executed by the
+    kernel: a diagnostic switch makes ONE tile never publish its progress and shortens the deadline to 2 ms.  The frame with the
+    fault returns without any host synchronisation; the NEXT frame's start reads the guard words the faulty frame mirrored into
+    pinned memory, raises, and leaves the dataflow form off -- the frame after that runs on the per-layer kernels and is right."""
+    from isosurfacesuperresolution_amd import ops, volumes as V
+    from isosurfacesuperresolution_amd.inference import DirectRenderer, LoadedModel
+    from isosurfacesuperresolution_amd.pipeline import SuperResolutionPipeline, default_shading
+    lib = ops._sr()
+    net = _net(21)
+    r = DirectRenderer()
+    r.load_dense(V.ejecta(64))
+    lm = LoadedModel.from_model(net, "cuda", parameters={"initialImage": "zero"})
+    pipe = SuperResolutionPipeline(r, lm, default_shading("cuda", 30.0), (96, 56), temporal=False)      # 4 x 3 tiles of 16 x 32
+    pipe.set_static(fov=30.0, isovalue=0.34)
+    try:
+        for k in range(3):
+            rgb_ok, raw_ok = pipe.frame(V.orbit_camera(k))          # clean frames (the first one takes the synchronous check)
+        torch.cuda.synchronize()
+        good = raw_ok.clone()
+        lib.isrDebugSetTrunkFault(5, 200000)                         # tile 5 never publishes; deadline 2 ms after the kernel's start
+        assert ops.debug_switches() != 0                             # bench.py would refuse to report in this state
+        _, raw_bad = pipe.frame(V.orbit_camera(2))                   # returns: nothing inside a frame waits for the host
+        lib.isrDebugSetTrunkFault(-1, 0)
+        torch.cuda.synchronize()
+        assert int(ops._range_state(raw_bad.device)["buf"][ops._TRUNK_ERROR_SLOT].item()) >= 2     # set by the KERNEL: 1 + layer
+        assert not torch.equal(raw_bad, good)                        # the launch's output was incomplete
+        with pytest.raises(RuntimeError, match="timed out waiting for its neighbours"):
+            pipe.frame(V.orbit_camera(2))                            # the next frame, not frame 256
+        assert ops.TRUNK_DATAFLOW is False
+        _, raw_again = pipe.frame(V.orbit_camera(2))                 # per-layer kernels: bit-identical to the dataflow form
+        torch.cuda.synchronize()
+        assert torch.equal(raw_again, good)
+        pipe.frame(V.orbit_camera(3))                                # and nothing is left pending
+    finally:
+        lib.isrDebugSetTrunkFault(-1, 0)
+        ops.TRUNK_DATAFLOW = True
+        torch.cuda.synchronize()
+        ops._range_state("cuda")["buf"][ops._TRUNK_ERROR_SLOT] = 0
