@@ -1101,6 +1101,7 @@ __global__ __launch_bounds__(256) void prepare_weights_split_many_kernel(const P
 } // namespace
 
 #include "sr_conv_ups3.h"       // the three-workgroups-per-CU upsampling kernel: same translation unit, same parameter block
+#include "sr_conv_ups4.h"       // the role-split upsampling kernel (producer / consumer waves)
 #include "sr_conv_block2.h"     // two chained convolutions of a batch of small images in one launch (training trunk)
 
 __device__ u32x4 g_split_zero_unit[4];      // zero initialised: source of the zero-padding units of the LDS-DMA staging
@@ -1274,7 +1275,11 @@ int isrConv3x3ForwardSplit(const float* x, const void* wq, const float* bias, co
         return hipGetLastError() == hipSuccess ? 0 : -2;
     }
     // algorithmic flops of the convolution (2 * 9 * Cin * Cout per output pixel), not the 3x matrix flops spent on it
-    const bool ups3 = upsample2x && g_split_ups_form == 3 && Cin > 0 && !(Cin & 15) && p.coutPad == 64 && Cout == 64 && p.cgroups == 1 && !p.xps;
+    if (upsample2x && g_split_ups_form == 4 && isr_split_ups4_takes(p)) {
+        isr_profile_record(ISR_VARIANT_SPLIT_UPS4, 2.0 * 9 * Cin * Cout * (double)N * H * W, &e0, &e1);
+        return isr_launch_split_ups4(p, s, e0, e1);
+    }
+    const bool ups3 = upsample2x && (g_split_ups_form == 3 || g_split_ups_form == 4) && Cin > 0 && !(Cin & 15) && p.coutPad == 64 && Cout == 64 && p.cgroups == 1 && !p.xps;
     isr_profile_record(ups3 ? ISR_VARIANT_SPLIT_UPS3 : upsample2x ? ISR_VARIANT_SPLIT_UPS : ISR_VARIANT_SPLIT, 2.0 * 9 * Cin * Cout * (double)N * H * W, &e0, &e1);
     if (ups3) {
         const int rc = isr_launch_split_ups3(p, (unsigned)nwg, s, e0, e1);

@@ -191,7 +191,7 @@ VARIANT_NAMES = {6: "conv3x3_small_cout_kernel", 2: "conv3x3_fwd_kernel<1,false>
                  13: "conv3x3_split_kernel<false>", 14: "conv3x3_split_kernel<true>",
                  15: "conv3x3_split_stream_kernel", 16: "conv3x3_split_wide_kernel", 17: "conv3x3_split_rows2_kernel",
                  18: "conv3x3_split_tail_kernel", 19: "resblock_split_kernel", 20: "trunk_dataflow_kernel",
-                 21: "conv3x3_split_ups3_kernel", 22: "conv3x3_split_block2_kernel"}
+                 21: "conv3x3_split_ups3_kernel", 22: "conv3x3_split_block2_kernel", 23: "conv3x3_split_ups4_kernel"}
 
 
 def debug_switches():

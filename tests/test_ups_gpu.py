@@ -1,6 +1,6 @@
-"""The three-workgroups-per-CU upsampling kernel (csrc/sr_conv_ups3.h) against the tile kernel (conv3x3_split_kernel<true>) -- the
-same interpolation and products in the same order: EQUAL bit for bit -- and against torch
-(SuperresolutionNetwork/models/enhancenet.py:113-124)."""
+"""The three-workgroups-per-CU upsampling kernel (csrc/sr_conv_ups3.h) and the role-split one (csrc/sr_conv_ups4.h: producer waves
+stage, consumer waves multiply) against the tile kernel (conv3x3_split_kernel<true>) -- the same interpolation and products in the
+same order: EQUAL bit for bit -- and against torch (SuperresolutionNetwork/models/enhancenet.py:113-124)."""
 import ctypes
 
 import pytest
@@ -21,28 +21,32 @@ def _forms(fn):
         tile = fn()
         lib.isrDebugSetSplitUpsForm(3)
         three = fn()
+        lib.isrDebugSetSplitUpsForm(4)
+        four = fn()
     finally:
         lib.isrDebugSetSplitUpsForm(default)
     torch.cuda.synchronize()
-    return tile, three
+    return tile, three, four
 
 
-@pytest.mark.parametrize("h,w,cin", [(4, 16, 64), (5, 18, 64), (17, 34, 64), (135, 240, 64), (270, 480, 64), (30, 50, 32), (9, 10, 16)])
-def test_three_per_cu_upsampling_kernel_is_bit_identical_to_the_tile_kernel(h, w, cin):
+@pytest.mark.parametrize("h,w,cin", [(4, 16, 64), (5, 18, 64), (17, 34, 64), (135, 240, 64), (270, 480, 64), (540, 960, 64), (30, 50, 32), (9, 10, 16)])
+def test_three_per_cu_and_role_split_upsampling_kernels_are_bit_identical_to_the_tile_kernel(h, w, cin):
     from isosurfacesuperresolution_amd import ops
     g = torch.Generator().manual_seed(h * 1000 + w)
     x = ((torch.rand(1, cin, h, w, generator=g) - 0.4) * 3).cuda()
     wt = ((torch.rand(64, cin, 3, 3, generator=g) - 0.5) * 0.2).cuda()
     b = ((torch.rand(64, generator=g) - 0.5) * 0.3).cuda()
     with torch.no_grad():
-        tile, three = _forms(lambda: ops.conv3x3_split(x, wt, b, act='relu', upsample2x=True))
+        tile, three, four = _forms(lambda: ops.conv3x3_split(x, wt, b, act='relu', upsample2x=True))
         assert torch.equal(tile, three), (tile - three).abs().max().item()
+        assert torch.equal(tile, four), (tile - four).abs().max().item()
         ref = F.relu(F.conv2d(F.interpolate(x.double(), scale_factor=2, mode='bilinear', align_corners=False), wt.double(), b.double(), padding=1))
         err = (three.double() - ref).abs().max().item()
         assert err <= 2e-6 * max(1.0, ref.abs().max().item()), err
         if ops.packed_supported(x, wt, True):
-            pt, p3 = _forms(lambda: ops.conv3x3_split_packed(x, wt, b, act='relu', upsample2x=True).data.clone())
+            pt, p3, p4 = _forms(lambda: ops.conv3x3_split_packed(x, wt, b, act='relu', upsample2x=True).data.clone())
             assert torch.equal(pt, p3)
+            assert torch.equal(pt, p4)
 
 
 def test_three_per_cu_upsampling_kernel_takes_batches_and_residuals():
@@ -51,5 +55,5 @@ def test_three_per_cu_upsampling_kernel_takes_batches_and_residuals():
     x = (torch.rand(3, 64, 20, 36, generator=g) - 0.5).cuda()
     wt = ((torch.rand(64, 64, 3, 3, generator=g) - 0.5) * 0.2).cuda()
     with torch.no_grad():
-        tile, three = _forms(lambda: ops.conv3x3_split(x, wt, None, act='none', upsample2x=True))
-    assert torch.equal(tile, three)
+        tile, three, four = _forms(lambda: ops.conv3x3_split(x, wt, None, act='none', upsample2x=True))
+    assert torch.equal(tile, three) and torch.equal(tile, four)
