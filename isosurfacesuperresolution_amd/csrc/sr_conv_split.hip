@@ -958,6 +958,9 @@ __global__ __launch_bounds__(S_THREADS, 1) void conv3x3_split_rows2_kernel(const
     isr_range_note(p.absmax, rmag);
 }
 
+// hi 2^-11, element-wise in fp16 (IEEE, subnormals kept): the value `a0h * (_Float16)0.00048828125f` has in the kernels
+__device__ __forceinline__ f16x8 split_scaled_hi(f16x8 qh) { return qh * (_Float16)0.00048828125f; }
+
 // header unit of the prepared weights: { 2^S, 2^-S, S (int), 0 } with max |w| 2^S in [2^13, 2^14)
 __global__ __launch_bounds__(1024) void split_scale_kernel(const float* __restrict__ w, int count, u32x4* __restrict__ wq)
 {
@@ -1014,6 +1017,8 @@ __global__ void prepare_weights_split_kernel(const float* __restrict__ w, u32x4*
         const size_t base = 1 + (size_t)(((tap * ksteps + s) * 2 + 0) * 2 + hh) * coutPad + co;
         wq[base] = __builtin_bit_cast(u32x4, qh);
         wq[base + (size_t)2 * coutPad] = __builtin_bit_cast(u32x4, ql);
+        // third plane, behind the (hi, lo) image: hi 2^-11 in fp16 -- what the kernels otherwise compute per fragment (v_pk_mul_f16)
+        wq[1 + (size_t)9 * ksteps * 4 * coutPad + (size_t)((tap * ksteps + s) * 2 + hh) * coutPad + co] = __builtin_bit_cast(u32x4, split_scaled_hi(qh));
     }
 }
 
@@ -1095,6 +1100,7 @@ __global__ __launch_bounds__(256) void prepare_weights_split_many_kernel(const P
         const size_t base = 1 + (size_t)(((tap * ksteps + s) * 2 + 0) * 2 + hh) * coutPad + co;
         wq[base] = __builtin_bit_cast(u32x4, qh);
         wq[base + (size_t)2 * coutPad] = __builtin_bit_cast(u32x4, ql);
+        wq[1 + (size_t)9 * ksteps * 4 * coutPad + (size_t)((tap * ksteps + s) * 2 + hh) * coutPad + co] = __builtin_bit_cast(u32x4, split_scaled_hi(qh));
     }
 }
 
@@ -1142,7 +1148,8 @@ void isrDebugSetSplitSmall(int on) { g_split_small = on; }
 long long isrConvSplitWeightBytes(int Cin, int Cout)
 {
     if (Cin <= 0 || Cout <= 0) return -1;
-    return 16 + (long long)9 * ((Cin + 15) / 16) * 2 * 2 * (((Cout + 31) / 32) * 32) * 16;
+    // header + [tap][k-step][hi | lo][lane half][coutPad] units + the third plane [tap][k-step][lane half][coutPad] (hi 2^-11)
+    return 16 + (long long)9 * ((Cin + 15) / 16) * (2 * 2 + 2) * (((Cout + 31) / 32) * 32) * 16;
 }
 
 int isrConvSplitPrepare(const float* w, void* wq, int Cout, int Cin, void* stream)

@@ -16,8 +16,8 @@ namespace {
 constexpr int U3_PART = 2 * SP_PIX;                                          // one k-step of the patch: 2 channel groups; hi, then lo' at + U3_PART
 constexpr int U3_PUNITS = 2 * U3_PART;                                       // 1360 units = 21 760 B
 constexpr int U3_WROW = 3 * 128;                                             // one tap row of one part: 3 taps x [lane half][64 couts]
-constexpr int U3_WUNITS = 2 * U3_WROW;                                       // hi then lo: 768 units = 12 288 B, 3 per thread
-constexpr int U3_LDS_BYTES = (U3_PUNITS + U3_WUNITS) * 16;                   // 34 048: three workgroups per CU (the epilogue's 32 KB scratch fits too)
+constexpr int U3_WUNITS = 3 * U3_WROW;                                       // hi, lo, then hi 2^-11 (the partner of the scaled x_lo'): 1 152 units = 18 432 B, 4.5 per thread
+constexpr int U3_LDS_BYTES = (U3_PUNITS + U3_WUNITS) * 16;                   // 40 192: three workgroups per CU (the epilogue's 32 KB scratch fits too)
 
 __global__ __launch_bounds__(S_THREADS, 3) void conv3x3_split_ups3_kernel(const SplitConvParams p)
 {
@@ -43,15 +43,27 @@ __global__ __launch_bounds__(S_THREADS, 3) void conv3x3_split_ups3_kernel(const 
     const rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<u32x4*>(p.wq + 1), 0, 9 * p.ksteps * 4096, 0x00020000);
     u32x4* const wdst = wbuf + (tid >> 7) * U3_WROW + (tid & 127);
     u32x4 wreg[3];
+    // the THIRD plane of the image (isrConvSplitPrepare): w_hi 2^-11 as fp16, [tap][k-step][128 units] behind the (hi, lo) planes -- the A
+    // operand of the x_lo' product, which the other kernels make with four v_pk_mul_f16 per fragment (288 vector instructions per wave
+    // and tile here).  384 units per tap row: thread t moves unit t, threads < 128 also unit 256 + t.
+    const rsrc_t w3rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<u32x4*>(p.wq + 1 + 9 * p.ksteps * 256), 0, 9 * p.ksteps * 2048, 0x00020000);
+    u32x4 wreg3[2];
     auto wfetch = [&](int step) {                                            // step = 3 ks + dy
         if (step >= 3 * p.ksteps) return;
         const int ks = step / 3, dy = step - 3 * ks;
 #pragma unroll
         for (int i = 0; i < 3; ++i) wreg[i] = __builtin_amdgcn_raw_buffer_load_b128(wrs, tid * 16, ((3 * dy + i) * p.ksteps + ks) * 4096, 0);
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            const int e = tid + 256 * k;                                     // (tap e / 128, unit e % 128) of the tap row
+            wreg3[k] = __builtin_amdgcn_raw_buffer_load_b128(w3rs, (int)(e < 384 ? (unsigned)(e & 127) * 16u : BAD_OFFSET), ((3 * dy + (e >> 7)) * p.ksteps + ks) * 2048, 0);
+        }
     };
     auto wpark = [&]() {
 #pragma unroll
         for (int i = 0; i < 3; ++i) wdst[i * 128] = wreg[i];
+        wbuf[2 * U3_WROW + tid] = wreg3[0];
+        if (tid < 128) wbuf[2 * U3_WROW + 256 + tid] = wreg3[1];
     };
 
     // ---- staging of one k-step (16 channels): low-resolution region -> fp32 copy on the (idle) weight buffer -> interpolate, split
@@ -89,45 +101,67 @@ __global__ __launch_bounds__(S_THREADS, 3) void conv3x3_split_ups3_kernel(const 
             if (q < LQ - 1) dst[3] = f.w;
         }
     };
+    // INTERIOR tiles (all but the image's outermost ring of tiles): every patch pixel lies in the image and no source index is clamped,
+    // so quad (kr, kc) blends the copy's rows kr, kr + 1 and columns kc, kc + 1 with the weights 3/4, 1/4 (upper / left pixel of the
+    // quad) and 1/4, 3/4 -- exactly what isr_src_index evaluates to there, as compile-time constants: no index arithmetic, no clamps,
+    // no validity selects (~100 of the ~230 vector instructions a unit costs; vector instructions are paid at full price beside the
+    // MFMAs, tools/mfma_valu_overlap.hip).  Same operations on the same values in the same order: bit-identical.
+    const bool interior = oy0 >= 2 && oy0 + ST_H + 2 <= p.H && ox0 >= 2 && ox0 + ST_W + 2 <= p.W;
     auto interpolate = [&]() {
         _Float16* const patch16 = reinterpret_cast<_Float16*>(patch);
         for (int u = tid; u < 4 * UQ; u += S_THREADS) {
             const int g4 = u & 3, q = u >> 2;                                // neighbouring lanes: the 4 four-channel groups of one quad
             const int kr = q / QC, kc = q - kr * QC;
-            const int Yu = oy0 - 1 + 2 * kr, Xl = ox0 - 1 + 2 * kc;
-            const bool oku = (unsigned)Yu < (unsigned)p.H, okd = (unsigned)(Yu + 1) < (unsigned)p.H;
-            const bool okl = (unsigned)Xl < (unsigned)p.W, okr = (unsigned)(Xl + 1) < (unsigned)p.W;
-            int y0, y1, x0, x1, t0, t1; float lyu, lyd, lxl, lxr, t;
-            isr_src_index(oku ? Yu : Yu + 1, 0.5f, p.Hin, y0, y1, t);         // both rows of the pair blend these two source rows
-            isr_src_index(okl ? Xl : Xl + 1, 0.5f, p.Win, x0, x1, t);
-            isr_src_index(Yu, 0.5f, p.Hin, t0, t1, lyu);
-            isr_src_index(Yu + 1, 0.5f, p.Hin, t0, t1, lyd);
-            isr_src_index(Xl, 0.5f, p.Win, t0, t1, lxl);
-            isr_src_index(Xl + 1, 0.5f, p.Win, t0, t1, lxr);
-            const float hyu = 1.f - lyu, hyd = 1.f - lyd, hxl = 1.f - lxl, hxr = 1.f - lxr;
-            // rows / columns wholly outside the image (tile overhang) keep their indices inside the staged region
-            y0 = min(max(y0 - ly0, 0), LR_H - 1); y1 = min(max(y1 - ly0, 0), LR_H - 1);
-            x0 = min(max(x0 - lx0, 0), LR_W - 1); x1 = min(max(x1 - lx0, 0), LR_W - 1);
-            const float* ta = tmp + (g4 * 4) * LR_CS + y0 * LR_W;
-            const float* tb = tmp + (g4 * 4) * LR_CS + y1 * LR_W;
             f16x4 h00, h01, h10, h11, l00, l01, l10, l11;
+            if (interior) {
+                const float* ta = tmp + (g4 * 4) * LR_CS + kr * LR_W + kc;
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const float a0 = ta[e * LR_CS + x0], a1 = ta[e * LR_CS + x1];
-                const float b0 = tb[e * LR_CS + x0], b1 = tb[e * LR_CS + x1];
-                const float al = isr_blend(hxl, a0, lxl, a1), ar = isr_blend(hxr, a0, lxr, a1);
-                const float bl = isr_blend(hxl, b0, lxl, b1), br = isr_blend(hxr, b0, lxr, b1);
-                _Float16 vh, vl;
-                split16x(isr_blend(hyu, al, lyu, bl), vh, vl); h00[e] = vh; l00[e] = vl;
-                split16x(isr_blend(hyu, ar, lyu, br), vh, vl); h01[e] = vh; l01[e] = vl;
-                split16x(isr_blend(hyd, al, lyd, bl), vh, vl); h10[e] = vh; l10[e] = vl;
-                split16x(isr_blend(hyd, ar, lyd, br), vh, vl); h11[e] = vh; l11[e] = vl;
+                for (int e = 0; e < 4; ++e) {
+                    const float a0 = ta[e * LR_CS], a1 = ta[e * LR_CS + 1];
+                    const float b0 = ta[e * LR_CS + LR_W], b1 = ta[e * LR_CS + LR_W + 1];
+                    const float al = isr_blend(0.75f, a0, 0.25f, a1), ar = isr_blend(0.25f, a0, 0.75f, a1);
+                    const float bl = isr_blend(0.75f, b0, 0.25f, b1), br = isr_blend(0.25f, b0, 0.75f, b1);
+                    _Float16 vh, vl;
+                    split16x(isr_blend(0.75f, al, 0.25f, bl), vh, vl); h00[e] = vh; l00[e] = vl;
+                    split16x(isr_blend(0.75f, ar, 0.25f, br), vh, vl); h01[e] = vh; l01[e] = vl;
+                    split16x(isr_blend(0.25f, al, 0.75f, bl), vh, vl); h10[e] = vh; l10[e] = vl;
+                    split16x(isr_blend(0.25f, ar, 0.75f, br), vh, vl); h11[e] = vh; l11[e] = vl;
+                }
+            } else {
+                const int Yu = oy0 - 1 + 2 * kr, Xl = ox0 - 1 + 2 * kc;
+                const bool oku = (unsigned)Yu < (unsigned)p.H, okd = (unsigned)(Yu + 1) < (unsigned)p.H;
+                const bool okl = (unsigned)Xl < (unsigned)p.W, okr = (unsigned)(Xl + 1) < (unsigned)p.W;
+                int y0, y1, x0, x1, t0, t1; float lyu, lyd, lxl, lxr, t;
+                isr_src_index(oku ? Yu : Yu + 1, 0.5f, p.Hin, y0, y1, t);     // both rows of the pair blend these two source rows
+                isr_src_index(okl ? Xl : Xl + 1, 0.5f, p.Win, x0, x1, t);
+                isr_src_index(Yu, 0.5f, p.Hin, t0, t1, lyu);
+                isr_src_index(Yu + 1, 0.5f, p.Hin, t0, t1, lyd);
+                isr_src_index(Xl, 0.5f, p.Win, t0, t1, lxl);
+                isr_src_index(Xl + 1, 0.5f, p.Win, t0, t1, lxr);
+                const float hyu = 1.f - lyu, hyd = 1.f - lyd, hxl = 1.f - lxl, hxr = 1.f - lxr;
+                // rows / columns wholly outside the image (tile overhang) keep their indices inside the staged region
+                y0 = min(max(y0 - ly0, 0), LR_H - 1); y1 = min(max(y1 - ly0, 0), LR_H - 1);
+                x0 = min(max(x0 - lx0, 0), LR_W - 1); x1 = min(max(x1 - lx0, 0), LR_W - 1);
+                const float* ta = tmp + (g4 * 4) * LR_CS + y0 * LR_W;
+                const float* tb = tmp + (g4 * 4) * LR_CS + y1 * LR_W;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float a0 = ta[e * LR_CS + x0], a1 = ta[e * LR_CS + x1];
+                    const float b0 = tb[e * LR_CS + x0], b1 = tb[e * LR_CS + x1];
+                    const float al = isr_blend(hxl, a0, lxl, a1), ar = isr_blend(hxr, a0, lxr, a1);
+                    const float bl = isr_blend(hxl, b0, lxl, b1), br = isr_blend(hxr, b0, lxr, b1);
+                    _Float16 vh, vl;
+                    split16x(isr_blend(hyu, al, lyu, bl), vh, vl); h00[e] = vh; l00[e] = vl;
+                    split16x(isr_blend(hyu, ar, lyu, br), vh, vl); h01[e] = vh; l01[e] = vl;
+                    split16x(isr_blend(hyd, al, lyd, bl), vh, vl); h10[e] = vh; l10[e] = vl;
+                    split16x(isr_blend(hyd, ar, lyd, br), vh, vl); h11[e] = vh; l11[e] = vl;
+                }
+                const f16x4 z = {(_Float16)0.0f, (_Float16)0.0f, (_Float16)0.0f, (_Float16)0.0f};
+                if (!(oku && okl)) { h00 = z; l00 = z; }
+                if (!(oku && okr)) { h01 = z; l01 = z; }
+                if (!(okd && okl)) { h10 = z; l10 = z; }
+                if (!(okd && okr)) { h11 = z; l11 = z; }
             }
-            const f16x4 z = {(_Float16)0.0f, (_Float16)0.0f, (_Float16)0.0f, (_Float16)0.0f};
-            if (!(oku && okl)) { h00 = z; l00 = z; }
-            if (!(oku && okr)) { h01 = z; l01 = z; }
-            if (!(okd && okl)) { h10 = z; l10 = z; }
-            if (!(okd && okr)) { h11 = z; l11 = z; }
             // 16-byte unit (8-channel group g4 / 2, pixel) holds 8 halves: this 4-channel group is its half (g4 & 1)
             _Float16* d = patch16 + ((size_t)((g4 >> 1) * SP_PIX + (2 * kr) * SP_W + 2 * kc)) * 8 + (g4 & 1) * 4;
             *reinterpret_cast<f16x4*>(d) = h00;
@@ -174,8 +208,8 @@ __global__ __launch_bounds__(S_THREADS, 3) void conv3x3_split_ups3_kernel(const 
                     const f16x8 a0l = __builtin_bit_cast(f16x8, wl[U3_WROW + dx * 128]);
                     const f16x8 a1h = __builtin_bit_cast(f16x8, wl[dx * 128 + 32]);
                     const f16x8 a1l = __builtin_bit_cast(f16x8, wl[U3_WROW + dx * 128 + 32]);
-                    const f16x8 a0s = a0h * (_Float16)0.00048828125f;       // w_hi 2^-11: partner of the scaled x_lo'
-                    const f16x8 a1s = a1h * (_Float16)0.00048828125f;
+                    const f16x8 a0s = __builtin_bit_cast(f16x8, wl[2 * U3_WROW + dx * 128]);        // w_hi 2^-11: partner of the scaled x_lo'
+                    const f16x8 a1s = __builtin_bit_cast(f16x8, wl[2 * U3_WROW + dx * 128 + 32]);
 #pragma unroll
                     for (int r = 0; r < 2; ++r) {
                         const f16x8 bh = __builtin_bit_cast(f16x8, bl[r * SP_W + dx]);
