@@ -15,6 +15,7 @@
 //
 // Against the three-kernel tail (conv3x3_split_stream_kernel, conv3x3_small_cout_kernel with its fused finish): the
 // fp32 4x4x1-MFMA kernel (0.20 ms, 72 TFLOP/s) and its 606 MB read are gone, the 531 MB write of y6 becomes 448 MB of z.
+#include <cstdlib>
 #include "sr_split_common.h"
 
 namespace {
@@ -36,6 +37,7 @@ struct TailParams {
     // ones it owns into the pixel's record [9 taps][6 channels]; tail_seam_finish_kernel adds them in the same tap order
     FinishParams fin;
     const float* bias8;
+    float* srec;                 // S form: [H][tilesX][6 kinds][18 groups] addends of the rows' end pixels
     float* rowrec;               // records of the pixels with Y % 8 in {0, 7}: [2 tilesY][W][54]
     float* colrec;               // records of the other pixels with X % 32 in {0, 31}: [H][2 tilesX][54]
     // PSIN = true: the input arrives PACKED-SPLIT (SplitConvParams::ps of the producing layer): xps[hi | lo][8 groups][xpsPlane
@@ -43,6 +45,13 @@ struct TailParams {
     const u32x4* xps; int xpsPlane;
     const u32x4* zero;
 };
+
+// Row of the z product that holds tap t = 3 dy + dx of output channel c: [dx][dy][c], so that the three horizontal taps of one (dy, c)
+// are 18 rows apart (the S form below adds them with constant offsets).  tail_prepare_kernel lays the weights out accordingly.
+__host__ __device__ __forceinline__ constexpr int tail_zrow(int t, int c) { return (t % 3) * 18 + (t / 3) * 6 + c; }
+constexpr int TS_GROUPS = 18;                                                // (dy, c) pairs: the planes of the S form
+constexpr int TS_STRIDE = ST_W + 2;                                          // slab row: pixels -1 .. 32 of the wave's row (the two pad columns are zero)
+constexpr int TS_REC = 6 * TS_GROUPS;                                        // floats of one (image row, tile) edge record: kinds A .. F x 18 groups
 
 __device__ __forceinline__ bool tail_in_image(int x, int y, int W, int H) { return (unsigned)x < (unsigned)W && (unsigned)y < (unsigned)H; }
 
@@ -71,9 +80,15 @@ __device__ __forceinline__ float* tail_record(const TailParams& tp, int x, int y
 // next k-step's operands in flight under the MFMAs) with the z stage between its last k-step and its epilogue.
 constexpr int ZW_OFF = S_WUNITS - TZ_UNITS;                                  // the z weights sit at the END of the weight buffer: the fused
                                                                              // form's z tile (54 x 8 x 32 fp32 = 55 296 B) grows from the patch into its start
-template <bool FUSED, bool PSIN>
+// FORM 0: the 54 tap-partial planes go to memory.  FORM 1 (= the old FUSED): a tile's partials are combined in LDS.  FORM 2, the
+// default: each wave adds the three HORIZONTAL taps of every (dy, c) for its own row of 32 pixels through its LDS slab (whose two
+// pad columns are zero) and stores 18 S planes instead of 54 z planes; the two pixels at the row's ends, whose sums need a value
+// of the neighbouring tile, get their three addends from small per-(row, tile) records and are added -- in the SAME order
+// (z[dx=0] + z[dx=1]) + z[dx=2] -- by the finishing kernel: every pixel's arithmetic is independent of where tile borders fall.
+template <int FORM, bool PSIN>
 __global__ __launch_bounds__(S_THREADS, 2) void conv3x3_split_tail_kernel(const TailParams tp)
 {
+    constexpr bool FUSED = FORM == 1;
     const SplitConvParams& p = tp.c;
     extern __shared__ u32x4 patch[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -170,7 +185,8 @@ __global__ __launch_bounds__(S_THREADS, 2) void conv3x3_split_tail_kernel(const 
     const float zunscale = reinterpret_cast<const float*>(tp.wz)[1];
     float* bias_lds = reinterpret_cast<float*>(wbuf + S_WUNITS);
     if (tid < 64) bias_lds[tid] = p.bias ? p.bias[tid] : 0.0f;
-    const rsrc_t zrs = __builtin_amdgcn_make_buffer_rsrc(tp.z, 0, (int)((size_t)TZ_ROWS * tp.zPlane * 4), 0x00020000);
+    const rsrc_t zrs = __builtin_amdgcn_make_buffer_rsrc(tp.z, 0, (int)((size_t)(FORM == 2 ? TS_GROUPS : TZ_ROWS) * tp.zPlane * 4), 0x00020000);
+    const rsrc_t rrs = __builtin_amdgcn_make_buffer_rsrc(tp.srec, 0, FORM == 2 ? (int)((size_t)p.H * p.tilesX * TS_REC * 4) : 0, 0x00020000);
     u32x4 zw[4];                                                             // this thread's 4 of the 1024 units of the z weights
 
     Tile cur = decode(jw);
@@ -263,18 +279,50 @@ __global__ __launch_bounds__(S_THREADS, 2) void conv3x3_split_tail_kernel(const 
                         const int m = mb * 32 + (i & 3) + 8 * (i >> 2) + 4 * h;
                         if (m < TZ_ROWS) zt[(m * ST_H + wave * 2 + r) * ST_W + j] = zacc[i] * zunscale;
                     }
+                } else if (FORM == 2) {                                      // ... into this wave's slab [row][pixel -1 .. 32]; rows >= 56 do not exist
+                    const float zs = (cur.ox0 + j < p.W) ? zunscale : 0.0f; // a pixel beyond the image's right edge contributes nothing to its neighbour
+#pragma unroll
+                    for (int i = 0; i < 16; ++i)
+                        if (mb == 0 || (i >> 2) < 3) tr[(mb * 32 + (i & 3) + 8 * (i >> 2) + 4 * h) * TS_STRIDE + j + 1] = zacc[i] * zs;
                 } else {                                                     // ... into this wave's transposition slab
 #pragma unroll
                     for (int i = 0; i < 16; ++i) tr[(mb * 32 + (i & 3) + 8 * (i >> 2) + 4 * h) * 32 + j] = zacc[i] * zunscale;
                 }
             }
             if (FUSED) continue;
+            if (FORM == 2) {
+                if (lane < TZ_ROWS) { tr[lane * TS_STRIDE] = 0.0f; tr[lane * TS_STRIDE + TS_STRIDE - 1] = 0.0f; }      // the pad columns
+                __builtin_amdgcn_s_waitcnt(0xC07F);                          // lgkmcnt(0): same-wave hand-off through LDS
+                // lane (j, h) adds groups g = 9 h + k, k = 0 .. 8: S[g][pixel j] = (z[dx 0][j - 1] + z[dx 1][j]) + z[dx 2][j + 1]
+                const float* sb = tr + (9 * h) * TS_STRIDE + j;
+                const bool live = oy < p.H && cur.ox0 + j < p.W;
+                const unsigned sv = live ? ((unsigned)(9 * h) * (unsigned)tp.zPlane + (unsigned)(oy * p.W + cur.ox0 + j)) * 4u : BAD_OFFSET;
+#pragma unroll
+                for (int k = 0; k < 9; ++k) {
+                    const float sum = (sb[k * TS_STRIDE] + sb[(TS_GROUPS + k) * TS_STRIDE + 1]) + sb[(2 * TS_GROUPS + k) * TS_STRIDE + 2];
+                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, sum), zrs, (int)sv, k * tp.zPlane * 4, 0);
+                }
+                // the addends of the two end pixels (and of the neighbours' end pixels), 6 x 18 floats per (row, tile):
+                //   A z[dx 0] @ 30, B z[dx 1] @ 31, C z[dx 0] @ 31, D z[dx 1] @ 0, E z[dx 2] @ 1, F z[dx 2] @ 0   (pixel of this row)
+#pragma unroll
+                for (int rr = 0; rr < 2; ++rr) {
+                    const int idx = lane + 64 * rr;
+                    const int kind = idx / TS_GROUPS, g = idx - kind * TS_GROUPS;
+                    const int zdx = kind == 0 || kind == 2 ? 0 : (kind == 1 || kind == 3 ? 1 : 2);
+                    const int col = kind == 0 ? 31 : (kind == 1 || kind == 2) ? 32 : (kind == 4 ? 2 : 1);        // slab column = pixel + 1
+                    const float val = idx < TS_REC ? tr[(zdx * TS_GROUPS + g) * TS_STRIDE + col] : 0.0f;
+                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, val), rrs,
+                                                          (int)((idx < TS_REC && oy < p.H) ? ((unsigned)(oy * p.tilesX + cur.ox0 / ST_W) * TS_REC + (unsigned)idx) * 4u : BAD_OFFSET), 0, 0);
+                }
+                __builtin_amdgcn_s_waitcnt(0xC07F);                          // reads done before the next row overwrites the slab
+                continue;
+            }
             __builtin_amdgcn_s_waitcnt(0xC07F);                              // lgkmcnt(0): same-wave hand-off through LDS
 #pragma unroll
             for (int k = 0; k < 8; ++k) {
                 const int qq = lane + 64 * k;                                // float4 index: z row = qq / 8, pixel group = qq % 8
                 const int m = qq >> 3, px = cur.ox0 + (qq & 7) * 4;
-                const bool ok = oy < p.H && px < p.W && m < TZ_ROWS;
+                const bool ok = oy < p.H && px < p.W && m < ((p.dbg & 64) ? 18 : TZ_ROWS);   // (dbg 64: timing experiment, a third of the planes)
                 const float4 val = reinterpret_cast<const float4*>(tr)[qq];
                 __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, val), zrs,
                                                        (int)(ok ? ((unsigned)m * (unsigned)tp.zPlane + (unsigned)(oy * p.W + px)) * 4u : BAD_OFFSET), 0, 0);
@@ -298,7 +346,7 @@ __global__ __launch_bounds__(S_THREADS, 2) void conv3x3_split_tail_kernel(const 
                         const int pc = col + t % 3 - 1, pr = row + t / 3 - 1;
                         if (tail_in_image(cur.ox0 + pc, cur.oy0 + pr, W, H)) {        // in the image = in this tile, for these pixels
 #pragma unroll
-                            for (int c = 0; c < 6; ++c) v[c] += zt[((t * 6 + c) * ST_H + pr) * ST_W + pc];
+                            for (int c = 0; c < 6; ++c) v[c] += zt[(tail_zrow(t, c) * ST_H + pr) * ST_W + pc];
                         }
                     }
                     isr_finish_pixel(tp.fin, X, Y, v);
@@ -315,7 +363,7 @@ __global__ __launch_bounds__(S_THREADS, 2) void conv3x3_split_tail_kernel(const 
                     const int pc = ec - 1 + t % 3 - 1, pr = er - 1 + t / 3 - 1;     // the tap's pixel, tile relative
                     if ((unsigned)pc < (unsigned)ST_W && (unsigned)pr < (unsigned)ST_H && tail_in_image(cur.ox0 + pc, cur.oy0 + pr, W, H)) {
 #pragma unroll
-                        for (int c = 0; c < 6; ++c) rec[t * 6 + c] = zt[((t * 6 + c) * ST_H + pr) * ST_W + pc];
+                        for (int c = 0; c < 6; ++c) rec[t * 6 + c] = zt[(tail_zrow(t, c) * ST_H + pr) * ST_W + pc];
                     }
                 }
             }
@@ -338,6 +386,7 @@ struct TailFinishParams {
     const float* z;
     int zPlane;
     const float* bias8;          // the last layer's bias (6 floats, device)
+    int taps;                    // 9 (timing experiments: fewer)
 };
 
 __global__ __launch_bounds__(256) void tail_combine_finish_kernel(const TailFinishParams p)
@@ -350,11 +399,77 @@ __global__ __launch_bounds__(256) void tail_combine_finish_kernel(const TailFini
     for (int c = 0; c < 6; ++c) v[c] = p.bias8[c];
 #pragma unroll
     for (int t = 0; t < 9; ++t) {
+        if (t >= p.taps) break;
         const int py = Y + t / 3 - 1, px = X + t % 3 - 1;
         if ((unsigned)py < (unsigned)H && (unsigned)px < (unsigned)W) {
-            const float* zp = p.z + (size_t)(t * 6) * p.zPlane + (size_t)py * W + px;
+            const float* zp = p.z + (size_t)tail_zrow(t, 0) * p.zPlane + (size_t)py * W + px;
 #pragma unroll
             for (int c = 0; c < 6; ++c) v[c] += zp[(size_t)c * p.zPlane];
+        }
+    }
+    isr_finish_pixel(p.fin, X, Y, v);
+}
+
+// S form, second launch: one thread per high-resolution pixel, a block = 256 consecutive pixels of row Y (eight tiles).
+//     out = ((bias + S[dy 0] @ Y - 1) + S[dy 1] @ Y) + S[dy 2] @ Y + 1        (rows outside the image skipped: the convolution's zero padding)
+// S comes from the planes, except for the first and last pixel of every tile's 32, whose S the block first rebuilds from the
+// records -- (z0 + z1) + z2 with z0 (first pixel) / z2 (last pixel) out of the neighbouring tile's record, zero at the image's
+// border -- into LDS (16 pixels x 18 groups), so that every thread runs the same code and the stores stay coalesced.
+struct TailSFinishParams {
+    FinishParams fin;
+    const float* s;              // [18][zPlane]
+    const float* rec;            // [H][tilesX][6][18]
+    int zPlane, tilesX;
+    const float* bias8;
+};
+
+__global__ __launch_bounds__(256) void tail_s_finish_kernel(const TailSFinishParams p)
+{
+    __shared__ float sedge[16][TS_GROUPS + 1];
+    const int H = 4 * p.fin.h, W = 4 * p.fin.w;
+    const int X0 = blockIdx.x * 256, Y = blockIdx.y, tid = threadIdx.x;
+    for (int t = tid; t < 16 * TS_GROUPS; t += 256) {
+        const int ep = t / TS_GROUPS, g = t - ep * TS_GROUPS;
+        const int tile = X0 / ST_W + (ep >> 1), side = ep & 1;
+        const int py = Y + g / 6 - 1, X = tile * ST_W + side * (ST_W - 1);
+        float val = 0.0f;
+        if (tile < p.tilesX && X < W && (unsigned)py < (unsigned)H) {
+            const float* own = p.rec + ((size_t)py * p.tilesX + tile) * TS_REC + g;
+            float z0, z1, z2;
+            if (side == 0) {
+                z0 = tile > 0 ? own[2 * TS_GROUPS - TS_REC] : 0.0f;                             // C of the tile to the left
+                z1 = own[3 * TS_GROUPS]; z2 = own[4 * TS_GROUPS];                               // D, E
+            } else {
+                z0 = own[0]; z1 = own[TS_GROUPS];                                               // A, B
+                z2 = (tile + 1 < p.tilesX && X + 1 < W) ? own[5 * TS_GROUPS + TS_REC] : 0.0f;   // F of the tile to the right
+            }
+            val = (z0 + z1) + z2;
+        }
+        sedge[ep][g] = val;
+    }
+    __syncthreads();
+    const int X = X0 + tid;
+    if (X >= W) return;
+    const int j = X & (ST_W - 1);
+    const bool edge = j == 0 || j == ST_W - 1;
+    const int ep = (tid >> 5) * 2 + (j == ST_W - 1 ? 1 : 0);
+    float v[6];
+#pragma unroll
+    for (int c = 0; c < 6; ++c) v[c] = p.bias8[c];
+#pragma unroll
+    for (int dy = 0; dy < 3; ++dy) {
+        const int py = Y + dy - 1;
+        if ((unsigned)py < (unsigned)H) {
+            const float* sp = p.s + (size_t)(dy * 6) * p.zPlane + (size_t)py * W + X;
+            float sv[6];
+#pragma unroll
+            for (int c = 0; c < 6; ++c) sv[c] = sp[(size_t)c * p.zPlane];
+            if (edge) {
+#pragma unroll
+                for (int c = 0; c < 6; ++c) sv[c] = sedge[ep][dy * 6 + c];
+            }
+#pragma unroll
+            for (int c = 0; c < 6; ++c) v[c] += sv[c];
         }
     }
     isr_finish_pixel(p.fin, X, Y, v);
@@ -394,7 +509,7 @@ __global__ __launch_bounds__(256) void tail_seam_finish_kernel(const TailParams 
 }
 
 // w8 [6][64][3][3] fp32 -> header + [q][part][h][m] units: element e of (q, h) is y6 channel 32 (q >> 1) + 16 (q & 1) + (e & 3) +
-// 8 (e >> 2) + 4 h, row m = 6 t + c holds w8[c][.][t] 2^S (rows >= 54 zero); part 0 = hi, 1 = lo
+// 8 (e >> 2) + 4 h, row m = tail_zrow(t, c) holds w8[c][.][t] 2^S (rows >= 54 zero); part 0 = hi, 1 = lo
 __global__ __launch_bounds__(256) void tail_prepare_kernel(const float* __restrict__ w8, u32x4* __restrict__ wz)
 {
     __shared__ float red[256];
@@ -422,7 +537,8 @@ __global__ __launch_bounds__(256) void tail_prepare_kernel(const float* __restri
     }
     for (int u = threadIdx.x; u < 4 * 2 * 64; u += 256) {                     // (q, h, m)
         const int mrow = u & 63, hh = (u >> 6) & 1, q = u >> 7;
-        const int t = mrow / 6, c = mrow - t * 6;
+        const int dxr = mrow / 18, gr = mrow - dxr * 18;                      // row [dx][dy][c] (tail_zrow)
+        const int t = 3 * (gr / 6) + dxr, c = gr % 6;
         f16x8 qh, ql;
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
@@ -447,10 +563,10 @@ long long isrConvTailWeightBytes(void) { return 16 + (long long)TZ_UNITS * 16; }
 // tail_seam_finish_kernel -- bit-identical output, 0.9 GB less traffic per 1080p frame, and SLOWER: the convolution kernel
 // runs two 256-register waves per SIMD at the board's power limit, and 54 LDS reads + the finishing code's scattered loads,
 // divisions and nine stores per pixel inside it cost 0.25 ms where the streaming kernel needs 0.10 (0.75 vs 0.51 + 0.10 ms)
-static int g_tail_fused = 0;
+static int g_tail_fused = getenv("ISR_TAIL_FORM") ? atoi(getenv("ISR_TAIL_FORM")) : 2;     // (ISR_TAIL_FORM: A/B runs) 2: the S form (default); 0: 54 planes; 1: combined in LDS; 3: timing experiment (a third of form 0's planes, wrong output)
 __device__ u32x4 g_tail_zero_unit[4];       // zero initialised: the source of out-of-image units of the LDS-DMA staging
 void isrDebugSetTailFused(int on) { g_tail_fused = on; }      // not part of the public header
-int isrDebugTailState(void) { return g_tail_fused ? 1 : 0; }
+int isrDebugTailState(void) { return g_tail_fused != 2 ? 1 : 0; }
 
 static long long tail_row_floats(int H, int W) { return 2LL * ((H + ST_H - 1) / ST_H) * W * TZ_ROWS; }
 static long long tail_col_floats(int H, int W) { return (long long)H * 2 * ((W + ST_W - 1) / ST_W) * TZ_ROWS; }
@@ -461,6 +577,7 @@ long long isrConvTailWorkspaceBytes(int h, int w)
     const long long H = 4LL * h, W = 4LL * w;
     const long long planes = (long long)TZ_ROWS * (H * W + W) * 4;           // two-kernel form: one extra row between planes (see ops.empty_planes)
     const long long records = (tail_row_floats((int)H, (int)W) + tail_col_floats((int)H, (int)W)) * 4;
+    // (the S form needs 18 planes + [H][tilesX][108] floats of end-pixel records: less than the 54 planes)
     return planes > records ? planes : records;
 }
 
@@ -521,7 +638,7 @@ static int tail_launch(const void* xin, int packed, const void* wq6, const float
     p.ksteps = 4; p.coutPad = 64; p.cgroups = 1;
     p.tilesX = (W + ST_W - 1) / ST_W; p.tilesY = (H + ST_H - 1) / ST_H;
     p.act = ISR_ACT_RELU; p.slope = 0.0f;
-    p.stamps = nullptr; p.dbg = 0; p.quads = 1;
+    p.stamps = nullptr; p.dbg = g_tail_fused == 3 ? 64 : 0; p.quads = 1;
     tp.wz = (const u32x4*)wz;
     tp.z = (float*)workspace;
     tp.zPlane = H * W + W;
@@ -540,9 +657,11 @@ static int tail_launch(const void* xin, int packed, const void* wq6, const float
         (void)hipGetDevice(&dev);
         if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
         slots = 2 * cus;
-        (void)hipFuncSetAttribute((const void*)conv3x3_split_tail_kernel<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, T_LDS_BYTES);
-        (void)hipFuncSetAttribute((const void*)conv3x3_split_tail_kernel<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, T_LDS_BYTES);
-        (void)hipFuncSetAttribute((const void*)conv3x3_split_tail_kernel<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, T_LDS_BYTES);
+        (void)hipFuncSetAttribute((const void*)conv3x3_split_tail_kernel<0, false>, hipFuncAttributeMaxDynamicSharedMemorySize, T_LDS_BYTES);
+        (void)hipFuncSetAttribute((const void*)conv3x3_split_tail_kernel<1, false>, hipFuncAttributeMaxDynamicSharedMemorySize, T_LDS_BYTES);
+        (void)hipFuncSetAttribute((const void*)conv3x3_split_tail_kernel<0, true>, hipFuncAttributeMaxDynamicSharedMemorySize, T_LDS_BYTES);
+        (void)hipFuncSetAttribute((const void*)conv3x3_split_tail_kernel<2, false>, hipFuncAttributeMaxDynamicSharedMemorySize, T_LDS_BYTES);
+        (void)hipFuncSetAttribute((const void*)conv3x3_split_tail_kernel<2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, T_LDS_BYTES);
     }
     const long long ntiles = (long long)p.tilesX * p.tilesY;
     const long long want = ntiles < slots ? ((ntiles + 7) / 8) * 8 : slots;
@@ -552,27 +671,34 @@ static int tail_launch(const void* xin, int packed, const void* wq6, const float
     tp.bias8 = bias8;
     tp.rowrec = (float*)workspace;
     tp.colrec = tp.rowrec + tail_row_floats(H, W);
-    const bool fused = g_tail_fused != 0 && !packed;
+    const bool fused = g_tail_fused == 1 && !packed;
     // algorithmic flops: postblock.6 and the final 64 -> 6 layer, whose arithmetic this launch carries
     isr_profile_record(ISR_VARIANT_SPLIT_TAIL, 2.0 * 9 * 64 * (64 + 6) * (double)H * W, &e0, &e1);
+    tp.srec = tp.z + (size_t)TS_GROUPS * tp.zPlane;
+    const dim3 tgrid((unsigned)want), tblock(S_THREADS);
+#define TAIL_LAUNCH(FORM, PS)                                                                                                          \
+    do {                                                                                                                               \
+        if (e0 || e1) hipExtLaunchKernelGGL((conv3x3_split_tail_kernel<FORM, PS>), tgrid, tblock, T_LDS_BYTES, s, e0, e1, 0, tp);      \
+        else hipLaunchKernelGGL((conv3x3_split_tail_kernel<FORM, PS>), tgrid, tblock, T_LDS_BYTES, s, tp);                             \
+    } while (0)
     if (fused) {
-        if (e0 || e1) hipExtLaunchKernelGGL((conv3x3_split_tail_kernel<true, false>), dim3((unsigned)want), dim3(S_THREADS), T_LDS_BYTES, s, e0, e1, 0, tp);
-        else hipLaunchKernelGGL((conv3x3_split_tail_kernel<true, false>), dim3((unsigned)want), dim3(S_THREADS), T_LDS_BYTES, s, tp);
+        TAIL_LAUNCH(1, false);
         const long long threads = 2LL * p.tilesY * W + (long long)H * 2 * p.tilesX;
         hipLaunchKernelGGL(tail_seam_finish_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, s, tp);
+    } else if (g_tail_fused == 2) {
+        if (packed) TAIL_LAUNCH(2, true); else TAIL_LAUNCH(2, false);
+        TailSFinishParams fp;
+        fp.fin = tp.fin;
+        fp.s = tp.z; fp.rec = tp.srec; fp.zPlane = tp.zPlane; fp.tilesX = p.tilesX; fp.bias8 = bias8;
+        hipLaunchKernelGGL(tail_s_finish_kernel, dim3((unsigned)((W + 255) / 256), (unsigned)H), dim3(256), 0, s, fp);
     } else {
-        if (packed) {
-            if (e0 || e1) hipExtLaunchKernelGGL((conv3x3_split_tail_kernel<false, true>), dim3((unsigned)want), dim3(S_THREADS), T_LDS_BYTES, s, e0, e1, 0, tp);
-            else hipLaunchKernelGGL((conv3x3_split_tail_kernel<false, true>), dim3((unsigned)want), dim3(S_THREADS), T_LDS_BYTES, s, tp);
-        } else {
-            if (e0 || e1) hipExtLaunchKernelGGL((conv3x3_split_tail_kernel<false, false>), dim3((unsigned)want), dim3(S_THREADS), T_LDS_BYTES, s, e0, e1, 0, tp);
-            else hipLaunchKernelGGL((conv3x3_split_tail_kernel<false, false>), dim3((unsigned)want), dim3(S_THREADS), T_LDS_BYTES, s, tp);
-        }
+        if (packed) TAIL_LAUNCH(0, true); else TAIL_LAUNCH(0, false);
         TailFinishParams fp;
         fp.fin = tp.fin;
-        fp.z = tp.z; fp.zPlane = tp.zPlane; fp.bias8 = bias8;
+        fp.z = tp.z; fp.zPlane = tp.zPlane; fp.bias8 = bias8; fp.taps = g_tail_fused == 3 ? 3 : 9;
         hipLaunchKernelGGL(tail_combine_finish_kernel, dim3((W + 255) / 256, H), dim3(256), 0, s, fp);
     }
+#undef TAIL_LAUNCH
     return hipGetLastError() == hipSuccess ? 0 : -2;
 }
 

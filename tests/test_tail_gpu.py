@@ -58,9 +58,10 @@ def test_tail_matches_the_three_kernel_path_and_fp64(h, w):
 
 @pytest.mark.parametrize("h,w", [(2, 8), (6, 8), (23, 37), (30, 52), (67, 120), (270, 480)])
 def test_fused_form_equals_the_two_kernel_form_bit_for_bit(h, w):
-    """The default form finishes every pixel whose nine partials lie in its own tile inside the convolution kernel and
-    assembles the others (the tiles' rims) from per-pixel records; the two-kernel form writes all 54 partial planes and adds
-    them in a streaming kernel.  Same partials, same order of additions: equal outputs, at ragged and full sizes."""
+    """Form 1 finishes every pixel whose nine partials lie in its own tile inside the convolution kernel and
+    assembles the others (the tiles' rims) from per-pixel records; form 0 writes all 54 partial planes and adds
+    them in a streaming kernel.  Same partials, same order of additions: equal outputs, at ragged and full sizes.
+    (Neither is the default any more: see test_s_form_*.)"""
     import ctypes
     from isosurfacesuperresolution_amd import ops
     lib = ops._sr()
@@ -77,7 +78,7 @@ def test_fused_form_equals_the_two_kernel_form_bit_for_bit(h, w):
                 assert torch.equal(out[fused][0], raw) and torch.equal(out[fused][1], rgb)      # and deterministic
             out[fused] = (raw, rgb)
     finally:
-        lib.isrDebugSetTailFused(0)
+        lib.isrDebugSetTailFused(2)                                   # the default form
     assert torch.equal(out[1][0], out[0][0]), (out[1][0] - out[0][0]).abs().max().item()
     # (the shading arithmetic is inlined into different kernels, where the compiler may contract different multiply-adds)
     assert (out[1][1] - out[0][1]).abs().max().item() <= 1e-6
@@ -187,3 +188,52 @@ def test_pipeline_uses_the_fused_tail_and_matches_the_unfused_frame():
     for (rgb_a, raw_a), (rgb_b, raw_b) in zip(frames[True], frames[False]):
         assert (raw_a - raw_b).abs().max().item() <= 1e-4 and (rgb_a - rgb_b).abs().max().item() <= 1e-4
     assert (frames[True][0][1] - frames[False][0][1]).abs().max().item() <= 5e-5      # first frame: no recurrence yet (normalised normals amplify)
+
+
+@pytest.mark.parametrize("h,w", [(2, 8), (6, 8), (23, 37), (30, 52), (67, 120), (270, 480)])
+def test_s_form_matches_the_54_plane_form_and_fp64(h, w):
+    """The default form (2): every wave adds the three horizontal taps of each (dy, c) for its row of 32 pixels and stores 18 S planes
+    (+ small records for the rows' end pixels) instead of 54 partial planes.  The additions associate differently from the 54-plane
+    form's tap-by-tap sum -- ((z0 + z1) + z2 per row, then the three rows) -- so the two agree to rounding, not bit for bit; both
+    are measured against fp64.  Ragged sizes (W % 32 != 0: 32, 148, 208; H % 8 != 0) included."""
+    import ctypes
+    from isosurfacesuperresolution_amd import ops
+    lib = ops._sr()
+    lib.isrDebugSetTailFused.argtypes = [ctypes.c_int]
+    f4, w6, b6, w8, b8, x, sh = _setup(h, w, seed=h * 17 + w)
+    out = {}
+    try:
+        for form in (2, 0, 2):
+            lib.isrDebugSetTailFused(form)
+            with torch.no_grad():
+                raw, rgb = ops.tail_conv_finish(f4, w6, b6, w8, b8, x, sh)
+            torch.cuda.synchronize()
+            if form in out:
+                assert torch.equal(out[form][0], raw) and torch.equal(out[form][1], rgb)      # deterministic
+            out[form] = (raw, rgb)
+    finally:
+        lib.isrDebugSetTailFused(2)
+    ref, pre = _reference64(f4, w6, b6, w8, b8, x)
+    scale = max(1.0, pre.abs().max().item())
+    err2 = (out[2][0].double().cpu() - ref).abs().max().item()
+    err0 = (out[0][0].double().cpu() - ref).abs().max().item()
+    assert err2 <= 2e-5 * scale and err2 <= 2 * err0 + 2e-6, (err2, err0)
+    assert (out[2][0] - out[0][0]).abs().max().item() <= 1e-5 * scale
+    assert (out[2][1] - out[0][1]).abs().max().item() <= 1e-5
+    assert torch.isfinite(out[2][0]).all() and torch.isfinite(out[2][1]).all()
+
+
+def test_s_form_does_not_depend_on_where_tile_borders_fall():
+    """The same pixels as part of images cropped at every horizontal offset 0 .. 33 (every position of a pixel relative to the 32-pixel
+    tiles: interior, first, last, next to an end) and two vertical offsets: bit for bit equal two pixels inside the crops."""
+    from isosurfacesuperresolution_amd import ops
+    h, w = 24, 40
+    f4, w6, b6, w8, b8, x, sh = _setup(h, w, seed=21)
+    with torch.no_grad():
+        full, _ = ops.tail_conv_finish(f4, w6, b6, w8, b8, x, None)
+        for oy in (0, 4):
+            for ox in range(0, 36, 4):
+                f4c = f4[:, :, oy:, ox:].contiguous()
+                xc = x[:, :, oy // 4:, ox // 4:].contiguous()
+                part, _ = ops.tail_conv_finish(f4c, w6, b6, w8, b8, xc, None)
+                assert torch.equal(full[:, 5, oy + 2:-2, ox + 2:-2], part[:, 5, 2:-2, 2:-2]), (oy, ox)

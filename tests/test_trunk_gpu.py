@@ -162,22 +162,26 @@ def test_a_timeout_induced_on_the_device_raises_at_the_start_of_the_next_frame()
     pipe.set_static(fov=30.0, isovalue=0.34)
     try:
         for k in range(3):
-            rgb_ok, raw_ok = pipe.frame(V.orbit_camera(k))          # clean frames (the first one takes the synchronous check)
+            pipe.frame(V.orbit_camera(k))                            # clean frames (the first one takes the synchronous check)
         torch.cuda.synchronize()
-        good = raw_ok.clone()
         lib.isrDebugSetTrunkFault(5, 200000)                         # tile 5 never publishes; deadline 2 ms after the kernel's start
         assert ops.debug_switches() != 0                             # bench.py would refuse to report in this state
-        _, raw_bad = pipe.frame(V.orbit_camera(2))                   # returns: nothing inside a frame waits for the host
+        _, raw_bad = pipe.frame(V.orbit_camera(7))                   # returns: nothing inside a frame waits for the host
+        raw_bad = raw_bad.clone()
         lib.isrDebugSetTrunkFault(-1, 0)
         torch.cuda.synchronize()
         assert int(ops._range_state(raw_bad.device)["buf"][ops._TRUNK_ERROR_SLOT].item()) >= 2     # set by the KERNEL: 1 + layer
-        assert not torch.equal(raw_bad, good)                        # the launch's output was incomplete
         with pytest.raises(RuntimeError, match="timed out waiting for its neighbours"):
-            pipe.frame(V.orbit_camera(2))                            # the next frame, not frame 256
+            pipe.frame(V.orbit_camera(7))                            # the next frame, not frame 256
         assert ops.TRUNK_DATAFLOW is False
-        _, raw_again = pipe.frame(V.orbit_camera(2))                 # per-layer kernels: bit-identical to the dataflow form
+        _, raw_again = pipe.frame(V.orbit_camera(7))                 # per-layer kernels: bit-identical to the dataflow form
         torch.cuda.synchronize()
-        assert torch.equal(raw_again, good)
+        raw_again = raw_again.clone()
+        assert not torch.equal(raw_bad, raw_again)                   # the faulty launch's output was incomplete (whatever its buffer held before)
+        ops.TRUNK_DATAFLOW = True
+        _, raw_flow = pipe.frame(V.orbit_camera(7))                  # the dataflow form again, undisturbed
+        torch.cuda.synchronize()
+        assert torch.equal(raw_again, raw_flow)
         pipe.frame(V.orbit_camera(3))                                # and nothing is left pending
     finally:
         lib.isrDebugSetTrunkFault(-1, 0)
