@@ -71,6 +71,9 @@ def parse(argv=None):
     ap.add_argument("--no-overlap", action="store_true", help="render frame t and super-resolve it back to back on one stream")
     ap.add_argument("--cpu-frames", type=int, default=6, help="frames in the CPU baseline sample (about 2 s each on 16 cores)")
     ap.add_argument("--side-waves", type=int, default=0, help="wave cap of the overlapped ray-march (0 = 4 per CU)")
+    ap.add_argument("--graph", action="store_true", help="steady-state frames replay as one HIP graph each (pipeline.py); the per-kernel "
+                    "durations of `roofline` / `kernels` then come from an eager pass of the same frames AFTER the timed region "
+                    "(a replayed graph has no per-dispatch events)")
     return ap.parse_args(argv)
 
 
@@ -261,7 +264,7 @@ def run_infer(args, job):
         net = models.createNetwork('EnhanceNet', 4, 101, [0, 1, 2, 3, 4], 6, opt)
     model = LoadedModel.from_model(net, "cuda", parameters={"initialImage": "zero"})
     pipe = SuperResolutionPipeline(renderer, model, default_shading("cuda", 30.0), (low_w, low_h),
-                                   temporal=not args.no_temporal)
+                                   temporal=not args.no_temporal, graph=args.graph)
     pipe.set_static(fov=30.0, isovalue=iso)
     pipe.foreground_variant = args.raymarch_variant
     renderer.set_kernel_variant(args.raymarch_variant)
@@ -284,9 +287,10 @@ def run_infer(args, job):
     # Per-kernel durations come from start/stop events carried on the dispatch packets themselves
     # (hipExtLaunchKernelGGL inside the libraries, on the stream the kernels run on): unlike
     # hipEventRecord they add no barrier packets / cache flushes to the timed stream.
-    prof_timed = os.environ.get("BENCH_PROFILE_TIMED", "1") != "0"
+    prof_timed = os.environ.get("BENCH_PROFILE_TIMED", "1") != "0" and not pipe.graph
     ops.profile_enable(prof_timed)
     renderer.profile_enable(prof_timed)
+    replays0 = pipe.graph_replays
     sync()
     t0 = time.perf_counter()
     for k in range(K):
@@ -294,6 +298,17 @@ def run_infer(args, job):
         pipe.frame(origins[Wm + k], origins[Wm + k + 1] if overlap and k + 1 < K else None)
     sync()
     elapsed = time.perf_counter() - t0
+    graph_replays = pipe.graph_replays - replays0
+    if pipe.graph:
+        # the per-kernel pass: the same K frames launched eagerly with the dispatch-packet events on (outside the timed region)
+        pipe.graph = False
+        pipe.reset()
+        ops.profile_enable(True)
+        renderer.profile_enable(True)
+        for k in range(K):
+            pipe.frame(origins[Wm + k], origins[Wm + k + 1] if overlap and k + 1 < K else None)
+        sync()
+        pipe.graph = True
     records = ops.profile_records()
     ops.trunk_check()                     # no dataflow launch of the timed region gave up on a neighbour (the error word is sticky)
     switches = ops.debug_switches()
@@ -373,6 +388,8 @@ def run_infer(args, job):
                             "split-operand: 3 x v_mfma_f32_32x32x16_f16 per product, fp32 accumulation (bench.py --exact = fp32 MFMA kernels); "
                             "1080p tail fused (postblock.6 + postblock.8 + finish), packed-split hand-over postblock.4 -> tail and inside the blocks"},
         **rank_keys,
+        "frame_graph": ({"replays_in_timed_region": graph_replays, "per_kernel_durations": "eager pass of the same frames after the timed region"}
+                        if pipe.graph else None),
         "debug_switches": switches,
         "roofline": {"kernel": dom_name, "bound": "mfma", "achieved": achieved, "peak": peak,
                      "unit": "TFLOP/s", "frac": achieved / peak, "traffic": traffic,

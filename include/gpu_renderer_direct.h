@@ -70,7 +70,9 @@ int isoLoadDenseDevice(unsigned long long devicePtr, int nx, int ny, int nz);
  * produces are bit for bit those of the unsplit render wherever its leaves hold the first crossing, and
  * the nearest-hit composite of all tiles equals the unsplit image.  An all-zero tile is valid.  Ray-cast
  * AO inside render() sees only the tile's own leaves: render with aosamples=0 and use the exact tiled-AO passes
- * (isoSetHitStateBuffer / isoAoDistancesAsync / isoAoFinishAsync below); semantics=gvdb is not available for tiles.
+ * (isoSetHitStateBuffer / isoAoDistancesAsync / isoAoFinishAsync below).  semantics=gvdb works on tiles the same way (round 4: the
+ * brick DDA covers the global box, a tile marches the bricks it owns; nearest hit = smallest NDC depth) with aosamples=0 -- the exact
+ * tiled-AO passes exist for the default semantics only.
  * 0 ok, -2 on failure (misaligned origin / clipLo, region outside the stored data, no memory). */
 int isoLoadDenseTileHost(const float* hostData, int nx, int ny, int nz, const int origin[3],
                          const int globalActiveMin[3], const int globalActiveMax[3], float globalMax,
@@ -79,6 +81,20 @@ int isoLoadDenseTileHost(const float* hostData, int nx, int ny, int nz, const in
 /* Launch the frame on `stream` (a hipStream_t, may be NULL) without synchronising; the "last
  * camera" bookkeeping is identical to render().  Returns 0 or -1. */
 int isoRenderAsync(unsigned long long devicePtr, void* stream);
+
+/* The frame as a REPLAYABLE launch (additive; pipeline.py's frame graph).  What changes when only the camera moves -- the camera, the
+ * previous camera (flow reference) and the light -- lives in a device block of isoFrameBlockBytes() bytes (8-byte aligned):
+ *   isoWriteFrameBlockAsync(block, stream): fills it from the CURRENT parameters (setParameter) by a one-wave kernel on `stream`
+ *     (ordered like any launch; no host staging buffer) and makes the current camera the "last camera", exactly as render() does;
+ *   isoRenderFromBlockAsync(devicePtr, block, stream): the default-semantics render without ambient occlusion (the SR-mode call of
+ *     mainGUI.py:690-701: aosamples = 0) whose kernel READS that block; everything else (volume, resolution, viewport, isovalue,
+ *     material) is taken from the current parameters at the time of the call.  The launch is identical from frame to frame, so a
+ *     stream capture that contains it can be replayed with a refreshed block.  Does not touch the "last camera".
+ * Pixels are bit for bit those of isoRenderAsync with the same parameters.  0 ok, -1 not available (no volume, semantics=gvdb,
+ * aosamples > 0, misaligned block). */
+int isoFrameBlockBytes(void);
+int isoWriteFrameBlockAsync(unsigned long long deviceBlock, void* stream);
+int isoRenderFromBlockAsync(unsigned long long devicePtr, unsigned long long deviceBlock, void* stream);
 
 /* info: [0..2] volume dims, [3] stored bricks, [4] leaf bricks, [5..7] node bbox min,
  * [8..10] node bbox max, [11] bytes of brick storage (MiB), out_max = grid max value. */

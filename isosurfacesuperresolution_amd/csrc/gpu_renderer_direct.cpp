@@ -730,7 +730,8 @@ bool launchFrame(float* out, hipStream_t stream)
         else e0 = e1 = nullptr;
     }
     if (g.semantics == 1) {
-        if (v.tile) return false;    // the CUDA renderer's arithmetic is implemented for whole volumes only
+        // (tiles too, round 4: the brick DDA runs over the GLOBAL box, a tile marches the bricks it owns; ray-cast AO inside this
+        // launch would see the tile's own bricks only, as in the default semantics: render tiles with aosamples = 0)
         IsoGvdbFrame f;
         buildGvdbFrame(f, a, v, g.lastOrigin, g.lastLookAt);
         iso_launch_render_gvdb(p, f, stream, e0, e1);
@@ -927,6 +928,36 @@ float render(unsigned long long devicePtr)
 int isoRenderAsync(unsigned long long devicePtr, void* stream)
 {
     return launchFrame(reinterpret_cast<float*>(devicePtr), static_cast<hipStream_t>(stream)) ? 0 : -1;
+}
+
+int isoFrameBlockBytes(void) { return (int)sizeof(IsoFrameBlock); }
+
+int isoWriteFrameBlockAsync(unsigned long long deviceBlock, void* stream)
+{
+    if (!deviceBlock || (deviceBlock & 7)) return -1;
+    IsoRenderParams p;
+    float dummy = 0.0f;       // buildParams wants an output pointer; nothing is launched with it
+    if (g.semantics == 1 || !buildParams(p, &dummy, static_cast<hipStream_t>(stream))) return -1;
+    IsoFrameBlock b;
+    b.cam = p.cam;
+    std::memcpy(b.Vlast, p.Vlast, sizeof(b.Vlast));
+    for (int k = 0; k < 3; ++k) b.light[k] = p.light[k];
+    iso_launch_write_block(b, reinterpret_cast<IsoFrameBlock*>(deviceBlock), stream);
+    if (hipGetLastError() != hipSuccess) return -1;
+    // as after a render: the camera just described becomes the flow reference of the next frame (GPURendererDirect.cpp:440-442)
+    for (int k = 0; k < 3; ++k) { g.lastOrigin[k] = g.args.cameraOrigin[k]; g.lastLookAt[k] = g.args.cameraLookAt[k]; }
+    return 0;
+}
+
+int isoRenderFromBlockAsync(unsigned long long devicePtr, unsigned long long deviceBlock, void* stream)
+{
+    if (!deviceBlock || (deviceBlock & 7)) return -1;
+    IsoRenderParams p;
+    if (g.semantics == 1 || g.args.aoSamples > 0 || g.statsOut) return -1;     // the plain SR-mode render only
+    if (!buildParams(p, reinterpret_cast<float*>(devicePtr), static_cast<hipStream_t>(stream))) return -1;
+    p.tileCost = nullptr; p.tileOrder = nullptr;
+    iso_launch_render_from_block(p, reinterpret_cast<const IsoFrameBlock*>(deviceBlock), stream);
+    return hipGetLastError() == hipSuccess ? 0 : -1;
 }
 
 int isoLoadDenseDevice(unsigned long long devicePtr, int nx, int ny, int nz)

@@ -41,8 +41,10 @@ __device__ __forceinline__ f3 safe_normalize(f3 a)          // render_kernel.cu:
     return mk(a.x / l, a.y / l, a.z / l);
 }
 
+// (x, y, z): GLOBAL index coordinates; a tile of a larger volume stores the region that starts at P.org (zero for a whole volume)
 __device__ __forceinline__ float voxel(const IsoRenderParams& P, int x, int y, int z)
 {
+    x -= P.org[0]; y -= P.org[1]; z -= P.org[2];
     if ((unsigned)x >= (unsigned)P.nx || (unsigned)y >= (unsigned)P.ny || (unsigned)z >= (unsigned)P.nz) return 0.0f;
     const int s = P.slot[((z >> 3) * P.nby + (y >> 3)) * P.nbx + (x >> 3)];
     if (s < 0) return 0.0f;
@@ -58,10 +60,11 @@ __device__ __forceinline__ float tex(const IsoRenderParams& P, f3 q)
     const int ix = (int)cx, iy = (int)cy, iz = (int)cz;
     const float a = fx - cx, b = fy - cy, c = fz - cz;
     float v000, v100, v010, v110, v001, v101, v011, v111;
-    if ((unsigned)ix < (unsigned)P.nx && (unsigned)iy < (unsigned)P.ny && (unsigned)iz < (unsigned)P.nz) {
-        const int s = P.slot[((iz >> 3) * P.nby + (iy >> 3)) * P.nbx + (ix >> 3)];
+    const int lx = ix - P.org[0], ly = iy - P.org[1], lz = iz - P.org[2];       // stored (tile-local) index; org is a multiple of 8
+    if ((unsigned)lx < (unsigned)P.nx && (unsigned)ly < (unsigned)P.ny && (unsigned)lz < (unsigned)P.nz) {
+        const int s = P.slot[((lz >> 3) * P.nby + (ly >> 3)) * P.nbx + (lx >> 3)];
         if (s < 0) return 0.0f;                              // all 8 corners are zero: 0 + a * 0 ... == +0
-        const float* w = P.bricks + (size_t)s * ISO_BRICK_STRIDE + ((iz & 7) * 9 + (iy & 7)) * 9 + (ix & 7);
+        const float* w = P.bricks + (size_t)s * ISO_BRICK_STRIDE + ((lz & 7) * 9 + (ly & 7)) * 9 + (lx & 7);
         v000 = w[0]; v100 = w[1]; v010 = w[9]; v110 = w[10];
         v001 = w[81]; v101 = w[82]; v011 = w[90]; v111 = w[91];
     } else {
@@ -144,11 +147,16 @@ __device__ __forceinline__ bool ray_cast(const IsoRenderParams& P, float iso, f3
         const float my = (float)((tside.y < tside.z) & (tside.y <= tside.x));
         const float mz = (float)((tside.z < tside.x) & (tside.z <= tside.y));
         const float ty = mx != 0.f ? tside.x : (my != 0.f ? tside.y : tside.z);
-        const int bx = ox + (int)p.x, by = oy + (int)p.y, bz = oz + (int)p.z;
-        const size_t bi = ((size_t)bz * P.nby + by) * P.nbx + bx;
+        const int bx = ox + (int)p.x, by = oy + (int)p.y, bz = oz + (int)p.z;                  // global brick coordinates
+        // a tile of a larger volume (P.org != 0 or a smaller table) walks the same bricks of the GLOBAL box and marches the ones it
+        // owns (its `leaf` table says "exists AND owned"); what a march computes depends on the brick's entry time and voxels only,
+        // so the tile that owns the first brick with a hit produces the unsplit pixel
+        const int tbx = bx - (P.org[0] >> 3), tby = by - (P.org[1] >> 3), tbz = bz - (P.org[2] >> 3);
+        const bool stored = (unsigned)tbx < (unsigned)P.nbx && (unsigned)tby < (unsigned)P.nby && (unsigned)tbz < (unsigned)P.nbz;
+        const size_t bi = stored ? ((size_t)tbz * P.nby + tby) * P.nbx + tbx : 0;
         // max skipping, exact: a march through this brick reads voxels of [8b-1, 8b+9]^3 only; if their maximum (plus the
         // rounding allowance of the float lerps) is below the isovalue no sample can reach it and the march finds nothing
-        if (P.leaf[bi] && !(iso > P.leafRange[2 * bi + 1] + 4e-6f * fmaxf(fabsf(P.leafRange[2 * bi]), fabsf(P.leafRange[2 * bi + 1])))) {
+        if (stored && P.leaf[bi] && !(iso > P.leafRange[2 * bi + 1] + 4e-6f * fmaxf(fabsf(P.leafRange[2 * bi]), fabsf(P.leafRange[2 * bi + 1])))) {
             const f3 vmin = mk((float)(bx * 8), (float)(by * 8), (float)(bz * 8));
             if (march_brick<CUSTOM>(P, iso, vmin, tx + GV_EPS, pos, dir, hit, grad)) return true;
         }

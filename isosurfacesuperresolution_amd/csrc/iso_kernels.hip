@@ -872,6 +872,33 @@ __global__ __launch_bounds__(64) void iso_render_gather(const IsoRenderParams P)
     render_gather_tile<AO, FLAT>(P, blockIdx.x, tiles_x, ntiles, threadIdx.x);
 }
 
+// The same kernel with the per-frame part of the parameter block (camera, previous camera, light) read from DEVICE memory through
+// the constant address space: the loads are scalar (s_load), the values live where the kernel arguments would -- and the launch itself
+// no longer changes from frame to frame, so a captured HIP graph of the frame replays it (pipeline.py, frame graph).
+typedef const double __attribute__((address_space(4))) iso_cdouble_t;
+__global__ __launch_bounds__(64) void iso_render_gather_block(const IsoRenderParams P0, const IsoFrameBlock* fb)
+{
+    IsoRenderParams P = P0;
+    const iso_cdouble_t* src = (const iso_cdouble_t*)(const void*)fb;
+    constexpr int NC = sizeof(IsoCamera) / 8;
+    double* cam = reinterpret_cast<double*>(&P.cam);
+#pragma unroll
+    for (int i = 0; i < NC; ++i) cam[i] = src[i];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) (&P.Vlast[0][0])[i] = src[NC + i];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) P.light[i] = src[NC + 16 + i];
+    const int tiles_x = (P.W + 7) >> 3, ntiles = tiles_x * ((P.H + 7) >> 3);
+    render_gather_tile<false, 3>(P, blockIdx.x, tiles_x, ntiles, threadIdx.x);
+}
+
+__global__ __launch_bounds__(64) void iso_write_block_kernel(const IsoFrameBlock b, IsoFrameBlock* dst)
+{
+    const unsigned* s = reinterpret_cast<const unsigned*>(&b);
+    unsigned* d = reinterpret_cast<unsigned*>(dst);
+    for (int i = threadIdx.x; i < (int)(sizeof(IsoFrameBlock) / 4); i += 64) d[i] = s[i];
+}
+
 // ---- diagnostics: variant 0 with per-tile clocks and per-ray step counts (never on the product path) ------------------
 // out[tile] = { cycles of the wave (s_memtime), samples of its busiest ray, leaves marched / skipped by that ray,
 //               sum of samples over its rays, rays that hit }
@@ -1347,6 +1374,17 @@ void iso_launch_render(const IsoRenderParams& p, int variant, void* stream, void
         if (p.aoSamples > 0) hipExtLaunchKernelGGL((iso_render_gather<true, 3>), grid, block, 0, st, e0, e1, 0, p);
         else hipExtLaunchKernelGGL((iso_render_gather<false, 3>), grid, block, 0, st, e0, e1, 0, p);
     }
+}
+
+void iso_launch_render_from_block(const IsoRenderParams& p, const IsoFrameBlock* deviceBlock, void* stream)
+{
+    const int tiles = ((p.W + 7) >> 3) * ((p.H + 7) >> 3);
+    hipLaunchKernelGGL(iso_render_gather_block, dim3(tiles), dim3(64), 0, (hipStream_t)stream, p, deviceBlock);
+}
+
+void iso_launch_write_block(const IsoFrameBlock& block, IsoFrameBlock* deviceDst, void* stream)
+{
+    hipLaunchKernelGGL(iso_write_block_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, block, deviceDst);
 }
 
 void iso_launch_ao_distances(const IsoRenderParams& p, const double* hitState, const float* gbuf, double* dist, void* stream)

@@ -60,6 +60,14 @@ struct IsoRenderParams {
 };
 constexpr int ISO_ORDER_MAX_TILES = 4096;
 
+// What changes from frame to frame when only the camera moves: a launch that reads this block from DEVICE memory (isoRenderFromBlockAsync)
+// is the same launch every frame -- it can be captured in a HIP graph and replayed (isoWriteFrameBlockAsync refreshes the block).
+struct IsoFrameBlock {
+    IsoCamera cam;
+    double Vlast[4][4];
+    double light[3];
+};
+
 // Per-frame constants of the `semantics=gvdb` kernel (iso_gvdb.hip), prepared in double and narrowed to float
 struct IsoGvdbFrame {
     float rpos[3];               // camera position in grid-local (voxel) coordinates
@@ -78,6 +86,10 @@ struct IsoGvdbFrame {
 // launchers (iso_kernels.hip, iso_gvdb.hip)
 // waveCap: variant 2 only -- launch at most this many one-wave workgroups (0 = one per 8x8 tile)
 void iso_launch_render(const IsoRenderParams& p, int variant, void* stream, void* startEvent, void* stopEvent, int waveCap);
+// variant 0 without AO with the camera part of `p` taken from a device-resident block; no dispatch-packet events (graph capture)
+void iso_launch_render_from_block(const IsoRenderParams& p, const IsoFrameBlock* deviceBlock, void* stream);
+// *deviceDst = block, by a one-wave kernel that carries the block as its argument: ordered in `stream` like any launch, no staging buffer to race on
+void iso_launch_write_block(const IsoFrameBlock& block, IsoFrameBlock* deviceDst, void* stream);
 void iso_launch_render_gvdb(const IsoRenderParams& p, const IsoGvdbFrame& f, void* stream, void* startEvent, void* stopEvent);
 // order[0 .. n) = a permutation of the tiles from cost[0 .. n): mode 1 heaviest first; mode 2 heaviest first for the first
 // `slots` workgroups (one per SIMD), then the LIGHTEST first, so that a SIMD's second wave is light where its first is heavy

@@ -80,6 +80,9 @@ class DirectRenderer:
         lib.isoProfileGet.restype = ctypes.c_int
         lib.isoShutdown.argtypes = []
         lib.isoShutdown.restype = None
+        lib.isoFrameBlockBytes.argtypes = []; lib.isoFrameBlockBytes.restype = ctypes.c_int
+        lib.isoWriteFrameBlockAsync.argtypes = [ctypes.c_ulonglong, ctypes.c_void_p]; lib.isoWriteFrameBlockAsync.restype = ctypes.c_int
+        lib.isoRenderFromBlockAsync.argtypes = [ctypes.c_ulonglong, ctypes.c_ulonglong, ctypes.c_void_p]; lib.isoRenderFromBlockAsync.restype = ctypes.c_int
         lib.isoSetLastCamera.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
         lib.isoSetLastCamera.restype = ctypes.c_int
         if lib.initGVDB() != 0:
@@ -134,6 +137,23 @@ class DirectRenderer:
         rc = self.lib.isoRenderAsync(ctypes.c_ulonglong(tensor.data_ptr()), handle)
         if rc != 0:
             raise RuntimeError("isoRenderAsync failed")
+
+    def frame_block_bytes(self):
+        return int(self.lib.isoFrameBlockBytes())
+
+    def write_frame_block(self, block, stream=None):
+        """Additive: the per-frame camera block (a device uint8 tensor of ``frame_block_bytes()``) from the current parameters,
+        written by a launch on ``stream``; the current camera becomes the flow reference as after a render."""
+        handle = ctypes.c_void_p(stream.cuda_stream) if stream is not None else None
+        if self.lib.isoWriteFrameBlockAsync(ctypes.c_ulonglong(block.data_ptr()), handle) != 0:
+            raise RuntimeError("isoWriteFrameBlockAsync failed")
+
+    def render_from_block(self, tensor, block, stream=None):
+        """Additive: the SR-mode render (aosamples = 0) with the camera read from ``block`` -- the same launch every frame, so a
+        captured HIP graph can replay it."""
+        handle = ctypes.c_void_p(stream.cuda_stream) if stream is not None else None
+        if self.lib.isoRenderFromBlockAsync(ctypes.c_ulonglong(tensor.data_ptr()), ctypes.c_ulonglong(block.data_ptr()), handle) != 0:
+            raise RuntimeError("isoRenderFromBlockAsync failed")
 
     def volume_info(self):
         info = (ctypes.c_int * 12)()

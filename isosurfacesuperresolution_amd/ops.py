@@ -202,8 +202,18 @@ def debug_switches():
     return int(lib.isrDebugSplitState()) | (int(lib.isrDebugTailState()) << 8) | (int(lib.isrDebugBlockState()) << 12) | (int(lib.isrDebugTrunkState()) << 16)
 
 
+_profile_on = False
+
+
 def profile_enable(on):
+    global _profile_on
+    _profile_on = bool(on)
     _sr().isrProfileEnable(1 if on else 0)
+
+
+def profile_is_on():
+    """Per-dispatch profiling puts start / stop events on the kernels' dispatch packets: not something to capture into a graph."""
+    return _profile_on
 
 
 def profile_records():
@@ -1680,10 +1690,11 @@ def packed_supported(x, weight, upsample2x):
     return (not upsample2x) or bool(_sr().isrConvF16SupportsUpsample(x.data_ptr(), x.shape[3], xp, x.shape[1] * xp))
 
 
-def tail_conv_finish(features, weight6, bias6, weight8, bias8, net_input, shading=None):
+def tail_conv_finish(features, weight6, bias6, weight8, bias8, net_input, shading=None, out=None):
     """features [1,64,4h,4w] (the output of postblock.4; channel planes may be padded) -> relu(conv3x3(., weight6) + bias6)
     -> conv3x3(., weight8) + bias8 -> ``finish_frame``: (next_prev [1,6,4h,4w], rgb [1,3,4h,4w] or None) in two launches
-    (``isrConvTailFinishFrame``); the 64-channel tensor between the two convolutions never exists in memory."""
+    (``isrConvTailFinishFrame``); the 64-channel tensor between the two convolutions never exists in memory.
+    ``out``: (next_prev, rgb) tensors to write into (the frame graph's static output buffers)."""
     lib = _sr()
     packed = isinstance(features, PackedSplit)
     if packed:
@@ -1702,11 +1713,13 @@ def tail_conv_finish(features, weight6, bias6, weight8, bias8, net_input, shadin
     if ws is None:
         ws = torch.empty(lib.isrConvTailWorkspaceBytes(h, w), dtype=torch.uint8, device=dev)
         _tail_ws[key] = ws
-    nxt = torch.empty((1, 6, H, W), dtype=torch.float32, device=dev)
+    nxt = out[0] if out is not None else torch.empty((1, 6, H, W), dtype=torch.float32, device=dev)
+    assert tuple(nxt.shape) == (1, 6, H, W) and nxt.is_contiguous() and nxt.dtype == torch.float32
     rgb, params = None, None
     exponent, ao, inv, spec = 1, 0.0, 0, 0
     if shading is not None:
-        rgb = torch.empty((1, 3, H, W), dtype=torch.float32, device=dev)
+        rgb = out[1] if out is not None else torch.empty((1, 3, H, W), dtype=torch.float32, device=dev)
+        assert tuple(rgb.shape) == (1, 3, H, W) and rgb.is_contiguous()
         params = (ctypes.c_float * 18)(*shading.packed_parameters())
         exponent, ao = int(shading._specular_exponent), float(shading._ao)
         inv, spec = int(bool(shading.inverse_ao)), int(bool(shading.enable_specular))

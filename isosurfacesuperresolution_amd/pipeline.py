@@ -33,11 +33,13 @@ def default_shading(device, fov=30.0):
     return sh
 
 
-def run_network(model, shading, x, after_trunk=None, prefetch_point="trunk"):
+def run_network(model, shading, x, after_trunk=None, prefetch_point="trunk", out=None):
     """The network and the frame's finishing on the fused HIP path: input [1,101,h,w] -> (raw [1,6,4h,4w] clamped / normalised,
     rgb [1,3,4h,4w]).  ``model``: inference.LoadedModel; ``after_trunk``: callable run once at ``prefetch_point`` (the frame
     pipeline releases the next frame's ray-march there).  Used by ``SuperResolutionPipeline`` for whole frames and by
-    ``parallel_sr.StripSuperResolution`` for a rank's strip (``enhancenet.py:92-144`` + ``mainGUI.py:594-603``)."""
+    ``parallel_sr.StripSuperResolution`` for a rank's strip (``enhancenet.py:92-144`` + ``mainGUI.py:594-603``).
+    ``out``: (raw, rgb) buffers to write into -- honoured on the fused-tail route only (returns None if another route was taken
+    while ``out`` was given: the frame graph then stays off)."""
     net = model.model
     shading.inverse_ao = model.inverse_ao
     last = net.postblock[8]
@@ -66,7 +68,9 @@ def run_network(model, shading, x, after_trunk=None, prefetch_point="trunk"):
     if isinstance(f4, ops.PackedSplit) or (f4 is not None and ops.tail_supported(f4, six.weight, last.weight)):
         # postblock.6, postblock.8 and the frame's finishing in two launches; the 64-channel 1080p tensor between the
         # two convolutions never goes to memory (csrc/sr_conv_tail.hip)
-        raw, rgb = ops.tail_conv_finish(f4, six.weight, six.bias, last.weight, last.bias, x, shading)
+        raw, rgb = ops.tail_conv_finish(f4, six.weight, six.bias, last.weight, last.bias, x, shading, out=out)
+        model._isr_static_out = out is not None          # the fused tail wrote straight into the caller's buffers
+        out = None
     elif f4 is not None:
         f6 = ops.conv3x3(f4, six.weight, six.bias, act='relu')
         raw, rgb = ops.final_conv_finish(f6, last.weight, last.bias, x, shading)
@@ -79,6 +83,10 @@ def run_network(model, shading, x, after_trunk=None, prefetch_point="trunk"):
         after_trunk = None
     if after_trunk is not None:
         after_trunk()
+    if out is not None:          # a route that allocates its own outputs: the caller's static buffers were not written
+        model._isr_static_out = False
+        out[0].copy_(raw); out[1].copy_(rgb)
+        raw, rgb = out
     return raw, rgb
 
 
@@ -90,7 +98,10 @@ def fused_path_ok(model, upscale=4):
 
 
 class SuperResolutionPipeline:
-    def __init__(self, renderer, model, shading, low_res, upscale=4, temporal=True, device="cuda", fused=True):
+    def __init__(self, renderer, model, shading, low_res, upscale=4, temporal=True, device="cuda", fused=True, graph=None):
+        """``graph`` (default: ISR_FRAME_GRAPH=1): steady-state frames -- temporal sequence, next frame's camera known -- replay as
+        ONE HIP graph per frame (``_frame_graph``).  The returned tensors are then the pipeline's static output buffers: valid
+        until the frame after next overwrites them."""
         self.renderer = renderer
         self.model = model            # inference.LoadedModel
         self.shading = shading
@@ -141,10 +152,26 @@ class SuperResolutionPipeline:
         # fused=True: input assembly and frame finishing run as two HIP kernels (ops.assemble_input /
         # ops.finish_frame); fused=False: the module-level PyTorch path (LoadedModel.inference etc.)
         self.fused = fused and fused_path_ok(model, upscale)
+        # ---- the frame as one HIP graph ------------------------------------------------------------------------
+        self.graph = (os.environ.get("ISR_FRAME_GRAPH", "0") == "1") if graph is None else bool(graph)
+        self.graph = self.graph and self.fused and self._render_stream is not None
+        self._graphs = [None, None]       # per G-buffer slot: the frame whose G-buffer sits in slot s (and renders the next one into s ^ 1)
+        self._graph_sig = None
+        self._graph_pool = None
+        self._static_version = 0
+        self.graph_replays = 0
+        if self.graph:
+            H, W = upscale * self.low_h, upscale * self.low_w
+            self._out_raw = [torch.empty((1, 6, H, W), dtype=torch.float32, device=device) for _ in range(2)]
+            self._out_rgb = [torch.empty((1, 3, H, W), dtype=torch.float32, device=device) for _ in range(2)]
+            self._cam_blocks = [torch.zeros(renderer.frame_block_bytes(), dtype=torch.uint8, device=device) for _ in range(2)]
+            self._graph_stream = torch.cuda.Stream(device=device)
+            self._fork, self._join = torch.cuda.Event(), torch.cuda.Event()
         self.set_static(fov=shading.get_fov(), isovalue=0.5)
 
     def set_static(self, fov, isovalue, lookat=(0.0, 0.0, 0.0), up=(0.0, 1.0, 0.0)):
         r = self.renderer
+        self._static_version = getattr(self, "_static_version", 0) + 1          # captured frames hold these parameters: capture again
         self._lookat = tuple(float(v) for v in fmt3(lookat).split(","))
         r.send_command("cameraLookAt", fmt3(lookat))
         r.send_command("cameraUp", fmt3(up))
@@ -224,11 +251,87 @@ class SuperResolutionPipeline:
         self.previous = raw
         return raw
 
-    def _network(self, x, after_trunk=None):
+    def _network(self, x, after_trunk=None, out=None):
         """Network input [1,101,h,w] -> (raw [1,6,4h,4w] clamped / normalised, rgb [1,3,4h,4w])."""
-        return run_network(self.model, self.shading, x, after_trunk=after_trunk, prefetch_point=self.prefetch_point)
+        return run_network(self.model, self.shading, x, after_trunk=after_trunk, prefetch_point=self.prefetch_point, out=out)
+
+    # ---- one HIP graph per frame ---------------------------------------------------------------------------------------------
+    # Steady state of a temporal sequence whose next camera is known: frame t's G-buffer and hole-filled flow sit in slot s (rendered
+    # under frame t - 1), its "previous" is frame t - 1's output in the static buffer s ^ 1.  Everything frame t launches -- input
+    # assembly, dataflow trunk, the fork to the side stream (render of frame t + 1 from the camera block + its flow fill), the
+    # upsampling layers, fused tail, guard-word mirror, the join -- has fixed arguments and is captured ONCE per slot; per frame the
+    # host sends the next camera, refreshes the camera block (one small launch on this stream) and replays.  Kernel boundaries
+    # inside a graph need no host: ~2 us instead of the 4-15 us of eager launches with event records between them.
+    def _graph_signature(self):
+        sh = self.shading
+        return (tuple(sh.packed_parameters()), int(sh._specular_exponent), float(sh._ao), bool(self.model.inverse_ao), bool(sh.enable_specular),
+                self.model.initial_image_mode, id(self.model.model), ops._images_epoch, self._static_version, self.flow_fill_threads)
+
+    def _graph_ready(self, origin, next_origin):
+        if not (self.graph and next_origin is not None and self.temporal and self.previous is not None and self._prefetched is not None):
+            return False
+        slot = self._prefetched[1]
+        return (self._prefetched[0] == tuple(origin) and self._flow_ready[slot] and self.previous is self._out_raw[slot ^ 1]
+                and getattr(self.model, "_isr_static_out", False) and self.side_variant is None and self.prefetch_after_trunk
+                and self.prefetch_point == "trunk" and self.flow_fill_on_side and not ops.any_hot(self.device)
+                and not ops.profile_is_on() and self.foreground_variant == 0)
+
+    def _graph_body(self, slot):
+        """Frame of slot ``slot`` on the current stream (eagerly once as the warm-up, then under capture)."""
+        nxt = slot ^ 1
+        cur, rs = torch.cuda.current_stream(), self._render_stream
+        x = ops.assemble_input(self._gbuffers[slot], self._flows[slot], self._out_raw[nxt], self.model.initial_image_mode, self.model.inverse_ao)
+
+        def start_next():
+            self._fork.record(cur)
+            rs.wait_event(self._fork)
+            self.renderer.render_from_block(self._gbuffers[nxt], self._cam_blocks[nxt], rs)
+            ops.fill_flow_gbuffer(self._gbuffers[nxt], out=self._flows[nxt], stream=rs, threads=self.flow_fill_threads)
+            self._join.record(rs)
+        run_network(self.model, self.shading, x, after_trunk=start_next, prefetch_point="trunk", out=(self._out_raw[slot], self._out_rgb[slot]))
+        ops.guards_publish(self.device, record=False)
+        cur.wait_event(self._join)
+
+    def _frame_graph(self, origin, next_origin):
+        slot = self._prefetched[1]
+        nxt = slot ^ 1
+        cur = torch.cuda.current_stream()
+        ops.guards_poll(self.device)
+        sig = self._graph_signature()
+        if sig != self._graph_sig:
+            self._graphs, self._graph_sig = [None, None], sig
+        self.renderer.send_command("cameraOrigin", fmt3(next_origin))
+        self.renderer.write_frame_block(self._cam_blocks[nxt], cur)      # next frame's camera (flow reference: this frame's), ordered before the replay
+        cur.wait_event(self._ready[slot])                                # (an EAGER render of this slot, if that is where it came from)
+        if self._graphs[slot] is None:
+            gs = self._graph_stream
+            gs.wait_stream(cur)
+            with torch.cuda.stream(gs):
+                self._graph_body(slot)                                   # this frame, and the warm-up of everything the capture touches
+            cur.wait_stream(gs)
+            g = torch.cuda.CUDAGraph()
+            kw = {"pool": self._graph_pool} if self._graph_pool is not None else {}
+            with ops.graph_capture(g, stream=gs, **kw):
+                self._graph_body(slot)
+            if self._graph_pool is None:
+                self._graph_pool = g.pool()
+            self._graphs[slot] = g
+        else:
+            self._graphs[slot].replay()
+            self.graph_replays += 1
+        ops.guards_mark(self.device)
+        self._slot = slot
+        self.gbuffer = self._gbuffers[slot]
+        self._displayed = tuple(float(v) for v in fmt3(origin).split(","))
+        self._prefetched = (tuple(next_origin), nxt)
+        self._flow_ready[nxt] = True
+        self.previous = self._out_raw[slot]
+        return self._out_rgb[slot], self._out_raw[slot]
 
     def frame_fused(self, origin, next_origin=None):
+        if self._graph_ready(origin, next_origin):
+            with torch.no_grad():
+                return self._frame_graph(origin, next_origin)
         with torch.no_grad():
             # what the previous frame's kernels reported (a plain read of pinned memory): a layer that came close to the split
             # operands' range is routed to the exact kernels from THIS frame on; a dataflow-trunk launch that timed out raises
@@ -255,7 +358,8 @@ class SuperResolutionPipeline:
                 flow = self._flows[self._slot] if self._flow_ready[self._slot] else ops.fill_flow_gbuffer(g)
             x = ops.assemble_input(g, flow, prev, self.model.initial_image_mode, self.model.inverse_ao)
             self._consumed[self._slot].record(torch.cuda.current_stream())   # G-buffer no longer needed
-            raw, rgb = self._network(x, after_trunk=start_next)
+            out = (self._out_raw[self._slot], self._out_rgb[self._slot]) if self.graph else None
+            raw, rgb = self._network(x, after_trunk=start_next, out=out)
             if ops.range_check_due(x.device):
                 # range guard (ops.RANGE_GUARD), a model's FIRST frame: a layer's output came close to the fp16 range of the split
                 # operands -- its consumers run on the exact fp32 kernels from now on; this frame is computed again with that routing.
@@ -264,7 +368,7 @@ class SuperResolutionPipeline:
                 for _ in range(4):
                     if not ops.refresh_range_flags(x.device):
                         break
-                    raw, rgb = self._network(x)
+                    raw, rgb = self._network(x, out=out)
             ops.guards_publish(x.device)
             self.previous = raw
         return rgb, raw
