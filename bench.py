@@ -264,7 +264,7 @@ def run_infer(args, job):
         net = models.createNetwork('EnhanceNet', 4, 101, [0, 1, 2, 3, 4], 6, opt)
     model = LoadedModel.from_model(net, "cuda", parameters={"initialImage": "zero"})
     pipe = SuperResolutionPipeline(renderer, model, default_shading("cuda", 30.0), (low_w, low_h),
-                                   temporal=not args.no_temporal, graph=args.graph)
+                                   temporal=not args.no_temporal, graph=True if args.graph else None)
     pipe.set_static(fov=30.0, isovalue=iso)
     pipe.foreground_variant = args.raymarch_variant
     renderer.set_kernel_variant(args.raymarch_variant)

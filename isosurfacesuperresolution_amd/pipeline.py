@@ -117,7 +117,8 @@ class SuperResolutionPipeline:
         # the hole-filled flow of a prefetched frame is computed on the render stream as well (it only needs the G-buffer)
         self._flows = [torch.empty((1, 2, self.low_h, self.low_w), dtype=torch.float32, device=device) for _ in range(2)]
         self._flow_ready = [False, False]
-        self._render_stream = torch.cuda.Stream(device=device) if str(device).startswith("cuda") else None
+        # (ISR_SIDE_PRIORITY: experiment -- a stream of another priority class is served by another hardware queue than the main stream)
+        self._render_stream = torch.cuda.Stream(device=device, priority=int(os.environ.get("ISR_SIDE_PRIORITY", "0"))) if str(device).startswith("cuda") else None
         self._ready = [torch.cuda.Event(), torch.cuda.Event()] if self._render_stream else None
         self._consumed = [torch.cuda.Event(), torch.cuda.Event()] if self._render_stream else None
         self._frame_start = torch.cuda.Event() if self._render_stream else None
