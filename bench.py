@@ -486,6 +486,22 @@ def run_train(args, job):
                      "buckets": 1, "backend": "RCCL" if job.backend == "nccl" else job.backend}
     flops = TRAIN_FLOPS_PER_SAMPLE_FRAME * (crop / 32.0) ** 2 * B * T
     achieved = flops / (elapsed / K) / 1e12
+    # per-kernel fractions of the convolution launchers that carry dispatch-packet events (forward and data-gradient convolutions;
+    # the weight-gradient kernels do not): ONE eager step after the timed region (a replayed graph has no per-dispatch events)
+    train_kernels = None
+    if dev == "cuda":
+        torch.cuda.synchronize()
+        ops.profile_enable(True)
+        trainer.step(batch, initial_image="zero")
+        torch.cuda.synchronize()
+        per = {}
+        for name, fl, kms in ops.profile_records():
+            d = per.setdefault(name, [0.0, 0.0, 0])
+            d[0] += fl; d[1] += kms * 1e-3; d[2] += 1
+        ops.profile_enable(False)
+        train_kernels = {n: {"tflops": v[0] / v[1] / 1e12, "ms_per_step": v[1] * 1e3, "launches_per_step": v[2],
+                             "frac": v[0] / v[1] / 1e12 / ((MFMA_F16_PEAK_TFLOPS / 3.0) if is_split_kernel(n) else MFMA_F32_PEAK_TFLOPS)}
+                         for n, v in per.items() if v[1] > 0}
     # Roofline per kernel family, weighted by the flops each family carries: the time the step's convolutions would take
     # at each family's own ceiling is sum(flops_f / peak_f); the step's ceiling is total / that time (a harmonic mean).
     peaks = {"split": MFMA_F16_PEAK_TFLOPS / 3.0, "exact": MFMA_F32_PEAK_TFLOPS, "bf16": MFMA_F16_PEAK_TFLOPS}
@@ -513,8 +529,10 @@ def run_train(args, job):
                                     "MFMA %.0f / 3 products, exact kernels against fp32 MFMA %.1f TFLOP/s; peak = 1 / sum(share / family peak)"
                                     % (MFMA_F16_PEAK_TFLOPS, MFMA_F32_PEAK_TFLOPS),
                      "matrix_tflops_executed": achieved * sum(shares.get(k, 0.0) * (3.0 if k == "split" else 1.0) for k in shares),
+                     "kernels": train_kernels,
                      "note": "`achieved` divides the step's algorithmic conv flops by the WHOLE step (loss, warp, Adam, all-reduce "
-                             "included), so it understates the kernels; profiles/r03_train_kernel_stats.csv has the per-kernel times"},
+                             "included), so it understates the kernels; `kernels` = the forward / data-gradient convolution launches of one "
+                             "eager step after the timed region with their own fractions; profiles/r04_train_kernel_stats.csv has every kernel"},
         "cpu_baseline": None,
     }
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
@@ -918,6 +936,7 @@ def cpu_reference_leg(args, vol, iso, net, pipe, origin, low_w, low_h, result, r
     # a few more frames of the same temporal sequence (flow fill + warp included), so that the sample is ~10 s
     shade_cpu = default_shading("cpu", 30.0)
     n_frames, prev, last = 1, raw, q
+    cpu_frames = [(origin, ref, raw)]                       # (camera, oracle G-buffer, CPU network output) per frame of the sample
     for k in range(1, max(1, args.cpu_frames)):
         qk = V.quantize3(V.orbit_camera(k))
         pk = iso_oracle.make_params(low_w, low_h, origin=qk, fov=30.0, isovalue=float("%5.3f" % iso), last_origin=last)
@@ -930,11 +949,23 @@ def cpu_reference_leg(args, vol, iso, net, pipe, origin, low_w, low_h, result, r
         shade_cpu(prev)
         t_sr += time.perf_counter() - t0
         n_frames, last = n_frames + 1, qk
-    # same frame on the GPU (fresh sequence) for PSNR and mask parity
+        cpu_frames.append((V.orbit_camera(k), gk, prev))
+    # the same frames on the GPU (fresh sequence): PSNR and parity of the first frame, and -- reported as they are -- of every further
+    # frame of the sample: the G-buffer parity holds on every frame; the network output of frame k > 0 depends on frame k - 1's
+    # output, and with random-init weights that recurrence amplifies rounding differences ~2.4x per frame
     pipe.reset()
-    rgb_gpu, raw_gpu = pipe.frame(origin)
-    torch.cuda.synchronize()
-    gbuf = pipe.gbuffer.cpu().numpy()
+    per_frame = []
+    rgb_gpu = raw_gpu = gbuf = None
+    for k, (cam, g_cpu, raw_cpu) in enumerate(cpu_frames):
+        rgb_k, raw_k = pipe.frame(cam)
+        torch.cuda.synchronize()
+        g_gpu = pipe.gbuffer.cpu().numpy()
+        if k == 0:
+            rgb_gpu, raw_gpu, gbuf = rgb_k.clone(), raw_k.clone(), g_gpu
+        cols = [c for c in range(12) if k > 0 or c not in (8, 9)]       # the first frame's flow depends on the camera rendered before it
+        per_frame.append({"mask_mismatches": int((g_gpu[..., 3] != g_cpu[..., 3]).sum()),
+                          "gbuffer_max_abs_err": float(np.abs(g_gpu[..., cols] - g_cpu[..., cols]).max()),
+                          "sr_raw_max_abs_err": float((raw_k.cpu() - raw_cpu).abs().max().item())})
     mse = torch.mean((rgb_gpu.cpu() - rgb_cpu) ** 2).item()
     psnr = 10 * np.log10(1 / max(1e-10, mse))      # mainVideoUnshaded.py:693
     bytes_alg = stats["bricks_touched"] * 2048 + low_w * low_h * 48
@@ -942,12 +973,15 @@ def cpu_reference_leg(args, vol, iso, net, pipe, origin, low_w, low_h, result, r
         "cpu_baseline": {"value": n_frames / (t_render + t_sr), "unit": "frames/s", "cores": cores, "kind": "port",
                          "sample": "%d frames of the bench sequence: oracle ray-march %dx%d (%.3f s, OpenMP %d threads) + PyTorch CPU flow fill, warp, EnhanceNet, shading (%.3f s, %d threads)" % (
                              n_frames, low_w, low_h, t_render, cores, t_sr, cores)},
-        "parity": {"frames_compared": 1,     # the FIRST frame of a sequence: with random-init weights the recurrence amplifies
-                                             # rounding differences ~2.4x per frame, so later frames drift
+        "parity": {"frames_compared": len(per_frame),     # the four numbers below are frame 0's (a sequence's first frame: no recurrence yet);
+                                                         # `per_frame` lists every frame of the sample
                    "mask_mismatches": int((gbuf[..., 3] != ref[..., 3]).sum()),
                    "gbuffer_max_abs_err_excl_flow": float(np.abs(np.delete(gbuf, [8, 9], axis=2) - np.delete(ref, [8, 9], axis=2)).max()),
                    "sr_raw_max_abs_err": float((raw_gpu.cpu() - raw).abs().max().item()),
-                   "psnr_rgb_vs_cpu_db": float(psnr)},
+                   "psnr_rgb_vs_cpu_db": float(psnr),
+                   # every frame of the CPU sample, as measured (frame 0 = the numbers above; G-buffer parity is per frame, the network
+                   # output of later frames carries the recurrence's amplification of rounding differences with random-init weights)
+                   "per_frame": per_frame},
     }
     result["raymarch"].update({
         "bricks_touched": stats["bricks_touched"], "samples": stats["samples"], "hit_pixels": stats["hits"],

@@ -104,11 +104,18 @@ __global__ __launch_bounds__(S_THREADS, 2) void conv3x3_split_tail_kernel(const 
     const unsigned planeBytes = (unsigned)p.xPlane * 4u;
 
     struct Tile { int oy0, ox0; };
+    // Tile list order: BANDS of `band` tile rows walked column by column, so that the ~64 workgroups of an XCD, which take consecutive
+    // list entries at any time, cover a 2-D block of tiles (16 columns x 4 rows) and find each other's halo rows and columns in their
+    // L2 instead of fetching them again (row-major order: a tile row of 60 tiles is 5 MB of patches, the row above has left the 4 MB L2
+    // by the time the row below wants its two shared image rows).  p.dbg bit 7: the row-major order (A/B runs).
+    const int band = (p.dbg & 128) ? 1 : 4;
     auto decode = [&](int t) {
-        int b = tstart + t;
+        const int b = tstart + t;
+        const int per = band * p.tilesX, bi = b / per, r0 = b - bi * per;
+        const int rows = min(band, p.tilesY - bi * band);
         Tile r;
-        r.ox0 = (b % p.tilesX) * ST_W; b /= p.tilesX;
-        r.oy0 = b * ST_H;
+        r.ox0 = (r0 / rows) * ST_W;
+        r.oy0 = (bi * band + r0 % rows) * ST_H;
         return r;
     };
     const bool staging = tid < SQ_UNITS;
@@ -638,7 +645,7 @@ static int tail_launch(const void* xin, int packed, const void* wq6, const float
     p.ksteps = 4; p.coutPad = 64; p.cgroups = 1;
     p.tilesX = (W + ST_W - 1) / ST_W; p.tilesY = (H + ST_H - 1) / ST_H;
     p.act = ISR_ACT_RELU; p.slope = 0.0f;
-    p.stamps = nullptr; p.dbg = g_tail_fused == 3 ? 64 : 0; p.quads = 1;
+    p.stamps = nullptr; p.dbg = (g_tail_fused == 3 ? 64 : 0) | (getenv("ISR_TAIL_ROWMAJOR") ? 128 : 0); p.quads = 1;
     tp.wz = (const u32x4*)wz;
     tp.z = (float*)workspace;
     tp.zPlane = H * W + W;
