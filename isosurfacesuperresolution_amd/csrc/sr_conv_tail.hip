@@ -123,19 +123,45 @@ __global__ __launch_bounds__(S_THREADS, 2) void conv3x3_split_tail_kernel(const 
     const int ur = urem / SQ_QPR, uq = urem - ur * SQ_QPR;
     const rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.x), 0, PSIN ? 0 : (int)((size_t)64 * p.xPlane * 4), 0x00020000);
     u32x4 v[PSIN ? 1 : 8];
-    // packed-split input: k-step ks of tile t into slot `slot` -- per part (hi, lo) 680 units [2 groups][10 x 34 pixels] = 11 pieces
-    auto dma_kstep = [&](const Tile& t, int ks, int slot) {
+    // packed-split input: k-step ks of tile t into slot `slot` -- per part (hi, lo) 680 units [2 groups][10 x 34 pixels] = 11 pieces.
+    // LDS-DMA through a BUFFER DESCRIPTOR (buffer_load_dwordx4 ... lds): the lane's 32-bit offset inside the patch is loop invariant (one
+    // register per piece), the tile's and k-step's position goes into the scalar offset, and a lane whose pixel lies outside the image
+    // gets the out-of-range offset, for which the hardware writes ZEROS into LDS (tools/probes/buffer_lds_oob_probe.hip) -- the
+    // convolution's zero padding without a zero unit.  Round 3 used global_load_lds with a 64-bit address per lane and piece: the six
+    // pointer pairs were spilled, and every reload ended in an `s_waitcnt vmcnt(0)` that waited for the PREVIOUS pieces' DMA to land.
+    // The descriptor starts one image row + one pixel BEFORE the tensor, so that the patch's halo offsets are never negative (the lanes
+    // that would read in front of the tensor are exactly the out-of-image ones, which are masked).
+    const int wv = __builtin_amdgcn_readfirstlane(wave);
+    unsigned pvoff[PSIN ? 6 : 1], prc[PSIN ? 6 : 1];
+    rsrc_t xprs = xrs;
+    if constexpr (PSIN) {
+        xprs = __builtin_amdgcn_make_buffer_rsrc(const_cast<u32x4*>(tp.xps) - (p.W + 1), 0, (int)(((size_t)2 * 8 * tp.xpsPlane + p.W + 1) * 16), 0x00020000);
 #pragma unroll
         for (int d = 0; d < 6; ++d) {
-            const int piece = wave + 4 * d;
-            const int part = piece / 11, pc = piece - part * 11, off = pc * 64 + lane;
-            if (piece < 22 && off < SQ_SLOT) {
-                const int gg = off / SP_PIX, pix = off - gg * SP_PIX;
-                const int r = pix / SP_W, c = pix - r * SP_W;
-                const int iy = t.oy0 + r - 1, ix = t.ox0 + c - 1;
-                const bool ok = (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
-                const u32x4* src = ok ? tp.xps + ((size_t)(part * 8 + 2 * ks + gg) * tp.xpsPlane + (size_t)iy * p.W + ix) : tp.zero;
-                isr_dma16(src, patch + part * S_PART + slot * SQ_SLOT + pc * 64);
+            const int piece = wv + 4 * d;
+            const int pc = piece % 11, off = pc * 64 + lane;
+            const int gg = off / SP_PIX, pix = off - gg * SP_PIX;
+            const int r = pix / SP_W, c = pix - r * SP_W;
+            pvoff[d] = (piece < 22 && off < SQ_SLOT) ? ((unsigned)gg * (unsigned)tp.xpsPlane + (unsigned)(r * p.W + c)) * 16u : BAD_OFFSET;
+            prc[d] = (unsigned)r | ((unsigned)c << 8);
+        }
+    }
+    auto dma_kstep = [&](const Tile& t, int ks, int slot) {
+        if constexpr (PSIN) {
+            const bool interior = t.oy0 >= 1 && t.oy0 + ST_H + 1 <= p.H && t.ox0 >= 1 && t.ox0 + ST_W + 1 <= p.W;
+#pragma unroll
+            for (int d = 0; d < 6; ++d) {
+                const int piece = wv + 4 * d;
+                if (piece >= 22) continue;
+                const int part = piece / 11, pc = piece - part * 11;
+                unsigned vo = pvoff[d];
+                if (!interior) {
+                    const int iy = t.oy0 + (int)(prc[d] & 255u) - 1, ix = t.ox0 + (int)(prc[d] >> 8) - 1;
+                    vo = ((unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W) ? vo : BAD_OFFSET;
+                }
+                const unsigned soff = ((unsigned)(part * 8 + 2 * ks) * (unsigned)tp.xpsPlane + (unsigned)(t.oy0 * p.W + t.ox0)) * 16u;
+                if (pc * 64 + lane < SQ_SLOT)        // (the last piece is 40 units: the other lanes must not write behind the slot)
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(xprs, (isr_lvoid_t*)(patch + part * S_PART + slot * SQ_SLOT + pc * 64), 16, (int)vo, (int)soff, 0, 0);
             }
         }
     };
