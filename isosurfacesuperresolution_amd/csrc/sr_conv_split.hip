@@ -203,19 +203,26 @@ __global__ __launch_bounds__(S_THREADS, 2) void conv3x3_split_kernel(const Split
         } else if (p.dbg & 2) {
         } else if (p.xps) {
             // packed-split input: the chunk's units are already what the slot holds -- 2 parts x 1360 units = 44 wave-wide 1 KB
-            // pieces, 11 per wave, by LDS-DMA (no registers, no conversion; they land before the barrier below)
+            // pieces, 11 per wave, by LDS-DMA (no registers, no conversion; they land before the barrier below).  Through a buffer
+            // descriptor that starts one image row + one pixel in front of the tensor (halo offsets never negative): a 32-bit lane
+            // offset, the chunk's / tile's position in the scalar offset, and lanes outside the image (or beyond the last channel
+            // group) get the out-of-range offset, for which the hardware writes zeros into LDS (tools/probes/buffer_lds_oob_probe.hip)
             const int groups = p.Cin >> 3;
+            const rsrc_t xprs = __builtin_amdgcn_make_buffer_rsrc(const_cast<u32x4*>(p.xps) - (p.W + 1), 0,
+                                                                  (int)(((size_t)2 * groups * p.xpsPlane + p.W + 1) * 16), 0x00020000);
+            const int wv = __builtin_amdgcn_readfirstlane(wave);
 #pragma unroll
             for (int d = 0; d < 11; ++d) {
-                const int piece = wave + 4 * d;                              // 0 .. 43: 22 pieces per part
+                const int piece = wv + 4 * d;                                // 0 .. 43: 22 pieces per part
                 const int part = piece / 22, pc = piece - part * 22, off = pc * 64 + lane;
                 if (off < S_PART) {
                     const int g = off / SP_PIX, pix = off - g * SP_PIX;
                     const int r = pix / SP_W, c = pix - r * SP_W;
                     const int iy = oy0 + r - 1, ix = ox0 + c - 1, gg = (cin0 >> 3) + g;
                     const bool ok = gg < groups && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
-                    const u32x4* src = ok ? p.xps + ((size_t)(part * groups + gg) * p.xpsPlane + (size_t)iy * p.W + ix) : p.zero;
-                    isr_dma16(src, patch + part * S_PART + pc * 64);
+                    const unsigned vo = ok ? ((unsigned)g * (unsigned)p.xpsPlane + (unsigned)(r * p.W + c)) * 16u : BAD_OFFSET;
+                    const unsigned so = ((unsigned)(part * groups + (cin0 >> 3)) * (unsigned)p.xpsPlane + (unsigned)(oy0 * p.W + ox0)) * 16u;
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(xprs, (isr_lvoid_t*)(patch + part * S_PART + pc * 64), 16, (int)vo, (int)so, 0, 0);
                 }
             }
         } else if (p.quads) {
