@@ -132,10 +132,15 @@ __device__ __forceinline__ void split_epilogue_ps(const SplitConvParams& p, f32x
         for (int i = 0; i < 16; ++i)
             bv[cb][i] = p.bias ? p.bias[min(co0 + cb * 32 + 8 * (i >> 2) + 4 * h + (i & 3), p.Cout - 1)] : 0.0f;
     unsigned mag = 0u;
+    // The lane pair (j, 0) / (j, 1) holds the two 8-byte halves of the hi unit and of the lo' unit of a pixel's channel group; they trade
+    // halves (v_permlane32_swap: the upper 32 lanes of one register against the lower 32 of another), after which lane (j, 0) holds the
+    // whole hi unit and lane (j, 1) the whole lo' unit: ONE 16-byte store per lane instead of two 8-byte ones -- the epilogue is
+    // store-ISSUE bound (tools/bench_ups4.py)
+    const unsigned lopart = (unsigned)h * (unsigned)(groups * p.psPlane) * 16u;
 #pragma unroll
     for (int r = 0; r < 2; ++r) {
         const int oy = oy0 + wave * 2 + r;
-        const unsigned voff = (oy < p.H && ox < p.W) ? (unsigned)(oy * p.W + ox) * 16u + 8u * (unsigned)h : BAD_OFFSET;
+        const unsigned voff = (oy < p.H && ox < p.W) ? (unsigned)(oy * p.W + ox) * 16u + lopart : BAD_OFFSET;
 #pragma unroll
         for (int cb = 0; cb < 2; ++cb) {
             if (cb == 1 && !second) break;
@@ -154,8 +159,11 @@ __device__ __forceinline__ void split_epilogue_ps(const SplitConvParams& p, f32x
                 }
                 const int g = (co0 >> 3) + cb * 4 + gi;
                 const bool live = g < groups;
-                __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, th), prs, (int)(live ? voff : BAD_OFFSET), g * p.psPlane * 16, 0);
-                __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, tl), prs, (int)(live ? voff : BAD_OFFSET), (groups + g) * p.psPlane * 16, 0);
+                const u32x2 uh = __builtin_bit_cast(u32x2, th), ul = __builtin_bit_cast(u32x2, tl);
+                const u32x2 s0 = __builtin_amdgcn_permlane32_swap(uh.x, ul.x, false, false);
+                const u32x2 s1 = __builtin_amdgcn_permlane32_swap(uh.y, ul.y, false, false);
+                const u32x4 unit = {s0.x, s1.x, s0.y, s1.y};                // h = 0: channels 8 g .. + 7 hi; h = 1: the same channels' lo'
+                __builtin_amdgcn_raw_buffer_store_b128(unit, prs, (int)(live ? voff : BAD_OFFSET), g * p.psPlane * 16, 0);
             }
         }
     }
