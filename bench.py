@@ -620,9 +620,9 @@ def run_tiled(args, job, make_local_renderer=None):
         t_load = time.perf_counter() - t0
 
         class _Local:
-            def render(self, tensor, origin):
+            def render(self, tensor, origin, stream=None):
                 renderer.send_command("cameraOrigin", V.fmt3(origin))
-                return renderer.render_direct(tensor)
+                renderer.render_async(tensor, stream if stream is not None else torch.cuda.current_stream())
         local = _Local()
     del tiles
     opt = argparse.Namespace(upsample='bilinear', reconType='residual', useBN=False, numResidualLayers=10)
@@ -631,45 +631,53 @@ def run_tiled(args, job, make_local_renderer=None):
         net = models.createNetwork('EnhanceNet', 4, 101, [0, 1, 2, 3, 4], 6, opt)
     lm = LoadedModel.from_model(net, dev, parameters={"initialImage": "zero"})
     sr = parallel_sr.StripSuperResolution(lm, default_shading(dev, 30.0))
-    mine = torch.empty((low_h, low_w, 12), dtype=torch.float32, device=dev)
-    gathered = torch.empty((world, low_h, low_w, 12), dtype=torch.float32, device=dev)
     K, Wm = args.steps, args.warmup
-    phases = {"render": 0.0, "allgather": 0.0, "composite": 0.0, "sr_strip_and_allgather": 0.0}
+    # render(t+1) + all-gather + composite on a side stream beside SR(t), released when SR(t)'s trunk is enqueued (as the default
+    # mode's pipeline does); --no-overlap: one after the other
+    overlap = dev == "cuda" and not args.no_overlap
+    release = os.environ.get("BENCH_TILED_RELEASE", "trunk")               # trunk | start: where in SR(t) the next frame is released
 
-    def tick():
-        if dev == "cuda":
-            torch.cuda.synchronize()
-        return time.perf_counter()
-
-    def frame(k, timed):
-        origin = V.orbit_camera(k)
-        a = tick()
-        local.render(mine, origin)
-        b = tick()
-        if world > 1:
-            dist.all_gather_into_tensor(gathered.view(world * low_h, low_w, 12), mine)
+    def render_fn(tensor, key, stream):
+        if renderer is not None:
+            local.render(tensor, V.orbit_camera(key), stream)
         else:
-            gathered[0].copy_(mine)
-        c = tick()
-        comp = PR.composite(gathered)
-        d = tick()
-        rgb, raw = sr.frame(comp)
-        e = tick()
+            local.render(tensor, V.orbit_camera(key))
+    source = PR.PrefetchedComposite(render_fn, low_h, low_w, dev)
+    sr_events = []
+
+    def stamp():
+        return torch.cuda.current_stream().record_event(torch.cuda.Event(enable_timing=True)) if dev == "cuda" else time.perf_counter()
+
+    def frame(k, timed, last):
+        """``last``: nothing is prefetched behind this frame (exactly K renders inside the timed region)."""
+        comp = source.take(k)
+        ahead = overlap and not last
+        if ahead and release == "start":
+            source.start(k + 1)
+        a = stamp()
+        rgb, raw = sr.frame(comp, after_trunk=(lambda: source.start(k + 1)) if (ahead and release != "start") else None)
         if timed:
-            for name, dt in zip(phases, (b - a, c - b, d - c, e - d)):
-                phases[name] += dt
+            sr_events.append((a, stamp()))
         return comp, rgb
 
     for k in range(Wm):
-        frame(k - Wm, False)
+        frame(k - Wm, False, k + 1 == Wm)
     if world > 1:
         # a silently no-op all-gather must not pass: every rank's own hit count travels through a DIFFERENT collective
         # (an all-reduce of a one-hot vector) and must equal the hit count of the slice the all-gather delivered for it
+        if dev == "cuda":
+            torch.cuda.synchronize()
+        check_mine = torch.empty_like(source.local)
+        render_fn(check_mine, -1, None)
+        check_all = torch.empty_like(source.gathered)
+        dist.all_gather_into_tensor(check_all.view(world * low_h, low_w, 12), check_mine)
         own = torch.zeros(world, dtype=torch.float64, device=job.coll_device)
-        own[rank] = float((mine[..., 3] == 1).sum().item())
+        own[rank] = float((check_mine[..., 3] == 1).sum().item())
         dist.all_reduce(own)
-        got = [float((gathered[r][..., 3] == 1).sum().item()) for r in range(world)]
+        got = [float((check_all[r][..., 3] == 1).sum().item()) for r in range(world)]
         assert got == own.tolist(), "all-gather of the G-buffers delivered %s hit pixels per rank, the ranks rendered %s" % (got, own.tolist())
+        del check_mine, check_all
+    source.record(True)
     sr.reset()
     from isosurfacesuperresolution_amd import ops
     if dev == "cuda":
@@ -677,9 +685,14 @@ def run_tiled(args, job, make_local_renderer=None):
     job.sync()
     t0 = time.perf_counter()
     for k in range(K):
-        comp, rgb = frame(k, True)
+        comp, rgb = frame(k, True, k + 1 == K)
     job.sync()
     elapsed = job.max_over_ranks(time.perf_counter() - t0)
+    if dev == "cuda":
+        torch.cuda.synchronize()
+    # per-phase times from events on the stream each phase ran on (no host synchronisation inside the timed region)
+    phases = dict(zip(("render", "allgather", "composite"), (v * 1e-3 for v in source.phase_ms())))
+    phases["sr_strip_and_allgather"] = sum(a.elapsed_time(b) * 1e-3 if dev == "cuda" else b - a for a, b in sr_events)
     ms = {name: job.max_over_ranks(v) / K * 1e3 for name, v in phases.items()}
     hits = int((comp[..., 3] == 1).sum().item())
     # roofline of the dominant kernel: the strip's convolutions (same formula as the default mode)
@@ -721,7 +734,9 @@ def run_tiled(args, job, make_local_renderer=None):
         "config": {"workload": "%d^3 volume in %s object-space tiles, %dx%d -> %dx%d, temporal on" % (
                        n, "x".join(str(v) for v in TILE_SPLITS[world]), low_w, low_h, 4 * low_w, 4 * low_h),
                    "sharding": "one tile per rank; all-gather of %.1f MB G-buffers + nearest-hit composite; SR in %d strips with a 24-px halo + all-gather"
-                               % (low_w * low_h * 48 / 1e6, world)},
+                               % (low_w * low_h * 48 / 1e6, world),
+                   "overlap": ("render + all-gather + composite of frame t+1 on a side HIP stream || SR(t), released at SR(t)'s %s" % release)
+                              if overlap else "none"},
         **job.rank_keys(),
         "phases_ms_max_over_ranks": ms,
         "tile": {"generate_s": t_gen, "voxels": [int(v) for v in tile["data"].shape[::-1]]},

@@ -71,7 +71,8 @@ struct Trunk16Params {
     unsigned* error;                 // 1 + the layer at which a wait timed out (0: none)
     unsigned* absmax;                // range guard over every value stored (may be NULL)
     int H, W, plane, tilesX, tilesY, layers;
-    int dbg;                         // diagnostics (isrDebugSetTrunkAblation): 1 no MFMAs, 2 no activation DMA, 4 no stores, 8 no waits, 16 no weight DMA
+    int dbg;                         // diagnostics (isrDebugSetTrunkAblation): 1 no MFMAs, 2 no activation DMA, 4 no stores, 8 no waits, 16 no weight DMA,
+                                     // 32 the MFMAs on operands read once per k-step, 64 (with 32) ... but every tap's fragments read from LDS all the same
     int faultTile;                   // diagnostics (isrDebugSetTrunkFault): the tile that never publishes, or -1
     unsigned long long timeoutTicks; // of the chip's 100 MHz clock
     unsigned long long* stamps;      // diagnostics: [tile][layer][8] = ticks at: layer start | neighbours there | first k-step staged | MFMAs done | epilogue done | stores drained
@@ -141,9 +142,18 @@ __device__ __forceinline__ Trunk16Operands trunk16_operands(const u32x4* wl, con
 template <typename Between>
 __device__ __forceinline__ void trunk16_kstep(f32x16 (&acc)[2][2], const u32x4* wl, const u32x4* bl, Between between)
 {
+    // Software-pipelined over the taps: tap t + 1's eight operand fragments are requested BEFORE tap t's MFMAs are issued and are
+    // consumed one basic block later (`between` branches, so every tap is a block of its own and the compiler's scheduler cannot
+    // do this by itself: it issued a tap's reads at the top of the tap's block and waited for them with lgkmcnt(0), eight LDS
+    // latencies per k-step and wave with only the other wave of the SIMD to cover them).  The fence keeps the requests in front.
+    Trunk16Operands cur = trunk16_operands(wl, bl, 0);
 #pragma unroll
     for (int tap = 0; tap < 9; ++tap) {
-        const Trunk16Operands cur = trunk16_operands(wl, bl, tap);
+        Trunk16Operands nxt = cur;
+        if (tap < 8) {
+            nxt = trunk16_operands(wl, bl, tap + 1);
+            __builtin_amdgcn_sched_barrier(0);
+        }
         const f16x8 a0s = cur.a0h * (_Float16)0.00048828125f;               // w_hi 2^-11: partner of the scaled x_lo'
         const f16x8 a1s = cur.a1h * (_Float16)0.00048828125f;
 #pragma unroll
@@ -156,6 +166,7 @@ __device__ __forceinline__ void trunk16_kstep(f32x16 (&acc)[2][2], const u32x4* 
             acc[1][r] = mfma16(cur.a1h, cur.bh[r], acc[1][r]);
         }
         between(tap);
+        cur = nxt;
     }
 }
 
@@ -204,7 +215,7 @@ __device__ __forceinline__ void trunk16_patch_run(int sub, const char* plane, un
 // Not LAST: channels 0 .. 31 -- the next layer's first two k-steps -- go straight into the two patch buffers (pk0, pk1: LDS, this
 // tile's centre; pixels outside the image as zeros) and to memory only where a neighbour will read them (the tile's outermost
 // ring); channels 32 .. 63 go to memory whole and come back by DMA under those two k-steps.
-template <int KIND, bool LAST>
+template <int KIND, bool LAST, bool DIAG>
 __device__ __forceinline__ void trunk16_epilogue(const Trunk16Params& p, f32x16 (&acc)[2][2], f32x16 (&F)[2][2], unsigned& mag, float unscale,
                                                  const float* biasl, const char* out, unsigned planeBytes, int oy0, int ox0, int wave, int j, int h,
                                                  u32x4* pk0, u32x4* pk1)
@@ -215,7 +226,7 @@ __device__ __forceinline__ void trunk16_epilogue(const Trunk16Params& p, f32x16 
 #pragma unroll
     for (int r = 0; r < 2; ++r) {
         const int oy = oy0 + wave * 2 + r;
-        const bool inside = oy < p.H && ox < p.W && !(p.dbg & 4);
+        const bool inside = oy < p.H && ox < p.W && !(DIAG && (p.dbg & 4));
         const unsigned voff = !inside ? BAD_OFFSET : LAST ? (unsigned)(oy * p.W + ox + 4 * h * p.yPlane) * 4u      // the lane half's 4 channels: in the lane offset
                                                           : (unsigned)(oy * p.W + ox) * 16u + 8u * (unsigned)h;
         const int row = wave * 2 + r;
@@ -263,8 +274,13 @@ __device__ __forceinline__ void trunk16_epilogue(const Trunk16Params& p, f32x16 
     }
 }
 
+// DIAG: the instantiation with the diagnostics (ablation switches, phase stamps) compiled in; the product launch is the one without:
+// the 108 unrolled MFMAs of the "operands read once" path and its nine copies of the DMA bookkeeping made the kernel's code large
+// enough to slow the real path down (measured when a second such path was added: 636 -> 755 us).
+template <bool DIAG>
 __global__ __launch_bounds__(T16_THREADS) void trunk_dataflow_kernel(const Trunk16Params p)
 {
+    const int dbg = DIAG ? p.dbg : 0;
     extern __shared__ u32x4 lds[];
     u32x4* const pbuf0 = lds;                                                // patch buffers at + P16_UNITS
     u32x4* const wbuf0 = lds + 2 * P16_UNITS;                                // weight buffers at + S_WUNITS
@@ -299,11 +315,10 @@ __global__ __launch_bounds__(T16_THREADS) void trunk_dataflow_kernel(const Trunk
 
     const char* const ws = trunk16_uniform(p.ws);
     const unsigned planeBytes = (unsigned)p.plane * 16u;                     // H W units + the plane's zero unit, rounded up to whole cache lines
-    const bool dmaX = !(p.dbg & 2), dmaW = !(p.dbg & 16);
+    const bool dmaX = !(dbg & 2), dmaW = !(dbg & 16);
     const u32x4* wq = trunk16_uniform(p.wq[0]);
     // bias of layer l into bias buffer l & 1: one dword-wide DMA (64 floats) by the last wave; a layer without bias reads zeros
-    auto stage_bias = [&](int l) {
-        const float* b = trunk16_uniform(p.bias[l]);
+    auto stage_bias = [&](int l, const float* b) {
         if (wave != T16_WAVES - 1) return;
         if (b) trunk16_dma4(b, (unsigned)lane * 4u, bAddr + (unsigned)(l & 1) * 256u);
         else biasl0[(l & 1) * 64 + lane] = 0.0f;
@@ -322,7 +337,7 @@ __global__ __launch_bounds__(T16_THREADS) void trunk_dataflow_kernel(const Trunk
         return tensor + (size_t)(rpart * groups_ + 2 * ks + rsel) * planeBytes;
     };
     // the first layer's first k-step: nothing to wait for
-    stage_bias(0);
+    stage_bias(0, trunk16_uniform(p.bias[0]));
     if (wrole) {
         if (dmaW) {
 #pragma unroll
@@ -342,14 +357,16 @@ __global__ __launch_bounds__(T16_THREADS) void trunk_dataflow_kernel(const Trunk
         const char* const tout = ws + ((l & 1) ? p.tpsOff : p.fpsOff);       // this layer's output = the next layer's input
         const bool last = l + 1 == p.layers;
         const u32x4* const wqNext = last ? nullptr : trunk16_uniform(p.wq[l + 1]);
+        // (fetched here, not where it is used: a scalar load inside the k-loop makes every LDS wait behind it an lgkmcnt(0))
+        const float* const biasNext = last ? nullptr : trunk16_uniform(p.bias[l + 1]);
         // diagnostics: raw ticks at the phase boundaries, straight to memory (no registers held for it)
         auto lap = [&](int slot) {
-            if (p.stamps && tid == 0) p.stamps[((size_t)tile * p.layers + l) * 8 + slot] = __builtin_amdgcn_s_memrealtime();
+            if (DIAG && p.stamps && tid == 0) p.stamps[((size_t)tile * p.layers + l) * 8 + slot] = __builtin_amdgcn_s_memrealtime();
         };
         lap(0);
         // ---- wait for the 3 x 3 neighbourhood to have finished layer l - 1, then fetch the halo of the first k-step ---------------
         if (l > 0) {
-            if (!(p.dbg & 8)) {
+            if (!(dbg & 8)) {
                 if (tid == 0) flags[0] = 0;
                 __syncthreads();
                 if (tid < 9 && tid != 4) {
@@ -414,20 +431,35 @@ __global__ __launch_bounds__(T16_THREADS) void trunk_dataflow_kernel(const Trunk
                             trunk16_patch_run<false>(tap, pplane, pnxt + pdstRole, lanes);
                             if (tap == 8) trunk16_patch_run<false>(9, pplane, pnxt + pdstRole, lanes);
                         }
-                    } else if (!more && !last && tap == 0) stage_bias(l + 1);
+                    } else if (!more && !last && tap == 0) stage_bias(l + 1, biasNext);
                 }
             };
-            if (p.dbg & 32) {                                                // diagnostics: the k-step's 108 MFMAs on operands read once
+            if (dbg & 32) {                                                // diagnostics: the k-step's 108 MFMAs on operands read once
                 const f16x8 a = __builtin_bit_cast(f16x8, wcur[h * 64 + j]), b = __builtin_bit_cast(f16x8, pcur[h * P16_PIX + j]);
+                if (dbg & 64) {                                            // ... with every tap's eight fragments read from LDS all the same (and dropped)
 #pragma unroll
-                for (int t = 0; t < 27; ++t)
+                    for (int t = 0; t < 9; ++t) {
+                        const Trunk16Operands o = trunk16_operands(wcur + h * 64 + j, pcur + h * P16_PIX + (wave * 2) * P16_W + j, t);
+                        asm volatile("" :: "v"(o.a0h), "v"(o.a0l), "v"(o.a1h), "v"(o.a1l), "v"(o.bh[0]), "v"(o.bh[1]), "v"(o.bo[0]), "v"(o.bo[1]));
 #pragma unroll
-                    for (int cb = 0; cb < 2; ++cb)
+                        for (int q = 0; q < 3; ++q)
 #pragma unroll
-                        for (int r = 0; r < 2; ++r) acc[cb][r] = mfma16(a, b, acc[cb][r]);
+                            for (int cb = 0; cb < 2; ++cb)
 #pragma unroll
-                for (int t = 0; t < 9; ++t) between(t);
-            } else if (!(p.dbg & 1)) {
+                                for (int r = 0; r < 2; ++r) acc[cb][r] = mfma16(a, b, acc[cb][r]);
+                        between(t);
+                    }
+                } else {
+#pragma unroll
+                    for (int t = 0; t < 27; ++t)
+#pragma unroll
+                        for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+                            for (int r = 0; r < 2; ++r) acc[cb][r] = mfma16(a, b, acc[cb][r]);
+#pragma unroll
+                    for (int t = 0; t < 9; ++t) between(t);
+                }
+            } else if (!(dbg & 1)) {
                 trunk16_kstep(acc, wcur + h * 64 + j, pcur + h * P16_PIX + (wave * 2) * P16_W + j, between);
             } else {
 #pragma unroll
@@ -442,11 +474,11 @@ __global__ __launch_bounds__(T16_THREADS) void trunk_dataflow_kernel(const Trunk
             u32x4* const pk0 = pbuf0 + (gk & 1) * P16_UNITS;                 // the next layer's k-steps 0 and 1
             u32x4* const pk1 = pbuf0 + ((gk + 1) & 1) * P16_UNITS;
             if (last) {
-                if (kind == 0) trunk16_epilogue<0, true>(p, acc, F, mag, unscale, biasl, tout, planeBytes, oy0, ox0, wave, j, h, pk0, pk1);
-                else trunk16_epilogue<2, true>(p, acc, F, mag, unscale, biasl, tout, planeBytes, oy0, ox0, wave, j, h, pk0, pk1);
-            } else if (kind == 0) trunk16_epilogue<0, false>(p, acc, F, mag, unscale, biasl, tout, planeBytes, oy0, ox0, wave, j, h, pk0, pk1);
-            else if (kind == 1) trunk16_epilogue<1, false>(p, acc, F, mag, unscale, biasl, tout, planeBytes, oy0, ox0, wave, j, h, pk0, pk1);
-            else trunk16_epilogue<2, false>(p, acc, F, mag, unscale, biasl, tout, planeBytes, oy0, ox0, wave, j, h, pk0, pk1);
+                if (kind == 0) trunk16_epilogue<0, true, DIAG>(p, acc, F, mag, unscale, biasl, tout, planeBytes, oy0, ox0, wave, j, h, pk0, pk1);
+                else trunk16_epilogue<2, true, DIAG>(p, acc, F, mag, unscale, biasl, tout, planeBytes, oy0, ox0, wave, j, h, pk0, pk1);
+            } else if (kind == 0) trunk16_epilogue<0, false, DIAG>(p, acc, F, mag, unscale, biasl, tout, planeBytes, oy0, ox0, wave, j, h, pk0, pk1);
+            else if (kind == 1) trunk16_epilogue<1, false, DIAG>(p, acc, F, mag, unscale, biasl, tout, planeBytes, oy0, ox0, wave, j, h, pk0, pk1);
+            else trunk16_epilogue<2, false, DIAG>(p, acc, F, mag, unscale, biasl, tout, planeBytes, oy0, ox0, wave, j, h, pk0, pk1);
         }
         lap(4);
         // ---- publish: every wave's stores drained, then one agent-scope store of the tile's progress -------------------------
@@ -518,12 +550,12 @@ extern "C" {
 /* Diagnostics only (tools/bench_trunk.py): bit 0 skip the MFMAs, 1 skip the activation DMA, 2 skip the stores, 3 skip the waits on
  * the neighbours, 4 skip the weight DMA, 5 the MFMAs on operands read once per k-step (no LDS traffic).  Results are wrong with any bit set; bench.py refuses to report with a non-zero
  * isrDebugTrunkState(). */
-void isrDebugSetTrunkAblation(int mask) { g_trunk_dbg = mask & 63; }
+void isrDebugSetTrunkAblation(int mask) { g_trunk_dbg = mask & 127; }
 /* [tiles][layers][8] unsigned long long of ZEROED device memory (or NULL): per tile and layer the tick (100 MHz, one clock for the
  * chip) at the layer's start | the neighbours' arrival | the first k-step staged | the MFMAs done | the epilogue done | the stores
  * drained (slot 1 stays 0 for the first layer). */
 void isrDebugSetTrunkStampBuffer(unsigned long long* stamps) { g_trunk_stamps = stamps; }
-int isrDebugTrunkState(void) { return g_trunk_dbg | (g_trunk_stamps ? 64 : 0) | ((g_trunk_fault_tile >= 0 || g_trunk_timeout_ticks != 5000000ull) ? 128 : 0); }
+int isrDebugTrunkState(void) { return g_trunk_dbg | ((g_trunk_fault_tile >= 0 || g_trunk_timeout_ticks != 5000000ull) ? 128 : 0) | (g_trunk_stamps ? 256 : 0); }
 /* Tests of the timeout path: tile `tile` (>= 0) never publishes its progress, so its neighbours' waits run into the deadline, which
  * is `timeoutTicks` of the 100 MHz clock after the kernel's start (0: the default 50 ms); tile < 0 switches the fault off.  The launch
  * then ends with the error word set BY THE KERNEL and an incomplete output. */
@@ -591,15 +623,23 @@ int isrTrunkDataflow(const float* x, int cin0, long long xPlane, float* y, long 
     // once, reads the word when it likes and resets it then): an error of any launch since the last look stays visible
     // (trunk_pack_input_kernel zeroes the counters; the 16-byte zero unit in front of them is never written)
     static bool attr = false;
-    if (!attr) { (void)hipFuncSetAttribute((const void*)trunk_dataflow_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, T16_LDS_BYTES); attr = true; }
+    if (!attr) {
+        (void)hipFuncSetAttribute((const void*)trunk_dataflow_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, T16_LDS_BYTES);
+        (void)hipFuncSetAttribute((const void*)trunk_dataflow_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, T16_LDS_BYTES);
+        attr = true;
+    }
+    const bool diag = p.dbg != 0 || p.stamps != nullptr;
     const int npix = H * W;
     hipLaunchKernelGGL(trunk_pack_input_kernel, dim3((unsigned)((npix + 255) / 256), (unsigned)(lay.groups0 > 8 ? lay.groups0 : 8)), dim3(256), 0, s,
                        x, cin0, xPlane, npix, xps, lay.groups0, (u32x4*)(ws + lay.fps), (u32x4*)(ws + lay.tps), p.done, ntiles);
     hipEvent_t e0 = nullptr, e1 = nullptr;
     isr_profile_record(ISR_VARIANT_SPLIT_TRUNK, 2.0 * 9 * 64 * ((double)cin0 + 2.0 * nblocks * 64) * (double)H * W, &e0, &e1);
     const dim3 grid((unsigned)(((ntiles + 7) / 8) * 8)), block(T16_THREADS);
-    if (e0 || e1) hipExtLaunchKernelGGL(trunk_dataflow_kernel, grid, block, T16_LDS_BYTES, s, e0, e1, 0, p);
-    else hipLaunchKernelGGL(trunk_dataflow_kernel, grid, block, T16_LDS_BYTES, s, p);
+    if (diag) {
+        if (e0 || e1) hipExtLaunchKernelGGL(trunk_dataflow_kernel<true>, grid, block, T16_LDS_BYTES, s, e0, e1, 0, p);
+        else hipLaunchKernelGGL(trunk_dataflow_kernel<true>, grid, block, T16_LDS_BYTES, s, p);
+    } else if (e0 || e1) hipExtLaunchKernelGGL(trunk_dataflow_kernel<false>, grid, block, T16_LDS_BYTES, s, e0, e1, 0, p);
+    else hipLaunchKernelGGL(trunk_dataflow_kernel<false>, grid, block, T16_LDS_BYTES, s, p);
     return hipGetLastError() == hipSuccess ? 0 : -2;
 }
 

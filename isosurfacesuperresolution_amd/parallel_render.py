@@ -13,6 +13,8 @@ leaf's own span (``CPURenderer/IsoVolumeRayTracer.h:37-46``), so what happens in
 depend on which other leaves exist; the tile that owns the first leaf with a crossing therefore computes
 exactly the unsplit pixel, every other tile a later hit or none, and the minimum depth selects it.
 """
+import time
+
 import numpy as np
 import torch
 import torch.distributed as dist
@@ -192,3 +194,100 @@ class TiledRenderer:
         r.ao_finish(d, local)
         torch.cuda.synchronize()
         return local
+
+
+class PrefetchedComposite:
+    """The composited G-buffer of frame t + 1 produced on a side HIP stream -- this rank's ray-march, the all-gather, the
+    nearest-hit composite -- while the caller's stream super-resolves frame t (the frame pipeline's render(t+1) || SR(t),
+    ``pipeline.py``, for the tiled path).  A frame's image does not depend on the previous frame's network output, only on the
+    camera path, so the order of results is unchanged: ``take(key)`` returns exactly what the serial sequence returns.
+
+    ``render_fn(tensor[H,W,12], key, stream)`` enqueues the local render of frame ``key`` on ``stream`` (None on the CPU).
+    Collectives: the all-gather is issued from the side stream through the SAME process group as every other collective of the
+    job; torch's group runs its collectives on one internal stream in the order the host issued them, and this class issues
+    them at the same point of the frame on every rank, so the two all-gathers of a frame (G-buffers of t + 1, strips of t) are
+    totally ordered and identical on all ranks -- no second communicator, nothing that can interleave differently per rank.
+    On a CPU device (gloo rehearsals) everything runs in the caller's thread, one step after the other."""
+
+    def __init__(self, render_fn, height, width, device, process_group=None):
+        self.render_fn = render_fn
+        self.group = process_group
+        self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
+        self.device = torch.device(device)
+        self.cuda = self.device.type == "cuda"
+        self.local = torch.empty((height, width, 12), dtype=torch.float32, device=device)
+        self.gathered = torch.empty((self.world, height, width, 12), dtype=torch.float32, device=device)
+        self.slots = [torch.empty((height, width, 12), dtype=torch.float32, device=device) for _ in range(2)]
+        self.side = torch.cuda.Stream(device=self.device) if self.cuda else None
+        self.ready = [None, None]          # per slot: event on the side stream when the composite is complete
+        self.free = [None, None]           # per slot: event on the consumer's stream after which the slot may be overwritten
+        self.keys = [None, None]
+        self.turn = 0                      # the slot the next start() fills
+        self.taken = None
+        self.timeline = None               # list of (e0, e1, e2, e3) event tuples while record(True)
+
+    def record(self, on):
+        self.timeline = [] if on else None
+
+    def _produce(self, key, slot, stream):
+        if self.timeline is None:
+            ev = lambda: None
+        elif self.cuda:
+            ev = lambda: stream.record_event(torch.cuda.Event(enable_timing=True))
+        else:
+            ev = time.perf_counter
+        e0 = ev()
+        self.render_fn(self.local, key, stream)
+        e1 = ev()
+        if self.world > 1:
+            dist.all_gather_into_tensor(self.gathered.view(self.world * self.local.shape[0], *self.local.shape[1:]), self.local, group=self.group)
+        else:
+            self.gathered[0].copy_(self.local)
+        e2 = ev()
+        self.slots[slot].copy_(composite(self.gathered))
+        e3 = ev()
+        if e0 is not None:
+            self.timeline.append((e0, e1, e2, e3))
+
+    def start(self, key, after_current=True):
+        """Enqueue frame ``key``.  ``after_current``: the side stream first waits for what the caller's stream holds now (the
+        frame pipeline's release point: "when the trunk has ended")."""
+        if key in self.keys:
+            return
+        slot = self.turn
+        self.turn ^= 1
+        self.keys[slot] = key
+        if not self.cuda:
+            self._produce(key, slot, None)
+            return
+        cur = torch.cuda.current_stream(self.device)
+        if after_current:
+            self.side.wait_stream(cur)
+        if self.free[slot] is not None:
+            self.side.wait_event(self.free[slot])
+        with torch.cuda.stream(self.side):
+            self._produce(key, slot, self.side)
+            self.ready[slot] = self.side.record_event()
+
+    def take(self, key):
+        """The composite of frame ``key`` (started earlier, or now); the caller's stream waits for it.  The tensor stays valid until
+        the second ``take`` after this one."""
+        if self.cuda and self.taken is not None:
+            self.free[self.taken] = torch.cuda.current_stream(self.device).record_event()      # the previous frame's consumer is enqueued
+        if key not in self.keys:
+            self.start(key, after_current=True)            # nothing ahead: the serial order, after everything enqueued so far
+        slot = self.keys.index(key)
+        if self.cuda:
+            torch.cuda.current_stream(self.device).wait_event(self.ready[slot])
+        self.taken = slot
+        return self.slots[slot]
+
+    def phase_ms(self):
+        """Summed (render, all-gather, composite) milliseconds of the recorded frames (after a device synchronisation)."""
+        out = [0.0, 0.0, 0.0]
+        for e0, e1, e2, e3 in self.timeline or ():
+            if self.cuda:
+                out[0] += e0.elapsed_time(e1); out[1] += e1.elapsed_time(e2); out[2] += e2.elapsed_time(e3)
+            else:
+                out[0] += (e1 - e0) * 1e3; out[1] += (e2 - e1) * 1e3; out[2] += (e3 - e2) * 1e3
+        return out

@@ -68,9 +68,10 @@ class StripSuperResolution:
         return torch.cat((inp, VideoTools.flatten_high(warped, self.upscale)), dim=1)
 
     # -- step 2 (this rank's rows) -----------------------------------------------------------------------------
-    def compute_strip(self, x, rank=None, world=None):
+    def compute_strip(self, x, rank=None, world=None, after_trunk=None):
         """Network + post-processing on the strip of ``rank`` (default: this process).  x: full-frame network input.
-        Returns (raw [1,6,u*rows,u*W], rgb [1,3,u*rows,u*W]) for the strip's own rows (halo cropped)."""
+        Returns (raw [1,6,u*rows,u*W], rgb [1,3,u*rows,u*W]) for the strip's own rows (halo cropped).
+        ``after_trunk``: called once when the low-resolution trunk is enqueued (``parallel_render.PrefetchedComposite.start``)."""
         rank = self.rank if rank is None else rank
         world = self.world if world is None else world
         h = x.shape[2]
@@ -86,7 +87,7 @@ class StripSuperResolution:
             # unsplit frame (tests/test_conv_gpu.py)
             xs = xs if (e0 == 0 and e1 == h) else xs.contiguous()
             ops.guards_poll(xs.device)                     # the previous frame's guard words (pipeline.frame_fused)
-            raw, rgb = run_network(self.model, self.shading, xs)
+            raw, rgb = run_network(self.model, self.shading, xs, after_trunk=after_trunk)
             if ops.range_check_due(xs.device):
                 for _ in range(4):                         # range guard, first frame: a hot layer reroutes its consumers; recompute
                     if not ops.refresh_range_flags(xs.device):
@@ -96,6 +97,8 @@ class StripSuperResolution:
             a, b = (y0 - e0) * u, (y1 - e0) * u
             return raw[:, :, a:b], rgb[:, :, a:b]
         raw, _ = net._recon_image(xs, net.forward_features(xs))
+        if after_trunk is not None:
+            after_trunk()
         raw = torch.cat([torch.clamp(raw[:, 0:1], -1, +1),
                          ScreenSpaceShading.normalize(raw[:, 1:4], dim=1),
                          torch.clamp(raw[:, 4:], 0, 1)], dim=1)
@@ -104,12 +107,12 @@ class StripSuperResolution:
         return raw, self.shading(raw)
 
     # -- step 3 ------------------------------------------------------------------------------------------------
-    def frame(self, gbuffer):
+    def frame(self, gbuffer, after_trunk=None):
         """gbuffer: the full low-resolution G-buffer [H, W, 12], identical on every rank (a replicated render or
         the composite of ``parallel_render.TiledRenderer``).  Returns (rgb, raw) of the full frame on every rank."""
         with torch.no_grad():
             x = self.network_input(gbuffer)
-            raw, rgb = self.compute_strip(x)
+            raw, rgb = self.compute_strip(x, after_trunk=after_trunk)
             if self.world > 1:
                 h, w, u = gbuffer.shape[0], gbuffer.shape[1], self.upscale
                 rows = [strip_bounds(h, self.world, r) for r in range(self.world)]

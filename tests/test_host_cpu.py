@@ -644,3 +644,32 @@ def test_flat_adam_checkpoint_restore_continues_like_an_uninterrupted_run(tmp_pa
     assert not od.views_intact()
     od.rebind().check_views()
     assert all(torch.equal(a, b) for a, b in zip(w, net_d.parameters())) and torch.equal(m, od.exp_avg) and float(od.steps.item()) == 1.0
+
+
+def test_prefetched_composite_hands_out_frames_in_request_order_on_the_cpu():
+    """parallel_render.PrefetchedComposite without a GPU: start / take bookkeeping (two slots, a frame started ahead is the
+    one taken, a frame never started is produced on demand), composite == parallel_render.composite of the same buffers."""
+    import torch
+    from isosurfacesuperresolution_amd import parallel_render as PR
+    calls = []
+
+    def render_fn(tensor, key, stream):
+        assert stream is None
+        calls.append(key)
+        g = torch.Generator().manual_seed(100 + key)
+        tensor.copy_(torch.rand(tensor.shape, generator=g))
+        tensor[..., 3] = (tensor[..., 3] > 0.5).float()
+
+    src = PR.PrefetchedComposite(render_fn, 6, 8, "cpu")
+    src.record(True)
+    a = src.take(0).clone()
+    src.start(1)
+    src.start(1)                                   # a second request for a frame in flight is a no-op
+    b = src.take(1).clone()
+    c = src.take(5).clone()                        # never started: produced now
+    assert calls == [0, 1, 5]
+    for key, got in ((0, a), (1, b), (5, c)):
+        ref = torch.empty(6, 8, 12)
+        render_fn(ref, key, None)
+        assert torch.equal(got, PR.composite(ref.unsqueeze(0)))
+    assert len(src.timeline) == 3 and all(v >= 0 for v in src.phase_ms())

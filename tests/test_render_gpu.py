@@ -447,3 +447,49 @@ def test_discarded_prefetch_does_not_disturb_the_flow(renderer):
     assert renderer.gate_resident(s, 2000000) == 0
     torch.cuda.synchronize()
     assert time.perf_counter() - t0 < 0.5
+
+
+def test_prefetched_tiled_frames_equal_the_serial_sequence(renderer):
+    """parallel_render.PrefetchedComposite: render(t+1) + composite on a side stream, released from inside SR(t)
+    (StripSuperResolution.frame's after_trunk hook), gives the G-buffers AND the network outputs of the serial sequence
+    bit for bit -- flow channels included (the renders stay in camera order)."""
+    import argparse
+    import torch
+    from isosurfacesuperresolution_amd import models, parallel_render as PR, parallel_sr
+    from isosurfacesuperresolution_amd.inference import LoadedModel
+    from isosurfacesuperresolution_amd.pipeline import default_shading
+    vol = V.ejecta(128)
+    tile = PR.partition_volume(vol, (1, 1, 1))[0]
+    renderer.set_kernel_variant(0)
+    renderer.load_tile(tile)
+    W, H = 160, 96
+    for c, v in (("cameraLookAt", "0,0,0"), ("cameraUp", "0,1,0"), ("cameraFoV", "30.000"), ("isovalue", "0.340"), ("aosamples", "0"),
+                 ("resolution", "%d,%d" % (W, H)), ("viewport", "0,0,%d,%d" % (W, H))):
+        assert renderer.send_command(c, v) == 0
+    opt = argparse.Namespace(upsample='bilinear', reconType='residual', useBN=False, numResidualLayers=10)
+    torch.manual_seed(0)
+    net = models.createNetwork('EnhanceNet', 4, 101, [0, 1, 2, 3, 4], 6, opt)
+    lm = LoadedModel.from_model(net, "cuda", parameters={"initialImage": "zero"})
+
+    def render_fn(tensor, key, stream):
+        renderer.send_command("cameraOrigin", V.fmt3(V.orbit_camera(key)))
+        renderer.render_async(tensor, stream)
+
+    results = {}
+    for mode in ("serial", "ahead"):
+        renderer.send_command("cameraOrigin", V.fmt3(V.orbit_camera(-1)))
+        renderer.render_direct(torch.empty((H, W, 12), dtype=torch.float32, device="cuda"))       # the flow reference of frame 0
+        sr = parallel_sr.StripSuperResolution(lm, default_shading("cuda", 30.0))
+        src = PR.PrefetchedComposite(render_fn, H, W, "cuda")
+        frames = []
+        for k in range(5):
+            comp = src.take(k)
+            hook = (lambda kk=k: src.start(kk + 1)) if (mode == "ahead" and k < 4) else None
+            rgb, raw = sr.frame(comp, after_trunk=hook)
+            frames.append((comp.clone(), raw.clone(), rgb.clone()))
+        torch.cuda.synchronize()
+        results[mode] = frames
+    for k, (a, b) in enumerate(zip(results["serial"], results["ahead"])):
+        for x, y in zip(a, b):
+            assert torch.equal(x, y), "frame %d differs" % k
+    assert results["serial"][3][0][..., 3].sum() > 500 and results["serial"][3][0][..., 8:10].abs().max() > 0

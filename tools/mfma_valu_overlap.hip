@@ -8,11 +8,18 @@
 #include <cstdio>
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 #define MFMA(acc) acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, acc, 0, 0, 0)
 
 // MODE 0: NV vector instructions after every MFMA (interleaved); 1: 12 MFMAs, then 12 NV vector instructions (clumped);
-// 2: role split -- waves < 4 only multiply, waves >= 4 only do the vector work; 3: MFMAs only; 4: vector work only
+// 2: role split -- waves < 4 only multiply, waves >= 4 only do the vector work; 3: MFMAs only; 4: vector work only;
+// 5: role split with the vector waves at s_setprio 3; 6: clumped with s_setprio 3 around the clump;
+// 7: MFMAs only, but every MFMA on ANOTHER pair of operand registers (eight random fragments each side, as a convolution's taps
+//    are) instead of the same pair every time: what the data's toggling costs (power -> clock), nothing else differs from mode 3;
+// 8: as 7 with all sixteen fragments zero;
+// 9: as 7 on v_mfma_f32_16x16x32_f16 -- 24 of them per iteration, the same multiply-adds as 12 of the 32x32x16 (MI355X_MICROARCH.md,
+//    DVFS give-back (7): the chip holds a higher clock on that shape)
 template <int MODE, int NV>
 __global__ __launch_bounds__(512, 2) void k(float* out, const float* rnd, int iters, unsigned long long* clk)
 {
@@ -24,11 +31,33 @@ __global__ __launch_bounds__(512, 2) void k(float* out, const float* rnd, int it
     float x[8];
     for (int e = 0; e < 8; ++e) x[e] = rnd[1024 + lane + e];
     const float c0 = rnd[2000], c1 = rnd[2001];
-    const bool mm = MODE == 3 || (MODE == 2 ? wave < 4 : MODE != 4);
-    const bool vv = MODE == 4 || (MODE == 2 ? wave >= 4 : MODE != 3);
+    const bool split = MODE == 2 || MODE == 5;
+    const bool mm = MODE == 3 || (split ? wave < 4 : MODE != 4);
+    const bool vv = MODE == 4 || (split ? wave >= 4 : MODE != 3);
+    if (MODE == 5 && vv) __builtin_amdgcn_s_setprio(3);
+    f16x8 av[8], bv[8];
+    f32x4 acc4[16];
+    for (int i = 0; i < 16; ++i) for (int j = 0; j < 4; ++j) acc4[i][j] = 0.f;
+    if (MODE == 7 || MODE == 8 || MODE == 9) {
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                av[q][e] = MODE == 8 ? (_Float16)0.f : (_Float16)rnd[(lane * 8 + e + 97 * q) & 2047];
+                bv[q][e] = MODE == 8 ? (_Float16)0.f : (_Float16)rnd[(1024 + lane * 8 + e + 131 * q) & 2047];
+            }
+            asm volatile("" : "+v"(av[q]), "+v"(bv[q]));                     // in registers before the clock is read
+        }
+    }
     unsigned long long t0 = __builtin_amdgcn_s_memtime();
     for (int it = 0; it < iters; ++it) {
-        if (MODE == 0) {
+        if (MODE == 9) {
+#pragma unroll
+            for (int m = 0; m < 24; ++m) acc4[m & 15] = __builtin_amdgcn_mfma_f32_16x16x32_f16(av[(m * 5) & 7], bv[(m * 3) & 7], acc4[m & 15], 0, 0, 0);
+        } else if (MODE == 7 || MODE == 8) {
+#pragma unroll
+            for (int m = 0; m < 12; ++m) acc[m & 3] = __builtin_amdgcn_mfma_f32_32x32x16_f16(av[(m * 5) & 7], bv[(m * 3) & 7], acc[m & 3], 0, 0, 0);
+        } else if (MODE == 0) {
 #pragma unroll
             for (int m = 0; m < 12; ++m) {
                 MFMA(acc[m & 3]);
@@ -47,8 +76,10 @@ __global__ __launch_bounds__(512, 2) void k(float* out, const float* rnd, int it
             }
             __builtin_amdgcn_sched_barrier(0);
             if (vv) {
+                if (MODE == 6) __builtin_amdgcn_s_setprio(3);
 #pragma unroll
                 for (int v = 0; v < 12 * NV; ++v) x[v & 7] = __builtin_fmaf(x[v & 7], c0, c1);
+                if (MODE == 6) __builtin_amdgcn_s_setprio(0);
             }
             __builtin_amdgcn_sched_barrier(0);
         }
@@ -57,6 +88,7 @@ __global__ __launch_bounds__(512, 2) void k(float* out, const float* rnd, int it
     float s = 0.f;
     for (int i = 0; i < 4; ++i) for (int j = 0; j < 16; ++j) s += acc[i][j];
     for (int e = 0; e < 8; ++e) s += x[e];
+    if (MODE == 9) for (int i = 0; i < 16; ++i) for (int j = 0; j < 4; ++j) s += acc4[i][j];
     out[blockIdx.x * blockDim.x + threadIdx.x] = s;
     if (threadIdx.x == 0 && blockIdx.x == 7) clk[0] = t1 - t0;
     if (threadIdx.x == 256 && blockIdx.x == 7) clk[1] = t1 - t0;
@@ -88,9 +120,13 @@ void sweep(float* out, float* rnd, unsigned long long* clk)
     run<0, NV>(out, rnd, clk, 512, 256, "2 waves/SIMD, each interleaved");
     run<1, NV>(out, rnd, clk, 512, 256, "2 waves/SIMD, each clumped");
     run<2, NV>(out, rnd, clk, 512, 256, "2 waves/SIMD, role split (one multiplies, one does the vector work)");
+    run<5, NV>(out, rnd, clk, 512, 256, "2 waves/SIMD, role split, vector waves at s_setprio 3");
+    run<6, NV>(out, rnd, clk, 512, 256, "2 waves/SIMD, each clumped, s_setprio 3 around the clump");
     run<0, NV>(out, rnd, clk, 512, 512, "4 waves/SIMD (2 workgroups), each interleaved");
     run<1, NV>(out, rnd, clk, 512, 512, "4 waves/SIMD (2 workgroups), each clumped");
     run<2, NV>(out, rnd, clk, 512, 512, "4 waves/SIMD (2 workgroups), role split");
+    run<5, NV>(out, rnd, clk, 512, 512, "4 waves/SIMD (2 workgroups), role split, vector waves at s_setprio 3");
+    run<6, NV>(out, rnd, clk, 512, 512, "4 waves/SIMD (2 workgroups), each clumped, s_setprio 3 around the clump");
     run<4, NV>(out, rnd, clk, 256, 256, "1 wave/SIMD, the vector work alone");
 }
 
@@ -103,6 +139,13 @@ int main()
     hipMemcpy(rnd, h, sizeof(h), hipMemcpyHostToDevice);
     run<3, 0>(out, rnd, clk, 256, 256, "1 wave/SIMD, MFMAs alone");
     run<3, 0>(out, rnd, clk, 512, 256, "2 waves/SIMD, MFMAs alone");
+    run<7, 0>(out, rnd, clk, 256, 256, "1 wave/SIMD, MFMAs alone, operands rotating over 8 + 8 random fragments");
+    run<7, 0>(out, rnd, clk, 512, 256, "2 waves/SIMD, MFMAs alone, operands rotating over 8 + 8 random fragments");
+    run<8, 0>(out, rnd, clk, 512, 256, "2 waves/SIMD, MFMAs alone, operands rotating over 8 + 8 ZERO fragments");
+    run<9, 0>(out, rnd, clk, 256, 256, "1 wave/SIMD, 24 x 16x16x32 (= 12 x 32x32x16 of work), rotating random fragments");
+    run<9, 0>(out, rnd, clk, 512, 256, "2 waves/SIMD, 24 x 16x16x32 (= 12 x 32x32x16 of work), rotating random fragments");
+    run<7, 0>(out, rnd, clk, 512, 256, "2 waves/SIMD, MFMAs alone, operands rotating over 8 + 8 random fragments (again)");
+    run<9, 0>(out, rnd, clk, 512, 256, "2 waves/SIMD, 24 x 16x16x32, rotating random fragments (again)");
     sweep<2>(out, rnd, clk);
     sweep<4>(out, rnd, clk);
     sweep<6>(out, rnd, clk);
