@@ -227,6 +227,15 @@ int isrFlowFill(const float* gbuffer_hwc12, float* flow_out, void* workspace, in
  * launches then fit beside the SR network's conv workgroups when the fill of the NEXT frame runs on a side stream
  * (1024-thread workgroups evict conv workgroups from their CU and cost the network more than the fill takes). */
 int isrFlowFillEx(const float* gbuffer_hwc12, float* flow_out, void* workspace, int h, int w, int threads, void* stream);
+/* The same result (bit for bit) in ONE launch: a workgroup per 64 x 64 tile pulls its own part of levels 1 .. 6 in LDS, the workgroup
+ * that arrives last finishes the few cells above, every tile pushes back down on regions widened by the bilinear footprint
+ * (csrc/sr_frame.hip: flow_fill_one_kernel).  `workspace` (isrFlowFillWorkspace bytes) must have been ZERO-FILLED ONCE before its first
+ * use here (launch tickets live in it) and serves one stream at a time.  isrFlowFillOneSupported: images of at most 256 tiles (the
+ * workgroups wait for one another inside the launch); otherwise -1 and the caller uses isrFlowFillEx.  A workgroup that waited
+ * longer than 50 ms gives up and sets the error word (isrSetFlowFillErrorWord; default: a word of the workspace) -- never a hang. */
+int isrFlowFillOneSupported(int h, int w);
+int isrFlowFillOne(const float* gbuffer_hwc12, float* flow_out, void* workspace, int h, int w, void* stream);
+void isrSetFlowFillErrorWord(unsigned* word);
 
 /* End of one inference frame: raw[6][4h][4w] (EnhanceNet output before its residual reconstruction)
  * -> next_prev = cat(clamp(mask +- 1), normalize(normal), clamp(depth, ao in [0,1])) after

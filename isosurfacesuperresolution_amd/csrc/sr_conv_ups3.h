@@ -229,7 +229,7 @@ __global__ __launch_bounds__(S_THREADS, 3) void conv3x3_split_ups3_kernel(const 
 
     if (p.stamps) st2 = __builtin_amdgcn_s_memrealtime();
     if (p.ps) split_epilogue_ps(p, acc, oy0, ox0, 0, true, wave, j, h);
-    else split_epilogue(p, acc, patch, n, oy0, ox0, 0, true, lane, wave, j, h);
+    else split_epilogue<true>(p, acc, patch, n, oy0, ox0, 0, true, lane, wave, j, h);       // (the host sends other shapes to the two-per-CU kernel)
     if (p.stamps && tid == 0) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         const unsigned long long st3 = __builtin_amdgcn_s_memrealtime();
@@ -245,6 +245,9 @@ __global__ __launch_bounds__(S_THREADS, 3) void conv3x3_split_ups3_kernel(const 
 static int isr_launch_split_ups3(const SplitConvParams& p, unsigned nwg, hipStream_t s, hipEvent_t e0, hipEvent_t e1)
 {
     if (p.Cin <= 0 || (p.Cin & 15) || p.coutPad != 64 || p.Cout != 64 || p.cgroups != 1 || p.xps) return -1;
+    // the fp32 epilogue is compiled for quads only (split_epilogue<WIDE_ONLY>: the per-element path, 20 KB of compare-and-branch code
+    // per value, is not in this kernel)
+    if (!p.ps && ((p.W | p.yPlane | p.rPlane) & 3)) return -1;
     static bool attr = false;
     if (!attr) { (void)hipFuncSetAttribute((const void*)conv3x3_split_ups3_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, U3_LDS_BYTES); attr = true; }
     if (e0 || e1) hipExtLaunchKernelGGL(conv3x3_split_ups3_kernel, dim3(nwg), dim3(S_THREADS), U3_LDS_BYTES, s, e0, e1, 0, p);

@@ -158,6 +158,14 @@ __global__ __launch_bounds__(256) void finish_frame_kernel(const FinishParams p)
 // it level by level with __syncthreads() in between -- no inter-kernel gaps, no grid sync.
 struct FillLevel { int h, w; size_t off; };     // v: [2][h][w] at off, m: [h][w] at off + 2*h*w
 
+// hy (hx a + lx b) + ly (hx c + lx d) with the roundings spelled out, so that both forms of the fill (three launches / one) produce
+// the same bits whatever the optimiser would have contracted in either
+__device__ __forceinline__ float fill_bilerp(float hy, float hx, float ly, float lx, float a, float b, float c, float d)
+{
+    const float t0 = __builtin_fmaf(lx, b, hx * a), t1 = __builtin_fmaf(lx, d, hx * c);
+    return __builtin_fmaf(ly, t1, hy * t0);
+}
+
 // mode 0: pull level 0 -> 1 over the whole grid; mode 1: one workgroup pulls levels 2..n and pushes
 // back down to level 1; mode 2: push level 1 -> 0 over the whole grid (the two big levels are
 // bandwidth work for every CU, the small ones latency work for one).
@@ -168,6 +176,10 @@ __global__ __launch_bounds__(1024) void flow_fill_kernel(const float* __restrict
     __shared__ int nlev;
     const int tid = threadIdx.x;
     const int gtid = blockIdx.x * blockDim.x + tid, gstride = gridDim.x * blockDim.x;
+    if (mode == 3) {                                  // a 1 x 1 image is its own coarsest level: flow * valid (flowfill.py: levels[-1])
+        if (gtid == 0) { const bool known = gbuf[3] != 0.f; out[0] = known ? gbuf[8] : 0.f; out[1] = known ? gbuf[9] : 0.f; }
+        return;
+    }
     if (tid == 0) {
         int ch = h, cw = w, n = 0;
         size_t off = 0;
@@ -238,11 +250,267 @@ __global__ __launch_bounds__(1024) void flow_fill_kernel(const float* __restrict
                 src_index(y, sy_, ch, y0, y1, ly);
                 src_index(x, sx_, cw, x0, x1, lx);
                 const float hy = 1.f - ly, hx = 1.f - lx;
-                ox = hy * (hx * cv[y0 * cw + x0] + lx * cv[y0 * cw + x1]) + ly * (hx * cv[y1 * cw + x0] + lx * cv[y1 * cw + x1]);
+                ox = fill_bilerp(hy, hx, ly, lx, cv[y0 * cw + x0], cv[y0 * cw + x1], cv[y1 * cw + x0], cv[y1 * cw + x1]);
                 const float* c2 = cv + ch * cw;
-                oy = hy * (hx * c2[y0 * cw + x0] + lx * c2[y0 * cw + x1]) + ly * (hx * c2[y1 * cw + x0] + lx * c2[y1 * cw + x1]);
+                oy = fill_bilerp(hy, hx, ly, lx, c2[y0 * cw + x0], c2[y0 * cw + x1], c2[y1 * cw + x0], c2[y1 * cw + x1]);
             }
             fv[e] = ox; fv[fh * fw + e] = oy;
+        }
+        __syncthreads();
+    }
+}
+
+
+// ---- the same pyramid in ONE launch of one workgroup per 64 x 64 tile --------------------------------------------------------
+// The 2 x 2 pulls are aligned, so a 64 x 64 tile owns its part of levels 1 .. 6 outright: phase A pulls them in LDS (and writes them
+// to the workspace, where neighbours read their halos later).  What is left above level 6 is one value per tile: the workgroup that
+// arrives last (a ticket) pulls those few levels to 1 x 1 and pushes them back down to level 6 in LDS, then raises a flag.  Phase B
+// pushes from level 6 back to level 0 per tile, on regions that grow by the bilinear footprint at every coarser level (1 + half the
+// finer halo: 5 x 5 tiles' values at level 6, 34 x 34 at level 1), recomputing the halo instead of waiting for neighbours level by
+// level.  Per pixel and level the arithmetic is flow_fill_kernel's, expression for expression: the results are bit-identical.
+// Hand-off between workgroups (MI355X_MICROARCH.md, inter-workgroup visibility): agent-scope (sc1, write-through) stores, every wave
+// drains them, barrier, ONE lane takes the ticket / raises the flag; readers poll with agent-scope loads and load the handed-off
+// values with agent-scope loads.  Every workgroup must get a slot while others spin: the host refuses more than 256 tiles, and the
+// spin has a deadline on the 100 MHz clock -- a launch that runs into it reports through the error word and never hangs.
+constexpr int F1_TILE = 64, F1_LEVELS = 6, F1_THREADS = 256;
+constexpr int F1_TOP_MAX = 1024;                  // tiles (= cells of level 6) the last workgroup takes in LDS
+constexpr int F1_SMEM = 8192;                     // floats of LDS: phase A 3 x 1365, top 3 x ~1400, phase B 2 x 2444
+
+struct FillOneParams {
+    const float* gbuf; float* out; float* ws;     // as flow_fill_kernel
+    float* top;                                   // [2][tiles] filled values of the tiles' level (6, or the last if there are fewer)
+    unsigned* sync;                               // [0] ticket, [1] flag (launch epochs: both only ever grow; zero before the first launch)
+    unsigned* error;                              // set to 1 by a launch that gave up waiting
+    int h, w, tilesX, tilesY;
+    unsigned long long timeoutTicks;
+};
+
+__device__ __forceinline__ void st_agent(float* q, float v) { __hip_atomic_store(q, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ float ld_agent(const float* q) { return __hip_atomic_load(q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
+__global__ __launch_bounds__(F1_THREADS) void flow_fill_one_kernel(const FillOneParams p)
+{
+    __shared__ FillLevel lv[20];
+    __shared__ int nlev, s_last, s_ok;
+    __shared__ unsigned s_epoch;
+    __shared__ int offs[20];                       // last workgroup: LDS offset of level l
+    __shared__ int ya[F1_LEVELS + 1], yb[F1_LEVELS + 1], xa[F1_LEVELS + 1], xb[F1_LEVELS + 1], fo[F1_LEVELS + 2];     // phase B regions
+    __shared__ float smem[F1_SMEM];
+    const int tid = threadIdx.x;
+    const int tx = blockIdx.x % p.tilesX, ty = blockIdx.x / p.tilesX;
+    const int ntiles = p.tilesX * p.tilesY;
+    const int h = p.h, w = p.w;
+    if (tid == 0) {
+        int ch = h, cw = w, n = 0;
+        size_t off = 0;
+        lv[0].h = h; lv[0].w = w; lv[0].off = 0;
+        while (!(ch <= 1 && cw <= 1) && n < 18) {
+            ch = (ch + 1) / 2; cw = (cw + 1) / 2;
+            ++n;
+            lv[n].h = ch; lv[n].w = cw; lv[n].off = off;
+            off += (size_t)3 * ch * cw;
+        }
+        nlev = n;
+    }
+    __syncthreads();
+    const int L = nlev < F1_LEVELS ? nlev : F1_LEVELS;               // the tiles' own levels: 1 .. L
+
+    // ---- phase A: pull levels 1 .. L of this tile -------------------------------------------------------------------------------
+    {
+        int base = 0, pbase = 0;                                     // LDS: level l at smem[base ..]: vx | vy | m, side x side each
+        for (int l = 1; l <= L; ++l) {
+            const int side = F1_TILE >> l, pside = side * 2;
+            const int ph = lv[l - 1].h, pw = lv[l - 1].w, ch = lv[l].h, cw = lv[l].w;
+            float* const v = p.ws + lv[l].off;
+            float* const m = v + (size_t)2 * ch * cw;
+            float* const mine = smem + base;
+            const float* const prev = smem + pbase;
+            for (int e = tid; e < side * side; e += F1_THREADS) {
+                const int ly = e / side, lx = e - ly * side;
+                const int y = ty * side + ly, x = tx * side + lx;
+                float rx = 0.f, ry = 0.f, rm = 0.f;
+                if (y < ch && x < cw) {
+                    float sm = 0.f, sx = 0.f, sy = 0.f;
+#pragma unroll
+                    for (int dy = 0; dy < 2; ++dy)
+#pragma unroll
+                        for (int dx = 0; dx < 2; ++dx) {
+                            const int yy = 2 * y + dy, xx = 2 * x + dx;
+                            if (yy < ph && xx < pw) {
+                                if (l == 1) {
+                                    const float* g = p.gbuf + ((size_t)yy * pw + xx) * 12;
+                                    const float valid = g[3] != 0.f ? 1.f : 0.f;
+                                    sm += valid; sx += g[8] * valid; sy += g[9] * valid;
+                                } else {
+                                    const int q = (2 * ly + dy) * pside + 2 * lx + dx;
+                                    sm += prev[2 * pside * pside + q]; sx += prev[q]; sy += prev[pside * pside + q];
+                                }
+                            }
+                        }
+                    const float ms = sm * 0.25f, vx = sx * 0.25f, vy = sy * 0.25f;
+                    const float den = ms > 1e-12f ? ms : 1e-12f;
+                    rx = ms > 0.f ? vx / den : 0.f;
+                    ry = ms > 0.f ? vy / den : 0.f;
+                    rm = ms > 0.f ? 1.f : 0.f;
+                    const int ge = y * cw + x;
+                    st_agent(v + ge, rx); st_agent(v + ch * cw + ge, ry); st_agent(m + ge, rm);
+                }
+                mine[e] = rx; mine[side * side + e] = ry; mine[2 * side * side + e] = rm;
+            }
+            __syncthreads();
+            pbase = base; base += 3 * side * side;
+        }
+    }
+    // ---- ticket: the last workgroup finishes the pyramid above level L ---------------------------------------------------------
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (tid == 0) {
+        const unsigned old = __hip_atomic_fetch_add(p.sync, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        s_epoch = old / (unsigned)ntiles + 1u;
+        s_last = (old % (unsigned)ntiles) == (unsigned)(ntiles - 1);
+    }
+    __syncthreads();
+    const unsigned epoch = s_epoch;
+    if (s_last) {
+        // levels L .. nlev in LDS: level l at tl[toff(l) ..]: vx | vy | m, lv[l].h x lv[l].w each
+        float* const tl = smem;
+        if (tid == 0) {
+            int o = 0;
+            for (int l = L; l <= nlev; ++l) { offs[l] = o; o += 3 * lv[l].h * lv[l].w; }
+        }
+        __syncthreads();
+        {
+            const int ch = lv[L].h, cw = lv[L].w, cells = ch * cw;
+            const float* const v = p.ws + lv[L].off;
+            for (int e = tid; e < 3 * cells; e += F1_THREADS) tl[offs[L] + e] = ld_agent(v + e);      // vx | vy | m are contiguous in the workspace too
+        }
+        __syncthreads();
+        for (int l = L + 1; l <= nlev; ++l) {
+            const int ph = lv[l - 1].h, pw = lv[l - 1].w, ch = lv[l].h, cw = lv[l].w;
+            float* const v = tl + offs[l];
+            float* const m = v + 2 * ch * cw;
+            const float* const pv = tl + offs[l - 1];
+            const float* const pm = pv + 2 * ph * pw;
+            for (int e = tid; e < ch * cw; e += F1_THREADS) {
+                const int y = e / cw, x = e - y * cw;
+                float sm = 0.f, sx = 0.f, sy = 0.f;
+#pragma unroll
+                for (int dy = 0; dy < 2; ++dy)
+#pragma unroll
+                    for (int dx = 0; dx < 2; ++dx) {
+                        const int yy = 2 * y + dy, xx = 2 * x + dx;
+                        if (yy < ph && xx < pw) { sm += pm[yy * pw + xx]; sx += pv[yy * pw + xx]; sy += pv[ph * pw + yy * pw + xx]; }
+                    }
+                const float ms = sm * 0.25f, vx = sx * 0.25f, vy = sy * 0.25f;
+                const float den = ms > 1e-12f ? ms : 1e-12f;
+                v[e] = ms > 0.f ? vx / den : 0.f;
+                v[ch * cw + e] = ms > 0.f ? vy / den : 0.f;
+                m[e] = ms > 0.f ? 1.f : 0.f;
+            }
+            __syncthreads();
+        }
+        for (int l = nlev - 1; l >= L; --l) {
+            const int fh = lv[l].h, fw = lv[l].w, ch = lv[l + 1].h, cw = lv[l + 1].w;
+            const float* const cv = tl + offs[l + 1];
+            float* const fv = tl + offs[l];
+            const float* const fm = fv + 2 * fh * fw;
+            const float sy_ = (float)ch / (float)fh, sx_ = (float)cw / (float)fw;
+            for (int e = tid; e < fh * fw; e += F1_THREADS) {
+                const int y = e / fw, x = e - y * fw;
+                const bool known = fm[e] > 0.f;
+                float ox = fv[e], oy = fv[fh * fw + e];
+                if (!known) {
+                    int y0, y1, x0, x1; float ly, lx;
+                    src_index(y, sy_, ch, y0, y1, ly);
+                    src_index(x, sx_, cw, x0, x1, lx);
+                    const float hy = 1.f - ly, hx = 1.f - lx;
+                    ox = fill_bilerp(hy, hx, ly, lx, cv[y0 * cw + x0], cv[y0 * cw + x1], cv[y1 * cw + x0], cv[y1 * cw + x1]);
+                    const float* c2 = cv + ch * cw;
+                    oy = fill_bilerp(hy, hx, ly, lx, c2[y0 * cw + x0], c2[y0 * cw + x1], c2[y1 * cw + x0], c2[y1 * cw + x1]);
+                }
+                fv[e] = ox; fv[fh * fw + e] = oy;
+            }
+            __syncthreads();
+        }
+        {
+            const int cells = lv[L].h * lv[L].w;
+            for (int e = tid; e < 2 * cells; e += F1_THREADS) st_agent(p.top + e, tl[offs[L] + e]);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (tid == 0) __hip_atomic_store(p.sync + 1, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    // ---- everyone: wait for the top of the pyramid ---------------------------------------------------------------------------
+    if (tid == 0) {
+        const unsigned long long deadline = __builtin_amdgcn_s_memrealtime() + p.timeoutTicks;
+        int ok = 1;
+        while ((int)(__hip_atomic_load(p.sync + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - epoch) < 0) {
+            __builtin_amdgcn_s_sleep(4);
+            if (__builtin_amdgcn_s_memrealtime() > deadline) { ok = 0; break; }
+        }
+        s_ok = ok;
+    }
+    __syncthreads();
+    if (!s_ok) {
+        if (tid == 0) atomicMax(p.error, 1u);
+        return;
+    }
+    // ---- phase B: push level L -> 0 on this tile's regions ----------------------------------------------------------------------
+    if (tid == 0) {
+        ya[0] = ty * F1_TILE; yb[0] = min(h, ya[0] + F1_TILE);
+        xa[0] = tx * F1_TILE; xb[0] = min(w, xa[0] + F1_TILE);
+        fo[1] = 0;
+        for (int l = 0; l < L; ++l) {
+            ya[l + 1] = max(0, (ya[l] >> 1) - 1); yb[l + 1] = min(lv[l + 1].h, ((yb[l] + 1) >> 1) + 1);
+            xa[l + 1] = max(0, (xa[l] >> 1) - 1); xb[l + 1] = min(lv[l + 1].w, ((xb[l] + 1) >> 1) + 1);
+            fo[l + 2] = fo[l + 1] + 2 * (yb[l + 1] - ya[l + 1]) * (xb[l + 1] - xa[l + 1]);  // level l + 1 at smem[fo[l + 1] ..]: vx | vy
+        }
+    }
+    __syncthreads();
+    {   // level L on its region: the last workgroup's values
+        const int rh = yb[L] - ya[L], rw = xb[L] - xa[L], cw = lv[L].w, cells = lv[L].h * lv[L].w;
+        float* const f = smem + fo[L];
+        for (int e = tid; e < rh * rw; e += F1_THREADS) {
+            const int ry = e / rw, rx = e - ry * rw;
+            const int ge = (ya[L] + ry) * cw + xa[L] + rx;
+            f[e] = ld_agent(p.top + ge); f[rh * rw + e] = ld_agent(p.top + cells + ge);
+        }
+    }
+    __syncthreads();
+    for (int l = L - 1; l >= 0; --l) {
+        const int fh = lv[l].h, fw = lv[l].w, ch = lv[l + 1].h, cw = lv[l + 1].w;
+        const int rh = yb[l] - ya[l], rw = xb[l] - xa[l];
+        const int crh = yb[l + 1] - ya[l + 1], crw = xb[l + 1] - xa[l + 1];
+        const float* const cvx = smem + fo[l + 1];
+        const float* const cvy = cvx + crh * crw;
+        float* const f = l == 0 ? nullptr : smem + fo[l];
+        const float* const pv = p.ws + lv[l].off;                       // (l > 0) the pulled values of this level: vx | vy | m
+        const float sy_ = (float)ch / (float)fh, sx_ = (float)cw / (float)fw;
+        for (int e = tid; e < rh * rw; e += F1_THREADS) {
+            const int ry = e / rw, rx = e - ry * rw;
+            const int y = ya[l] + ry, x = xa[l] + rx;
+            const int ge = y * fw + x;
+            bool known; float kx, ky;
+            if (l == 0) {
+                const float* g = p.gbuf + (size_t)ge * 12;
+                known = g[3] != 0.f; kx = g[8]; ky = g[9];
+            } else {
+                known = ld_agent(pv + 2 * fh * fw + ge) > 0.f; kx = ld_agent(pv + ge); ky = ld_agent(pv + fh * fw + ge);
+            }
+            float ox = kx, oy = ky;
+            if (!known) {
+                int y0, y1, x0, x1; float ly, lx;
+                src_index(y, sy_, ch, y0, y1, ly);
+                src_index(x, sx_, cw, x0, x1, lx);
+                const float hy = 1.f - ly, hx = 1.f - lx;
+                // (inside the region by construction; the clamps keep a mistake in that from reading outside the LDS image)
+                const int r0 = min(max(y0 - ya[l + 1], 0), crh - 1) * crw, r1 = min(max(y1 - ya[l + 1], 0), crh - 1) * crw;
+                const int c0 = min(max(x0 - xa[l + 1], 0), crw - 1), c1 = min(max(x1 - xa[l + 1], 0), crw - 1);
+                ox = fill_bilerp(hy, hx, ly, lx, cvx[r0 + c0], cvx[r0 + c1], cvx[r1 + c0], cvx[r1 + c1]);
+                oy = fill_bilerp(hy, hx, ly, lx, cvy[r0 + c0], cvy[r0 + c1], cvy[r1 + c0], cvy[r1 + c1]);
+            }
+            if (l == 0) { p.out[ge] = ox; p.out[(size_t)fh * fw + ge] = oy; }
+            else { f[e] = ox; f[rh * rw + e] = oy; }
         }
         __syncthreads();
     }
@@ -267,7 +535,7 @@ long long isrFlowFillWorkspace(int h, int w)
 {
     long long floats = 0;
     while (!(h <= 1 && w <= 1)) { h = (h + 1) / 2; w = (w + 1) / 2; floats += 3LL * h * w; }
-    return (floats + 16) * (long long)sizeof(float);
+    return (floats + 16 + 2 * F1_TOP_MAX + 16) * (long long)sizeof(float);     // pyramid | spare | isrFlowFillOne: top values, sync words
 }
 
 int isrFlowFill(const float* gbuffer_hwc12, float* flow_out, void* workspace, int h, int w, void* stream)
@@ -282,11 +550,41 @@ int isrFlowFillEx(const float* gbuffer_hwc12, float* flow_out, void* workspace, 
     const int per = 4 * threads;
     const int big = (h * w + per - 1) / per;
     hipStream_t st = (hipStream_t)stream;
+    if (h == 1 && w == 1) {
+        hipLaunchKernelGGL(flow_fill_kernel, dim3(1), dim3(64), 0, st, gbuffer_hwc12, flow_out, (float*)workspace, h, w, 3);
+        return hipGetLastError() == hipSuccess ? 0 : -2;
+    }
     hipLaunchKernelGGL(flow_fill_kernel, dim3(big > 0 ? big : 1), dim3(threads), 0, st, gbuffer_hwc12, flow_out, (float*)workspace, h, w, 0);
     // the pyramid in between is ONE workgroup whatever `threads` says: 1024 threads on a single CU cost the network
     // nothing measurable and finish nine times sooner than 256
     hipLaunchKernelGGL(flow_fill_kernel, dim3(1), dim3(1024), 0, st, gbuffer_hwc12, flow_out, (float*)workspace, h, w, 1);
     hipLaunchKernelGGL(flow_fill_kernel, dim3(4 * big > 0 ? 4 * big : 1), dim3(threads), 0, st, gbuffer_hwc12, flow_out, (float*)workspace, h, w, 2);
+    return hipGetLastError() == hipSuccess ? 0 : -2;
+}
+
+static unsigned* g_fill_error_word = nullptr;
+void isrSetFlowFillErrorWord(unsigned* word) { g_fill_error_word = word; }
+
+int isrFlowFillOneSupported(int h, int w)
+{
+    if (h <= 0 || w <= 0 || (h == 1 && w == 1)) return 0;     // (a single pixel has no pyramid)
+    const long long tiles = (long long)((h + F1_TILE - 1) / F1_TILE) * ((w + F1_TILE - 1) / F1_TILE);
+    return tiles <= 256 ? 1 : 0;              // every workgroup must find a slot while others wait (and the top fits the LDS: F1_TOP_MAX)
+}
+
+int isrFlowFillOne(const float* gbuffer_hwc12, float* flow_out, void* workspace, int h, int w, void* stream)
+{
+    if (!gbuffer_hwc12 || !flow_out || !workspace || !isrFlowFillOneSupported(h, w)) return -1;
+    long long floats = 0;
+    for (int ch = h, cw = w; !(ch <= 1 && cw <= 1);) { ch = (ch + 1) / 2; cw = (cw + 1) / 2; floats += 3LL * ch * cw; }
+    FillOneParams p;
+    p.gbuf = gbuffer_hwc12; p.out = flow_out; p.ws = (float*)workspace;
+    p.h = h; p.w = w; p.tilesX = (w + F1_TILE - 1) / F1_TILE; p.tilesY = (h + F1_TILE - 1) / F1_TILE;
+    p.top = p.ws + floats + 16;
+    p.sync = reinterpret_cast<unsigned*>(p.top + 2 * F1_TOP_MAX);
+    p.error = g_fill_error_word ? g_fill_error_word : p.sync + 2;
+    p.timeoutTicks = 5000000ull;                  // 50 ms of the 100 MHz clock
+    hipLaunchKernelGGL(flow_fill_one_kernel, dim3(p.tilesX * p.tilesY), dim3(F1_THREADS), 0, (hipStream_t)stream, p);
     return hipGetLastError() == hipSuccess ? 0 : -2;
 }
 

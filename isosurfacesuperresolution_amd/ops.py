@@ -73,6 +73,9 @@ def _sr():
         lib.isrFlowFillWorkspace.argtypes = [ci, ci]; lib.isrFlowFillWorkspace.restype = ll
         lib.isrFlowFill.argtypes = [vp, vp, vp, ci, ci, vp]; lib.isrFlowFill.restype = ci
         lib.isrFlowFillEx.argtypes = [vp, vp, vp, ci, ci, ci, vp]; lib.isrFlowFillEx.restype = ci
+        lib.isrFlowFillOne.argtypes = [vp, vp, vp, ci, ci, vp]; lib.isrFlowFillOne.restype = ci
+        lib.isrFlowFillOneSupported.argtypes = [ci, ci]; lib.isrFlowFillOneSupported.restype = ci
+        lib.isrSetFlowFillErrorWord.argtypes = [vp]; lib.isrSetFlowFillErrorWord.restype = None
         lib.isrFinishFrame.argtypes = [vp, vp, vp, vp, ci, ci, vp, ci, cf, ci, ci, vp]; lib.isrFinishFrame.restype = ci
         lib.isrConvSmallFinishFrame.argtypes = [vp, vp, vp, vp, vp, vp, ci, ci, ci, ll, vp, ci, cf, ci, ci, vp]
         lib.isrConvSmallFinishFrame.restype = ci
@@ -413,6 +416,7 @@ RANGE_GUARD = True
 RANGE_LIMIT = 3.0e4
 _RANGE_SLOTS = 512
 _TRUNK_ERROR_SLOT = _RANGE_SLOTS - 1
+_FILL_ERROR_SLOT = _RANGE_SLOTS - 2       # ... and the word before it the one-launch flow fill's (``isrSetFlowFillErrorWord``), same rule
 HOT = "hot"                      # range key of a tensor of unknown / large range (e.g. produced by an exact kernel on the guarded path)
 _range = {}                      # device -> state, see _range_state
 
@@ -439,9 +443,9 @@ def _arm_range(key, device, members=None):
     st = _range_state(device)
     idx = st["slots"].get(key)
     if idx is None:
-        if len(st["slots"]) >= _TRUNK_ERROR_SLOT:
+        if len(st["slots"]) >= _FILL_ERROR_SLOT:
             _warn_once("range_slots", "range guard: all %d flag words are in use (models loaded without ops.range_reset()?); "
-                       "further layers' consumers run on the exact fp32 kernels" % _TRUNK_ERROR_SLOT)
+                       "further layers' consumers run on the exact fp32 kernels" % _FILL_ERROR_SLOT)
             return HOT
         idx = st["slots"][key] = len(st["slots"])
     if members is not None:
@@ -541,13 +545,15 @@ def guards_poll(device):
     err = int(words[_TRUNK_ERROR_SLOT])
     if err:
         _trunk_failed(st, err)
+    if int(words[_FILL_ERROR_SLOT]):
+        _fill_failed(st)
     return _mark_hot(st, words.view(torch.float32), conservative=True)
 
 
 def range_reset():
     """Forget every maximum, every hot producer and every producer's word (a new model was loaded)."""
     for st in _range.values():
-        st["buf"][:_TRUNK_ERROR_SLOT].zero_()
+        st["buf"][:_FILL_ERROR_SLOT].zero_()
         st["hot"].clear()
         st["slots"].clear()
         st["members"].clear()
@@ -1514,22 +1520,43 @@ def assemble_input(gbuffer_hwc, flow_filled, prev_high, initial_image="zero", ao
 _fill_ws = {}
 
 
-def fill_flow_gbuffer(gbuffer_hwc, out=None, stream=None, threads=1024):
-    """Hole-filled flow [1,2,h,w] straight from the renderer's G-buffer [h,w,12] (``isrFlowFill``).
-    ``out`` / ``stream``: caller-owned result tensor and HIP stream (the frame pipeline fills the flow of the next
-    frame on its render stream, with 256-thread workgroups that fit beside the conv kernels); the pyramid workspace
-    is per (device, size, stream)."""
+FLOW_FILL_ONE = os.environ.get("ISR_FLOW_FILL_ONE", "1") != "0"       # the push-pull pyramid as ONE launch (isrFlowFillOne) where it applies
+
+
+def _fill_failed(st):
+    global FLOW_FILL_ONE
+    st["buf"][_FILL_ERROR_SLOT] = 0
+    FLOW_FILL_ONE = False                       # whoever catches this goes on with the three-launch form
+    raise RuntimeError("flow_fill_one_kernel: a workgroup waited 50 ms for the top of the pyramid in a launch since the last look "
+                       "(that frame's filled flow is incomplete; is the device shared?).  The three-launch form is used from now on.")
+
+
+def fill_flow_gbuffer(gbuffer_hwc, out=None, stream=None, threads=1024, one_launch=None):
+    """Hole-filled flow [1,2,h,w] straight from the renderer's G-buffer [h,w,12] (``isrFlowFillOne``: one launch, a workgroup
+    per 64 x 64 tile; ``isrFlowFillEx``: three launches, for images of more than 256 tiles or ``one_launch=False`` /
+    ISR_FLOW_FILL_ONE=0 -- bit-identical).  ``out`` / ``stream``: caller-owned result tensor and HIP stream (the frame pipeline
+    fills the flow of the next frame on its render stream); the pyramid workspace is per (device, size, stream);
+    ``threads``: workgroup size of the three-launch form's two grid-wide passes."""
     lib = _sr()
     h, w = gbuffer_hwc.shape[0], gbuffer_hwc.shape[1]
     st = torch.cuda.current_stream() if stream is None else stream
     key = (gbuffer_hwc.device, h, w, st.cuda_stream)
     ws = _fill_ws.get(key)
     if ws is None:
-        ws = torch.empty(lib.isrFlowFillWorkspace(h, w), dtype=torch.uint8, device=gbuffer_hwc.device)
+        with torch.cuda.stream(st):             # zero-filled once, in stream order with its first use: the one-launch form's tickets live in it
+            ws = torch.zeros(lib.isrFlowFillWorkspace(h, w), dtype=torch.uint8, device=gbuffer_hwc.device)
         _fill_ws[key] = ws
     if out is None:
         out = torch.empty((1, 2, h, w), dtype=torch.float32, device=gbuffer_hwc.device)
-    rc = lib.isrFlowFillEx(_ptr(gbuffer_hwc), _ptr(out), _ptr(ws), h, w, int(threads), ctypes.c_void_p(st.cuda_stream))
+    one = FLOW_FILL_ONE if one_launch is None else one_launch
+    if one and lib.isrFlowFillOneSupported(h, w):
+        if RANGE_GUARD:
+            lib.isrSetFlowFillErrorWord(ctypes.c_void_p(_range_state(gbuffer_hwc.device)["buf"].data_ptr() + 4 * _FILL_ERROR_SLOT))
+        else:
+            lib.isrSetFlowFillErrorWord(None)
+        rc = lib.isrFlowFillOne(_ptr(gbuffer_hwc), _ptr(out), _ptr(ws), h, w, ctypes.c_void_p(st.cuda_stream))
+    else:
+        rc = lib.isrFlowFillEx(_ptr(gbuffer_hwc), _ptr(out), _ptr(ws), h, w, int(threads), ctypes.c_void_p(st.cuda_stream))
     if rc != 0:
         raise RuntimeError("isrFlowFill failed (%d)" % rc)
     return out
