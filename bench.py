@@ -355,10 +355,12 @@ def run_infer(args, job):
     for name in PMC_TRAFFIC_FILES:
         try:
             with open(os.path.join(ROOT, "profiles", name)) as f:
-                traffic = json.load(f)[dom_name]["traffic_bytes_per_launch"]
+                table = json.load(f)
+            key = dom_name if dom_name in table else next(k for k in table if k.startswith(dom_name + "<"))    # template arguments
+            traffic = table[key]["traffic_bytes_per_launch"]
             traffic_file = name
             break
-        except (OSError, KeyError, ValueError):
+        except (OSError, KeyError, ValueError, StopIteration):
             continue
     # Roofline of the dominant kernel.  `achieved` is always ALGORITHMIC: 2*9*Cin*Cout flops per output pixel.  The exact
     # kernels spend one fp32 MFMA multiply-accumulate per algorithmic one (peak 157.3); the split-operand kernels spend
@@ -396,6 +398,8 @@ def run_infer(args, job):
                      "peak_source": ("dense fp16 MFMA %.0f TFLOP/s / 3 matrix products per algorithmic multiply-accumulate" % MFMA_F16_PEAK_TFLOPS)
                                     if split else "fp32 MFMA",
                      "matrix_tflops_executed": achieved * (3.0 if split else 1.0),
+                     "sustained_clock_note": ("measured, not used for `peak`: a bare v_mfma_f32_32x32x16_f16 loop on changing random operands holds 1.45-1.65 GHz "
+                                              "of the 2.4 GHz `peak` is priced at (zeros: 2.13 GHz; profiles/r04_mfma_valu_overlap.txt, DESIGN 4.2g)") if split else None,
                      "traffic_source": ("profiles/%s (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, bytes per launch)" % traffic_file) if traffic else None,
                      "avg_launch_ms": dom_time / dom_launches * 1e3, "launches_per_frame": dom_launches / K,
                      "flops_per_launch": dom_flops / dom_launches},
