@@ -271,9 +271,10 @@ int isrConv3x3ForwardSplitFromPacked(const void* xps, const void* wq, const floa
  *   F = relu(conv3x3(x [cin0][H][W], w[0]) + b[0]);  nblocks times  F += conv3x3(relu(conv3x3(F, w[2k+1]) + b[2k+1]), w[2k+2]) + b[2k+2]
  * (models/enhancenet.py:92-112,136-141), split-operand arithmetic, bit-identical to the per-layer launches of
  * isrConv3x3ForwardSplit.  Workgroup w owns tile w of 16 x 32 pixels through all layers and starts a layer when its 3 x 3
- * neighbourhood has finished the previous one; every tile must be resident at once, one workgroup per CU: at most
- * isrTrunkDataflowMaxTiles() tiles (isrTrunkDataflowSupported says whether these tensors qualify; larger images use the per-layer
- * kernels).  Between the layers the activations live in the workspace in the packed-split format, the residual stream in registers.
+ * neighbourhood has finished the previous one; one workgroup per CU, all resident at once.  Up to isrTrunkDataflowMaxTiles() tiles a
+ * workgroup owns ONE tile (residual stream in registers, half of every hand-over through LDS); larger images (ISR_TRUNK_MT, default on)
+ * take trunk_mt_kernel: a workgroup owns every #CUs-th tile and keeps the residual stream in y.  isrTrunkDataflowSupported says whether
+ * these tensors qualify.  Between the layers the activations live in the workspace in the packed-split format.
  *   x: planes xPlane floats apart (rows contiguous); y (the result F): [64][H][W], planes `plane` floats apart;
  *   wq[l]: isrConvSplitPrepare images, bias[l]: [64] device or NULL, l = 0 .. 2 nblocks;
  *   workspace: isrTrunkDataflowWorkspaceBytes(cin0, H, W) bytes of device memory, 256-byte aligned, ZERO-FILLED by the caller before

@@ -44,6 +44,7 @@
 // Measured (tools/bench_trunk.py, tools/trunk_timeline.py; 480 x 270, 21 layers): 0.58-0.65 ms against 0.84 for the first form and
 // 0.83-1.15 for 21 launches.  Per layer ~29 us: MFMA phase 22 (the 108 x 4 MFMAs of a wave take 17 at the 1.6 GHz the chip holds
 // under this load -- 11 with operands read once, i.e. at full clock), epilogue 2.2, drain 1.4, wait 2.5, halo fetch 1.8.
+#include <cstdlib>
 #include <cstring>
 
 #include "sr_split_common.h"
@@ -106,6 +107,9 @@ typedef __attribute__((address_space(3))) char t16_lds_char;
 template <bool COHERENT = false>
 __device__ __forceinline__ void trunk16_dma16(const void* base, unsigned voff, unsigned ldsaddr)
 {
+    // (readfirstlane: a uniform address the compiler chose to compute on the vector side -- it multiplies the buffer index with a
+    // constant it holds in a vector register for the fragment addresses -- otherwise reaches the "s" operand as a VGPR)
+    ldsaddr = __builtin_amdgcn_readfirstlane(ldsaddr);
     if (COHERENT)
         asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2 sc1" :: "s"(ldsaddr), "v"(voff), "s"(base) : "m0");
     else
@@ -114,6 +118,7 @@ __device__ __forceinline__ void trunk16_dma16(const void* base, unsigned voff, u
 // ... and 64 floats (lane l's dword to ldsaddr + 4 l)
 __device__ __forceinline__ void trunk16_dma4(const void* base, unsigned voff, unsigned ldsaddr)
 {
+    ldsaddr = __builtin_amdgcn_readfirstlane(ldsaddr);
     asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dword %1, %2" :: "s"(ldsaddr), "v"(voff), "s"(base) : "m0");
 }
 #pragma clang diagnostic pop
@@ -491,6 +496,219 @@ __global__ __launch_bounds__(T16_THREADS) void trunk_dataflow_kernel(const Trunk
     isr_range_note(p.absmax, mag);
 }
 
+// ---- the same trunk for images of MORE tiles than CUs: trunk_mt_kernel ---------------------------------------------------------
+// One persistent workgroup per CU again, but workgroup g now owns tiles g, g + G, g + 2 G, ... (G workgroups) and walks
+// (layer 0: its tiles in order), (layer 1: its tiles), ...: at any time the G tiles in flight form a band of consecutive tile rows, the
+// neighbours a tile waits for are tiles of the SAME round of other workgroups one layer back, and the launch cannot lock up: a task
+// (layer l, tile t) waits only for tasks of layer l - 1, every workgroup runs its tasks in (layer, tile) order, so by induction over
+// l every task is reached.  Nothing of a tile stays in the CU between its layers, so
+//   * every k-step's whole 18 x 34 patch comes by LDS-DMA (no centre hand-over through LDS),
+//   * all 64 output channels go to memory packed-split (not just the ring and channels 32 .. 63),
+//   * the residual stream F lives in the RESULT tensor y (fp32): a block's second convolution reads y, adds and writes it back --
+//     the same fp32 values the one-tile form keeps in registers -- with agent-scope loads (the line may sit in this CU's L1 from
+//     the block before).
+// Same products, same order, same epilogue arithmetic as trunk_dataflow_kernel and the per-layer kernels: bit-identical output.
+// Per tile and layer ~29 us (MFMA phase 22 as the one-tile form, + the first k-step's staging exposed) against ~39 for the
+// per-layer launches of sr_conv_split.hip at 960 x 540.
+template <int KIND, bool LAST>
+__device__ __forceinline__ void trunk_mt_epilogue(const Trunk16Params& p, f32x16 (&acc)[2][2], unsigned& mag, float unscale, const float* biasl,
+                                                  const char* out, unsigned planeBytes, int oy0, int ox0, int wave, int j, int h)
+{
+    const rsrc_t prs = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(out), 0, (int)(16u * planeBytes), 0x00020000);
+    const rsrc_t yrs = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<char*>(p.y), 0, (int)((size_t)64 * p.yPlane * 4), 0x00020000);
+    const int ox = ox0 + j;
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+        const int oy = oy0 + wave * 2 + r;
+        const bool inside = oy < p.H && ox < p.W;
+        const unsigned voff = !inside ? BAD_OFFSET : (unsigned)(oy * p.W + ox) * 16u + 8u * (unsigned)h;
+        const unsigned yoff = !inside ? BAD_OFFSET : (unsigned)(oy * p.W + ox + 4 * h * p.yPlane) * 4u;
+        float fold[2][16];
+        if (KIND == 2) {                                                     // F of this lane's pixel: all 32 loads first, one latency
+#pragma unroll
+            for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+                for (int i = 0; i < 16; ++i)
+                    fold[cb][i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(yrs, (int)yoff, (cb * 32 + 8 * (i >> 2) + (i & 3)) * p.yPlane * 4, 16));
+        }
+#pragma unroll
+        for (int cb = 0; cb < 2; ++cb) {
+#pragma unroll
+            for (int gi = 0; gi < 4; ++gi) {
+                const float4 b4 = *reinterpret_cast<const float4*>(biasl + cb * 32 + 8 * gi + 4 * h);
+                const float bv[4] = {b4.x, b4.y, b4.z, b4.w};
+                f16x4 th, tl;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    float v = acc[cb][r][4 * gi + e] * unscale + bv[e];
+                    if (KIND != 2) v = v > 0.f ? v : 0.f;
+                    else v += fold[cb][4 * gi + e];
+                    if (inside) mag = isr_umax(mag, isr_mag(v));
+                    if (KIND != 1) __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), yrs, (int)yoff, (cb * 32 + 8 * gi + e) * p.yPlane * 4, LAST ? 0 : 16);
+                    _Float16 a, b;
+                    split16x(v, a, b);
+                    th[e] = a; tl[e] = b;
+                }
+                if (!LAST) {
+                    const int g = cb * 4 + gi;
+                    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, th), prs, (int)voff, g * planeBytes, 16);
+                    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, tl), prs, (int)voff, (8 + g) * planeBytes, 16);
+                }
+            }
+        }
+    }
+}
+
+__global__ __launch_bounds__(T16_THREADS) void trunk_mt_kernel(const Trunk16Params p)
+{
+    extern __shared__ u32x4 lds[];
+    u32x4* const pbuf0 = lds;
+    u32x4* const wbuf0 = lds + 2 * P16_UNITS;
+    float* const biasl0 = reinterpret_cast<float*>(lds + T16_LDS_UNITS);
+    int* const flags = reinterpret_cast<int*>(biasl0 + 128);
+    const unsigned ldsBase = (unsigned)(uintptr_t)(t16_lds_char*)lds;
+    const unsigned pAddr = ldsBase, wAddr = ldsBase + 2 * P16_UNITS * 16, bAddr = ldsBase + T16_LDS_UNITS * 16;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int j = lane & 31, h = lane >> 5;
+    const int ntiles = p.tilesX * p.tilesY;
+    const int nwg = gridDim.x;
+    int slot;
+    {   // an XCD (= an L2) gets a contiguous range of every round's tiles: neighbours share halo lines
+        const int q = nwg >> 3, r = nwg & 7, xcd = blockIdx.x & 7;
+        slot = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (blockIdx.x >> 3);
+    }
+    if (slot >= ntiles) return;
+    const unsigned long long deadline = __builtin_amdgcn_s_memrealtime() + p.timeoutTicks;
+    unsigned mag = 0u;
+    int gk = 0;
+    const char* const ws = trunk16_uniform(p.ws);
+    const unsigned planeBytes = (unsigned)p.plane * 16u;
+    const bool wrole = wave < 4;
+    const int rpart = (wave & 3) >> 1, rsel = wave & 1;
+    const unsigned wdstRole = (unsigned)(rpart * S_WPART + rsel * 64) * 16u;
+    const unsigned pdstRole = (unsigned)((rpart * 2 + rsel) * P16_PIX) * 16u;
+    const unsigned wlane = (unsigned)lane * 16u;
+    auto weight_tap = [&](int tap, const u32x4* image, int ksteps_, int ks, unsigned wbuf) {
+        trunk16_dma16(image + 1 + (size_t)(tap * ksteps_ + ks) * 256 + rpart * 128 + rsel * 64, wlane, wbuf + wdstRole + (unsigned)tap * 2048u);
+    };
+    auto patch_plane = [&](const char* tensor, int groups_, int ks) {
+        return tensor + (size_t)(rpart * groups_ + 2 * ks + rsel) * planeBytes;
+    };
+#pragma unroll 1
+    for (int l = 0; l < p.layers; ++l) {
+        const int kind = l == 0 ? 0 : (l & 1) ? 1 : 2;
+        const int groups = l == 0 ? p.groups0 : 8, ksteps = groups >> 1;
+        const char* const tin = ws + (l == 0 ? p.xpsOff : (l & 1) ? p.fpsOff : p.tpsOff);
+        const char* const tout = ws + ((l & 1) ? p.tpsOff : p.fpsOff);
+        const bool last = l + 1 == p.layers;
+        const u32x4* const wq = trunk16_uniform(p.wq[l]);
+        const float* const bias = trunk16_uniform(p.bias[l]);
+        const float unscale = reinterpret_cast<const float*>(wq)[1];
+        bool staged = false;                                                 // this tile's first k-step is on its way already (fetched under the previous tile's last)
+        Trunk16Lane lanes = trunk16_lane_setup(p, (slot / p.tilesX) * T16_H, (slot % p.tilesX) * T16_W, lane);
+#pragma unroll 1
+        for (int tile = slot; tile < ntiles; tile += nwg) {
+            const int tx = tile % p.tilesX, ty = tile / p.tilesX;
+            const int oy0 = ty * T16_H, ox0 = tx * T16_W;
+            const int tnext = tile + nwg;                                    // this workgroup's next tile of the layer
+            const int txn = tnext % p.tilesX, tyn = tnext / p.tilesX;
+            // ---- wait for the 3 x 3 neighbourhood (itself included: its own layer l - 1 wrote what this layer reads) to be there;
+            //      and look (without waiting) whether the NEXT tile's neighbourhood is there as well: then its first k-step travels
+            //      under this tile's last one instead of in front of its own ----------------------------------------------------
+            bool ahead = tnext < ntiles;
+            if (l > 0) {
+                if (tid == 0) { flags[0] = 0; flags[1] = 0; }
+                __syncthreads();
+                if (tid < 9) {
+                    const int ny = ty + tid / 3 - 1, nx = tx + tid % 3 - 1;
+                    if ((unsigned)ny < (unsigned)p.tilesY && (unsigned)nx < (unsigned)p.tilesX) {
+                        const unsigned* f = p.done + ny * p.tilesX + nx;
+                        while (__hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (unsigned)l) {
+                            __builtin_amdgcn_s_sleep(2);
+                            if (__builtin_amdgcn_s_memrealtime() > deadline) { flags[0] = 1; break; }
+                        }
+                    }
+                } else if (tid >= 64 && tid < 73 && ahead) {
+                    const int q = tid - 64, ny = tyn + q / 3 - 1, nx = txn + q % 3 - 1;
+                    if ((unsigned)ny < (unsigned)p.tilesY && (unsigned)nx < (unsigned)p.tilesX &&
+                        __hip_atomic_load(p.done + ny * p.tilesX + nx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (unsigned)l) flags[1] = 1;
+                }
+                __syncthreads();
+                if (flags[0]) {
+                    if (tid == 0) atomicMax(p.error, (unsigned)(1 + l));
+                    return;
+                }
+                ahead = ahead && !__builtin_amdgcn_readfirstlane(flags[1]);  // (provably uniform: the DMA addresses chosen under it stay scalar)
+            }
+            const Trunk16Lane lanesNext = trunk16_lane_setup(p, tyn * T16_H, txn * T16_W, lane);
+            // ---- the tile's first k-step: weights, bias (the layer's first tile), whole patch ------------------------------------
+            if (!staged) {
+                if (tile == slot && wave == T16_WAVES - 1) {
+                    if (bias) trunk16_dma4(bias, (unsigned)lane * 4u, bAddr);
+                    else biasl0[lane] = 0.0f;
+                }
+                if (wrole) {
+#pragma unroll
+                    for (int tap = 0; tap < 9; ++tap) weight_tap(tap, wq, ksteps, 0, wAddr + (unsigned)(gk & 1) * (S_WUNITS * 16));
+                } else {
+                    const char* const plane = patch_plane(tin, groups, 0);
+#pragma unroll
+                    for (int sub = 0; sub < P16_SUBS; ++sub) trunk16_patch_run<false>(sub, plane, pAddr + (unsigned)(gk & 1) * (P16_UNITS * 16) + pdstRole, lanes);
+                }
+            }
+            f32x16 acc[2][2];
+#pragma unroll
+            for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+                for (int r = 0; r < 2; ++r)
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) acc[cb][r][i] = 0.0f;
+#pragma unroll 1
+            for (int ks = 0; ks < ksteps; ++ks, ++gk) {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __syncthreads();
+                const int cur = gk & 1, nxt = cur ^ 1;
+                const u32x4* const pcur = pbuf0 + cur * P16_UNITS;
+                const u32x4* const wcur = wbuf0 + cur * S_WUNITS;
+                const unsigned pnxt = pAddr + (unsigned)nxt * (P16_UNITS * 16), wnxt = wAddr + (unsigned)nxt * (S_WUNITS * 16);
+                const bool more = ks + 1 < ksteps;
+                const char* const pplane = patch_plane(tin, groups, more ? ks + 1 : 0);
+                auto between = [&](int tap) {
+                    if (more) {
+                        if (wrole) weight_tap(tap, wq, ksteps, ks + 1, wnxt);
+                        else {
+                            trunk16_patch_run<false>(tap, pplane, pnxt + pdstRole, lanes);
+                            if (tap == 8) trunk16_patch_run<false>(9, pplane, pnxt + pdstRole, lanes);
+                        }
+                    } else if (ahead) {                                        // the next tile's first k-step (same layer: same weights image, same bias)
+                        if (wrole) weight_tap(tap, wq, ksteps, 0, wnxt);
+                        else {
+                            trunk16_patch_run<false>(tap, pplane, pnxt + pdstRole, lanesNext);
+                            if (tap == 8) trunk16_patch_run<false>(9, pplane, pnxt + pdstRole, lanesNext);
+                        }
+                    }
+                };
+                trunk16_kstep(acc, wcur + h * 64 + j, pcur + h * P16_PIX + (wave * 2) * P16_W + j, between);
+            }
+            __syncthreads();                                                 // every wave is done with the last k-step's buffers (and the bias row is read below)
+            if (last) {
+                if (kind == 0) trunk_mt_epilogue<0, true>(p, acc, mag, unscale, biasl0, tout, planeBytes, oy0, ox0, wave, j, h);
+                else trunk_mt_epilogue<2, true>(p, acc, mag, unscale, biasl0, tout, planeBytes, oy0, ox0, wave, j, h);
+            } else if (kind == 0) trunk_mt_epilogue<0, false>(p, acc, mag, unscale, biasl0, tout, planeBytes, oy0, ox0, wave, j, h);
+            else if (kind == 1) trunk_mt_epilogue<1, false>(p, acc, mag, unscale, biasl0, tout, planeBytes, oy0, ox0, wave, j, h);
+            else trunk_mt_epilogue<2, false>(p, acc, mag, unscale, biasl0, tout, planeBytes, oy0, ox0, wave, j, h);
+            // ---- publish ----------------------------------------------------------------------------------------------------
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            if (tid == 0 && tile != p.faultTile) __hip_atomic_store(p.done + tile, (unsigned)(l + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            staged = ahead;
+            lanes = lanesNext;
+        }
+    }
+    isr_range_note(p.absmax, mag);
+}
+
 // x fp32 planes [cin][xPlane] -> packed-split [hi | lo][groups][npix + 1 units] (channels beyond cin are zero), and the zero unit
 // that ends every plane of the three packed-split tensors of the launch (the padding pixels of the LDS-DMA staging read it)
 __global__ __launch_bounds__(256) void trunk_pack_input_kernel(const float* __restrict__ x, int cin, long long xPlane, int npix, u32x4* __restrict__ ps,
@@ -555,7 +773,7 @@ void isrDebugSetTrunkAblation(int mask) { g_trunk_dbg = mask & 127; }
  * chip) at the layer's start | the neighbours' arrival | the first k-step staged | the MFMAs done | the epilogue done | the stores
  * drained (slot 1 stays 0 for the first layer). */
 void isrDebugSetTrunkStampBuffer(unsigned long long* stamps) { g_trunk_stamps = stamps; }
-int isrDebugTrunkState(void) { return g_trunk_dbg | ((g_trunk_fault_tile >= 0 || g_trunk_timeout_ticks != 5000000ull) ? 128 : 0) | (g_trunk_stamps ? 256 : 0); }
+int isrDebugTrunkState(void);
 /* Tests of the timeout path: tile `tile` (>= 0) never publishes its progress, so its neighbours' waits run into the deadline, which
  * is `timeoutTicks` of the 100 MHz clock after the kernel's start (0: the default 50 ms); tile < 0 switches the fault off.  The launch
  * then ends with the error word set BY THE KERNEL and an incomplete output. */
@@ -567,6 +785,15 @@ void isrDebugSetTrunkFault(int tile, unsigned long long timeoutTicks)
 /* Where every later isrTrunkDataflow launch reports a timed-out wait (atomic maximum of 1 + layer; sticky until the caller clears
  * it): a device word the caller mirrors to the host once per frame (ops.guards_publish), or NULL for the workspace's own word. */
 void isrSetTrunkErrorWord(unsigned* word) { g_trunk_error_word = word; }
+
+// ISR_TRUNK_MT: 1 (default) images of more tiles than CUs take trunk_mt_kernel; 0 they are refused (per-layer kernels); 2 every image
+// takes it (A/B against the one-tile form)
+static int g_trunk_mt = getenv("ISR_TRUNK_MT") ? atoi(getenv("ISR_TRUNK_MT")) : 1;
+void isrDebugSetTrunkMultiTile(int mode) { g_trunk_mt = mode; }
+int isrDebugTrunkState(void)
+{
+    return g_trunk_dbg | ((g_trunk_fault_tile >= 0 || g_trunk_timeout_ticks != 5000000ull) ? 128 : 0) | (g_trunk_stamps ? 256 : 0) | (g_trunk_mt != 1 ? 512 : 0);
+}
 
 int isrTrunkDataflowMaxTiles(void)
 {
@@ -587,7 +814,8 @@ int isrTrunkDataflowSupported(const float* x, int cin0, int H, int W, long long 
     if (!x || H <= 0 || W <= 0 || cin0 <= 0 || cin0 > 1024) return 0;
     if (xPlane < (long long)H * W || plane < (long long)H * W || plane * 64 * 4 > 0x7fffffffLL) return 0;
     if (trunk16_layout(cin0, H, W).total > 0xffffffffLL || ((long long)H * W + 8) * 16 * 16 > 0x7fffffffLL) return 0;   // 32-bit offsets into the workspace
-    return ((W + T16_W - 1) / T16_W) * ((H + T16_H - 1) / T16_H) <= isrTrunkDataflowMaxTiles() ? 1 : 0;
+    const long long tiles = (long long)((W + T16_W - 1) / T16_W) * ((H + T16_H - 1) / T16_H);
+    return (tiles <= isrTrunkDataflowMaxTiles() || (g_trunk_mt && tiles <= 65535)) ? 1 : 0;
 }
 
 /* x [cin0][H][W] -> y = F after: F = relu(conv(x, w[0]) + b[0]); nblocks times F += conv(relu(conv(F, w[2k+1]) + b[2k+1]), w[2k+2]) + b[2k+2]
@@ -626,6 +854,7 @@ int isrTrunkDataflow(const float* x, int cin0, long long xPlane, float* y, long 
     if (!attr) {
         (void)hipFuncSetAttribute((const void*)trunk_dataflow_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, T16_LDS_BYTES);
         (void)hipFuncSetAttribute((const void*)trunk_dataflow_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, T16_LDS_BYTES);
+        (void)hipFuncSetAttribute((const void*)trunk_mt_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, T16_LDS_BYTES);
         attr = true;
     }
     const bool diag = p.dbg != 0 || p.stamps != nullptr;
@@ -633,9 +862,17 @@ int isrTrunkDataflow(const float* x, int cin0, long long xPlane, float* y, long 
     hipLaunchKernelGGL(trunk_pack_input_kernel, dim3((unsigned)((npix + 255) / 256), (unsigned)(lay.groups0 > 8 ? lay.groups0 : 8)), dim3(256), 0, s,
                        x, cin0, xPlane, npix, xps, lay.groups0, (u32x4*)(ws + lay.fps), (u32x4*)(ws + lay.tps), p.done, ntiles);
     hipEvent_t e0 = nullptr, e1 = nullptr;
-    isr_profile_record(ISR_VARIANT_SPLIT_TRUNK, 2.0 * 9 * 64 * ((double)cin0 + 2.0 * nblocks * 64) * (double)H * W, &e0, &e1);
+    const int cus = isrTrunkDataflowMaxTiles();
+    const bool mt = g_trunk_mt == 2 || ntiles > cus;
+    isr_profile_record(mt ? ISR_VARIANT_SPLIT_TRUNK_MT : ISR_VARIANT_SPLIT_TRUNK, 2.0 * 9 * 64 * ((double)cin0 + 2.0 * nblocks * 64) * (double)H * W, &e0, &e1);
     const dim3 grid((unsigned)(((ntiles + 7) / 8) * 8)), block(T16_THREADS);
-    if (diag) {
+    if (mt) {
+        // one workgroup per CU, each walking every cus-th tile (a whole number of XCD groups; never more workgroups than CUs: all must be resident)
+        const int round8 = ((ntiles + 7) / 8) * 8;
+        const dim3 mgrid((unsigned)(round8 < cus ? round8 : cus));
+        if (e0 || e1) hipExtLaunchKernelGGL(trunk_mt_kernel, mgrid, block, T16_LDS_BYTES, s, e0, e1, 0, p);
+        else hipLaunchKernelGGL(trunk_mt_kernel, mgrid, block, T16_LDS_BYTES, s, p);
+    } else if (diag) {
         if (e0 || e1) hipExtLaunchKernelGGL(trunk_dataflow_kernel<true>, grid, block, T16_LDS_BYTES, s, e0, e1, 0, p);
         else hipLaunchKernelGGL(trunk_dataflow_kernel<true>, grid, block, T16_LDS_BYTES, s, p);
     } else if (e0 || e1) hipExtLaunchKernelGGL(trunk_dataflow_kernel<false>, grid, block, T16_LDS_BYTES, s, e0, e1, 0, p);

@@ -15,6 +15,7 @@ constexpr int ISR_VARIANT_SPLIT_TRUNK = 20;    // trunk_dataflow_kernel (sr_conv
 constexpr int ISR_VARIANT_SPLIT_UPS3 = 21;     // conv3x3_split_ups3_kernel (sr_conv_ups3.h)
 constexpr int ISR_VARIANT_SPLIT_BLOCK2 = 22;   // conv3x3_split_block2_kernel (sr_conv_block2.h)
 constexpr int ISR_VARIANT_SPLIT_UPS4 = 23;     // conv3x3_split_ups4_kernel (sr_conv_ups4.h)
+constexpr int ISR_VARIANT_SPLIT_TRUNK_MT = 24; // trunk_mt_kernel (sr_conv_trunk.hip)
 
 // Sets *e0 / *e1 to an event pair (and records the launch) when profiling is on, leaves them untouched otherwise.
 void isr_profile_record(int variant, double flops, hipEvent_t* e0, hipEvent_t* e1);

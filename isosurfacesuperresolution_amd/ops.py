@@ -125,6 +125,7 @@ def _sr():
         lib.isrSetRangeFlag.argtypes = [vp]; lib.isrSetRangeFlag.restype = None
         lib.isrSetTrunkErrorWord.argtypes = [vp]; lib.isrSetTrunkErrorWord.restype = None
         lib.isrDebugSetTrunkFault.argtypes = [ci, ctypes.c_ulonglong]; lib.isrDebugSetTrunkFault.restype = None
+        lib.isrDebugSetTrunkMultiTile.argtypes = [ci]; lib.isrDebugSetTrunkMultiTile.restype = None
         lib.isrProfileEnable.argtypes = [ci]; lib.isrProfileEnable.restype = ci
         lib.isrDebugSetSplitAlgo.argtypes = [ci]
         if os.environ.get("ISR_SPLIT_ALGO"):          # experiments: force a kernel form of the plain split layers (see sr_conv_split.hip)
@@ -194,7 +195,8 @@ VARIANT_NAMES = {6: "conv3x3_small_cout_kernel", 2: "conv3x3_fwd_kernel<1,false>
                  13: "conv3x3_split_kernel<false>", 14: "conv3x3_split_kernel<true>",
                  15: "conv3x3_split_stream_kernel", 16: "conv3x3_split_wide_kernel", 17: "conv3x3_split_rows2_kernel",
                  18: "conv3x3_split_tail_kernel", 19: "resblock_split_kernel", 20: "trunk_dataflow_kernel",
-                 21: "conv3x3_split_ups3_kernel", 22: "conv3x3_split_block2_kernel", 23: "conv3x3_split_ups4_kernel"}
+                 21: "conv3x3_split_ups3_kernel", 22: "conv3x3_split_block2_kernel", 23: "conv3x3_split_ups4_kernel",
+                 24: "trunk_mt_kernel"}
 
 
 def debug_switches():

@@ -60,12 +60,17 @@ def test_network_uses_the_dataflow_trunk_and_is_unchanged():
     assert names.count("trunk_dataflow_kernel") == 1 and not any(n.startswith("conv3x3_split_kernel<false>") for n in names)
     assert torch.equal(f, _per_layer(net, x))
     ops.trunk_check()
-    # too many tiles for one round (960 x 540 has 2040): the per-layer kernels take over
+    # more tiles than CUs (960 x 540 has 1020): the multi-tile form of the dataflow trunk (or, with it off, the per-layer kernels)
     big = torch.rand(1, 101, 540, 960, device="cuda")
     pre = net.preblock[0]
     convs = [(pre.weight, pre.bias)] + [(m.weight, m.bias) for b in net.blocks for m in (b[0], b[2])]
     with torch.no_grad():
-        assert not ops.trunk_supported(big, convs)
+        assert ops.trunk_supported(big, convs)
+        ops._sr().isrDebugSetTrunkMultiTile(0)
+        try:
+            assert not ops.trunk_supported(big, convs)
+        finally:
+            ops._sr().isrDebugSetTrunkMultiTile(1)
 
 
 def test_dataflow_trunk_under_uneven_load_and_repeated_launches():
@@ -188,3 +193,60 @@ def test_a_timeout_induced_on_the_device_raises_at_the_start_of_the_next_frame()
         ops.TRUNK_DATAFLOW = True
         torch.cuda.synchronize()
         ops._range_state("cuda")["buf"][ops._TRUNK_ERROR_SLOT] = 0
+
+
+@pytest.mark.parametrize("h,w", [(270, 960), (300, 500), (540, 960), (272, 481)])
+def test_multi_tile_trunk_is_bit_identical_to_the_per_layer_launches(h, w):
+    """trunk_mt_kernel (images of more tiles than CUs: a workgroup owns every 256th tile, the residual stream lives in the result
+    tensor): the network's trunk equals the 21 per-layer launches bit for bit, twice in a row through one workspace."""
+    from isosurfacesuperresolution_amd import ops
+    net = _net(h + w)
+    x = torch.rand(1, 101, h, w, device="cuda") * 2 - 0.5
+    pre = net.preblock[0]
+    convs = [(pre.weight, pre.bias)] + [(m.weight, m.bias) for b in net.blocks for m in (b[0], b[2])]
+    ops.profile_enable(True)
+    with torch.no_grad():
+        assert ops.trunk_supported(x, convs)
+        f = ops.trunk_dataflow(x, convs)
+        f2 = ops.trunk_dataflow(x * 0.5, convs)
+        f3 = ops.trunk_dataflow(x, convs)
+    torch.cuda.synchronize()
+    names = [n for n, _, _ in ops.profile_records()]
+    ops.profile_enable(False)
+    assert names.count("trunk_mt_kernel") == 3
+    ops.trunk_check()
+
+    def layers(inp):
+        with torch.no_grad():
+            r = ops.conv3x3_split(inp, pre.weight, pre.bias, act='relu')
+            for b in net.blocks:
+                r = ops.conv3x3_split(ops.conv3x3_split(r, b[0].weight, b[0].bias, act='relu'), b[2].weight, b[2].bias, residual=r)
+        return r
+    ref = layers(x)
+    assert torch.equal(f, ref), (f - ref).abs().max().item()
+    assert torch.equal(f3, ref) and not torch.equal(f2, ref)
+    assert torch.equal(f2, layers(x * 0.5))
+
+
+@pytest.mark.parametrize("cin,nblocks,h,w", [(101, 10, 270, 480), (5, 1, 33, 70), (16, 0, 16, 32), (40, 2, 50, 64), (24, 3, 300, 520)])
+def test_multi_tile_form_forced_on_every_size_equals_the_one_tile_form(cin, nblocks, h, w):
+    from isosurfacesuperresolution_amd import ops
+    g = torch.Generator().manual_seed(cin * 100 + nblocks)
+    convs = [(((torch.rand(64, cin if k == 0 else 64, 3, 3, generator=g) - 0.5) * 0.15).cuda(), ((torch.rand(64, generator=g) - 0.5) * 0.2).cuda())
+             for k in range(1 + 2 * nblocks)]
+    lib = ops._sr()
+    with torch.no_grad():
+        for trial in range(2):
+            x = ((torch.rand(1, cin, h, w, generator=g) - 0.4) * (1 + trial)).cuda()
+            ref = ops.conv3x3_split(x, convs[0][0], convs[0][1], act='relu')
+            for k in range(nblocks):
+                t = ops.conv3x3_split(ref, convs[2 * k + 1][0], convs[2 * k + 1][1], act='relu')
+                ref = ops.conv3x3_split(t, convs[2 * k + 2][0], convs[2 * k + 2][1], residual=ref)
+            lib.isrDebugSetTrunkMultiTile(2)
+            try:
+                f = ops.trunk_dataflow(x, convs)
+            finally:
+                lib.isrDebugSetTrunkMultiTile(1)
+            torch.cuda.synchronize()
+            ops.trunk_check()
+            assert torch.equal(f, ref), (trial, (f - ref).abs().max().item())
