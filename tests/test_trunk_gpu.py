@@ -250,3 +250,33 @@ def test_multi_tile_form_forced_on_every_size_equals_the_one_tile_form(cin, nblo
             torch.cuda.synchronize()
             ops.trunk_check()
             assert torch.equal(f, ref), (trial, (f - ref).abs().max().item())
+
+
+def test_multi_tile_trunk_gives_up_loudly_when_a_tile_never_publishes():
+    """The multi-tile form's waits have the same deadline and error word as the one-tile form's: a tile that never publishes
+    (isrDebugSetTrunkFault, deadline 2 ms) ends the launch with the word set by the kernel -- no hang -- and the next launch is right."""
+    from isosurfacesuperresolution_amd import ops
+    lib = ops._sr()
+    g = torch.Generator().manual_seed(5)
+    convs = [(((torch.rand(64, 24 if k == 0 else 64, 3, 3, generator=g) - 0.5) * 0.15).cuda(), ((torch.rand(64, generator=g) - 0.5) * 0.2).cuda())
+             for k in range(5)]
+    x = ((torch.rand(1, 24, 300, 520, generator=g) - 0.4)).cuda()                 # 19 x 17 = 323 tiles: more than CUs
+    st = ops._range_state(x.device)
+    try:
+        with torch.no_grad():
+            good = ops.trunk_dataflow(x, convs)
+            torch.cuda.synchronize()
+            lib.isrDebugSetTrunkFault(40, 200000)
+            ops.trunk_dataflow(x, convs)
+            lib.isrDebugSetTrunkFault(-1, 0)
+            torch.cuda.synchronize()
+            assert int(st["buf"][ops._TRUNK_ERROR_SLOT].item()) >= 2
+            st["buf"][ops._TRUNK_ERROR_SLOT] = 0
+            again = ops.trunk_dataflow(x, convs)
+            torch.cuda.synchronize()
+            assert torch.equal(good, again)
+            ops.trunk_check()
+    finally:
+        lib.isrDebugSetTrunkFault(-1, 0)
+        torch.cuda.synchronize()
+        st["buf"][ops._TRUNK_ERROR_SLOT] = 0
