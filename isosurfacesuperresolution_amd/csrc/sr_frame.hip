@@ -283,6 +283,7 @@ struct FillOneParams {
     unsigned* error;                              // set to 1 by a launch that gave up waiting
     int h, w, tilesX, tilesY;
     unsigned long long timeoutTicks;
+    int fault;                                    // diagnostics (isrDebugSetFlowFillFault): the last workgroup never raises the flag
 };
 
 __device__ __forceinline__ void st_agent(float* q, float v) { __hip_atomic_store(q, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
@@ -438,7 +439,7 @@ __global__ __launch_bounds__(F1_THREADS) void flow_fill_one_kernel(const FillOne
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
-        if (tid == 0) __hip_atomic_store(p.sync + 1, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (tid == 0 && !p.fault) __hip_atomic_store(p.sync + 1, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     // ---- everyone: wait for the top of the pyramid ---------------------------------------------------------------------------
     if (tid == 0) {
@@ -564,6 +565,13 @@ int isrFlowFillEx(const float* gbuffer_hwc12, float* flow_out, void* workspace, 
 
 static unsigned* g_fill_error_word = nullptr;
 void isrSetFlowFillErrorWord(unsigned* word) { g_fill_error_word = word; }
+/* Tests of the timeout path: with `on` the workgroup that finishes the pyramid's top never raises its flag, so every workgroup's wait runs
+ * into the deadline, `timeoutTicks` of the 100 MHz clock (0: the default 50 ms).  The launch after a faulty one is NOT usable on the same
+ * workspace before the flag has caught up (the ticket epoch has advanced): the caller zero-fills the workspace again. */
+static int g_fill_fault = 0;
+static unsigned long long g_fill_timeout_ticks = 5000000ull;
+void isrDebugSetFlowFillFault(int on, unsigned long long timeoutTicks) { g_fill_fault = on ? 1 : 0; g_fill_timeout_ticks = timeoutTicks ? timeoutTicks : 5000000ull; }
+int isrDebugFlowFillState(void) { return (g_fill_fault || g_fill_timeout_ticks != 5000000ull) ? 1 : 0; }
 
 int isrFlowFillOneSupported(int h, int w)
 {
@@ -583,7 +591,8 @@ int isrFlowFillOne(const float* gbuffer_hwc12, float* flow_out, void* workspace,
     p.top = p.ws + floats + 16;
     p.sync = reinterpret_cast<unsigned*>(p.top + 2 * F1_TOP_MAX);
     p.error = g_fill_error_word ? g_fill_error_word : p.sync + 2;
-    p.timeoutTicks = 5000000ull;                  // 50 ms of the 100 MHz clock
+    p.timeoutTicks = g_fill_timeout_ticks;        // 50 ms of the 100 MHz clock unless a test shortened it
+    p.fault = g_fill_fault;
     hipLaunchKernelGGL(flow_fill_one_kernel, dim3(p.tilesX * p.tilesY), dim3(F1_THREADS), 0, (hipStream_t)stream, p);
     return hipGetLastError() == hipSuccess ? 0 : -2;
 }

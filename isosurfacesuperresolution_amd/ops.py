@@ -76,6 +76,7 @@ def _sr():
         lib.isrFlowFillOne.argtypes = [vp, vp, vp, ci, ci, vp]; lib.isrFlowFillOne.restype = ci
         lib.isrFlowFillOneSupported.argtypes = [ci, ci]; lib.isrFlowFillOneSupported.restype = ci
         lib.isrSetFlowFillErrorWord.argtypes = [vp]; lib.isrSetFlowFillErrorWord.restype = None
+        lib.isrDebugSetFlowFillFault.argtypes = [ci, ctypes.c_ulonglong]; lib.isrDebugSetFlowFillFault.restype = None
         lib.isrFinishFrame.argtypes = [vp, vp, vp, vp, ci, ci, vp, ci, cf, ci, ci, vp]; lib.isrFinishFrame.restype = ci
         lib.isrConvSmallFinishFrame.argtypes = [vp, vp, vp, vp, vp, vp, ci, ci, ci, ll, vp, ci, cf, ci, ci, vp]
         lib.isrConvSmallFinishFrame.restype = ci
@@ -204,7 +205,8 @@ def debug_switches():
     forms, grid caps, stamp buffers) that are not in their default position; 0 on a clean process.  bench.py reports it and
     refuses to print a headline measured with an ablation active."""
     lib = _sr()
-    return int(lib.isrDebugSplitState()) | (int(lib.isrDebugTailState()) << 8) | (int(lib.isrDebugBlockState()) << 12) | (int(lib.isrDebugTrunkState()) << 16)
+    return (int(lib.isrDebugSplitState()) | (int(lib.isrDebugTailState()) << 8) | (int(lib.isrDebugBlockState()) << 12) | (int(lib.isrDebugTrunkState()) << 16)
+            | (int(lib.isrDebugFlowFillState()) << 28))
 
 
 _profile_on = False
@@ -1529,6 +1531,7 @@ def _fill_failed(st):
     global FLOW_FILL_ONE
     st["buf"][_FILL_ERROR_SLOT] = 0
     FLOW_FILL_ONE = False                       # whoever catches this goes on with the three-launch form
+    _fill_ws.clear()                            # (a launch that gave up leaves its workspace's ticket / flag epochs out of step: fresh ones if the form is switched on again)
     raise RuntimeError("flow_fill_one_kernel: a workgroup waited 50 ms for the top of the pyramid in a launch since the last look "
                        "(that frame's filled flow is incomplete; is the device shared?).  The three-launch form is used from now on.")
 

@@ -91,3 +91,34 @@ def test_images_of_more_than_256_tiles_take_the_three_launch_form():
     assert ops._sr().isrFlowFillOneSupported(1100, 1100) == 0
     gb = _gbuffer(1100, 1100, 5, "blobs")
     assert torch.equal(ops.fill_flow_gbuffer(gb), ops.fill_flow_gbuffer(gb, one_launch=False))
+
+
+def test_a_fill_that_times_out_reports_through_the_guard_word_and_the_three_launch_form_takes_over():
+    """isrDebugSetFlowFillFault: the workgroup that finishes the top of the pyramid never raises the flag, the deadline is 2 ms -- every
+    workgroup gives up (no hang), the KERNEL sets the guard word, the next frame's poll raises and switches the one-launch form off."""
+    from isosurfacesuperresolution_amd import ops
+    lib = ops._sr()
+    gb = _gbuffer(270, 480, 21, "blobs")
+    good = ops.fill_flow_gbuffer(gb, one_launch=False).clone()
+    dev = gb.device
+    try:
+        assert torch.equal(ops.fill_flow_gbuffer(gb, one_launch=True), good)
+        ops.guards_publish(dev); torch.cuda.synchronize(); ops.guards_poll(dev)            # clean so far
+        lib.isrDebugSetFlowFillFault(1, 200000)
+        assert ops.debug_switches() != 0
+        ops.fill_flow_gbuffer(gb, one_launch=True)
+        lib.isrDebugSetFlowFillFault(0, 0)
+        ops.guards_publish(dev)
+        torch.cuda.synchronize()
+        assert int(ops._range_state(dev)["buf"][ops._FILL_ERROR_SLOT].item()) == 1
+        with pytest.raises(RuntimeError, match="flow_fill_one_kernel"):
+            ops.guards_poll(dev)
+        assert ops.FLOW_FILL_ONE is False
+        assert torch.equal(ops.fill_flow_gbuffer(gb), good)                               # the default is the three-launch form now
+        ops.FLOW_FILL_ONE = True
+        assert torch.equal(ops.fill_flow_gbuffer(gb), good)                               # switched on again: fresh workspace, right again
+    finally:
+        lib.isrDebugSetFlowFillFault(0, 0)
+        ops.FLOW_FILL_ONE = True
+        torch.cuda.synchronize()
+        ops._range_state(dev)["buf"][ops._FILL_ERROR_SLOT] = 0
