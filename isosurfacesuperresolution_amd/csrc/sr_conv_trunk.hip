@@ -606,6 +606,7 @@ __global__ __launch_bounds__(T16_THREADS) void trunk_mt_kernel(const Trunk16Para
         const float* const bias = trunk16_uniform(p.bias[l]);
         const float unscale = reinterpret_cast<const float*>(wq)[1];
         bool staged = false;                                                 // this tile's first k-step is on its way already (fetched under the previous tile's last)
+        int owed = -1;                                                       // a tile whose stores are out but whose progress is not published yet
         Trunk16Lane lanes = trunk16_lane_setup(p, (slot / p.tilesX) * T16_H, (slot % p.tilesX) * T16_W, lane);
 #pragma unroll 1
         for (int tile = slot; tile < ntiles; tile += nwg) {
@@ -668,6 +669,10 @@ __global__ __launch_bounds__(T16_THREADS) void trunk_mt_kernel(const Trunk16Para
             for (int ks = 0; ks < ksteps; ++ks, ++gk) {
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 __syncthreads();
+                if (owed >= 0) {                                             // the previous tile's stores have drained with this k-step's operands: publish it now
+                    if (tid == 0 && owed != p.faultTile) __hip_atomic_store(p.done + owed, (unsigned)(l + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    owed = -1;
+                }
                 const int cur = gk & 1, nxt = cur ^ 1;
                 const u32x4* const pcur = pbuf0 + cur * P16_UNITS;
                 const u32x4* const wcur = wbuf0 + cur * S_WUNITS;
@@ -698,10 +703,16 @@ __global__ __launch_bounds__(T16_THREADS) void trunk_mt_kernel(const Trunk16Para
             } else if (kind == 0) trunk_mt_epilogue<0, false>(p, acc, mag, unscale, biasl0, tout, planeBytes, oy0, ox0, wave, j, h);
             else if (kind == 1) trunk_mt_epilogue<1, false>(p, acc, mag, unscale, biasl0, tout, planeBytes, oy0, ox0, wave, j, h);
             else trunk_mt_epilogue<2, false>(p, acc, mag, unscale, biasl0, tout, planeBytes, oy0, ox0, wave, j, h);
-            // ---- publish ----------------------------------------------------------------------------------------------------
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __syncthreads();
-            if (tid == 0 && tile != p.faultTile) __hip_atomic_store(p.done + tile, (unsigned)(l + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            // ---- publish: every wave's stores drained, then one agent-scope store of the tile's progress.  Where this workgroup has
+            //      another tile of the layer to do, the drain is the next tile's first k-step barrier (the stores land under its
+            //      operands' flight) and the publish follows it: its consumers are a whole round behind.  The layer's LAST tile of the
+            //      workgroup is published at once: the next layer's first tiles everywhere are waiting for exactly these. ----------
+            if (tnext < ntiles) owed = tile;
+            else {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __syncthreads();
+                if (tid == 0 && tile != p.faultTile) __hip_atomic_store(p.done + tile, (unsigned)(l + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
             staged = ahead;
             lanes = lanesNext;
         }
