@@ -163,7 +163,7 @@ __device__ __forceinline__ void split_epilogue_ps(const SplitConvParams& p, f32x
                 const u32x2 s0 = __builtin_amdgcn_permlane32_swap(uh.x, ul.x, false, false);
                 const u32x2 s1 = __builtin_amdgcn_permlane32_swap(uh.y, ul.y, false, false);
                 const u32x4 unit = {s0.x, s1.x, s0.y, s1.y};                // h = 0: channels 8 g .. + 7 hi; h = 1: the same channels' lo'
-                __builtin_amdgcn_raw_buffer_store_b128(unit, prs, (int)(live ? voff : BAD_OFFSET), g * p.psPlane * 16, 0);
+                __builtin_amdgcn_raw_buffer_store_b128(unit, prs, (int)((live && !(p.dbg & 16)) ? voff : BAD_OFFSET), g * p.psPlane * 16, 0);
             }
         }
     }
