@@ -31,7 +31,7 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-SPLIT_KERNEL_PREFIXES = ("conv3x3_split", "resblock_split", "trunk_dataflow")      # three fp16 MFMAs per product
+SPLIT_KERNEL_PREFIXES = ("conv3x3_split", "resblock_split", "trunk_dataflow", "trunk_mt")      # three fp16 MFMAs per product
 
 
 def is_split_kernel(name):
