@@ -216,6 +216,10 @@ int isrActBackward(const float* gy, const float* y, float* gz, long long count, 
  * selects initialImage: 0 "zero", 1 "unshaded", 2 "input". */
 int isrAssembleInput(const float* gbuffer_hwc12, const float* flow_filled, const float* prev_high, float* net_input,
                      int h, int w, int init_mode, int ao_inverted, void* stream);
+/* ... rows [row0, row1) of it only (the other rows of net_input are left as they are): a rank that super-resolves a screen strip
+ * assembles its strip + halo instead of the whole frame (parallel_sr.py). */
+int isrAssembleInputRows(const float* gbuffer_hwc12, const float* flow_filled, const float* prev_high, float* net_input,
+                         int h, int w, int init_mode, int ao_inverted, int row0, int row1, void* stream);
 
 /* Hole filling of the low-res flow (channels 8,9 of the HWC G-buffer) where the mask (channel 3) is 0:
  * mask-weighted push-pull pyramid, the on-device replacement of the reference's CPU OpenCV

@@ -32,6 +32,7 @@ struct AssembleParams {
     int h, w;
     int init_mode;          // prev == NULL: 0 zero, 1 unshaded constants, 2 upsampled input (+ones)
     int ao_inverted;
+    int row0;               // first row of the launch (isrAssembleInputRows: a rank that needs only its strip + halo)
 };
 
 // one thread per (low-res pixel, dx): neighbouring lanes read neighbouring hi-res columns (the gathers of the
@@ -40,7 +41,7 @@ __global__ __launch_bounds__(256) void assemble_input_kernel(const AssembleParam
 {
     const int t = blockIdx.x * blockDim.x + threadIdx.x;
     const int x = t >> 2, dx = t & 3;
-    const int y = blockIdx.y;
+    const int y = p.row0 + blockIdx.y;
     if (x >= p.w) return;
     const size_t plane = (size_t)p.h * p.w;
     const size_t pix = (size_t)y * p.w + x;
@@ -527,8 +528,17 @@ int isrAssembleInput(const float* gbuffer_hwc12, const float* flow_filled, const
     if (!gbuffer_hwc12 || !net_input || h <= 0 || w <= 0) return -1;
     if (prev_high && !flow_filled) return -1;
     if (init_mode < 0 || init_mode > 2) return -1;
-    AssembleParams p = { gbuffer_hwc12, flow_filled, prev_high, net_input, h, w, init_mode, ao_inverted };
-    hipLaunchKernelGGL(assemble_input_kernel, dim3((4 * w + 255) / 256, h), dim3(256), 0, (hipStream_t)stream, p);
+    return isrAssembleInputRows(gbuffer_hwc12, flow_filled, prev_high, net_input, h, w, init_mode, ao_inverted, 0, h, stream);
+}
+
+int isrAssembleInputRows(const float* gbuffer_hwc12, const float* flow_filled, const float* prev_high, float* net_input,
+                         int h, int w, int init_mode, int ao_inverted, int row0, int row1, void* stream)
+{
+    if (!gbuffer_hwc12 || !net_input || h <= 0 || w <= 0 || row0 < 0 || row1 > h || row0 >= row1) return -1;
+    if (prev_high && !flow_filled) return -1;
+    if (init_mode < 0 || init_mode > 2) return -1;
+    AssembleParams p = { gbuffer_hwc12, flow_filled, prev_high, net_input, h, w, init_mode, ao_inverted, row0 };
+    hipLaunchKernelGGL(assemble_input_kernel, dim3((4 * w + 255) / 256, row1 - row0), dim3(256), 0, (hipStream_t)stream, p);
     return hipGetLastError() == hipSuccess ? 0 : -2;
 }
 

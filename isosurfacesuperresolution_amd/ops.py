@@ -64,6 +64,7 @@ def _sr():
         lib.isrSetWeightGradAccumulate.argtypes = [ci]; lib.isrSetWeightGradAccumulate.restype = None
         lib.isrTakeMaxSlotWords.argtypes = []; lib.isrTakeMaxSlotWords.restype = ci
         lib.isrAssembleInput.argtypes = [vp, vp, vp, vp, ci, ci, ci, ci, vp]; lib.isrAssembleInput.restype = ci
+        lib.isrAssembleInputRows.argtypes = [vp, vp, vp, vp, ci, ci, ci, ci, ci, ci, vp]; lib.isrAssembleInputRows.restype = ci
         lib.isrConvSmallCinPad.argtypes = [ci]; lib.isrConvSmallCinPad.restype = ci
         lib.isrConvSmallWeightFloats.argtypes = [ci]; lib.isrConvSmallWeightFloats.restype = ll
         lib.isrConvSmallPrepare.argtypes = [vp, vp, vp, vp, ci, ci, vp]; lib.isrConvSmallPrepare.restype = ci
@@ -1503,9 +1504,10 @@ def adam_flat_step(params, grads, exp_avg, exp_avg_sq, step, lr, beta1, beta2, e
 INIT_MODES = {"zero": 0, "unshaded": 1, "input": 2}
 
 
-def assemble_input(gbuffer_hwc, flow_filled, prev_high, initial_image="zero", ao_inverted=False, out=None):
+def assemble_input(gbuffer_hwc, flow_filled, prev_high, initial_image="zero", ao_inverted=False, out=None, rows=None):
     """Renderer G-buffer [h,w,12] (+ hole-filled flow [1,2,h,w], previous frame [1,6,4h,4w] or None)
-    -> network input [1,101,h,w] in one launch (``isrAssembleInput``)."""
+    -> network input [1,101,h,w] in one launch (``isrAssembleInput``).  ``rows`` = (row0, row1): only those rows are written
+    (``isrAssembleInputRows``; the rest of the result is uninitialised unless ``out`` was given)."""
     assert gbuffer_hwc.is_cuda and gbuffer_hwc.is_contiguous() and gbuffer_hwc.shape[-1] == 12
     h, w = gbuffer_hwc.shape[0], gbuffer_hwc.shape[1]
     if out is None:
@@ -1514,8 +1516,9 @@ def assemble_input(gbuffer_hwc, flow_filled, prev_high, initial_image="zero", ao
         prev_high = prev_high.contiguous()
         flow_filled = flow_filled.contiguous()
         assert prev_high.shape == (1, 6, 4 * h, 4 * w) and flow_filled.shape == (1, 2, h, w)
-    rc = _sr().isrAssembleInput(_ptr(gbuffer_hwc), _ptr(flow_filled) if prev_high is not None else None,
-                                _ptr(prev_high), _ptr(out), h, w, INIT_MODES[initial_image], 1 if ao_inverted else 0, _stream())
+    r0, r1 = (0, h) if rows is None else (int(rows[0]), int(rows[1]))
+    rc = _sr().isrAssembleInputRows(_ptr(gbuffer_hwc), _ptr(flow_filled) if prev_high is not None else None,
+                                    _ptr(prev_high), _ptr(out), h, w, INIT_MODES[initial_image], 1 if ao_inverted else 0, r0, r1, _stream())
     if rc != 0:
         raise RuntimeError("isrAssembleInput failed (%d)" % rc)
     return out

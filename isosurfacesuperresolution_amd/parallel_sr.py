@@ -6,8 +6,9 @@ receptive field of about 23 low-resolution pixels (1 pre-block conv + 20 block c
 at 2x/4x and the bilinear footprints), so a rank that runs it on its strip plus a 24-pixel halo gets exactly the
 full-frame values inside the strip.  Per frame and rank:
 
-1. replicated (cheap, exact): flow hole filling and the assembly of the network input for the WHOLE frame -- the
-   warp of the previous high-resolution output samples across strip borders, so it stays global;
+1. replicated (cheap, exact): the flow hole filling of the whole frame (its pyramid spans the image); the assembly of the
+   network input for the rank's rows + halo only -- the warp of the previous high-resolution output samples across strip
+   borders, which is why every rank holds the whole previous frame;
 2. the convolutional trunk + reconstruction + clamp/normalise + shading on rows ``[y0 - halo, y1 + halo)``;
 3. ONE ``all_gather_into_tensor`` of the cropped strips (raw 6 + rgb 3 channels in one buffer), after which every
    rank holds the full output -- which is also the next frame's "previous" input.
@@ -50,13 +51,14 @@ class StripSuperResolution:
         self.previous = None
 
     # -- step 1 (replicated) ---------------------------------------------------------------------------------
-    def network_input(self, gbuffer):
-        """gbuffer [H, W, 12] -> the network's input [1, 5 + 6*upscale^2, H, W] for the whole frame."""
+    def network_input(self, gbuffer, rows=None):
+        """gbuffer [H, W, 12] -> the network's input [1, 5 + 6*upscale^2, H, W].  ``rows`` = (e0, e1): on the fused path only those
+        rows are assembled (a rank's strip + halo; the flow hole filling stays global: its pyramid spans the image)."""
         net, lm = self.model.model, self.model
         fused = gbuffer.is_cuda and self.upscale == 4
         if fused:
             flow = ops.fill_flow_gbuffer(gbuffer) if self.previous is not None else None
-            return ops.assemble_input(gbuffer, flow, self.previous, lm.initial_image_mode, lm.inverse_ao)
+            return ops.assemble_input(gbuffer, flow, self.previous, lm.initial_image_mode, lm.inverse_ao, rows=rows)
         low = gbuffer.permute(2, 0, 1).unsqueeze(0)
         mask = low[:, 3:4]
         inp = torch.cat((mask * 2 - 1, low[:, 4:8]), dim=1)
@@ -111,7 +113,9 @@ class StripSuperResolution:
         """gbuffer: the full low-resolution G-buffer [H, W, 12], identical on every rank (a replicated render or
         the composite of ``parallel_render.TiledRenderer``).  Returns (rgb, raw) of the full frame on every rank."""
         with torch.no_grad():
-            x = self.network_input(gbuffer)
+            h = gbuffer.shape[0]
+            y0, y1 = strip_bounds(h, self.world, self.rank)
+            x = self.network_input(gbuffer, rows=(max(0, y0 - self.halo), min(h, y1 + self.halo)))      # what compute_strip reads
             raw, rgb = self.compute_strip(x, after_trunk=after_trunk)
             if self.world > 1:
                 h, w, u = gbuffer.shape[0], gbuffer.shape[1], self.upscale

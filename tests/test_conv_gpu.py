@@ -523,3 +523,23 @@ def test_graphed_train_step_matches_eager():
     rel = ((finals[0] - finals[1]).norm() / finals[0].norm()).item()
     assert rel < 2e-2, rel
     assert abs(last[0] - last[1]) <= 2e-2 * abs(last[0]), last
+
+
+def test_input_assembly_of_a_row_range_equals_those_rows_of_the_whole():
+    """ops.assemble_input(rows=(a, b)) (isrAssembleInputRows: a strip rank's rows + halo) writes exactly what the whole-frame
+    assembly holds in those rows and leaves the others alone -- with and without a previous frame."""
+    import torch
+    from isosurfacesuperresolution_amd import ops
+    g = torch.Generator().manual_seed(4)
+    h, w = 61, 100
+    gb = (torch.rand((h, w, 12), generator=g) * 2 - 1).cuda()
+    gb[..., 3] = (gb[..., 3] > 0).float()
+    flow = ((torch.rand((1, 2, h, w), generator=g) - 0.5) * 0.05).cuda()
+    prev = (torch.rand((1, 6, 4 * h, 4 * w), generator=g) * 2 - 1).cuda()
+    for fl, pv, mode in ((flow, prev, "zero"), (None, None, "input"), (None, None, "unshaded")):
+        whole = ops.assemble_input(gb, fl, pv, mode, False)
+        for a, b in ((0, 17), (13, 48), (40, 61), (0, 61)):
+            out = torch.full((1, 101, h, w), 7.0, device="cuda")
+            part = ops.assemble_input(gb, fl, pv, mode, False, out=out, rows=(a, b))
+            assert part is out and torch.equal(part[:, :, a:b], whole[:, :, a:b])
+            assert bool((part[:, :, :a] == 7.0).all()) and bool((part[:, :, b:] == 7.0).all())
