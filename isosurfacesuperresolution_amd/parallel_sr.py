@@ -127,8 +127,8 @@ class StripSuperResolution:
                 everyone = torch.empty((self.world * 9, most, w * u), dtype=raw.dtype, device=raw.device)
                 dist.all_gather_into_tensor(everyone, mine, group=self.group)
                 everyone = everyone.view(self.world, 9, most, w * u)
-                parts = [everyone[r, :, :(b - a) * u] for r, (a, b) in enumerate(rows)]
-                full = torch.cat(parts, dim=1).unsqueeze(0)
-                raw, rgb = full[:, 0:6].contiguous(), full[:, 6:9].contiguous()
+                # one pass each (the concatenation writes the contiguous result; no intermediate 9-channel frame)
+                raw = torch.cat([everyone[r, 0:6, :(b - a) * u] for r, (a, b) in enumerate(rows)], dim=1).unsqueeze(0)
+                rgb = torch.cat([everyone[r, 6:9, :(b - a) * u] for r, (a, b) in enumerate(rows)], dim=1).unsqueeze(0)
             self.previous = raw
         return rgb, raw
