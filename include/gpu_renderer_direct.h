@@ -80,6 +80,10 @@ int isoLoadDenseDevice(unsigned long long devicePtr, int nx, int ny, int nz);
 int isoLoadDenseTileHost(const float* hostData, int nx, int ny, int nz, const int origin[3],
                          const int globalActiveMin[3], const int globalActiveMax[3], float globalMax,
                          const int clipLo[3], const int clipHi[3]);
+/* ... the same from DEVICE memory (a tile that a solver or an earlier pass left on the GPU: no staging through the host). */
+int isoLoadDenseTileDevice(unsigned long long devicePtr, int nx, int ny, int nz, const int origin[3],
+                           const int globalActiveMin[3], const int globalActiveMax[3], float globalMax,
+                           const int clipLo[3], const int clipHi[3]);
 
 /* Launch the frame on `stream` (a hipStream_t, may be NULL) without synchronising; the "last
  * camera" bookkeeping is identical to render().  Returns 0 or -1. */

@@ -978,17 +978,33 @@ int isoLoadDenseHost(const float* hostData, int nx, int ny, int nz)
     return ok ? 0 : -2;
 }
 
-int isoLoadDenseTileHost(const float* hostData, int nx, int ny, int nz, const int origin[3],
-                         const int globalActiveMin[3], const int globalActiveMax[3], float globalMax,
+static bool fillTileInfo(TileInfo& t, const int origin[3], const int globalActiveMin[3], const int globalActiveMax[3], float globalMax,
                          const int clipLo[3], const int clipHi[3])
 {
-    if (!g.initialised || !hostData || nx <= 0 || ny <= 0 || nz <= 0 || !origin || !globalActiveMin || !globalActiveMax || !clipLo || !clipHi) return -2;
-    TileInfo t;
+    if (!origin || !globalActiveMin || !globalActiveMax || !clipLo || !clipHi) return false;
     for (int k = 0; k < 3; ++k) {
         t.origin[k] = origin[k]; t.gmin[k] = globalActiveMin[k]; t.gmax[k] = globalActiveMax[k];
         t.clipLo[k] = clipLo[k]; t.clipHi[k] = clipHi[k];
     }
     t.globalMax = globalMax;
+    return true;
+}
+
+int isoLoadDenseTileDevice(unsigned long long devicePtr, int nx, int ny, int nz, const int origin[3],
+                           const int globalActiveMin[3], const int globalActiveMax[3], float globalMax,
+                           const int clipLo[3], const int clipHi[3])
+{
+    TileInfo t;
+    if (!g.initialised || !devicePtr || nx <= 0 || ny <= 0 || nz <= 0 || !fillTileInfo(t, origin, globalActiveMin, globalActiveMax, globalMax, clipLo, clipHi)) return -2;
+    return uploadFromDevice(reinterpret_cast<const float*>(devicePtr), nx, ny, nz, &t) ? 0 : -2;
+}
+
+int isoLoadDenseTileHost(const float* hostData, int nx, int ny, int nz, const int origin[3],
+                         const int globalActiveMin[3], const int globalActiveMax[3], float globalMax,
+                         const int clipLo[3], const int clipHi[3])
+{
+    TileInfo t;
+    if (!g.initialised || !hostData || nx <= 0 || ny <= 0 || nz <= 0 || !fillTileInfo(t, origin, globalActiveMin, globalActiveMax, globalMax, clipLo, clipHi)) return -2;
     float* dense = nullptr;
     const size_t bytes = size_t(nx) * ny * nz * sizeof(float);
     if (hipMalloc(&dense, bytes) != hipSuccess) return -2;

@@ -11,6 +11,8 @@ import collections
 import ctypes
 import os
 
+import torch
+
 from .. import _native
 from .camera import Camera
 
@@ -54,6 +56,8 @@ class DirectRenderer:
         lib.isoLoadDenseDevice.restype = ctypes.c_int
         lib.isoLoadDenseTileHost.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int] + [ctypes.c_void_p] * 3 + [ctypes.c_float] + [ctypes.c_void_p] * 2
         lib.isoLoadDenseTileHost.restype = ctypes.c_int
+        lib.isoLoadDenseTileDevice.argtypes = [ctypes.c_ulonglong, ctypes.c_int, ctypes.c_int, ctypes.c_int] + [ctypes.c_void_p] * 3 + [ctypes.c_float] + [ctypes.c_void_p] * 2
+        lib.isoLoadDenseTileDevice.restype = ctypes.c_int
         lib.isoRenderAsync.argtypes = [ctypes.c_ulonglong, ctypes.c_void_p]
         lib.isoRenderAsync.restype = ctypes.c_int
         lib.isoGetVolumeInfo.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
@@ -109,13 +113,22 @@ class DirectRenderer:
         return rc
 
     def load_tile(self, tile):
-        """Additive: one tile of a larger volume (see ``parallel_render.partition_volume``)."""
+        """Additive: one tile of a larger volume (see ``parallel_render.partition_volume``).  ``tile['data']``: a numpy array
+        [z][y][x] (``isoLoadDenseTileHost``) or a float32 CUDA tensor of that shape (``isoLoadDenseTileDevice``: no host staging)."""
         import numpy as np
+        i3 = lambda v: (ctypes.c_int * 3)(*[int(a) for a in v])
+        meta = (i3(tile['origin']), i3(tile['gmin']), i3(tile['gmax']), ctypes.c_float(tile['gmaxval']), i3(tile['clip_lo']), i3(tile['clip_hi']))
+        if torch.is_tensor(tile['data']) and tile['data'].is_cuda:
+            data = tile['data'].to(torch.float32).contiguous()
+            nz, ny, nx = data.shape
+            rc = self.lib.isoLoadDenseTileDevice(ctypes.c_ulonglong(data.data_ptr()), nx, ny, nz, *meta)
+            torch.cuda.synchronize()
+            if rc != 0:
+                raise RuntimeError("loading the volume tile failed (rc=%d)" % rc)
+            return rc
         data = np.ascontiguousarray(tile['data'], dtype=np.float32)
         nz, ny, nx = data.shape
-        i3 = lambda v: (ctypes.c_int * 3)(*[int(a) for a in v])
-        rc = self.lib.isoLoadDenseTileHost(data.ctypes.data, nx, ny, nz, i3(tile['origin']), i3(tile['gmin']), i3(tile['gmax']),
-                                           ctypes.c_float(tile['gmaxval']), i3(tile['clip_lo']), i3(tile['clip_hi']))
+        rc = self.lib.isoLoadDenseTileHost(data.ctypes.data, nx, ny, nz, *meta)
         if rc != 0:
             raise RuntimeError("loading the volume tile failed (rc=%d)" % rc)
         return rc

@@ -493,3 +493,24 @@ def test_prefetched_tiled_frames_equal_the_serial_sequence(renderer):
         for x, y in zip(a, b):
             assert torch.equal(x, y), "frame %d differs" % k
     assert results["serial"][3][0][..., 3].sum() > 500 and results["serial"][3][0][..., 8:10].abs().max() > 0
+
+
+def test_a_tile_loaded_from_device_memory_renders_like_the_host_load(renderer):
+    """isoLoadDenseTileDevice (DirectRenderer.load_tile with a CUDA tensor): the same bricks, the same pixels."""
+    import torch
+    from isosurfacesuperresolution_amd import parallel_render as PR
+    vol = V.ejecta(128)
+    renderer.set_kernel_variant(0)
+    origin = V.quantize3(V.orbit_camera(13))
+    W, H = 160, 90
+    tile = PR.partition_volume(vol, (2, 2, 1))[3]
+    renderer.load_tile(tile)
+    _render_gpu(renderer, W, H, origin, 30.0, 0.34)
+    host = _render_gpu(renderer, W, H, origin, 30.0, 0.34)
+    info_host = renderer.volume_info()
+    dev_tile = dict(tile, data=torch.from_numpy(np.ascontiguousarray(tile["data"], dtype=np.float32)).cuda())
+    renderer.load_tile(dev_tile)
+    _render_gpu(renderer, W, H, origin, 30.0, 0.34)
+    dev = _render_gpu(renderer, W, H, origin, 30.0, 0.34)
+    assert renderer.volume_info() == info_host
+    assert host[..., 3].sum() > 200 and np.array_equal(host, dev)
