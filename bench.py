@@ -34,6 +34,38 @@ sys.path.insert(0, ROOT)
 SPLIT_KERNEL_PREFIXES = ("conv3x3_split", "resblock_split", "trunk_dataflow", "trunk_mt")      # three fp16 MFMAs per product
 
 
+def tally_kernels(records):
+    """[(kernel name, algorithmic flops, ms)] of ops.profile_records() -> {name: [flops, seconds, launches]}."""
+    out = {}
+    for name, flops, ms in records:
+        d = out.setdefault(name, [0.0, 0.0, 0])
+        d[0] += flops
+        d[1] += ms * 1e-3
+        d[2] += 1
+    return out
+
+
+# kernels the frame pipeline runs on the RENDER stream, beside the network (not part of the main stream's serial chain)
+SIDE_STREAM_KERNELS = ("flow_fill_one_kernel",)
+
+
+def gap_accounting(ms_per_step, per, K, host_ms):
+    """Where a frame's time is when it is not inside a kernel of the main stream.  ``per``: tally_kernels() of the timed region;
+    ``host_ms``: per-frame host time of the K ``pipe.frame`` calls (enqueue only: nothing in a frame synchronises).
+    gap = ms_per_step - sum of the main-stream kernels' own durations: launch gaps, waits on the side stream's events, the
+    host falling behind.  A slow run explains itself from this one record: kernel rows unchanged + a large gap = the time is
+    BETWEEN kernels; host_enqueue close to ms_per_step = the host was the bottleneck."""
+    main = sum(v[1] for n, v in per.items() if n not in SIDE_STREAM_KERNELS and n != "unprofiled") / K * 1e3
+    side = sum(v[1] for n, v in per.items() if n in SIDE_STREAM_KERNELS) / K * 1e3
+    host = sorted(host_ms)
+    return {"main_stream_kernels_ms_per_frame": main, "gap_ms_per_frame": ms_per_step - main,
+            "side_stream_kernels_ms_per_frame": side,
+            "host_enqueue_ms_per_frame": sum(host) / max(1, len(host)), "host_enqueue_ms_max": host[-1] if host else None,
+            "host_enqueue_ms_median": host[len(host) // 2] if host else None,
+            "note": "gap = ms_per_step - (sum of main-stream kernel durations from the dispatch-packet events); the ray-march of frame t+1 "
+                    "and its flow fill run on the render stream and are not in the sum; host_enqueue = wall time of the pipe.frame() calls"}
+
+
 def is_split_kernel(name):
     """Kernel families of libisr_sr.so that compute each fp32 product as three fp16 MFMAs on split operands: their MFMA
     ceiling is a third of the dense fp16 peak; every other profiled convolution runs on fp32 MFMA."""
@@ -103,14 +135,67 @@ class Job:
                 local_rank = 0
             torch.cuda.set_device(local_rank)
             self.device = "cuda"
+        # ranks sharing ONE device (a rehearsal): the all-resident spin kernels (dataflow trunk, one-launch flow fill) need every
+        # workgroup of a launch resident at once -- two processes' grids interleaved on the CUs would wait for each other until the
+        # 50 ms deadline.  The hint switches those forms off in EVERY mode (ops.set_device_shared)
+        self.shared = os.environ.get("BENCH_SHARE_DEVICE") == "1"
+        if self.shared and not self.cpu:
+            from isosurfacesuperresolution_amd import ops
+            ops.set_device_shared(True)
+        self.timeout_s = float(os.environ.get("BENCH_DIST_TIMEOUT_S", "120"))
         if self.world > 1:
-            if self.backend == "nccl":
-                dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-            else:
-                dist.init_process_group(self.backend)
+            # A rank that never arrives (or an RCCL bootstrap that is stuck) must end THIS process with a message and a non-zero
+            # exit code well inside the driver's limit -- torch's default is 600 s, which is that limit.  Two phases are bounded
+            # and named: the rendezvous (init_process_group) and the first collective (where RCCL builds its rings).
+            from datetime import timedelta
+            self._phase("init_process_group", lambda: dist.init_process_group(
+                "nccl", device_id=torch.device("cuda", local_rank), timeout=timedelta(seconds=self.timeout_s))
+                if self.backend == "nccl" else dist.init_process_group(self.backend, timeout=timedelta(seconds=self.timeout_s)))
         assert args.gpus == self.world, "--gpus must equal the number of launched ranks"
         # tensors a collective can take: device tensors with RCCL, CPU tensors with gloo
         self.coll_device = "cuda" if (self.backend == "nccl" and not self.cpu) else "cpu"
+        if self.world > 1:
+            def first():
+                ones = torch.ones(1, dtype=torch.float32, device=self.coll_device)
+                dist.all_reduce(ones)
+                if not self.cpu:
+                    torch.cuda.synchronize()
+                assert int(ones.item()) == self.world, "first all-reduce joined %d of %d ranks" % (int(ones.item()), self.world)
+            self._phase("first collective (all-reduce)", first)
+            # the start-up is bounded; the RUN's collectives get torch's usual limit back (a 1024^3 tile takes a rank tens of seconds
+            # to generate while its peers already wait in the next all-reduce)
+            try:
+                from datetime import timedelta
+                from torch.distributed import distributed_c10d as c10d
+                c10d._set_pg_timeout(timedelta(seconds=float(os.environ.get("BENCH_DIST_RUN_TIMEOUT_S", "600"))))
+            except Exception:      # noqa: BLE001 -- a torch without that hook keeps the start-up limit
+                pass
+
+    def _phase(self, name, fn):
+        """Run one start-up phase under a deadline of ``timeout_s`` (+ a margin for the backend's own timeout to fire first).  On a
+        timeout or an error: one line on stderr naming rank and phase, exit code 3 -- a fresh exit of this process, nothing is
+        re-executed.  (The watchdog thread is what ends a phase the backend itself never returns from: an RCCL bootstrap that
+        hangs inside a C call cannot be interrupted from Python.)"""
+        import threading
+        t0 = time.perf_counter()
+
+        def expire():
+            sys.stderr.write("bench.py: rank %d/%d: phase '%s' did not finish within %.0f s (MASTER %s:%s, backend %s); exiting 3\n" % (
+                self.rank, self.world, name, time.perf_counter() - t0, os.environ.get("MASTER_ADDR"), os.environ.get("MASTER_PORT"), self.backend))
+            sys.stderr.flush()
+            os._exit(3)
+        dog = threading.Timer(self.timeout_s + 15.0, expire)
+        dog.daemon = True
+        dog.start()
+        try:
+            fn()
+        except BaseException as exc:      # noqa: BLE001 -- whatever the backend raised (DistStoreError, RuntimeError, timeout)
+            dog.cancel()
+            sys.stderr.write("bench.py: rank %d/%d: phase '%s' failed after %.0f s: %s: %s; exiting 3\n" % (
+                self.rank, self.world, name, time.perf_counter() - t0, type(exc).__name__, (str(exc).splitlines() or [""])[0][:300]))
+            sys.stderr.flush()
+            os._exit(3)
+        dog.cancel()
 
     def sync(self):
         import torch
@@ -251,8 +336,6 @@ def run_infer(args, job):
 
     if args.exact:
         ops.SPLIT_F16 = False
-    if os.environ.get("BENCH_SHARE_DEVICE") == "1":
-        ops.TRUNK_DATAFLOW = False          # several ranks on ONE device (a rehearsal): the dataflow trunk needs every tile resident
     low_w, low_h = (int(v) for v in (args.low or "480x270").split("x"))
     iso = {"ejecta256": 0.34, "ejecta128": 0.34, "sphere64": 0.5}[args.volume]
     vol = V.VOLUMES[args.volume][0]()
@@ -292,10 +375,15 @@ def run_infer(args, job):
     renderer.profile_enable(prof_timed)
     replays0 = pipe.graph_replays
     sync()
+    host_ms = []
     t0 = time.perf_counter()
+    th = t0
     for k in range(K):
         # the next frame's ray-march is enqueued on a side stream and overlaps this frame's network
         pipe.frame(origins[Wm + k], origins[Wm + k + 1] if overlap and k + 1 < K else None)
+        tn = time.perf_counter()
+        host_ms.append((tn - th) * 1e3)
+        th = tn
     sync()
     elapsed = time.perf_counter() - t0
     graph_replays = pipe.graph_replays - replays0
@@ -322,15 +410,10 @@ def run_infer(args, job):
     elapsed = job.max_over_ranks(elapsed)
     rank_keys = job.rank_keys()
 
-    per = {}
-    for name, flops, ms in records:
-        d = per.setdefault(name, [0.0, 0.0, 0])
-        d[0] += flops
-        d[1] += ms * 1e-3
-        d[2] += 1
+    per = tally_kernels(records)
     if not per:          # BENCH_PROFILE_TIMED=0 (experiment: what the dispatch-packet events cost the timed region)
         per = {"unprofiled": [0.0, 1.0, 1]}
-    dominant = max(per.items(), key=lambda kv: kv[1][1])
+    dominant = max(((n, v) for n, v in per.items() if v[0] > 0 or n == "unprofiled"), key=lambda kv: kv[1][1])      # among the kernels that do matrix work
     dom_name, (dom_flops, dom_time, dom_launches) = dominant
     achieved = dom_flops / dom_time / 1e12
     rm_time = sum(rm_ms) * 1e-3 / max(1, len(rm_ms))
@@ -382,6 +465,7 @@ def run_infer(args, job):
         "config": {"workload": "%s volume, %dx%d -> %dx%d 4x SR inference, orbit camera, temporal=%s" % (
             args.volume, low_w, low_h, 4 * low_w, 4 * low_h, "off" if args.no_temporal else "on"),
             "frames_per_rank": K, "sharding": "contiguous frame chunks per rank, no collective",
+            "spin_kernel_forms": ops.spin_kernel_forms(),       # all-resident forms (dataflow trunk, one-launch flow fill): off when ranks share a device
             "overlap": ("render(t+1) on a side HIP stream || SR(t), released when the trunk has ended" +
                         (", kernel variant %d capped at %d ray-march waves" % (pipe.side_variant, pipe.side_waves) if pipe.side_variant == 2 else
                          ", ray-march kernel variant %d (124 registers)" % pipe.side_variant if pipe.side_variant == 5 else
@@ -405,9 +489,11 @@ def run_infer(args, job):
                      "flops_per_launch": dom_flops / dom_launches},
         # every profiled kernel with ITS OWN roofline fraction (the 1080p kernels and the 480 x 270 trunk are bound differently)
         "kernels": {n: {"tflops": v[0] / v[1] / 1e12, "ms_per_frame": v[1] / K * 1e3, "launches_per_frame": v[2] / K,
-                        "frac": v[0] / v[1] / 1e12 / ((MFMA_F16_PEAK_TFLOPS / 3.0) if is_split_kernel(n)
-                                                      else MFMA_F32_PEAK_TFLOPS)}
+                        "frac": (v[0] / v[1] / 1e12 / ((MFMA_F16_PEAK_TFLOPS / 3.0) if is_split_kernel(n)
+                                                       else MFMA_F32_PEAK_TFLOPS)) if v[0] > 0 else None}      # None: no matrix work (assembly, packing, finishing)
                     for n, v in per.items()},
+        # the frame's time that is NOT inside a main-stream kernel, and the host's share (an outlier run explains itself from this)
+        "frame_time": gap_accounting(elapsed / K * 1e3, per, K, host_ms) if prof_timed or pipe.graph else None,
         "raymarch": {"kernel": "iso_render_gather (on a side stream under the network)" if overlap else "iso_render_gather",
                      "ms_per_frame": rm_time * 1e3, "alone_ms_per_frame": rm_alone * 1e3},
     }
@@ -447,7 +533,7 @@ def run_train(args, job):
     world, rank, dev = job.world, job.rank, job.device
     B, T, crop = args.train_batch, args.train_frames, args.train_crop
     assert B % world == 0, "--train-batch must be divisible by the number of ranks"
-    per = B // world
+    clips_per_rank = B // world
     opt = argparse.Namespace(**TRAIN_OPT)
     torch.manual_seed(124)                                              # mainVideoUnshaded.py:157
     with contextlib.redirect_stdout(sys.stderr):
@@ -456,7 +542,7 @@ def run_train(args, job):
     # FlatAdam: torch.optim.Adam's update over one flat buffer in one launch; its gradient buffer is the all-reduce bucket
     optim, _ = train.make_optimizer(net, capturable=(dev == "cuda"), flat=True)
     trainer = train.DataParallelTrainer(net, crit, optim)
-    batch = _clip_batch(torch, per, T, crop, 1000 + rank, dev)
+    batch = _clip_batch(torch, clips_per_rank, T, crop, 1000 + rank, dev)
     from isosurfacesuperresolution_amd import ops
     # which kernel family every convolution of ONE step goes to (algorithmic flops; shapes decide, so one eager step tells)
     ops.FLOP_TALLY = {}
@@ -498,14 +584,11 @@ def run_train(args, job):
         ops.profile_enable(True)
         trainer.step(batch, initial_image="zero")
         torch.cuda.synchronize()
-        per = {}
-        for name, fl, kms in ops.profile_records():
-            d = per.setdefault(name, [0.0, 0.0, 0])
-            d[0] += fl; d[1] += kms * 1e-3; d[2] += 1
+        kernel_tally = tally_kernels(ops.profile_records())
         ops.profile_enable(False)
         train_kernels = {n: {"tflops": v[0] / v[1] / 1e12, "ms_per_step": v[1] * 1e3, "launches_per_step": v[2],
                              "frac": v[0] / v[1] / 1e12 / ((MFMA_F16_PEAK_TFLOPS / 3.0) if is_split_kernel(n) else MFMA_F32_PEAK_TFLOPS)}
-                         for n, v in per.items() if v[1] > 0}
+                         for n, v in kernel_tally.items() if v[1] > 0 and v[0] > 0}
     # Roofline per kernel family, weighted by the flops each family carries: the time the step's convolutions would take
     # at each family's own ceiling is sum(flops_f / peak_f); the step's ceiling is total / that time (a harmonic mean).
     peaks = {"split": MFMA_F16_PEAK_TFLOPS / 3.0, "exact": MFMA_F32_PEAK_TFLOPS, "bf16": MFMA_F16_PEAK_TFLOPS}
@@ -522,7 +605,7 @@ def run_train(args, job):
         "dtype": dtype, "data": "synthetic (random clips of the dataset's shapes, seeded random-init EnhanceNet)",
         "config": {"workload": "EnhanceNet training step: global batch %d clips x %d frames, %dx%d -> %dx%d crops, "
                                "losses l1:mask:1,l1:ao:1,l1:normal:10,l1:depth:10,temp-l2:color:0.1, Adam 1e-4" % (B, T, crop, crop, 4 * crop, 4 * crop),
-                   "clips_per_rank": per, "parallelism": "dp%d, one flat %.2f MB gradient all-reduce per step" % (world, trainer.numel * 4 / 1e6),
+                   "clips_per_rank": clips_per_rank, "spin_kernel_forms": ops.spin_kernel_forms() if dev == "cuda" else None, "parallelism": "dp%d, one flat %.2f MB gradient all-reduce per step" % (world, trainer.numel * 4 / 1e6),
                    "step": step_kind},
         **job.rank_keys(), "allreduce": allreduce, "loss": loss,
         "roofline": {"kernel": "all convolutions of the step (forward + data gradient + weight gradient), whole-step time", "bound": "mfma",
@@ -705,12 +788,9 @@ def run_tiled(args, job, make_local_renderer=None):
     strip_flops = 564.5e9 * (low_w * rows) / (480.0 * 270.0)             # SURVEY.md App. B, scaled to this rank's rows (halo included)
     if dev == "cuda":
         torch.cuda.synchronize()
-        per = {}
-        for name, flops, kms in ops.profile_records():
-            d = per.setdefault(name, [0.0, 0.0, 0])
-            d[0] += flops; d[1] += kms * 1e-3; d[2] += 1
+        per = tally_kernels(ops.profile_records())
         ops.profile_enable(False)
-        dom_name, (dom_flops, dom_time, dom_launches) = max(per.items(), key=lambda kv: kv[1][1])
+        dom_name, (dom_flops, dom_time, dom_launches) = max(((n, v) for n, v in per.items() if v[0] > 0), key=lambda kv: kv[1][1])
         split = is_split_kernel(dom_name)
         peak = MFMA_F16_PEAK_TFLOPS / 3.0 if split else MFMA_F32_PEAK_TFLOPS
         achieved = dom_flops / dom_time / 1e12
@@ -740,7 +820,8 @@ def run_tiled(args, job, make_local_renderer=None):
                    "sharding": "one tile per rank; all-gather of %.1f MB G-buffers + nearest-hit composite; SR in %d strips with a 24-px halo + all-gather"
                                % (low_w * low_h * 48 / 1e6, world),
                    "overlap": ("render + all-gather + composite of frame t+1 on a side HIP stream || SR(t), released at SR(t)'s %s" % release)
-                              if overlap else "none"},
+                              if overlap else "none",
+                   "spin_kernel_forms": ops.spin_kernel_forms() if dev == "cuda" else None},
         **job.rank_keys(),
         "phases_ms_max_over_ranks": ms,
         "tile": {"generate_s": t_gen, "voxels": [int(v) for v in tile["data"].shape[::-1]]},
@@ -969,22 +1050,51 @@ def cpu_reference_leg(args, vol, iso, net, pipe, origin, low_w, low_h, result, r
         t_sr += time.perf_counter() - t0
         n_frames, last = n_frames + 1, qk
         cpu_frames.append((V.orbit_camera(k), gk, prev))
-    # the same frames on the GPU (fresh sequence): PSNR and parity of the first frame, and -- reported as they are -- of every further
-    # frame of the sample: the G-buffer parity holds on every frame; the network output of frame k > 0 depends on frame k - 1's
-    # output, and with random-init weights that recurrence amplifies rounding differences ~2.4x per frame
-    pipe.reset()
+    # The same frames on the GPU.  Three passes over the sample, all outside the timed region:
+    #  * free-running (what a viewer sees): frame k's "previous" is the GPU's own frame k - 1.  G-buffer parity holds per frame; the
+    #    network output of frame k > 0 inherits frame k - 1's rounding differences through the recurrence, amplified by the
+    #    network's gain (random-init weights: > 1) -- reported per frame as it is, NOT the kernels' parity figure;
+    #  * TEACHER-FORCED single step (the kernels' parity claim, independent of the network's gain): frame k's "previous" is the CPU
+    #    path's frame k - 1 output, uploaded -- every frame must be within 1e-4 of the CPU path's frame k;
+    #  * both again on the exact-fp32 HIP kernels (ops.SPLIT_F16 = False): does the split-operand path behave like IEEE fp32 here?
+    # (SuperresolutionNetwork/inference/loadedmodel.py:86-96 is the recurrence, mainComparisonVideo3.py:461-467 its driver.)
+    from isosurfacesuperresolution_amd import ops
+
+    def gpu_pass(teacher_forced):
+        pipe.reset()
+        out = []
+        for k, (cam, g_cpu, raw_cpu) in enumerate(cpu_frames):
+            if teacher_forced and k > 0:
+                pipe.previous = cpu_frames[k - 1][2].to("cuda").contiguous()
+            rgb_k, raw_k = pipe.frame(cam)
+            torch.cuda.synchronize()
+            out.append((rgb_k.clone() if k == 0 else None, raw_k.clone(), pipe.gbuffer.cpu().numpy()))
+        return out
+
+    def raw_err(frames):
+        return [float((f[1].cpu() - c[2]).abs().max().item()) for f, c in zip(frames, cpu_frames)]
+
+    free = gpu_pass(False)
+    forced = gpu_pass(True)
+    split_was = ops.SPLIT_F16
+    ops.SPLIT_F16 = False
+    try:
+        exact_free, exact_forced = raw_err(gpu_pass(False)), raw_err(gpu_pass(True))
+    finally:
+        ops.SPLIT_F16 = split_was
+        pipe.reset()
+    err_free, err_forced = raw_err(free), raw_err(forced)
+    rgb_gpu, raw_gpu, gbuf = free[0][0], free[0][1], free[0][2]
     per_frame = []
-    rgb_gpu = raw_gpu = gbuf = None
     for k, (cam, g_cpu, raw_cpu) in enumerate(cpu_frames):
-        rgb_k, raw_k = pipe.frame(cam)
-        torch.cuda.synchronize()
-        g_gpu = pipe.gbuffer.cpu().numpy()
-        if k == 0:
-            rgb_gpu, raw_gpu, gbuf = rgb_k.clone(), raw_k.clone(), g_gpu
+        g_gpu = free[k][2]
         cols = [c for c in range(12) if k > 0 or c not in (8, 9)]       # the first frame's flow depends on the camera rendered before it
         per_frame.append({"mask_mismatches": int((g_gpu[..., 3] != g_cpu[..., 3]).sum()),
                           "gbuffer_max_abs_err": float(np.abs(g_gpu[..., cols] - g_cpu[..., cols]).max()),
-                          "sr_raw_max_abs_err": float((raw_k.cpu() - raw_cpu).abs().max().item())})
+                          "sr_raw_err_single_step": err_forced[k],            # teacher-forced: the kernels' claim (<= 1e-4)
+                          "sr_raw_err_free_running": err_free[k],             # the GPU's own recurrence (carries the network's gain)
+                          "sr_raw_err_single_step_exact_f32": exact_forced[k],
+                          "sr_raw_err_free_running_exact_f32": exact_free[k]})
     mse = torch.mean((rgb_gpu.cpu() - rgb_cpu) ** 2).item()
     psnr = 10 * np.log10(1 / max(1e-10, mse))      # mainVideoUnshaded.py:693
     bytes_alg = stats["bricks_touched"] * 2048 + low_w * low_h * 48
@@ -992,14 +1102,23 @@ def cpu_reference_leg(args, vol, iso, net, pipe, origin, low_w, low_h, result, r
         "cpu_baseline": {"value": n_frames / (t_render + t_sr), "unit": "frames/s", "cores": cores, "kind": "port",
                          "sample": "%d frames of the bench sequence: oracle ray-march %dx%d (%.3f s, OpenMP %d threads) + PyTorch CPU flow fill, warp, EnhanceNet, shading (%.3f s, %d threads)" % (
                              n_frames, low_w, low_h, t_render, cores, t_sr, cores)},
-        "parity": {"frames_compared": len(per_frame),     # the four numbers below are frame 0's (a sequence's first frame: no recurrence yet);
-                                                         # `per_frame` lists every frame of the sample
-                   "mask_mismatches": int((gbuf[..., 3] != ref[..., 3]).sum()),
+        "parity": {"frames_compared": len(per_frame),
+                   "mask_mismatches": int(sum(f["mask_mismatches"] for f in per_frame)),                      # over ALL frames of the sample
                    "gbuffer_max_abs_err_excl_flow": float(np.abs(np.delete(gbuf, [8, 9], axis=2) - np.delete(ref, [8, 9], axis=2)).max()),
-                   "sr_raw_max_abs_err": float((raw_gpu.cpu() - raw).abs().max().item()),
+                   "gbuffer_max_abs_err": max(f["gbuffer_max_abs_err"] for f in per_frame),
+                   # the kernels' parity figure: max over the frames of the TEACHER-FORCED single-step error (frame k computed from the
+                   # CPU path's frame k - 1); tolerance 1e-4 (BASELINE.json north_star)
+                   "sr_raw_max_abs_err": max(err_forced),
+                   "sr_raw_max_abs_err_first_frame": err_forced[0],
+                   "sr_raw_max_abs_err_free_running": max(err_free),
+                   "sr_raw_max_abs_err_exact_f32": max(exact_forced),
+                   "sr_raw_max_abs_err_free_running_exact_f32": max(exact_free),
+                   "tolerance": 1e-4, "within_tolerance": bool(max(err_forced) <= 1e-4),
                    "psnr_rgb_vs_cpu_db": float(psnr),
-                   # every frame of the CPU sample, as measured (frame 0 = the numbers above; G-buffer parity is per frame, the network
-                   # output of later frames carries the recurrence's amplification of rounding differences with random-init weights)
+                   "note": "single_step = frame k from the CPU path's frame k-1 (isolates the kernels); free_running = the GPU's own "
+                           "recurrence, which also carries the random-init network's amplification of rounding differences from frame "
+                           "to frame (the exact-fp32 HIP kernels show the same growth: *_exact_f32; tests/test_recurrence_gpu.py bounds "
+                           "both against an fp64 CPU pass)",
                    "per_frame": per_frame},
     }
     result["raymarch"].update({

@@ -717,19 +717,19 @@ static int tail_launch(const void* xin, int packed, const void* wq6, const float
     if (fused) {
         TAIL_LAUNCH(1, false);
         const long long threads = 2LL * p.tilesY * W + (long long)H * 2 * p.tilesX;
-        hipLaunchKernelGGL(tail_seam_finish_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, s, tp);
+        ISR_LAUNCH_PROFILED(ISR_VARIANT_TAIL_FINISH, tail_seam_finish_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, s, tp);
     } else if (g_tail_fused == 2) {
         if (packed) TAIL_LAUNCH(2, true); else TAIL_LAUNCH(2, false);
         TailSFinishParams fp;
         fp.fin = tp.fin;
         fp.s = tp.z; fp.rec = tp.srec; fp.zPlane = tp.zPlane; fp.tilesX = p.tilesX; fp.bias8 = bias8;
-        hipLaunchKernelGGL(tail_s_finish_kernel, dim3((unsigned)((W + 255) / 256), (unsigned)H), dim3(256), 0, s, fp);
+        ISR_LAUNCH_PROFILED(ISR_VARIANT_TAIL_FINISH, tail_s_finish_kernel, dim3((unsigned)((W + 255) / 256), (unsigned)H), dim3(256), 0, s, fp);
     } else {
         if (packed) TAIL_LAUNCH(0, true); else TAIL_LAUNCH(0, false);
         TailFinishParams fp;
         fp.fin = tp.fin;
         fp.z = tp.z; fp.zPlane = tp.zPlane; fp.bias8 = bias8; fp.taps = g_tail_fused == 3 ? 3 : 9;
-        hipLaunchKernelGGL(tail_combine_finish_kernel, dim3((W + 255) / 256, H), dim3(256), 0, s, fp);
+        ISR_LAUNCH_PROFILED(ISR_VARIANT_TAIL_FINISH, tail_combine_finish_kernel, dim3((W + 255) / 256, H), dim3(256), 0, s, fp);
     }
 #undef TAIL_LAUNCH
     return hipGetLastError() == hipSuccess ? 0 : -2;

@@ -579,7 +579,10 @@ __global__ __launch_bounds__(T16_THREADS) void trunk_mt_kernel(const Trunk16Para
         slot = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (blockIdx.x >> 3);
     }
     if (slot >= ntiles) return;
-    const unsigned long long deadline = __builtin_amdgcn_s_memrealtime() + p.timeoutTicks;
+    // The deadline is PER WAIT and grows with the rounds a layer takes: a healthy launch of many rounds (65 535 tiles are admitted:
+    // ~170 ms) outlives any fixed limit counted from its start, while a single wait never lasts longer than the slowest workgroup's
+    // pass over ONE layer (rounds x ~31 us).  timeoutTicks x rounds per wait keeps the 1 600-fold margin of the one-round form.
+    const unsigned long long waitTicks = p.timeoutTicks * (unsigned long long)((ntiles + nwg - 1) / nwg);
     unsigned mag = 0u;
     int gk = 0;
     const char* const ws = trunk16_uniform(p.ws);
@@ -625,9 +628,12 @@ __global__ __launch_bounds__(T16_THREADS) void trunk_mt_kernel(const Trunk16Para
                     const int ny = ty + tid / 3 - 1, nx = tx + tid % 3 - 1;
                     if ((unsigned)ny < (unsigned)p.tilesY && (unsigned)nx < (unsigned)p.tilesX) {
                         const unsigned* f = p.done + ny * p.tilesX + nx;
-                        while (__hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (unsigned)l) {
-                            __builtin_amdgcn_s_sleep(2);
-                            if (__builtin_amdgcn_s_memrealtime() > deadline) { flags[0] = 1; break; }
+                        if (__hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (unsigned)l) {
+                            const unsigned long long deadline = __builtin_amdgcn_s_memrealtime() + waitTicks;       // armed when THIS wait begins
+                            do {
+                                __builtin_amdgcn_s_sleep(2);
+                                if (__builtin_amdgcn_s_memrealtime() > deadline) { flags[0] = 1; break; }
+                            } while (__hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (unsigned)l);
                         }
                     }
                 } else if (tid >= 64 && tid < 73 && ahead) {
@@ -870,8 +876,8 @@ int isrTrunkDataflow(const float* x, int cin0, long long xPlane, float* y, long 
     }
     const bool diag = p.dbg != 0 || p.stamps != nullptr;
     const int npix = H * W;
-    hipLaunchKernelGGL(trunk_pack_input_kernel, dim3((unsigned)((npix + 255) / 256), (unsigned)(lay.groups0 > 8 ? lay.groups0 : 8)), dim3(256), 0, s,
-                       x, cin0, xPlane, npix, xps, lay.groups0, (u32x4*)(ws + lay.fps), (u32x4*)(ws + lay.tps), p.done, ntiles);
+    ISR_LAUNCH_PROFILED(ISR_VARIANT_TRUNK_PACK, trunk_pack_input_kernel, dim3((unsigned)((npix + 255) / 256), (unsigned)(lay.groups0 > 8 ? lay.groups0 : 8)), dim3(256), 0, s,
+                        x, cin0, xPlane, npix, xps, lay.groups0, (u32x4*)(ws + lay.fps), (u32x4*)(ws + lay.tps), p.done, ntiles);
     hipEvent_t e0 = nullptr, e1 = nullptr;
     const int cus = isrTrunkDataflowMaxTiles();
     const bool mt = g_trunk_mt == 2 || ntiles > cus;

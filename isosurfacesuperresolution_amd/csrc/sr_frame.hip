@@ -12,10 +12,12 @@
 //
 // Both are HBM-streaming kernels (each ~100-125 MB of traffic at 1080p).
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 #include <stdint.h>
 
 #include "../../include/isr_sr_kernels.h"
 #include "sr_finish.h"
+#include "sr_profile.h"
 
 namespace {
 
@@ -280,7 +282,7 @@ constexpr int F1_SMEM = 8192;                     // floats of LDS: phase A 3 x 
 struct FillOneParams {
     const float* gbuf; float* out; float* ws;     // as flow_fill_kernel
     float* top;                                   // [2][tiles] filled values of the tiles' level (6, or the last if there are fewer)
-    unsigned* sync;                               // [0] ticket, [1] flag (launch epochs: both only ever grow; zero before the first launch)
+    unsigned* sync;                               // [0] ticket (0 .. ntiles - 1 inside a launch, zero between launches), [1] flag = number of completed launches (wraps)
     unsigned* error;                              // set to 1 by a launch that gave up waiting
     int h, w, tilesX, tilesY;
     unsigned long long timeoutTicks;
@@ -364,12 +366,17 @@ __global__ __launch_bounds__(F1_THREADS) void flow_fill_one_kernel(const FillOne
         }
     }
     // ---- ticket: the last workgroup finishes the pyramid above level L ---------------------------------------------------------
+    // The launch's epoch is the flag's value when the launch began + 1 (read BEFORE this workgroup's ticket: the flag only moves after
+    // the last ticket of a launch has been taken); the ticket counts 0 .. ntiles - 1 within ONE launch and is put back to zero by the
+    // last workgroup.  Nothing here grows without bound: a viewer that runs for 2^32 launches wraps the flag, and the signed
+    // comparison below is wrap-safe (the earlier form derived epoch and "last" from one ever-growing ticket, which lost its
+    // alignment at the wrap unless ntiles was a power of two).
+    if (tid == 0) s_epoch = __hip_atomic_load(p.sync + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u;
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     if (tid == 0) {
         const unsigned old = __hip_atomic_fetch_add(p.sync, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        s_epoch = old / (unsigned)ntiles + 1u;
-        s_last = (old % (unsigned)ntiles) == (unsigned)(ntiles - 1);
+        s_last = old == (unsigned)(ntiles - 1);
     }
     __syncthreads();
     const unsigned epoch = s_epoch;
@@ -440,7 +447,10 @@ __global__ __launch_bounds__(F1_THREADS) void flow_fill_one_kernel(const FillOne
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
-        if (tid == 0 && !p.fault) __hip_atomic_store(p.sync + 1, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (tid == 0) {
+            __hip_atomic_store(p.sync, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);          // every ticket of this launch is taken: the next launch counts from zero
+            if (!p.fault) __hip_atomic_store(p.sync + 1, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
     }
     // ---- everyone: wait for the top of the pyramid ---------------------------------------------------------------------------
     if (tid == 0) {
@@ -538,7 +548,7 @@ int isrAssembleInputRows(const float* gbuffer_hwc12, const float* flow_filled, c
     if (prev_high && !flow_filled) return -1;
     if (init_mode < 0 || init_mode > 2) return -1;
     AssembleParams p = { gbuffer_hwc12, flow_filled, prev_high, net_input, h, w, init_mode, ao_inverted, row0 };
-    hipLaunchKernelGGL(assemble_input_kernel, dim3((4 * w + 255) / 256, row1 - row0), dim3(256), 0, (hipStream_t)stream, p);
+    ISR_LAUNCH_PROFILED(ISR_VARIANT_ASSEMBLE, assemble_input_kernel, dim3((4 * w + 255) / 256, row1 - row0), dim3(256), 0, (hipStream_t)stream, p);
     return hipGetLastError() == hipSuccess ? 0 : -2;
 }
 
@@ -576,8 +586,9 @@ int isrFlowFillEx(const float* gbuffer_hwc12, float* flow_out, void* workspace, 
 static unsigned* g_fill_error_word = nullptr;
 void isrSetFlowFillErrorWord(unsigned* word) { g_fill_error_word = word; }
 /* Tests of the timeout path: with `on` the workgroup that finishes the pyramid's top never raises its flag, so every workgroup's wait runs
- * into the deadline, `timeoutTicks` of the 100 MHz clock (0: the default 50 ms).  The launch after a faulty one is NOT usable on the same
- * workspace before the flag has caught up (the ticket epoch has advanced): the caller zero-fills the workspace again. */
+ * into the deadline, `timeoutTicks` of the 100 MHz clock (0: the default 50 ms).  (With the fault the ticket is still put back to zero, so the
+ * next launch on the same workspace works; after a REAL timeout -- a workgroup that never arrived -- the ticket is out of step and the caller
+ * zero-fills the workspace: ops._fill_failed.) */
 static int g_fill_fault = 0;
 static unsigned long long g_fill_timeout_ticks = 5000000ull;
 void isrDebugSetFlowFillFault(int on, unsigned long long timeoutTicks) { g_fill_fault = on ? 1 : 0; g_fill_timeout_ticks = timeoutTicks ? timeoutTicks : 5000000ull; }
@@ -603,7 +614,7 @@ int isrFlowFillOne(const float* gbuffer_hwc12, float* flow_out, void* workspace,
     p.error = g_fill_error_word ? g_fill_error_word : p.sync + 2;
     p.timeoutTicks = g_fill_timeout_ticks;        // 50 ms of the 100 MHz clock unless a test shortened it
     p.fault = g_fill_fault;
-    hipLaunchKernelGGL(flow_fill_one_kernel, dim3(p.tilesX * p.tilesY), dim3(F1_THREADS), 0, (hipStream_t)stream, p);
+    ISR_LAUNCH_PROFILED(ISR_VARIANT_FLOW_FILL, flow_fill_one_kernel, dim3(p.tilesX * p.tilesY), dim3(F1_THREADS), 0, (hipStream_t)stream, p);
     return hipGetLastError() == hipSuccess ? 0 : -2;
 }
 
@@ -613,7 +624,7 @@ int isrFinishFrame(const float* raw, const float* net_input, float* next_prev, f
     if (!raw || !net_input || !next_prev || h <= 0 || w <= 0 || (rgb && !shading24)) return -1;
     FinishParams p;
     isr_fill_finish_params(p, raw, net_input, next_prev, rgb, h, w, shading24, exponent, ao_strength, inverse_ao, enable_specular);
-    hipLaunchKernelGGL(finish_frame_kernel, dim3((4 * w + 255) / 256, 4 * h), dim3(256), 0, (hipStream_t)stream, p);
+    ISR_LAUNCH_PROFILED(ISR_VARIANT_FINISH, finish_frame_kernel, dim3((4 * w + 255) / 256, 4 * h), dim3(256), 0, (hipStream_t)stream, p);
     return hipGetLastError() == hipSuccess ? 0 : -2;
 }
 

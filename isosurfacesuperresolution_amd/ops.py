@@ -162,6 +162,46 @@ def invalidate_weight_images():
     _images_epoch += 1
 
 
+# ---- routing epoch: what a CAPTURED frame (pipeline.SuperResolutionPipeline, ISR_FRAME_GRAPH) has baked in ----------------------
+# A captured HIP graph holds raw device pointers and the routing decisions of the moment it was captured: which kernel form ran
+# (dataflow trunk or per-layer, one-launch or three-launch flow fill), which guard word a launch reports to, which workspace it
+# spins in.  Every code path that changes one of these behind a graph's back moves this epoch (``_trunk_failed``,
+# ``_fill_failed``, ``range_reset``, ``set_device_shared``); the pipeline puts it -- with the switches themselves and the weights'
+# (version, address) -- into the signature that decides whether its captured frames are still valid.
+_routing_epoch = 0
+
+
+def routing_epoch():
+    return _routing_epoch
+
+
+def _routing_changed():
+    global _routing_epoch
+    _routing_epoch += 1
+
+
+# Several processes (or several independent streams of kernels) share ONE device: the all-resident spin kernels -- the dataflow
+# trunk (one workgroup per CU, neighbours wait for each other) and the one-launch flow fill (every workgroup waits for the last) --
+# assume that all workgroups of a launch are resident at once; beside another process's grid they may not be, and then they wait
+# for each other until the 50 ms deadline.  With the hint set those forms are refused everywhere (``trunk_supported``,
+# ``fill_flow_gbuffer``) and the per-layer / three-launch forms run: bit-identical results.  ISR_DEVICE_SHARED=1 or
+# ``set_device_shared(True)`` (bench.py: BENCH_SHARE_DEVICE=1, in every mode).
+DEVICE_SHARED = os.environ.get("ISR_DEVICE_SHARED", "0") == "1"
+
+
+def set_device_shared(on):
+    global DEVICE_SHARED
+    on = bool(on)
+    if on != DEVICE_SHARED:
+        DEVICE_SHARED = on
+        _routing_changed()
+
+
+def spin_kernel_forms():
+    """Which of the all-resident forms a launch may take right now (bench lines and tests report it)."""
+    return {"trunk_dataflow": bool(TRUNK_DATAFLOW and not DEVICE_SHARED), "flow_fill_one": bool(FLOW_FILL_ONE and not DEVICE_SHARED)}
+
+
 def prepare_weights(weight, transpose_flip=False):
     """PyTorch [Cout,Cin,3,3] -> kernel layout [9][cinPad][coutPad] (device tensor)."""
     lib = _sr()
@@ -198,7 +238,10 @@ VARIANT_NAMES = {6: "conv3x3_small_cout_kernel", 2: "conv3x3_fwd_kernel<1,false>
                  15: "conv3x3_split_stream_kernel", 16: "conv3x3_split_wide_kernel", 17: "conv3x3_split_rows2_kernel",
                  18: "conv3x3_split_tail_kernel", 19: "resblock_split_kernel", 20: "trunk_dataflow_kernel",
                  21: "conv3x3_split_ups3_kernel", 22: "conv3x3_split_block2_kernel", 23: "conv3x3_split_ups4_kernel",
-                 24: "trunk_mt_kernel"}
+                 24: "trunk_mt_kernel",
+                 # the frame's small kernels (zero algorithmic flops; registered for bench.py's gap accounting)
+                 25: "trunk_pack_input_kernel", 26: "assemble_input_kernel", 27: "tail_finish_kernel", 28: "flow_fill_one_kernel",
+                 29: "finish_frame_kernel"}
 
 
 def debug_switches():
@@ -522,9 +565,7 @@ def guards_publish(device, record=True):
     """End of a frame: copy the guard words (range maxima + the trunk's error word) into pinned host memory, asynchronously on
     the current stream.  ``record=False`` inside a stream capture (an event recorded there is a graph node, not something the host
     can query): the caller marks the replay's end with ``guards_mark``."""
-    if not RANGE_GUARD:
-        return
-    st = _range_state(device)
+    st = _range_state(device)      # (with RANGE_GUARD off the range words stay zero; the two error words of the spin kernels are still mirrored)
     st["mirror"].copy_(st["buf"], non_blocking=True)
     if record:
         guards_mark(device)
@@ -540,11 +581,13 @@ def guards_poll(device):
     """Start of a frame: look at what the PREVIOUS frame published -- a plain read of pinned memory, no synchronisation (if that
     copy has not landed yet it is looked at a frame later).  Marks new hot producers (returned) and raises if a dataflow-trunk
     launch timed out."""
-    if not RANGE_GUARD:
-        return set()
     st = _range_state(device)
     if not st["pending"] or not st["event"].query():
         return set()
+    return _guards_look(st)
+
+
+def _guards_look(st):
     st["pending"] = False
     words = st["mirror"]
     err = int(words[_TRUNK_ERROR_SLOT])
@@ -552,7 +595,22 @@ def guards_poll(device):
         _trunk_failed(st, err)
     if int(words[_FILL_ERROR_SLOT]):
         _fill_failed(st)
+    if not RANGE_GUARD:
+        return set()
     return _mark_hot(st, words.view(torch.float32), conservative=True)
+
+
+def guards_flush(device):
+    """END of a sequence (``SuperResolutionPipeline.reset()`` / ``close()``, the end of an offline render): the frame-late look of
+    ``guards_poll`` done NOW for the last frame -- waits for that frame's guard-word copy (one event synchronisation, the frame's
+    work is what it waits for) and raises / marks exactly like ``guards_poll``.  Without it the last frame of a sequence is never
+    followed by a poll."""
+    device = _range_device(device)
+    st = _range.get(device)
+    if st is None or not st["pending"]:
+        return set()
+    st["event"].synchronize()
+    return _guards_look(st)
 
 
 def range_reset():
@@ -564,6 +622,7 @@ def range_reset():
         st["members"].clear()
         st["frames"] = 0
         st["pending"] = False
+    _routing_changed()           # guard words are handed out anew: a captured launch would keep writing the old ones
 
 
 def range_check_due(device):
@@ -1029,7 +1088,7 @@ _trunk_ws = {}
 
 def trunk_supported(x, convs):
     """x [1, Cin, h, w]; convs: [(weight, bias)] = preblock, then conv1 / conv2 of every block."""
-    if not (TRUNK_DATAFLOW and SPLIT_F16 and not FAST_F16 and x.is_cuda and x.dtype == torch.float32 and x.dim() == 4 and x.shape[0] == 1):
+    if not (TRUNK_DATAFLOW and not DEVICE_SHARED and SPLIT_F16 and not FAST_F16 and x.is_cuda and x.dtype == torch.float32 and x.dim() == 4 and x.shape[0] == 1):
         return False
     if torch.is_grad_enabled() and (x.requires_grad or any(w.requires_grad for w, _ in convs)):
         return False
@@ -1073,6 +1132,7 @@ def _trunk_failed(st, err):
     global TRUNK_DATAFLOW
     st["buf"][_TRUNK_ERROR_SLOT] = 0           # sticky on the device: an error of ANY launch since the last look was still there
     TRUNK_DATAFLOW = False                      # whoever catches this goes on with the per-layer kernels
+    _routing_changed()                          # ... and a captured frame that holds the dataflow launch is stale (pipeline._graph_signature)
     raise RuntimeError("trunk_dataflow_kernel: a tile timed out waiting for its neighbours at layer %d in a launch since the last "
                        "look (that launch's output is incomplete; a workgroup was not resident -- is the device shared?).  The "
                        "dataflow trunk is now off for this process (ops.TRUNK_DATAFLOW)" % (err - 1))
@@ -1534,7 +1594,13 @@ def _fill_failed(st):
     global FLOW_FILL_ONE
     st["buf"][_FILL_ERROR_SLOT] = 0
     FLOW_FILL_ONE = False                       # whoever catches this goes on with the three-launch form
-    _fill_ws.clear()                            # (a launch that gave up leaves its workspace's ticket / flag epochs out of step: fresh ones if the form is switched on again)
+    _routing_changed()                          # a captured frame that holds the one-launch fill is stale (pipeline._graph_signature)
+    # A launch that gave up leaves its workspace's ticket / flag words out of step.  The workspaces are NOT freed (a captured graph
+    # or a launch still in flight on the render stream may point into them): they are zero-filled again at a quiescent point.
+    torch.cuda.synchronize()
+    for ws in _fill_ws.values():
+        ws.zero_()
+    torch.cuda.synchronize()
     raise RuntimeError("flow_fill_one_kernel: a workgroup waited 50 ms for the top of the pyramid in a launch since the last look "
                        "(that frame's filled flow is incomplete; is the device shared?).  The three-launch form is used from now on.")
 
@@ -1556,12 +1622,11 @@ def fill_flow_gbuffer(gbuffer_hwc, out=None, stream=None, threads=1024, one_laun
         _fill_ws[key] = ws
     if out is None:
         out = torch.empty((1, 2, h, w), dtype=torch.float32, device=gbuffer_hwc.device)
-    one = FLOW_FILL_ONE if one_launch is None else one_launch
+    one = (FLOW_FILL_ONE and not DEVICE_SHARED) if one_launch is None else one_launch
     if one and lib.isrFlowFillOneSupported(h, w):
-        if RANGE_GUARD:
-            lib.isrSetFlowFillErrorWord(ctypes.c_void_p(_range_state(gbuffer_hwc.device)["buf"].data_ptr() + 4 * _FILL_ERROR_SLOT))
-        else:
-            lib.isrSetFlowFillErrorWord(None)
+        # the error word is one of the per-frame guard words whether or not the RANGE guard is on (a spin kernel's timeout must
+        # never go to a word that nobody reads)
+        lib.isrSetFlowFillErrorWord(ctypes.c_void_p(_range_state(gbuffer_hwc.device)["buf"].data_ptr() + 4 * _FILL_ERROR_SLOT))
         rc = lib.isrFlowFillOne(_ptr(gbuffer_hwc), _ptr(out), _ptr(ws), h, w, ctypes.c_void_p(st.cuda_stream))
     else:
         rc = lib.isrFlowFillEx(_ptr(gbuffer_hwc), _ptr(out), _ptr(ws), h, w, int(threads), ctypes.c_void_p(st.cuda_stream))

@@ -277,6 +277,10 @@ class PrefetchedComposite:
         if key not in self.keys:
             self.start(key, after_current=True)            # nothing ahead: the serial order, after everything enqueued so far
         slot = self.keys.index(key)
+        # a composite is handed out ONCE: the key is forgotten here, so a later request for the same key (a looping sequence, the
+        # same frame index after the camera path or isovalue changed) renders again instead of returning what sits in the slot --
+        # its flow channels were measured against the camera that preceded it THEN
+        self.keys[slot] = None
         if self.cuda:
             torch.cuda.current_stream(self.device).wait_event(self.ready[slot])
         self.taken = slot

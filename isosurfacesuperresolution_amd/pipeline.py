@@ -184,8 +184,23 @@ class SuperResolutionPipeline:
         r.send_command("viewport", "%d,%d,%d,%d" % (0, 0, self.low_w, self.low_h))
 
     def reset(self):
+        """Start a new temporal sequence.  Also the END of the one before: the guards watch every frame one frame late
+        (``ops.guards_publish`` at a frame's end, ``ops.guards_poll`` at the next frame's start), so the sequence's LAST frame is
+        looked at here -- a dataflow-trunk / flow-fill launch of that frame that timed out raises RuntimeError from this call (the
+        frame it produced is incomplete), a layer that came close to the split operands' range is routed to the exact kernels from
+        the next sequence on.  Offline renderers call ``reset()`` or ``close()`` after their last frame."""
         self.previous = None
         self._drop_prefetched()
+        if self.fused and str(self.device).startswith("cuda"):
+            ops.guards_flush(self.device)
+
+    def close(self):
+        """End of use: the last frame's guard look (see ``reset``) and the captured frames dropped."""
+        try:
+            self.reset()
+        finally:
+            self._graphs = [None, None]
+            self._graph_sig = None
 
     def _drop_prefetched(self):
         """Forget a frame that was rendered ahead but is not going to be displayed.  The renderer's "last camera" is
@@ -264,9 +279,16 @@ class SuperResolutionPipeline:
     # host sends the next camera, refreshes the camera block (one small launch on this stream) and replays.  Kernel boundaries
     # inside a graph need no host: ~2 us instead of the 4-15 us of eager launches with event records between them.
     def _graph_signature(self):
+        """Everything a captured frame has baked in besides its static buffers: shading constants, the model object, the weight
+        images (``_images_epoch`` + every parameter's (version, address): an in-place update makes the eager path build new images
+        and drop the ones a graph points at), the renderer's static parameters, and the ROUTING -- which kernel forms a launch takes
+        (``ops.TRUNK_DATAFLOW``, ``ops.FLOW_FILL_ONE``, the device-shared hint) and ``ops.routing_epoch()``, which moves whenever a
+        guard failure switched a form off, re-zeroed a workspace or ``range_reset`` handed the guard words out anew."""
         sh = self.shading
+        weights = tuple((p._version, p.data_ptr()) for p in self.model.model.parameters())
         return (tuple(sh.packed_parameters()), int(sh._specular_exponent), float(sh._ao), bool(self.model.inverse_ao), bool(sh.enable_specular),
-                self.model.initial_image_mode, id(self.model.model), ops._images_epoch, self._static_version, self.flow_fill_threads)
+                self.model.initial_image_mode, id(self.model.model), ops._images_epoch, self._static_version, self.flow_fill_threads,
+                ops.TRUNK_DATAFLOW, ops.FLOW_FILL_ONE, ops.DEVICE_SHARED, ops.SPLIT_F16, ops.FAST_F16, ops.routing_epoch(), weights)
 
     def _graph_ready(self, origin, next_origin):
         if not (self.graph and next_origin is not None and self.temporal and self.previous is not None and self._prefetched is not None):
@@ -297,7 +319,14 @@ class SuperResolutionPipeline:
         slot = self._prefetched[1]
         nxt = slot ^ 1
         cur = torch.cuda.current_stream()
-        ops.guards_poll(self.device)
+        try:
+            ops.guards_poll(self.device)
+        except RuntimeError:
+            # a spin kernel of the previous (replayed) frame timed out: that form is now off (ops.routing_epoch moved).  The captured
+            # frames hold exactly that launch -- drop them BEFORE the error leaves, so that whoever catches it and goes on gets
+            # frames on the fallback forms (eagerly first, then captured again)
+            self._graphs, self._graph_sig = [None, None], None
+            raise
         sig = self._graph_signature()
         if sig != self._graph_sig:
             self._graphs, self._graph_sig = [None, None], sig

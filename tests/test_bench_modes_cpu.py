@@ -169,3 +169,68 @@ bench.main(sys.argv[1:], make_local_renderer=Local)
                  0, tmp_path, nproc=1)
     _check_line(d1, 1)
     assert d1["hit_pixels"] > 50 and d1["cpu_baseline"]["unit"] == "frames/s"
+
+
+def test_kernel_tally_and_gap_accounting():
+    """The default line's ``frame_time``: what part of a frame is NOT inside a main-stream kernel, and the host's enqueue time --
+    an outlier run must explain itself from the one record (gpurun_out/r04_bench0.json had 0.53 ms of gap and no
+    field that said so)."""
+    sys.path.insert(0, ROOT)
+    import bench
+    K = 4
+    records = []
+    for _ in range(K):
+        records += [("assemble_input_kernel", 0.0, 0.04), ("trunk_pack_input_kernel", 0.0, 0.016), ("trunk_dataflow_kernel", 206e9, 0.60),
+                    ("flow_fill_one_kernel", 0.0, 0.045), ("conv3x3_split_ups3_kernel", 38.2e9, 0.14), ("conv3x3_split_ups3_kernel", 152.9e9, 0.46),
+                    ("conv3x3_split_tail_kernel", 167e9, 0.47), ("tail_finish_kernel", 0.0, 0.05)]
+    per = bench.tally_kernels(records)
+    assert per["conv3x3_split_ups3_kernel"][2] == 2 * K and abs(per["conv3x3_split_ups3_kernel"][1] - K * 0.60e-3) < 1e-12
+    g = bench.gap_accounting(2.30, per, K, [0.9, 1.0, 1.1, 2.9])
+    main = 0.04 + 0.016 + 0.60 + 0.14 + 0.46 + 0.47 + 0.05
+    assert abs(g["main_stream_kernels_ms_per_frame"] - main) < 1e-9
+    assert abs(g["gap_ms_per_frame"] - (2.30 - main)) < 1e-9                       # the flow fill runs on the render stream: not in the sum
+    assert abs(g["side_stream_kernels_ms_per_frame"] - 0.045) < 1e-9
+    assert g["host_enqueue_ms_max"] == 2.9 and abs(g["host_enqueue_ms_per_frame"] - 1.475) < 1e-9 and g["host_enqueue_ms_median"] == 1.1
+    # kernels without matrix work never become the roofline's dominant kernel
+    dom = max(((n, v) for n, v in per.items() if v[0] > 0), key=lambda kv: kv[1][1])
+    assert dom[0] == "conv3x3_split_ups3_kernel" or dom[0] == "trunk_dataflow_kernel"
+
+
+def test_a_rank_that_never_joins_ends_the_run_with_rank_and_phase_named(tmp_path):
+    """the first real multi-rank run must fail loudly, not hang to the driver's limit.  World size 2, only rank 0
+    started: the rendezvous is bounded (BENCH_DIST_TIMEOUT_S, default 120 s), the process says which rank and phase, exits 3."""
+    import time
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29741", BENCH_DEVICE="cpu", BENCH_DIST_BACKEND="gloo",
+               WORLD_SIZE="2", RANK="0", LOCAL_RANK="0", BENCH_DIST_TIMEOUT_S="5", OMP_NUM_THREADS="2")
+    t0 = time.time()
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--mode", "train", "--gpus", "2", "--steps", "1", "--warmup", "0",
+                          "--train-batch", "2", "--train-frames", "2", "--train-crop", "16"],
+                         env=env, cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=150, text=True)
+    assert out.returncode == 3 and time.time() - t0 < 150
+    assert "rank 0/2: phase 'init_process_group'" in out.stderr
+    assert not [l for l in out.stdout.splitlines() if l.startswith("{")]
+
+
+def test_a_rank_that_stalls_in_the_first_collective_is_ended_by_the_deadline(tmp_path):
+    """Both ranks pass the rendezvous; rank 1 then never returns from its first all-reduce (a stuck RCCL bootstrap is a C call
+    that Python cannot interrupt: simulated by a sleeping all_reduce).  Rank 0's collective times out and names the phase; rank
+    1 is ended by the watchdog thread of ITS phase; the self-launching parent returns non-zero and prints no line."""
+    script = tmp_path / "stall.py"
+    script.write_text('''
+import os, sys, time
+sys.path.insert(0, %r)
+import torch.distributed as dist
+import bench
+if os.environ.get("RANK") == "1":
+    dist.all_reduce = lambda *a, **k: time.sleep(600)
+bench.main(sys.argv[1:])
+''' % ROOT)
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", BENCH_DEVICE="cpu", BENCH_DIST_BACKEND="gloo", BENCH_DIST_TIMEOUT_S="5", OMP_NUM_THREADS="2")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT"):
+        env.pop(k, None)
+    out = subprocess.run([sys.executable, str(script), "--mode", "train", "--gpus", "2", "--steps", "1", "--warmup", "0",
+                          "--train-batch", "2", "--train-frames", "2", "--train-crop", "16"],
+                         env=env, cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=150, text=True)
+    assert out.returncode != 0
+    assert "phase 'first collective (all-reduce)'" in out.stderr
+    assert not [l for l in out.stdout.splitlines() if l.startswith("{")]

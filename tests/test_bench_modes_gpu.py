@@ -30,6 +30,10 @@ def test_tiled_mode_two_ranks_on_one_gpu_composite_and_output_equal_one_rank():
     two = _bench(common, 2, 29812)
     serial = _bench(common + ["--no-overlap"], 2, 29813)
     assert two["n_gpus"] == 2 and two["ranks_joined"] == 2 and one["n_gpus"] == 1
+    # ranks that share a device never take the all-resident spin kernels (two processes' grids interleaved on the CUs would
+    # wait for each other until the deadline) -- in EVERY mode, not only the default one
+    for d in (one, two, serial):
+        assert d["config"]["spin_kernel_forms"] == {"trunk_dataflow": False, "flow_fill_one": False}
     assert "side HIP stream" in two["config"]["overlap"] and serial["config"]["overlap"] == "none"
     # tiles walk the global ray: the two-tile composite IS the unsplit render; strips reproduce the whole frame
     assert one["hit_pixels"] == two["hit_pixels"] == serial["hit_pixels"] > 1000
@@ -41,3 +45,13 @@ def test_default_mode_two_ranks_on_one_gpu():
     d = _bench(["--steps", "6", "--warmup", "2", "--no-cpu-baseline", "--no-fast-mode", "--no-exact-leg"], 2, 29814)
     assert d["n_gpus"] == 2 and d["ranks_joined"] == 2 and d["scaling"] == "weak" and d["value"] > 0
     assert d["config"]["frames_per_rank"] == 6
+    assert d["config"]["spin_kernel_forms"] == {"trunk_dataflow": False, "flow_fill_one": False}
+    ft = d["frame_time"]
+    assert ft["gap_ms_per_frame"] == pytest.approx(d["ms_per_step"] - ft["main_stream_kernels_ms_per_frame"]) and ft["host_enqueue_ms_per_frame"] > 0
+
+
+def test_train_mode_on_the_gpu_reports_clips_per_rank():
+    """``config.clips_per_rank`` was overwritten by the per-kernel tally on the GPU path (the line a SCALE run emits)."""
+    d = _bench(["--mode", "train", "--steps", "2", "--warmup", "1", "--train-batch", "4", "--train-frames", "3", "--no-cpu-baseline"], 1, 29815)
+    assert d["config"]["clips_per_rank"] == 4 and d["unit"] == "clips/s" and d["value"] > 0
+    assert d["roofline"]["kernels"] and all(v["frac"] > 0 for v in d["roofline"]["kernels"].values())

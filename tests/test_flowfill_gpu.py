@@ -122,3 +122,24 @@ def test_a_fill_that_times_out_reports_through_the_guard_word_and_the_three_laun
         ops.FLOW_FILL_ONE = True
         torch.cuda.synchronize()
         ops._range_state(dev)["buf"][ops._FILL_ERROR_SLOT] = 0
+
+
+def test_the_flag_epoch_wraps_and_the_ticket_returns_to_zero():
+    """the hand-off words must not grow without bound.  The ticket counts 0 .. ntiles - 1 inside ONE launch and is zero
+    between launches (whatever ntiles is: 40 tiles here, not a power of two); the flag counts completed launches and the wait
+    compares it wrap-safely -- started two launches before 2^32 the fill stays right across the wrap."""
+    from isosurfacesuperresolution_amd import ops
+    gb = _gbuffer(270, 480, 11, "blobs")
+    good = ops.fill_flow_gbuffer(gb, one_launch=False).clone()
+    assert torch.equal(ops.fill_flow_gbuffer(gb, one_launch=True), good)
+    torch.cuda.synchronize()
+    ws = ops._fill_ws[(gb.device, 270, 480, torch.cuda.current_stream().cuda_stream)].view(torch.int32)
+    sync = ws.numel() - 16                                      # [0] ticket, [1] flag (csrc/sr_frame.hip: isrFlowFillOne)
+    assert int(ws[sync].item()) == 0 and int(ws[sync + 1].item()) >= 1
+    ws[sync + 1] = -2                                           # 0xFFFFFFFE completed launches
+    for k in range(5):
+        assert torch.equal(ops.fill_flow_gbuffer(gb, one_launch=True), good), k
+        torch.cuda.synchronize()
+        assert int(ws[sync].item()) == 0
+    assert int(ws[sync + 1].item()) == 3                        # ... FFFFFFFF, 0, 1, 2, 3
+    ops.guards_publish(gb.device); torch.cuda.synchronize(); ops.guards_poll(gb.device)     # no launch gave up

@@ -91,3 +91,60 @@ def test_graph_is_recaptured_when_static_parameters_change():
     for (rgb_a, raw_a, _), (rgb_b, raw_b, _) in zip(a, b):
         assert torch.equal(raw_a, raw_b) and torch.equal(rgb_a, rgb_b)
     assert pipe.graph_replays > n0
+
+
+def test_a_timeout_under_graph_mode_drops_the_captured_frames_and_the_fallback_forms_take_over():
+    """a captured frame holds the dataflow-trunk launch, its workspace pointers and guard words.  A launch that times
+    out (device-induced fault) raises at the next frame's start; the captured frames are dropped before the error leaves, the
+    next frames run on the per-layer kernels (eagerly, then captured again) and equal the eager pipeline bit for bit."""
+    from isosurfacesuperresolution_amd import ops
+    lib = ops._sr()
+    _, mk, V = _pipes()
+    seq = [(k, k + 1) for k in range(4)]
+    eager = mk(False)
+    ref = _run(eager, V, seq + [(4, 5), (5, 6), (6, 7), (7, 8)])
+    pipe = mk(True)
+    try:
+        got = _run(pipe, V, seq)
+        assert pipe.graph_replays >= 1 and all(g is not None for g in pipe._graphs)
+        lib.isrDebugSetTrunkFault(5, 200000)                     # tile 5 never publishes, 2 ms deadline: the REPLAYED launch reads these
+        # (the fault switches are launch parameters: a captured launch keeps the values of its capture -- so capture again with them)
+        pipe._graphs, pipe._graph_sig = [None, None], None
+        pipe.frame(V.orbit_camera(4), V.orbit_camera(5))         # eager warm-up + capture of the faulty launch
+        lib.isrDebugSetTrunkFault(-1, 0)
+        torch.cuda.synchronize()
+        with pytest.raises(RuntimeError, match="timed out waiting for its neighbours"):
+            pipe.frame(V.orbit_camera(5), V.orbit_camera(6))
+        assert ops.TRUNK_DATAFLOW is False and pipe._graphs == [None, None]
+        # go on: a new sequence from frame 4 (the frame that was lost) on the fallback forms
+        pipe.reset()
+        eager.reset()
+        a = _run(eager, V, [(4, 5), (5, 6), (6, 7), (7, 8)])
+        b = _run(pipe, V, [(4, 5), (5, 6), (6, 7), (7, 8)])
+        for (rgb_a, raw_a, _), (rgb_b, raw_b, _) in zip(a, b):
+            assert torch.equal(raw_a, raw_b) and torch.equal(rgb_a, rgb_b)
+        assert all(g is not None for g in pipe._graphs)          # captured again, without the dataflow trunk
+    finally:
+        lib.isrDebugSetTrunkFault(-1, 0)
+        ops.TRUNK_DATAFLOW = True
+        torch.cuda.synchronize()
+        ops._range_state("cuda")["buf"][ops._TRUNK_ERROR_SLOT] = 0
+
+
+def test_an_in_place_weight_update_invalidates_the_captured_frames():
+    """load_state_dict bumps the weights' versions; the eager path then builds new split images and drops the old
+    ones, which a captured frame would keep reading.  The signature carries every parameter's (version, address)."""
+    _, mk, V = _pipes()
+    pipe, eager = mk(True), mk(False)
+    seq = [(k, k + 1) for k in range(4)]
+    _run(pipe, V, seq)
+    assert all(g is not None for g in pipe._graphs)
+    net = pipe.model.model
+    with torch.no_grad():
+        sd = {k: v * 0.9 for k, v in net.state_dict().items()}
+    net.load_state_dict(sd)
+    pipe.reset(); eager.reset()
+    a = _run(eager, V, seq)
+    b = _run(pipe, V, seq)
+    for (rgb_a, raw_a, _), (rgb_b, raw_b, _) in zip(a, b):
+        assert torch.equal(raw_a, raw_b) and torch.equal(rgb_a, rgb_b)

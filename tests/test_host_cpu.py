@@ -673,3 +673,12 @@ def test_prefetched_composite_hands_out_frames_in_request_order_on_the_cpu():
         render_fn(ref, key, None)
         assert torch.equal(got, PR.composite(ref.unsqueeze(0)))
     assert len(src.timeline) == 3 and all(v >= 0 for v in src.phase_ms())
+    # a key is handed out once: asking again for a frame that was already taken renders it again (a looping sequence of period
+    # <= 2, or the same index after the camera path changed, must not get the composite that still sits in a slot)
+    calls.clear()
+    d = src.take(5).clone()
+    src.start(0)
+    e = src.take(0).clone()
+    f = src.take(0).clone()
+    assert calls == [5, 0, 0]
+    assert torch.equal(d, c) and torch.equal(e, a) and torch.equal(f, a)

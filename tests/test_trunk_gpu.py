@@ -280,3 +280,35 @@ def test_multi_tile_trunk_gives_up_loudly_when_a_tile_never_publishes():
         lib.isrDebugSetTrunkFault(-1, 0)
         torch.cuda.synchronize()
         st["buf"][ops._TRUNK_ERROR_SLOT] = 0
+
+
+def test_multi_round_launch_outlives_its_timeout_because_the_deadline_is_per_wait():
+    """a healthy multi-round launch must not fail because it LASTS longer than the limit.  1 020 tiles = 4 rounds
+    (~2.5 ms); the limit is shortened to 0.2 ms per round (0.8 ms per wait): counted from the kernel's start -- the earlier form --
+    every wait after 0.2 ms would have given up; per wait nothing comes near it.  Result bit-identical, error word clean."""
+    from isosurfacesuperresolution_amd import ops
+    lib = ops._sr()
+    g = torch.Generator().manual_seed(9)
+    convs = [(((torch.rand(64, 24 if k == 0 else 64, 3, 3, generator=g) - 0.5) * 0.15).cuda(), ((torch.rand(64, generator=g) - 0.5) * 0.2).cuda())
+             for k in range(21)]
+    x = ((torch.rand(1, 24, 540, 960, generator=g) - 0.4)).cuda()
+    st = ops._range_state(x.device)
+    try:
+        with torch.no_grad():
+            good = ops.trunk_dataflow(x, convs)
+            torch.cuda.synchronize()
+            ops.trunk_check()
+            lib.isrDebugSetTrunkFault(-1, 20000)                # no faulty tile, 0.2 ms x rounds
+            t0, t1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            t0.record()
+            short = ops.trunk_dataflow(x, convs)
+            t1.record()
+            lib.isrDebugSetTrunkFault(-1, 0)
+            torch.cuda.synchronize()
+            assert t0.elapsed_time(t1) > 0.4                     # the launch did last longer than the 0.2 ms the old form allowed
+            assert int(st["buf"][ops._TRUNK_ERROR_SLOT].item()) == 0
+            assert torch.equal(short, good)
+    finally:
+        lib.isrDebugSetTrunkFault(-1, 0)
+        torch.cuda.synchronize()
+        st["buf"][ops._TRUNK_ERROR_SLOT] = 0
