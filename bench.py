@@ -37,11 +37,12 @@ SPLIT_KERNEL_PREFIXES = ("conv3x3_split", "resblock_split", "trunk_dataflow", "t
 def tally_kernels(records):
     """[(kernel name, algorithmic flops, ms)] of ops.profile_records() -> {name: [flops, seconds, launches]}."""
     out = {}
-    for name, flops, ms in records:
+    for name, flops, ms, *weight in records:          # (an optional 4th element: the record stands for that many launches)
+        w = weight[0] if weight else 1
         d = out.setdefault(name, [0.0, 0.0, 0])
-        d[0] += flops
-        d[1] += ms * 1e-3
-        d[2] += 1
+        d[0] += flops * w
+        d[1] += ms * 1e-3 * w
+        d[2] += w
     return out
 
 
@@ -371,7 +372,10 @@ def run_infer(args, job):
     # (hipExtLaunchKernelGGL inside the libraries, on the stream the kernels run on): unlike
     # hipEventRecord they add no barrier packets / cache flushes to the timed stream.
     prof_timed = os.environ.get("BENCH_PROFILE_TIMED", "1") != "0" and not pipe.graph
-    ops.profile_enable(prof_timed)
+    # the timed region carries events on the CONVOLUTION dispatches only (as every round did); the frame's small kernels are timed
+    # in a pass of their own afterwards (BENCH_PROFILE_SMALL=1: inside the timed region too -- an experiment)
+    prof_small_timed = os.environ.get("BENCH_PROFILE_SMALL", "0") == "1"
+    ops.profile_enable(prof_timed, small_kernels=prof_small_timed)
     renderer.profile_enable(prof_timed)
     replays0 = pipe.graph_replays
     sync()
@@ -391,13 +395,24 @@ def run_infer(args, job):
         # the per-kernel pass: the same K frames launched eagerly with the dispatch-packet events on (outside the timed region)
         pipe.graph = False
         pipe.reset()
-        ops.profile_enable(True)
+        ops.profile_enable(True, small_kernels=True)
         renderer.profile_enable(True)
         for k in range(K):
             pipe.frame(origins[Wm + k], origins[Wm + k + 1] if overlap and k + 1 < K else None)
         sync()
         pipe.graph = True
     records = ops.profile_records()
+    if prof_timed and not prof_small_timed:
+        # the small kernels' durations: the same frames once more, eagerly, outside the timed region
+        n_small = min(K, 10)
+        pipe.reset()
+        ops.profile_enable(True, small_kernels=True)
+        for k in range(n_small):
+            pipe.frame(origins[Wm + k], origins[Wm + k + 1] if overlap and k + 1 < n_small else None)
+        sync()
+        scale = K / float(n_small)
+        records += [(n, f, ms, scale) for n, f, ms in ops.profile_records() if f == 0.0]      # weighted to the K frames `per` is normalised by
+        ops.profile_enable(prof_timed)
     ops.trunk_check()                     # no dataflow launch of the timed region gave up on a neighbour (the error word is sticky)
     switches = ops.debug_switches()
     # an ablation (MFMAs skipped, stores skipped, stamp buffers) must never be behind a reported number; a forced kernel form

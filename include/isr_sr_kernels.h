@@ -346,7 +346,8 @@ int isrConvTailFinishFramePacked(const void* xps, const void* wq6, const float* 
 
 /* Optional per-dispatch timing of isrConv3x3Forward for benchmarks: while enabled, every forward
  * dispatch carries a start/stop event pair on its own packet (no extra stream operations).
- * isrProfileEnable(1) clears the records and starts recording, (0) stops.  After synchronising the
+ * isrProfileEnable(1) clears the records and starts recording, (0) stops; (2) also records the frame's small kernels
+ * (input assembly, trunk input packing, flow fill, tail finishing: variants 25-29, zero flops).  After synchronising the
  * stream, record i gives variant = 2*MT + upsample (MT = 1|2 M tiles of 32 output channels), the
  * algorithmic FLOPs 2*9*Cin*Cout*N*H*W of the dispatch and its duration in ms. */
 int isrProfileEnable(int on);

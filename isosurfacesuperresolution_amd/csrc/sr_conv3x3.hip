@@ -1682,6 +1682,7 @@ constexpr int WGRAD_MAX_SLABS = 512;
 // (hipExtLaunchKernelGGL), so no extra barrier packets or cache flushes perturb the stream.
 struct ProfileRecord { int variant; double flops; hipEvent_t e0, e1; };
 static bool g_profile = false;
+static bool g_profile_small = false;      // isrProfileEnable(2): also the frame's small kernels (variants >= ISR_VARIANT_TRUNK_PACK)
 static std::vector<ProfileRecord> g_records;
 static std::vector<hipEvent_t> g_event_pool;
 static size_t g_pool_used = 0;
@@ -1697,7 +1698,7 @@ static hipEvent_t pool_event()
 
 void isr_profile_record(int variant, double flops, hipEvent_t* e0, hipEvent_t* e1)
 {
-    if (!g_profile) return;
+    if (!g_profile || (variant >= ISR_VARIANT_TRUNK_PACK && !g_profile_small)) return;
     *e0 = pool_event(); *e1 = pool_event();
     g_records.push_back({ variant, flops, *e0, *e1 });
 }
@@ -1717,6 +1718,7 @@ extern "C" {
 int isrProfileEnable(int on)
 {
     g_profile = on != 0;
+    g_profile_small = on == 2;
     g_records.clear();
     g_pool_used = 0;
     return 0;

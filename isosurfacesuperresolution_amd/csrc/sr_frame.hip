@@ -18,13 +18,13 @@
 #include "../../include/isr_sr_kernels.h"
 #include "sr_finish.h"
 #include "sr_profile.h"
+#include "sr_warp_exact.h"
 
 namespace {
 
-__device__ __forceinline__ void src_index(int dst, float scale, int in_size, int& i0, int& i1, float& l1)
-{
-    isr_src_index(dst, scale, in_size, i0, i1, l1);
-}
+__device__ __forceinline__ void src_index(int dst, float scale, int in_size, int& i0, int& i1, float& l1) { isr_src_index_rn(dst, scale, in_size, i0, i1, l1); }
+__device__ __forceinline__ float bilerp_rn(float hy, float hx, float ly, float lx, float a, float b, float c, float d) { return isr_bilerp_rn(hy, hx, ly, lx, a, b, c, d); }
+__device__ __forceinline__ float pixel_grid(int i, int n) { return isr_pixel_grid(i, n); }
 
 struct AssembleParams {
     const float* gbuf;      // [h][w][12]
@@ -94,6 +94,7 @@ __global__ __launch_bounds__(256) void assemble_input_kernel(const AssembleParam
     const float* fy = p.flow + plane;
     const float sx_scale = 0.5f * (float)(W - 1), sy_scale = 0.5f * (float)(H - 1);
     for (int dy = 0; dy < 4; ++dy) {
+#pragma clang fp contract(off)
         const int Y = 4 * y + dy;
         int y0, y1; float ly;
         src_index(Y, 0.25f, p.h, y0, y1, ly);
@@ -102,37 +103,38 @@ __global__ __launch_bounds__(256) void assemble_input_kernel(const AssembleParam
             int x0, x1; float lx;
             src_index(X, 0.25f, p.w, x0, x1, lx);
             const float hy = 1.f - ly, hx = 1.f - lx;
-            // flow scaled by (-2, +2) then bilinearly upsampled (videotools.py:65-70)
-            const float f00x = fx[y0 * p.w + x0] * -2.0f, f01x = fx[y0 * p.w + x1] * -2.0f;
-            const float f10x = fx[y1 * p.w + x0] * -2.0f, f11x = fx[y1 * p.w + x1] * -2.0f;
-            const float f00y = fy[y0 * p.w + x0] * 2.0f, f01y = fy[y0 * p.w + x1] * 2.0f;
-            const float f10y = fy[y1 * p.w + x0] * 2.0f, f11y = fy[y1 * p.w + x1] * 2.0f;
-            const float flx = hy * (hx * f00x + lx * f01x) + ly * (hx * f10x + lx * f11x);
-            const float fly = hy * (hx * f00y + lx * f01y) + ly * (hx * f10y + lx * f11y);
+            // flow scaled by (-2, +2) (exact) then bilinearly upsampled (videotools.py:65-70)
+            const float flx = bilerp_rn(hy, hx, ly, lx, fx[y0 * p.w + x0] * -2.0f, fx[y0 * p.w + x1] * -2.0f, fx[y1 * p.w + x0] * -2.0f, fx[y1 * p.w + x1] * -2.0f);
+            const float fly = bilerp_rn(hy, hx, ly, lx, fy[y0 * p.w + x0] * 2.0f, fy[y0 * p.w + x1] * 2.0f, fy[y1 * p.w + x0] * 2.0f, fy[y1 * p.w + x1] * 2.0f);
             // grid = linspace(-1, 1)[X] + flow ; sample position with align_corners=True
-            const float gx = (-1.0f + 2.0f * (float)X / (float)(W - 1)) + flx;
-            const float gy = (-1.0f + 2.0f * (float)Y / (float)(H - 1)) + fly;
-            const float sx = (gx + 1.0f) * sx_scale, sy = (gy + 1.0f) * sy_scale;
+            const float gx = pixel_grid(X, W) + flx;
+            const float gy = pixel_grid(Y, H) + fly;
+            const float gx1 = gx + 1.0f, gy1 = gy + 1.0f;
+            const float sx = gx1 * sx_scale, sy = gy1 * sy_scale;
             const float fx0 = floorf(sx), fy0 = floorf(sy);
-            const int ix0 = (int)fx0, iy0 = (int)fy0;
-            const float wx1 = sx - fx0, wy1 = sy - fy0, wx0 = 1.f - wx1, wy0 = 1.f - wy1;
+            const int ix0 = (int)fminf(fmaxf(fx0, -2.f), (float)W), iy0 = (int)fminf(fmaxf(fy0, -2.f), (float)H);
+            const float wx1 = sx - fx0, wy1 = sy - fy0;
+            const float wx0 = 1.f - wx1, wy0 = 1.f - wy1;
             const bool vx0 = (unsigned)ix0 < (unsigned)W, vx1 = (unsigned)(ix0 + 1) < (unsigned)W;
             const bool vy0 = (unsigned)iy0 < (unsigned)H, vy1 = (unsigned)(iy0 + 1) < (unsigned)H;
             const float w00 = wx0 * wy0, w01 = wx1 * wy0, w10 = wx0 * wy1, w11 = wx1 * wy1;
-            const size_t b00 = (size_t)iy0 * W + ix0;
+            const long long b00 = (long long)iy0 * W + ix0;
 #pragma unroll
             for (int c = 0; c < 6; ++c) {
                 const float* q = p.prev + (size_t)c * hplane;
                 float v00 = (vy0 && vx0) ? q[b00] : 0.f, v01 = (vy0 && vx1) ? q[b00 + 1] : 0.f;
                 float v10 = (vy1 && vx0) ? q[b00 + W] : 0.f, v11 = (vy1 && vx1) ? q[b00 + W + 1] : 0.f;
-                float r;
                 if (c == 0) {   // special mask: [-1,1] -> [0,1] before sampling, back after (zero padding == -1)
-                    v00 = (vy0 && vx0) ? v00 * 0.5f + 0.5f : 0.f; v01 = (vy0 && vx1) ? v01 * 0.5f + 0.5f : 0.f;
-                    v10 = (vy1 && vx0) ? v10 * 0.5f + 0.5f : 0.f; v11 = (vy1 && vx1) ? v11 * 0.5f + 0.5f : 0.f;
-                    r = (v00 * w00 + v01 * w01 + v10 * w10 + v11 * w11) * 2.0f - 1.0f;
-                } else {
-                    r = v00 * w00 + v01 * w01 + v10 * w10 + v11 * w11;
+                    const float h00 = v00 * 0.5f, h01 = v01 * 0.5f, h10 = v10 * 0.5f, h11 = v11 * 0.5f;
+                    v00 = (vy0 && vx0) ? h00 + 0.5f : 0.f; v01 = (vy0 && vx1) ? h01 + 0.5f : 0.f;
+                    v10 = (vy1 && vx0) ? h10 + 0.5f : 0.f; v11 = (vy1 && vx1) ? h11 + 0.5f : 0.f;
                 }
+                // ((v00 w00 + v01 w01) + v10 w10) + v11 w11, one rounding per operation
+                const float t00 = v00 * w00, t01 = v01 * w01, t10 = v10 * w10, t11 = v11 * w11;
+                float r = t00 + t01;
+                r = r + t10;
+                r = r + t11;
+                if (c == 0) { r = r * 2.0f; r = r - 1.0f; }
                 o[(size_t)(c * 16 + dy * 4 + dx) * plane] = r;
             }
         }
@@ -161,12 +163,11 @@ __global__ __launch_bounds__(256) void finish_frame_kernel(const FinishParams p)
 // it level by level with __syncthreads() in between -- no inter-kernel gaps, no grid sync.
 struct FillLevel { int h, w; size_t off; };     // v: [2][h][w] at off, m: [h][w] at off + 2*h*w
 
-// hy (hx a + lx b) + ly (hx c + lx d) with the roundings spelled out, so that both forms of the fill (three launches / one) produce
-// the same bits whatever the optimiser would have contracted in either
+// hy (hx a + lx b) + ly (hx c + lx d) with the roundings spelled out (seven, no FMA: inference/flowfill.py defines the fill in
+// elementwise operations and both forms of the kernel -- three launches / one -- produce its bits)
 __device__ __forceinline__ float fill_bilerp(float hy, float hx, float ly, float lx, float a, float b, float c, float d)
 {
-    const float t0 = __builtin_fmaf(lx, b, hx * a), t1 = __builtin_fmaf(lx, d, hx * c);
-    return __builtin_fmaf(ly, t1, hy * t0);
+    return bilerp_rn(hy, hx, ly, lx, a, b, c, d);
 }
 
 // mode 0: pull level 0 -> 1 over the whole grid; mode 1: one workgroup pulls levels 2..n and pushes

@@ -11,6 +11,7 @@
 #include <stdint.h>
 #include "../../include/isr_sr_kernels.h"
 #include "sr_finish.h"
+#include "sr_warp_exact.h"
 
 namespace {
 
@@ -523,27 +524,27 @@ struct RecurParams {
 
 struct WarpTaps { size_t b00; int ix0, iy0; float w00, w01, w10, w11; bool v00, v01, v10, v11; };
 
+// (operation for operation models/videotools.py: warp_upscale -- see sr_warp_exact.h)
 __device__ __forceinline__ WarpTaps warp_taps(const float* fx, const float* fy, int h, int w, int Y, int X)
 {
+#pragma clang fp contract(off)
     const int H = 4 * h, W = 4 * w;
     int y0, y1, x0, x1; float ly, lx;
-    isr_src_index(Y, 0.25f, h, y0, y1, ly);
-    isr_src_index(X, 0.25f, w, x0, x1, lx);
+    isr_src_index_rn(Y, 0.25f, h, y0, y1, ly);
+    isr_src_index_rn(X, 0.25f, w, x0, x1, lx);
     const float hy = 1.f - ly, hx = 1.f - lx;
     // flow scaled by (-2, +2), then bilinearly upsampled (videotools.py:65-70)
-    const float f00x = fx[y0 * w + x0] * -2.0f, f01x = fx[y0 * w + x1] * -2.0f;
-    const float f10x = fx[y1 * w + x0] * -2.0f, f11x = fx[y1 * w + x1] * -2.0f;
-    const float f00y = fy[y0 * w + x0] * 2.0f, f01y = fy[y0 * w + x1] * 2.0f;
-    const float f10y = fy[y1 * w + x0] * 2.0f, f11y = fy[y1 * w + x1] * 2.0f;
-    const float flx = hy * (hx * f00x + lx * f01x) + ly * (hx * f10x + lx * f11x);
-    const float fly = hy * (hx * f00y + lx * f01y) + ly * (hx * f10y + lx * f11y);
+    const float flx = isr_bilerp_rn(hy, hx, ly, lx, fx[y0 * w + x0] * -2.0f, fx[y0 * w + x1] * -2.0f, fx[y1 * w + x0] * -2.0f, fx[y1 * w + x1] * -2.0f);
+    const float fly = isr_bilerp_rn(hy, hx, ly, lx, fy[y0 * w + x0] * 2.0f, fy[y0 * w + x1] * 2.0f, fy[y1 * w + x0] * 2.0f, fy[y1 * w + x1] * 2.0f);
     // grid = linspace(-1, 1) + flow; bilinear sampler with align_corners=True and zero padding
-    const float gx = (-1.0f + 2.0f * (float)X / (float)(W - 1)) + flx;
-    const float gy = (-1.0f + 2.0f * (float)Y / (float)(H - 1)) + fly;
-    const float sx = (gx + 1.0f) * (0.5f * (float)(W - 1)), sy = (gy + 1.0f) * (0.5f * (float)(H - 1));
+    const float gx = isr_pixel_grid(X, W) + flx;
+    const float gy = isr_pixel_grid(Y, H) + fly;
+    const float gx1 = gx + 1.0f, gy1 = gy + 1.0f;
+    const float sx = gx1 * (0.5f * (float)(W - 1)), sy = gy1 * (0.5f * (float)(H - 1));
     const float fx0 = floorf(sx), fy0 = floorf(sy);
-    const int ix0 = (int)fx0, iy0 = (int)fy0;
-    const float wx1 = sx - fx0, wy1 = sy - fy0, wx0 = 1.f - wx1, wy0 = 1.f - wy1;
+    const int ix0 = (int)fminf(fmaxf(fx0, -2.f), (float)W), iy0 = (int)fminf(fmaxf(fy0, -2.f), (float)H);
+    const float wx1 = sx - fx0, wy1 = sy - fy0;
+    const float wx0 = 1.f - wx1, wy0 = 1.f - wy1;
     const bool vx0 = (unsigned)ix0 < (unsigned)W, vx1 = (unsigned)(ix0 + 1) < (unsigned)W;
     const bool vy0 = (unsigned)iy0 < (unsigned)H, vy1 = (unsigned)(iy0 + 1) < (unsigned)H;
     WarpTaps t;
@@ -599,8 +600,15 @@ __global__ __launch_bounds__(256) void recurrent_input_fwd_kernel(const RecurPar
         if (tp.v11) prev_output_at(raw, hplane, tp.b00 + W + 1, d);
 #pragma unroll
         for (int c = 0; c < 6; ++c) {
-            float r = a[c] * tp.w00 + bq[c] * tp.w01 + c_[c] * tp.w10 + d[c] * tp.w11;
-            if (c == 0) r = r * 2.0f - 1.0f;      // special mask: zero padding means "mask = -1"
+            float r;
+            {
+#pragma clang fp contract(off)
+                const float t00 = a[c] * tp.w00, t01 = bq[c] * tp.w01, t10 = c_[c] * tp.w10, t11 = d[c] * tp.w11;
+                r = t00 + t01;
+                r = r + t10;
+                r = r + t11;
+                if (c == 0) { r = r * 2.0f; r = r - 1.0f; }      // special mask: zero padding means "mask = -1"
+            }
             o[(size_t)(c * 16 + dy * 4 + dx) * plane] = r;
             wout[(size_t)c * hplane + (size_t)Y * W + X] = r;
         }

@@ -256,10 +256,11 @@ def debug_switches():
 _profile_on = False
 
 
-def profile_enable(on):
+def profile_enable(on, small_kernels=False):
+    """``small_kernels``: also the frame's kernels without matrix work (assembly, packing, flow fill, finishing)."""
     global _profile_on
     _profile_on = bool(on)
-    _sr().isrProfileEnable(1 if on else 0)
+    _sr().isrProfileEnable((2 if small_kernels else 1) if on else 0)
 
 
 def profile_is_on():

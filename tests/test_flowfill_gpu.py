@@ -143,3 +143,25 @@ def test_the_flag_epoch_wraps_and_the_ticket_returns_to_zero():
         assert int(ws[sync].item()) == 0
     assert int(ws[sync + 1].item()) == 3                        # ... FFFFFFFF, 0, 1, 2, 3
     ops.guards_publish(gb.device); torch.cuda.synchronize(); ops.guards_poll(gb.device)     # no launch gave up
+
+
+@pytest.mark.parametrize("h,w", [(270, 480), (135, 240), (37, 53), (65, 129), (300, 7), (2, 3)])
+@pytest.mark.parametrize("density", ["blobs", 0.02, 0.5])
+def test_fill_is_bit_identical_to_the_module_definition(h, w, density):
+    """inference/flowfill.py DEFINES the fill in elementwise operations (one rounding each); both kernel forms compute its bits --
+    against the definition evaluated on the CPU and by torch's own device kernels.  (The filled flow positions the warp of the
+    previous frame: 1e-9 of flow is 1e-6 pixels at 1080p, and the recurrence amplifies what reaches the network.)"""
+    from isosurfacesuperresolution_amd import ops
+    from isosurfacesuperresolution_amd.inference.flowfill import fill_flow
+    gb = _gbuffer(h, w, 13 * h + w, density)
+    gb[..., 8:10] *= 0.03
+    low = gb.permute(2, 0, 1).unsqueeze(0)
+    ref_cpu = fill_flow(low[:, 8:10].cpu(), (low[:, 3:4] != 0).cpu())
+    ref_dev = fill_flow(low[:, 8:10], low[:, 3:4] != 0)
+    assert torch.equal(ref_dev.cpu(), ref_cpu)
+    for one in (True, False):
+        if one and not ops._sr().isrFlowFillOneSupported(h, w):
+            continue
+        got = ops.fill_flow_gbuffer(gb, one_launch=one)
+        torch.cuda.synchronize()
+        assert torch.equal(got.cpu(), ref_cpu), (one, (got.cpu() - ref_cpu).abs().max().item())
