@@ -1,0 +1,111 @@
+"""The statistics harness (isosurfacesuperresolution_amd/stats.py = SuperresolutionNetwork/mainPSNR3_AllStats.py:71-377) on the CPU:
+its ingredients against reference-generated values (tests/golden/make_stats_fixtures.py imports the reference's utils), the table
+format, the recurrence and the accumulation."""
+import importlib.util
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from isosurfacesuperresolution_amd import models, stats, utils
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+G = np.load(os.path.join(HERE, "golden", "stats_reference.npz"))
+
+
+def stats_inputs():
+    spec = importlib.util.spec_from_file_location("make_stats_fixtures", os.path.join(HERE, "golden", "make_stats_fixtures.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)                       # (defines functions only; nothing of the reference is imported until main())
+    return mod.stats_inputs()
+
+
+def check_against_golden(device):
+    for tag, (pred, gt) in stats_inputs().items():
+        assert abs(pred.double().sum().item() + 2.0 * gt.double().sum().item() - float(G["sum_" + tag])) < 1e-6, "other random stream"
+        pred, gt = pred.to(device), gt.to(device)
+        m = (gt[:, 0:1] > 0.5).float()
+        assert abs(utils.MSSSIM()(pred, gt).item() - float(G["msssim_" + tag])) <= 1e-5, tag
+        assert abs(utils.SSIM()(pred, gt).item() - float(G["ssim_" + tag])) <= 1e-5, tag
+        assert abs(utils.PSNR()(pred, gt).item() - float(G["psnr_" + tag])) <= 1e-3, tag
+        assert abs(utils.PSNR()(pred, gt, mask=m).item() - float(G["psnr_masked_" + tag])) <= 1e-3 * max(1.0, float(G["psnr_masked_" + tag]) / 60), tag
+
+
+def test_ssim_msssim_psnr_match_the_reference_generated_values():
+    check_against_golden("cpu")
+
+
+def synthetic_clips(folder, clips=2, frames=3, h=48, w=64, seed=0):
+    """Clips in the dataset's .npy contract: a shaded blob that moves a little from frame to frame."""
+    os.makedirs(folder, exist_ok=True)
+    g = torch.Generator().manual_seed(seed)
+    for c in range(clips):
+        highs, lows, flows = [], [], []
+        for t in range(frames):
+            H, W = 4 * h, 4 * w
+            yy, xx = torch.meshgrid(torch.linspace(-1, 1, H), torch.linspace(-1, 1, W), indexing="ij")
+            cx, cy = 0.1 * c + 0.02 * t, -0.05 * c + 0.01 * t
+            r2 = (xx - cx) ** 2 + (yy - cy) ** 2
+            inside = (r2 < 0.45).float()
+            nz = torch.sqrt((0.45 - r2).clamp_min(1e-4) / 0.45)
+            n = torch.nn.functional.normalize(torch.stack([(xx - cx), (yy - cy), nz]), dim=0) * inside
+            depth = (0.5 + 0.2 * nz) * inside
+            ao = (0.6 + 0.4 * nz) * inside + (1 - inside)
+            high = torch.cat([(inside * 2 - 1).unsqueeze(0), n, depth.unsqueeze(0), ao.unsqueeze(0)])
+            high = high + 0.002 * torch.rand(high.shape, generator=g) * inside
+            low = torch.nn.functional.avg_pool2d(high[:5].unsqueeze(0), 4)[0]
+            low[0] = (low[0] > 0).float() * 2 - 1
+            highs.append(high); lows.append(low)
+            flows.append(torch.stack([torch.full((h, w), 0.01), torch.full((h, w), 0.005)]))
+        np.save(os.path.join(folder, "high_%05d.npy" % c), torch.stack(highs).numpy())
+        np.save(os.path.join(folder, "low_%05d.npy" % c), torch.stack(lows).numpy())
+        np.save(os.path.join(folder, "flow_%05d.npy" % c), torch.stack(flows).numpy())
+
+
+def test_run_statistics_writes_the_reference_tables(tmp_path):
+    folder = str(tmp_path / "clips")
+    synthetic_clips(folder)
+    out = str(tmp_path / "results")
+    res = stats.run_statistics([("Blob", [folder])], [{"name": "nearest", "path": None}, {"name": "bilinear", "path": None}], out,
+                               device="cpu", log=lambda *a: None)
+    for name in ("nearest", "bilinear"):
+        lines = open(os.path.join(out, "Stats_Blob_%s.txt" % name)).read().splitlines()
+        assert lines[0].split("\t") == list(stats.COLUMNS) and len(stats.COLUMNS) == 14          # mainPSNR3_AllStats.py:160-163
+        assert len(lines) == 3                                                                    # header + one row per clip
+        rows = np.array([[float(v) for v in l.split("\t")] for l in lines[1:]])
+        assert rows.shape == (2, 14) and np.isfinite(rows).all()
+        cols = res["Blob"][name]
+        assert cols["PSNR-normal"][2] == 2
+        assert abs(cols["PSNR-normal"][0] - rows[:, 0].mean()) < 1e-5 and abs(cols["SSIM-depth"][1] - rows[:, 6].var()) < 1e-9
+        hist = open(os.path.join(out, "Histogram_Blob_%s.txt" % name)).read().splitlines()
+        assert len(hist) == 1 + stats.NUM_BINS and hist[0].startswith("BinStart\tBinEnd\tL2ErrorMask")
+    assert res["Blob"]["bilinear"]["PSNR-normal"][0] > res["Blob"]["nearest"]["PSNR-normal"][0]      # smooth data: bilinear beats nearest
+    assert 0.5 < res["Blob"]["bilinear"]["SSIM-normal"][0] <= 1.0
+    summary = open(os.path.join(out, "Summary_Blob.txt")).read().splitlines()
+    assert len(summary) == 3 and summary[1].split("\t")[0] == "nearest" and summary[1].split("\t")[1] == "2"
+
+
+def test_statistics_of_one_frame_equal_the_ingredients_applied_by_hand(tmp_path):
+    folder = str(tmp_path / "clips")
+    synthetic_clips(folder, clips=1, frames=1)
+    low, high = (torch.from_numpy(np.load(os.path.join(folder, "%s_00000.npy" % k))) for k in ("low", "high"))
+    net = stats.SimpleUpsample(4, "bilinear")
+    st = stats.Statistics("cpu")
+    stats.run_clip(net, low, high, None, st)
+    row = st.sample_row()
+    pred, _ = net(torch.cat((low[0:1], torch.zeros(1, 96, *low.shape[2:])), dim=1))
+    pred = torch.cat([pred[:, 0:1].clamp(-1, 1), utils.ScreenSpaceShading.normalize(pred[:, 1:4], dim=1), pred[:, 4:6].clamp(0, 1)], dim=1)
+    b = 60
+    p, g = pred[:, :, b:-b, b:-b], high[0:1, :, b:-b, b:-b]
+    mask = g[:, 0:1] * 0.5 + 0.5
+    assert abs(row[0] - utils.PSNR()(p[:, 1:4], g[:, 1:4], mask=mask).item()) < 1e-4
+    blended = g + mask * (p - g)
+    assert abs(row[5] - utils.MSSSIM()(blended[:, 1:4], g[:, 1:4]).item()) < 1e-6
+    assert abs(row[6] - utils.MSSSIM()(blended[:, 4:5], g[:, 4:5]).item()) < 1e-6
+
+
+def test_frames_with_too_little_coverage_are_skipped():
+    st = stats.Statistics("cpu")
+    empty = torch.zeros(1, 6, 192, 256); empty[:, 0] = -1
+    assert st.add_timestep_sample(empty.clone(), empty, torch.zeros(1, 5, 48, 64)) is False and st.n == 0

@@ -1,0 +1,56 @@
+"""The statistics harness on the HIP path (SuperresolutionNetwork/mainPSNR3_AllStats.py:129-377): clips rendered by
+this package's ray-marcher, the table of a run on the MI355X against the table of the same run on the CPU path, and SSIM / MS-SSIM /
+PSNR on the device against the reference-generated values."""
+import argparse
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+OPT = argparse.Namespace(upsample='bilinear', reconType='residual', useBN=False, numResidualLayers=10)
+
+
+def test_ssim_msssim_psnr_on_the_device_match_the_reference_generated_values():
+    from test_stats_cpu import check_against_golden
+    check_against_golden("cuda")
+
+
+def test_statistics_table_of_the_hip_run_equals_the_cpu_run(tmp_path):
+    from isosurfacesuperresolution_amd import inference, models, stats, volumes as V
+    from isosurfacesuperresolution_amd.dataset_video import render_clip
+    r = inference.DirectRenderer()
+    r.load_dense(V.ejecta(128))
+    folder = tmp_path / "clips"
+    folder.mkdir()
+    for c in range(2):
+        origins = [V.orbit_camera(6 * c + k, K=64, distance=1.9, pitch=0.3) for k in range(4)]
+        high, low, flow = render_clip(r, origins, (128, 72), isovalue=0.34, ao_samples=4, ao_radius=0.05)
+        for name, arr in (("high", high), ("low", low), ("flow", flow)):
+            np.save(folder / ("%s_%05d.npy" % (name, c)), arr)
+    torch.manual_seed(11)
+    net = models.createNetwork('EnhanceNet', 4, 101, [0, 1, 2, 3, 4], 6, OPT)
+    with torch.no_grad():                                    # a network that stays near the bilinear baseline: finite, meaningful SSIM
+        net.postblock[8].weight.mul_(0.05); net.postblock[8].bias.mul_(0.05)
+    state = {k: v.clone() for k, v in net.state_dict().items()}
+
+    def specs():
+        m = models.createNetwork('EnhanceNet', 4, 101, [0, 1, 2, 3, 4], 6, OPT)
+        m.load_state_dict(state)
+        return [{"name": "bilinear", "path": None}, {"name": "enhancenet", "model": m}]
+    torch.set_num_threads(max(1, min(16, torch.get_num_threads())))
+    res_gpu = stats.run_statistics([("Ejecta", [str(folder)])], specs(), str(tmp_path / "gpu"), device="cuda", log=lambda *a: None)
+    res_cpu = stats.run_statistics([("Ejecta", [str(folder)])], specs(), str(tmp_path / "cpu"), device="cpu", log=lambda *a: None)
+    for name in ("bilinear", "enhancenet"):
+        rows = {}
+        for dev in ("gpu", "cpu"):
+            lines = open(os.path.join(str(tmp_path / dev), "Stats_Ejecta_%s.txt" % name)).read().splitlines()
+            assert lines[0].split("\t") == list(stats.COLUMNS) and len(lines) == 3
+            rows[dev] = np.array([[float(v) for v in l.split("\t")] for l in lines[1:]])
+        assert np.isfinite(rows["gpu"]).all() and np.isfinite(rows["cpu"]).all()
+        assert np.abs(rows["gpu"][:, 0:5] - rows["cpu"][:, 0:5]).max() <= 1e-3, (name, rows)            # PSNR, dB
+        assert np.abs(rows["gpu"][:, 5:10] - rows["cpu"][:, 5:10]).max() <= 1e-5, (name, rows)          # MS-SSIM
+        assert np.allclose(rows["gpu"][:, 10:], rows["cpu"][:, 10:], rtol=1e-3, atol=1e-7)
+        assert res_gpu["Ejecta"][name]["PSNR-normal"][2] == 2
+    assert rows["gpu"][:, 5].min() > 0.3 and rows["gpu"][:, 0].min() > 10.0                             # a sensible network, not noise
