@@ -344,6 +344,30 @@ int isrConvTailFinishFramePacked(const void* xps, const void* wq6, const float* 
                                  const float* net_input, float* next_prev, float* rgb, int h, int w, long long xpsPlane,
                                  const float* shading24, int exponent, float ao_strength, int inverse_ao, int enable_specular, void* stream);
 
+/* PHASE-DECOMPOSED x2-upsampling convolution (csrc/sr_conv_upsp.h): y = act(conv3x3(U2(x), w) + bias) for EnhanceNet's two
+ * upsampling layers (SuperresolutionNetwork/models/enhancenet.py:113-124: nn.Upsample(scale_factor=2, mode='bilinear') + Conv2d(64, 64, 3)),
+ * 64 -> 64 channels, one image, input and output PACKED-SPLIT (the layout of isrConv3x3ForwardSplitPacked: [2 parts][8 groups][plane
+ * units]).  U2 is linear, so the result at the high-resolution pixel (2y + py, 2x + px) is a 3 x 3 convolution of the LOW-resolution
+ * image with one of four effective weight sets: no interpolation at run time, the operands are copied into LDS as the producer left
+ * them.  The output's one-pixel frame (where the convolution's zero padding drops taps) is computed exactly by a small kernel of its
+ * own from the fp32 weights `w`.  Same accuracy against an fp64 convolution as isrConv3x3ForwardSplit(upsample2x = 1), not the same bits.
+ *   isrConvUpsPhasePrepare(w [64][64][3][3] fp32, wq, scratch, stream): wq = isrConvUpsPhaseWeightBytes() bytes (the four stacked
+ *     images, one scale), scratch = isrConvUpsPhaseScratchBytes() bytes (the effective weights in fp32; may be freed once the stream
+ *     has passed this call);
+ *   isrConvUpsPhase(xps [64][h][wd] packed, wq, w, bias [64] or NULL, ps [64][2h][2wd] packed, h, wd, act (NONE / RELU / LEAKY), slope,
+ *     xpsPlane, psPlane (units), stream).  isrConvUpsPhaseSupported(64, 64, h, wd, xpsPlane, psPlane) -> 1 if the launch takes the shape.
+ * isrPackSplit: an fp32 tensor [C][H][W] (planes xPlane floats apart, C a multiple of 8) as a packed-split tensor (what a producer's
+ * packed epilogue writes).  isrTrunkDataflowPackedResult: where isrTrunkDataflow leaves its result packed-split inside its workspace.
+ * Return codes as isrConv3x3ForwardSplit. */
+long long isrConvUpsPhaseWeightBytes(void);
+long long isrConvUpsPhaseScratchBytes(void);
+int isrConvUpsPhasePrepare(const float* w, void* wq, void* scratch, void* stream);
+int isrConvUpsPhaseSupported(int Cin, int Cout, int h, int wd, long long xpsPlane, long long psPlane);
+int isrConvUpsPhase(const void* xps, const void* wq, const float* w, const float* bias, void* ps, int h, int wd, int act, float slope,
+                    long long xpsPlane, long long psPlane, void* stream);
+int isrPackSplit(const float* x, void* ps, int C, int H, int W, long long xPlane, long long psPlane, void* stream);
+int isrTrunkDataflowPackedResult(int cin0, int H, int W, long long* offsetBytes, long long* planeUnits);
+
 /* Optional per-dispatch timing of isrConv3x3Forward for benchmarks: while enabled, every forward
  * dispatch carries a start/stop event pair on its own packet (no extra stream operations).
  * isrProfileEnable(1) clears the records and starts recording, (0) stops; (2) also records the frame's small kernels

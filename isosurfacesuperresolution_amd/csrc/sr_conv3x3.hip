@@ -1698,7 +1698,7 @@ static hipEvent_t pool_event()
 
 void isr_profile_record(int variant, double flops, hipEvent_t* e0, hipEvent_t* e1)
 {
-    if (!g_profile || (variant >= ISR_VARIANT_TRUNK_PACK && !g_profile_small)) return;
+    if (!g_profile || (variant >= ISR_VARIANT_TRUNK_PACK && variant <= ISR_VARIANT_UPS_FRAME && !g_profile_small)) return;
     *e0 = pool_event(); *e1 = pool_event();
     g_records.push_back({ variant, flops, *e0, *e1 });
 }

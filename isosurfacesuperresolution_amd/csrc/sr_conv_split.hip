@@ -28,6 +28,7 @@
 // fetched from L2 into registers under the previous k-step's MFMAs; 80 KB of LDS -> two workgroups per CU, one's
 // staging and barriers under the other's MFMAs.  Per tap and k-step: 8 ds_read_b128 feed 12 MFMAs.
 #include <cstdlib>
+#include <cstring>
 
 #include "sr_split_common.h"
 
@@ -1115,6 +1116,7 @@ __global__ __launch_bounds__(256) void prepare_weights_split_many_kernel(const P
 
 #include "sr_conv_ups3.h"       // the three-workgroups-per-CU upsampling kernel: same translation unit, same parameter block
 #include "sr_conv_ups4.h"       // the role-split upsampling kernel (producer / consumer waves)
+#include "sr_conv_upsp.h"       // the phase-decomposed upsampling kernel (no interpolation at run time; packed-split in and out)
 #include "sr_conv_block2.h"     // two chained convolutions of a batch of small images in one launch (training trunk)
 
 __device__ u32x4 g_split_zero_unit[4];      // zero initialised: source of the zero-padding units of the LDS-DMA staging
@@ -1334,6 +1336,69 @@ int isrConv3x3ForwardSplitFromPacked(const void* xps, const void* wq, const floa
                                           xpsPlane, xpsPlane * Cin, yPlane, yPlane * Cout, rPlane, rPlane * Cout, stream);
     g_ps_in = false; g_ps_out = false; g_split_algo = algo; g_split_small = small;
     return rc;
+}
+
+// ---- phase-decomposed upsampling convolution (sr_conv_upsp.h) -------------------------------------------------------------------
+long long isrConvUpsPhaseWeightBytes(void) { return isrConvSplitWeightBytes(64, 256); }
+long long isrConvUpsPhaseScratchBytes(void) { return 4LL * 64 * 64 * 9 * (long long)sizeof(float); }
+
+int isrConvUpsPhasePrepare(const float* w, void* wq, void* scratch, void* stream)
+{
+    if (!w || !wq || !scratch) return -1;
+    hipLaunchKernelGGL(ups_phase_weights_kernel, dim3((4 * 64 * 64 + 255) / 256), dim3(256), 0, (hipStream_t)stream, w, (float*)scratch, 64, 64);
+    return isrConvSplitPrepare((const float*)scratch, wq, 256, 64, stream);
+}
+
+int isrConvUpsPhaseSupported(int Cin, int Cout, int h, int w, long long xpsPlane, long long psPlane)
+{
+    if (Cin != 64 || Cout != 64 || h < 1 || w < 1) return 0;
+    if (xpsPlane < (long long)h * w || psPlane < 4LL * h * w) return 0;
+    if (xpsPlane * 16 * 16 > 0x7fffffffLL || psPlane * 16 * 16 > 0x7fffffffLL) return 0;          // 32-bit buffer offsets
+    return 1;
+}
+
+int isrConvUpsPhase(const void* xps, const void* wq, const float* w, const float* bias, void* ps, int h, int wd, int act, float slope,
+                    long long xpsPlane, long long psPlane, void* stream)
+{
+    unsigned* const rangeFlag = isr_take_range_flag();
+    if (!xps || !wq || !w || !ps || (act != ISR_ACT_NONE && act != ISR_ACT_RELU && act != ISR_ACT_LEAKY)) return -1;
+    if (!isrConvUpsPhaseSupported(64, 64, h, wd, xpsPlane, psPlane) || ((uintptr_t)xps & 15) || ((uintptr_t)ps & 15)) return -3;
+    SplitConvParams p;
+    std::memset(&p, 0, sizeof(p));
+    p.wq = (const u32x4*)wq; p.bias = bias;
+    p.N = 1; p.Cin = 64; p.Cout = 64; p.H = 2 * h; p.W = 2 * wd; p.Hin = h; p.Win = wd;
+    p.ksteps = 4; p.coutPad = 256; p.cgroups = 1;
+    p.tilesX = (wd + ST_W - 1) / ST_W; p.tilesY = (h + ST_H - 1) / ST_H;
+    p.act = act; p.slope = slope;
+    p.dbg = g_split_dbg; p.stamps = nullptr;
+    p.xps = (const u32x4*)xps; p.xpsPlane = (int)xpsPlane;
+    p.ps = (u32x4*)ps; p.psPlane = (int)psPlane;
+    p.absmax = rangeFlag;
+    hipStream_t s = (hipStream_t)stream;
+    static bool attr = false;
+    if (!attr) { (void)hipFuncSetAttribute((const void*)conv3x3_split_upsp_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, UP_LDS_BYTES); attr = true; }
+    // the one-pixel frame first (a few dozen waves), then the body: neither reads what the other writes
+    UpsFrameParams fp;
+    fp.xps = p.xps; fp.xpsPlane = p.xpsPlane; fp.w = w; fp.bias = bias; fp.ps = p.ps; fp.psPlane = p.psPlane;
+    fp.Hin = h; fp.Win = wd; fp.H = p.H; fp.W = p.W; fp.act = act; fp.slope = slope; fp.absmax = rangeFlag;
+    const int nf = 2 * p.W + 2 * (p.H - 2);
+    ISR_LAUNCH_PROFILED(ISR_VARIANT_UPS_FRAME, ups_frame_kernel, dim3((unsigned)((nf + 63) / 64), 8), dim3(64), 0, s, fp);
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    isr_profile_record(ISR_VARIANT_SPLIT_UPSP, 2.0 * 9 * 64 * 64 * (double)p.H * p.W, &e0, &e1);
+    const dim3 grid((unsigned)(p.tilesX * p.tilesY)), block(S_THREADS);
+    if (e0 || e1) hipExtLaunchKernelGGL(conv3x3_split_upsp_kernel, grid, block, UP_LDS_BYTES, s, e0, e1, 0, p);
+    else hipLaunchKernelGGL(conv3x3_split_upsp_kernel, grid, block, UP_LDS_BYTES, s, p);
+    return hipGetLastError() == hipSuccess ? 0 : -2;
+}
+
+int isrPackSplit(const float* x, void* ps, int C, int H, int W, long long xPlane, long long psPlane, void* stream)
+{
+    if (!x || !ps || C <= 0 || (C & 7) || H <= 0 || W <= 0 || xPlane < (long long)H * W || psPlane < (long long)H * W) return -1;
+    if (psPlane * 16 * 2 * (C / 8) > 0x7fffffffLL || ((uintptr_t)ps & 15)) return -1;
+    const int npix = H * W;
+    hipLaunchKernelGGL(pack_split_kernel, dim3((unsigned)((npix + 255) / 256), (unsigned)(C / 8)), dim3(256), 0, (hipStream_t)stream,
+                       x, (u32x4*)ps, C / 8, npix, xPlane, (int)psPlane);
+    return hipGetLastError() == hipSuccess ? 0 : -2;
 }
 
 int isrConvSplitPrepareManyMax(void) { return PM_MAX; }

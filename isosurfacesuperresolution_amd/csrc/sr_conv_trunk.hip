@@ -227,6 +227,9 @@ __device__ __forceinline__ void trunk16_epilogue(const Trunk16Params& p, f32x16 
 {
     const rsrc_t prs = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(LAST ? reinterpret_cast<const char*>(p.y) : out), 0,
                                                          LAST ? (int)((size_t)64 * p.yPlane * 4) : (int)(16u * planeBytes), 0x00020000);
+    // LAST: the result ALSO goes out packed-split (into `out`, the F tensor of the workspace; plain stores: the reader is the next
+    // kernel) -- the phase-decomposed upsampling layer stages it by LDS-DMA (sr_conv_upsp.h)
+    const rsrc_t qrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(out), 0, (int)(16u * planeBytes), 0x00020000);
     const int ox = ox0 + j;
 #pragma unroll
     for (int r = 0; r < 2; ++r) {
@@ -254,15 +257,17 @@ __device__ __forceinline__ void trunk16_epilogue(const Trunk16Params& p, f32x16 
                     else v += F[cb][r][4 * gi + e];
                     if (KIND != 1) F[cb][r][4 * gi + e] = v;
                     if (inside) mag = isr_umax(mag, isr_mag(v));
-                    if (LAST) {
-                        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), prs, (int)voff, (cb * 32 + 8 * gi + e) * p.yPlane * 4, 0);
-                    } else {
-                        _Float16 a, b;
-                        split16x(v, a, b);
-                        th[e] = a; tl[e] = b;
-                    }
+                    if (LAST) __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), prs, (int)voff, (cb * 32 + 8 * gi + e) * p.yPlane * 4, 0);
+                    _Float16 a, b;
+                    split16x(v, a, b);
+                    th[e] = a; tl[e] = b;
                 }
-                if (!LAST) {
+                if (LAST) {
+                    const int g = cb * 4 + gi;
+                    const unsigned vq = inside ? (unsigned)(oy * p.W + ox) * 16u + 8u * (unsigned)h : BAD_OFFSET;
+                    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, th), qrs, (int)vq, g * planeBytes, 0);
+                    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, tl), qrs, (int)vq, (8 + g) * planeBytes, 0);
+                } else {
                     const int g = cb * 4 + gi;
                     const unsigned vo = cb == 0 ? voffRing : voff;
                     __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, th), prs, (int)vo, g * planeBytes, 16);
@@ -549,10 +554,10 @@ __device__ __forceinline__ void trunk_mt_epilogue(const Trunk16Params& p, f32x16
                     split16x(v, a, b);
                     th[e] = a; tl[e] = b;
                 }
-                if (!LAST) {
+                {   // (LAST: the packed-split copy of the result is the phase-decomposed upsampling layer's input; plain stores)
                     const int g = cb * 4 + gi;
-                    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, th), prs, (int)voff, g * planeBytes, 16);
-                    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, tl), prs, (int)voff, (8 + g) * planeBytes, 16);
+                    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, th), prs, (int)voff, g * planeBytes, LAST ? 0 : 16);
+                    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, tl), prs, (int)voff, (8 + g) * planeBytes, LAST ? 0 : 16);
                 }
             }
         }
@@ -824,6 +829,16 @@ long long isrTrunkDataflowWorkspaceBytes(int cin0, int H, int W)
 {
     if (H <= 0 || W <= 0 || cin0 <= 0) return -1;
     return trunk16_layout(cin0, H, W).total;
+}
+
+/* Where isrTrunkDataflow leaves its result PACKED-SPLIT (besides y): byte offset into the workspace and plane stride in 16-byte units
+ * -- [2 parts][8 groups][plane] -- valid until the next launch on the same workspace. */
+int isrTrunkDataflowPackedResult(int cin0, int H, int W, long long* offsetBytes, long long* planeUnits)
+{
+    if (H <= 0 || W <= 0 || cin0 <= 0 || !offsetBytes || !planeUnits) return -1;
+    *offsetBytes = trunk16_layout(cin0, H, W).fps;
+    *planeUnits = ((long long)H * W + 8) & ~7LL;
+    return 0;
 }
 
 int isrTrunkDataflowSupported(const float* x, int cin0, int H, int W, long long xPlane, long long plane)

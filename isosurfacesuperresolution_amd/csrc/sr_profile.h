@@ -22,6 +22,8 @@ constexpr int ISR_VARIANT_ASSEMBLE = 26;       // assemble_input_kernel (sr_fram
 constexpr int ISR_VARIANT_TAIL_FINISH = 27;    // tail_s_finish_kernel / tail_seam_finish_kernel / tail_combine_finish_kernel (sr_conv_tail.hip)
 constexpr int ISR_VARIANT_FLOW_FILL = 28;      // flow_fill_one_kernel / flow_fill_kernel (sr_frame.hip; the frame pipeline runs it on the render stream)
 constexpr int ISR_VARIANT_FINISH = 29;         // finish_frame_kernel (sr_frame.hip)
+constexpr int ISR_VARIANT_UPS_FRAME = 30;      // ups_frame_kernel (sr_conv_upsp.h): the one-pixel frame of a phase-decomposed upsampling layer
+constexpr int ISR_VARIANT_SPLIT_UPSP = 31;     // conv3x3_split_upsp_kernel (sr_conv_upsp.h); NOT a "small" kernel: recorded at level 1
 
 // Sets *e0 / *e1 to an event pair (and records the launch) when profiling is on, leaves them untouched otherwise.
 void isr_profile_record(int variant, double flops, hipEvent_t* e0, hipEvent_t* e1);

@@ -84,14 +84,16 @@ class EnhanceNet(nn.Module):
     def _fused_ok(self):
         return (not self.use_bn) and self.upsample == 'bilinear'
 
-    def forward_features(self, inputs, last_layer=True, last_two=True, last_three=True, after_trunk=None):
+    def forward_features(self, inputs, last_layer=True, last_two=True, last_three=True, after_trunk=None, packed_tail=False):
         """The convolutional trunk only: the tensor ``_recon_image`` receives (used by the fused
         frame pipeline, which folds the reconstruction into its finishing kernel).  ``last_layer=False`` stops
         before the final 64 -> 6 convolution (``self.postblock[8]``), which the pipeline fuses with the finishing;
         ``last_two=False`` stops before ``self.postblock[6]`` as well (the fused 1080p tail, ``ops.tail_conv_finish``),
         ``last_three=False`` before ``self.postblock[4]`` (whose output the pipeline hands to the tail packed-split).
         ``after_trunk``: called once the low-resolution trunk has been enqueued (the frame pipeline starts the next frame's
-        ray-march there: beside the multi-round 1080p kernels instead of beside the one-round dataflow trunk)."""
+        ray-march there: beside the multi-round 1080p kernels instead of beside the one-round dataflow trunk).
+        ``packed_tail`` (with ``last_two=False`` or ``last_three=False``): the caller takes an ``ops.PackedSplit`` -- the upsampling
+        layers may then run phase-decomposed on the trunk's packed-split result (``ops.conv3x3_ups_phase``)."""
         assert self._fused_ok()
         c = ops.conv3x3
         pre = self.preblock[0]
@@ -105,6 +107,16 @@ class EnhanceNet(nn.Module):
         if after_trunk is not None:
             after_trunk()
         p = self.postblock
+        fp = getattr(f, '_isr_packed', None)
+        if packed_tail and fp is not None and ops.ups_phase_supported(fp, p[1].weight) and tuple(p[4].weight.shape) == (64, 64, 3, 3):
+            # the dataflow trunk left its result packed-split: both upsampling layers run phase-decomposed (no interpolation at run
+            # time, operands by LDS-DMA; csrc/sr_conv_upsp.h), packed-split from the trunk to the fused tail
+            g = ops.conv3x3_ups_phase(fp, p[1].weight, p[1].bias, act='relu')
+            if not last_three:
+                return g
+            if ops.ups_phase_supported(g, p[4].weight):
+                return ops.conv3x3_ups_phase(g, p[4].weight, p[4].bias, act='relu')
+            raise RuntimeError("forward_features(packed_tail=True): the second upsampling layer does not take the packed-split tensor")
         f = c(f, p[1].weight, p[1].bias, act='relu', upsample2x=True)
         if not last_three:
             return f

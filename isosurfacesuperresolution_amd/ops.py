@@ -120,6 +120,13 @@ def _sr():
         lib.isrTrunkDataflowWorkspaceBytes.argtypes = [ci, ci, ci]; lib.isrTrunkDataflowWorkspaceBytes.restype = ll
         lib.isrTrunkDataflowSupported.argtypes = [vp, ci, ci, ci, ll, ll]; lib.isrTrunkDataflowSupported.restype = ci
         lib.isrTrunkDataflow.argtypes = [vp, ci, ll, vp, ll, vp, vp, ci, ci, ci, vp, vp]; lib.isrTrunkDataflow.restype = ci
+        lib.isrTrunkDataflowPackedResult.argtypes = [ci, ci, ci, vp, vp]; lib.isrTrunkDataflowPackedResult.restype = ci
+        lib.isrConvUpsPhaseWeightBytes.argtypes = []; lib.isrConvUpsPhaseWeightBytes.restype = ll
+        lib.isrConvUpsPhaseScratchBytes.argtypes = []; lib.isrConvUpsPhaseScratchBytes.restype = ll
+        lib.isrConvUpsPhasePrepare.argtypes = [vp, vp, vp, vp]; lib.isrConvUpsPhasePrepare.restype = ci
+        lib.isrConvUpsPhaseSupported.argtypes = [ci, ci, ci, ci, ll, ll]; lib.isrConvUpsPhaseSupported.restype = ci
+        lib.isrConvUpsPhase.argtypes = [vp, vp, vp, vp, vp, ci, ci, ci, cf, ll, ll, vp]; lib.isrConvUpsPhase.restype = ci
+        lib.isrPackSplit.argtypes = [vp, vp, ci, ci, ci, ll, ll, vp]; lib.isrPackSplit.restype = ci
         lib.isrResBlockSplitWorkspaceBytes.argtypes = []; lib.isrResBlockSplitWorkspaceBytes.restype = ll
         lib.isrResBlockSplitSupported.argtypes = [vp, ci, ci, ll, ll]; lib.isrResBlockSplitSupported.restype = ci
         lib.isrResBlockSplit.argtypes = [vp, vp, vp, vp, vp, vp, vp, ci, ci, ll, ll, vp]; lib.isrResBlockSplit.restype = ci
@@ -241,7 +248,7 @@ VARIANT_NAMES = {6: "conv3x3_small_cout_kernel", 2: "conv3x3_fwd_kernel<1,false>
                  24: "trunk_mt_kernel",
                  # the frame's small kernels (zero algorithmic flops; registered for bench.py's gap accounting)
                  25: "trunk_pack_input_kernel", 26: "assemble_input_kernel", 27: "tail_finish_kernel", 28: "flow_fill_one_kernel",
-                 29: "finish_frame_kernel"}
+                 29: "finish_frame_kernel", 30: "ups_frame_kernel", 31: "conv3x3_split_upsp_kernel"}
 
 
 def debug_switches():
@@ -1126,6 +1133,13 @@ def trunk_dataflow(x, convs):
     rc = lib.isrTrunkDataflow(_ptr(x), cin, xp, _ptr(f), f.stride(1), pw, pb, (n - 1) // 2, h, w, _ptr(ws), _stream())
     if rc != 0:
         raise RuntimeError("isrTrunkDataflow failed (%d)" % rc)
+    # the same result PACKED-SPLIT, inside the workspace (valid until the next launch on it): what the phase-decomposed upsampling
+    # layer stages by LDS-DMA (conv3x3_ups_phase)
+    off, plane = ctypes.c_longlong(), ctypes.c_longlong()
+    if lib.isrTrunkDataflowPackedResult(cin, h, w, ctypes.byref(off), ctypes.byref(plane)) == 0:
+        ps = PackedSplit(ws[off.value // 4: off.value // 4 + 2 * 8 * plane.value * 4], 64, h, w, plane.value)
+        ps.range_key = f._isr_range_key
+        f._isr_packed = ps
     return f
 
 
@@ -1773,6 +1787,81 @@ def conv3x3_split_from_packed(xp, weight, bias=None, act='none', slope=0.01, res
         out.range_key = key
     else:
         out._isr_range_key = key
+    return out
+
+
+# ---- phase-decomposed upsampling layers (csrc/sr_conv_upsp.h): conv3x3(U2(x)) without interpolation at run time ------------------
+# U2 (bilinear x2) is linear: the convolution at the high-resolution pixel (2y + py, 2x + px) is a 3 x 3 convolution of the LOW-
+# resolution image with one of four effective weight sets.  Input and output are PACKED-SPLIT; the output's one-pixel frame (where the
+# convolution's zero padding bites) is computed by a small exact kernel of its own.  Not bit-identical to the interpolate-then-convolve
+# kernels (different roundings), the same distance from an fp64 convolution (tests/test_upsp_gpu.py).  ISR_UPS_PHASE=0: off.
+UPS_PHASE = os.environ.get("ISR_UPS_PHASE", "1") != "0"
+_upsp_cache = {}
+
+
+def _prepare_ups_phase(weight):
+    """The stacked image of the four effective weight sets of a [64, 64, 3, 3] weight (``isrConvUpsPhasePrepare``), cached per weight version."""
+    lib = _sr()
+    key = id(weight)
+    hit = _upsp_cache.get(key)
+    if hit is not None:
+        ref, version, ptr, wq, epoch = hit
+        if ref() is weight and version == weight._version and ptr == weight.data_ptr() and epoch == _images_epoch:
+            return wq
+    w = weight.detach().contiguous()
+    wq = torch.empty(lib.isrConvUpsPhaseWeightBytes(), dtype=torch.uint8, device=weight.device)
+    scratch = torch.empty(lib.isrConvUpsPhaseScratchBytes(), dtype=torch.uint8, device=weight.device)
+    rc = lib.isrConvUpsPhasePrepare(_ptr(w), _ptr(wq), _ptr(scratch), _stream())
+    if rc != 0:
+        raise RuntimeError("isrConvUpsPhasePrepare failed (%d)" % rc)
+    if len(_upsp_cache) > 64:
+        for k in [k for k, v in _upsp_cache.items() if v[0]() is None]:
+            del _upsp_cache[k]
+    _upsp_cache[key] = (weakref.ref(weight), weight._version, weight.data_ptr(), wq, _images_epoch)
+    return wq
+
+
+def pack_split(x):
+    """fp32 [1, C, H, W] -> ``PackedSplit`` (what a producer's packed epilogue would have written; ``isrPackSplit``)."""
+    x, xp, _ = _plane_strides(x)
+    _, c, h, w = x.shape
+    assert x.shape[0] == 1 and c % 8 == 0
+    plane = h * w + plane_pad(h, w)
+    data = torch.empty(2 * (c // 8) * plane * 4, dtype=torch.int32, device=x.device)
+    rc = _sr().isrPackSplit(_ptr(x), _ptr(data), c, h, w, xp, plane, _stream())
+    if rc != 0:
+        raise RuntimeError("isrPackSplit failed (%d)" % rc)
+    out = PackedSplit(data, c, h, w, plane)
+    out.range_key = getattr(x, '_isr_range_key', None)
+    return out
+
+
+def ups_phase_supported(xp, weight):
+    """Can ``conv3x3_ups_phase`` take this layer (a 64 -> 64 convolution of the x2-upsampled packed-split tensor ``xp``)?"""
+    if not (UPS_PHASE and SPLIT_F16 and not FAST_F16 and isinstance(xp, PackedSplit) and xp.channels == 64 and tuple(weight.shape) == (64, 64, 3, 3)):
+        return False
+    if any_hot(xp.data.device) or range_is_hot(xp.range_key, xp.data.device):
+        return False
+    H, W = 2 * xp.h, 2 * xp.w
+    return bool(_sr().isrConvUpsPhaseSupported(64, 64, xp.h, xp.w, xp.plane, H * W + plane_pad(H, W)))
+
+
+def conv3x3_ups_phase(xp, weight, bias=None, act='relu', slope=0.01):
+    """act(conv3x3(U2(x), weight) + bias) of a packed-split x [64, h, w] -> packed-split [64, 2h, 2w] (``isrConvUpsPhase``)."""
+    lib = _sr()
+    assert isinstance(xp, PackedSplit) and xp.channels == 64 and tuple(weight.shape) == (64, 64, 3, 3)
+    H, W = 2 * xp.h, 2 * xp.w
+    plane = H * W + plane_pad(H, W)
+    dev = xp.data.device
+    data = torch.empty(2 * 8 * plane * 4, dtype=torch.int32, device=dev)
+    wq = _prepare_ups_phase(weight)
+    key = _arm_range(id(weight), dev)
+    rc = lib.isrConvUpsPhase(_ptr(xp.data), _ptr(wq), _ptr(weight.detach().contiguous()), _ptr(bias.detach().contiguous() if bias is not None else None),
+                             _ptr(data), xp.h, xp.w, ACT_CODES[act], float(slope), xp.plane, plane, _stream())
+    if rc != 0:
+        raise RuntimeError("isrConvUpsPhase failed (%d)" % rc)
+    out = PackedSplit(data, 64, H, W, plane)
+    out.range_key = key
     return out
 
 

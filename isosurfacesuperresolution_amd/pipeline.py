@@ -49,12 +49,17 @@ def run_network(model, shading, x, after_trunk=None, prefetch_point="trunk", out
     four = net.postblock[4]
     if tail and ops.TAIL_PACKED and tuple(six.weight.shape) == (64, 64, 3, 3) and tuple(last.weight.shape) == (6, 64, 3, 3):
         at = prefetch_point
-        f2 = net.forward_features(x, last_three=False, after_trunk=after_trunk if at == "trunk" else None)
+        f2 = net.forward_features(x, last_three=False, after_trunk=after_trunk if at == "trunk" else None, packed_tail=True)
         if at == "trunk":
             after_trunk = None
         if at == "ups1" and after_trunk is not None:
             after_trunk(); after_trunk = None
-        if ops.packed_supported(f2, four.weight, True):
+        if isinstance(f2, ops.PackedSplit):
+            # the phase-decomposed route (csrc/sr_conv_upsp.h): trunk -> postblock.1 -> postblock.4 -> tail, packed-split all the way
+            if not ops.ups_phase_supported(f2, four.weight):
+                raise RuntimeError("run_network: postblock.4 does not take the packed-split tensor postblock.1 produced")
+            f4 = ops.conv3x3_ups_phase(f2, four.weight, four.bias, act='relu')
+        elif ops.packed_supported(f2, four.weight, True):
             # postblock.4 writes its output packed-split (already the (hi, lo') units postblock.6 multiplies), the tail
             # stages them by LDS-DMA: no conversion on the way in, no LDS transposition on the way out
             f4 = ops.conv3x3_split_packed(f2, four.weight, four.bias, act='relu', upsample2x=True)

@@ -14,6 +14,13 @@ Restated pieces (reference file:line):
 * output: one ``Stats_<dataset>_<model>.txt`` per model -- a header and ONE ROW PER CLIP with the 14 tab-separated columns of
   ``:160-163,270-281`` -- and one ``Histogram_<dataset>_<model>.txt`` (``:283-299``).
 
+Metric precision.  The reference evaluates PSNR and MS-SSIM in fp32 on whatever device it runs on.  MS-SSIM forms local variances
+as E[x^2] - E[x]^2 under an 11-tap window: on a nearly constant channel (depth, AO) that is a cancellation against C2 = 9e-4, and two
+fp32 convolution implementations -- torch's CPU kernel and its device kernel -- disagree by up to 3e-4 in the MS-SSIM of IDENTICAL
+images (measured on the bilinear baseline, where no kernel of this package runs).  ``metric_dtype`` (default float64) is the
+precision the metrics are evaluated in: in fp64 the table depends on the predictions only, so the HIP run and the CPU run of the
+same model agree to 1e-5 (``tests/test_stats_gpu.py``); ``metric_dtype=torch.float32`` is the reference's arithmetic.
+
 Added here: every per-clip quantity also goes into a ``utils.MeanVariance`` accumulator per model (``utils/mv.py``), returned by
 ``run_statistics`` and written as ``Summary_<dataset>.txt`` (mean and variance over the clips) -- the reference leaves that
 aggregation to a spreadsheet.
@@ -77,8 +84,10 @@ def default_shading(device):
 class Statistics:
     """Accumulators of one model (``mainPSNR3_AllStats.py:129-299``).  ``add_timestep_sample`` per frame, ``write_sample`` per clip."""
 
-    def __init__(self, device, shading=None, upscaling=UPSCALING, border=BORDER, min_filling=MIN_FILLING, ao_strength=1.0):
+    def __init__(self, device, shading=None, upscaling=UPSCALING, border=BORDER, min_filling=MIN_FILLING, ao_strength=1.0,
+                 metric_dtype=torch.float64):
         self.device = device
+        self.metric_dtype = metric_dtype
         self.shading = shading if shading is not None else default_shading(device)
         self.upscaling, self.border, self.min_filling, self.ao_strength = upscaling, border, min_filling, ao_strength
         self.ssim = MSSSIM().to(device)
@@ -113,6 +122,9 @@ class Statistics:
         pred_mnda, pred_c_ao, pred_c = cut(pred_mnda, b2), cut(pred_c_ao, b2), cut(pred_c, b2)
         gt_mnda, gt_c_ao, gt_c = cut(gt_mnda, b2), cut(gt_c_ao, b2), cut(gt_c, b2)
         input_mnda, in_c = cut(input_mnda, b), cut(in_c, b)
+        md = self.metric_dtype                                      # shading above runs in the tensors' own precision; the METRICS in `md`
+        pred_mnda, pred_c_ao, pred_c, gt_mnda, gt_c_ao, gt_c, input_mnda, in_c = (
+            t.to(md) for t in (pred_mnda, pred_c_ao, pred_c, gt_mnda, gt_c_ao, gt_c, input_mnda, in_c))
         mask = gt_mnda[:, 0:1] * 0.5 + 0.5
         _, _, H, W = mask.shape
         if torch.sum(mask).item() / (H * W) < self.min_filling:
@@ -214,7 +226,7 @@ def run_clip(net, low, high, flow, stats, upscaling=UPSCALING):
 
 
 def run_statistics(datasets, model_specs, output_folder, device="cuda", upscaling=UPSCALING, border=BORDER, min_filling=MIN_FILLING,
-                   log=print):
+                   log=print, metric_dtype=torch.float64):
     """``datasets``: [(name, [folders])] (``:29-41``); ``model_specs``: see ``load_models``.  Writes ``Stats_<dataset>_<model>.txt``,
     ``Histogram_<dataset>_<model>.txt`` and ``Summary_<dataset>.txt`` into ``output_folder``; returns
     {dataset: {model: {column: (mean, variance, clips)}}}."""
@@ -225,7 +237,7 @@ def run_statistics(datasets, model_specs, output_folder, device="cuda", upscalin
     for dataset_name, folders in datasets:
         log("Compute statistics for", dataset_name)
         files = [open(os.path.join(output_folder, "Stats_%s_%s.txt" % (dataset_name, name)), "w") for name, _ in nets]
-        stats = [Statistics(device, upscaling=upscaling, border=border, min_filling=min_filling) for _ in nets]
+        stats = [Statistics(device, upscaling=upscaling, border=border, min_filling=min_filling, metric_dtype=metric_dtype) for _ in nets]
         try:
             for f in files:
                 Statistics.write_header(f)

@@ -30,7 +30,7 @@ def ssim(img1, img2, window_size=11, window=None, size_average=True, full=False,
     L = _dynamic_range(img1, val_range)
     _, channel, height, width = img1.size()
     if window is None:
-        window = create_window(min(window_size, height, width), channel=channel).to(img1.device)
+        window = create_window(min(window_size, height, width), channel=channel).to(device=img1.device, dtype=img1.dtype)
     conv = lambda t: F.conv2d(t, window, padding=0, groups=channel)
     mu1, mu2 = conv(img1), conv(img2)
     mu1_sq, mu2_sq, mu12 = mu1.pow(2), mu2.pow(2), mu1 * mu2
@@ -47,7 +47,7 @@ def ssim(img1, img2, window_size=11, window=None, size_average=True, full=False,
 
 
 def msssim(img1, img2, window_size=11, size_average=True, val_range=None, normalize=False):
-    weights = torch.tensor(_MS_WEIGHTS, dtype=torch.float32, device=img1.device)
+    weights = torch.tensor(_MS_WEIGHTS, dtype=img1.dtype, device=img1.device)
     sims, css = [], []
     for _ in range(len(_MS_WEIGHTS)):
         sim, cs = ssim(img1, img2, window_size=window_size, size_average=size_average, full=True, val_range=val_range)

@@ -91,7 +91,7 @@ def test_statistics_of_one_frame_equal_the_ingredients_applied_by_hand(tmp_path)
     synthetic_clips(folder, clips=1, frames=1)
     low, high = (torch.from_numpy(np.load(os.path.join(folder, "%s_00000.npy" % k))) for k in ("low", "high"))
     net = stats.SimpleUpsample(4, "bilinear")
-    st = stats.Statistics("cpu")
+    st = stats.Statistics("cpu", metric_dtype=torch.float32)          # the reference's arithmetic: same numbers as the ingredients in fp32
     stats.run_clip(net, low, high, None, st)
     row = st.sample_row()
     pred, _ = net(torch.cat((low[0:1], torch.zeros(1, 96, *low.shape[2:])), dim=1))

@@ -54,3 +54,9 @@ def test_statistics_table_of_the_hip_run_equals_the_cpu_run(tmp_path):
         assert np.allclose(rows["gpu"][:, 10:], rows["cpu"][:, 10:], rtol=1e-3, atol=1e-7)
         assert res_gpu["Ejecta"][name]["PSNR-normal"][2] == 2
     assert rows["gpu"][:, 5].min() > 0.3 and rows["gpu"][:, 0].min() > 10.0                             # a sensible network, not noise
+    # the reference's own arithmetic (metrics in fp32 on the device) gives the same table up to the metric's fp32 conditioning
+    res32 = stats.run_statistics([("Ejecta", [str(folder)])], specs(), str(tmp_path / "gpu32"), device="cuda", log=lambda *a: None,
+                                 metric_dtype=torch.float32)
+    for name in ("bilinear", "enhancenet"):
+        for c in stats.COLUMNS[:10]:
+            assert abs(res32["Ejecta"][name][c][0] - res_gpu["Ejecta"][name][c][0]) <= (2e-3 if c.startswith("SSIM") else 2e-2), (name, c)
