@@ -1376,7 +1376,9 @@ int isrConvUpsPhase(const void* xps, const void* wq, const float* w, const float
     p.absmax = rangeFlag;
     hipStream_t s = (hipStream_t)stream;
     static bool attr = false;
-    if (!attr) { (void)hipFuncSetAttribute((const void*)conv3x3_split_upsp_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, UP_LDS_BYTES); attr = true; }
+    static int ldsExtra = getenv("ISR_UPSP_LDS_EXTRA") ? atoi(getenv("ISR_UPSP_LDS_EXTRA")) : 0;      // experiment: pad the allocation (one workgroup per CU)
+    const int ldsBytes = UP_LDS_BYTES + ldsExtra;
+    if (!attr) { (void)hipFuncSetAttribute((const void*)conv3x3_split_upsp_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, ldsBytes); attr = true; }
     // the one-pixel frame first (a few dozen waves), then the body: neither reads what the other writes
     UpsFrameParams fp;
     fp.xps = p.xps; fp.xpsPlane = p.xpsPlane; fp.w = w; fp.bias = bias; fp.ps = p.ps; fp.psPlane = p.psPlane;
@@ -1386,8 +1388,8 @@ int isrConvUpsPhase(const void* xps, const void* wq, const float* w, const float
     hipEvent_t e0 = nullptr, e1 = nullptr;
     isr_profile_record(ISR_VARIANT_SPLIT_UPSP, 2.0 * 9 * 64 * 64 * (double)p.H * p.W, &e0, &e1);
     const dim3 grid((unsigned)(p.tilesX * p.tilesY)), block(S_THREADS);
-    if (e0 || e1) hipExtLaunchKernelGGL(conv3x3_split_upsp_kernel, grid, block, UP_LDS_BYTES, s, e0, e1, 0, p);
-    else hipLaunchKernelGGL(conv3x3_split_upsp_kernel, grid, block, UP_LDS_BYTES, s, p);
+    if (e0 || e1) hipExtLaunchKernelGGL(conv3x3_split_upsp_kernel, grid, block, ldsBytes, s, e0, e1, 0, p);
+    else hipLaunchKernelGGL(conv3x3_split_upsp_kernel, grid, block, ldsBytes, s, p);
     return hipGetLastError() == hipSuccess ? 0 : -2;
 }
 

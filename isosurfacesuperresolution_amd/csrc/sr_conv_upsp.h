@@ -90,6 +90,7 @@ __global__ __launch_bounds__(S_THREADS, 2) void conv3x3_split_upsp_kernel(const 
         poff[k] = ((unsigned)(part * groups + g) * (unsigned)p.xpsPlane + (unsigned)(iy * p.Win + ix)) * 16u;
     }
     auto patch_dma = [&](int ks, int buf) {
+        if (p.dbg & 2) return;                                               // (diagnostics: no patch requests)
         const unsigned so = (unsigned)(2 * ks) * (unsigned)p.xpsPlane * 16u;
         const unsigned dst = pAddr + (unsigned)buf * (UP_PUNITS * 16);
 #pragma unroll
@@ -101,6 +102,7 @@ __global__ __launch_bounds__(S_THREADS, 2) void conv3x3_split_upsp_kernel(const 
     // ---- weights of step (m, ks, dy): 18 pieces = (plane: hi | lo | hi 2^-11) x (tap dx) x (lane half); lane = output channel
     const unsigned wplane3 = (unsigned)(9 * K * 4 * CP) * 16u;               // the third plane starts behind the (hi, lo) image
     auto weight_dma = [&](int m, int ks, int dy, int buf) {
+        if (p.dbg & 4) return;                                               // (diagnostics: no weight requests)
         const unsigned dst = wAddr + (unsigned)buf * (UP_WUNITS * 16);
 #pragma unroll
         for (int k = 0; k < 5; ++k) {
@@ -148,6 +150,10 @@ __global__ __launch_bounds__(S_THREADS, 2) void conv3x3_split_upsp_kernel(const 
                     if (nm < 4) weight_dma(nm, nks, ndy, (G + 1) & 1);
                     if (dy == 0 && q + 1 < 4 * K) patch_dma(ks + 1 < K ? ks + 1 : 0, (q + 1) & 1);
                 }
+                if (p.dbg & 32) {                                            // (diagnostics: the requests land before the MFMAs start)
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    __syncthreads();
+                }
                 if (!(p.dbg & 1)) {
                     const u32x4* wl = wbuf0 + (G & 1) * UP_WUNITS + h * 64 + j;
                     const u32x4* bl = pbuf0 + (q & 1) * UP_PUNITS + h * SP_PIX + (wave * 2 + dy) * SP_W + j;
@@ -181,8 +187,25 @@ __global__ __launch_bounds__(S_THREADS, 2) void conv3x3_split_upsp_kernel(const 
             if (acc[0][0][0] == 123.456f) p.ps[0] = u32x4{1u, 2u, 3u, 4u};
             continue;
         }
+        if (p.dbg & 64) asm volatile("s_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15" ::: "memory");      // (diagnostics)
+        if (p.dbg & 128) __syncthreads();
         const int py = m >> 1, px = m & 1;
         const int lx = ox0 + j, X = 2 * lx + px;
+        // All bias values into registers BEFORE the first store, behind a scheduling fence.  Found the hard way (round 5): with the bias
+        // read from LDS inside the loop the compiler placed `ds_read_b128 v[10:13]` directly behind `buffer_store_dwordx4 v[10:13]`; a
+        // 16-byte store reads its data registers a little AFTER it issues, the LDS return is not ordered against that, and with two
+        // workgroups per CU (a busier memory pipeline) the first dword of the unit -- 8 lanes of one channel -- was overwritten by bias
+        // bits before the store had taken it.  The hazard recogniser guards vector-ALU writes behind wide stores, not LDS returns.
+        float bvv[2][4][4];
+#pragma unroll
+        for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+            for (int gi = 0; gi < 4; ++gi) {
+                const float4 bq = *reinterpret_cast<const float4*>(biasl + cb * 32 + 8 * gi + 4 * h);
+                bvv[cb][gi][0] = bq.x; bvv[cb][gi][1] = bq.y; bvv[cb][gi][2] = bq.z; bvv[cb][gi][3] = bq.w;
+            }
+        __builtin_amdgcn_s_waitcnt(0xC07F);                                  // lgkmcnt(0): the LDS returns have landed
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int r = 0; r < 2; ++r) {
             const int ly = oy0 + wave * 2 + r, Y = 2 * ly + py;
@@ -192,12 +215,10 @@ __global__ __launch_bounds__(S_THREADS, 2) void conv3x3_split_upsp_kernel(const 
             for (int cb = 0; cb < 2; ++cb) {
 #pragma unroll
                 for (int gi = 0; gi < 4; ++gi) {
-                    const float4 bq = *reinterpret_cast<const float4*>(biasl + cb * 32 + 8 * gi + 4 * h);
-                    const float bvv[4] = { bq.x, bq.y, bq.z, bq.w };
                     f16x4 th, tl;
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
-                        float v = acc[cb][r][4 * gi + e] * unscale + bvv[e];
+                        float v = acc[cb][r][4 * gi + e] * unscale + bvv[cb][gi][e];
                         if (p.act == ISR_ACT_RELU) v = v > 0.f ? v : 0.f;
                         else if (p.act == ISR_ACT_LEAKY) v = v > 0.f ? v : v * p.slope;
                         _Float16 a, b;
