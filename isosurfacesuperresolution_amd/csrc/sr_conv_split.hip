@@ -1370,7 +1370,7 @@ int isrConvUpsPhase(const void* xps, const void* wq, const float* w, const float
     p.ksteps = 4; p.coutPad = 256; p.cgroups = 1;
     p.tilesX = (wd + ST_W - 1) / ST_W; p.tilesY = (h + ST_H - 1) / ST_H;
     p.act = act; p.slope = slope;
-    p.dbg = g_split_dbg; p.stamps = nullptr;
+    p.dbg = g_split_dbg; p.stamps = g_split_stamps;
     p.xps = (const u32x4*)xps; p.xpsPlane = (int)xpsPlane;
     p.ps = (u32x4*)ps; p.psPlane = (int)psPlane;
     p.absmax = rangeFlag;

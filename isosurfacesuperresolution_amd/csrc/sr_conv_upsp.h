@@ -30,11 +30,12 @@ namespace {
 constexpr int UP_PART = 2 * SP_PIX;                                          // one k-step of the low-res patch: 2 channel groups; hi, lo' at + UP_PART
 constexpr int UP_PUNITS = 2 * UP_PART;                                       // 1360 units = 21 760 B
 constexpr int UP_WROW = 3 * 128;                                             // one tap row of one plane: 3 taps x [lane half][64 couts]
-constexpr int UP_WUNITS = 3 * UP_WROW;                                       // planes hi, lo, hi 2^-11: 1 152 units = 18 432 B
-constexpr int UP_LDS_UNITS = 2 * UP_PUNITS + 2 * UP_WUNITS;                  // both operands double buffered: 80 384 B
+constexpr int UP_WUNITS = 2 * UP_WROW;                                       // planes hi, lo (hi 2^-11 is made in registers): 768 units = 12 288 B
+constexpr int UP_WBUFS = 3;                                                  // weight rows in flight: the row being multiplied + two on their way
+constexpr int UP_LDS_UNITS = 2 * UP_PUNITS + UP_WBUFS * UP_WUNITS;           // 80 384 B
 constexpr int UP_LDS_BYTES = UP_LDS_UNITS * 16 + 256;                        // + the bias row: two workgroups per CU
 constexpr int UP_PPIECES = (UP_PUNITS + 63) / 64;                            // 22 wave-wide pieces of a patch slice (the last one 16 units)
-constexpr int UP_WPIECES = UP_WUNITS / 64;                                   // 18 pieces of a tap row
+constexpr int UP_WPIECES = UP_WUNITS / 64;                                   // 12 pieces of a tap row: three per wave
 
 typedef __attribute__((address_space(3))) char up_lds_char;
 
@@ -50,16 +51,19 @@ __device__ __forceinline__ void up_dma16(const void* base, unsigned voff, unsign
 // image of the four stacked effective weight sets (Cout = 256: image m = 2 py + px at output channels 64 m ..); tiles of 8 x 32
 // LOW-resolution pixels (p.tilesX, p.tilesY).
 //
-// Schedule.  A tile is 48 steps (image m, k-step ks, tap row dy), each 36 MFMAs per wave on one tap row of weights (18 KB) and one
-// k-step slice of the patch (21 KB, shared by the three rows of a k-step).  Both operands are double buffered in LDS and arrive by
-// LDS-DMA straight from L2 -- no registers, no conversion, no vector instructions: the requests for step G + 1 (and, at the first row
-// of a slice, for the next slice) are issued right after the barrier that opens step G and travel under its MFMAs.  ONE barrier per
-// step.  The only vector work left is the epilogue of each image (64 values per lane), which runs beside the other workgroup's MFMAs.
+// Schedule.  A tile is 48 steps (image m, k-step ks, tap row dy), each 36 MFMAs per wave (~0.6 us) on one tap row of weights (12 KB:
+// hi and lo planes; the partner of the scaled x_lo', w_hi 2^-11, is an exponent shift of the hi fragment in registers) and one k-step
+// slice of the patch (21 KB, shared by the three rows of a k-step).  Operands arrive by LDS-DMA straight from L2 -- no registers, no
+// conversion.  A request takes 1-2 us under load, longer than a step: the weights of step G + 2 are requested when step G opens (THREE
+// rotating row buffers), the next patch slice when its predecessor's first row opens (two buffers), and the wait that opens a step
+// leaves everything younger than its own operands in flight (`s_waitcnt vmcnt(N)`: requests complete in issue order; N = what this
+// wave issued after the operands it needs now).  ONE barrier per step.  The only vector work left is the epilogue of each image
+// (64 values per lane), which runs beside the other workgroup's MFMAs.
 __global__ __launch_bounds__(S_THREADS, 2) void conv3x3_split_upsp_kernel(const SplitConvParams p)
 {
     extern __shared__ u32x4 lds[];
     u32x4* const pbuf0 = lds;                                                // [2][UP_PUNITS]
-    u32x4* const wbuf0 = lds + 2 * UP_PUNITS;                                // [2][UP_WUNITS]
+    u32x4* const wbuf0 = lds + 2 * UP_PUNITS;                                // [UP_WBUFS][UP_WUNITS]
     float* const biasl = reinterpret_cast<float*>(lds + UP_LDS_UNITS);
     const unsigned ldsBase = (unsigned)(uintptr_t)(up_lds_char*)lds;
     const unsigned pAddr = ldsBase, wAddr = ldsBase + 2 * UP_PUNITS * 16;
@@ -73,12 +77,21 @@ __global__ __launch_bounds__(S_THREADS, 2) void conv3x3_split_upsp_kernel(const 
     }
     const int tx = bid % p.tilesX, ty = bid / p.tilesX;
     const int oy0 = ty * ST_H, ox0 = tx * ST_W;                              // low-resolution origin of the tile
-    const int groups = p.Cin >> 3, K = p.ksteps;
+    const int groups = p.Cin >> 3;
+    constexpr int K = 4;                                                     // k-steps (64 input channels): the launcher admits nothing else
     constexpr int CP = 256;                                                  // coutPad of the stacked image
+    constexpr int STEPS = 4 * K * 3;
     if (tid < 64) biasl[tid] = p.bias ? p.bias[tid] : 0.0f;
+    // diagnostics (isrDebugSetSplitStampBuffer): 10 ticks of the 100 MHz clock per workgroup -- start, first operands landed, and per image
+    // "MFMAs issued" / "epilogue issued"; straight to memory, no registers held
+    auto lap = [&](int slot) {
+        if (p.stamps && tid == 0) p.stamps[(size_t)blockIdx.x * 10 + slot] = __builtin_amdgcn_s_memrealtime();
+    };
+    lap(0);
 
     // ---- patch slice of k-step ks: 2 parts x 2 channel groups x 10 x 34 pixels.  Wave w moves pieces w, w + 4, ..; lane l of piece pc moves
     //      unit u = 64 pc + l.  Source pixels are CLAMPED into the image (replicate padding); the lane offsets depend on the tile only.
+    //      Waves 0, 1 issue six requests per slice, waves 2, 3 five (the wait counts below know).
     unsigned poff[6];
 #pragma unroll
     for (int k = 0; k < 6; ++k) {
@@ -96,24 +109,24 @@ __global__ __launch_bounds__(S_THREADS, 2) void conv3x3_split_upsp_kernel(const 
 #pragma unroll
         for (int k = 0; k < 6; ++k) {
             const int pc = wave + 4 * k;
-            if (pc < UP_PPIECES && pc * 64 + lane < UP_PUNITS) up_dma16(p.xps, poff[k] + so, dst + (unsigned)pc * 1024u);
+            if (pc < UP_PPIECES - 1) up_dma16(p.xps, poff[k] + so, dst + (unsigned)pc * 1024u);
+            else if (pc == UP_PPIECES - 1 && lane < UP_PUNITS - 64 * (UP_PPIECES - 1)) up_dma16(p.xps, poff[k] + so, dst + (unsigned)pc * 1024u);
         }
     };
-    // ---- weights of step (m, ks, dy): 18 pieces = (plane: hi | lo | hi 2^-11) x (tap dx) x (lane half); lane = output channel
-    const unsigned wplane3 = (unsigned)(9 * K * 4 * CP) * 16u;               // the third plane starts behind the (hi, lo) image
-    auto weight_dma = [&](int m, int ks, int dy, int buf) {
+    // ---- weights of step g (image m, k-step ks, row dy): 12 pieces = (plane: hi | lo) x (tap dx) x (lane half); lane = output channel;
+    //      three requests per wave
+    auto weight_dma = [&](int g) {
         if (p.dbg & 4) return;                                               // (diagnostics: no weight requests)
-        const unsigned dst = wAddr + (unsigned)buf * (UP_WUNITS * 16);
+        const int m = g / (3 * K), rem = g - m * (3 * K);
+        const int ks = rem / 3, dy = rem - 3 * ks;
+        const unsigned dst = wAddr + (unsigned)(g % UP_WBUFS) * (UP_WUNITS * 16);
 #pragma unroll
-        for (int k = 0; k < 5; ++k) {
+        for (int k = 0; k < 3; ++k) {
             const int pc = wave + 4 * k;
-            if (pc < UP_WPIECES) {
-                const int plane = pc / 6, dx = (pc % 6) >> 1, hh = pc & 1;
-                const int tk = (3 * dy + dx) * K + ks;
-                const unsigned unit = plane < 2 ? (unsigned)(((tk * 2 + plane) * 2 + hh) * CP + m * 64)
-                                                : (unsigned)((tk * 2 + hh) * CP + m * 64);
-                up_dma16(p.wq + 1, unit * 16u + (plane == 2 ? wplane3 : 0u) + (unsigned)lane * 16u, dst + (unsigned)pc * 1024u);
-            }
+            const int plane = pc / 6, dx = (pc % 6) >> 1, hh = pc & 1;
+            const int tk = (3 * dy + dx) * K + ks;
+            const unsigned unit = (unsigned)(((tk * 2 + plane) * 2 + hh) * CP + m * 64);
+            up_dma16(p.wq + 1, unit * 16u + (unsigned)lane * 16u, dst + (unsigned)pc * 1024u);
         }
     };
 
@@ -122,10 +135,13 @@ __global__ __launch_bounds__(S_THREADS, 2) void conv3x3_split_upsp_kernel(const 
     const rsrc_t prs = __builtin_amdgcn_make_buffer_rsrc(p.ps, 0, (int)((size_t)2 * ogroups * p.psPlane * 16), 0x00020000);
     unsigned mag = 0u;
     const unsigned lopart = (unsigned)h * (unsigned)(ogroups * p.psPlane) * 16u;
+    const bool six = wave < 2;                                               // this wave's patch requests per slice: 6, else 5
 
-    weight_dma(0, 0, 0, 0);
+    // requests in issue order: W(0), P(0) | step 0: W(2)?? -- no: W(0), P(0), W(1) before the loop; step G issues W(G + 2), then (dy = 0) P(next)
+    weight_dma(0);
     patch_dma(0, 0);
-    int G = 0;                                                               // step counter of the tile: weight buffer G & 1
+    weight_dma(1);
+    int G = 0;                                                               // step counter of the tile
 #pragma unroll 1
     for (int m = 0; m < 4; ++m) {
         f32x16 acc[2][2];
@@ -140,22 +156,23 @@ __global__ __launch_bounds__(S_THREADS, 2) void conv3x3_split_upsp_kernel(const 
             const int q = m * K + ks;                                        // slice counter: patch buffer q & 1
 #pragma unroll 1
             for (int dy = 0; dy < 3; ++dy, ++G) {
-                // step G's operands have landed (this wave's requests: the explicit wait; everyone's: the barrier) and every wave is
-                // done with step G - 1: the other weight buffer -- and, at dy = 0, the other patch buffer -- is free
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                __syncthreads();
-                {
-                    int nm = m, nks = ks, ndy = dy + 1;
-                    if (ndy == 3) { ndy = 0; if (++nks == K) { nks = 0; ++nm; } }
-                    if (nm < 4) weight_dma(nm, nks, ndy, (G + 1) & 1);
-                    if (dy == 0 && q + 1 < 4 * K) patch_dma(ks + 1 < K ? ks + 1 : 0, (q + 1) & 1);
-                }
-                if (p.dbg & 32) {                                            // (diagnostics: the requests land before the MFMAs start)
-                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                    __syncthreads();
-                }
+                // Step G needs W(G) (requested when step G - 2 opened) and its patch slice (requested earlier still).  Younger, and
+                // allowed to stay in flight: W(G + 1) (3 requests), a patch slice requested behind W(G) or W(G + 1) (dy = 2 / dy = 1:
+                // 6 or 5), and the 16 stores of an epilogue that ran between step G - 1 and this one (dy = 0, ks = 0, m > 0).
+                //   (the tile's last slice requests no further slice: dy = 1 leaves W(G + 1) alone in flight, dy = 2 nothing)
+                if ((p.dbg & 32) || G + 1 >= STEPS) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                else if (dy == 0) {
+                    if (ks == 0 && m > 0 && !(p.dbg & 8)) asm volatile("s_waitcnt vmcnt(19)" ::: "memory");
+                    else asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+                } else if (q + 1 >= 4 * K) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+                else if (six) asm volatile("s_waitcnt vmcnt(9)" ::: "memory");
+                else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+                __syncthreads();                                             // everyone's requests for this step have landed; everyone is done with step G - 1
+                if (G == 0) lap(1);
+                if (G + 2 < STEPS) weight_dma(G + 2);                        // its buffer was step G - 1's
+                if (dy == 0 && q + 1 < 4 * K) patch_dma(ks + 1 < K ? ks + 1 : 0, (q + 1) & 1);      // its buffer was slice q - 1's
                 if (!(p.dbg & 1)) {
-                    const u32x4* wl = wbuf0 + (G & 1) * UP_WUNITS + h * 64 + j;
+                    const u32x4* wl = wbuf0 + (G % UP_WBUFS) * UP_WUNITS + h * 64 + j;
                     const u32x4* bl = pbuf0 + (q & 1) * UP_PUNITS + h * SP_PIX + (wave * 2 + dy) * SP_W + j;
 #pragma unroll
                     for (int dx = 0; dx < 3; ++dx) {
@@ -163,8 +180,8 @@ __global__ __launch_bounds__(S_THREADS, 2) void conv3x3_split_upsp_kernel(const 
                         const f16x8 a0l = __builtin_bit_cast(f16x8, wl[UP_WROW + dx * 128]);
                         const f16x8 a1h = __builtin_bit_cast(f16x8, wl[dx * 128 + 32]);
                         const f16x8 a1l = __builtin_bit_cast(f16x8, wl[UP_WROW + dx * 128 + 32]);
-                        const f16x8 a0s = __builtin_bit_cast(f16x8, wl[2 * UP_WROW + dx * 128]);        // w_hi 2^-11: partner of the scaled x_lo'
-                        const f16x8 a1s = __builtin_bit_cast(f16x8, wl[2 * UP_WROW + dx * 128 + 32]);
+                        const f16x8 a0s = a0h * (_Float16)0.00048828125f;   // w_hi 2^-11: partner of the scaled x_lo'
+                        const f16x8 a1s = a1h * (_Float16)0.00048828125f;
 #pragma unroll
                         for (int r = 0; r < 2; ++r) {
                             const f16x8 bh = __builtin_bit_cast(f16x8, bl[r * SP_W + dx]);
@@ -180,6 +197,7 @@ __global__ __launch_bounds__(S_THREADS, 2) void conv3x3_split_upsp_kernel(const 
                 }
             }
         }
+        lap(2 + 2 * m);
         // ---- epilogue of parity (py, px): act(acc 2^-S + bias) as (hi, lo') units at the high-resolution pixel (2 y + py, 2 x + px);
         //      the frame pixels are ups_frame_kernel's.  Lane pairs trade halves as in split_epilogue_ps: one 16-byte store per lane.
         //      (The next image's first operands are already on their way.)
@@ -187,8 +205,6 @@ __global__ __launch_bounds__(S_THREADS, 2) void conv3x3_split_upsp_kernel(const 
             if (acc[0][0][0] == 123.456f) p.ps[0] = u32x4{1u, 2u, 3u, 4u};
             continue;
         }
-        if (p.dbg & 64) asm volatile("s_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15" ::: "memory");      // (diagnostics)
-        if (p.dbg & 128) __syncthreads();
         const int py = m >> 1, px = m & 1;
         const int lx = ox0 + j, X = 2 * lx + px;
         // All bias values into registers BEFORE the first store, behind a scheduling fence.  Found the hard way (round 5): with the bias
@@ -235,6 +251,7 @@ __global__ __launch_bounds__(S_THREADS, 2) void conv3x3_split_upsp_kernel(const 
                 }
             }
         }
+        lap(3 + 2 * m);
     }
     isr_range_note(p.absmax, mag);
 }

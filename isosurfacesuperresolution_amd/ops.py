@@ -1794,8 +1794,13 @@ def conv3x3_split_from_packed(xp, weight, bias=None, act='none', slope=0.01, res
 # U2 (bilinear x2) is linear: the convolution at the high-resolution pixel (2y + py, 2x + px) is a 3 x 3 convolution of the LOW-
 # resolution image with one of four effective weight sets.  Input and output are PACKED-SPLIT; the output's one-pixel frame (where the
 # convolution's zero padding bites) is computed by a small exact kernel of its own.  Not bit-identical to the interpolate-then-convolve
-# kernels (different roundings), the same distance from an fp64 convolution (tests/test_upsp_gpu.py).  ISR_UPS_PHASE=0: off.
-UPS_PHASE = os.environ.get("ISR_UPS_PHASE", "1") != "0"
+# kernels (different roundings), the same distance from an fp64 convolution (tests/test_upsp_gpu.py).
+# OPT-IN (ISR_UPS_PHASE=1): built, parity-green and MEASURED SLOWER in round 5 -- 1080p layer 0.60 ms + 0.08 ms frame kernel against
+# 0.47 ms of conv3x3_split_ups3_kernel.  Why (profiles/r05_upsp_ablation.md): with every operand arriving by LDS-DMA the launch's
+# MFMAs + operand reads alone take 0.345 ms at the clock the matrix pipe really holds (~1.5 GHz under load, not the 2.4 GHz the
+# roofline's peak is priced at), the operand DMA adds 0.08 ms of LDS write traffic beside 0.67 LDS reads per MFMA, and the four
+# epilogues per tile with their stride-2 pixel stores 0.17 ms; the interpolating kernel was never more than 35 % above that floor.
+UPS_PHASE = os.environ.get("ISR_UPS_PHASE", "0") == "1"
 _upsp_cache = {}
 
 

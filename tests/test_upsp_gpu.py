@@ -34,7 +34,7 @@ def test_phase_decomposed_layer_against_fp64(h, w, act):
     x = ((torch.rand(1, 64, h, w, generator=g) - 0.3) * 2).cuda()
     xp = ops.pack_split(x)
     assert (xp.to_float() - x).abs().max().item() <= 2 ** -21 * 2                   # the packed pair carries 22 bits
-    assert ops.ups_phase_supported(xp, wt)
+    assert bool(ops._sr().isrConvUpsPhaseSupported(64, 64, h, w, xp.plane, 4 * h * w + ops.plane_pad(2 * h, 2 * w)))
     y = ops.conv3x3_ups_phase(xp, wt, b, act=act)
     old = ops.conv3x3_split(x, wt, b, act=act, upsample2x=True) if w % 4 == 0 else None
     torch.cuda.synchronize()
@@ -82,20 +82,22 @@ def test_packed_chain_trunk_to_tail_matches_the_per_layer_route():
     g = torch.Generator().manual_seed(5)
     x = (torch.rand(1, 101, 136, 240, generator=g) * 2 - 0.5).cuda()
     x[:, 0] = (x[:, 0] > 0.3).float() * 2 - 1
-    ops.profile_enable(True)
-    with torch.no_grad():
-        raw_a, rgb_a = run_network(lm, sh, x)
-    torch.cuda.synchronize()
-    names = [n for n, _, _ in ops.profile_records()]
-    ops.profile_enable(False)
-    assert names.count("conv3x3_split_upsp_kernel") == 2 and "conv3x3_split_ups3_kernel" not in names
-    ops.UPS_PHASE = False
+    was = ops.UPS_PHASE
+    ops.UPS_PHASE = True                                    # (opt-in: ISR_UPS_PHASE=1)
     try:
+        ops.profile_enable(True)
+        with torch.no_grad():
+            raw_a, rgb_a = run_network(lm, sh, x)
+        torch.cuda.synchronize()
+        names = [n for n, _, _ in ops.profile_records()]
+        ops.profile_enable(False)
+        assert names.count("conv3x3_split_upsp_kernel") == 2 and "conv3x3_split_ups3_kernel" not in names
+        ops.UPS_PHASE = False
         with torch.no_grad():
             raw_b, rgb_b = run_network(lm, sh, x)
         torch.cuda.synchronize()
     finally:
-        ops.UPS_PHASE = True
+        ops.UPS_PHASE = was
     assert (raw_a - raw_b).abs().max().item() <= 2e-5 and (rgb_a - rgb_b).abs().max().item() <= 2e-5
     # against the CPU fp32 path of the same network
     cnet = models.createNetwork('EnhanceNet', 4, 101, [0, 1, 2, 3, 4], 6, OPT)
