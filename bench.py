@@ -732,7 +732,11 @@ def run_tiled(args, job, make_local_renderer=None):
     with contextlib.redirect_stdout(sys.stderr):
         net = models.createNetwork('EnhanceNet', 4, 101, [0, 1, 2, 3, 4], 6, opt)
     lm = LoadedModel.from_model(net, dev, parameters={"initialImage": "zero"})
-    sr = parallel_sr.StripSuperResolution(lm, default_shading(dev, 30.0))
+    # screen tiles of the super-resolution: the (rows x columns) grid whose largest tile + halo is smallest (8 ranks at 960 x 540: 2 x 4,
+    # 1.31 x a rank's share against 1.71 x with strips); BENCH_TILED_GRID=strips forces horizontal strips
+    sr_grid = None if os.environ.get("BENCH_TILED_GRID", "auto") == "strips" else parallel_sr.best_grid(world, low_h, low_w)
+    sr = parallel_sr.StripSuperResolution(lm, default_shading(dev, 30.0), grid=sr_grid)
+    sr_grid = sr_grid or (world, 1)
     K, Wm = args.steps, args.warmup
     # render(t+1) + all-gather + composite on a side stream beside SR(t), released when SR(t)'s trunk is enqueued (as the default
     # mode's pipeline does); --no-overlap: one after the other
@@ -798,9 +802,9 @@ def run_tiled(args, job, make_local_renderer=None):
     ms = {name: job.max_over_ranks(v) / K * 1e3 for name, v in phases.items()}
     hits = int((comp[..., 3] == 1).sum().item())
     # roofline of the dominant kernel: the strip's convolutions (same formula as the default mode)
-    y0, y1 = parallel_sr.strip_bounds(low_h, world, rank)
-    rows = min(low_h, y1 + sr.halo) - max(0, y0 - sr.halo)
-    strip_flops = 564.5e9 * (low_w * rows) / (480.0 * 270.0)             # SURVEY.md App. B, scaled to this rank's rows (halo included)
+    y0, y1, x0, x1 = parallel_sr.tile_bounds(low_h, low_w, sr_grid, rank)
+    rows, cols = min(low_h, y1 + sr.halo) - max(0, y0 - sr.halo), min(low_w, x1 + sr.halo) - max(0, x0 - sr.halo)
+    strip_flops = 564.5e9 * (cols * rows) / (480.0 * 270.0)              # SURVEY.md App. B, scaled to this rank's tile (halo included)
     if dev == "cuda":
         torch.cuda.synchronize()
         per = tally_kernels(ops.profile_records())
@@ -832,8 +836,9 @@ def run_tiled(args, job, make_local_renderer=None):
         "dtype": "f32", "data": "synthetic (ejecta %d^3 stand-in volume generated tile-wise, seeded random-init EnhanceNet weights)" % n,
         "config": {"workload": "%d^3 volume in %s object-space tiles, %dx%d -> %dx%d, temporal on" % (
                        n, "x".join(str(v) for v in TILE_SPLITS[world]), low_w, low_h, 4 * low_w, 4 * low_h),
-                   "sharding": "one tile per rank; all-gather of %.1f MB G-buffers + nearest-hit composite; SR in %d strips with a 24-px halo + all-gather"
-                               % (low_w * low_h * 48 / 1e6, world),
+                   "sharding": "one tile per rank; all-gather of %.1f MB G-buffers + nearest-hit composite; SR in %d x %d screen tiles with a 24-px halo "
+                               "(largest tile + halo = %.2f x a rank's share) + all-gather"
+                               % (low_w * low_h * 48 / 1e6, sr_grid[0], sr_grid[1], parallel_sr.extended_area(low_h, low_w, sr_grid) * world / float(low_h * low_w)),
                    "overlap": ("render + all-gather + composite of frame t+1 on a side HIP stream || SR(t), released at SR(t)'s %s" % release)
                               if overlap else "none",
                    "spin_kernel_forms": ops.spin_kernel_forms() if dev == "cuda" else None},

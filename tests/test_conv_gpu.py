@@ -453,6 +453,39 @@ def test_strip_super_resolution_is_bit_identical_on_gpu():
         prev = full_raw
 
 
+def test_tile_grid_super_resolution_is_bit_identical_on_gpu():
+    """parallel_sr with a (rows x columns) grid of screen tiles: every tile of a 4 x 2 and a 2 x 4 grid -- halo in y
+    AND x, column cuts on multiples of 8 -- reproduces its part of the full-frame network output bit for bit on the HIP kernels."""
+    from isosurfacesuperresolution_amd import models, parallel_sr
+    from isosurfacesuperresolution_amd.inference import LoadedModel
+    from isosurfacesuperresolution_amd.pipeline import default_shading
+    opt = argparse.Namespace(upsample='bilinear', reconType='residual', useBN=False, numResidualLayers=10)
+    torch.manual_seed(5)
+    net = models.createNetwork('EnhanceNet', 4, 101, [0, 1, 2, 3, 4], 6, opt)
+    lm = LoadedModel.from_model(net, "cuda", parameters={"initialImage": "zero"})
+    sr = parallel_sr.StripSuperResolution(lm, default_shading("cuda", 30.0))
+    g = torch.Generator().manual_seed(9)
+    prev = None
+    h, w = 136, 240
+    for step in range(2):
+        gb = torch.rand(h, w, 12, generator=g)
+        gb[..., 3] = (gb[..., 3] > 0.4).float()
+        gb[..., 8:10] = (gb[..., 8:10] - 0.5) * 0.05
+        gb = gb.cuda()
+        sr.previous = prev
+        with torch.no_grad():
+            x = sr.network_input(gb)
+            full_raw, full_rgb = sr.compute_strip(x, 0, 1)
+            for grid in ((4, 2), (2, 4), (1, 3)):
+                world = grid[0] * grid[1]
+                for r in range(world):
+                    raw_t, rgb_t = sr.compute_strip(x, r, world, grid=grid)
+                    y0, y1, x0, x1 = parallel_sr.tile_bounds(h, w, grid, r)
+                    assert torch.equal(raw_t, full_raw[:, :, 4 * y0:4 * y1, 4 * x0:4 * x1]), (step, grid, r)
+                    assert torch.equal(rgb_t, full_rgb[:, :, 4 * y0:4 * y1, 4 * x0:4 * x1]), (step, grid, r)
+        prev = full_raw
+
+
 def test_config4_clips_rendered_here_train_with_temporal_loss():
     """BASELINE config #4 in miniature (tools/config4_cloud.py runs the 512^3 version): a cloud volume, clips of 3
     frames rendered by this package's ray-marcher (low + 4x ground truth with ray-cast AO), 32^2 crops, EnhanceNet

@@ -1,5 +1,6 @@
 """Per-rank critical path of parallel_sr at 960x540 -> 3840x2160 (BASELINE config #5's SR half) on ONE GPU:
-replicated input assembly + the strip of rank world//2 (a middle strip has both halos), for world = 1, 2, 4, 8."""
+replicated input assembly + the tile of the rank with the largest extended area (a middle strip has both halos), for world = 1, 2, 4, 8
+as strips and -- where it differs -- as the best (rows x columns) grid."""
 import sys
 sys.path.insert(0, '.')
 import argparse
@@ -22,17 +23,20 @@ g[..., 8:10] = (g[..., 8:10] - 0.5) * 0.02
 with torch.no_grad():
     sr.previous = torch.rand(1, 6, 4 * h, 4 * w, device="cuda")
     for world in (1, 2, 4, 8):
-        rank = world // 2
-        for it in range(3):
-            if it == 1:
-                torch.cuda.synchronize()
-                e0, e1, e2 = (torch.cuda.Event(enable_timing=True) for _ in range(3))
-                e0.record()
-            x = sr.network_input(g)
-            if it >= 1 and it == 1: e1.record()
-            raw, rgb = sr.compute_strip(x, rank, world)
-            if it == 1: e2.record()
-        torch.cuda.synchronize()
-        y0, y1 = parallel_sr.strip_bounds(h, world, rank)
-        print("world %d: rows %d + halo -> assembly %.2f ms + strip %.2f ms = %.2f ms; all-gather payload %.1f MB per rank" % (
-            world, y1 - y0, e0.elapsed_time(e1), e1.elapsed_time(e2), e0.elapsed_time(e2), 9 * (y1 - y0) * 4 * w * 4 * 4 / 1e6), flush=True)
+        for grid in sorted({(world, 1), parallel_sr.best_grid(world, h, w)}, key=lambda gr: gr[1]):
+            rank = max(range(world), key=lambda r: (lambda b: (min(h, b[1] + 24) - max(0, b[0] - 24)) * (min(w, b[3] + 24) - max(0, b[2] - 24)))(
+                parallel_sr.tile_bounds(h, w, grid, r)))
+            for it in range(3):
+                if it == 1:
+                    torch.cuda.synchronize()
+                    e0, e1, e2 = (torch.cuda.Event(enable_timing=True) for _ in range(3))
+                    e0.record()
+                y0, y1, x0, x1 = parallel_sr.tile_bounds(h, w, grid, rank)
+                x = sr.network_input(g, rows=(max(0, y0 - 24), min(h, y1 + 24)))
+                if it == 1: e1.record()
+                raw, rgb = sr.compute_strip(x, rank, world, grid=grid)
+                if it == 1: e2.record()
+            torch.cuda.synchronize()
+            print("world %d, grid %dx%d: tile %dx%d + halo = %.2fx its share -> assembly %.2f ms + tile %.2f ms = %.2f ms; all-gather payload %.1f MB per rank" % (
+                world, grid[0], grid[1], y1 - y0, x1 - x0, parallel_sr.extended_area(h, w, grid) * world / float(h * w), e0.elapsed_time(e1),
+                e1.elapsed_time(e2), e0.elapsed_time(e2), 9 * (y1 - y0) * 4 * (x1 - x0) * 4 * 4 / 1e6), flush=True)
