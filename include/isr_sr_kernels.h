@@ -220,6 +220,10 @@ int isrAssembleInput(const float* gbuffer_hwc12, const float* flow_filled, const
  * assembles its strip + halo instead of the whole frame (parallel_sr.py). */
 int isrAssembleInputRows(const float* gbuffer_hwc12, const float* flow_filled, const float* prev_high, float* net_input,
                          int h, int w, int init_mode, int ao_inverted, int row0, int row1, void* stream);
+/* ... and of a rectangle rows [row0, row1) x columns [col0, col1) only: a rank that super-resolves a screen TILE + halo
+ * (parallel_sr.StripSuperResolution with a rows x columns grid). */
+int isrAssembleInputRect(const float* gbuffer_hwc12, const float* flow_filled, const float* prev_high, float* net_input,
+                         int h, int w, int init_mode, int ao_inverted, int row0, int row1, int col0, int col1, void* stream);
 
 /* Hole filling of the low-res flow (channels 8,9 of the HWC G-buffer) where the mask (channel 3) is 0:
  * mask-weighted push-pull pyramid, the on-device replacement of the reference's CPU OpenCV
@@ -367,6 +371,7 @@ int isrConvUpsPhase(const void* xps, const void* wq, const float* w, const float
                     long long xpsPlane, long long psPlane, void* stream);
 int isrPackSplit(const float* x, void* ps, int C, int H, int W, long long xPlane, long long psPlane, void* stream);
 int isrTrunkDataflowPackedResult(int cin0, int H, int W, long long* offsetBytes, long long* planeUnits);
+void isrSetTrunkPackedResult(int on);      /* 1: isrTrunkDataflow also writes that packed-split result (default 0) */
 
 /* Optional per-dispatch timing of isrConv3x3Forward for benchmarks: while enabled, every forward
  * dispatch carries a start/stop event pair on its own packet (no extra stream operations).

@@ -75,6 +75,7 @@ struct Trunk16Params {
     int dbg;                         // diagnostics (isrDebugSetTrunkAblation): 1 no MFMAs, 2 no activation DMA, 4 no stores, 8 no waits, 16 no weight DMA,
                                      // 32 the MFMAs on operands read once per k-step, 64 (with 32) ... but every tap's fragments read from LDS all the same
     int faultTile;                   // diagnostics (isrDebugSetTrunkFault): the tile that never publishes, or -1
+    int lastPacked;                  // isrSetTrunkPackedResult: the last layer ALSO writes its result packed-split (for sr_conv_upsp.h)
     unsigned long long timeoutTicks; // of the chip's 100 MHz clock
     unsigned long long* stamps;      // diagnostics: [tile][layer][8] = ticks at: layer start | neighbours there | first k-step staged | MFMAs done | epilogue done | stores drained
 };
@@ -264,7 +265,7 @@ __device__ __forceinline__ void trunk16_epilogue(const Trunk16Params& p, f32x16 
                 }
                 if (LAST) {
                     const int g = cb * 4 + gi;
-                    const unsigned vq = inside ? (unsigned)(oy * p.W + ox) * 16u + 8u * (unsigned)h : BAD_OFFSET;
+                    const unsigned vq = (inside && p.lastPacked) ? (unsigned)(oy * p.W + ox) * 16u + 8u * (unsigned)h : BAD_OFFSET;
                     __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, th), qrs, (int)vq, g * planeBytes, 0);
                     __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, tl), qrs, (int)vq, (8 + g) * planeBytes, 0);
                 } else {
@@ -554,10 +555,11 @@ __device__ __forceinline__ void trunk_mt_epilogue(const Trunk16Params& p, f32x16
                     split16x(v, a, b);
                     th[e] = a; tl[e] = b;
                 }
-                {   // (LAST: the packed-split copy of the result is the phase-decomposed upsampling layer's input; plain stores)
+                {   // (LAST: the packed-split copy of the result is the phase-decomposed upsampling layer's input -- on request; plain stores)
                     const int g = cb * 4 + gi;
-                    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, th), prs, (int)voff, g * planeBytes, LAST ? 0 : 16);
-                    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, tl), prs, (int)voff, (8 + g) * planeBytes, LAST ? 0 : 16);
+                    const unsigned vq = (LAST && !p.lastPacked) ? BAD_OFFSET : voff;
+                    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, th), prs, (int)vq, g * planeBytes, LAST ? 0 : 16);
+                    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, tl), prs, (int)vq, (8 + g) * planeBytes, LAST ? 0 : 16);
                 }
             }
         }
@@ -831,8 +833,12 @@ long long isrTrunkDataflowWorkspaceBytes(int cin0, int H, int W)
     return trunk16_layout(cin0, H, W).total;
 }
 
-/* Where isrTrunkDataflow leaves its result PACKED-SPLIT (besides y): byte offset into the workspace and plane stride in 16-byte units
- * -- [2 parts][8 groups][plane] -- valid until the next launch on the same workspace. */
+/* isrSetTrunkPackedResult(1): later isrTrunkDataflow launches leave their result PACKED-SPLIT as well (besides y), at the byte offset
+ * into the workspace and with the plane stride in 16-byte units that isrTrunkDataflowPackedResult reports -- [2 parts][8 groups][plane]
+ * -- valid until the next launch on the same workspace. */
+static int g_trunk_last_packed = 0;
+void isrSetTrunkPackedResult(int on) { g_trunk_last_packed = on ? 1 : 0; }
+
 int isrTrunkDataflowPackedResult(int cin0, int H, int W, long long* offsetBytes, long long* planeUnits)
 {
     if (H <= 0 || W <= 0 || cin0 <= 0 || !offsetBytes || !planeUnits) return -1;
@@ -878,6 +884,7 @@ int isrTrunkDataflow(const float* x, int cin0, long long xPlane, float* y, long 
     p.dbg = g_trunk_dbg; p.stamps = g_trunk_stamps;
     p.timeoutTicks = g_trunk_timeout_ticks;                                  // 50 ms unless a test shortened it: a frame is 2 ms
     p.faultTile = g_trunk_fault_tile;
+    p.lastPacked = g_trunk_last_packed;
     hipStream_t s = (hipStream_t)stream;
     // the progress counters start at zero every launch; the error word behind them is STICKY (the caller zero-fills the workspace
     // once, reads the word when it likes and resets it then): an error of any launch since the last look stays visible

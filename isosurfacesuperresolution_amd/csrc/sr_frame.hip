@@ -35,6 +35,7 @@ struct AssembleParams {
     int init_mode;          // prev == NULL: 0 zero, 1 unshaded constants, 2 upsampled input (+ones)
     int ao_inverted;
     int row0;               // first row of the launch (isrAssembleInputRows: a rank that needs only its strip + halo)
+    int col0, col1;         // columns [col0, col1) of the launch (isrAssembleInputRect: a screen TILE + halo)
 };
 
 // one thread per (low-res pixel, dx): neighbouring lanes read neighbouring hi-res columns (the gathers of the
@@ -42,9 +43,9 @@ struct AssembleParams {
 __global__ __launch_bounds__(256) void assemble_input_kernel(const AssembleParams p)
 {
     const int t = blockIdx.x * blockDim.x + threadIdx.x;
-    const int x = t >> 2, dx = t & 3;
+    const int x = p.col0 + (t >> 2), dx = t & 3;
     const int y = p.row0 + blockIdx.y;
-    if (x >= p.w) return;
+    if (x >= p.col1) return;
     const size_t plane = (size_t)p.h * p.w;
     const size_t pix = (size_t)y * p.w + x;
     const float* g = p.gbuf + pix * 12;
@@ -545,11 +546,17 @@ int isrAssembleInput(const float* gbuffer_hwc12, const float* flow_filled, const
 int isrAssembleInputRows(const float* gbuffer_hwc12, const float* flow_filled, const float* prev_high, float* net_input,
                          int h, int w, int init_mode, int ao_inverted, int row0, int row1, void* stream)
 {
-    if (!gbuffer_hwc12 || !net_input || h <= 0 || w <= 0 || row0 < 0 || row1 > h || row0 >= row1) return -1;
+    return isrAssembleInputRect(gbuffer_hwc12, flow_filled, prev_high, net_input, h, w, init_mode, ao_inverted, row0, row1, 0, w, stream);
+}
+
+int isrAssembleInputRect(const float* gbuffer_hwc12, const float* flow_filled, const float* prev_high, float* net_input,
+                         int h, int w, int init_mode, int ao_inverted, int row0, int row1, int col0, int col1, void* stream)
+{
+    if (!gbuffer_hwc12 || !net_input || h <= 0 || w <= 0 || row0 < 0 || row1 > h || row0 >= row1 || col0 < 0 || col1 > w || col0 >= col1) return -1;
     if (prev_high && !flow_filled) return -1;
     if (init_mode < 0 || init_mode > 2) return -1;
-    AssembleParams p = { gbuffer_hwc12, flow_filled, prev_high, net_input, h, w, init_mode, ao_inverted, row0 };
-    ISR_LAUNCH_PROFILED(ISR_VARIANT_ASSEMBLE, assemble_input_kernel, dim3((4 * w + 255) / 256, row1 - row0), dim3(256), 0, (hipStream_t)stream, p);
+    AssembleParams p = { gbuffer_hwc12, flow_filled, prev_high, net_input, h, w, init_mode, ao_inverted, row0, col0, col1 };
+    ISR_LAUNCH_PROFILED(ISR_VARIANT_ASSEMBLE, assemble_input_kernel, dim3((4 * (col1 - col0) + 255) / 256, row1 - row0), dim3(256), 0, (hipStream_t)stream, p);
     return hipGetLastError() == hipSuccess ? 0 : -2;
 }
 

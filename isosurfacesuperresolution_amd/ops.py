@@ -65,6 +65,7 @@ def _sr():
         lib.isrTakeMaxSlotWords.argtypes = []; lib.isrTakeMaxSlotWords.restype = ci
         lib.isrAssembleInput.argtypes = [vp, vp, vp, vp, ci, ci, ci, ci, vp]; lib.isrAssembleInput.restype = ci
         lib.isrAssembleInputRows.argtypes = [vp, vp, vp, vp, ci, ci, ci, ci, ci, ci, vp]; lib.isrAssembleInputRows.restype = ci
+        lib.isrAssembleInputRect.argtypes = [vp, vp, vp, vp, ci, ci, ci, ci, ci, ci, ci, ci, vp]; lib.isrAssembleInputRect.restype = ci
         lib.isrConvSmallCinPad.argtypes = [ci]; lib.isrConvSmallCinPad.restype = ci
         lib.isrConvSmallWeightFloats.argtypes = [ci]; lib.isrConvSmallWeightFloats.restype = ll
         lib.isrConvSmallPrepare.argtypes = [vp, vp, vp, vp, ci, ci, vp]; lib.isrConvSmallPrepare.restype = ci
@@ -121,6 +122,7 @@ def _sr():
         lib.isrTrunkDataflowSupported.argtypes = [vp, ci, ci, ci, ll, ll]; lib.isrTrunkDataflowSupported.restype = ci
         lib.isrTrunkDataflow.argtypes = [vp, ci, ll, vp, ll, vp, vp, ci, ci, ci, vp, vp]; lib.isrTrunkDataflow.restype = ci
         lib.isrTrunkDataflowPackedResult.argtypes = [ci, ci, ci, vp, vp]; lib.isrTrunkDataflowPackedResult.restype = ci
+        lib.isrSetTrunkPackedResult.argtypes = [ci]; lib.isrSetTrunkPackedResult.restype = None
         lib.isrConvUpsPhaseWeightBytes.argtypes = []; lib.isrConvUpsPhaseWeightBytes.restype = ll
         lib.isrConvUpsPhaseScratchBytes.argtypes = []; lib.isrConvUpsPhaseScratchBytes.restype = ll
         lib.isrConvUpsPhasePrepare.argtypes = [vp, vp, vp, vp]; lib.isrConvUpsPhasePrepare.restype = ci
@@ -1130,13 +1132,14 @@ def trunk_dataflow(x, convs):
     st = _range_state(x.device)
     lib.isrSetTrunkErrorWord(ctypes.c_void_p(st["buf"].data_ptr() + 4 * _TRUNK_ERROR_SLOT))
     f._isr_range_key = _arm_range(("trunk", id(convs[0][0])), x.device, members=[id(wt) for wt, _ in convs])
+    lib.isrSetTrunkPackedResult(1 if UPS_PHASE else 0)
     rc = lib.isrTrunkDataflow(_ptr(x), cin, xp, _ptr(f), f.stride(1), pw, pb, (n - 1) // 2, h, w, _ptr(ws), _stream())
     if rc != 0:
         raise RuntimeError("isrTrunkDataflow failed (%d)" % rc)
     # the same result PACKED-SPLIT, inside the workspace (valid until the next launch on it): what the phase-decomposed upsampling
     # layer stages by LDS-DMA (conv3x3_ups_phase)
     off, plane = ctypes.c_longlong(), ctypes.c_longlong()
-    if lib.isrTrunkDataflowPackedResult(cin, h, w, ctypes.byref(off), ctypes.byref(plane)) == 0:
+    if UPS_PHASE and lib.isrTrunkDataflowPackedResult(cin, h, w, ctypes.byref(off), ctypes.byref(plane)) == 0:
         ps = PackedSplit(ws[off.value // 4: off.value // 4 + 2 * 8 * plane.value * 4], 64, h, w, plane.value)
         ps.range_key = f._isr_range_key
         f._isr_packed = ps
@@ -1532,7 +1535,7 @@ def loss_unshaded(gt, pred, prev, cfg):
 
 @contextlib.contextmanager
 def graph_capture(graph, **kw):
-    """``torch.cuda.graph(graph, **kw)`` with the cyclic garbage collector out of the way.
+    """``torch.cuda.graph(graph, **kw)`` with the CYCLIC garbage collector out of the way.
 
     A global-mode stream capture makes most HIP calls illegal on every thread until it ends.  If a cyclic collection runs
     INSIDE the capture and finalises GPU objects that an earlier caller dropped in a reference cycle (a HIP graph, a
@@ -1541,7 +1544,14 @@ def graph_capture(graph, **kw):
     throws, ``std::terminate`` -- "Fatal Python error: Aborted" with the main thread "Garbage-collecting" (one full GPU
     test run of round 3 died exactly there, in ``GraphedTrainStep.__init__``).  torch 2.10's ``graph.__enter__`` does not
     collect by itself any more.  So: drain the device, collect NOW (destructors run at a quiescent point), and keep the
-    collector off until the capture has ended."""
+    collector off until the capture has ended.
+
+    What this does NOT cover (the caller's contract): it removes the cyclic collector, the path that produced the abort.  An
+    object whose reference count drops to zero INSIDE the capture body (a stream, event, graph or tensor the body itself lets
+    go of) is still finalised there and then, and a collection or a free triggered from ANOTHER thread during the capture is
+    not held back either.  Capture bodies in this package (``train.GraphedTrainStep``, ``SuperResolutionPipeline._frame_graph``)
+    therefore allocate their streams / events / workspaces before the capture (the eager warm-up pass) and hold them in
+    attributes for the graph's lifetime; multi-threaded hosts must not free GPU objects while a capture is open."""
     import gc
     torch.cuda.synchronize()
     gc.collect()
@@ -1579,7 +1589,7 @@ def adam_flat_step(params, grads, exp_avg, exp_avg_sq, step, lr, beta1, beta2, e
 INIT_MODES = {"zero": 0, "unshaded": 1, "input": 2}
 
 
-def assemble_input(gbuffer_hwc, flow_filled, prev_high, initial_image="zero", ao_inverted=False, out=None, rows=None):
+def assemble_input(gbuffer_hwc, flow_filled, prev_high, initial_image="zero", ao_inverted=False, out=None, rows=None, cols=None):
     """Renderer G-buffer [h,w,12] (+ hole-filled flow [1,2,h,w], previous frame [1,6,4h,4w] or None)
     -> network input [1,101,h,w] in one launch (``isrAssembleInput``).  ``rows`` = (row0, row1): only those rows are written
     (``isrAssembleInputRows``; the rest of the result is uninitialised unless ``out`` was given)."""
@@ -1592,8 +1602,9 @@ def assemble_input(gbuffer_hwc, flow_filled, prev_high, initial_image="zero", ao
         flow_filled = flow_filled.contiguous()
         assert prev_high.shape == (1, 6, 4 * h, 4 * w) and flow_filled.shape == (1, 2, h, w)
     r0, r1 = (0, h) if rows is None else (int(rows[0]), int(rows[1]))
-    rc = _sr().isrAssembleInputRows(_ptr(gbuffer_hwc), _ptr(flow_filled) if prev_high is not None else None,
-                                    _ptr(prev_high), _ptr(out), h, w, INIT_MODES[initial_image], 1 if ao_inverted else 0, r0, r1, _stream())
+    c0, c1 = (0, w) if cols is None else (int(cols[0]), int(cols[1]))          # ``cols``: likewise columns (a screen tile + halo)
+    rc = _sr().isrAssembleInputRect(_ptr(gbuffer_hwc), _ptr(flow_filled) if prev_high is not None else None,
+                                    _ptr(prev_high), _ptr(out), h, w, INIT_MODES[initial_image], 1 if ao_inverted else 0, r0, r1, c0, c1, _stream())
     if rc != 0:
         raise RuntimeError("isrAssembleInput failed (%d)" % rc)
     return out

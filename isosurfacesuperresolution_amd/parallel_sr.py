@@ -92,14 +92,14 @@ class StripSuperResolution:
         self.previous = None
 
     # -- step 1 (replicated) ---------------------------------------------------------------------------------
-    def network_input(self, gbuffer, rows=None):
-        """gbuffer [H, W, 12] -> the network's input [1, 5 + 6*upscale^2, H, W].  ``rows`` = (e0, e1): on the fused path only those
-        rows are assembled (a rank's strip + halo; the flow hole filling stays global: its pyramid spans the image)."""
+    def network_input(self, gbuffer, rows=None, cols=None):
+        """gbuffer [H, W, 12] -> the network's input [1, 5 + 6*upscale^2, H, W].  ``rows`` = (e0, e1), ``cols`` = (f0, f1): on the fused
+        path only that rectangle is assembled (a rank's tile + halo; the flow hole filling stays global: its pyramid spans the image)."""
         net, lm = self.model.model, self.model
         fused = gbuffer.is_cuda and self.upscale == 4
         if fused:
             flow = ops.fill_flow_gbuffer(gbuffer) if self.previous is not None else None
-            return ops.assemble_input(gbuffer, flow, self.previous, lm.initial_image_mode, lm.inverse_ao, rows=rows)
+            return ops.assemble_input(gbuffer, flow, self.previous, lm.initial_image_mode, lm.inverse_ao, rows=rows, cols=cols)
         low = gbuffer.permute(2, 0, 1).unsqueeze(0)
         mask = low[:, 3:4]
         inp = torch.cat((mask * 2 - 1, low[:, 4:8]), dim=1)
@@ -169,8 +169,9 @@ class StripSuperResolution:
         with torch.no_grad():
             h, w, u = gbuffer.shape[0], gbuffer.shape[1], self.upscale
             grid = self._grid(h, w)
-            y0, y1, _, _ = tile_bounds(h, w, grid, self.rank)
-            x = self.network_input(gbuffer, rows=(max(0, y0 - self.halo), min(h, y1 + self.halo)))      # what compute_strip reads
+            y0, y1, x0, x1 = tile_bounds(h, w, grid, self.rank)
+            x = self.network_input(gbuffer, rows=(max(0, y0 - self.halo), min(h, y1 + self.halo)),
+                                   cols=(max(0, x0 - self.halo), min(w, x1 + self.halo)))               # what compute_strip reads
             raw, rgb = self.compute_strip(x, after_trunk=after_trunk, grid=grid)
             if self.world > 1:
                 tiles = [tile_bounds(h, w, grid, r) for r in range(self.world)]

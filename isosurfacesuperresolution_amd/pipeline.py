@@ -293,7 +293,7 @@ class SuperResolutionPipeline:
         weights = tuple((p._version, p.data_ptr()) for p in self.model.model.parameters())
         return (tuple(sh.packed_parameters()), int(sh._specular_exponent), float(sh._ao), bool(self.model.inverse_ao), bool(sh.enable_specular),
                 self.model.initial_image_mode, id(self.model.model), ops._images_epoch, self._static_version, self.flow_fill_threads,
-                ops.TRUNK_DATAFLOW, ops.FLOW_FILL_ONE, ops.DEVICE_SHARED, ops.SPLIT_F16, ops.FAST_F16, ops.routing_epoch(), weights)
+                ops.TRUNK_DATAFLOW, ops.FLOW_FILL_ONE, ops.DEVICE_SHARED, ops.SPLIT_F16, ops.FAST_F16, ops.UPS_PHASE, ops.routing_epoch(), weights)
 
     def _graph_ready(self, origin, next_origin):
         if not (self.graph and next_origin is not None and self.temporal and self.previous is not None and self._prefetched is not None):

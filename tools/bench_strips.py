@@ -32,7 +32,7 @@ with torch.no_grad():
                     e0, e1, e2 = (torch.cuda.Event(enable_timing=True) for _ in range(3))
                     e0.record()
                 y0, y1, x0, x1 = parallel_sr.tile_bounds(h, w, grid, rank)
-                x = sr.network_input(g, rows=(max(0, y0 - 24), min(h, y1 + 24)))
+                x = sr.network_input(g, rows=(max(0, y0 - 24), min(h, y1 + 24)), cols=(max(0, x0 - 24), min(w, x1 + 24)))
                 if it == 1: e1.record()
                 raw, rgb = sr.compute_strip(x, rank, world, grid=grid)
                 if it == 1: e2.record()
