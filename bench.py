@@ -76,7 +76,7 @@ def is_split_kernel(name):
 MFMA_F32_PEAK_TFLOPS = 157.3      # /opt/skills/guides/MI355X_MICROARCH.md, chip-level parameters
 MFMA_F16_PEAK_TFLOPS = 2500.0     # dense fp16/bf16 MFMA (same table)
 HBM_PEAK_GBS = 8000.0
-PMC_TRAFFIC_FILES = ("r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json")   # committed rocprofv3 --pmc passes of this command
+PMC_TRAFFIC_FILES = ("r05_pmc_traffic.json", "r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json")   # committed rocprofv3 --pmc passes of this command
 
 
 def parse(argv=None):
@@ -498,7 +498,7 @@ def run_infer(args, job):
                                     if split else "fp32 MFMA",
                      "matrix_tflops_executed": achieved * (3.0 if split else 1.0),
                      "sustained_clock_note": ("measured, not used for `peak`: a bare v_mfma_f32_32x32x16_f16 loop on changing random operands holds 1.45-1.65 GHz "
-                                              "of the 2.4 GHz `peak` is priced at (zeros: 2.13 GHz; profiles/r04_mfma_valu_overlap.txt, DESIGN 4.2g)") if split else None,
+                                              "of the 2.4 GHz `peak` is priced at (zeros: 2.13 GHz; profiles/r04_mfma_valu_overlap.txt, DESIGN 4.2g; in the frame GRBM_GUI_ACTIVE gives 2.06-2.11 GHz for the three convolution kernels, profiles/r05_clock.txt)") if split else None,
                      "traffic_source": ("profiles/%s (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, bytes per launch)" % traffic_file) if traffic else None,
                      "avg_launch_ms": dom_time / dom_launches * 1e3, "launches_per_frame": dom_launches / K,
                      "flops_per_launch": dom_flops / dom_launches},

@@ -167,7 +167,7 @@ __global__ __launch_bounds__(S_THREADS, 2) void conv3x3_split_upsp_kernel(const 
                 } else if (q + 1 >= 4 * K) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
                 else if (six) asm volatile("s_waitcnt vmcnt(9)" ::: "memory");
                 else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-                __syncthreads();                                             // everyone's requests for this step have landed; everyone is done with step G - 1
+                if (!(p.dbg & 64)) __syncthreads();                          // everyone's requests for this step have landed; everyone is done with step G - 1 (64: diagnostics, no barrier)
                 if (G == 0) lap(1);
                 if (G + 2 < STEPS) weight_dma(G + 2);                        // its buffer was step G - 1's
                 if (dy == 0 && q + 1 < 4 * K) patch_dma(ks + 1 < K ? ks + 1 : 0, (q + 1) & 1);      // its buffer was slice q - 1's
