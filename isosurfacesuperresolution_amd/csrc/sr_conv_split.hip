@@ -1387,7 +1387,17 @@ int isrConvUpsPhase(const void* xps, const void* wq, const float* w, const float
     ISR_LAUNCH_PROFILED(ISR_VARIANT_UPS_FRAME, ups_frame_kernel, dim3((unsigned)((nf + 63) / 64), 8), dim3(64), 0, s, fp);
     hipEvent_t e0 = nullptr, e1 = nullptr;
     isr_profile_record(ISR_VARIANT_SPLIT_UPSP, 2.0 * 9 * 64 * 64 * (double)p.H * p.W, &e0, &e1);
-    const dim3 grid((unsigned)(p.tilesX * p.tilesY)), block(S_THREADS);
+    static int form = getenv("ISR_UPSP_FORM") ? atoi(getenv("ISR_UPSP_FORM")) : 0;      // 0: the LDS-DMA form (default), 1: form Q (4 rows per wave, activations from L1; measured slower)
+    const dim3 block(S_THREADS);
+    if (form == 1) {
+        p.tilesY = (h + UQ_TILE_H - 1) / UQ_TILE_H;
+        const dim3 qgrid((unsigned)(p.tilesX * p.tilesY));
+        const int qlds = UQ_LDS_BYTES + ldsExtra;
+        if (e0 || e1) hipExtLaunchKernelGGL(conv3x3_split_upsq_kernel, qgrid, block, qlds, s, e0, e1, 0, p);
+        else hipLaunchKernelGGL(conv3x3_split_upsq_kernel, qgrid, block, qlds, s, p);
+        return hipGetLastError() == hipSuccess ? 0 : -2;
+    }
+    const dim3 grid((unsigned)(p.tilesX * p.tilesY));
     if (e0 || e1) hipExtLaunchKernelGGL(conv3x3_split_upsp_kernel, grid, block, ldsBytes, s, e0, e1, 0, p);
     else hipLaunchKernelGGL(conv3x3_split_upsp_kernel, grid, block, ldsBytes, s, p);
     return hipGetLastError() == hipSuccess ? 0 : -2;

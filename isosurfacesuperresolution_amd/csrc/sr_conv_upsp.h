@@ -256,6 +256,191 @@ __global__ __launch_bounds__(S_THREADS, 2) void conv3x3_split_upsp_kernel(const 
     isr_range_note(p.absmax, mag);
 }
 
+// ---- form Q: a larger register tile, activations straight from L1 -----------------------------------------------------------------
+// What bounds the kernel above is operand traffic through LDS: 0.67 ds_read_b128 per MFMA (2 rows x 64 channels per wave: 4 weight +
+// 4 activation fragments per 12 MFMAs) + the DMA's LDS writes (profiles/r05_upsp_ablation.md).  Here a wave owns FOUR rows of 32 pixels
+// (tile 16 x 32 low-resolution pixels, 128 accumulator registers) and walks the taps column by column (dx outer, dy inner): the six
+// activation rows a column needs stay in registers across its three vertical taps, and they come from the packed-split tensor by
+// ordinary 16-byte loads (a lane's B fragment IS one unit of the tensor; neighbouring lanes read neighbouring units; the three columns
+// and the neighbouring waves' rows re-read the same lines: L1 hits) -- each row is reloaded for the next column right behind its last
+// use.  LDS holds weights only: 12 ds_read_b128 per 72 MFMAs (0.17), three rotating 12 KB rows by DMA, one barrier per 72 MFMAs.
+// Tap order is (k-step, dx, dy): not the other kernels' order -- rounding-level differences, as the phase decomposition has anyway.
+constexpr int UQ_ROWS = 4;                                                   // output rows per wave
+constexpr int UQ_TILE_H = 4 * UQ_ROWS;                                       // 16 low-resolution rows per workgroup
+constexpr int UQ_LDS_BYTES = UP_WBUFS * UP_WUNITS * 16 + 256;                // weights + the bias row: 37 120 B
+
+__global__ __launch_bounds__(S_THREADS, 2) void conv3x3_split_upsq_kernel(const SplitConvParams p)
+{
+    extern __shared__ u32x4 lds[];
+    u32x4* const wbuf0 = lds;                                                // [UP_WBUFS][UP_WUNITS]
+    float* const biasl = reinterpret_cast<float*>(lds + UP_WBUFS * UP_WUNITS);
+    const unsigned wAddr = (unsigned)(uintptr_t)(up_lds_char*)lds;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int j = lane & 31, h = lane >> 5;
+    int bid;
+    {
+        const int nwg = gridDim.x, q = nwg >> 3, r = nwg & 7, xcd = blockIdx.x & 7;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (blockIdx.x >> 3);
+    }
+    const int tx = bid % p.tilesX, ty = bid / p.tilesX;
+    const int oy0 = ty * UQ_TILE_H + wave * UQ_ROWS, ox0 = tx * ST_W;       // this WAVE's first low-resolution row, the tile's first column
+    const int groups = p.Cin >> 3;
+    constexpr int K = 4, CP = 256, STEPS = 4 * K * 3;
+    if (tid < 64) biasl[tid] = p.bias ? p.bias[tid] : 0.0f;
+    auto lap = [&](int slot) {
+        if (p.stamps && tid == 0) p.stamps[(size_t)blockIdx.x * 10 + slot] = __builtin_amdgcn_s_memrealtime();
+    };
+    lap(0);
+
+    // weights of step g = (image m, k-step ks, column dx): the three taps (dy, dx) as (plane: hi | lo) x (dy) x (lane half): 12 pieces
+    auto weight_dma = [&](int g) {
+        if (p.dbg & 4) return;
+        const int m = g / (3 * K), rem = g - m * (3 * K);
+        const int ks = rem / 3, dx = rem - 3 * ks;
+        const unsigned dst = wAddr + (unsigned)(g % UP_WBUFS) * (UP_WUNITS * 16);
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            const int pc = wave + 4 * k;
+            const int plane = pc / 6, dy = (pc % 6) >> 1, hh = pc & 1;
+            const int tk = (3 * dy + dx) * K + ks;
+            const unsigned unit = (unsigned)(((tk * 2 + plane) * 2 + hh) * CP + m * 64);
+            up_dma16(p.wq + 1, unit * 16u + (unsigned)lane * 16u, dst + (unsigned)pc * 1024u);
+        }
+    };
+    // activations: row i (0..5 = image rows oy0 - 1 + i, clamped) of column dx, group 2 ks + h, parts hi / lo' -- one 16-byte load per lane
+    const rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<u32x4*>(p.xps), 0, (int)((size_t)2 * groups * p.xpsPlane * 16), 0x00020000);
+    unsigned rowoff[UQ_ROWS + 2], coloff[3];
+#pragma unroll
+    for (int i = 0; i < UQ_ROWS + 2; ++i) rowoff[i] = (unsigned)(min(max(oy0 - 1 + i, 0), p.Hin - 1) * p.Win) * 16u + (unsigned)h * (unsigned)p.xpsPlane * 16u;
+#pragma unroll
+    for (int d = 0; d < 3; ++d) coloff[d] = (unsigned)min(max(ox0 + j + d - 1, 0), p.Win - 1) * 16u;
+    const unsigned lostep = (unsigned)groups * (unsigned)p.xpsPlane * 16u;   // hi -> lo' part
+    u32x4 bh[UQ_ROWS + 2], bo[UQ_ROWS + 2];
+    auto bload = [&](int i, int g) {                                         // row i for step g
+        const int rem = g % (3 * K), ks = rem / 3, dx = rem - 3 * ks;
+        const unsigned vo = rowoff[i] + (dx == 0 ? coloff[0] : dx == 1 ? coloff[1] : coloff[2]);
+        const unsigned so = (unsigned)(2 * ks) * (unsigned)p.xpsPlane * 16u;
+        if (p.dbg & 2) return;
+        bh[i] = __builtin_amdgcn_raw_buffer_load_b128(xrs, (int)vo, (int)so, 0);
+        bo[i] = __builtin_amdgcn_raw_buffer_load_b128(xrs, (int)vo, (int)(so + lostep), 0);
+    };
+
+    const float unscale = reinterpret_cast<const float*>(p.wq)[1];
+    const int ogroups = p.Cout >> 3;
+    const rsrc_t prs = __builtin_amdgcn_make_buffer_rsrc(p.ps, 0, (int)((size_t)2 * ogroups * p.psPlane * 16), 0x00020000);
+    unsigned mag = 0u;
+    const unsigned lopart = (unsigned)h * (unsigned)(ogroups * p.psPlane) * 16u;
+
+    weight_dma(0);
+    weight_dma(1);
+#pragma unroll
+    for (int i = 0; i < UQ_ROWS + 2; ++i) { bh[i] = u32x4{0u, 0u, 0u, 0u}; bo[i] = bh[i]; bload(i, 0); }
+    int G = 0;
+#pragma unroll 1
+    for (int m = 0; m < 4; ++m) {
+        f32x16 acc[2][UQ_ROWS];
+#pragma unroll
+        for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+            for (int r = 0; r < UQ_ROWS; ++r)
+#pragma unroll
+                for (int i = 0; i < 16; ++i) acc[cb][r][i] = 0.0f;
+#pragma unroll 1
+        for (int s = 0; s < 3 * K; ++s, ++G) {
+            // W(G) has landed (requested two steps ago; everything this wave requested since may stay in flight -- simply: all of it
+            // has had a step's time), everyone is done with step G - 1
+            // Requests complete in issue order; behind W(G) this wave has issued: the 12 row reloads of step G - 2, W(G + 1) (3), the
+            // 12 reloads of step G - 1 -- and the 32 stores of an epilogue that ran in between.  All of that may stay in flight.
+            if (p.dbg) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            else if (G == 0) asm volatile("s_waitcnt vmcnt(15)" ::: "memory");
+            else if (s == 0) asm volatile("s_waitcnt vmcnt(59)" ::: "memory");
+            else if (G + 1 >= STEPS) asm volatile("s_waitcnt vmcnt(24)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(27)" ::: "memory");
+            if (!(p.dbg & 64)) __syncthreads();
+            if (G == 0) lap(1);
+            if (G + 2 < STEPS) weight_dma(G + 2);
+            const u32x4* wl = wbuf0 + (G % UP_WBUFS) * UP_WUNITS + h * 64 + j;
+            const int gn = G + 1 < STEPS ? G + 1 : G;                        // the step the rows are reloaded for
+#pragma unroll
+            for (int dy = 0; dy < 3; ++dy) {
+                const f16x8 a0h = __builtin_bit_cast(f16x8, wl[dy * 128]);
+                const f16x8 a0l = __builtin_bit_cast(f16x8, wl[UP_WROW + dy * 128]);
+                const f16x8 a1h = __builtin_bit_cast(f16x8, wl[dy * 128 + 32]);
+                const f16x8 a1l = __builtin_bit_cast(f16x8, wl[UP_WROW + dy * 128 + 32]);
+                const f16x8 a0s = a0h * (_Float16)0.00048828125f;
+                const f16x8 a1s = a1h * (_Float16)0.00048828125f;
+#pragma unroll
+                for (int r = 0; r < UQ_ROWS; ++r) {
+                    if (!(p.dbg & 1)) {
+                        const f16x8 vh = __builtin_bit_cast(f16x8, bh[r + dy]);
+                        const f16x8 vo = __builtin_bit_cast(f16x8, bo[r + dy]);
+                        acc[0][r] = mfma16(a0l, vh, acc[0][r]);
+                        acc[0][r] = mfma16(a0s, vo, acc[0][r]);
+                        acc[0][r] = mfma16(a0h, vh, acc[0][r]);
+                        acc[1][r] = mfma16(a1l, vh, acc[1][r]);
+                        acc[1][r] = mfma16(a1s, vo, acc[1][r]);
+                        acc[1][r] = mfma16(a1h, vh, acc[1][r]);
+                    }
+                    // a row is reloaded for the next step right behind its last use: rows 0, 1, 2 after (dy, r = 0), rows 3, 4, 5 after (dy = 2, r)
+                    if (r == 0) bload(dy, gn);
+                    else if (dy == 2) bload(r + 2, gn);
+                }
+            }
+        }
+        lap(2 + 2 * m);
+        if (p.dbg & 8) {
+            if (acc[0][0][0] == 123.456f) p.ps[0] = u32x4{1u, 2u, 3u, 4u};
+            lap(3 + 2 * m);
+            continue;
+        }
+        // ---- epilogue of parity (py, px), as conv3x3_split_upsp_kernel's (bias in registers before the first store)
+        const int py = m >> 1, px = m & 1;
+        const int lx = ox0 + j, X = 2 * lx + px;
+        float bvv[2][4][4];
+#pragma unroll
+        for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+            for (int gi = 0; gi < 4; ++gi) {
+                const float4 bq = *reinterpret_cast<const float4*>(biasl + cb * 32 + 8 * gi + 4 * h);
+                bvv[cb][gi][0] = bq.x; bvv[cb][gi][1] = bq.y; bvv[cb][gi][2] = bq.z; bvv[cb][gi][3] = bq.w;
+            }
+        __builtin_amdgcn_s_waitcnt(0xC07F);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int r = 0; r < UQ_ROWS; ++r) {
+            const int ly = oy0 + r, Y = 2 * ly + py;
+            const bool inside = ly < p.Hin && lx < p.Win && Y > 0 && Y < p.H - 1 && X > 0 && X < p.W - 1;
+            const unsigned voff = inside ? (unsigned)(Y * p.W + X) * 16u + lopart : BAD_OFFSET;
+#pragma unroll
+            for (int cb = 0; cb < 2; ++cb) {
+#pragma unroll
+                for (int gi = 0; gi < 4; ++gi) {
+                    f16x4 th, tl;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        float v = acc[cb][r][4 * gi + e] * unscale + bvv[cb][gi][e];
+                        if (p.act == ISR_ACT_RELU) v = v > 0.f ? v : 0.f;
+                        else if (p.act == ISR_ACT_LEAKY) v = v > 0.f ? v : v * p.slope;
+                        _Float16 a, b;
+                        split16x(v, a, b);
+                        th[e] = a; tl[e] = b;
+                        if (inside) mag = isr_umax(mag, isr_mag(v));
+                    }
+                    const int g = cb * 4 + gi;
+                    const u32x2 uh = __builtin_bit_cast(u32x2, th), ul = __builtin_bit_cast(u32x2, tl);
+                    const u32x2 s0 = __builtin_amdgcn_permlane32_swap(uh.x, ul.x, false, false);
+                    const u32x2 s1 = __builtin_amdgcn_permlane32_swap(uh.y, ul.y, false, false);
+                    const u32x4 unit = {s0.x, s1.x, s0.y, s1.y};
+                    __builtin_amdgcn_raw_buffer_store_b128(unit, prs, (int)((p.dbg & 16) ? BAD_OFFSET : voff), g * p.psPlane * 16, 0);
+                }
+            }
+        }
+        lap(3 + 2 * m);
+    }
+    isr_range_note(p.absmax, mag);
+}
+
 // ---- the output's one-pixel frame: the convolution as it is defined (interpolate, zero-pad, nine taps), per pixel and group of eight
 //      output channels in fp32 -- a k-ordered FMA chain over (tap, input channel) on U(x), x = hi + lo' 2^-11 of the packed input.
 struct UpsFrameParams {
