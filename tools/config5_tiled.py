@@ -77,16 +77,26 @@ with torch.no_grad():
         parts.append(sr.compute_strip(x, rank, 8))
         torch.cuda.synchronize(); t_strip.append(time.perf_counter() - t0)
     same = torch.equal(torch.cat([p[0] for p in parts], dim=2), full_raw)
-print("4K super-resolution: whole frame %.1f ms; 8 strips %.1f ms each (max %.1f); strips == whole frame bit for bit: %s" % (
-    t_full * 1e3, 1e3 * np.mean(t_strip), 1e3 * max(t_strip), same))
+    # the same frame as the (rows x columns) grid of screen tiles with the smallest largest tile + halo (round 5)
+    grid = parallel_sr.best_grid(8, H, W)
+    t_tile, same_grid = [], True
+    for rank in range(8):
+        y0, y1, x0, x1 = parallel_sr.tile_bounds(H, W, grid, rank)
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        raw_t, rgb_t = sr.compute_strip(x, rank, 8, grid=grid)
+        torch.cuda.synchronize(); t_tile.append(time.perf_counter() - t0)
+        same_grid = same_grid and torch.equal(raw_t, full_raw[:, :, 4 * y0:4 * y1, 4 * x0:4 * x1]) and torch.equal(rgb_t, full_rgb[:, :, 4 * y0:4 * y1, 4 * x0:4 * x1])
+print("4K super-resolution: whole frame %.1f ms; 8 strips %.1f ms each (max %.1f); strips == whole frame bit for bit: %s; %d x %d tiles %.1f ms each (max %.1f), bit for bit: %s" % (
+    t_full * 1e3, 1e3 * np.mean(t_strip), 1e3 * max(t_strip), same, grid[0], grid[1], 1e3 * np.mean(t_tile), 1e3 * max(t_tile), same_grid))
 result = {"config": "BASELINE #5 rehearsed on one GPU", "volume": "ejecta%d (seed %d), generated tile-wise" % (n, 1024 if n == 1024 else 272),
           "tiles": "2x2x2 + 8-voxel halo", "image": [W, H], "generate_s": round(t_gen, 1),
           "tile_load_s_mean": round(float(np.mean([t[0] for t in times])), 2),
           "tile_raymarch_ms": [round(t[1], 3) for t in times], "unsplit_raymarch_ms": round(ms_whole, 3), "unsplit_bricks": info["bricks"],
           "hit_pixels": hits, "composite_mask_mismatches": diff_mask, "composite_bit_identical_12ch": identical,
-          "sr_4k_whole_ms": round(t_full * 1e3, 2), "sr_4k_strip_ms": [round(t * 1e3, 2) for t in t_strip], "sr_strips_bit_identical": bool(same)}
+          "sr_4k_whole_ms": round(t_full * 1e3, 2), "sr_4k_strip_ms": [round(t * 1e3, 2) for t in t_strip], "sr_strips_bit_identical": bool(same),
+          "sr_tile_grid": list(grid), "sr_4k_tile_ms": [round(t * 1e3, 2) for t in t_tile], "sr_tiles_bit_identical": bool(same_grid)}
 print(json.dumps(result), flush=True)
 if out_json:
     with open(out_json, "w") as f:
         json.dump(result, f, indent=1)
-assert same and identical and diff_mask == 0
+assert same and same_grid and identical and diff_mask == 0
