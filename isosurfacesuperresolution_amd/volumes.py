@@ -26,6 +26,16 @@ def sphere64():
     return _sparsify(v)
 
 
+def slab64():
+    """A field that is LINEAR along x inside a box (0 outside): node-centred trilinear interpolation reproduces a linear field exactly,
+    so the isosurface of the relative isovalue q is the plane x = 15 + 32 q, for every ray that enters through the low-x face -- an
+    analytic answer of a different kind than the sphere's (flat faces, long runs through one leaf row, a constant gradient)."""
+    v = np.zeros((64, 64, 64), np.float32)
+    ramp = (np.arange(16, 48, dtype=np.float32) - 15.0) / 32.0           # 1/32 .. 1 at x = 16 .. 47
+    v[12:52, 12:52, 16:48] = ramp[None, None, :]
+    return v
+
+
 def _upsample_axis(a, n, axis):
     """Linear resampling of ``a`` along ``axis`` to ``n`` samples, endpoints aligned."""
     m = a.shape[axis]

@@ -58,6 +58,40 @@ def test_sphere_depth_and_normal_analytic(oracle):
     assert st["hits"] == int(hit.sum())
 
 
+@pytest.mark.parametrize("origin,lookat", [((-1.7, 0.0, 0.0), (0.0, 0.0, 0.0)), ((-1.5, 0.35, 0.2), (0.0, 0.0, 0.0)),
+                                           ((-1.6, -0.2, 0.3), (0.1, 0.05, -0.05))])
+@pytest.mark.parametrize("iso", [0.3, 0.5, 0.8])
+def test_slab_plane_depth_and_normal_analytic(oracle, origin, lookat, iso):
+    """A field linear in x (volumes.slab64): trilinear interpolation is exact on it, the isosurface of the RELATIVE isovalue q is the
+    plane x_index = 15 + 32 q.  The centre pixel of an odd-sized image looks along the optical axis, so its depth is the distance
+    from the camera to that plane along (lookat - origin) whatever the projection's conventions are, to the resolution of the five
+    bisections (a voxel / 64); the camera-space normal, flipped to z >= 0, has z = |axis . plane normal| exactly (constant gradient)."""
+    vol = V.slab64()
+    ov = oracle.OracleVolume(vol)
+    info = ov.info()
+    s, t = info["scale"], info["translation"]
+    res = 97
+    p = oracle.make_params(res, res, origin=origin, lookat=lookat, fov=40.0, isovalue=iso)
+    img, st = oracle.render(ov, p, threads=2)
+    c = res // 2
+    px = img[c, c]
+    assert px[3] == 1.0
+    o, a = np.array(origin, np.float64), np.array(lookat, np.float64)
+    f = (a - o) / np.linalg.norm(a - o)
+    x_plane = (15.0 + 32.0 * iso * float(info["max_value"])) * s + t[0]             # world x of the plane
+    depth = (x_plane - o[0]) / f[0]
+    hit = o + depth * f
+    lo = (np.array([16, 12, 12]) * s + np.array(t))[1:]
+    hi = (np.array([47, 51, 51]) * s + np.array(t))[1:]
+    assert (hit[1:] > lo + 2 * s).all() and (hit[1:] < hi - 2 * s).all()            # the axis does hit the low-x face region
+    assert abs(px[7] - depth) < s / 64 * 1.5 / abs(f[0]) + 1e-6, (px[7], depth)
+    assert abs(px[6] - abs(f[0])) < 1e-5 and abs(np.linalg.norm(px[4:7]) - 1.0) < 1e-5
+    # ... and every pixel whose axis-parallel neighbour rays hit the same face sees a depth that varies smoothly: the central 9 x 9 block
+    blk = img[c - 4:c + 5, c - 4:c + 5]
+    assert (blk[..., 3] == 1).all() and np.abs(blk[..., 6] - abs(f[0])).max() < 1e-5
+    assert np.abs(blk[..., 7] - depth).max() < 0.05 * depth
+
+
 def test_miss_pixels_and_constants(oracle):
     _, ov, _, p = _sphere_setup(oracle, res=64)
     img, _ = oracle.render(ov, p, threads=1)

@@ -53,9 +53,10 @@ def _compare(gpu, ref):
     dict(vol="sphere64", W=128, H=128, fov=45.0, iso=0.5, frames=(0, 7, 19)),
     dict(vol="ejecta64", W=160, H=90, fov=30.0, iso=0.34, frames=(3, 40)),
     dict(vol="ejecta128", W=240, H=135, fov=30.0, iso=0.34, frames=(11,)),
+    dict(vol="slab64", W=144, H=96, fov=40.0, iso=0.5, frames=(30, 33, 2)),      # flat faces, a linear field (analytic: test_oracle_iso.py)
 ])
 def test_parity_with_oracle(renderer, oracle, case, variant):
-    vol = {"sphere64": V.sphere64, "ejecta64": lambda: V.ejecta(64), "ejecta128": lambda: V.ejecta(128)}[case["vol"]]()
+    vol = {"sphere64": V.sphere64, "ejecta64": lambda: V.ejecta(64), "ejecta128": lambda: V.ejecta(128), "slab64": V.slab64}[case["vol"]]()
     renderer.set_kernel_variant(variant)
     renderer.load_dense(vol)
     ov = oracle.OracleVolume(vol)
