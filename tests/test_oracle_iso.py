@@ -183,6 +183,29 @@ def test_gvdb_semantics_sphere_analytic(oracle):
     assert oracle.render_gvdb(ov, p2, threads=2)[..., 3].sum() < hit.sum()
 
 
+@pytest.mark.parametrize("q", [0.3, 0.5, 0.8])
+def test_gvdb_semantics_slab_plane_analytic(oracle, q):
+    """The CUDA renderer's arithmetic on the linear-field slab: cell-centred sampling (voxel i at i + 0.5) is exact on a linear field,
+    the ABSOLUTE isovalue q is met on the plane x_index = 15.5 + 32 q; world = (index - 32) * 0.5 / 48 (brick box [16, 48) x [8, 56)^2,
+    longest edge -> 0.5).  Seen from (-1, 0, 0) the plane is perpendicular to the optical axis, so the NDC depth (a function of z_eye
+    only, render_kernel.cu:247) is the same constant on every pixel that hits the low-x face, and the outward view-space normal is
+    (0, 0, 1) -- to the 0.05-voxel march + 10 bisections' resolution (5e-5 voxel)."""
+    ov = oracle.OracleVolume(V.slab64())
+    p = oracle.make_params(96, 96, origin=(-1.0, 0.0, 0.0), fov=45.0, isovalue=q)
+    img = oracle.render_gvdb(ov, p, threads=2)
+    near, far = 0.1, 5000.0
+    ndc = lambda d: (far + near) / (far - near) - 2 * far * near / ((far - near) * d)
+    z_eye = (15.5 + 32.0 * q - 32.0) * (0.5 / 48.0) + 1.0
+    blk = img[24:72, 24:72]                                      # rays through the face's interior
+    assert (blk[..., 3] == 1).all()
+    assert np.abs(blk[..., 7] - ndc(z_eye)).max() < 2e-6
+    assert np.abs(blk[..., 4:7] - np.array([0.0, 0.0, 1.0])).max() < 1e-5
+    # a larger absolute isovalue lies deeper in the ramp
+    if q < 0.8:
+        p2 = oracle.make_params(96, 96, origin=(-1.0, 0.0, 0.0), fov=45.0, isovalue=q + 0.1)
+        assert oracle.render_gvdb(ov, p2, threads=2)[48, 48, 7] > img[48, 48, 7]
+
+
 def test_gvdb_semantics_flow_depth_viewport_and_ao(oracle):
     ov, p = _gvdb_sphere(oracle, res=64, origin=(0.3, 0.1, 1.0), last_origin=(0.25, 0.1, 1.0))
     img = oracle.render_gvdb(ov, p, threads=2)
