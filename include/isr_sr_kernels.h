@@ -372,6 +372,10 @@ int isrConvUpsPhase(const void* xps, const void* wq, const float* w, const float
 int isrPackSplit(const float* x, void* ps, int C, int H, int W, long long xPlane, long long psPlane, void* stream);
 int isrTrunkDataflowPackedResult(int cin0, int H, int W, long long* offsetBytes, long long* planeUnits);
 void isrSetTrunkPackedResult(int on);      /* 1: isrTrunkDataflow also writes that packed-split result (default 0) */
+/* Rows of the 16 x 32 tile per wave in the one-tile form of isrTrunkDataflow: 2 (default; eight waves, two per SIMD) or 4 (four waves of
+ * 4 rows x 64 channels, one per SIMD, accumulators in AGPRs).  Same bits either way; 4 is the slower one on MI355X.
+ * Environment: ISR_TRUNK_ROWS. */
+void isrSetTrunkRows(int rows);
 
 /* Optional per-dispatch timing of isrConv3x3Forward for benchmarks: while enabled, every forward
  * dispatch carries a start/stop event pair on its own packet (no extra stream operations).

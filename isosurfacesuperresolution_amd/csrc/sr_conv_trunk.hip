@@ -127,49 +127,64 @@ __device__ __forceinline__ void trunk16_dma4(const void* base, unsigned voff, un
 // One k-step of MFMAs on this form's LDS geometry: the arithmetic of split_kstep (sr_split_common.h), tap for tap, product for
 // product.  `between(tap)` runs after each tap's MFMAs are issued: the caller spreads its DMA requests over the k-step there, so
 // that a request that has to queue for the memory pipeline does so behind 12 MFMAs of cover instead of in front of the k-step.
-struct Trunk16Operands { f16x8 a0h, a0l, a1h, a1l, bh[2], bo[2]; };
+// ROWS: image rows of the tile per wave -- 2 (eight waves, two per SIMD) or 4 (four waves, one per SIMD: the same four weight
+// fragments serve twice the MFMAs, i.e. 0.5 instead of 0.67 LDS fragment reads per MFMA, and a wave has the SIMD's 512 registers).
+template <int ROWS>
+struct Trunk16Operands { f16x8 a0h, a0l, a1h, a1l, bh[ROWS], bo[ROWS]; };
 
-__device__ __forceinline__ Trunk16Operands trunk16_operands(const u32x4* wl, const u32x4* bl, int tap)
+template <int ROWS>
+__device__ __forceinline__ Trunk16Operands<ROWS> trunk16_operands(const u32x4* wl, const u32x4* bl, int tap)
 {
     const int dy = tap / 3, dx = tap - dy * 3;
-    Trunk16Operands o;
+    Trunk16Operands<ROWS> o;
     o.a0h = __builtin_bit_cast(f16x8, wl[tap * 128]);
     o.a0l = __builtin_bit_cast(f16x8, wl[S_WPART + tap * 128]);
     o.a1h = __builtin_bit_cast(f16x8, wl[tap * 128 + 32]);
     o.a1l = __builtin_bit_cast(f16x8, wl[S_WPART + tap * 128 + 32]);
 #pragma unroll
-    for (int r = 0; r < 2; ++r) {
+    for (int r = 0; r < ROWS; ++r) {
         o.bh[r] = __builtin_bit_cast(f16x8, bl[(r + dy) * P16_W + dx]);
         o.bo[r] = __builtin_bit_cast(f16x8, bl[P16_PART + (r + dy) * P16_W + dx]);
     }
     return o;
 }
 
-template <typename Between>
-__device__ __forceinline__ void trunk16_kstep(f32x16 (&acc)[2][2], const u32x4* wl, const u32x4* bl, Between between)
+template <int ROWS, typename Between>
+__device__ __forceinline__ void trunk16_kstep(f32x16 (&acc)[2][ROWS], const u32x4* wl, const u32x4* bl, Between between)
 {
     // Software-pipelined over the taps: tap t + 1's eight operand fragments are requested BEFORE tap t's MFMAs are issued and are
     // consumed one basic block later (`between` branches, so every tap is a block of its own and the compiler's scheduler cannot
     // do this by itself: it issued a tap's reads at the top of the tap's block and waited for them with lgkmcnt(0), eight LDS
     // latencies per k-step and wave with only the other wave of the SIMD to cover them).  The fence keeps the requests in front.
-    Trunk16Operands cur = trunk16_operands(wl, bl, 0);
+    Trunk16Operands<ROWS> cur = trunk16_operands<ROWS>(wl, bl, 0);
 #pragma unroll
     for (int tap = 0; tap < 9; ++tap) {
-        Trunk16Operands nxt = cur;
+        Trunk16Operands<ROWS> nxt = cur;
         if (tap < 8) {
-            nxt = trunk16_operands(wl, bl, tap + 1);
+            nxt = trunk16_operands<ROWS>(wl, bl, tap + 1);
             __builtin_amdgcn_sched_barrier(0);
         }
         const f16x8 a0s = cur.a0h * (_Float16)0.00048828125f;               // w_hi 2^-11: partner of the scaled x_lo'
         const f16x8 a1s = cur.a1h * (_Float16)0.00048828125f;
+        if (ROWS == 2) {
 #pragma unroll
-        for (int r = 0; r < 2; ++r) {
-            acc[0][r] = mfma16(cur.a0l, cur.bh[r], acc[0][r]);
-            acc[0][r] = mfma16(a0s, cur.bo[r], acc[0][r]);
-            acc[0][r] = mfma16(cur.a0h, cur.bh[r], acc[0][r]);
-            acc[1][r] = mfma16(cur.a1l, cur.bh[r], acc[1][r]);
-            acc[1][r] = mfma16(a1s, cur.bo[r], acc[1][r]);
-            acc[1][r] = mfma16(cur.a1h, cur.bh[r], acc[1][r]);
+            for (int r = 0; r < ROWS; ++r) {
+                acc[0][r] = mfma16(cur.a0l, cur.bh[r], acc[0][r]);
+                acc[0][r] = mfma16(a0s, cur.bo[r], acc[0][r]);
+                acc[0][r] = mfma16(cur.a0h, cur.bh[r], acc[0][r]);
+                acc[1][r] = mfma16(cur.a1l, cur.bh[r], acc[1][r]);
+                acc[1][r] = mfma16(a1s, cur.bo[r], acc[1][r]);
+                acc[1][r] = mfma16(cur.a1h, cur.bh[r], acc[1][r]);
+            }
+        } else {
+            // one wave per SIMD: nobody else fills the pipe behind a dependent MFMA, so the three products of an accumulator are
+            // issued eight MFMAs apart (product-major) -- per accumulator the same three products in the same order: same bits
+#pragma unroll
+            for (int r = 0; r < ROWS; ++r) { acc[0][r] = mfma16(cur.a0l, cur.bh[r], acc[0][r]); acc[1][r] = mfma16(cur.a1l, cur.bh[r], acc[1][r]); }
+#pragma unroll
+            for (int r = 0; r < ROWS; ++r) { acc[0][r] = mfma16(a0s, cur.bo[r], acc[0][r]); acc[1][r] = mfma16(a1s, cur.bo[r], acc[1][r]); }
+#pragma unroll
+            for (int r = 0; r < ROWS; ++r) { acc[0][r] = mfma16(cur.a0h, cur.bh[r], acc[0][r]); acc[1][r] = mfma16(cur.a1h, cur.bh[r], acc[1][r]); }
         }
         between(tap);
         cur = nxt;
@@ -221,8 +236,8 @@ __device__ __forceinline__ void trunk16_patch_run(int sub, const char* plane, un
 // Not LAST: channels 0 .. 31 -- the next layer's first two k-steps -- go straight into the two patch buffers (pk0, pk1: LDS, this
 // tile's centre; pixels outside the image as zeros) and to memory only where a neighbour will read them (the tile's outermost
 // ring); channels 32 .. 63 go to memory whole and come back by DMA under those two k-steps.
-template <int KIND, bool LAST, bool DIAG>
-__device__ __forceinline__ void trunk16_epilogue(const Trunk16Params& p, f32x16 (&acc)[2][2], f32x16 (&F)[2][2], unsigned& mag, float unscale,
+template <int KIND, bool LAST, bool DIAG, int ROWS>
+__device__ __forceinline__ void trunk16_epilogue(const Trunk16Params& p, f32x16 (&acc)[2][ROWS], f32x16 (&F)[2][ROWS], unsigned& mag, float unscale,
                                                  const float* biasl, const char* out, unsigned planeBytes, int oy0, int ox0, int wave, int j, int h,
                                                  u32x4* pk0, u32x4* pk1)
 {
@@ -233,12 +248,12 @@ __device__ __forceinline__ void trunk16_epilogue(const Trunk16Params& p, f32x16 
     const rsrc_t qrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(out), 0, (int)(16u * planeBytes), 0x00020000);
     const int ox = ox0 + j;
 #pragma unroll
-    for (int r = 0; r < 2; ++r) {
-        const int oy = oy0 + wave * 2 + r;
+    for (int r = 0; r < ROWS; ++r) {
+        const int oy = oy0 + wave * ROWS + r;
         const bool inside = oy < p.H && ox < p.W && !(DIAG && (p.dbg & 4));
         const unsigned voff = !inside ? BAD_OFFSET : LAST ? (unsigned)(oy * p.W + ox + 4 * h * p.yPlane) * 4u      // the lane half's 4 channels: in the lane offset
                                                           : (unsigned)(oy * p.W + ox) * 16u + 8u * (unsigned)h;
-        const int row = wave * 2 + r;
+        const int row = wave * ROWS + r;
         const bool ring = row == 0 || row == T16_H - 1 || j == 0 || j == T16_W - 1;
         const unsigned voffRing = ring ? voff : BAD_OFFSET;
         const bool live = oy < p.H && ox < p.W;                              // (the stores' ablation switch does not touch the LDS hand-over)
@@ -288,9 +303,10 @@ __device__ __forceinline__ void trunk16_epilogue(const Trunk16Params& p, f32x16 
 // DIAG: the instantiation with the diagnostics (ablation switches, phase stamps) compiled in; the product launch is the one without:
 // the 108 unrolled MFMAs of the "operands read once" path and its nine copies of the DMA bookkeeping made the kernel's code large
 // enough to slow the real path down (measured when a second such path was added: 636 -> 755 us).
-template <bool DIAG>
-__global__ __launch_bounds__(T16_THREADS) void trunk_dataflow_kernel(const Trunk16Params p)
+template <bool DIAG, int ROWS>
+__global__ __launch_bounds__(64 * T16_H / ROWS) void trunk_dataflow_kernel(const Trunk16Params p)
 {
+    constexpr int WAVES = T16_H / ROWS;                                      // 8 or 4
     const int dbg = DIAG ? p.dbg : 0;
     extern __shared__ u32x4 lds[];
     u32x4* const pbuf0 = lds;                                                // patch buffers at + P16_UNITS
@@ -314,11 +330,11 @@ __global__ __launch_bounds__(T16_THREADS) void trunk_dataflow_kernel(const Trunk
     const unsigned long long deadline = __builtin_amdgcn_s_memrealtime() + p.timeoutTicks;
     const Trunk16Lane lanes = trunk16_lane_setup(p, oy0, ox0, lane);
 
-    f32x16 F[2][2];                                                          // the residual stream of this lane's 2 rows x 64 channels
+    f32x16 F[2][ROWS];                                                       // the residual stream of this lane's ROWS rows x 64 channels
 #pragma unroll
     for (int cb = 0; cb < 2; ++cb)
 #pragma unroll
-        for (int r = 0; r < 2; ++r)
+        for (int r = 0; r < ROWS; ++r)
 #pragma unroll
             for (int i = 0; i < 16; ++i) F[cb][r][i] = 0.0f;
     unsigned mag = 0u;
@@ -330,12 +346,13 @@ __global__ __launch_bounds__(T16_THREADS) void trunk_dataflow_kernel(const Trunk
     const u32x4* wq = trunk16_uniform(p.wq[0]);
     // bias of layer l into bias buffer l & 1: one dword-wide DMA (64 floats) by the last wave; a layer without bias reads zeros
     auto stage_bias = [&](int l, const float* b) {
-        if (wave != T16_WAVES - 1) return;
+        if (wave != WAVES - 1) return;
         if (b) trunk16_dma4(b, (unsigned)lane * 4u, bAddr + (unsigned)(l & 1) * 256u);
         else biasl0[(l & 1) * 64 + lane] = 0.0f;
     };
-    // this wave's role (see Trunk16Lane): weights (waves 0..3: part, half) or patch (waves 4..7: part, group)
-    const bool wrole = wave < 4;
+    // this wave's role (see Trunk16Lane): weights (waves 0..3: part, half) or patch (waves 4..7: part, group); with four waves
+    // every wave has one role of each kind
+    const bool wrole = WAVES == 4 || wave < 4, prole = WAVES == 4 || wave >= 4;
     const int rpart = (wave & 3) >> 1, rsel = wave & 1;
     const unsigned wdstRole = (unsigned)(rpart * S_WPART + rsel * 64) * 16u;             // + the weight buffer + tap * 2048
     const unsigned pdstRole = (unsigned)((rpart * 2 + rsel) * P16_PIX) * 16u;            // + the patch buffer + run * 1024
@@ -349,12 +366,11 @@ __global__ __launch_bounds__(T16_THREADS) void trunk_dataflow_kernel(const Trunk
     };
     // the first layer's first k-step: nothing to wait for
     stage_bias(0, trunk16_uniform(p.bias[0]));
-    if (wrole) {
-        if (dmaW) {
+    if (wrole && dmaW) {
 #pragma unroll
-            for (int tap = 0; tap < 9; ++tap) weight_tap(tap, wq, p.groups0 >> 1, 0, wAddr);
-        }
-    } else if (dmaX) {
+        for (int tap = 0; tap < 9; ++tap) weight_tap(tap, wq, p.groups0 >> 1, 0, wAddr);
+    }
+    if (prole && dmaX) {
         const char* const plane = patch_plane(ws + p.xpsOff, p.groups0, 0);
 #pragma unroll
         for (int sub = 0; sub < P16_SUBS; ++sub) trunk16_patch_run<false>(sub, plane, pAddr + pdstRole, lanes);
@@ -397,17 +413,17 @@ __global__ __launch_bounds__(T16_THREADS) void trunk_dataflow_kernel(const Trunk
                 }
             }
             lap(1);
-            if (dmaX && !wrole) {
+            if (dmaX && prole) {
                 const char* const plane = patch_plane(tin, groups, 0);
 #pragma unroll
                 for (int sub = 0; sub < P16_SUBS; ++sub) trunk16_patch_run<true>(sub, plane, pAddr + (unsigned)(gk & 1) * (P16_UNITS * 16) + pdstRole, lanes);
             }
         }
-        f32x16 acc[2][2];
+        f32x16 acc[2][ROWS];
 #pragma unroll
         for (int cb = 0; cb < 2; ++cb)
 #pragma unroll
-            for (int r = 0; r < 2; ++r)
+            for (int r = 0; r < ROWS; ++r)
 #pragma unroll
                 for (int i = 0; i < 16; ++i) acc[cb][r][i] = 0.0f;
 #pragma unroll 1
@@ -433,7 +449,8 @@ __global__ __launch_bounds__(T16_THREADS) void trunk_dataflow_kernel(const Trunk
             auto between = [&](int tap) {
                 if (wrole) {
                     if (wany) weight_tap(tap, wimg, wksteps, wks, wnxt);
-                } else {
+                }
+                if (prole) {
                     if (pany) {
                         if (haloOnly) {
                             trunk16_patch_run<true>(tap, pplane, pnxt + pdstRole, lanes);
@@ -445,19 +462,21 @@ __global__ __launch_bounds__(T16_THREADS) void trunk_dataflow_kernel(const Trunk
                     } else if (!more && !last && tap == 0) stage_bias(l + 1, biasNext);
                 }
             };
-            if (dbg & 32) {                                                // diagnostics: the k-step's 108 MFMAs on operands read once
+            if (ROWS == 2 && (dbg & 32)) {                                  // diagnostics: the k-step's 108 MFMAs on operands read once (eight-wave form only: registers)
                 const f16x8 a = __builtin_bit_cast(f16x8, wcur[h * 64 + j]), b = __builtin_bit_cast(f16x8, pcur[h * P16_PIX + j]);
                 if (dbg & 64) {                                            // ... with every tap's eight fragments read from LDS all the same (and dropped)
 #pragma unroll
                     for (int t = 0; t < 9; ++t) {
-                        const Trunk16Operands o = trunk16_operands(wcur + h * 64 + j, pcur + h * P16_PIX + (wave * 2) * P16_W + j, t);
-                        asm volatile("" :: "v"(o.a0h), "v"(o.a0l), "v"(o.a1h), "v"(o.a1l), "v"(o.bh[0]), "v"(o.bh[1]), "v"(o.bo[0]), "v"(o.bo[1]));
+                        const Trunk16Operands<ROWS> o = trunk16_operands<ROWS>(wcur + h * 64 + j, pcur + h * P16_PIX + (wave * ROWS) * P16_W + j, t);
+                        asm volatile("" :: "v"(o.a0h), "v"(o.a0l), "v"(o.a1h), "v"(o.a1l));
+#pragma unroll
+                        for (int r = 0; r < ROWS; ++r) asm volatile("" :: "v"(o.bh[r]), "v"(o.bo[r]));
 #pragma unroll
                         for (int q = 0; q < 3; ++q)
 #pragma unroll
                             for (int cb = 0; cb < 2; ++cb)
 #pragma unroll
-                                for (int r = 0; r < 2; ++r) acc[cb][r] = mfma16(a, b, acc[cb][r]);
+                                for (int r = 0; r < ROWS; ++r) acc[cb][r] = mfma16(a, b, acc[cb][r]);
                         between(t);
                     }
                 } else {
@@ -466,12 +485,12 @@ __global__ __launch_bounds__(T16_THREADS) void trunk_dataflow_kernel(const Trunk
 #pragma unroll
                         for (int cb = 0; cb < 2; ++cb)
 #pragma unroll
-                            for (int r = 0; r < 2; ++r) acc[cb][r] = mfma16(a, b, acc[cb][r]);
+                            for (int r = 0; r < ROWS; ++r) acc[cb][r] = mfma16(a, b, acc[cb][r]);
 #pragma unroll
                     for (int t = 0; t < 9; ++t) between(t);
                 }
             } else if (!(dbg & 1)) {
-                trunk16_kstep(acc, wcur + h * 64 + j, pcur + h * P16_PIX + (wave * 2) * P16_W + j, between);
+                trunk16_kstep<ROWS>(acc, wcur + h * 64 + j, pcur + h * P16_PIX + (wave * ROWS) * P16_W + j, between);
             } else {
 #pragma unroll
                 for (int t = 0; t < 9; ++t) between(t);
@@ -485,11 +504,11 @@ __global__ __launch_bounds__(T16_THREADS) void trunk_dataflow_kernel(const Trunk
             u32x4* const pk0 = pbuf0 + (gk & 1) * P16_UNITS;                 // the next layer's k-steps 0 and 1
             u32x4* const pk1 = pbuf0 + ((gk + 1) & 1) * P16_UNITS;
             if (last) {
-                if (kind == 0) trunk16_epilogue<0, true, DIAG>(p, acc, F, mag, unscale, biasl, tout, planeBytes, oy0, ox0, wave, j, h, pk0, pk1);
-                else trunk16_epilogue<2, true, DIAG>(p, acc, F, mag, unscale, biasl, tout, planeBytes, oy0, ox0, wave, j, h, pk0, pk1);
-            } else if (kind == 0) trunk16_epilogue<0, false, DIAG>(p, acc, F, mag, unscale, biasl, tout, planeBytes, oy0, ox0, wave, j, h, pk0, pk1);
-            else if (kind == 1) trunk16_epilogue<1, false, DIAG>(p, acc, F, mag, unscale, biasl, tout, planeBytes, oy0, ox0, wave, j, h, pk0, pk1);
-            else trunk16_epilogue<2, false, DIAG>(p, acc, F, mag, unscale, biasl, tout, planeBytes, oy0, ox0, wave, j, h, pk0, pk1);
+                if (kind == 0) trunk16_epilogue<0, true, DIAG, ROWS>(p, acc, F, mag, unscale, biasl, tout, planeBytes, oy0, ox0, wave, j, h, pk0, pk1);
+                else trunk16_epilogue<2, true, DIAG, ROWS>(p, acc, F, mag, unscale, biasl, tout, planeBytes, oy0, ox0, wave, j, h, pk0, pk1);
+            } else if (kind == 0) trunk16_epilogue<0, false, DIAG, ROWS>(p, acc, F, mag, unscale, biasl, tout, planeBytes, oy0, ox0, wave, j, h, pk0, pk1);
+            else if (kind == 1) trunk16_epilogue<1, false, DIAG, ROWS>(p, acc, F, mag, unscale, biasl, tout, planeBytes, oy0, ox0, wave, j, h, pk0, pk1);
+            else trunk16_epilogue<2, false, DIAG, ROWS>(p, acc, F, mag, unscale, biasl, tout, planeBytes, oy0, ox0, wave, j, h, pk0, pk1);
         }
         lap(4);
         // ---- publish: every wave's stores drained, then one agent-scope store of the tile's progress -------------------------
@@ -707,7 +726,7 @@ __global__ __launch_bounds__(T16_THREADS) void trunk_mt_kernel(const Trunk16Para
                         }
                     }
                 };
-                trunk16_kstep(acc, wcur + h * 64 + j, pcur + h * P16_PIX + (wave * 2) * P16_W + j, between);
+                trunk16_kstep<2>(acc, wcur + h * 64 + j, pcur + h * P16_PIX + (wave * 2) * P16_W + j, between);
             }
             __syncthreads();                                                 // every wave is done with the last k-step's buffers (and the bias row is read below)
             if (last) {
@@ -813,6 +832,9 @@ void isrSetTrunkErrorWord(unsigned* word) { g_trunk_error_word = word; }
 // ISR_TRUNK_MT: 1 (default) images of more tiles than CUs take trunk_mt_kernel; 0 they are refused (per-layer kernels); 2 every image
 // takes it (A/B against the one-tile form)
 static int g_trunk_mt = getenv("ISR_TRUNK_MT") ? atoi(getenv("ISR_TRUNK_MT")) : 1;
+// ISR_TRUNK_ROWS: image rows per wave of the one-tile form -- 2 (eight waves per workgroup) or 4 (four waves, one per SIMD)
+static int g_trunk_rows = (getenv("ISR_TRUNK_ROWS") && atoi(getenv("ISR_TRUNK_ROWS")) == 4) ? 4 : 2;
+void isrSetTrunkRows(int rows) { g_trunk_rows = rows == 4 ? 4 : 2; }
 void isrDebugSetTrunkMultiTile(int mode) { g_trunk_mt = mode; }
 int isrDebugTrunkState(void)
 {
@@ -891,8 +913,10 @@ int isrTrunkDataflow(const float* x, int cin0, long long xPlane, float* y, long 
     // (trunk_pack_input_kernel zeroes the counters; the 16-byte zero unit in front of them is never written)
     static bool attr = false;
     if (!attr) {
-        (void)hipFuncSetAttribute((const void*)trunk_dataflow_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, T16_LDS_BYTES);
-        (void)hipFuncSetAttribute((const void*)trunk_dataflow_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, T16_LDS_BYTES);
+        (void)hipFuncSetAttribute((const void*)trunk_dataflow_kernel<false, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, T16_LDS_BYTES);
+        (void)hipFuncSetAttribute((const void*)trunk_dataflow_kernel<true, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, T16_LDS_BYTES);
+        (void)hipFuncSetAttribute((const void*)trunk_dataflow_kernel<false, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, T16_LDS_BYTES);
+        (void)hipFuncSetAttribute((const void*)trunk_dataflow_kernel<true, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, T16_LDS_BYTES);
         (void)hipFuncSetAttribute((const void*)trunk_mt_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, T16_LDS_BYTES);
         attr = true;
     }
@@ -911,11 +935,18 @@ int isrTrunkDataflow(const float* x, int cin0, long long xPlane, float* y, long 
         const dim3 mgrid((unsigned)(round8 < cus ? round8 : cus));
         if (e0 || e1) hipExtLaunchKernelGGL(trunk_mt_kernel, mgrid, block, T16_LDS_BYTES, s, e0, e1, 0, p);
         else hipLaunchKernelGGL(trunk_mt_kernel, mgrid, block, T16_LDS_BYTES, s, p);
+    } else if (g_trunk_rows == 4) {
+        const dim3 block4(256);
+        if (diag) {
+            if (e0 || e1) hipExtLaunchKernelGGL((trunk_dataflow_kernel<true, 4>), grid, block4, T16_LDS_BYTES, s, e0, e1, 0, p);
+            else hipLaunchKernelGGL((trunk_dataflow_kernel<true, 4>), grid, block4, T16_LDS_BYTES, s, p);
+        } else if (e0 || e1) hipExtLaunchKernelGGL((trunk_dataflow_kernel<false, 4>), grid, block4, T16_LDS_BYTES, s, e0, e1, 0, p);
+        else hipLaunchKernelGGL((trunk_dataflow_kernel<false, 4>), grid, block4, T16_LDS_BYTES, s, p);
     } else if (diag) {
-        if (e0 || e1) hipExtLaunchKernelGGL(trunk_dataflow_kernel<true>, grid, block, T16_LDS_BYTES, s, e0, e1, 0, p);
-        else hipLaunchKernelGGL(trunk_dataflow_kernel<true>, grid, block, T16_LDS_BYTES, s, p);
-    } else if (e0 || e1) hipExtLaunchKernelGGL(trunk_dataflow_kernel<false>, grid, block, T16_LDS_BYTES, s, e0, e1, 0, p);
-    else hipLaunchKernelGGL(trunk_dataflow_kernel<false>, grid, block, T16_LDS_BYTES, s, p);
+        if (e0 || e1) hipExtLaunchKernelGGL((trunk_dataflow_kernel<true, 2>), grid, block, T16_LDS_BYTES, s, e0, e1, 0, p);
+        else hipLaunchKernelGGL((trunk_dataflow_kernel<true, 2>), grid, block, T16_LDS_BYTES, s, p);
+    } else if (e0 || e1) hipExtLaunchKernelGGL((trunk_dataflow_kernel<false, 2>), grid, block, T16_LDS_BYTES, s, e0, e1, 0, p);
+    else hipLaunchKernelGGL((trunk_dataflow_kernel<false, 2>), grid, block, T16_LDS_BYTES, s, p);
     return hipGetLastError() == hipSuccess ? 0 : -2;
 }
 

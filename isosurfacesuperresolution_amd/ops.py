@@ -137,6 +137,7 @@ def _sr():
         lib.isrSetTrunkErrorWord.argtypes = [vp]; lib.isrSetTrunkErrorWord.restype = None
         lib.isrDebugSetTrunkFault.argtypes = [ci, ctypes.c_ulonglong]; lib.isrDebugSetTrunkFault.restype = None
         lib.isrDebugSetTrunkMultiTile.argtypes = [ci]; lib.isrDebugSetTrunkMultiTile.restype = None
+        lib.isrSetTrunkRows.argtypes = [ci]; lib.isrSetTrunkRows.restype = None
         lib.isrProfileEnable.argtypes = [ci]; lib.isrProfileEnable.restype = ci
         lib.isrDebugSetSplitAlgo.argtypes = [ci]
         if os.environ.get("ISR_SPLIT_ALGO"):          # experiments: force a kernel form of the plain split layers (see sr_conv_split.hip)

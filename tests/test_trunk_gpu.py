@@ -252,6 +252,28 @@ def test_multi_tile_form_forced_on_every_size_equals_the_one_tile_form(cin, nblo
             assert torch.equal(f, ref), (trial, (f - ref).abs().max().item())
 
 
+@pytest.mark.parametrize("cin,nblocks,h,w", [(101, 10, 270, 480), (5, 1, 33, 70), (16, 0, 16, 32), (40, 2, 50, 64)])
+def test_four_rows_per_wave_form_equals_the_default_form(cin, nblocks, h, w):
+    """isrSetTrunkRows(4) / ISR_TRUNK_ROWS=4: four waves per workgroup, each 4 rows x 64 channels (one wave per SIMD, product-major MFMA
+    order); per accumulator the same products in the same order, so the same bits.  Opt-in: measured slower."""
+    from isosurfacesuperresolution_amd import ops
+    g = torch.Generator().manual_seed(cin * 10 + nblocks)
+    convs = [(((torch.rand(64, cin if k == 0 else 64, 3, 3, generator=g) - 0.5) * 0.15).cuda(), ((torch.rand(64, generator=g) - 0.5) * 0.2).cuda())
+             for k in range(1 + 2 * nblocks)]
+    lib = ops._sr()
+    with torch.no_grad():
+        x = ((torch.rand(1, cin, h, w, generator=g) - 0.4)).cuda()
+        ref = ops.trunk_dataflow(x, convs).clone()
+        lib.isrSetTrunkRows(4)
+        try:
+            f = ops.trunk_dataflow(x, convs).clone()
+        finally:
+            lib.isrSetTrunkRows(2)
+        torch.cuda.synchronize()
+        ops.trunk_check()
+        assert torch.equal(f, ref), (f - ref).abs().max().item()
+
+
 def test_multi_tile_trunk_gives_up_loudly_when_a_tile_never_publishes():
     """The multi-tile form's waits have the same deadline and error word as the one-tile form's: a tile that never publishes
     (isrDebugSetTrunkFault, deadline 2 ms) ends the launch with the word set by the kernel -- no hang -- and the next launch is right."""
