@@ -116,6 +116,20 @@ __device__ __forceinline__ void trunk16_dma16(const void* base, unsigned voff, u
     else
         asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" :: "s"(ldsaddr), "v"(voff), "s"(base) : "m0");
 }
+// ... for the lanes of `mask` only, WITHOUT a branch (the 4-row form: a branch per request makes every tap a basic block of its own
+// and nothing covers the bookkeeping between them): EXEC is narrowed and put back inside the statement
+template <bool COHERENT = true>
+__device__ __forceinline__ void trunk16_dma16_masked(const void* base, unsigned voff, unsigned ldsaddr, unsigned long long mask)
+{
+    ldsaddr = __builtin_amdgcn_readfirstlane(ldsaddr);
+    unsigned long long saved;
+    if (COHERENT)
+        asm volatile("s_mov_b64 %0, exec\n\ts_mov_b64 exec, %4\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, %3 sc1\n\ts_mov_b64 exec, %0"
+                     : "=&s"(saved) : "s"(ldsaddr), "v"(voff), "s"(base), "s"(mask) : "m0");
+    else
+        asm volatile("s_mov_b64 %0, exec\n\ts_mov_b64 exec, %4\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, %3\n\ts_mov_b64 exec, %0"
+                     : "=&s"(saved) : "s"(ldsaddr), "v"(voff), "s"(base), "s"(mask) : "m0");
+}
 // ... and 64 floats (lane l's dword to ldsaddr + 4 l)
 __device__ __forceinline__ void trunk16_dma4(const void* base, unsigned voff, unsigned ldsaddr)
 {
@@ -149,8 +163,11 @@ __device__ __forceinline__ Trunk16Operands<ROWS> trunk16_operands(const u32x4* w
     return o;
 }
 
-template <int ROWS, typename Between>
-__device__ __forceinline__ void trunk16_kstep(f32x16 (&acc)[2][ROWS], const u32x4* wl, const u32x4* bl, Between between)
+struct Trunk16NoMid { __device__ __forceinline__ void operator()(int, int) const {} };
+
+// `mid(tap, q)` (4-row form only) runs after the tap's product groups q = 0 and 1: straight-line DMA requests placed UNDER the tap's MFMAs
+template <int ROWS, typename Between, typename Mid = Trunk16NoMid>
+__device__ __forceinline__ void trunk16_kstep(f32x16 (&acc)[2][ROWS], const u32x4* wl, const u32x4* bl, Between between, Mid mid = Mid())
 {
     // Software-pipelined over the taps: tap t + 1's eight operand fragments are requested BEFORE tap t's MFMAs are issued and are
     // consumed one basic block later (`between` branches, so every tap is a block of its own and the compiler's scheduler cannot
@@ -172,6 +189,7 @@ __device__ __forceinline__ void trunk16_kstep(f32x16 (&acc)[2][ROWS], const u32x
                 acc[0][r] = mfma16(cur.a0l, cur.bh[r], acc[0][r]);
                 acc[0][r] = mfma16(a0s, cur.bo[r], acc[0][r]);
                 acc[0][r] = mfma16(cur.a0h, cur.bh[r], acc[0][r]);
+                mid(tap, r);
                 acc[1][r] = mfma16(cur.a1l, cur.bh[r], acc[1][r]);
                 acc[1][r] = mfma16(a1s, cur.bo[r], acc[1][r]);
                 acc[1][r] = mfma16(cur.a1h, cur.bh[r], acc[1][r]);
@@ -181,8 +199,10 @@ __device__ __forceinline__ void trunk16_kstep(f32x16 (&acc)[2][ROWS], const u32x
             // issued eight MFMAs apart (product-major) -- per accumulator the same three products in the same order: same bits
 #pragma unroll
             for (int r = 0; r < ROWS; ++r) { acc[0][r] = mfma16(cur.a0l, cur.bh[r], acc[0][r]); acc[1][r] = mfma16(cur.a1l, cur.bh[r], acc[1][r]); }
+            mid(tap, 0);
 #pragma unroll
             for (int r = 0; r < ROWS; ++r) { acc[0][r] = mfma16(a0s, cur.bo[r], acc[0][r]); acc[1][r] = mfma16(a1s, cur.bo[r], acc[1][r]); }
+            mid(tap, 1);
 #pragma unroll
             for (int r = 0; r < ROWS; ++r) { acc[0][r] = mfma16(cur.a0h, cur.bh[r], acc[0][r]); acc[1][r] = mfma16(cur.a1h, cur.bh[r], acc[1][r]); }
         }
@@ -303,7 +323,7 @@ __device__ __forceinline__ void trunk16_epilogue(const Trunk16Params& p, f32x16 
 // DIAG: the instantiation with the diagnostics (ablation switches, phase stamps) compiled in; the product launch is the one without:
 // the 108 unrolled MFMAs of the "operands read once" path and its nine copies of the DMA bookkeeping made the kernel's code large
 // enough to slow the real path down (measured when a second such path was added: 636 -> 755 us).
-template <bool DIAG, int ROWS>
+template <bool DIAG, int ROWS, bool LINE = (ROWS == 4)>
 __global__ __launch_bounds__(64 * T16_H / ROWS) void trunk_dataflow_kernel(const Trunk16Params p)
 {
     constexpr int WAVES = T16_H / ROWS;                                      // 8 or 4
@@ -489,6 +509,26 @@ __global__ __launch_bounds__(64 * T16_H / ROWS) void trunk_dataflow_kernel(const
 #pragma unroll
                     for (int t = 0; t < 9; ++t) between(t);
                 }
+            } else if (LINE && !(dbg & 1)) {
+                // Four waves, one per SIMD: no other wave covers a tap's DMA bookkeeping, so it is straight-line code under the tap's MFMAs --
+                // the weight piece after the first product group, the patch run after the second, each switched off by an empty lane mask
+                // instead of a branch: the k-step is ONE basic block.  (The same code serves the 2-row form -- LINE = true there measured
+                // within 1 % of its branching form: two waves per SIMD cover each other's bookkeeping anyway.)
+                if (!more && !last) stage_bias(l + 1, biasNext);
+                const u32x4* const wsrc = (wany ? wimg : wq) + 1 + (size_t)wks * 256 + rpart * 128 + rsel * 64;
+                const size_t wtap = (size_t)(wany ? wksteps : ksteps) * 256;
+                const unsigned wdst = wnxt + wdstRole;
+                const unsigned takeBits = (l > 0 && ks == 0) ? (lanes.live & ~lanes.centre) : lanes.live;
+                const unsigned long long pmask = __builtin_amdgcn_ballot_w64(pany && prole), wmask = __builtin_amdgcn_ballot_w64(wany && wrole);   // all lanes or none
+                auto mid = [&](int tap, int q) {
+                    if (q == 0) trunk16_dma16_masked<false>(wsrc + tap * wtap, wlane, wdst + (unsigned)tap * 2048u, wmask);
+                    else {
+                        trunk16_dma16_masked(pplane, lanes.poff[tap], pnxt + pdstRole + (unsigned)tap * 1024u, __builtin_amdgcn_ballot_w64((takeBits >> tap) & 1u) & pmask);
+                        if (tap == 8)
+                            trunk16_dma16_masked(pplane, lanes.poff[9], pnxt + pdstRole + 9u * 1024u, __builtin_amdgcn_ballot_w64((takeBits >> 9) & 1u) & pmask);
+                    }
+                };
+                trunk16_kstep<ROWS>(acc, wcur + h * 64 + j, pcur + h * P16_PIX + (wave * ROWS) * P16_W + j, [](int) {}, mid);
             } else if (!(dbg & 1)) {
                 trunk16_kstep<ROWS>(acc, wcur + h * 64 + j, pcur + h * P16_PIX + (wave * ROWS) * P16_W + j, between);
             } else {
