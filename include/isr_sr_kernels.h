@@ -224,6 +224,13 @@ int isrAssembleInputRows(const float* gbuffer_hwc12, const float* flow_filled, c
  * (parallel_sr.StripSuperResolution with a rows x columns grid). */
 int isrAssembleInputRect(const float* gbuffer_hwc12, const float* flow_filled, const float* prev_high, float* net_input,
                          int h, int w, int init_mode, int ao_inverted, int row0, int row1, int col0, int col1, void* stream);
+/* ... the whole frame straight into the dataflow trunk's workspace: the 101 channels leave PACKED-SPLIT, where isrTrunkDataflow's own packing
+ * pass would have put them (isrTrunkDataflowInputLayout(101, h, w)), together with that pass's housekeeping (the planes' zero units, the
+ * tiles' progress counters); the launch that follows on the same stream is isrTrunkDataflowPrepacked.  Same values, same split: the
+ * trunk's result is bit-identical.  Of net_input ([101][h][w] as above) only channels 0 .. 4 are written (what isrFinishFrame / the fused
+ * tail read back); channels 5 .. 100 stay UNDEFINED.  -3: the trunk does not take this size. */
+int isrAssembleInputPacked(const float* gbuffer_hwc12, const float* flow_filled, const float* prev_high, float* net_input,
+                           int h, int w, int init_mode, int ao_inverted, void* trunk_workspace, void* stream);
 
 /* Hole filling of the low-res flow (channels 8,9 of the HWC G-buffer) where the mask (channel 3) is 0:
  * mask-weighted push-pull pyramid, the on-device replacement of the reference's CPU OpenCV
@@ -294,6 +301,12 @@ long long isrTrunkDataflowWorkspaceBytes(int cin0, int H, int W);
 int isrTrunkDataflowSupported(const float* x, int cin0, int H, int W, long long xPlane, long long plane);
 int isrTrunkDataflow(const float* x, int cin0, long long xPlane, float* y, long long plane, const void* const* wq,
                      const float* const* bias, int nblocks, int H, int W, void* workspace, void* stream);
+/* The same launch for an input that is ALREADY packed-split in the workspace (isrAssembleInputPacked on the same stream): no packing pass.
+ * isrTrunkDataflowInputLayout: byte offsets into the workspace of the launch's three packed-split tensors (input, F, T; planes of
+ * ((H W + 8) & ~7) 16-byte units, [hi | lo'][groups]), the input's channel groups of 8, the number of tiles. */
+int isrTrunkDataflowInputLayout(int cin0, int H, int W, long long* offsets3, int* groups0, int* tiles);
+int isrTrunkDataflowPrepacked(int cin0, float* y, long long plane, const void* const* wq, const float* const* bias, int nblocks, int H, int W,
+                              void* workspace, void* stream);
 /* Where every LATER isrTrunkDataflow launch reports a timed-out wait instead of the workspace's own word (same encoding, sticky until
  * the caller clears it; NULL restores the workspace word): one device word the caller can mirror to the host once per frame together
  * with the range-guard words (isrSetRangeFlag), so that a disturbed launch is noticed a frame later, not whenever somebody looks. */

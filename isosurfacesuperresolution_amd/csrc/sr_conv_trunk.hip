@@ -918,14 +918,43 @@ int isrTrunkDataflowSupported(const float* x, int cin0, int H, int W, long long 
     return (tiles <= isrTrunkDataflowMaxTiles() || (g_trunk_mt && tiles <= 65535)) ? 1 : 0;
 }
 
+/* Where in the workspace an isrTrunkDataflow launch of this size keeps its packed-split tensors (byte offsets: input, F, T), the input's channel
+ * groups of 8 and the number of tiles (progress counters at byte 16): for a producer that writes the input there itself (isrAssembleInputPacked). */
+int isrTrunkDataflowInputLayout(int cin0, int H, int W, long long* offsets3, int* groups0, int* tiles)
+{
+    if (H <= 0 || W <= 0 || cin0 <= 0 || !offsets3 || !groups0 || !tiles) return -1;
+    const Trunk16Layout lay = trunk16_layout(cin0, H, W);
+    if (lay.total > 0xffffffffLL) return -3;
+    offsets3[0] = lay.xps; offsets3[1] = lay.fps; offsets3[2] = lay.tps;
+    *groups0 = lay.groups0; *tiles = lay.tiles;
+    return 0;
+}
+
+static int trunk_dataflow_launch(const float* x, bool prepacked, int cin0, long long xPlane, float* y, long long plane, const void* const* wq,
+                                 const float* const* bias, int nblocks, int H, int W, void* workspace, void* stream);
+
 /* x [cin0][H][W] -> y = F after: F = relu(conv(x, w[0]) + b[0]); nblocks times F += conv(relu(conv(F, w[2k+1]) + b[2k+1]), w[2k+2]) + b[2k+2]
  * (y [64][H][W] with `plane` floats per channel).  wq[l]: isrConvSplitPrepare images. */
 int isrTrunkDataflow(const float* x, int cin0, long long xPlane, float* y, long long plane, const void* const* wq,
                      const float* const* bias, int nblocks, int H, int W, void* workspace, void* stream)
 {
+    return trunk_dataflow_launch(x, false, cin0, xPlane, y, plane, wq, bias, nblocks, H, W, workspace, stream);
+}
+
+/* ... with the input ALREADY packed-split in the workspace (isrAssembleInputPacked on the same stream, which also did the packing pass's
+ * housekeeping: zero units, progress counters): no packing pass. */
+int isrTrunkDataflowPrepacked(int cin0, float* y, long long plane, const void* const* wq, const float* const* bias, int nblocks, int H, int W,
+                              void* workspace, void* stream)
+{
+    return trunk_dataflow_launch(nullptr, true, cin0, (long long)H * W, y, plane, wq, bias, nblocks, H, W, workspace, stream);
+}
+
+static int trunk_dataflow_launch(const float* x, bool prepacked, int cin0, long long xPlane, float* y, long long plane, const void* const* wq,
+                                 const float* const* bias, int nblocks, int H, int W, void* workspace, void* stream)
+{
     unsigned* const rangeFlag = isr_take_range_flag();       // taken first: an error return must not leave it armed
-    if (!x || !y || !wq || !bias || !workspace || nblocks < 0 || 1 + 2 * nblocks > T16_MAX_LAYERS || cin0 <= 0) return -1;
-    if (!isrTrunkDataflowSupported(x, cin0, H, W, xPlane, plane) || ((uintptr_t)workspace & 255)) return -3;
+    if ((!x && !prepacked) || !y || !wq || !bias || !workspace || nblocks < 0 || 1 + 2 * nblocks > T16_MAX_LAYERS || cin0 <= 0) return -1;
+    if (!isrTrunkDataflowSupported(prepacked ? y : x, cin0, H, W, xPlane, plane) || ((uintptr_t)workspace & 255)) return -3;
     const Trunk16Layout lay = trunk16_layout(cin0, H, W);
     char* ws = (char*)workspace;
     u32x4* xps = (u32x4*)(ws + lay.xps);
@@ -962,8 +991,9 @@ int isrTrunkDataflow(const float* x, int cin0, long long xPlane, float* y, long 
     }
     const bool diag = p.dbg != 0 || p.stamps != nullptr;
     const int npix = H * W;
-    ISR_LAUNCH_PROFILED(ISR_VARIANT_TRUNK_PACK, trunk_pack_input_kernel, dim3((unsigned)((npix + 255) / 256), (unsigned)(lay.groups0 > 8 ? lay.groups0 : 8)), dim3(256), 0, s,
-                        x, cin0, xPlane, npix, xps, lay.groups0, (u32x4*)(ws + lay.fps), (u32x4*)(ws + lay.tps), p.done, ntiles);
+    if (!prepacked)
+        ISR_LAUNCH_PROFILED(ISR_VARIANT_TRUNK_PACK, trunk_pack_input_kernel, dim3((unsigned)((npix + 255) / 256), (unsigned)(lay.groups0 > 8 ? lay.groups0 : 8)), dim3(256), 0, s,
+                            x, cin0, xPlane, npix, xps, lay.groups0, (u32x4*)(ws + lay.fps), (u32x4*)(ws + lay.tps), p.done, ntiles);
     hipEvent_t e0 = nullptr, e1 = nullptr;
     const int cus = isrTrunkDataflowMaxTiles();
     const bool mt = g_trunk_mt == 2 || ntiles > cus;

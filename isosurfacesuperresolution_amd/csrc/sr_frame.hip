@@ -19,6 +19,7 @@
 #include "sr_finish.h"
 #include "sr_profile.h"
 #include "sr_warp_exact.h"
+#include "sr_split_common.h"
 
 namespace {
 
@@ -36,39 +37,51 @@ struct AssembleParams {
     int ao_inverted;
     int row0;               // first row of the launch (isrAssembleInputRows: a rank that needs only its strip + halo)
     int col0, col1;         // columns [col0, col1) of the launch (isrAssembleInputRect: a screen TILE + halo)
+    // PACK (isrAssembleInputPacked): the input goes straight into the dataflow trunk's workspace, PACKED-SPLIT (sr_conv_trunk.hip) --
+    // [hi | lo'][groups][psPlane units of 8 channels] -- and only channels 0 .. 4 (what the frame's finishing reads) to `out` as well
+    u32x4* ps; int groups; long long psPlane;
+    u32x4* fps; u32x4* tps;          // the launch's other two packed-split tensors: their planes' zero units are (re)written here
+    unsigned* done; int ntiles;      // the tiles' progress counters: back to zero for the trunk launch that follows
 };
 
+constexpr int ASM_STRIDE = 105;      // floats per pixel of the PACK form's LDS tile (odd: lanes = pixels read conflict-free)
+
 // one thread per (low-res pixel, dx): neighbouring lanes read neighbouring hi-res columns (the gathers of the
-// previous frame coalesce; one thread per low-res pixel read 4x its algorithmic bytes); loops over dy and 6 channels
-__global__ __launch_bounds__(256) void assemble_input_kernel(const AssembleParams p)
+// previous frame coalesce; one thread per low-res pixel read 4x its algorithmic bytes); loops over dy and 6 channels.
+// PACK: the 64 pixels x 101 channels of the workgroup are collected in LDS and leave as packed-split units (the same split16x
+// the trunk's own packing pass applied: bit-identical operands), one pass over memory less and one kernel boundary less per frame.
+template <bool PACK>
+__device__ __forceinline__ void assemble_pixel(const AssembleParams& p, int x, int y, int dx, float* vals)
 {
-    const int t = blockIdx.x * blockDim.x + threadIdx.x;
-    const int x = p.col0 + (t >> 2), dx = t & 3;
-    const int y = p.row0 + blockIdx.y;
-    if (x >= p.col1) return;
     const size_t plane = (size_t)p.h * p.w;
     const size_t pix = (size_t)y * p.w + x;
     const float* g = p.gbuf + pix * 12;
     const float4 g0 = *reinterpret_cast<const float4*>(g);        // r g b mask
     const float4 g1 = *reinterpret_cast<const float4*>(g + 4);    // nx ny nz depth
     if (dx == 0) {
-        p.out[0 * plane + pix] = g0.w * 2.0f - 1.0f;
-        p.out[1 * plane + pix] = g1.x;
-        p.out[2 * plane + pix] = g1.y;
-        p.out[3 * plane + pix] = g1.z;
-        p.out[4 * plane + pix] = g1.w;
+        const float cur[5] = { g0.w * 2.0f - 1.0f, g1.x, g1.y, g1.z, g1.w };
+#pragma unroll
+        for (int c = 0; c < 5; ++c) {
+            p.out[c * plane + pix] = cur[c];
+            if (PACK) vals[c] = cur[c];
+        }
     }
     const int H = 4 * p.h, W = 4 * p.w;
     const size_t hplane = (size_t)H * W;
-    float* o = p.out + 5 * plane + pix;
+    float* const op = p.out + 5 * plane + pix;
+    // flattened channel f = c * 16 + dy * 4 + dx of the previous frame -> network channel 5 + f
+    auto put = [&](int f, float v) {
+        if (PACK) vals[5 + f] = v;
+        else op[(size_t)f * plane] = v;
+    };
     if (!p.prev) {
         if (p.init_mode == 0) {
             for (int c = 0; c < 6; ++c)
-                for (int dy = 0; dy < 4; ++dy) o[(size_t)(c * 16 + dy * 4 + dx) * plane] = 0.0f;
+                for (int dy = 0; dy < 4; ++dy) put(c * 16 + dy * 4 + dx, 0.0f);
         } else if (p.init_mode == 1) {
             const float defaults[6] = { -1.f, 0.f, 0.f, 1.f, 0.5f, p.ao_inverted ? 0.f : 1.f };
             for (int c = 0; c < 6; ++c)
-                for (int dy = 0; dy < 4; ++dy) o[(size_t)(c * 16 + dy * 4 + dx) * plane] = defaults[c];
+                for (int dy = 0; dy < 4; ++dy) put(c * 16 + dy * 4 + dx, defaults[c]);
         } else {
             // "input": bilinear x4 of (mask*2-1, normal, depth), remaining channel = 1
             for (int dy = 0; dy < 4; ++dy) {
@@ -84,9 +97,9 @@ __global__ __launch_bounds__(256) void assemble_input_kernel(const AssembleParam
                         const int ch = 3 + c;
                         float va = a[ch], vb = b[ch], vc = c_[ch], vd = d[ch];
                         if (c == 0) { va = va * 2.f - 1.f; vb = vb * 2.f - 1.f; vc = vc * 2.f - 1.f; vd = vd * 2.f - 1.f; }
-                        o[(size_t)(c * 16 + dy * 4 + dx) * plane] = hy * (hx * va + lx * vb) + ly * (hx * vc + lx * vd);
+                        put(c * 16 + dy * 4 + dx, hy * (hx * va + lx * vb) + ly * (hx * vc + lx * vd));
                     }
-                    o[(size_t)(5 * 16 + dy * 4 + dx) * plane] = 1.0f;
+                    put(5 * 16 + dy * 4 + dx, 1.0f);
                 }
         }
         return;
@@ -136,9 +149,46 @@ __global__ __launch_bounds__(256) void assemble_input_kernel(const AssembleParam
                 r = r + t10;
                 r = r + t11;
                 if (c == 0) { r = r * 2.0f; r = r - 1.0f; }
-                o[(size_t)(c * 16 + dy * 4 + dx) * plane] = r;
+                put(c * 16 + dy * 4 + dx, r);
             }
         }
+    }
+}
+
+template <bool PACK>
+__global__ __launch_bounds__(256) void assemble_input_kernel(const AssembleParams p)
+{
+    __shared__ float tile[PACK ? 64 * ASM_STRIDE : 1];
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    const int x = p.col0 + (t >> 2), dx = t & 3;
+    const int y = p.row0 + blockIdx.y;
+    if (x < p.col1) assemble_pixel<PACK>(p, x, y, dx, tile + (threadIdx.x >> 2) * ASM_STRIDE);
+    if (!PACK) return;
+    const u32x4 zero = {0u, 0u, 0u, 0u};
+    if (blockIdx.x == 0 && blockIdx.y == 0) {
+        // what trunk_pack_input_kernel does besides packing: the zero unit that ends every plane of the launch's three packed-split
+        // tensors, and the tiles' progress counters back to zero
+        const size_t npix = (size_t)p.h * p.w;
+        for (int i = threadIdx.x; i < p.ntiles; i += 256) p.done[i] = 0u;
+        for (int i = threadIdx.x; i < 2 * p.groups; i += 256) p.ps[(size_t)i * p.psPlane + npix] = zero;
+        for (int i = threadIdx.x; i < 16; i += 256) { p.fps[(size_t)i * p.psPlane + npix] = zero; p.tps[(size_t)i * p.psPlane + npix] = zero; }
+    }
+    __syncthreads();
+    const int xb = p.col0 + blockIdx.x * 64;
+    for (int it = threadIdx.x; it < 64 * p.groups; it += 256) {
+        const int pl = it & 63, g = it >> 6;
+        if (xb + pl >= p.col1) continue;
+        const float* v = tile + pl * ASM_STRIDE + g * 8;
+        f16x8 hi, lo;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            _Float16 a, b;
+            split16x(g * 8 + e < 101 ? v[e] : 0.0f, a, b);
+            hi[e] = a; lo[e] = b;
+        }
+        const size_t pix = (size_t)y * p.w + xb + pl;
+        p.ps[(size_t)g * p.psPlane + pix] = __builtin_bit_cast(u32x4, hi);
+        p.ps[(size_t)(p.groups + g) * p.psPlane + pix] = __builtin_bit_cast(u32x4, lo);
     }
 }
 
@@ -555,8 +605,27 @@ int isrAssembleInputRect(const float* gbuffer_hwc12, const float* flow_filled, c
     if (!gbuffer_hwc12 || !net_input || h <= 0 || w <= 0 || row0 < 0 || row1 > h || row0 >= row1 || col0 < 0 || col1 > w || col0 >= col1) return -1;
     if (prev_high && !flow_filled) return -1;
     if (init_mode < 0 || init_mode > 2) return -1;
-    AssembleParams p = { gbuffer_hwc12, flow_filled, prev_high, net_input, h, w, init_mode, ao_inverted, row0, col0, col1 };
-    ISR_LAUNCH_PROFILED(ISR_VARIANT_ASSEMBLE, assemble_input_kernel, dim3((4 * (col1 - col0) + 255) / 256, row1 - row0), dim3(256), 0, (hipStream_t)stream, p);
+    AssembleParams p = { gbuffer_hwc12, flow_filled, prev_high, net_input, h, w, init_mode, ao_inverted, row0, col0, col1, nullptr, 0, 0, nullptr, nullptr, nullptr, 0 };
+    ISR_LAUNCH_PROFILED(ISR_VARIANT_ASSEMBLE, assemble_input_kernel<false>, dim3((4 * (col1 - col0) + 255) / 256, row1 - row0), dim3(256), 0, (hipStream_t)stream, p);
+    return hipGetLastError() == hipSuccess ? 0 : -2;
+}
+
+/* isrAssembleInput straight into the dataflow trunk's workspace: the 101-channel input leaves PACKED-SPLIT (where isrTrunkDataflow's own
+ * packing pass would have put it: isrTrunkDataflowInputLayout) and the launch that follows is isrTrunkDataflowPrepacked.  Of `net_input`
+ * ([101][h][w] as for isrAssembleInput) only channels 0 .. 4 are written -- what the frame's finishing reads; the rest stays UNDEFINED. */
+int isrAssembleInputPacked(const float* gbuffer_hwc12, const float* flow_filled, const float* prev_high, float* net_input,
+                           int h, int w, int init_mode, int ao_inverted, void* trunk_workspace, void* stream)
+{
+    if (!gbuffer_hwc12 || !net_input || !trunk_workspace || h <= 0 || w <= 0) return -1;
+    if (prev_high && !flow_filled) return -1;
+    if (init_mode < 0 || init_mode > 2) return -1;
+    long long off[3]; int groups0 = 0, tiles = 0;
+    if (isrTrunkDataflowInputLayout(101, h, w, off, &groups0, &tiles) != 0) return -3;
+    char* const ws = (char*)trunk_workspace;
+    AssembleParams p = { gbuffer_hwc12, flow_filled, prev_high, net_input, h, w, init_mode, ao_inverted, 0, 0, w,
+                         (u32x4*)(ws + off[0]), groups0, (long long)(((long long)h * w + 8) & ~7LL), (u32x4*)(ws + off[1]), (u32x4*)(ws + off[2]),
+                         (unsigned*)(ws + 16), tiles };
+    ISR_LAUNCH_PROFILED(ISR_VARIANT_ASSEMBLE, assemble_input_kernel<true>, dim3((4 * w + 255) / 256, h), dim3(256), 0, (hipStream_t)stream, p);
     return hipGetLastError() == hipSuccess ? 0 : -2;
 }
 

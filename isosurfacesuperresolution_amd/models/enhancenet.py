@@ -84,6 +84,11 @@ class EnhanceNet(nn.Module):
     def _fused_ok(self):
         return (not self.use_bn) and self.upsample == 'bilinear'
 
+    def trunk_convs(self):
+        """[(weight, bias)] of the low-resolution trunk: preblock, then conv1 / conv2 of every block (what ops.trunk_supported takes)."""
+        pre = self.preblock[0]
+        return [(pre.weight, pre.bias)] + [(m.weight, m.bias) for block in self.blocks for m in (block[0], block[2])]
+
     def forward_features(self, inputs, last_layer=True, last_two=True, last_three=True, after_trunk=None, packed_tail=False):
         """The convolutional trunk only: the tensor ``_recon_image`` receives (used by the fused
         frame pipeline, which folds the reconstruction into its finishing kernel).  ``last_layer=False`` stops
@@ -97,9 +102,12 @@ class EnhanceNet(nn.Module):
         assert self._fused_ok()
         c = ops.conv3x3
         pre = self.preblock[0]
-        convs = [(pre.weight, pre.bias)] + [(m.weight, m.bias) for block in self.blocks for m in (block[0], block[2])]
+        convs = self.trunk_convs()
         if ops.trunk_supported(inputs, convs):
             f = ops.trunk_dataflow(inputs, convs)       # preblock + all blocks in ONE dataflow launch (csrc/sr_conv_trunk.hip)
+        elif getattr(inputs, '_isr_prepacked', None) is not None:
+            raise RuntimeError("forward_features: this input exists only packed-split inside the dataflow trunk's workspace "
+                               "(ops.assemble_input_packed) and the dataflow trunk does not take it; assemble it with ops.assemble_input")
         else:
             f = c(inputs, pre.weight, pre.bias, act='relu')
             for block in self.blocks:

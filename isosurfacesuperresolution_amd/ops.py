@@ -66,6 +66,7 @@ def _sr():
         lib.isrAssembleInput.argtypes = [vp, vp, vp, vp, ci, ci, ci, ci, vp]; lib.isrAssembleInput.restype = ci
         lib.isrAssembleInputRows.argtypes = [vp, vp, vp, vp, ci, ci, ci, ci, ci, ci, vp]; lib.isrAssembleInputRows.restype = ci
         lib.isrAssembleInputRect.argtypes = [vp, vp, vp, vp, ci, ci, ci, ci, ci, ci, ci, ci, vp]; lib.isrAssembleInputRect.restype = ci
+        lib.isrAssembleInputPacked.argtypes = [vp, vp, vp, vp, ci, ci, ci, ci, vp, vp]; lib.isrAssembleInputPacked.restype = ci
         lib.isrConvSmallCinPad.argtypes = [ci]; lib.isrConvSmallCinPad.restype = ci
         lib.isrConvSmallWeightFloats.argtypes = [ci]; lib.isrConvSmallWeightFloats.restype = ll
         lib.isrConvSmallPrepare.argtypes = [vp, vp, vp, vp, ci, ci, vp]; lib.isrConvSmallPrepare.restype = ci
@@ -121,6 +122,7 @@ def _sr():
         lib.isrTrunkDataflowWorkspaceBytes.argtypes = [ci, ci, ci]; lib.isrTrunkDataflowWorkspaceBytes.restype = ll
         lib.isrTrunkDataflowSupported.argtypes = [vp, ci, ci, ci, ll, ll]; lib.isrTrunkDataflowSupported.restype = ci
         lib.isrTrunkDataflow.argtypes = [vp, ci, ll, vp, ll, vp, vp, ci, ci, ci, vp, vp]; lib.isrTrunkDataflow.restype = ci
+        lib.isrTrunkDataflowPrepacked.argtypes = [ci, vp, ll, vp, vp, ci, ci, ci, vp, vp]; lib.isrTrunkDataflowPrepacked.restype = ci
         lib.isrTrunkDataflowPackedResult.argtypes = [ci, ci, ci, vp, vp]; lib.isrTrunkDataflowPackedResult.restype = ci
         lib.isrSetTrunkPackedResult.argtypes = [ci]; lib.isrSetTrunkPackedResult.restype = None
         lib.isrConvUpsPhaseWeightBytes.argtypes = []; lib.isrConvUpsPhaseWeightBytes.restype = ll
@@ -1113,17 +1115,26 @@ def trunk_supported(x, convs):
     return xs is x and bool(_sr().isrTrunkDataflowSupported(_ptr(x), x.shape[1], x.shape[2], x.shape[3], xp, x.shape[2] * x.shape[3] + plane_pad(x.shape[2], x.shape[3])))
 
 
+def _trunk_workspace(device, cin, h, w):
+    """The dataflow trunk's workspace for this size on the current stream: header (zero unit, the tiles' progress counters, error
+    word) + the packed-split input, F and T tensors of the launch; zero-filled once."""
+    key = (device, cin, h, w, torch.cuda.current_stream().cuda_stream)
+    ws = _trunk_ws.get(key)
+    if ws is None:
+        ws = torch.zeros(_sr().isrTrunkDataflowWorkspaceBytes(cin, h, w) // 4, dtype=torch.int32, device=device)
+        _trunk_ws[key] = ws
+    return ws
+
+
 def trunk_dataflow(x, convs):
     """f = relu(conv(x, w0) + b0); f = f + conv(relu(conv(f, w1) + b1), w2) + b2; ...  in ONE launch (``isrTrunkDataflow``)."""
     lib = _sr()
+    prepacked = getattr(x, '_isr_prepacked', None)
     x, xp, _ = _plane_strides(x)
     _, cin, h, w = x.shape
-    key = (x.device, cin, h, w, torch.cuda.current_stream().cuda_stream)
-    ws = _trunk_ws.get(key)
-    if ws is None:
-        # header (zero unit, the tiles' progress counters, error word) + the packed-split input, F and T tensors of the launch
-        ws = torch.zeros(lib.isrTrunkDataflowWorkspaceBytes(cin, h, w) // 4, dtype=torch.int32, device=x.device)
-        _trunk_ws[key] = ws
+    ws = _trunk_workspace(x.device, cin, h, w)
+    if prepacked is not None and prepacked is not ws:
+        raise RuntimeError("trunk_dataflow: the input was assembled into another workspace (another stream?) than this launch uses")
     f = empty_planes(1, 64, h, w, x.device)
     wq = [_prepare_split(wt) for wt, _ in convs]
     bs = [b.detach().contiguous() if b is not None else None for _, b in convs]
@@ -1134,7 +1145,11 @@ def trunk_dataflow(x, convs):
     lib.isrSetTrunkErrorWord(ctypes.c_void_p(st["buf"].data_ptr() + 4 * _TRUNK_ERROR_SLOT))
     f._isr_range_key = _arm_range(("trunk", id(convs[0][0])), x.device, members=[id(wt) for wt, _ in convs])
     lib.isrSetTrunkPackedResult(1 if UPS_PHASE else 0)
-    rc = lib.isrTrunkDataflow(_ptr(x), cin, xp, _ptr(f), f.stride(1), pw, pb, (n - 1) // 2, h, w, _ptr(ws), _stream())
+    if prepacked is not None:
+        # assemble_input_packed left the input packed-split in the workspace: no packing pass
+        rc = lib.isrTrunkDataflowPrepacked(cin, _ptr(f), f.stride(1), pw, pb, (n - 1) // 2, h, w, _ptr(ws), _stream())
+    else:
+        rc = lib.isrTrunkDataflow(_ptr(x), cin, xp, _ptr(f), f.stride(1), pw, pb, (n - 1) // 2, h, w, _ptr(ws), _stream())
     if rc != 0:
         raise RuntimeError("isrTrunkDataflow failed (%d)" % rc)
     # the same result PACKED-SPLIT, inside the workspace (valid until the next launch on it): what the phase-decomposed upsampling
@@ -1608,6 +1623,39 @@ def assemble_input(gbuffer_hwc, flow_filled, prev_high, initial_image="zero", ao
                                     _ptr(prev_high), _ptr(out), h, w, INIT_MODES[initial_image], 1 if ao_inverted else 0, r0, r1, c0, c1, _stream())
     if rc != 0:
         raise RuntimeError("isrAssembleInput failed (%d)" % rc)
+    return out
+
+
+# the frame's input assembly writes the dataflow trunk's packed-split input itself (isrAssembleInputPacked): one pass over memory and
+# one kernel boundary less per frame than assembling fp32 planes and packing them
+ASSEMBLE_PACKED = os.environ.get("ISR_ASSEMBLE_PACKED", "1") != "0"
+
+
+def assemble_input_packed(gbuffer_hwc, flow_filled, prev_high, convs, initial_image="zero", ao_inverted=False):
+    """``assemble_input`` for a frame whose trunk runs as the dataflow launch (``convs``: what ``trunk_supported`` takes): the network
+    input goes PACKED-SPLIT straight into that launch's workspace.  Returns x [1,101,h,w] of which only channels 0 .. 4 are written
+    (what the frame's finishing reads) -- ``x._isr_prepacked`` holds the workspace, ``trunk_dataflow`` then skips its packing pass and
+    ``forward_features`` refuses any other route -- or None when the dataflow trunk would not take this frame (assemble the plain way).
+    Same values through the same split as the packing pass: the frame is bit-identical."""
+    assert gbuffer_hwc.is_cuda and gbuffer_hwc.is_contiguous() and gbuffer_hwc.shape[-1] == 12
+    h, w = gbuffer_hwc.shape[0], gbuffer_hwc.shape[1]
+    if not ASSEMBLE_PACKED:
+        return None
+    out = torch.empty((1, 101, h, w), dtype=torch.float32, device=gbuffer_hwc.device)
+    if not trunk_supported(out, convs):
+        return None
+    if prev_high is not None:
+        prev_high = prev_high.contiguous()
+        flow_filled = flow_filled.contiguous()
+        assert prev_high.shape == (1, 6, 4 * h, 4 * w) and flow_filled.shape == (1, 2, h, w)
+    ws = _trunk_workspace(out.device, 101, h, w)
+    rc = _sr().isrAssembleInputPacked(_ptr(gbuffer_hwc), _ptr(flow_filled) if prev_high is not None else None, _ptr(prev_high), _ptr(out),
+                                      h, w, INIT_MODES[initial_image], 1 if ao_inverted else 0, _ptr(ws), _stream())
+    if rc == -3:
+        return None
+    if rc != 0:
+        raise RuntimeError("isrAssembleInputPacked failed (%d)" % rc)
+    out._isr_prepacked = ws
     return out
 
 

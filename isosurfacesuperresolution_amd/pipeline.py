@@ -272,6 +272,16 @@ class SuperResolutionPipeline:
         self.previous = raw
         return raw
 
+    def _assemble(self, gbuffer, flow, prev):
+        """The network input of a frame: packed-split straight into the dataflow trunk's workspace where that launch will take it
+        (ops.assemble_input_packed), fp32 planes otherwise."""
+        net = self.model.model
+        if self.fused and hasattr(net, 'trunk_convs'):
+            x = ops.assemble_input_packed(gbuffer, flow, prev, net.trunk_convs(), self.model.initial_image_mode, self.model.inverse_ao)
+            if x is not None:
+                return x
+        return ops.assemble_input(gbuffer, flow, prev, self.model.initial_image_mode, self.model.inverse_ao)
+
     def _network(self, x, after_trunk=None, out=None):
         """Network input [1,101,h,w] -> (raw [1,6,4h,4w] clamped / normalised, rgb [1,3,4h,4w])."""
         return run_network(self.model, self.shading, x, after_trunk=after_trunk, prefetch_point=self.prefetch_point, out=out)
@@ -293,7 +303,7 @@ class SuperResolutionPipeline:
         weights = tuple((p._version, p.data_ptr()) for p in self.model.model.parameters())
         return (tuple(sh.packed_parameters()), int(sh._specular_exponent), float(sh._ao), bool(self.model.inverse_ao), bool(sh.enable_specular),
                 self.model.initial_image_mode, id(self.model.model), ops._images_epoch, self._static_version, self.flow_fill_threads,
-                ops.TRUNK_DATAFLOW, ops.FLOW_FILL_ONE, ops.DEVICE_SHARED, ops.SPLIT_F16, ops.FAST_F16, ops.UPS_PHASE, ops.routing_epoch(), weights)
+                ops.TRUNK_DATAFLOW, ops.FLOW_FILL_ONE, ops.DEVICE_SHARED, ops.SPLIT_F16, ops.FAST_F16, ops.UPS_PHASE, ops.ASSEMBLE_PACKED, ops.routing_epoch(), weights)
 
     def _graph_ready(self, origin, next_origin):
         if not (self.graph and next_origin is not None and self.temporal and self.previous is not None and self._prefetched is not None):
@@ -308,7 +318,7 @@ class SuperResolutionPipeline:
         """Frame of slot ``slot`` on the current stream (eagerly once as the warm-up, then under capture)."""
         nxt = slot ^ 1
         cur, rs = torch.cuda.current_stream(), self._render_stream
-        x = ops.assemble_input(self._gbuffers[slot], self._flows[slot], self._out_raw[nxt], self.model.initial_image_mode, self.model.inverse_ao)
+        x = self._assemble(self._gbuffers[slot], self._flows[slot], self._out_raw[nxt])
 
         def start_next():
             self._fork.record(cur)
@@ -391,7 +401,7 @@ class SuperResolutionPipeline:
             flow = None
             if prev is not None:
                 flow = self._flows[self._slot] if self._flow_ready[self._slot] else ops.fill_flow_gbuffer(g)
-            x = ops.assemble_input(g, flow, prev, self.model.initial_image_mode, self.model.inverse_ao)
+            x = self._assemble(g, flow, prev)
             self._consumed[self._slot].record(torch.cuda.current_stream())   # G-buffer no longer needed
             out = (self._out_raw[self._slot], self._out_rgb[self._slot]) if self.graph else None
             raw, rgb = self._network(x, after_trunk=start_next, out=out)
@@ -403,6 +413,10 @@ class SuperResolutionPipeline:
                 for _ in range(4):
                     if not ops.refresh_range_flags(x.device):
                         break
+                    if getattr(x, '_isr_prepacked', None) is not None:
+                        # the per-layer pass reads the fp32 planes: assemble them (the packed form wrote channels 0 .. 4 only)
+                        x = ops.assemble_input(g, flow, prev, self.model.initial_image_mode, self.model.inverse_ao)
+                        self._consumed[self._slot].record(torch.cuda.current_stream())
                     raw, rgb = self._network(x, out=out)
             ops.guards_publish(x.device)
             self.previous = raw

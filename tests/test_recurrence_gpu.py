@@ -9,6 +9,11 @@ paths (split-operand = default, exact fp32):
   kernels from the network's gain.  It holds because the temporal input path (flow fill, flow resize, pixel grid, warp) is
   computed bit for bit like the module path (models/videotools.py): the reference's normalised-grid warp has an fp32
   conditioning of ~1e-4 at silhouette edges, so two fp32 paths that round it differently start a frame 1e-4 apart.
+  The network input of the step is then IDENTICAL on both paths and what is left is the convolutions' own fp32 rounding through
+  this random-init network -- which on some frames (frame 2 here) puts the CPU fp32 path itself 2e-4 from an fp64 evaluation of
+  the same step, and how far depends on the host CPU's convolution kernels (one box: 0.9e-4 / 1.2e-4 between the paths, others
+  less).  So the bound per frame is max(1e-4, 3 d + 2e-6) with d = |CPU32 - fp64 step from the same previous frame|: 1e-4 wherever
+  the CPU path is itself an accurate reference, the triangle inequality over the next statement where it is not.
 * single step from the fp64 pass's frame k - 1: against fp64 no fp32 path can be better than that conditioning; the HIP paths
   are as close to the fp64 frame k as the CPU fp32 path started from the same fp64 frame is (factor two + 2e-6).
 * free-running (each path feeds its own output back): |HIP - CPU64| <= 2 |CPU32 - CPU64| + 2e-6 -- the growth from frame to
@@ -81,6 +86,7 @@ def test_recurrent_frames_single_step_and_free_running_against_the_cpu_paths():
     cpu64 = cpu_pass(torch.float64)
     cpu32 = cpu_pass(torch.float32)
     cpu32_from64 = cpu_pass(torch.float32, previous_of=cpu64)
+    cpu64_from32 = cpu_pass(torch.float64, previous_of=cpu32)      # the fp64 evaluation of the very steps the CPU fp32 path took
     split_from32, _ = gpu_pass(previous_of=cpu32)
     split_from64, _ = gpu_pass(previous_of=cpu64)
     ops.SPLIT_F16 = False
@@ -98,17 +104,20 @@ def test_recurrent_frames_single_step_and_free_running_against_the_cpu_paths():
     e32, es, ee = err(cpu32, cpu64), err(split_free, cpu64), err(exact_free, cpu64)
     s32, x32 = err(split_from32, cpu32), err(exact_from32, cpu32)
     c64, s64, x64 = err(cpu32_from64, cpu64), err(split_from64, cpu64), err(exact_from64, cpu64)
+    d32 = err(cpu32, cpu64_from32)
     report = "\n".join(
-        "frame %d: single step vs CPU32: split %.2e exact %.2e | single step from fp64, vs fp64: CPU32 %.2e split %.2e exact %.2e | "
-        "free-running vs fp64: CPU32 %.2e split %.2e exact %.2e" % (k, s32[k], x32[k], c64[k], s64[k], x64[k], e32[k], es[k], ee[k])
+        "frame %d: single step vs CPU32: split %.2e exact %.2e (CPU32's own step vs fp64: %.2e) | single step from fp64, vs fp64: CPU32 %.2e "
+        "split %.2e exact %.2e | free-running vs fp64: CPU32 %.2e split %.2e exact %.2e" % (k, s32[k], x32[k], d32[k], c64[k], s64[k], x64[k], e32[k], es[k], ee[k])
         for k in range(FRAMES))
     print(report)
     for k in range(FRAMES):
         # the parity claim, frame by frame
-        assert s32[k] <= 1e-4, "split-operand path, single step vs the CPU fp32 path, frame %d: %g\n%s" % (k, s32[k], report)
-        assert x32[k] <= 1e-4, "exact fp32 path, single step vs the CPU fp32 path, frame %d: %g\n%s" % (k, x32[k], report)
+        bound = max(1e-4, 3.0 * d32[k] + 2e-6)
+        assert s32[k] <= bound, "split-operand path, single step vs the CPU fp32 path, frame %d: %g\n%s" % (k, s32[k], report)
+        assert x32[k] <= bound, "exact fp32 path, single step vs the CPU fp32 path, frame %d: %g\n%s" % (k, x32[k], report)
         # against fp64: as close as the CPU's own fp32 arithmetic (factor two + a floor for frames where that is ~0)
         assert s64[k] <= 2.0 * c64[k] + 2e-6 and x64[k] <= 2.0 * c64[k] + 2e-6, "single step from fp64, frame %d\n%s" % (k, report)
         assert es[k] <= 2.0 * e32[k] + 2e-6, "split-operand path, free-running, frame %d\n%s" % (k, report)
         assert ee[k] <= 2.0 * e32[k] + 2e-6, "exact fp32 path, free-running, frame %d\n%s" % (k, report)
     assert e32[-1] > e32[0]                                      # the sequence does amplify (otherwise this test says nothing about the recurrence)
+    assert sum(1 for k in range(FRAMES) if max(s32[k], x32[k]) <= 1e-4) >= FRAMES - 2, report      # the plain 1e-4 statement on (nearly) every frame
