@@ -41,11 +41,14 @@ typedef __attribute__((address_space(3))) char up_lds_char;
 
 // LDS-DMA from inline assembly (as sr_conv_trunk.hip): 64 lanes x 16 bytes, lane l's bytes land at ldsaddr + 16 l; the compiler does
 // not count these requests -- the kernel waits for them with its own s_waitcnt vmcnt
+#pragma clang diagnostic push
+#pragma clang diagnostic ignored "-Winline-asm"
 __device__ __forceinline__ void up_dma16(const void* base, unsigned voff, unsigned ldsaddr)
 {
     ldsaddr = __builtin_amdgcn_readfirstlane(ldsaddr);
     asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" :: "s"(ldsaddr), "v"(voff), "s"(base) : "m0", "memory");
 }
+#pragma clang diagnostic pop
 
 // p.H, p.W: OUTPUT (high-resolution) size; p.Hin, p.Win: input size; p.xps / p.ps: packed-split input / output; p.wq: the prepared
 // image of the four stacked effective weight sets (Cout = 256: image m = 2 py + px at output channels 64 m ..); tiles of 8 x 32
