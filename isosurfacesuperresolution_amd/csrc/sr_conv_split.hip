@@ -1116,6 +1116,7 @@ __global__ __launch_bounds__(256) void prepare_weights_split_many_kernel(const P
 
 #include "sr_conv_ups3.h"       // the three-workgroups-per-CU upsampling kernel: same translation unit, same parameter block
 #include "sr_conv_ups4.h"       // the role-split upsampling kernel (producer / consumer waves)
+#include "sr_conv_ups5.h"       // the software-pipelined upsampling kernel (staging of k-step g + 1 between the MFMAs of k-step g)
 #include "sr_conv_upsp.h"       // the phase-decomposed upsampling kernel (no interpolation at run time; packed-split in and out)
 #include "sr_conv_block2.h"     // two chained convolutions of a batch of small images in one launch (training trunk)
 
@@ -1294,6 +1295,11 @@ int isrConv3x3ForwardSplit(const float* x, const void* wq, const float* bias, co
     if (upsample2x && g_split_ups_form == 4 && isr_split_ups4_takes(p)) {
         isr_profile_record(ISR_VARIANT_SPLIT_UPS4, 2.0 * 9 * Cin * Cout * (double)N * H * W, &e0, &e1);
         return isr_launch_split_ups4(p, s, e0, e1);
+    }
+    if (upsample2x && g_split_ups_form == 5 && isr_split_ups5_takes(p)) {
+        // (recorded under the three-per-CU kernel's variant: the same layer, the same column of bench.py's kernel table)
+        isr_profile_record(ISR_VARIANT_SPLIT_UPS3, 2.0 * 9 * Cin * Cout * (double)N * H * W, &e0, &e1);
+        return isr_launch_split_ups5(p, (unsigned)nwg, s, e0, e1);
     }
     const bool ups3 = upsample2x && (g_split_ups_form == 3 || g_split_ups_form == 4) && Cin > 0 && !(Cin & 15) && p.coutPad == 64 && Cout == 64 && p.cgroups == 1 && !p.xps;
     isr_profile_record(ups3 ? ISR_VARIANT_SPLIT_UPS3 : upsample2x ? ISR_VARIANT_SPLIT_UPS : ISR_VARIANT_SPLIT, 2.0 * 9 * Cin * Cout * (double)N * H * W, &e0, &e1);

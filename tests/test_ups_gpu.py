@@ -23,9 +23,12 @@ def _forms(fn):
         three = fn()
         lib.isrDebugSetSplitUpsForm(4)
         four = fn()
+        lib.isrDebugSetSplitUpsForm(5)                       # the software-pipelined form (sr_conv_ups5.h): must equal the others too
+        five = fn()
     finally:
         lib.isrDebugSetSplitUpsForm(default)
     torch.cuda.synchronize()
+    assert torch.equal(five, three), (five - three).abs().max().item()
     return tile, three, four
 
 
