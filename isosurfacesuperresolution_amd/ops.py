@@ -1613,6 +1613,8 @@ def assemble_input(gbuffer_hwc, flow_filled, prev_high, initial_image="zero", ao
     h, w = gbuffer_hwc.shape[0], gbuffer_hwc.shape[1]
     if out is None:
         out = torch.empty((1, 101, h, w), dtype=torch.float32, device=gbuffer_hwc.device)
+    elif getattr(out, '_isr_prepacked', None) is not None:
+        del out._isr_prepacked                      # a tensor assemble_input_packed handed out before: its planes are written now
     if prev_high is not None:
         prev_high = prev_high.contiguous()
         flow_filled = flow_filled.contiguous()
