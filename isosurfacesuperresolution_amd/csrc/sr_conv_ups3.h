@@ -17,6 +17,12 @@ constexpr int U3_PART = 2 * SP_PIX;                                          // 
 constexpr int U3_PUNITS = 2 * U3_PART;                                       // 1360 units = 21 760 B
 constexpr int U3_WROW = 3 * 128;                                             // one tap row of one part: 3 taps x [lane half][64 couts]
 constexpr int U3_WUNITS = 3 * U3_WROW;                                       // hi, lo, then hi 2^-11 (the partner of the scaled x_lo'): 1 152 units = 18 432 B, 4.5 per thread
+// Channel stride (floats) of the fp32 copy of the low-resolution region.  The interpolation reads it with ds_read_b32 (banks = dword mod 32,
+// 32 lanes per LDS cycle): a half-wave is 8 consecutive quads x the 4 four-channel groups, i.e. addresses quad + 4 g LR_CS -- with 113
+// (4 x 113 = 4 mod 32) the groups land 4 banks apart and overlap two-way, with 114 (= 8 mod 32) the 32 lanes hit 32 banks.
+#ifndef U3_LR_CS
+#define U3_LR_CS 114
+#endif
 constexpr int U3_LDS_BYTES = (U3_PUNITS + U3_WUNITS) * 16;                   // 40 192: three workgroups per CU (the epilogue's 32 KB scratch fits too)
 
 __global__ __launch_bounds__(S_THREADS, 3) void conv3x3_split_ups3_kernel(const SplitConvParams p)
@@ -70,7 +76,7 @@ __global__ __launch_bounds__(S_THREADS, 3) void conv3x3_split_ups3_kernel(const 
     constexpr int LR_H = ST_H / 2 + 2, LR_W = ST_W / 2 + 2;                 // 6 x 18 low-res pixels: rows oy0/2 - 1 .., cols ox0/2 - 1 ..
     constexpr int LQ = (ST_W / 2 + 8) / 4;                                   // 6 aligned quads per row
     constexpr int LUNITS = 16 * LR_H * LQ;                                   // (channel, row, quad) = 576: 2.25 per thread
-    constexpr int LR_CS = 113;                                               // channel stride of the fp32 copy (see conv3x3_split_kernel)
+    constexpr int LR_CS = U3_LR_CS;                                          // channel stride of the fp32 copy
     constexpr int QR = SP_H / 2, QC = SP_W / 2, UQ = QR * QC;               // 5 x 17 quads of 2 x 2 patch pixels
     float* const tmp = reinterpret_cast<float*>(wbuf);                       // [16][113] fp32 = 7.2 KB of the 12.3 KB weight buffer
     const int ly0 = oy0 / 2 - 1, lx0 = ox0 / 2 - 1;
