@@ -104,7 +104,8 @@ typedef __attribute__((address_space(3))) char t16_lds_char;
 // vector add per request): lane l's 16 bytes at base + voff land at LDS address ldsaddr + 16 l.
 #pragma clang diagnostic push
 #pragma clang diagnostic ignored "-Winline-asm"
-// COHERENT: an agent-scope load (sc1): served past this XCD's L2, which may hold a stale copy of a line another XCD has rewritten.
+// COHERENT: an agent-scope load (sc1): past this CU's L1 (which no other CU's store ever refreshes); the producers' `sc1` stores have
+// dropped the line from their XCD's L2, so the bytes come from memory / the Infinity Cache.
 template <bool COHERENT = false>
 __device__ __forceinline__ void trunk16_dma16(const void* base, unsigned voff, unsigned ldsaddr)
 {

@@ -49,7 +49,7 @@ with torch.no_grad():
     for guard in (False,):
         ops.RANGE_GUARD = guard
         print("range guard %s: per-layer %.0f us, dataflow %.0f us" % ("on" if guard else "off", timed(per_layer), timed(dataflow)))
-        names = {1: "no MFMAs", 2: "no activation DMA", 4: "no stores", 8: "no waits", 16: "no weight DMA", 3: "no MFMAs, no activation DMA",
+        names = {64: "everything, on the DIAGNOSTICS build (the build every ablation below runs on: 24 registers spilled)", 1: "no MFMAs", 2: "no activation DMA", 4: "no stores", 8: "no waits", 16: "no weight DMA", 3: "no MFMAs, no activation DMA",
                  5: "no MFMAs, no stores", 9: "no MFMAs, no waits", 18: "no DMA at all", 22: "no DMA, no stores", 23: "no MFMAs, DMA, stores",
                  31: "barriers + bias only", 30: "MFMAs only", 62: "MFMAs only, operands read once",
                  126: "MFMAs only on operands read once, the taps' LDS reads issued and dropped", 32: "everything, operands read once",
