@@ -51,6 +51,9 @@
 
 namespace {
 
+#ifndef T16_EARLY_PATCH
+#define T16_EARLY_PATCH 5
+#endif
 constexpr int T16_H = 16, T16_W = 32, T16_THREADS = 512, T16_WAVES = 8;
 constexpr int P16_H = T16_H + 2, P16_W = T16_W + 2, P16_PIX = P16_H * P16_W;          // 612 patch pixels
 constexpr int P16_PART = 2 * P16_PIX;                                                 // one k-step: 2 channel groups; hi, then lo at + P16_PART
@@ -460,8 +463,8 @@ __global__ __launch_bounds__(64 * T16_H / ROWS) void trunk_dataflow_kernel(const
             const u32x4* const wcur = wbuf0 + cur * S_WUNITS;
             const unsigned pnxt = pAddr + (unsigned)nxt * (P16_UNITS * 16), wnxt = wAddr + (unsigned)nxt * (S_WUNITS * 16);
             const bool more = ks + 1 < ksteps;
-            // the next k-step's weights (weight waves: one tap's piece after each tap's MFMAs) and patch (patch waves: one run after
-            // each tap, two after the last) -- or, under the layer's last k-step, the next layer's first weights and its bias
+            // the next k-step's weights (weight waves: one tap's piece after each tap's MFMAs) and patch (patch waves: T16_EARLY_PATCH
+            // runs after each of the first taps) -- or, under the layer's last k-step, the next layer's first weights and its bias
             const u32x4* const wimg = more ? wq : wqNext;
             const int wks = more ? ks + 1 : 0, wksteps = more ? ksteps : 4;
             const bool wany = dmaW && (more || !last), pany = dmaX && more;
@@ -473,7 +476,20 @@ __global__ __launch_bounds__(64 * T16_H / ROWS) void trunk_dataflow_kernel(const
                 }
                 if (prole) {
                     if (pany) {
-                        if (haloOnly) {
+                        // T16_EARLY_PATCH runs after each of the first taps (5: all ten behind taps 0 and 1) instead of one per tap and two
+                        // after the last: the activation bytes come over the fabric (microseconds), and what is requested behind the last
+                        // tap has ~0.5 us until the k-step's barrier waits for it.  In the frame, trunk: 0.59-0.61 ms with one run per tap,
+                        // 0.58-0.60 with 2 or 3, 0.57-0.59 with 5, 0.57-0.60 with all ten behind tap 0 (profiles/r05_trunk_rows.md)
+                        if (T16_EARLY_PATCH) {                          // (= runs per tap)
+#pragma unroll
+                            for (int q = 0; q < T16_EARLY_PATCH; ++q) {
+                                const int run = T16_EARLY_PATCH * tap + q;
+                                if (run < P16_SUBS) {
+                                    if (haloOnly) trunk16_patch_run<true>(run, pplane, pnxt + pdstRole, lanes);
+                                    else trunk16_patch_run<false>(run, pplane, pnxt + pdstRole, lanes);
+                                }
+                            }
+                        } else if (haloOnly) {
                             trunk16_patch_run<true>(tap, pplane, pnxt + pdstRole, lanes);
                             if (tap == 8) trunk16_patch_run<true>(9, pplane, pnxt + pdstRole, lanes);
                         } else {
@@ -524,9 +540,12 @@ __global__ __launch_bounds__(64 * T16_H / ROWS) void trunk_dataflow_kernel(const
                 auto mid = [&](int tap, int q) {
                     if (q == 0) trunk16_dma16_masked<false>(wsrc + tap * wtap, wlane, wdst + (unsigned)tap * 2048u, wmask);
                     else {
-                        trunk16_dma16_masked(pplane, lanes.poff[tap], pnxt + pdstRole + (unsigned)tap * 1024u, __builtin_amdgcn_ballot_w64((takeBits >> tap) & 1u) & pmask);
-                        if (tap == 8)
-                            trunk16_dma16_masked(pplane, lanes.poff[9], pnxt + pdstRole + 9u * 1024u, __builtin_amdgcn_ballot_w64((takeBits >> 9) & 1u) & pmask);
+#pragma unroll
+                        for (int qq = 0; qq < T16_EARLY_PATCH; ++qq) {          // the patch runs early in the k-step, as in the eight-wave form
+                            const int run = T16_EARLY_PATCH * tap + qq;
+                            if (run < P16_SUBS)
+                                trunk16_dma16_masked(pplane, lanes.poff[run], pnxt + pdstRole + (unsigned)run * 1024u, __builtin_amdgcn_ballot_w64((takeBits >> run) & 1u) & pmask);
+                        }
                     }
                 };
                 trunk16_kstep<ROWS>(acc, wcur + h * 64 + j, pcur + h * P16_PIX + (wave * ROWS) * P16_W + j, [](int) {}, mid);
@@ -756,14 +775,16 @@ __global__ __launch_bounds__(T16_THREADS) void trunk_mt_kernel(const Trunk16Para
                     if (more) {
                         if (wrole) weight_tap(tap, wq, ksteps, ks + 1, wnxt);
                         else {
-                            trunk16_patch_run<false>(tap, pplane, pnxt + pdstRole, lanes);
-                            if (tap == 8) trunk16_patch_run<false>(9, pplane, pnxt + pdstRole, lanes);
+#pragma unroll
+                            for (int q = 0; q < T16_EARLY_PATCH; ++q)
+                                if (T16_EARLY_PATCH * tap + q < P16_SUBS) trunk16_patch_run<false>(T16_EARLY_PATCH * tap + q, pplane, pnxt + pdstRole, lanes);
                         }
                     } else if (ahead) {                                        // the next tile's first k-step (same layer: same weights image, same bias)
                         if (wrole) weight_tap(tap, wq, ksteps, 0, wnxt);
                         else {
-                            trunk16_patch_run<false>(tap, pplane, pnxt + pdstRole, lanesNext);
-                            if (tap == 8) trunk16_patch_run<false>(9, pplane, pnxt + pdstRole, lanesNext);
+#pragma unroll
+                            for (int q = 0; q < T16_EARLY_PATCH; ++q)
+                                if (T16_EARLY_PATCH * tap + q < P16_SUBS) trunk16_patch_run<false>(T16_EARLY_PATCH * tap + q, pplane, pnxt + pdstRole, lanesNext);
                         }
                     }
                 };
