@@ -20,6 +20,12 @@ constexpr int U3_WUNITS = 3 * U3_WROW;                                       // 
 // Channel stride (floats) of the fp32 copy of the low-resolution region.  The interpolation reads it with ds_read_b32 (banks = dword mod 32,
 // 32 lanes per LDS cycle): a half-wave is 8 consecutive quads x the 4 four-channel groups, i.e. addresses quad + 4 g LR_CS -- with 113
 // (4 x 113 = 4 mod 32) the groups land 4 banks apart and overlap two-way, with 114 (= 8 mod 32) the 32 lanes hit 32 banks.
+// tap row of a k-step under whose MFMAs the NEXT k-step's low-resolution region is requested (0: three rows of cover for bytes that
+// come from memory; 2: one row, the registers that hold them live a third as long).  Measured equal (0.617-0.629 ms for the two launches with
+// 0, 1 or 2: the other two workgroups of the CU cover the latency): the short lifetime stays.
+#ifndef U3_LFETCH_ROW
+#define U3_LFETCH_ROW 2
+#endif
 #ifndef U3_LR_CS
 #define U3_LR_CS 114
 #endif
@@ -204,7 +210,7 @@ __global__ __launch_bounds__(S_THREADS, 3) void conv3x3_split_ups3_kernel(const 
             wpark();
             __syncthreads();
             wfetch(3 * ks + dy + 1);                                         // the next tap row's weights travel under these MFMAs
-            if (dy == 2 && ks + 1 < p.ksteps) lfetch(16 * (ks + 1));         // ... and so does the next k-step's low-resolution region
+            if (dy == U3_LFETCH_ROW && ks + 1 < p.ksteps) lfetch(16 * (ks + 1));   // ... and so does the next k-step's low-resolution region
             if (!(p.dbg & 1)) {
                 const u32x4* wl = wbuf + h * 64 + j;
                 const u32x4* bl = patch + h * SP_PIX + (wave * 2 + dy) * SP_W + j;
