@@ -11,25 +11,33 @@
 #pragma once
 #include "sr_split_common.h"
 
-namespace {
-
-constexpr int U3_PART = 2 * SP_PIX;                                          // one k-step of the patch: 2 channel groups; hi, then lo' at + U3_PART
-constexpr int U3_PUNITS = 2 * U3_PART;                                       // 1360 units = 21 760 B
-constexpr int U3_WROW = 3 * 128;                                             // one tap row of one part: 3 taps x [lane half][64 couts]
-constexpr int U3_WUNITS = 3 * U3_WROW;                                       // hi, lo, then hi 2^-11 (the partner of the scaled x_lo'): 1 152 units = 18 432 B, 4.5 per thread
-// Channel stride (floats) of the fp32 copy of the low-resolution region.  The interpolation reads it with ds_read_b32 (banks = dword mod 32,
-// 32 lanes per LDS cycle): a half-wave is 8 consecutive quads x the 4 four-channel groups, i.e. addresses quad + 4 g LR_CS -- with 113
-// (4 x 113 = 4 mod 32) the groups land 4 banks apart and overlap two-way, with 114 (= 8 mod 32) the 32 lanes hit 32 banks.
 // tap row of a k-step under whose MFMAs the NEXT k-step's low-resolution region is requested (0: three rows of cover for bytes that
 // come from memory; 2: one row, the registers that hold them live a third as long).  Measured equal (0.617-0.629 ms for the two launches with
 // 0, 1 or 2: the other two workgroups of the CU cover the latency): the short lifetime stays.
 #ifndef U3_LFETCH_ROW
 #define U3_LFETCH_ROW 2
 #endif
+// U3_SPLANE 1: the partner of the scaled x_lo' (w_hi 2^-11 as fp16) is read from a THIRD weight plane in LDS (round 4: 288 v_pk_mul_f16 per
+// wave and tile less); 0: made with v_pk_mul_f16 from the hi fragment, as every other kernel does.  The loop is co-limited by LDS traffic
+// (0.83 against 0.67 ds_read_b128 per MFMA, 18 against 12 KB parked per tap row): 0 measured 3 % faster (0.595 against 0.613 ms for the two
+// launches, interleaved), the same bits.
+#ifndef U3_SPLANE
+#define U3_SPLANE 0
+#endif
+// Channel stride (floats) of the fp32 copy of the low-resolution region.  The interpolation reads it with ds_read_b32 (banks = dword mod 32,
+// 32 lanes per LDS cycle): a half-wave is 8 consecutive quads x the 4 four-channel groups, i.e. addresses quad + 4 g LR_CS -- with 113
+// (4 x 113 = 4 mod 32) the groups land 4 banks apart and overlap two-way, with 114 (= 8 mod 32) the 32 lanes hit 32 banks.
 #ifndef U3_LR_CS
 #define U3_LR_CS 114
 #endif
-constexpr int U3_LDS_BYTES = (U3_PUNITS + U3_WUNITS) * 16;                   // 40 192: three workgroups per CU (the epilogue's 32 KB scratch fits too)
+
+namespace {
+
+constexpr int U3_PART = 2 * SP_PIX;                                          // one k-step of the patch: 2 channel groups; hi, then lo' at + U3_PART
+constexpr int U3_PUNITS = 2 * U3_PART;                                       // 1360 units = 21 760 B
+constexpr int U3_WROW = 3 * 128;                                             // one tap row of one part: 3 taps x [lane half][64 couts]
+constexpr int U3_WUNITS = (U3_SPLANE ? 3 : 2) * U3_WROW;                     // hi, lo (12 288 B, 3 units per thread) [, then hi 2^-11: 18 432 B]
+constexpr int U3_LDS_BYTES = (U3_PUNITS + U3_WUNITS) * 16;                   // 34 048 (40 192 with the third plane): three workgroups per CU (registers); the epilogue's 32 KB scratch fits too
 
 __global__ __launch_bounds__(S_THREADS, 3) void conv3x3_split_ups3_kernel(const SplitConvParams p)
 {
@@ -65,17 +73,21 @@ __global__ __launch_bounds__(S_THREADS, 3) void conv3x3_split_ups3_kernel(const 
         const int ks = step / 3, dy = step - 3 * ks;
 #pragma unroll
         for (int i = 0; i < 3; ++i) wreg[i] = __builtin_amdgcn_raw_buffer_load_b128(wrs, tid * 16, ((3 * dy + i) * p.ksteps + ks) * 4096, 0);
+        if (U3_SPLANE) {
 #pragma unroll
-        for (int k = 0; k < 2; ++k) {
-            const int e = tid + 256 * k;                                     // (tap e / 128, unit e % 128) of the tap row
-            wreg3[k] = __builtin_amdgcn_raw_buffer_load_b128(w3rs, (int)(e < 384 ? (unsigned)(e & 127) * 16u : BAD_OFFSET), ((3 * dy + (e >> 7)) * p.ksteps + ks) * 2048, 0);
+            for (int k = 0; k < 2; ++k) {
+                const int e = tid + 256 * k;                                 // (tap e / 128, unit e % 128) of the tap row
+                wreg3[k] = __builtin_amdgcn_raw_buffer_load_b128(w3rs, (int)(e < 384 ? (unsigned)(e & 127) * 16u : BAD_OFFSET), ((3 * dy + (e >> 7)) * p.ksteps + ks) * 2048, 0);
+            }
         }
     };
     auto wpark = [&]() {
 #pragma unroll
         for (int i = 0; i < 3; ++i) wdst[i * 128] = wreg[i];
-        wbuf[2 * U3_WROW + tid] = wreg3[0];
-        if (tid < 128) wbuf[2 * U3_WROW + 256 + tid] = wreg3[1];
+        if (U3_SPLANE) {
+            wbuf[2 * U3_WROW + tid] = wreg3[0];
+            if (tid < 128) wbuf[2 * U3_WROW + 256 + tid] = wreg3[1];
+        }
     };
 
     // ---- staging of one k-step (16 channels): low-resolution region -> fp32 copy on the (idle) weight buffer -> interpolate, split
@@ -220,8 +232,9 @@ __global__ __launch_bounds__(S_THREADS, 3) void conv3x3_split_ups3_kernel(const 
                     const f16x8 a0l = __builtin_bit_cast(f16x8, wl[U3_WROW + dx * 128]);
                     const f16x8 a1h = __builtin_bit_cast(f16x8, wl[dx * 128 + 32]);
                     const f16x8 a1l = __builtin_bit_cast(f16x8, wl[U3_WROW + dx * 128 + 32]);
-                    const f16x8 a0s = __builtin_bit_cast(f16x8, wl[2 * U3_WROW + dx * 128]);        // w_hi 2^-11: partner of the scaled x_lo'
-                    const f16x8 a1s = __builtin_bit_cast(f16x8, wl[2 * U3_WROW + dx * 128 + 32]);
+                    // w_hi 2^-11, the partner of the scaled x_lo': read from the third plane (U3_SPLANE) or made here (the same fp16 product)
+                    const f16x8 a0s = U3_SPLANE ? __builtin_bit_cast(f16x8, wl[2 * U3_WROW + dx * 128]) : a0h * (_Float16)0.00048828125f;
+                    const f16x8 a1s = U3_SPLANE ? __builtin_bit_cast(f16x8, wl[2 * U3_WROW + dx * 128 + 32]) : a1h * (_Float16)0.00048828125f;
 #pragma unroll
                     for (int r = 0; r < 2; ++r) {
                         const f16x8 bh = __builtin_bit_cast(f16x8, bl[r * SP_W + dx]);
