@@ -27,6 +27,12 @@
 // Channel stride (floats) of the fp32 copy of the low-resolution region.  The interpolation reads it with ds_read_b32 (banks = dword mod 32,
 // 32 lanes per LDS cycle): a half-wave is 8 consecutive quads x the 4 four-channel groups, i.e. addresses quad + 4 g LR_CS -- with 113
 // (4 x 113 = 4 mod 32) the groups land 4 banks apart and overlap two-way, with 114 (= 8 mod 32) the 32 lanes hit 32 banks.
+// U3_WDMA 1: a tap row's weights arrive by LDS-DMA (buffer_load ... lds: no registers, no ds_write_b128 -- 22 % of the loop's LDS cycles
+// were those stores) into the OTHER of two 12 KB weight slots while the row before multiplies: ONE barrier per tap row instead of two.  The
+// fp32 copy of the low-resolution region moves with the idle slot.  46 KB of LDS: still three workgroups per CU.
+#ifndef U3_WDMA
+#define U3_WDMA 1
+#endif
 #ifndef U3_LR_CS
 #define U3_LR_CS 114
 #endif
@@ -37,7 +43,7 @@ constexpr int U3_PART = 2 * SP_PIX;                                          // 
 constexpr int U3_PUNITS = 2 * U3_PART;                                       // 1360 units = 21 760 B
 constexpr int U3_WROW = 3 * 128;                                             // one tap row of one part: 3 taps x [lane half][64 couts]
 constexpr int U3_WUNITS = (U3_SPLANE ? 3 : 2) * U3_WROW;                     // hi, lo (12 288 B, 3 units per thread) [, then hi 2^-11: 18 432 B]
-constexpr int U3_LDS_BYTES = (U3_PUNITS + U3_WUNITS) * 16;                   // 34 048 (40 192 with the third plane): three workgroups per CU (registers); the epilogue's 32 KB scratch fits too
+constexpr int U3_LDS_BYTES = (U3_PUNITS + (U3_WDMA ? 2 : 1) * U3_WUNITS) * 16;   // (with U3_WDMA: 46 336)                   // 34 048 (40 192 with the third plane): three workgroups per CU (registers); the epilogue's 32 KB scratch fits too
 
 __global__ __launch_bounds__(S_THREADS, 3) void conv3x3_split_ups3_kernel(const SplitConvParams p)
 {
@@ -96,7 +102,19 @@ __global__ __launch_bounds__(S_THREADS, 3) void conv3x3_split_ups3_kernel(const 
     constexpr int LUNITS = 16 * LR_H * LQ;                                   // (channel, row, quad) = 576: 2.25 per thread
     constexpr int LR_CS = U3_LR_CS;                                          // channel stride of the fp32 copy
     constexpr int QR = SP_H / 2, QC = SP_W / 2, UQ = QR * QC;               // 5 x 17 quads of 2 x 2 patch pixels
-    float* const tmp = reinterpret_cast<float*>(wbuf);                       // [16][113] fp32 = 7.2 KB of the 12.3 KB weight buffer
+    float* tmp = reinterpret_cast<float*>(wbuf);                             // [16][114] fp32 = 7.3 KB of the (idle) 12.3 KB weight buffer / slot
+    // U3_WDMA: tap row `step` = 3 ks + dy into weight slot step & 1: 12 wave-wide pieces (tap i, part, half), three per wave
+    const int wv = __builtin_amdgcn_readfirstlane(wave);
+    auto wdma = [&](int step) {
+        if (step >= 3 * p.ksteps) return;
+        const int ks = step / 3, dy = step - 3 * ks;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            const int idx = wv + 4 * k, i = idx >> 2, part = (idx >> 1) & 1, half = idx & 1;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(wrs, (isr_lvoid_t*)(wbuf + (step & 1) * U3_WUNITS + part * U3_WROW + i * 128 + half * 64), 16,
+                                                     lane * 16, (((3 * dy + i) * p.ksteps + ks) * 256 + part * 128 + half * 64) * 16, 0, 0);
+        }
+    };
     const int ly0 = oy0 / 2 - 1, lx0 = ox0 / 2 - 1;
     u32x4 v[3];
     auto lfetch = [&](int cin0) {                                            // requests only: the values are parked after a barrier
@@ -208,6 +226,51 @@ __global__ __launch_bounds__(S_THREADS, 3) void conv3x3_split_ups3_kernel(const 
             for (int i = 0; i < 16; ++i) acc[cb][r][i] = 0.0f;
 
     lfetch(0);
+    if (U3_WDMA) {
+        wdma(0);
+#pragma unroll 1
+        for (int ks = 0; ks < p.ksteps; ++ks) {
+            // row 3 ks multiplies on slot (3 ks) & 1 (in flight or landed); the other slot is idle: the fp32 copy lives there
+            tmp = reinterpret_cast<float*>(wbuf + ((3 * ks + 1) & 1) * U3_WUNITS);
+            lpark();
+            __syncthreads();
+            if (!(p.dbg & 2)) interpolate();
+#pragma unroll 1
+            for (int dy = 0; dy < 3; ++dy) {
+                // this row's weights have landed (every wave's pieces: the wait, then the barrier), the patch is complete (dy = 0) and
+                // everybody is done with the slot the next row's weights go to (the row before last read it; dy = 0: the fp32 copy)
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __syncthreads();
+                wdma(3 * ks + dy + 1);
+                if (dy == U3_LFETCH_ROW && ks + 1 < p.ksteps) lfetch(16 * (ks + 1));
+                if (!(p.dbg & 1)) {
+                    const u32x4* wl = wbuf + ((3 * ks + dy) & 1) * U3_WUNITS + h * 64 + j;
+                    const u32x4* bl = patch + h * SP_PIX + (wave * 2 + dy) * SP_W + j;
+#pragma unroll
+                    for (int dx = 0; dx < 3; ++dx) {
+                        const f16x8 a0h = __builtin_bit_cast(f16x8, wl[dx * 128]);
+                        const f16x8 a0l = __builtin_bit_cast(f16x8, wl[U3_WROW + dx * 128]);
+                        const f16x8 a1h = __builtin_bit_cast(f16x8, wl[dx * 128 + 32]);
+                        const f16x8 a1l = __builtin_bit_cast(f16x8, wl[U3_WROW + dx * 128 + 32]);
+                        const f16x8 a0s = a0h * (_Float16)0.00048828125f;   // w_hi 2^-11: partner of the scaled x_lo'
+                        const f16x8 a1s = a1h * (_Float16)0.00048828125f;
+#pragma unroll
+                        for (int r = 0; r < 2; ++r) {
+                            const f16x8 bh = __builtin_bit_cast(f16x8, bl[r * SP_W + dx]);
+                            const f16x8 bo = __builtin_bit_cast(f16x8, bl[U3_PART + r * SP_W + dx]);
+                            acc[0][r] = mfma16(a0l, bh, acc[0][r]);
+                            acc[0][r] = mfma16(a0s, bo, acc[0][r]);
+                            acc[0][r] = mfma16(a0h, bh, acc[0][r]);
+                            acc[1][r] = mfma16(a1l, bh, acc[1][r]);
+                            acc[1][r] = mfma16(a1s, bo, acc[1][r]);
+                            acc[1][r] = mfma16(a1h, bh, acc[1][r]);
+                        }
+                    }
+                }
+            }
+            __syncthreads();                                                 // the patch and the slot the next fp32 copy goes to are free
+        }
+    } else {
     wfetch(0);
 #pragma unroll 1
     for (int ks = 0; ks < p.ksteps; ++ks) {
@@ -250,6 +313,7 @@ __global__ __launch_bounds__(S_THREADS, 3) void conv3x3_split_ups3_kernel(const 
             }
             __syncthreads();                                                 // weight buffer (after the third row: the patch too) free
         }
+    }
     }
 
     if (p.stamps) st2 = __builtin_amdgcn_s_memrealtime();
