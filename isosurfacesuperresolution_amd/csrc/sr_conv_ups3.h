@@ -33,6 +33,9 @@
 #ifndef U3_WDMA
 #define U3_WDMA 1
 #endif
+#ifndef U3_CARRY
+#define U3_CARRY 1
+#endif
 #ifndef U3_LR_CS
 #define U3_LR_CS 114
 #endif
@@ -235,7 +238,8 @@ __global__ __launch_bounds__(S_THREADS, 3) void conv3x3_split_ups3_kernel(const 
             lpark();
             __syncthreads();
             if (!(p.dbg & 2)) interpolate();
-#pragma unroll 1
+            f16x8 carry[3];                                                  // U3_CARRY: the hi fragments of the patch row two consecutive tap rows share
+#pragma unroll
             for (int dy = 0; dy < 3; ++dy) {
                 // this row's weights have landed (every wave's pieces: the wait, then the barrier), the patch is complete (dy = 0) and
                 // everybody is done with the slot the next row's weights go to (the row before last read it; dy = 0: the fp32 copy)
@@ -256,8 +260,10 @@ __global__ __launch_bounds__(S_THREADS, 3) void conv3x3_split_ups3_kernel(const 
                         const f16x8 a1s = a1h * (_Float16)0.00048828125f;
 #pragma unroll
                         for (int r = 0; r < 2; ++r) {
-                            const f16x8 bh = __builtin_bit_cast(f16x8, bl[r * SP_W + dx]);
+                            // (patch row wave * 2 + dy + r: this tap row's r = 1 is the next tap row's r = 0)
+                            const f16x8 bh = (U3_CARRY && r == 0 && dy > 0) ? carry[dx] : __builtin_bit_cast(f16x8, bl[r * SP_W + dx]);
                             const f16x8 bo = __builtin_bit_cast(f16x8, bl[U3_PART + r * SP_W + dx]);
+                            if (U3_CARRY && r == 1) carry[dx] = bh;
                             acc[0][r] = mfma16(a0l, bh, acc[0][r]);
                             acc[0][r] = mfma16(a0s, bo, acc[0][r]);
                             acc[0][r] = mfma16(a0h, bh, acc[0][r]);
