@@ -34,7 +34,7 @@
 #define U3_WDMA 1
 #endif
 #ifndef U3_CARRY
-#define U3_CARRY 1
+#define U3_CARRY 2
 #endif
 #ifndef U3_LR_CS
 #define U3_LR_CS 114
@@ -238,7 +238,7 @@ __global__ __launch_bounds__(S_THREADS, 3) void conv3x3_split_ups3_kernel(const 
             lpark();
             __syncthreads();
             if (!(p.dbg & 2)) interpolate();
-            f16x8 carry[3];                                                  // U3_CARRY: the hi fragments of the patch row two consecutive tap rows share
+            f16x8 carry[3], carryo[3];                                       // U3_CARRY: the hi (2: and lo') fragments of the patch row two consecutive tap rows share
 #pragma unroll
             for (int dy = 0; dy < 3; ++dy) {
                 // this row's weights have landed (every wave's pieces: the wait, then the barrier), the patch is complete (dy = 0) and
@@ -262,8 +262,9 @@ __global__ __launch_bounds__(S_THREADS, 3) void conv3x3_split_ups3_kernel(const 
                         for (int r = 0; r < 2; ++r) {
                             // (patch row wave * 2 + dy + r: this tap row's r = 1 is the next tap row's r = 0)
                             const f16x8 bh = (U3_CARRY && r == 0 && dy > 0) ? carry[dx] : __builtin_bit_cast(f16x8, bl[r * SP_W + dx]);
-                            const f16x8 bo = __builtin_bit_cast(f16x8, bl[U3_PART + r * SP_W + dx]);
+                            const f16x8 bo = (U3_CARRY == 2 && r == 0 && dy > 0) ? carryo[dx] : __builtin_bit_cast(f16x8, bl[U3_PART + r * SP_W + dx]);
                             if (U3_CARRY && r == 1) carry[dx] = bh;
+                            if (U3_CARRY == 2 && r == 1) carryo[dx] = bo;
                             acc[0][r] = mfma16(a0l, bh, acc[0][r]);
                             acc[0][r] = mfma16(a0s, bo, acc[0][r]);
                             acc[0][r] = mfma16(a0h, bh, acc[0][r]);
