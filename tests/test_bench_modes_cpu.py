@@ -196,6 +196,23 @@ def test_kernel_tally_and_gap_accounting():
     assert dom[0] == "conv3x3_split_ups3_kernel" or dom[0] == "trunk_dataflow_kernel"
 
 
+def test_sustained_object_of_the_default_line():
+    """The shape of the default line's `sustained` object (>= 2 000 more frames of the same pipeline after the timed
+    region, whole-run frames/s, min / median / max over 100-frame windows, the guard words read at the end) from raw measurements."""
+    sys.path.insert(0, ROOT)
+    import bench
+    window_ms = [175.0, 174.0, 180.0, 350.0] + [176.0] * 16                      # one window with an outlier in it
+    d = bench.sustained_summary(2000, 3.6, window_ms)
+    assert {"frames", "seconds", "value", "unit", "ms_per_step", "window_frames", "windows", "window_frames_per_s", "guards", "note"} <= set(d)
+    assert d["frames"] == 2000 and d["unit"] == "frames/s" and d["window_frames"] == bench.SUSTAINED_WINDOW == 100 and d["windows"] == 20
+    assert abs(d["value"] - 2000 / 3.6) < 1e-9 and abs(d["ms_per_step"] - 1.8) < 1e-9
+    w = d["window_frames_per_s"]
+    assert abs(w["min"] - 100e3 / 350.0) < 1e-9 and abs(w["max"] - 100e3 / 174.0) < 1e-9 and abs(w["median"] - 100e3 / 176.0) < 1e-9
+    assert w["min"] <= w["median"] <= w["max"] and d["guards"] == "clean"
+    assert bench.parse([]).sustained_frames >= 2000                              # on by default, in the driver's own command
+    assert bench.parse(["--sustained-frames", "0"]).sustained_frames == 0
+
+
 def test_a_rank_that_never_joins_ends_the_run_with_rank_and_phase_named(tmp_path):
     """the first real multi-rank run must fail loudly, not hang to the driver's limit.  World size 2, only rank 0
     started: the rendezvous is bounded (BENCH_DIST_TIMEOUT_S, default 120 s), the process says which rank and phase, exits 3."""

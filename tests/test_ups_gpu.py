@@ -25,10 +25,13 @@ def _forms(fn):
         four = fn()
         lib.isrDebugSetSplitUpsForm(5)                       # the software-pipelined form (sr_conv_ups5.h): must equal the others too
         five = fn()
+        lib.isrDebugSetSplitUpsForm(7)                       # the four-rows-per-wave form (sr_conv_ups4r.h): must equal the others too
+        seven = fn()
     finally:
         lib.isrDebugSetSplitUpsForm(default)
     torch.cuda.synchronize()
     assert torch.equal(five, three), (five - three).abs().max().item()
+    assert torch.equal(seven, three), (seven - three).abs().max().item()
     return tile, three, four
 
 
