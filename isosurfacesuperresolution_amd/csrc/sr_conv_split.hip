@@ -1116,6 +1116,7 @@ __global__ __launch_bounds__(256) void prepare_weights_split_many_kernel(const P
 
 #include "sr_conv_ups3.h"       // the three-workgroups-per-CU upsampling kernel: same translation unit, same parameter block
 #include "sr_conv_ups4r.h"      // the four-rows-per-wave upsampling kernel (16 x 32 tiles, two workgroups per CU, prefetched fragments)
+#include "sr_conv_upsw.h"       // the one-stream upsampling kernel (persistent workgroup per CU, staging sliced into the MFMA gaps)
 #include "sr_conv_ups4.h"       // the role-split upsampling kernel (producer / consumer waves)
 #include "sr_conv_ups5.h"       // the software-pipelined upsampling kernel (staging of k-step g + 1 between the MFMAs of k-step g)
 #include "sr_conv_upsp.h"       // the phase-decomposed upsampling kernel (no interpolation at run time; packed-split in and out)
@@ -1302,8 +1303,12 @@ int isrConv3x3ForwardSplit(const float* x, const void* wq, const float* bias, co
         isr_profile_record(ISR_VARIANT_SPLIT_UPS3, 2.0 * 9 * Cin * Cout * (double)N * H * W, &e0, &e1);
         return isr_launch_split_ups5(p, (unsigned)nwg, s, e0, e1);
     }
-    const bool ups3 = upsample2x && (g_split_ups_form == 3 || g_split_ups_form == 4 || g_split_ups_form == 7) && Cin > 0 && !(Cin & 15) && p.coutPad == 64 && Cout == 64 && p.cgroups == 1 && !p.xps;
+    const bool ups3 = upsample2x && (g_split_ups_form == 3 || g_split_ups_form == 4 || g_split_ups_form == 7 || g_split_ups_form == 8) && Cin > 0 && !(Cin & 15) && p.coutPad == 64 && Cout == 64 && p.cgroups == 1 && !p.xps;
     isr_profile_record(ups3 ? ISR_VARIANT_SPLIT_UPS3 : upsample2x ? ISR_VARIANT_SPLIT_UPS : ISR_VARIANT_SPLIT, 2.0 * 9 * Cin * Cout * (double)N * H * W, &e0, &e1);
+    if (ups3 && g_split_ups_form == 8) {
+        const int rc = isr_launch_split_upsw(p, s, e0, e1);
+        if (rc != -1) return rc;
+    }
     if (ups3 && g_split_ups_form == 7) {
         const int rc = isr_launch_split_ups4r(p, s, e0, e1);
         if (rc != -1) return rc;

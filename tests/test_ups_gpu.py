@@ -27,11 +27,14 @@ def _forms(fn):
         five = fn()
         lib.isrDebugSetSplitUpsForm(7)                       # the four-rows-per-wave form (sr_conv_ups4r.h): must equal the others too
         seven = fn()
+        lib.isrDebugSetSplitUpsForm(8)                       # the one-stream persistent form (sr_conv_upsw.h): must equal the others too
+        eight = fn()
     finally:
         lib.isrDebugSetSplitUpsForm(default)
     torch.cuda.synchronize()
     assert torch.equal(five, three), (five - three).abs().max().item()
     assert torch.equal(seven, three), (seven - three).abs().max().item()
+    assert torch.equal(eight, three), (eight - three).abs().max().item()
     return tile, three, four
 
 
@@ -50,7 +53,10 @@ def test_three_per_cu_and_role_split_upsampling_kernels_are_bit_identical_to_the
         err = (three.double() - ref).abs().max().item()
         assert err <= 2e-6 * max(1.0, ref.abs().max().item()), err
         if ops.packed_supported(x, wt, True):
-            pt, p3, p4 = _forms(lambda: ops.conv3x3_split_packed(x, wt, b, act='relu', upsample2x=True).data.clone())
+            def packed_pixels():                                 # (the planes' padding behind the last pixel is never written: not part of the result)
+                ps = ops.conv3x3_split_packed(x, wt, b, act='relu', upsample2x=True)
+                return ps.data.view(2 * (ps.channels // 8), ps.plane, 4)[:, :ps.h * ps.w].clone()
+            pt, p3, p4 = _forms(packed_pixels)
             assert torch.equal(pt, p3)
             assert torch.equal(pt, p4)
 

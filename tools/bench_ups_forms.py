@@ -27,7 +27,7 @@ def timed(fn, n=12):
 
 with torch.no_grad():
     for rnd in range(3):
-        for form in (3, 7):
+        for form in (3, 7, 8):
             lib.isrDebugSetSplitUpsForm(form)
             t1 = timed(lambda: ops.conv3x3_split(x1, wt, b, act='relu', upsample2x=True))
             t2 = timed(lambda: ops.conv3x3_split_packed(x2, wt, b, act='relu', upsample2x=True))
