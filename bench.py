@@ -428,7 +428,7 @@ def run_infer(args, job):
     switches = ops.debug_switches()
     # an ablation (MFMAs skipped, stores skipped, stamp buffers) must never be behind a reported number; a forced kernel form
     # (ISR_SPLIT_ALGO, an experiment switch) is allowed and shows up in the line
-    if os.environ.get("BENCH_ALLOW_SWITCHES") != "1":      # (tools/ab_bench.sh compares kernel forms; the line carries `debug_switches` either way)
+    if os.environ.get("BENCH_ALLOW_SWITCHES") != "1" and os.environ.get("ISR_SR_DIAG") != "1":      # (tools/ab_bench.sh compares kernel forms; the line carries `debug_switches` either way)
         assert not (switches & ~2), "diagnostic switches of libisr_sr.so are set (mask %#x): not a measurement" % switches
     rm_ms = renderer.profile_times_ms()
     ops.profile_enable(False)
@@ -504,6 +504,8 @@ def run_infer(args, job):
                          "per_kernel_durations": "eager pass of the same frames after the timed region"}
                         if pipe.graph else None),
         "debug_switches": switches,
+        # lib/libisr_sr.so is the PRODUCT build (no isrDebug* symbol: `debug_switches` is 0 by construction); a line measured on the diagnostics build says so
+        "kernel_library": {"file": os.path.basename(ops._native.SR_LIB), "diagnostics_build": ops.is_diagnostics_library()},
         "roofline": {"kernel": dom_name, "bound": "mfma", "achieved": achieved, "peak": peak,
                      "unit": "TFLOP/s", "frac": achieved / peak, "traffic": traffic,
                      "peak_source": ("dense fp16 MFMA %.0f TFLOP/s / 3 matrix products per algorithmic multiply-accumulate" % MFMA_F16_PEAK_TFLOPS)

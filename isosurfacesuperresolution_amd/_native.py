@@ -13,20 +13,25 @@ _PKG = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_PKG, "csrc")
 LIBDIR = os.path.join(_PKG, "lib")
 RENDERER_LIB = os.path.join(LIBDIR, "libGPURendererDirect.so")
-# ISR_SR_LIB: another build of the same library (A/B measurements of kernel changes on one box: tools/ab_bench.sh)
-SR_LIB = os.environ.get("ISR_SR_LIB") or os.path.join(LIBDIR, "libisr_sr.so")
+# The PRODUCT build of the super-resolution kernels (csrc/sr_diag.h: no isrDebug* export, no ablation switch in a kernel, none of the
+# experimental kernel forms) and the DIAGNOSTICS build of the same sources (`make diag`: what tools/ and the timeout-path / form-parity
+# tests load -- ops.diagnostics_library()).
+SR_DIAG_LIB = os.path.join(LIBDIR, "libisr_sr_diag.so")
+# ISR_SR_LIB: another build of the same library (A/B measurements of kernel changes on one box: tools/ab_bench.sh);
+# ISR_SR_DIAG=1: the whole process on the diagnostics build (the scripts under tools/ that flip isrDebug* switches)
+SR_LIB = os.environ.get("ISR_SR_LIB") or (SR_DIAG_LIB if os.environ.get("ISR_SR_DIAG") == "1" else os.path.join(LIBDIR, "libisr_sr.so"))
 
 _cache = {}
 
 
 def build(force=False, verbose=False):
     """Compile every HIP extension for gfx950 (hipcc cross-compiles without a GPU)."""
-    cmd = ["make", "-j8", "-C", CSRC, "all"]
+    cmd = ["make", "-j8", "-C", CSRC, "all", "diag"]
     if force:
         cmd.insert(1, "-B")
     out = None if verbose else subprocess.DEVNULL
     subprocess.check_call(cmd, stdout=out)
-    return [RENDERER_LIB, SR_LIB]
+    return [RENDERER_LIB, os.path.join(LIBDIR, "libisr_sr.so"), SR_DIAG_LIB]
 
 
 def _preload_hip_runtime():

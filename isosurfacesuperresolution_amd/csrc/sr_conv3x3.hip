@@ -18,6 +18,7 @@
 // 0-31 read 32 consecutive floats: conflict free).  Weights are read straight from L1/L2 in a
 // [tap][cin][cout] layout (256 B per k-step and M tile; fp32 MFMA is so slow -- 64 cycles per
 // instruction -- that this is ~4 B/clk/CU).
+#include "sr_diag.h"
 #include <hip/hip_runtime.h>
 #include <hip/hip_ext.h>
 #include <stdint.h>
@@ -67,8 +68,8 @@ struct ConvParams {
     int tilesX, tilesY;
     int act;
     float slope;
-    int dbg;                 // ablation bits for tools/bench_conv.py (0 in production)
-    unsigned long long* stamps;   // dbg & 8: per-workgroup s_memtime stamps (diagnostic builds only)
+    ISR_DIAG_MEMBER(int, dbg, 0);                 // ablation bits for tools/bench_conv.py (0 in production)
+    ISR_DIAG_MEMBER(unsigned long long*, stamps, nullptr);   // dbg & 8: per-workgroup s_memtime stamps (diagnostic builds only)
 };
 
 __device__ __forceinline__ int xcd_remap(int bid, int nwg)
@@ -917,7 +918,7 @@ struct WGradParams {
     int ci0, co0;       // channel group handled by this launch
     int tilesX, tilesY, ntiles;
     const float* scale; // split-operand kernel only: { 2^S, 2^-S } with max |gz| 2^S in [2^13, 2^14)
-    int dbg;            // diagnostics (isrDebugSetAblation; conv3x3_wgrad_split2_kernel): 1 no MFMAs, 2 no split / park, 4 no fetch
+    ISR_DIAG_MEMBER(int, dbg, 0);            // diagnostics (isrDebugSetAblation; conv3x3_wgrad_split2_kernel): 1 no MFMAs, 2 no split / park, 4 no fetch
 };
 
 // Staging is branch-free and software pipelined: the next tile's 8 + 51 elements per thread are fetched through
@@ -1703,14 +1704,14 @@ void isr_profile_record(int variant, double flops, hipEvent_t* e0, hipEvent_t* e
     g_records.push_back({ variant, flops, *e0, *e1 });
 }
 
-static int g_conv_dbg = 0;
-static int g_wgrad_split_form = [] { const char* e = getenv("ISR_WGRAD_FORM"); return (e && e[0] == '1') ? 1 : 2; }();
+[[maybe_unused]] static int g_conv_dbg = 0;
+static int g_wgrad_split_form = isr_diag_env_int("ISR_WGRAD_FORM", 2) == 1 ? 1 : 2;
 static int g_conv_tile = 0;   // 0: automatic, 1: always 4x32 tiles, 2: always 16x32 tiles, 3: one row per workgroup (tools / tests)
 static long long g_row_threshold = 160;   // automatic: rows when the 4x32 tiling has at most this many workgroups
                                           // (HIP-graph chain of 64 -> 64 layers on N crops of 32x32, rows vs 4x32 tiles:
                                           //  N=2 7.5 vs 15.1 us, N=4 8.4 vs 15.2, N=8 12.1 vs 15.1, N=12 16.1 vs 16.0, N=16 19.5 vs 16.1)
 static int g_conv_algo = 1;   // 0: one workgroup per CU (64 channels), 1: two per CU (32 channels each)
-static unsigned long long* g_conv_stamps = nullptr;
+[[maybe_unused]] static unsigned long long* g_conv_stamps = nullptr;
 
 extern "C" {
 
@@ -1736,6 +1737,7 @@ int isrProfileGet(int i, int* variant, double* flops, float* ms)
     return 0;
 }
 
+#ifdef ISR_DIAG
 void isrDebugSetAblation(int bits) { g_conv_dbg = bits; }
 // split-operand weight gradient: 2 = staging on its own waves (conv3x3_wgrad_split2_kernel, the default), 1 = one wave per SIMD
 void isrDebugSetWgradSplitForm(int form) { g_wgrad_split_form = form == 1 ? 1 : 2; }
@@ -1744,6 +1746,7 @@ void isrDebugSetForwardAlgo(int a) { g_conv_algo = a; }
 void isrDebugSetForwardTile(int t) { g_conv_tile = t; }   // not part of the public header
 void isrDebugSetRowThreshold(long long n) { g_row_threshold = n; }
 void isrDebugSetStampBuffer(void* p) { g_conv_stamps = (unsigned long long*)p; }
+#endif
 
 int isrConvCinPad(int Cin) { return ((Cin + CK - 1) / CK) * CK; }
 int isrConvCoutPad(int Cout) { return ((Cout + 31) / 32) * 32; }
@@ -1793,8 +1796,8 @@ int isrConv3x3ForwardStrided(const float* x, const float* wprep, const float* bi
     p.cinPad = isrConvCinPad(Cin); p.coutPad = isrConvCoutPad(Cout);
     p.tilesX = (W + TW - 1) / TW; p.tilesY = (H + TH - 1) / TH;
     p.act = act; p.slope = slope;
-    p.dbg = g_conv_dbg;
-    p.stamps = g_conv_stamps;
+    ISR_DIAG_SET(p.dbg, g_conv_dbg);
+    ISR_DIAG_SET(p.stamps, g_conv_stamps);
     const long long nwg = (long long)N * p.tilesX * p.tilesY;
     if (nwg > 0x7fffffffLL) return -1;
     const dim3 grid((unsigned)nwg), block(NTHREADS);
@@ -1914,7 +1917,7 @@ int isrConv3x3WeightGradSegments(const float* const* xs, const float* const* gzs
         return -1;
     hipStream_t s = (hipStream_t)stream;
     WGradParams p;
-    p.dbg = g_conv_dbg;
+    ISR_DIAG_SET(p.dbg, g_conv_dbg);
     for (int k = 0; k < WG_MAX_SEG; ++k) {
         p.x[k] = k < segments ? xs[k] : nullptr;
         p.gz[k] = k < segments ? gzs[k] : nullptr;
@@ -1954,7 +1957,7 @@ int isrConv3x3WeightGradSegmentsBf16(const float* const* xs, const float* const*
     if (W & 3) return -3;                          // the gz tile is fetched as aligned groups of four pixels
     hipStream_t s = (hipStream_t)stream;
     WGradParams p;
-    p.dbg = g_conv_dbg;
+    ISR_DIAG_SET(p.dbg, g_conv_dbg);
     for (int k = 0; k < WG_MAX_SEG; ++k) {
         p.x[k] = k < segments ? xs[k] : nullptr;
         p.gz[k] = k < segments ? gzs[k] : nullptr;
@@ -2000,7 +2003,7 @@ int isrConv3x3WeightGradSegmentsSplitMax(const float* const* xs, const float* co
     if (W & 3) return -3;                          // the gz tile is fetched as aligned groups of four pixels
     hipStream_t s = (hipStream_t)stream;
     WGradParams p;
-    p.dbg = g_conv_dbg;
+    ISR_DIAG_SET(p.dbg, g_conv_dbg);
     AbsMaxParams ap;
     for (int k = 0; k < WG_MAX_SEG; ++k) {
         p.x[k] = k < segments ? xs[k] : nullptr;

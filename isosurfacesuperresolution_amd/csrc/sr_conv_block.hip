@@ -16,6 +16,7 @@
 // LDS stays at 80 KB -> two workgroups per CU, one's barriers and epilogues under the other's MFMAs, as in the layer kernels.
 // Per block: one launch and one first-staging / epilogue pair less, t (33 MB written, 44 MB read back through the memory system
 // by another launch) stays next to the CU that made it.
+#include "sr_diag.h"
 #include "sr_split_common.h"
 
 namespace {
@@ -44,8 +45,8 @@ struct BlockParams {
     u32x4* scratch;               // gridDim.x * SCR_UNITS units
     int H, W, xPlane, yPlane, tilesX, tilesY;
     unsigned* absmax;             // range guard (SplitConvParams::absmax): over the intermediate t AND the output
-    unsigned long long* stamps;   // diagnostics: 8 s_memrealtime stamps (100 MHz, chip-wide clock) per workgroup, first tile; or NULL
-    int dbg;                      // diagnostics: 1 skip conv1's MFMAs, 2 skip conv2's MFMAs, 4 skip the scratch stores, 8 skip the DMA
+    ISR_DIAG_MEMBER(unsigned long long*, stamps, nullptr);   // diagnostics: 8 s_memrealtime stamps (100 MHz, chip-wide clock) per workgroup, first tile; or NULL
+    ISR_DIAG_MEMBER(int, dbg, 0);                      // diagnostics: 1 skip conv1's MFMAs, 2 skip conv2's MFMAs, 4 skip the scratch stores, 8 skip the DMA
 };
 
 typedef u32x2 uint2_t;
@@ -149,7 +150,7 @@ __global__ __launch_bounds__(B_THREADS, 2) void resblock_split_kernel(const Bloc
     p2.xPlane = p.xPlane; p2.yPlane = p.yPlane; p2.rPlane = p.xPlane;
     p2.xImage = 0; p2.yImage = 0; p2.rImage = 0;
     p2.ksteps = 4; p2.coutPad = 64; p2.cgroups = 1; p2.tilesX = p.tilesX; p2.tilesY = p.tilesY;
-    p2.act = ISR_ACT_NONE; p2.slope = 0.0f; p2.Hin = p.H; p2.Win = p.W; p2.quads = 1; p2.dbg = 0; p2.stamps = nullptr; p2.ps = nullptr; p2.psPlane = 0; p2.xps = nullptr; p2.xpsPlane = 0; p2.zero = nullptr; p2.absmax = p.absmax; p2.slotmax = nullptr;
+    p2.act = ISR_ACT_NONE; p2.slope = 0.0f; p2.Hin = p.H; p2.Win = p.W; p2.quads = 1; ISR_DIAG_SET(p2.dbg, 0); ISR_DIAG_SET(p2.stamps, nullptr); p2.ps = nullptr; p2.psPlane = 0; p2.xps = nullptr; p2.xpsPlane = 0; p2.zero = nullptr; p2.absmax = p.absmax; p2.slotmax = nullptr;
 
     // The two workgroups of a CU share its SIMDs, and issue arbitration prefers the OLDER wave: the first-dispatched workgroup
     // of a CU runs near full speed, the second (in practice blockIdx >= half the grid) gets the leftovers and finishes ~20 us
@@ -300,11 +301,13 @@ __global__ __launch_bounds__(B_THREADS, 2) void resblock_split_kernel(const Bloc
 
 extern "C" {
 
-static unsigned long long* g_block_stamps = nullptr;
-static int g_block_dbg = 0;
+[[maybe_unused]] static unsigned long long* g_block_stamps = nullptr;
+[[maybe_unused]] static int g_block_dbg = 0;
+#ifdef ISR_DIAG
 void isrDebugSetBlockStampBuffer(unsigned long long* buf) { g_block_stamps = buf; }   // not part of the public header
 void isrDebugSetBlockAblation(int bits) { g_block_dbg = bits; }
 int isrDebugBlockState(void) { return (g_block_stamps ? 1 : 0) | (g_block_dbg ? 2 : 0); }
+#endif
 
 static int block_slots()
 {
@@ -341,7 +344,7 @@ int isrResBlockSplit(const float* x, const void* wq1, const float* bias1, const 
     p.scratch = (u32x4*)workspace;
     p.H = H; p.W = W; p.xPlane = (int)xPlane; p.yPlane = (int)yPlane;
     p.tilesX = (W + ST_W - 1) / ST_W; p.tilesY = (H + ST_H - 1) / ST_H;
-    p.stamps = g_block_stamps; p.dbg = g_block_dbg;
+    ISR_DIAG_SET(p.stamps, g_block_stamps); ISR_DIAG_SET(p.dbg, g_block_dbg);
     p.absmax = rangeFlag;
     const int slots = block_slots();
     const long long ntiles = (long long)p.tilesX * p.tilesY;

@@ -22,6 +22,7 @@
 // COUNTED wait (the nine requests just issued may stay in flight).  x patch + three buffers + biases = 163 328 of the 163 840 bytes
 // of LDS.  The z image overwrites the x patch.
 #pragma once
+#include "sr_diag.h"
 #include "sr_split_common.h"
 
 namespace {
@@ -56,8 +57,8 @@ struct Block2Params {
     unsigned* zmax; unsigned* ymax;  // [4 x workgroups] bit patterns of max |z| / max |y| per WAVE (plain stores, may be NULL): the
                                      // weight-gradient kernels scale their gz operand by the maximum (isrConv3x3WeightGradSegmentsSplitMax).
                                      // (One word and atomics: 1024 waves on one address per launch cost 4.5 us per word.)
-    int dbg;                         // diagnostics: 1 skip the MFMAs, 4 skip the stores, 8 stage 1 on operands read once per k-step, 16 no weight DMA, 32 stage 1 eight times
-    unsigned long long* stamps;      // diagnostics: [workgroup][8] s_memrealtime ticks (100 MHz): entry | x patch parked | stage 1 done |
+    ISR_DIAG_MEMBER(int, dbg, 0);                         // diagnostics: 1 skip the MFMAs, 4 skip the stores, 8 stage 1 on operands read once per k-step, 16 no weight DMA, 32 stage 1 eight times
+    ISR_DIAG_MEMBER(unsigned long long*, stamps, nullptr);      // diagnostics: [workgroup][8] s_memrealtime ticks (100 MHz): entry | x patch parked | stage 1 done |
                                      // z image written | stage 2 done | stores issued | stores drained
 };
 

@@ -18,6 +18,7 @@
 //     pass through LDS one 16-channel k-step at a time, double buffered, fetched under the previous k-step's MFMAs
 //     (read straight from L2 per MFMA they cost ~1000 cycles each: the loop ran at a quarter of its MFMA time);
 //   * two workgroups per CU (80 KB of LDS each) overlap one's staging with the other's MFMAs.
+#include "sr_diag.h"
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <type_traits>
@@ -55,8 +56,8 @@ struct F16ConvParams {
     int act; float slope;
     int Hin, Win;                 // input size: (H, W), or (H / 2, W / 2) for the upsampling variant
     int quads;                    // 1: W, the plane stride of x and its base address allow aligned dwordx4 staging
-    int dbg;                      // diagnostics: 1 skip the MFMAs, 2 skip the staging loads, 4 skip the stores
-    unsigned long long* stamps;   // diagnostics (tools/bench_conv_f16.py): per-workgroup s_memtime stamps, or NULL
+    ISR_DIAG_MEMBER(int, dbg, 0);                      // diagnostics: 1 skip the MFMAs, 2 skip the staging loads, 4 skip the stores
+    ISR_DIAG_MEMBER(unsigned long long*, stamps, nullptr);   // diagnostics (tools/bench_conv_f16.py): per-workgroup s_memtime stamps, or NULL
 };
 
 // round to fp16, saturating (activations of this network are O(1) -- depth, normals, ReLU features of unit-gain
@@ -416,13 +417,15 @@ __global__ void prepare_weights_f16_kernel(const float* __restrict__ w, u32x4* _
 
 } // namespace
 
-static unsigned long long* g_f16_stamps = nullptr;
-static int g_f16_dbg = 0;
+[[maybe_unused]] static unsigned long long* g_f16_stamps = nullptr;
+[[maybe_unused]] static int g_f16_dbg = 0;
 
 extern "C" {
 
+#ifdef ISR_DIAG
 void isrDebugSetF16StampBuffer(unsigned long long* buf) { g_f16_stamps = buf; }   // not part of the public header
 void isrDebugSetF16Ablation(int bits) { g_f16_dbg = bits; }
+#endif
 
 long long isrConvF16WeightBytes(int Cin, int Cout)
 {
@@ -467,8 +470,8 @@ static int forward_lp(const float* x, const void* wq, const float* bias, const f
     p.cgroups = (Cout + 63) / 64;
     p.tilesX = (W + BT_W - 1) / BT_W; p.tilesY = (H + BT_H - 1) / BT_H;
     p.act = act; p.slope = slope;
-    p.stamps = g_f16_stamps;
-    p.dbg = g_f16_dbg;
+    ISR_DIAG_SET(p.stamps, g_f16_stamps);
+    ISR_DIAG_SET(p.dbg, g_f16_dbg);
     p.quads = ((W & 3) == 0 && aligned) ? 1 : 0;
     const long long nwg = (long long)N * p.tilesX * p.tilesY * p.cgroups;
     if (nwg > 0x7fffffffLL) return -1;

@@ -27,6 +27,7 @@
 // shift = +16 bytes); the weights [hi|lo][tap][lane half][cout][8 x fp16] of one 16-channel k-step pass through LDS,
 // fetched from L2 into registers under the previous k-step's MFMAs; 80 KB of LDS -> two workgroups per CU, one's
 // staging and barriers under the other's MFMAs.  Per tap and k-step: 8 ds_read_b128 feed 12 MFMAs.
+#include "sr_diag.h"
 #include <cstdlib>
 #include <cstring>
 
@@ -1114,12 +1115,30 @@ __global__ __launch_bounds__(256) void prepare_weights_split_many_kernel(const P
 
 } // namespace
 
+namespace {
+
+// fp32 [C][H][W] (planes xPlane floats apart) -> packed-split [2][C / 8][psPlane] (hi, lo' units): what a producer's packed epilogue writes
+__global__ __launch_bounds__(256) void pack_split_kernel(const float* __restrict__ x, u32x4* __restrict__ ps, int groups, int npix, long long xPlane, int psPlane)
+{
+    const int pix = blockIdx.x * 256 + threadIdx.x, g = blockIdx.y;
+    if (pix >= npix) return;
+    f16x8 qh, ql;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { _Float16 a, b; split16x(x[(size_t)(8 * g + e) * xPlane + pix], a, b); qh[e] = a; ql[e] = b; }
+    ps[(size_t)g * psPlane + pix] = __builtin_bit_cast(u32x4, qh);
+    ps[(size_t)(groups + g) * psPlane + pix] = __builtin_bit_cast(u32x4, ql);
+}
+
+} // namespace
+
 #include "sr_conv_ups3.h"       // the three-workgroups-per-CU upsampling kernel: same translation unit, same parameter block
+#ifdef ISR_DIAG                 // forms of the upsampling layer that were built, parity-tested and measured slower (profiles/r0N_ups*.md): diagnostics build only
 #include "sr_conv_ups4r.h"      // the four-rows-per-wave upsampling kernel (16 x 32 tiles, two workgroups per CU, prefetched fragments)
 #include "sr_conv_upsw.h"       // the one-stream upsampling kernel (persistent workgroup per CU, staging sliced into the MFMA gaps)
 #include "sr_conv_ups4.h"       // the role-split upsampling kernel (producer / consumer waves)
 #include "sr_conv_ups5.h"       // the software-pipelined upsampling kernel (staging of k-step g + 1 between the MFMAs of k-step g)
 #include "sr_conv_upsp.h"       // the phase-decomposed upsampling kernel (no interpolation at run time; packed-split in and out)
+#endif
 #include "sr_conv_block2.h"     // two chained convolutions of a batch of small images in one launch (training trunk)
 
 __device__ u32x4 g_split_zero_unit[4];      // zero initialised: source of the zero-padding units of the LDS-DMA staging
@@ -1129,13 +1148,13 @@ static int g_max_slot_cap = 0, g_max_slot_used = 0;
 unsigned* isr_take_range_flag() { unsigned* f = g_range_flag; g_range_flag = nullptr; return f; }
 static bool g_ps_in = false;       // set around the launch by isrConv3x3ForwardSplitFromPacked
 static bool g_ps_out = false;      // set around the launch by isrConv3x3ForwardSplitPacked (the library is single threaded by contract)
-static unsigned long long* g_split_stamps = nullptr;
-static int g_split_dbg = 0;
+[[maybe_unused]] static unsigned long long* g_split_stamps = nullptr;
+[[maybe_unused]] static int g_split_dbg = 0;
 static int g_split_small = 1;     // 2-row-tile kernel for small images (isrDebugSetSplitSmall)
 static int g_split_slots = 0;     // tests: cap on the persistent kernels' grid (0 = two / one workgroup per CU)
 // upsampling layers: 3 = sr_conv_ups3.h (three workgroups per CU; default), 0 = the tile kernel (two); ISR_UPS_FORM overrides
-static int g_split_ups_form = getenv("ISR_UPS_FORM") ? atoi(getenv("ISR_UPS_FORM")) : 3;
-static int g_split_algo = getenv("ISR_SPLIT_ALGO") ? atoi(getenv("ISR_SPLIT_ALGO")) : 1;      // (ISR_SPLIT_ALGO overrides) plain layers: 1 persistent streaming kernel (default), 2 wide 512-thread kernel, 0 one workgroup per tile
+static int g_split_ups_form = isr_diag_env_int("ISR_UPS_FORM", 3);
+static int g_split_algo = isr_diag_env_int("ISR_SPLIT_ALGO", 1);      // (ISR_SPLIT_ALGO overrides) plain layers: 1 persistent streaming kernel (default), 2 wide 512-thread kernel, 0 one workgroup per tile
 
 extern "C" {
 
@@ -1145,6 +1164,7 @@ int isrTakeMaxSlotWords(void) { const int n = g_max_slot_used; g_max_slot_used =
 // bit mask of the process-global diagnostic switches of this translation unit that are NOT in their default position
 // (bench.py refuses to report a number measured with any of them set): 1 ablation, 2 kernel form, 4 grid cap, 8 small-image
 // form off, 16 stamp buffer
+#ifdef ISR_DIAG
 int isrDebugSplitState(void)
 {
     return (g_split_dbg ? 1 : 0) | (g_split_algo != 1 ? 2 : 0) | (g_split_slots ? 4 : 0) | (g_split_small != 1 ? 8 : 0) | (g_split_stamps ? 16 : 0) | (g_split_ups_form != 3 ? 2 : 0);
@@ -1156,6 +1176,7 @@ void isrDebugSetSplitUpsForm(int f) { g_split_ups_form = f; }       // not part 
 int isrDebugSplitUpsForm(void) { return g_split_ups_form; }
 void isrDebugSetSplitSlots(int n) { g_split_slots = n; }
 void isrDebugSetSplitSmall(int on) { g_split_small = on; }
+#endif
 
 long long isrConvSplitWeightBytes(int Cin, int Cout)
 {
@@ -1201,8 +1222,8 @@ int isrConv3x3ForwardSplit(const float* x, const void* wq, const float* bias, co
     p.cgroups = (Cout + 63) / 64;
     p.tilesX = (W + ST_W - 1) / ST_W; p.tilesY = (H + ST_H - 1) / ST_H;
     p.act = act; p.slope = slope;
-    p.stamps = g_split_stamps;
-    p.dbg = g_split_dbg;
+    ISR_DIAG_SET(p.stamps, g_split_stamps);
+    ISR_DIAG_SET(p.dbg, g_split_dbg);
     p.quads = ((W & 3) == 0 && aligned) ? 1 : 0;
     p.ps = nullptr; p.psPlane = 0;
     p.xps = nullptr; p.xpsPlane = 0; p.zero = nullptr;
@@ -1294,6 +1315,7 @@ int isrConv3x3ForwardSplit(const float* x, const void* wq, const float* bias, co
         return hipGetLastError() == hipSuccess ? 0 : -2;
     }
     // algorithmic flops of the convolution (2 * 9 * Cin * Cout per output pixel), not the 3x matrix flops spent on it
+#ifdef ISR_DIAG
     if (upsample2x && g_split_ups_form == 4 && isr_split_ups4_takes(p)) {
         isr_profile_record(ISR_VARIANT_SPLIT_UPS4, 2.0 * 9 * Cin * Cout * (double)N * H * W, &e0, &e1);
         return isr_launch_split_ups4(p, s, e0, e1);
@@ -1303,8 +1325,10 @@ int isrConv3x3ForwardSplit(const float* x, const void* wq, const float* bias, co
         isr_profile_record(ISR_VARIANT_SPLIT_UPS3, 2.0 * 9 * Cin * Cout * (double)N * H * W, &e0, &e1);
         return isr_launch_split_ups5(p, (unsigned)nwg, s, e0, e1);
     }
+#endif
     const bool ups3 = upsample2x && (g_split_ups_form == 3 || g_split_ups_form == 4 || g_split_ups_form == 7 || g_split_ups_form == 8) && Cin > 0 && !(Cin & 15) && p.coutPad == 64 && Cout == 64 && p.cgroups == 1 && !p.xps;
     isr_profile_record(ups3 ? ISR_VARIANT_SPLIT_UPS3 : upsample2x ? ISR_VARIANT_SPLIT_UPS : ISR_VARIANT_SPLIT, 2.0 * 9 * Cin * Cout * (double)N * H * W, &e0, &e1);
+#ifdef ISR_DIAG
     if (ups3 && g_split_ups_form == 8) {
         const int rc = isr_launch_split_upsw(p, s, e0, e1);
         if (rc != -1) return rc;
@@ -1313,6 +1337,7 @@ int isrConv3x3ForwardSplit(const float* x, const void* wq, const float* bias, co
         const int rc = isr_launch_split_ups4r(p, s, e0, e1);
         if (rc != -1) return rc;
     }
+#endif
     if (ups3) {
         const int rc = isr_launch_split_ups3(p, (unsigned)nwg, s, e0, e1);
         if (rc != -1) return rc;
@@ -1354,7 +1379,15 @@ int isrConv3x3ForwardSplitFromPacked(const void* xps, const void* wq, const floa
     return rc;
 }
 
-// ---- phase-decomposed upsampling convolution (sr_conv_upsp.h) -------------------------------------------------------------------
+// ---- phase-decomposed upsampling convolution (sr_conv_upsp.h): an experiment of round 5 (parity-green, slower than the default: profiles/r05_upsp_ablation.md).
+// The entry points stay in the ABI; in the product build the layer is "not supported" and callers take the default kernels.
+#ifndef ISR_DIAG
+long long isrConvUpsPhaseWeightBytes(void) { return isrConvSplitWeightBytes(64, 256); }
+long long isrConvUpsPhaseScratchBytes(void) { return 4LL * 64 * 64 * 9 * (long long)sizeof(float); }
+int isrConvUpsPhasePrepare(const float*, void*, void*, void*) { return -3; }
+int isrConvUpsPhaseSupported(int, int, int, int, long long, long long) { return 0; }
+int isrConvUpsPhase(const void*, const void*, const float*, const float*, void*, int, int, int, float, long long, long long, void*) { (void)isr_take_range_flag(); return -3; }
+#else
 long long isrConvUpsPhaseWeightBytes(void) { return isrConvSplitWeightBytes(64, 256); }
 long long isrConvUpsPhaseScratchBytes(void) { return 4LL * 64 * 64 * 9 * (long long)sizeof(float); }
 
@@ -1386,13 +1419,13 @@ int isrConvUpsPhase(const void* xps, const void* wq, const float* w, const float
     p.ksteps = 4; p.coutPad = 256; p.cgroups = 1;
     p.tilesX = (wd + ST_W - 1) / ST_W; p.tilesY = (h + ST_H - 1) / ST_H;
     p.act = act; p.slope = slope;
-    p.dbg = g_split_dbg; p.stamps = g_split_stamps;
+    ISR_DIAG_SET(p.dbg, g_split_dbg); ISR_DIAG_SET(p.stamps, g_split_stamps);
     p.xps = (const u32x4*)xps; p.xpsPlane = (int)xpsPlane;
     p.ps = (u32x4*)ps; p.psPlane = (int)psPlane;
     p.absmax = rangeFlag;
     hipStream_t s = (hipStream_t)stream;
     static bool attr = false;
-    static int ldsExtra = getenv("ISR_UPSP_LDS_EXTRA") ? atoi(getenv("ISR_UPSP_LDS_EXTRA")) : 0;      // experiment: pad the allocation (one workgroup per CU)
+    static int ldsExtra = isr_diag_env_int("ISR_UPSP_LDS_EXTRA", 0);      // experiment: pad the allocation (one workgroup per CU)
     const int ldsBytes = UP_LDS_BYTES + ldsExtra;
     if (!attr) { (void)hipFuncSetAttribute((const void*)conv3x3_split_upsp_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, ldsBytes); attr = true; }
     // the one-pixel frame first (a few dozen waves), then the body: neither reads what the other writes
@@ -1403,7 +1436,7 @@ int isrConvUpsPhase(const void* xps, const void* wq, const float* w, const float
     ISR_LAUNCH_PROFILED(ISR_VARIANT_UPS_FRAME, ups_frame_kernel, dim3((unsigned)((nf + 63) / 64), 8), dim3(64), 0, s, fp);
     hipEvent_t e0 = nullptr, e1 = nullptr;
     isr_profile_record(ISR_VARIANT_SPLIT_UPSP, 2.0 * 9 * 64 * 64 * (double)p.H * p.W, &e0, &e1);
-    static int form = getenv("ISR_UPSP_FORM") ? atoi(getenv("ISR_UPSP_FORM")) : 0;      // 0: the LDS-DMA form (default), 1: form Q (4 rows per wave, activations from L1; measured slower)
+    static int form = isr_diag_env_int("ISR_UPSP_FORM", 0);      // 0: the LDS-DMA form (default), 1: form Q (4 rows per wave, activations from L1; measured slower)
     const dim3 block(S_THREADS);
     if (form == 1) {
         p.tilesY = (h + UQ_TILE_H - 1) / UQ_TILE_H;
@@ -1418,6 +1451,8 @@ int isrConvUpsPhase(const void* xps, const void* wq, const float* w, const float
     else hipLaunchKernelGGL(conv3x3_split_upsp_kernel, grid, block, ldsBytes, s, p);
     return hipGetLastError() == hipSuccess ? 0 : -2;
 }
+
+#endif
 
 int isrPackSplit(const float* x, void* ps, int C, int H, int W, long long xPlane, long long psPlane, void* stream)
 {
@@ -1474,7 +1509,7 @@ int isrResBlockSmall(const float* x, const void* wa, const float* ba, const floa
     p.N = N; p.H = H; p.W = W; p.tilesY = (H + R2_H - 1) / R2_H;
     p.absmax = rangeFlag;
     p.zmax = (unsigned*)zmax; p.ymax = (unsigned*)ymax;
-    p.dbg = g_split_dbg; p.stamps = g_split_stamps;
+    ISR_DIAG_SET(p.dbg, g_split_dbg); ISR_DIAG_SET(p.stamps, g_split_stamps);
     static bool attr = false;
     if (!attr) { (void)hipFuncSetAttribute((const void*)conv3x3_split_block2_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, B2_LDS_BYTES); attr = true; }
     hipEvent_t e0 = nullptr, e1 = nullptr;

@@ -15,6 +15,7 @@
 //
 // Against the three-kernel tail (conv3x3_split_stream_kernel, conv3x3_small_cout_kernel with its fused finish): the
 // fp32 4x4x1-MFMA kernel (0.20 ms, 72 TFLOP/s) and its 606 MB read are gone, the 531 MB write of y6 becomes 448 MB of z.
+#include "sr_diag.h"
 #include <cstdlib>
 #include "sr_split_common.h"
 
@@ -596,10 +597,12 @@ long long isrConvTailWeightBytes(void) { return 16 + (long long)TZ_UNITS * 16; }
 // tail_seam_finish_kernel -- bit-identical output, 0.9 GB less traffic per 1080p frame, and SLOWER: the convolution kernel
 // runs two 256-register waves per SIMD at the board's power limit, and 54 LDS reads + the finishing code's scattered loads,
 // divisions and nine stores per pixel inside it cost 0.25 ms where the streaming kernel needs 0.10 (0.75 vs 0.51 + 0.10 ms)
-static int g_tail_fused = getenv("ISR_TAIL_FORM") ? atoi(getenv("ISR_TAIL_FORM")) : 2;     // (ISR_TAIL_FORM: A/B runs) 2: the S form (default); 0: 54 planes; 1: combined in LDS; 3: timing experiment (a third of form 0's planes, wrong output)
+static int g_tail_fused = isr_diag_env_int("ISR_TAIL_FORM", 2);     // (ISR_TAIL_FORM: A/B runs) 2: the S form (default); 0: 54 planes; 1: combined in LDS; 3: timing experiment (a third of form 0's planes, wrong output)
 __device__ u32x4 g_tail_zero_unit[4];       // zero initialised: the source of out-of-image units of the LDS-DMA staging
+#ifdef ISR_DIAG
 void isrDebugSetTailFused(int on) { g_tail_fused = on; }      // not part of the public header
 int isrDebugTailState(void) { return g_tail_fused != 2 ? 1 : 0; }
+#endif
 
 static long long tail_row_floats(int H, int W) { return 2LL * ((H + ST_H - 1) / ST_H) * W * TZ_ROWS; }
 static long long tail_col_floats(int H, int W) { return (long long)H * 2 * ((W + ST_W - 1) / ST_W) * TZ_ROWS; }
@@ -671,7 +674,7 @@ static int tail_launch(const void* xin, int packed, const void* wq6, const float
     p.ksteps = 4; p.coutPad = 64; p.cgroups = 1;
     p.tilesX = (W + ST_W - 1) / ST_W; p.tilesY = (H + ST_H - 1) / ST_H;
     p.act = ISR_ACT_RELU; p.slope = 0.0f;
-    p.stamps = nullptr; p.dbg = (g_tail_fused == 3 ? 64 : 0) | (getenv("ISR_TAIL_ROWMAJOR") ? 128 : 0); p.quads = 1;
+    ISR_DIAG_SET(p.stamps, nullptr); ISR_DIAG_SET(p.dbg, (g_tail_fused == 3 ? 64 : 0) | (isr_diag_env_int("ISR_TAIL_ROWMAJOR", 0) ? 128 : 0)); p.quads = 1;
     tp.wz = (const u32x4*)wz;
     tp.z = (float*)workspace;
     tp.zPlane = H * W + W;

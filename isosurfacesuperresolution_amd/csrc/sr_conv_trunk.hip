@@ -44,6 +44,7 @@
 // Measured (tools/bench_trunk.py, tools/trunk_timeline.py; 480 x 270, 21 layers): 0.58-0.65 ms against 0.84 for the first form and
 // 0.83-1.15 for 21 launches.  Per layer ~29 us: MFMA phase 22 (the 108 x 4 MFMAs of a wave take 17 at the 1.6 GHz the chip holds
 // under this load -- 11 with operands read once, i.e. at full clock), epilogue 2.2, drain 1.4, wait 2.5, halo fetch 1.8.
+#include "sr_diag.h"
 #include <cstdlib>
 #include <cstring>
 
@@ -75,12 +76,12 @@ struct Trunk16Params {
     unsigned* error;                 // 1 + the layer at which a wait timed out (0: none)
     unsigned* absmax;                // range guard over every value stored (may be NULL)
     int H, W, plane, tilesX, tilesY, layers;
-    int dbg;                         // diagnostics (isrDebugSetTrunkAblation): 1 no MFMAs, 2 no activation DMA, 4 no stores, 8 no waits, 16 no weight DMA,
+    ISR_DIAG_MEMBER(int, dbg, 0);                         // diagnostics (isrDebugSetTrunkAblation): 1 no MFMAs, 2 no activation DMA, 4 no stores, 8 no waits, 16 no weight DMA,
                                      // 32 the MFMAs on operands read once per k-step, 64 (with 32) ... but every tap's fragments read from LDS all the same
-    int faultTile;                   // diagnostics (isrDebugSetTrunkFault): the tile that never publishes, or -1
+    ISR_DIAG_MEMBER(int, faultTile, -1);                   // diagnostics (isrDebugSetTrunkFault): the tile that never publishes, or -1
     int lastPacked;                  // isrSetTrunkPackedResult: the last layer ALSO writes its result packed-split (for sr_conv_upsp.h)
     unsigned long long timeoutTicks; // of the chip's 100 MHz clock
-    unsigned long long* stamps;      // diagnostics: [tile][layer][8] = ticks at: layer start | neighbours there | first k-step staged | MFMAs done | epilogue done | stores drained
+    ISR_DIAG_MEMBER(unsigned long long*, stamps, nullptr);      // diagnostics: [tile][layer][8] = ticks at: layer start | neighbours there | first k-step staged | MFMAs done | epilogue done | stores drained
 };
 
 // a wave-uniform pointer, held in scalar registers
@@ -92,10 +93,10 @@ __device__ __forceinline__ T* trunk16_uniform(T* q)
     return (T*)(((unsigned long long)hi << 32) | lo);
 }
 
-int g_trunk_dbg = 0;
-unsigned long long* g_trunk_stamps = nullptr;
+[[maybe_unused]] int g_trunk_dbg = 0;
+[[maybe_unused]] unsigned long long* g_trunk_stamps = nullptr;
 unsigned* g_trunk_error_word = nullptr;          // isrSetTrunkErrorWord: where launches report a timed-out wait (NULL: the workspace's own word)
-int g_trunk_fault_tile = -1;                     // isrDebugSetTrunkFault: this tile never publishes its progress (tests of the timeout path)
+[[maybe_unused]] int g_trunk_fault_tile = -1;                     // isrDebugSetTrunkFault: this tile never publishes its progress (tests of the timeout path)
 unsigned long long g_trunk_timeout_ticks = 5000000ull;     // 50 ms of the chip's 100 MHz clock: a frame is 2 ms
 
 typedef __attribute__((address_space(3))) char t16_lds_char;
@@ -873,6 +874,7 @@ extern "C" {
 /* Diagnostics only (tools/bench_trunk.py): bit 0 skip the MFMAs, 1 skip the activation DMA, 2 skip the stores, 3 skip the waits on
  * the neighbours, 4 skip the weight DMA, 5 the MFMAs on operands read once per k-step (no LDS traffic).  Results are wrong with any bit set; bench.py refuses to report with a non-zero
  * isrDebugTrunkState(). */
+#ifdef ISR_DIAG
 void isrDebugSetTrunkAblation(int mask) { g_trunk_dbg = mask & 127; }
 /* [tiles][layers][8] unsigned long long of ZEROED device memory (or NULL): per tile and layer the tick (100 MHz, one clock for the
  * chip) at the layer's start | the neighbours' arrival | the first k-step staged | the MFMAs done | the epilogue done | the stores
@@ -887,21 +889,24 @@ void isrDebugSetTrunkFault(int tile, unsigned long long timeoutTicks)
     g_trunk_fault_tile = tile;
     g_trunk_timeout_ticks = timeoutTicks ? timeoutTicks : 5000000ull;
 }
+#endif
 /* Where every later isrTrunkDataflow launch reports a timed-out wait (atomic maximum of 1 + layer; sticky until the caller clears
  * it): a device word the caller mirrors to the host once per frame (ops.guards_publish), or NULL for the workspace's own word. */
 void isrSetTrunkErrorWord(unsigned* word) { g_trunk_error_word = word; }
 
 // ISR_TRUNK_MT: 1 (default) images of more tiles than CUs take trunk_mt_kernel; 0 they are refused (per-layer kernels); 2 every image
 // takes it (A/B against the one-tile form)
-static int g_trunk_mt = getenv("ISR_TRUNK_MT") ? atoi(getenv("ISR_TRUNK_MT")) : 1;
+static int g_trunk_mt = isr_diag_env_int("ISR_TRUNK_MT", 1);
 // ISR_TRUNK_ROWS: image rows per wave of the one-tile form -- 2 (eight waves per workgroup) or 4 (four waves, one per SIMD)
 static int g_trunk_rows = (getenv("ISR_TRUNK_ROWS") && atoi(getenv("ISR_TRUNK_ROWS")) == 4) ? 4 : 2;
 void isrSetTrunkRows(int rows) { g_trunk_rows = rows == 4 ? 4 : 2; }
+#ifdef ISR_DIAG
 void isrDebugSetTrunkMultiTile(int mode) { g_trunk_mt = mode; }
 int isrDebugTrunkState(void)
 {
     return g_trunk_dbg | ((g_trunk_fault_tile >= 0 || g_trunk_timeout_ticks != 5000000ull) ? 128 : 0) | (g_trunk_stamps ? 256 : 0) | (g_trunk_mt != 1 ? 512 : 0);
 }
+#endif
 
 int isrTrunkDataflowMaxTiles(void)
 {
@@ -994,9 +999,9 @@ static int trunk_dataflow_launch(const float* x, bool prepacked, int cin0, long 
     const int ntiles = p.tilesX * p.tilesY;
     p.ws = ws; p.done = (unsigned*)(ws + 16); p.error = g_trunk_error_word ? g_trunk_error_word : p.done + ntiles;
     p.absmax = rangeFlag;
-    p.dbg = g_trunk_dbg; p.stamps = g_trunk_stamps;
+    ISR_DIAG_SET(p.dbg, g_trunk_dbg); ISR_DIAG_SET(p.stamps, g_trunk_stamps);
     p.timeoutTicks = g_trunk_timeout_ticks;                                  // 50 ms unless a test shortened it: a frame is 2 ms
-    p.faultTile = g_trunk_fault_tile;
+    ISR_DIAG_SET(p.faultTile, g_trunk_fault_tile);
     p.lastPacked = g_trunk_last_packed;
     hipStream_t s = (hipStream_t)stream;
     // the progress counters start at zero every launch; the error word behind them is STICKY (the caller zero-fills the workspace

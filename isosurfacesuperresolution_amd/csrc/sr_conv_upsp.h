@@ -543,16 +543,4 @@ __global__ __launch_bounds__(256) void ups_phase_weights_kernel(const float* __r
         }
 }
 
-// fp32 [C][H][W] (planes xPlane floats apart) -> packed-split [2][C / 8][psPlane] (hi, lo' units): what a producer's packed epilogue writes
-__global__ __launch_bounds__(256) void pack_split_kernel(const float* __restrict__ x, u32x4* __restrict__ ps, int groups, int npix, long long xPlane, int psPlane)
-{
-    const int pix = blockIdx.x * 256 + threadIdx.x, g = blockIdx.y;
-    if (pix >= npix) return;
-    f16x8 qh, ql;
-#pragma unroll
-    for (int e = 0; e < 8; ++e) { _Float16 a, b; split16x(x[(size_t)(8 * g + e) * xPlane + pix], a, b); qh[e] = a; ql[e] = b; }
-    ps[(size_t)g * psPlane + pix] = __builtin_bit_cast(u32x4, qh);
-    ps[(size_t)(groups + g) * psPlane + pix] = __builtin_bit_cast(u32x4, ql);
-}
-
 } // namespace

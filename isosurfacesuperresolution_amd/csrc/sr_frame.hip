@@ -11,6 +11,7 @@
 //                      (utils/shading.py:148-191).
 //
 // Both are HBM-streaming kernels (each ~100-125 MB of traffic at 1080p).
+#include "sr_diag.h"
 #include <hip/hip_runtime.h>
 #include <hip/hip_ext.h>
 #include <stdint.h>
@@ -338,7 +339,7 @@ struct FillOneParams {
     unsigned* error;                              // set to 1 by a launch that gave up waiting
     int h, w, tilesX, tilesY;
     unsigned long long timeoutTicks;
-    int fault;                                    // diagnostics (isrDebugSetFlowFillFault): the last workgroup never raises the flag
+    ISR_DIAG_MEMBER(int, fault, 0);                                    // diagnostics (isrDebugSetFlowFillFault): the last workgroup never raises the flag
 };
 
 __device__ __forceinline__ void st_agent(float* q, float v) { __hip_atomic_store(q, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
@@ -666,10 +667,12 @@ void isrSetFlowFillErrorWord(unsigned* word) { g_fill_error_word = word; }
  * into the deadline, `timeoutTicks` of the 100 MHz clock (0: the default 50 ms).  (With the fault the ticket is still put back to zero, so the
  * next launch on the same workspace works; after a REAL timeout -- a workgroup that never arrived -- the ticket is out of step and the caller
  * zero-fills the workspace: ops._fill_failed.) */
-static int g_fill_fault = 0;
+[[maybe_unused]] static int g_fill_fault = 0;
 static unsigned long long g_fill_timeout_ticks = 5000000ull;
+#ifdef ISR_DIAG
 void isrDebugSetFlowFillFault(int on, unsigned long long timeoutTicks) { g_fill_fault = on ? 1 : 0; g_fill_timeout_ticks = timeoutTicks ? timeoutTicks : 5000000ull; }
 int isrDebugFlowFillState(void) { return (g_fill_fault || g_fill_timeout_ticks != 5000000ull) ? 1 : 0; }
+#endif
 
 int isrFlowFillOneSupported(int h, int w)
 {
@@ -690,7 +693,7 @@ int isrFlowFillOne(const float* gbuffer_hwc12, float* flow_out, void* workspace,
     p.sync = reinterpret_cast<unsigned*>(p.top + 2 * F1_TOP_MAX);
     p.error = g_fill_error_word ? g_fill_error_word : p.sync + 2;
     p.timeoutTicks = g_fill_timeout_ticks;        // 50 ms of the 100 MHz clock unless a test shortened it
-    p.fault = g_fill_fault;
+    ISR_DIAG_SET(p.fault, g_fill_fault);
     ISR_LAUNCH_PROFILED(ISR_VARIANT_FLOW_FILL, flow_fill_one_kernel, dim3(p.tilesX * p.tilesY), dim3(F1_THREADS), 0, (hipStream_t)stream, p);
     return hipGetLastError() == hipSuccess ? 0 : -2;
 }

@@ -2,6 +2,7 @@
 // (hi, lo) split, the parameter block, one k-step of MFMAs and the common epilogue.  Every function is inline / static: each
 // translation unit gets its own copy, nothing is called across translation units (no relocatable device code).
 #pragma once
+#include "sr_diag.h"
 #include <hip/hip_runtime.h>
 #include <hip/hip_ext.h>
 #include <stdint.h>
@@ -42,8 +43,8 @@ struct SplitConvParams {
     int act; float slope;
     int Hin, Win;                 // input size: (H, W), or (H / 2, W / 2) for the upsampling variant
     int quads;                    // 1: W, the plane stride of x and its base address allow aligned dwordx4 staging
-    int dbg;                      // diagnostics: 1 skip the MFMAs, 2 skip the staging loads, 4 skip the stores
-    unsigned long long* stamps;   // diagnostics: per-workgroup s_memrealtime stamps (100 MHz, one clock for the whole chip), or NULL
+    ISR_DIAG_MEMBER(int, dbg, 0);                      // diagnostics: 1 skip the MFMAs, 2 skip the staging loads, 4 skip the stores
+    ISR_DIAG_MEMBER(unsigned long long*, stamps, nullptr);   // diagnostics: per-workgroup s_memrealtime stamps (100 MHz, one clock for the whole chip), or NULL
     // PACKED-SPLIT output (ps != NULL; y unused): the activations as the NEXT split-operand layer's LDS image, i.e. already
     // split into (hi, lo') fp16 pairs, eight channels of one pixel per 16-byte unit: ps[part: hi | lo][Cout / 8 groups][psPlane
     // units, pixel y W + x].  The consumer stages k-steps with plain 16-byte copies (LDS-DMA); same values as converting the

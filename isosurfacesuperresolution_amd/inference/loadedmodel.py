@@ -100,6 +100,32 @@ from ..utils import initialImage
 from .flowfill import fill_flow
 
 
+def guarded_forward(model, net_in):
+    """``prediction, _ = model(net_in)`` with the guard contract of the HIP path around it -- what EVERY caller
+    that feeds frames to a network on the device goes through (``LoadedModel.inference``, ``stats.run_clip``):
+
+    * start of the frame: ``ops.guards_poll`` -- what the PREVIOUS frame's kernels reported (range maxima of the split-operand layers,
+      the error words of the dataflow trunk and the one-launch flow fill): a plain read of pinned memory, one frame late; raises if a
+      spin kernel timed out, re-routes the consumers of a layer that came close to the fp16 split's range;
+    * FIRST frame of a model (``ops.range_check_due``): the synchronous check -- a layer came close to the split operands' range: exact
+      routing from now on and this frame again (repeated: a fused launch only says THAT something inside it was hot, the per-layer
+      pass that replaces it says where);
+    * end of the frame: ``ops.guards_publish`` -- the words travel to pinned memory behind the frame's kernels.
+    The caller ends a SEQUENCE with ``ops.guards_flush`` (the last frame has no successor to poll for it).  CPU tensors: the plain call."""
+    if not net_in.is_cuda:
+        return model(net_in)[0]
+    from .. import ops
+    ops.guards_poll(net_in.device)
+    prediction, _ = model(net_in)
+    if ops.range_check_due(net_in.device):
+        for _ in range(4):
+            if not ops.refresh_range_flags(net_in.device):
+                break
+            prediction, _ = model(net_in)
+    ops.guards_publish(net_in.device)
+    return prediction
+
+
 class LoadedModel:
     def __init__(self, name, device, upscale_factor):
         self.name = os.path.splitext(os.path.basename(name))[0]
@@ -157,18 +183,5 @@ class LoadedModel:
                                                           self.upscale_factor, special_mask=True)
             flat = VideoTools.flatten_high(previous_warped, self.upscale_factor)
             net_in = torch.cat((inp, flat), dim=1)
-            if net_in.is_cuda:
-                from .. import ops
-                ops.guards_poll(net_in.device)       # what the previous frame's kernels reported (plain read of pinned memory, one frame late)
-            prediction, _ = self.model(net_in)
-            if net_in.is_cuda:
-                if ops.range_check_due(net_in.device):
-                    # FIRST frame of a model -- a layer came close to the split operands' fp16 range: exact routing from now on, this
-                    # frame again (repeated: a fused launch only says THAT something inside it was hot, the per-layer pass that
-                    # replaces it says where).  Later frames: guards_publish here, guards_poll at the next frame's start.
-                    for _ in range(4):
-                        if not ops.refresh_range_flags(net_in.device):
-                            break
-                        prediction, _ = self.model(net_in)
-                ops.guards_publish(net_in.device)
+            prediction = guarded_forward(self.model, net_in)
         return prediction

@@ -20,9 +20,11 @@ Since round 5 the warp is spelled out in elementwise operations (one IEEE roundi
 its ``grid_sample`` on FMA contraction), and the temporal recurrence multiplies the difference by the
 network's gain every frame.  With every operation, its order and its rounding fixed HERE, the HIP kernels
 (``csrc/sr_frame.hip: assemble_input_kernel``, ``csrc/sr_train.hip``) compute the SAME bits on the same
-inputs (``tests/test_conv_gpu.py::test_assembled_input_is_bit_identical_to_the_module_path``), and the
-CPU path stays within 1e-6 of the reference's own output on the reference-generated fixture
-(``tests/test_sr_golden_cpu.py``).  ``warp_upscale_library`` keeps the library-call form.
+inputs (``tests/test_conv_gpu.py::test_assembled_input_is_bit_identical_to_the_module_path``).  This default is a deliberate
+RE-ROUNDING of the reference's warp: against the reference-generated fixture (``tests/test_sr_golden_cpu.py``) it is within 2e-5
+(1e-5 with zero flow) -- the conditioning described above -- and no further from an fp64 evaluation than the reference's own fp32
+output is; ``warp_upscale_library`` keeps the library-call form and is the one that meets 1e-6 against the fixture.  Upscale factors
+whose reciprocal is not exact in binary (3, 5, 6, ...) take the library form: the explicit form's source indices assume ``1 / r`` exact.
 """
 import torch
 import torch.nn.functional as F
@@ -100,7 +102,10 @@ class VideoTools:
         assert C == 2
         r = int(upscale_factor)
         H, W = r * h, r * w
-        assert (1.0 / r) * r == 1.0 and tuple(image_high.shape[-2:]) == (H, W)
+        if tuple(image_high.shape[-2:]) != (H, W):
+            raise ValueError("warp_upscale: previous frame %s is not %d x the flow's %s" % (tuple(image_high.shape[-2:]), r, (H // r, W // r)))
+        if (1.0 / r) * r != 1.0:             # (the reference accepts any factor: the library form does too)
+            return VideoTools.warp_upscale_library(image_high, flow_low, upscale_factor, special_mask)
         dtype, device = flow_low.dtype, flow_low.device
         (y0, y1, ly), (x0, x1, lx), lin_y, lin_x = VideoTools._warp_plan(h, w, r, dtype, device)
         # flow (x, y) scaled by (-2, +2) (exact), resized bilinearly, added to the pixel grid

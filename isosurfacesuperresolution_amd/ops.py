@@ -34,120 +34,165 @@ def _warn_once(key, message):
         warnings.warn(message, RuntimeWarning, stacklevel=3)
 
 
+def _bind(lib):
+    """ctypes signatures of include/isr_sr_kernels.h on a loaded build of the library (product or diagnostics: the same ABI)."""
+    vp, ci, cf, ll = ctypes.c_void_p, ctypes.c_int, ctypes.c_float, ctypes.c_longlong
+    lib.isrConvCinPad.argtypes = [ci]; lib.isrConvCinPad.restype = ci
+    lib.isrConvCoutPad.argtypes = [ci]; lib.isrConvCoutPad.restype = ci
+    lib.isrConvPrepareWeights.argtypes = [vp, vp, ci, ci, ci, vp]; lib.isrConvPrepareWeights.restype = ci
+    lib.isrConv3x3Forward.argtypes = [vp, vp, vp, vp, vp, ci, ci, ci, ci, ci, ci, cf, ci, vp]
+    lib.isrConv3x3Forward.restype = ci
+    lib.isrConv3x3ForwardStrided.argtypes = [vp, vp, vp, vp, vp, ci, ci, ci, ci, ci, ci, cf, ci, ll, ll, ll, ll, ll, ll, vp]
+    lib.isrConv3x3ForwardStrided.restype = ci
+    lib.isrConvWeightGradWorkspace.argtypes = [ci, ci, ci, ci, ci]; lib.isrConvWeightGradWorkspace.restype = ll
+    lib.isrConv3x3WeightGrad.argtypes = [vp, vp, vp, vp, vp, ci, ci, ci, ci, ci, vp]; lib.isrConv3x3WeightGrad.restype = ci
+    lib.isrConvWeightGradMaxSegments.argtypes = []; lib.isrConvWeightGradMaxSegments.restype = ci
+    lib.isrConv3x3WeightGradSegments.argtypes = [vp, vp, ci, vp, vp, vp, ci, ci, ci, ci, ci, vp]
+    lib.isrConv3x3WeightGradSegments.restype = ci
+    lib.isrConv3x3WeightGradSegmentsBf16.argtypes = lib.isrConv3x3WeightGradSegments.argtypes
+    lib.isrConv3x3WeightGradSegmentsBf16.restype = ci
+    lib.isrConv3x3WeightGradSegmentsSplit.argtypes = lib.isrConv3x3WeightGradSegments.argtypes
+    lib.isrConv3x3WeightGradSegmentsSplit.restype = ci
+    lib.isrActBackward.argtypes = [vp, vp, vp, ll, ci, cf, vp]; lib.isrActBackward.restype = ci
+    lib.isrResBlockSmallSupported.argtypes = [ci, ci, ci]; lib.isrResBlockSmallSupported.restype = ci
+    lib.isrResBlockSmall.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, ci, ci, ci, vp, vp, vp]; lib.isrResBlockSmall.restype = ci
+    lib.isrConv3x3WeightGradSegmentsSplitMax.argtypes = [vp, vp, vp, ci, ci, vp, vp, vp, ci, ci, ci, ci, ci, vp]
+    lib.isrConv3x3WeightGradSegmentsSplitMax.restype = ci
+    lib.isrSetMaxSlots.argtypes = [vp, ci]; lib.isrSetMaxSlots.restype = None
+    lib.isrSetWeightGradAccumulate.argtypes = [ci]; lib.isrSetWeightGradAccumulate.restype = None
+    lib.isrTakeMaxSlotWords.argtypes = []; lib.isrTakeMaxSlotWords.restype = ci
+    lib.isrAssembleInput.argtypes = [vp, vp, vp, vp, ci, ci, ci, ci, vp]; lib.isrAssembleInput.restype = ci
+    lib.isrAssembleInputRows.argtypes = [vp, vp, vp, vp, ci, ci, ci, ci, ci, ci, vp]; lib.isrAssembleInputRows.restype = ci
+    lib.isrAssembleInputRect.argtypes = [vp, vp, vp, vp, ci, ci, ci, ci, ci, ci, ci, ci, vp]; lib.isrAssembleInputRect.restype = ci
+    lib.isrAssembleInputPacked.argtypes = [vp, vp, vp, vp, ci, ci, ci, ci, vp, vp]; lib.isrAssembleInputPacked.restype = ci
+    lib.isrConvSmallCinPad.argtypes = [ci]; lib.isrConvSmallCinPad.restype = ci
+    lib.isrConvSmallWeightFloats.argtypes = [ci]; lib.isrConvSmallWeightFloats.restype = ll
+    lib.isrConvSmallPrepare.argtypes = [vp, vp, vp, vp, ci, ci, vp]; lib.isrConvSmallPrepare.restype = ci
+    lib.isrConv3x3SmallCout.argtypes = [vp, vp, vp, vp, vp, ci, ci, ci, ci, ci, ci, cf, vp]; lib.isrConv3x3SmallCout.restype = ci
+    lib.isrConv3x3SmallCoutStrided.argtypes = [vp, vp, vp, vp, vp, ci, ci, ci, ci, ci, ci, cf, ll, ll, vp]
+    lib.isrConv3x3SmallCoutStrided.restype = ci
+    lib.isrFlowFillWorkspace.argtypes = [ci, ci]; lib.isrFlowFillWorkspace.restype = ll
+    lib.isrFlowFill.argtypes = [vp, vp, vp, ci, ci, vp]; lib.isrFlowFill.restype = ci
+    lib.isrFlowFillEx.argtypes = [vp, vp, vp, ci, ci, ci, vp]; lib.isrFlowFillEx.restype = ci
+    lib.isrFlowFillOne.argtypes = [vp, vp, vp, ci, ci, vp]; lib.isrFlowFillOne.restype = ci
+    lib.isrFlowFillOneSupported.argtypes = [ci, ci]; lib.isrFlowFillOneSupported.restype = ci
+    lib.isrSetFlowFillErrorWord.argtypes = [vp]; lib.isrSetFlowFillErrorWord.restype = None
+    lib.isrFinishFrame.argtypes = [vp, vp, vp, vp, ci, ci, vp, ci, cf, ci, ci, vp]; lib.isrFinishFrame.restype = ci
+    lib.isrConvSmallFinishFrame.argtypes = [vp, vp, vp, vp, vp, vp, ci, ci, ci, ll, vp, ci, cf, ci, ci, vp]
+    lib.isrConvSmallFinishFrame.restype = ci
+    lib.isrUpsample2xForward.argtypes = [vp, vp, ll, ci, ci, vp]; lib.isrUpsample2xForward.restype = ci
+    lib.isrUpsample2xBackward.argtypes = [vp, vp, ll, ci, ci, vp]; lib.isrUpsample2xBackward.restype = ci
+    lib.isrReconResidualForward.argtypes = [vp, vp, vp, ci, ci, ci, ci, ci, ci, vp]; lib.isrReconResidualForward.restype = ci
+    lib.isrReconResidualBackward.argtypes = [vp, vp, ci, ci, ci, ci, ci, ci, vp]; lib.isrReconResidualBackward.restype = ci
+    lib.isrLossUnshadedWorkspace.argtypes = []; lib.isrLossUnshadedWorkspace.restype = ll
+    lib.isrLossUnshadedForward.argtypes = [vp, vp, vp, ci, ci, ci, ci, vp, ctypes.c_uint, vp, cf, ci, vp, vp, vp]
+    lib.isrLossUnshadedForward.restype = ci
+    lib.isrLossUnshadedBackward.argtypes = [vp, vp, vp, ci, ci, ci, ci, vp, ctypes.c_uint, vp, cf, ci, vp, vp, vp, vp]
+    lib.isrLossUnshadedBackward.restype = ci
+    lib.isrRecurrentInputForward.argtypes = [vp, vp, vp, vp, vp, ci, ci, ci, ll, ll, vp]; lib.isrRecurrentInputForward.restype = ci
+    lib.isrRecurrentInputBackward.argtypes = [vp, vp, vp, vp, vp, vp, ci, ci, ci, ll, vp]; lib.isrRecurrentInputBackward.restype = ci
+    lib.isrConvF16WeightBytes.argtypes = [ci, ci]; lib.isrConvF16WeightBytes.restype = ll
+    lib.isrConvF16Prepare.argtypes = [vp, vp, ci, ci, vp]; lib.isrConvF16Prepare.restype = ci
+    lib.isrConv3x3ForwardF16.argtypes = [vp, vp, vp, vp, vp, ci, ci, ci, ci, ci, ci, cf, ci, ll, ll, ll, ll, ll, ll, vp]
+    lib.isrConvF16SupportsUpsample.argtypes = [ll, ci, ll, ll]; lib.isrConvF16SupportsUpsample.restype = ci
+    lib.isrConvBf16Prepare.argtypes = [vp, vp, ci, ci, vp]; lib.isrConvBf16Prepare.restype = ci
+    lib.isrConv3x3ForwardBf16.argtypes = lib.isrConv3x3ForwardF16.argtypes; lib.isrConv3x3ForwardBf16.restype = ci
+    lib.isrConv3x3ForwardF16.restype = ci
+    lib.isrConvSplitWeightBytes.argtypes = [ci, ci]; lib.isrConvSplitWeightBytes.restype = ll
+    lib.isrConvSplitPrepare.argtypes = [vp, vp, ci, ci, vp]; lib.isrConvSplitPrepare.restype = ci
+    lib.isrConvSplitPrepareManyMax.argtypes = []; lib.isrConvSplitPrepareManyMax.restype = ci
+    lib.isrConvSplitPrepareMany.argtypes = [ci, vp, vp, vp, vp, vp, vp]; lib.isrConvSplitPrepareMany.restype = ci
+    lib.isrConv3x3ForwardSplit.argtypes = lib.isrConv3x3ForwardF16.argtypes; lib.isrConv3x3ForwardSplit.restype = ci
+    lib.isrConvTailWeightBytes.argtypes = []; lib.isrConvTailWeightBytes.restype = ll
+    lib.isrConvTailWorkspaceBytes.argtypes = [ci, ci]; lib.isrConvTailWorkspaceBytes.restype = ll
+    lib.isrConvTailPrepare.argtypes = [vp, vp, vp]; lib.isrConvTailPrepare.restype = ci
+    lib.isrConvTailSupported.argtypes = [vp, ci, ci, ll]; lib.isrConvTailSupported.restype = ci
+    lib.isrConvTailFinishFrame.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, vp, ci, ci, ll, vp, ci, cf, ci, ci, vp]
+    lib.isrConvTailFinishFrame.restype = ci
+    lib.isrConv3x3ForwardSplitPacked.argtypes = [vp, vp, vp, vp, ci, ci, ci, ci, ci, cf, ci, ll, ll, vp]
+    lib.isrConv3x3ForwardSplitPacked.restype = ci
+    lib.isrConv3x3ForwardSplitFromPacked.argtypes = [vp, vp, vp, vp, vp, ci, ci, ci, ci, ci, ci, cf, ll, ll, ll, vp]
+    lib.isrConv3x3ForwardSplitFromPacked.restype = ci
+    lib.isrConvTailFinishFramePacked.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, vp, ci, ci, ll, vp, ci, cf, ci, ci, vp]
+    lib.isrConvTailFinishFramePacked.restype = ci
+    lib.isrTrunkDataflowMaxTiles.argtypes = []; lib.isrTrunkDataflowMaxTiles.restype = ci
+    lib.isrTrunkDataflowWorkspaceBytes.argtypes = [ci, ci, ci]; lib.isrTrunkDataflowWorkspaceBytes.restype = ll
+    lib.isrTrunkDataflowSupported.argtypes = [vp, ci, ci, ci, ll, ll]; lib.isrTrunkDataflowSupported.restype = ci
+    lib.isrTrunkDataflow.argtypes = [vp, ci, ll, vp, ll, vp, vp, ci, ci, ci, vp, vp]; lib.isrTrunkDataflow.restype = ci
+    lib.isrTrunkDataflowPrepacked.argtypes = [ci, vp, ll, vp, vp, ci, ci, ci, vp, vp]; lib.isrTrunkDataflowPrepacked.restype = ci
+    lib.isrTrunkDataflowPackedResult.argtypes = [ci, ci, ci, vp, vp]; lib.isrTrunkDataflowPackedResult.restype = ci
+    lib.isrSetTrunkPackedResult.argtypes = [ci]; lib.isrSetTrunkPackedResult.restype = None
+    lib.isrConvUpsPhaseWeightBytes.argtypes = []; lib.isrConvUpsPhaseWeightBytes.restype = ll
+    lib.isrConvUpsPhaseScratchBytes.argtypes = []; lib.isrConvUpsPhaseScratchBytes.restype = ll
+    lib.isrConvUpsPhasePrepare.argtypes = [vp, vp, vp, vp]; lib.isrConvUpsPhasePrepare.restype = ci
+    lib.isrConvUpsPhaseSupported.argtypes = [ci, ci, ci, ci, ll, ll]; lib.isrConvUpsPhaseSupported.restype = ci
+    lib.isrConvUpsPhase.argtypes = [vp, vp, vp, vp, vp, ci, ci, ci, cf, ll, ll, vp]; lib.isrConvUpsPhase.restype = ci
+    lib.isrPackSplit.argtypes = [vp, vp, ci, ci, ci, ll, ll, vp]; lib.isrPackSplit.restype = ci
+    lib.isrResBlockSplitWorkspaceBytes.argtypes = []; lib.isrResBlockSplitWorkspaceBytes.restype = ll
+    lib.isrResBlockSplitSupported.argtypes = [vp, ci, ci, ll, ll]; lib.isrResBlockSplitSupported.restype = ci
+    lib.isrResBlockSplit.argtypes = [vp, vp, vp, vp, vp, vp, vp, ci, ci, ll, ll, vp]; lib.isrResBlockSplit.restype = ci
+    lib.isrAdamFlatStep.argtypes = [vp, vp, vp, vp, ll, vp, cf, cf, cf, cf, vp, vp]; lib.isrAdamFlatStep.restype = ci
+    lib.isrSetRangeFlag.argtypes = [vp]; lib.isrSetRangeFlag.restype = None
+    lib.isrSetTrunkErrorWord.argtypes = [vp]; lib.isrSetTrunkErrorWord.restype = None
+    lib.isrSetTrunkRows.argtypes = [ci]; lib.isrSetTrunkRows.restype = None
+    lib.isrProfileEnable.argtypes = [ci]; lib.isrProfileEnable.restype = ci
+    lib.isrProfileCount.argtypes = []; lib.isrProfileCount.restype = ci
+    lib.isrProfileGet.argtypes = [ci, vp, vp, vp]; lib.isrProfileGet.restype = ci
+    if hasattr(lib, "isrDebugSplitState"):            # the diagnostics build (csrc/sr_diag.h): its switches on top
+        lib.isrDebugSetFlowFillFault.argtypes = [ci, ctypes.c_ulonglong]; lib.isrDebugSetFlowFillFault.restype = None
+        lib.isrDebugSetTrunkFault.argtypes = [ci, ctypes.c_ulonglong]; lib.isrDebugSetTrunkFault.restype = None
+        lib.isrDebugSetTrunkMultiTile.argtypes = [ci]; lib.isrDebugSetTrunkMultiTile.restype = None
+        for name in ("isrDebugSetSplitAlgo", "isrDebugSetSplitUpsForm", "isrDebugSetSplitSlots", "isrDebugSetSplitSmall", "isrDebugSetSplitAblation",
+                     "isrDebugSetTailFused", "isrDebugSetForwardTile", "isrDebugSetForwardAlgo", "isrDebugSetWgradSplitForm", "isrDebugSetAblation",
+                     "isrDebugSetTrunkAblation", "isrDebugSetBlockAblation", "isrDebugSetF16Ablation"):
+            getattr(lib, name).argtypes = [ci]; getattr(lib, name).restype = None
+        for name in ("isrDebugSplitState", "isrDebugTailState", "isrDebugBlockState", "isrDebugTrunkState", "isrDebugFlowFillState",
+                     "isrDebugSplitUpsForm", "isrDebugWgradSplitForm"):
+            getattr(lib, name).argtypes = []; getattr(lib, name).restype = ci
+        for name in ("isrDebugSetSplitStampBuffer", "isrDebugSetTrunkStampBuffer", "isrDebugSetBlockStampBuffer", "isrDebugSetF16StampBuffer",
+                     "isrDebugSetStampBuffer"):
+            getattr(lib, name).argtypes = [vp]; getattr(lib, name).restype = None
+    return lib
+
+
 def _sr():
     global _lib
     if _lib is None:
-        lib = _native.load(_native.SR_LIB)
-        vp, ci, cf, ll = ctypes.c_void_p, ctypes.c_int, ctypes.c_float, ctypes.c_longlong
-        lib.isrConvCinPad.argtypes = [ci]; lib.isrConvCinPad.restype = ci
-        lib.isrConvCoutPad.argtypes = [ci]; lib.isrConvCoutPad.restype = ci
-        lib.isrConvPrepareWeights.argtypes = [vp, vp, ci, ci, ci, vp]; lib.isrConvPrepareWeights.restype = ci
-        lib.isrConv3x3Forward.argtypes = [vp, vp, vp, vp, vp, ci, ci, ci, ci, ci, ci, cf, ci, vp]
-        lib.isrConv3x3Forward.restype = ci
-        lib.isrConv3x3ForwardStrided.argtypes = [vp, vp, vp, vp, vp, ci, ci, ci, ci, ci, ci, cf, ci, ll, ll, ll, ll, ll, ll, vp]
-        lib.isrConv3x3ForwardStrided.restype = ci
-        lib.isrConvWeightGradWorkspace.argtypes = [ci, ci, ci, ci, ci]; lib.isrConvWeightGradWorkspace.restype = ll
-        lib.isrConv3x3WeightGrad.argtypes = [vp, vp, vp, vp, vp, ci, ci, ci, ci, ci, vp]; lib.isrConv3x3WeightGrad.restype = ci
-        lib.isrConvWeightGradMaxSegments.argtypes = []; lib.isrConvWeightGradMaxSegments.restype = ci
-        lib.isrConv3x3WeightGradSegments.argtypes = [vp, vp, ci, vp, vp, vp, ci, ci, ci, ci, ci, vp]
-        lib.isrConv3x3WeightGradSegments.restype = ci
-        lib.isrConv3x3WeightGradSegmentsBf16.argtypes = lib.isrConv3x3WeightGradSegments.argtypes
-        lib.isrConv3x3WeightGradSegmentsBf16.restype = ci
-        lib.isrConv3x3WeightGradSegmentsSplit.argtypes = lib.isrConv3x3WeightGradSegments.argtypes
-        lib.isrConv3x3WeightGradSegmentsSplit.restype = ci
-        lib.isrActBackward.argtypes = [vp, vp, vp, ll, ci, cf, vp]; lib.isrActBackward.restype = ci
-        lib.isrResBlockSmallSupported.argtypes = [ci, ci, ci]; lib.isrResBlockSmallSupported.restype = ci
-        lib.isrResBlockSmall.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, ci, ci, ci, vp, vp, vp]; lib.isrResBlockSmall.restype = ci
-        lib.isrConv3x3WeightGradSegmentsSplitMax.argtypes = [vp, vp, vp, ci, ci, vp, vp, vp, ci, ci, ci, ci, ci, vp]
-        lib.isrConv3x3WeightGradSegmentsSplitMax.restype = ci
-        lib.isrSetMaxSlots.argtypes = [vp, ci]; lib.isrSetMaxSlots.restype = None
-        lib.isrSetWeightGradAccumulate.argtypes = [ci]; lib.isrSetWeightGradAccumulate.restype = None
-        lib.isrTakeMaxSlotWords.argtypes = []; lib.isrTakeMaxSlotWords.restype = ci
-        lib.isrAssembleInput.argtypes = [vp, vp, vp, vp, ci, ci, ci, ci, vp]; lib.isrAssembleInput.restype = ci
-        lib.isrAssembleInputRows.argtypes = [vp, vp, vp, vp, ci, ci, ci, ci, ci, ci, vp]; lib.isrAssembleInputRows.restype = ci
-        lib.isrAssembleInputRect.argtypes = [vp, vp, vp, vp, ci, ci, ci, ci, ci, ci, ci, ci, vp]; lib.isrAssembleInputRect.restype = ci
-        lib.isrAssembleInputPacked.argtypes = [vp, vp, vp, vp, ci, ci, ci, ci, vp, vp]; lib.isrAssembleInputPacked.restype = ci
-        lib.isrConvSmallCinPad.argtypes = [ci]; lib.isrConvSmallCinPad.restype = ci
-        lib.isrConvSmallWeightFloats.argtypes = [ci]; lib.isrConvSmallWeightFloats.restype = ll
-        lib.isrConvSmallPrepare.argtypes = [vp, vp, vp, vp, ci, ci, vp]; lib.isrConvSmallPrepare.restype = ci
-        lib.isrConv3x3SmallCout.argtypes = [vp, vp, vp, vp, vp, ci, ci, ci, ci, ci, ci, cf, vp]; lib.isrConv3x3SmallCout.restype = ci
-        lib.isrConv3x3SmallCoutStrided.argtypes = [vp, vp, vp, vp, vp, ci, ci, ci, ci, ci, ci, cf, ll, ll, vp]
-        lib.isrConv3x3SmallCoutStrided.restype = ci
-        lib.isrFlowFillWorkspace.argtypes = [ci, ci]; lib.isrFlowFillWorkspace.restype = ll
-        lib.isrFlowFill.argtypes = [vp, vp, vp, ci, ci, vp]; lib.isrFlowFill.restype = ci
-        lib.isrFlowFillEx.argtypes = [vp, vp, vp, ci, ci, ci, vp]; lib.isrFlowFillEx.restype = ci
-        lib.isrFlowFillOne.argtypes = [vp, vp, vp, ci, ci, vp]; lib.isrFlowFillOne.restype = ci
-        lib.isrFlowFillOneSupported.argtypes = [ci, ci]; lib.isrFlowFillOneSupported.restype = ci
-        lib.isrSetFlowFillErrorWord.argtypes = [vp]; lib.isrSetFlowFillErrorWord.restype = None
-        lib.isrDebugSetFlowFillFault.argtypes = [ci, ctypes.c_ulonglong]; lib.isrDebugSetFlowFillFault.restype = None
-        lib.isrFinishFrame.argtypes = [vp, vp, vp, vp, ci, ci, vp, ci, cf, ci, ci, vp]; lib.isrFinishFrame.restype = ci
-        lib.isrConvSmallFinishFrame.argtypes = [vp, vp, vp, vp, vp, vp, ci, ci, ci, ll, vp, ci, cf, ci, ci, vp]
-        lib.isrConvSmallFinishFrame.restype = ci
-        lib.isrUpsample2xForward.argtypes = [vp, vp, ll, ci, ci, vp]; lib.isrUpsample2xForward.restype = ci
-        lib.isrUpsample2xBackward.argtypes = [vp, vp, ll, ci, ci, vp]; lib.isrUpsample2xBackward.restype = ci
-        lib.isrReconResidualForward.argtypes = [vp, vp, vp, ci, ci, ci, ci, ci, ci, vp]; lib.isrReconResidualForward.restype = ci
-        lib.isrReconResidualBackward.argtypes = [vp, vp, ci, ci, ci, ci, ci, ci, vp]; lib.isrReconResidualBackward.restype = ci
-        lib.isrLossUnshadedWorkspace.argtypes = []; lib.isrLossUnshadedWorkspace.restype = ll
-        lib.isrLossUnshadedForward.argtypes = [vp, vp, vp, ci, ci, ci, ci, vp, ctypes.c_uint, vp, cf, ci, vp, vp, vp]
-        lib.isrLossUnshadedForward.restype = ci
-        lib.isrLossUnshadedBackward.argtypes = [vp, vp, vp, ci, ci, ci, ci, vp, ctypes.c_uint, vp, cf, ci, vp, vp, vp, vp]
-        lib.isrLossUnshadedBackward.restype = ci
-        lib.isrRecurrentInputForward.argtypes = [vp, vp, vp, vp, vp, ci, ci, ci, ll, ll, vp]; lib.isrRecurrentInputForward.restype = ci
-        lib.isrRecurrentInputBackward.argtypes = [vp, vp, vp, vp, vp, vp, ci, ci, ci, ll, vp]; lib.isrRecurrentInputBackward.restype = ci
-        lib.isrConvF16WeightBytes.argtypes = [ci, ci]; lib.isrConvF16WeightBytes.restype = ll
-        lib.isrConvF16Prepare.argtypes = [vp, vp, ci, ci, vp]; lib.isrConvF16Prepare.restype = ci
-        lib.isrConv3x3ForwardF16.argtypes = [vp, vp, vp, vp, vp, ci, ci, ci, ci, ci, ci, cf, ci, ll, ll, ll, ll, ll, ll, vp]
-        lib.isrConvF16SupportsUpsample.argtypes = [ll, ci, ll, ll]; lib.isrConvF16SupportsUpsample.restype = ci
-        lib.isrConvBf16Prepare.argtypes = [vp, vp, ci, ci, vp]; lib.isrConvBf16Prepare.restype = ci
-        lib.isrConv3x3ForwardBf16.argtypes = lib.isrConv3x3ForwardF16.argtypes; lib.isrConv3x3ForwardBf16.restype = ci
-        lib.isrConv3x3ForwardF16.restype = ci
-        lib.isrConvSplitWeightBytes.argtypes = [ci, ci]; lib.isrConvSplitWeightBytes.restype = ll
-        lib.isrConvSplitPrepare.argtypes = [vp, vp, ci, ci, vp]; lib.isrConvSplitPrepare.restype = ci
-        lib.isrConvSplitPrepareManyMax.argtypes = []; lib.isrConvSplitPrepareManyMax.restype = ci
-        lib.isrConvSplitPrepareMany.argtypes = [ci, vp, vp, vp, vp, vp, vp]; lib.isrConvSplitPrepareMany.restype = ci
-        lib.isrConv3x3ForwardSplit.argtypes = lib.isrConv3x3ForwardF16.argtypes; lib.isrConv3x3ForwardSplit.restype = ci
-        lib.isrConvTailWeightBytes.argtypes = []; lib.isrConvTailWeightBytes.restype = ll
-        lib.isrConvTailWorkspaceBytes.argtypes = [ci, ci]; lib.isrConvTailWorkspaceBytes.restype = ll
-        lib.isrConvTailPrepare.argtypes = [vp, vp, vp]; lib.isrConvTailPrepare.restype = ci
-        lib.isrConvTailSupported.argtypes = [vp, ci, ci, ll]; lib.isrConvTailSupported.restype = ci
-        lib.isrConvTailFinishFrame.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, vp, ci, ci, ll, vp, ci, cf, ci, ci, vp]
-        lib.isrConvTailFinishFrame.restype = ci
-        lib.isrConv3x3ForwardSplitPacked.argtypes = [vp, vp, vp, vp, ci, ci, ci, ci, ci, cf, ci, ll, ll, vp]
-        lib.isrConv3x3ForwardSplitPacked.restype = ci
-        lib.isrConv3x3ForwardSplitFromPacked.argtypes = [vp, vp, vp, vp, vp, ci, ci, ci, ci, ci, ci, cf, ll, ll, ll, vp]
-        lib.isrConv3x3ForwardSplitFromPacked.restype = ci
-        lib.isrConvTailFinishFramePacked.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, vp, ci, ci, ll, vp, ci, cf, ci, ci, vp]
-        lib.isrConvTailFinishFramePacked.restype = ci
-        lib.isrTrunkDataflowMaxTiles.argtypes = []; lib.isrTrunkDataflowMaxTiles.restype = ci
-        lib.isrTrunkDataflowWorkspaceBytes.argtypes = [ci, ci, ci]; lib.isrTrunkDataflowWorkspaceBytes.restype = ll
-        lib.isrTrunkDataflowSupported.argtypes = [vp, ci, ci, ci, ll, ll]; lib.isrTrunkDataflowSupported.restype = ci
-        lib.isrTrunkDataflow.argtypes = [vp, ci, ll, vp, ll, vp, vp, ci, ci, ci, vp, vp]; lib.isrTrunkDataflow.restype = ci
-        lib.isrTrunkDataflowPrepacked.argtypes = [ci, vp, ll, vp, vp, ci, ci, ci, vp, vp]; lib.isrTrunkDataflowPrepacked.restype = ci
-        lib.isrTrunkDataflowPackedResult.argtypes = [ci, ci, ci, vp, vp]; lib.isrTrunkDataflowPackedResult.restype = ci
-        lib.isrSetTrunkPackedResult.argtypes = [ci]; lib.isrSetTrunkPackedResult.restype = None
-        lib.isrConvUpsPhaseWeightBytes.argtypes = []; lib.isrConvUpsPhaseWeightBytes.restype = ll
-        lib.isrConvUpsPhaseScratchBytes.argtypes = []; lib.isrConvUpsPhaseScratchBytes.restype = ll
-        lib.isrConvUpsPhasePrepare.argtypes = [vp, vp, vp, vp]; lib.isrConvUpsPhasePrepare.restype = ci
-        lib.isrConvUpsPhaseSupported.argtypes = [ci, ci, ci, ci, ll, ll]; lib.isrConvUpsPhaseSupported.restype = ci
-        lib.isrConvUpsPhase.argtypes = [vp, vp, vp, vp, vp, ci, ci, ci, cf, ll, ll, vp]; lib.isrConvUpsPhase.restype = ci
-        lib.isrPackSplit.argtypes = [vp, vp, ci, ci, ci, ll, ll, vp]; lib.isrPackSplit.restype = ci
-        lib.isrResBlockSplitWorkspaceBytes.argtypes = []; lib.isrResBlockSplitWorkspaceBytes.restype = ll
-        lib.isrResBlockSplitSupported.argtypes = [vp, ci, ci, ll, ll]; lib.isrResBlockSplitSupported.restype = ci
-        lib.isrResBlockSplit.argtypes = [vp, vp, vp, vp, vp, vp, vp, ci, ci, ll, ll, vp]; lib.isrResBlockSplit.restype = ci
-        lib.isrAdamFlatStep.argtypes = [vp, vp, vp, vp, ll, vp, cf, cf, cf, cf, vp, vp]; lib.isrAdamFlatStep.restype = ci
-        lib.isrSetRangeFlag.argtypes = [vp]; lib.isrSetRangeFlag.restype = None
-        lib.isrSetTrunkErrorWord.argtypes = [vp]; lib.isrSetTrunkErrorWord.restype = None
-        lib.isrDebugSetTrunkFault.argtypes = [ci, ctypes.c_ulonglong]; lib.isrDebugSetTrunkFault.restype = None
-        lib.isrDebugSetTrunkMultiTile.argtypes = [ci]; lib.isrDebugSetTrunkMultiTile.restype = None
-        lib.isrSetTrunkRows.argtypes = [ci]; lib.isrSetTrunkRows.restype = None
-        lib.isrProfileEnable.argtypes = [ci]; lib.isrProfileEnable.restype = ci
-        lib.isrDebugSetSplitAlgo.argtypes = [ci]
-        if os.environ.get("ISR_SPLIT_ALGO"):          # experiments: force a kernel form of the plain split layers (see sr_conv_split.hip)
-            lib.isrDebugSetSplitAlgo(int(os.environ["ISR_SPLIT_ALGO"]))
-        lib.isrProfileCount.argtypes = []; lib.isrProfileCount.restype = ci
-        lib.isrProfileGet.argtypes = [ci, vp, vp, vp]; lib.isrProfileGet.restype = ci
-        _lib = lib
+        _lib = _bind(_native.load(_native.SR_LIB))
     return _lib
+
+
+def is_diagnostics_library():
+    """Is the library this process launches on the DIAGNOSTICS build (isrDebug* switches, stamp buffers, fault injection, the experimental
+    kernel forms)?  The product build -- what a deployment ships and what bench.py / the driver measure -- has none of them."""
+    return hasattr(_sr(), "isrDebugSplitState")
+
+
+@contextlib.contextmanager
+def diagnostics_library():
+    """Run the enclosed launches on the DIAGNOSTICS build of the kernels (lib/libisr_sr_diag.so, `make diag`), then go back to the product
+    build: the tests of the timeout paths (fault injection) and of kernel forms only a switch selects, and tools/.  The two builds are
+    the same sources and the same ABI; weight images and workspaces made by one are valid for the other, the per-launch globals (range
+    flag, error words, trunk rows) are set by ``ops`` at every launch.  Single-threaded by contract, like the libraries."""
+    global _lib
+    saved = _sr()
+    if hasattr(saved, "isrDebugSplitState"):          # already there (ISR_SR_DIAG=1 / ISR_SR_LIB=...)
+        yield saved
+        return
+    torch.cuda.synchronize()
+    diag = _bind(_native.load(_native.SR_DIAG_LIB))
+    assert hasattr(diag, "isrDebugSplitState"), "%s is not a diagnostics build (make -C csrc diag)" % _native.SR_DIAG_LIB
+    was_profiling = _profile_on
+    _lib = diag
+    try:
+        if was_profiling:
+            diag.isrProfileEnable(1)
+        yield diag
+    finally:
+        torch.cuda.synchronize()
+        if was_profiling:
+            diag.isrProfileEnable(0)
+        _lib = saved
 
 
 def _stream():
@@ -261,6 +306,8 @@ def debug_switches():
     forms, grid caps, stamp buffers) that are not in their default position; 0 on a clean process.  bench.py reports it and
     refuses to print a headline measured with an ablation active."""
     lib = _sr()
+    if not hasattr(lib, "isrDebugSplitState"):        # the product build has no switches (csrc/sr_diag.h): 0 by construction
+        return 0
     return (int(lib.isrDebugSplitState()) | (int(lib.isrDebugTailState()) << 8) | (int(lib.isrDebugBlockState()) << 12) | (int(lib.isrDebugTrunkState()) << 16)
             | (int(lib.isrDebugFlowFillState()) << 28))
 
@@ -1662,6 +1709,7 @@ def assemble_input_packed(gbuffer_hwc, flow_filled, prev_high, convs, initial_im
 
 
 _fill_ws = {}
+_FILL_WS_MAX = 16                               # (device, size, stream) workspaces kept; a frame pipeline uses one or two
 
 
 FLOW_FILL_ONE = os.environ.get("ISR_FLOW_FILL_ONE", "1") != "0"       # the push-pull pyramid as ONE launch (isrFlowFillOne) where it applies
@@ -1692,11 +1740,18 @@ def fill_flow_gbuffer(gbuffer_hwc, out=None, stream=None, threads=1024, one_laun
     h, w = gbuffer_hwc.shape[0], gbuffer_hwc.shape[1]
     st = torch.cuda.current_stream() if stream is None else stream
     key = (gbuffer_hwc.device, h, w, st.cuda_stream)
-    ws = _fill_ws.get(key)
+    ws = _fill_ws.pop(key, None)
     if ws is None:
+        if len(_fill_ws) >= _FILL_WS_MAX:
+            # bounded: the key holds a raw stream handle (streams come and go in a long-lived viewer).  The least recently used workspace is
+            # dropped at a quiescent point -- a launch in flight or a captured frame may still point into it, so: synchronise, and tell the
+            # frame pipelines that what they captured is stale
+            torch.cuda.synchronize()
+            _fill_ws.pop(next(iter(_fill_ws)))
+            _routing_changed()
         with torch.cuda.stream(st):             # zero-filled once, in stream order with its first use: the one-launch form's tickets live in it
             ws = torch.zeros(lib.isrFlowFillWorkspace(h, w), dtype=torch.uint8, device=gbuffer_hwc.device)
-        _fill_ws[key] = ws
+    _fill_ws[key] = ws                          # (re-inserted: most recently used last)
     if out is None:
         out = torch.empty((1, 2, h, w), dtype=torch.float32, device=gbuffer_hwc.device)
     one = (FLOW_FILL_ONE and not DEVICE_SHARED) if one_launch is None else one_launch

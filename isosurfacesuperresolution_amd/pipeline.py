@@ -188,15 +188,18 @@ class SuperResolutionPipeline:
         r.send_command("resolution", "%d,%d" % (self.low_w, self.low_h))
         r.send_command("viewport", "%d,%d,%d,%d" % (0, 0, self.low_w, self.low_h))
 
-    def reset(self):
-        """Start a new temporal sequence.  Also the END of the one before: the guards watch every frame one frame late
+    def reset(self, flush=True):
+        """Start a new temporal sequence.  ``flush=True`` (default) BLOCKS the host until the in-flight frame's guard words have landed
+        (one event synchronisation) and MAY RAISE -- after the sequence state has been cleared, so the pipeline is usable either way;
+        an interactive viewer that resets on every camera jump passes ``flush=False``: no wait, no exception here, the last frame's
+        words are looked at by the next frame's ``guards_poll`` instead (they stay published).  Also the END of the sequence before: the guards watch every frame one frame late
         (``ops.guards_publish`` at a frame's end, ``ops.guards_poll`` at the next frame's start), so the sequence's LAST frame is
         looked at here -- a dataflow-trunk / flow-fill launch of that frame that timed out raises RuntimeError from this call (the
         frame it produced is incomplete), a layer that came close to the split operands' range is routed to the exact kernels from
         the next sequence on.  Offline renderers call ``reset()`` or ``close()`` after their last frame."""
         self.previous = None
         self._drop_prefetched()
-        if self.fused and str(self.device).startswith("cuda"):
+        if flush and self.fused and str(self.device).startswith("cuda"):
             ops.guards_flush(self.device)
 
     def close(self):
@@ -300,7 +303,7 @@ class SuperResolutionPipeline:
         (``ops.TRUNK_DATAFLOW``, ``ops.FLOW_FILL_ONE``, the device-shared hint) and ``ops.routing_epoch()``, which moves whenever a
         guard failure switched a form off, re-zeroed a workspace or ``range_reset`` handed the guard words out anew."""
         sh = self.shading
-        weights = tuple((p._version, p.data_ptr()) for p in self.model.model.parameters())
+        weights = tuple((p._version, p.data_ptr()) for p in self.model.model.parameters())      # (an address can change without the version moving: every frame, ~50 pairs; graph mode is opt-in)
         return (tuple(sh.packed_parameters()), int(sh._specular_exponent), float(sh._ao), bool(self.model.inverse_ao), bool(sh.enable_specular),
                 self.model.initial_image_mode, id(self.model.model), ops._images_epoch, self._static_version, self.flow_fill_threads,
                 ops.TRUNK_DATAFLOW, ops.FLOW_FILL_ONE, ops.DEVICE_SHARED, ops.SPLIT_F16, ops.FAST_F16, ops.UPS_PHASE, ops.ASSEMBLE_PACKED, ops.routing_epoch(), weights)

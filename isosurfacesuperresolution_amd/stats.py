@@ -37,6 +37,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from . import models
+from .inference.loadedmodel import guarded_forward
 from .utils import MSSSIM, PSNR, MeanVariance, ScreenSpaceShading, initialImage
 
 UPSCALING = 4
@@ -217,7 +218,9 @@ def run_clip(net, low, high, flow, stats, upscaling=UPSCALING):
         else:
             previous_warped = models.VideoTools.warp_upscale(previous_output, flow[j - 1:j], upscaling, special_mask=True)
         single_input = torch.cat((low[j:j + 1], models.VideoTools.flatten_high(previous_warped, upscaling)), dim=1)
-        prediction, _ = net(single_input)
+        # (on the device: with the guard contract of LoadedModel.inference around the call -- poll, first-frame range check, publish;
+        # run_statistics flushes the last frame's words at the end of the clip)
+        prediction = net(single_input)[0] if isinstance(net, SimpleUpsample) else guarded_forward(net, single_input)
         prediction = torch.cat([torch.clamp(prediction[:, 0:1], -1, +1), ScreenSpaceShading.normalize(prediction[:, 1:4], dim=1),
                                 torch.clamp(prediction[:, 4:6], 0, +1)], dim=1)
         stats.add_timestep_sample(prediction, high[j:j + 1], low[j:j + 1])
@@ -247,6 +250,11 @@ def run_statistics(datasets, model_specs, output_folder, device="cuda", upscalin
                         low, high, flow = (torch.from_numpy(np.load(p)).to(device) for p in (p_low, p_high, p_flow))
                         for (name, net), st, f in zip(nets, stats, files):
                             st.reset()
+                            if is_cuda:
+                                from . import ops
+                                # every (model, clip) starts like a freshly loaded model: guard words handed out anew, the clip's FIRST frame gets
+                                # the synchronous range check (LoadedModel._setup does the same for a checkpoint) -- several models take turns here
+                                ops.range_reset()
                             run_clip(net, low, high, flow, st, upscaling)
                             if is_cuda:
                                 from . import ops

@@ -21,6 +21,16 @@ def oracle():
     return iso_oracle
 
 
+@pytest.fixture
+def diag_lib():
+    """The DIAGNOSTICS build of the kernel library for the duration of one test (``ops.diagnostics_library()``): fault injection for the
+    timeout paths, switches that force a kernel form no shape selects, the experimental forms.  Every other GPU test runs on the product
+    build -- lib/libisr_sr.so, which has no ``isrDebug*`` symbol."""
+    from isosurfacesuperresolution_amd import ops
+    with ops.diagnostics_library() as lib:
+        yield lib
+
+
 @pytest.fixture(autouse=True)
 def _quiescent_teardown(request):
     """GPU tests: drain the device and collect this test's garbage (HIP graphs, streams, events, pipelines) at its end, i.e. at a

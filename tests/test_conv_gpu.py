@@ -92,7 +92,7 @@ def _forward_case(case):
 
 @pytest.mark.parametrize("tile", [1, 2, 3])
 @pytest.mark.parametrize("case", [c for c in CASES if c[2] > 8 or c[8]])
-def test_conv3x3_forward_both_tilings(case, tile, exact_mode):
+def test_conv3x3_forward_both_tilings(case, tile, exact_mode, diag_lib):
     """The forward kernel has a 16x32 and a 4x32 tiling and a one-row-per-workgroup form with K split over the waves
     (picked by problem size; 3 = the latter, which has no upsampling variant and falls back to the 4x32 tiling
     there); all must give the reference result on every case, whatever the heuristic would choose."""
@@ -133,7 +133,7 @@ def test_conv3x3_padded_channel_planes(conv_mode):
 
 @pytest.mark.parametrize("form", ["tile", "stream", "wide", "rows2"])
 @pytest.mark.parametrize("slots", [8, 24])
-def test_split_kernel_forms_agree_when_workgroups_walk_many_tiles(form, slots):
+def test_split_kernel_forms_agree_when_workgroups_walk_many_tiles(form, slots, diag_lib):
     """The plain split-operand layer has four kernel forms (one workgroup per 8x32 tile; persistent streaming; wide
     512-thread; 2-row tiles for small images).  The persistent ones walk a list of tiles per workgroup -- with the grid
     capped to a few workgroups even a small image exercises the tile-to-tile hand-over (next tile's operands in flight

@@ -93,7 +93,7 @@ def test_graph_is_recaptured_when_static_parameters_change():
     assert pipe.graph_replays > n0
 
 
-def test_a_timeout_under_graph_mode_drops_the_captured_frames_and_the_fallback_forms_take_over():
+def test_a_timeout_under_graph_mode_drops_the_captured_frames_and_the_fallback_forms_take_over(diag_lib):
     """a captured frame holds the dataflow-trunk launch, its workspace pointers and guard words.  A launch that times
     out (device-induced fault) raises at the next frame's start; the captured frames are dropped before the error leaves, the
     next frames run on the per-layer kernels (eagerly, then captured again) and equal the eager pipeline bit for bit."""

@@ -57,7 +57,7 @@ def test_tail_matches_the_three_kernel_path_and_fp64(h, w):
 
 
 @pytest.mark.parametrize("h,w", [(2, 8), (6, 8), (23, 37), (30, 52), (67, 120), (270, 480)])
-def test_fused_form_equals_the_two_kernel_form_bit_for_bit(h, w):
+def test_fused_form_equals_the_two_kernel_form_bit_for_bit(h, w, diag_lib):
     """Form 1 finishes every pixel whose nine partials lie in its own tile inside the convolution kernel and
     assembles the others (the tiles' rims) from per-pixel records; form 0 writes all 54 partial planes and adds
     them in a streaming kernel.  Same partials, same order of additions: equal outputs, at ragged and full sizes.
@@ -191,7 +191,7 @@ def test_pipeline_uses_the_fused_tail_and_matches_the_unfused_frame():
 
 
 @pytest.mark.parametrize("h,w", [(2, 8), (6, 8), (23, 37), (30, 52), (67, 120), (270, 480)])
-def test_s_form_matches_the_54_plane_form_and_fp64(h, w):
+def test_s_form_matches_the_54_plane_form_and_fp64(h, w, diag_lib):
     """The default form (2): every wave adds the three horizontal taps of each (dy, c) for its row of 32 pixels and stores 18 S planes
     (+ small records for the rows' end pixels) instead of 54 partial planes.  The additions associate differently from the 54-plane
     form's tap-by-tap sum -- ((z0 + z1) + z2 per row, then the three rows) -- so the two agree to rounding, not bit for bit; both

@@ -471,7 +471,7 @@ def test_split_operand_weight_gradient_matches_fp64(case, gz_scale):
 
 @pytest.mark.parametrize("case", [(10, 16, 64, 64, 32, 32), (3, 12, 101, 64, 64, 64), (2, 16, 64, 64, 128, 128), (2, 16, 64, 6, 128, 128),
                                   (5, 7, 64, 64, 36, 40), (1, 3, 64, 64, 130, 68)])
-def test_staged_weight_gradient_kernel_is_bit_identical_to_the_one_wave_form(case):
+def test_staged_weight_gradient_kernel_is_bit_identical_to_the_one_wave_form(case, diag_lib):
     """conv3x3_wgrad_split2_kernel (staging on its own waves, half-tile pipeline) walks the tiles of conv3x3_wgrad_split_kernel in
     the same order: the weight gradients are EQUAL bit for bit (odd tile counts, ragged rows and columns, partial channel groups
     included); the bias gradient groups its fp32 sums differently and is equal to rounding."""

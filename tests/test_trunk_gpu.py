@@ -47,7 +47,7 @@ def test_dataflow_trunk_is_bit_identical_to_the_per_layer_launches(h, w):
     assert torch.equal(f, f2)
 
 
-def test_network_uses_the_dataflow_trunk_and_is_unchanged():
+def test_network_uses_the_dataflow_trunk_and_is_unchanged(diag_lib):
     from isosurfacesuperresolution_amd import ops
     net = _net(3)
     x = torch.rand(1, 101, 270, 480, device="cuda")
@@ -150,7 +150,7 @@ def test_error_word_of_the_dataflow_trunk_is_sticky():
         ops.TRUNK_DATAFLOW = True
 
 
-def test_a_timeout_induced_on_the_device_raises_at_the_start_of_the_next_frame():
+def test_a_timeout_induced_on_the_device_raises_at_the_start_of_the_next_frame(diag_lib):
     """the timeout path itself (deadline -> LDS flag -> atomicMax(error) -> early return), executed by the
     kernel: a diagnostic switch makes ONE tile never publish its progress and shortens the deadline to 2 ms.  The frame with the
     fault returns without any host synchronisation; the NEXT frame's start reads the guard words the faulty frame mirrored into
@@ -229,7 +229,7 @@ def test_multi_tile_trunk_is_bit_identical_to_the_per_layer_launches(h, w):
 
 
 @pytest.mark.parametrize("cin,nblocks,h,w", [(101, 10, 270, 480), (5, 1, 33, 70), (16, 0, 16, 32), (40, 2, 50, 64), (24, 3, 300, 520)])
-def test_multi_tile_form_forced_on_every_size_equals_the_one_tile_form(cin, nblocks, h, w):
+def test_multi_tile_form_forced_on_every_size_equals_the_one_tile_form(cin, nblocks, h, w, diag_lib):
     from isosurfacesuperresolution_amd import ops
     g = torch.Generator().manual_seed(cin * 100 + nblocks)
     convs = [(((torch.rand(64, cin if k == 0 else 64, 3, 3, generator=g) - 0.5) * 0.15).cuda(), ((torch.rand(64, generator=g) - 0.5) * 0.2).cuda())
@@ -274,7 +274,7 @@ def test_four_rows_per_wave_form_equals_the_default_form(cin, nblocks, h, w):
         assert torch.equal(f, ref), (f - ref).abs().max().item()
 
 
-def test_multi_tile_trunk_gives_up_loudly_when_a_tile_never_publishes():
+def test_multi_tile_trunk_gives_up_loudly_when_a_tile_never_publishes(diag_lib):
     """The multi-tile form's waits have the same deadline and error word as the one-tile form's: a tile that never publishes
     (isrDebugSetTrunkFault, deadline 2 ms) ends the launch with the word set by the kernel -- no hang -- and the next launch is right."""
     from isosurfacesuperresolution_amd import ops
@@ -304,7 +304,7 @@ def test_multi_tile_trunk_gives_up_loudly_when_a_tile_never_publishes():
         st["buf"][ops._TRUNK_ERROR_SLOT] = 0
 
 
-def test_multi_round_launch_outlives_its_timeout_because_the_deadline_is_per_wait():
+def test_multi_round_launch_outlives_its_timeout_because_the_deadline_is_per_wait(diag_lib):
     """a healthy multi-round launch must not fail because it LASTS longer than the limit.  1 020 tiles = 4 rounds
     (~2.5 ms); the limit is shortened to 0.2 ms per round (0.8 ms per wait): counted from the kernel's start -- the earlier form --
     every wait after 0.2 ms would have given up; per wait nothing comes near it.  Result bit-identical, error word clean."""

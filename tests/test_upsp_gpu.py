@@ -9,6 +9,12 @@ import torch
 import torch.nn.functional as F
 
 pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(autouse=True)
+def _diagnostics_build(diag_lib):
+    """Every test of this module is about kernel forms that exist in the diagnostics build only (csrc/sr_diag.h)."""
+    yield diag_lib
 OPT = argparse.Namespace(upsample='bilinear', reconType='residual', useBN=False, numResidualLayers=10)
 
 
