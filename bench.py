@@ -76,7 +76,7 @@ def is_split_kernel(name):
 MFMA_F32_PEAK_TFLOPS = 157.3      # /opt/skills/guides/MI355X_MICROARCH.md, chip-level parameters
 MFMA_F16_PEAK_TFLOPS = 2500.0     # dense fp16/bf16 MFMA (same table)
 HBM_PEAK_GBS = 8000.0
-PMC_TRAFFIC_FILES = ("r05_pmc_traffic.json", "r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json")   # committed rocprofv3 --pmc passes of this command
+PMC_TRAFFIC_FILES = ("r06_pmc_traffic.json", "r05_pmc_traffic.json", "r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json")   # committed rocprofv3 --pmc passes of this command
 
 
 def parse(argv=None):

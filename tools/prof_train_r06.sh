@@ -1,0 +1,26 @@
+#!/bin/bash
+# rocprofv3 kernel stats of the training step (bench.py --mode train, one HIP graph per step) and the full GPU test run
+cd $GRAFT_REPO_ROOT
+export TMPDIR=/tmp
+OUT=gpurun_out/r06_prof_train
+rm -rf $OUT; mkdir -p $OUT
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -o train -- python3 bench.py --mode train --steps 5 --warmup 2 --no-cpu-baseline > $OUT/stats.log 2>&1
+python3 - <<'PY'
+import csv, glob
+p = glob.glob('gpurun_out/r06_prof_train/stats/**/*kernel_stats.csv', recursive=True)[0]
+rows = list(csv.DictReader(open(p)))
+tot = sum(float(r['TotalDurationNs']) for r in rows)
+print("total kernel time %.1f ms over 7 steps (2 warm-up + capture + 5 timed ... see Calls)" % (tot / 1e6))
+for r in rows[:22]:
+    print("%-100s calls %6s  avg %8.1f us  %5.1f%%" % (r['Name'][:100], r['Calls'], float(r['AverageNs']) / 1e3, float(r['Percentage'])))
+PY
+find $OUT -name "*kernel_trace.csv" -size +8M -delete
+# one PMC pass per counter over the same command (MI355X_MICROARCH.md: separate --pmc runs, no other trace domains)
+rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/fetch -o run -- python3 bench.py --mode train --steps 3 --warmup 1 --no-cpu-baseline > $OUT/fetch.log 2>&1
+rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/write -o run -- python3 bench.py --mode train --steps 3 --warmup 1 --no-cpu-baseline > $OUT/write.log 2>&1
+find $OUT -name "*kernel_trace.csv" -size +8M -delete
+du -sh $OUT
+# condensed tables for profiles/ (copy what you want judged): kernel stats csv + the PMC summary
+cp $(find $OUT/stats -name "*kernel_stats.csv" | head -1) $OUT/r06_train_kernel_stats.csv
+python3 tools/pmc_summary.py r06_train $OUT/fetch $OUT/write > $OUT/pmc_summary.log 2>&1
+ls profiles/ | grep r06_train
