@@ -25,7 +25,35 @@ import torch.nn.functional as F
 
 from .. import ops
 from ..utils import ScreenSpaceShading
-from .lossbuilder import LossBuilder
+
+
+class LossBuilder:
+    """Factory of the elementary loss modules ``LossNetUnshaded`` is assembled from (``SuperresolutionNetwork/losses/lossbuilder.py``): the
+    terms of the hot-path training recipe (``l1``, ``mse``; README.md:45-64).  The reference's VGG perceptual / texture losses need a download
+    of VGG19 weights (``lossbuilder.py:10,173``) and the GAN losses are not part of the recipe: out of scope,
+    they raise."""
+
+    def __init__(self, device):
+        self.device = device
+
+    def mse(self):
+        return nn.MSELoss()
+
+    def l1_loss(self):
+        return nn.L1Loss()
+
+    def _unsupported(self, what):
+        raise NotImplementedError("%s is outside the accelerated hot path (SURVEY.md section 2, row 12)" % what)
+
+    def downsample_loss(self, *a, **k):
+        self._unsupported("downsample loss")
+
+    def gan_loss(self, *a, **k):
+        self._unsupported("adversarial loss")
+
+    def get_style_and_content_loss(self, *a, **k):
+        self._unsupported("VGG perceptual/texture loss")
+
 
 _TARGETS = ('mask', 'normal', 'color', 'ao', 'depth', 'all')
 
