@@ -31,7 +31,7 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-SPLIT_KERNEL_PREFIXES = ("conv3x3_split", "resblock_split", "trunk_dataflow", "trunk_mt")      # three fp16 MFMAs per product
+SPLIT_KERNEL_PREFIXES = ("conv3x3_split", "conv3x3_wgrad_split", "resblock_split", "trunk_dataflow", "trunk_mt")      # three fp16 MFMAs per product
 
 
 def tally_kernels(records):
@@ -607,8 +607,9 @@ def run_train(args, job):
                      "buckets": 1, "backend": "RCCL" if job.backend == "nccl" else job.backend}
     flops = TRAIN_FLOPS_PER_SAMPLE_FRAME * (crop / 32.0) ** 2 * B * T
     achieved = flops / (elapsed / K) / 1e12
-    # per-kernel fractions of the convolution launchers that carry dispatch-packet events (forward and data-gradient convolutions;
-    # the weight-gradient kernels do not): ONE eager step after the timed region (a replayed graph has no per-dispatch events)
+    # per-kernel fractions of the convolution launchers that carry dispatch-packet events -- forward and data-gradient convolutions and, since
+    # round 6, the split-operand weight gradient (conv3x3_wgrad_split_kernel: one entry per 64 x 64 channel block and layer): ONE eager step
+    # after the timed region (a replayed graph has no per-dispatch events)
     train_kernels = None
     if dev == "cuda":
         torch.cuda.synchronize()

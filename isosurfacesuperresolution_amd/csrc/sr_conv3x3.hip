@@ -2050,8 +2050,16 @@ int isrConv3x3WeightGradSegmentsSplitMax(const float* const* xs, const float* co
         for (int ci0 = 0; ci0 < Cin; ci0 += 64) {
             p.co0 = co0; p.ci0 = ci0;
             p.bslabs = (db && ci0 == 0) ? bslabs : nullptr;
-            if (g_wgrad_split_form == 2) hipLaunchKernelGGL(conv3x3_wgrad_split2_kernel, dim3(G), dim3(W2_THREADS), W2_LDS_BYTES, s, p);
-            else hipLaunchKernelGGL(conv3x3_wgrad_split_kernel, dim3(G), dim3(NTHREADS), WS_LDS_BYTES, s, p);
+            // (dispatch-packet events when profiling is on, like the forward kernels: the training bench line's weight-gradient family)
+            hipEvent_t pe0 = nullptr, pe1 = nullptr;
+            isr_profile_record(ISR_VARIANT_WGRAD_SPLIT, 2.0 * 9 * (Cin - ci0 < 64 ? Cin - ci0 : 64) * (Cout - co0 < 64 ? Cout - co0 : 64) * (double)segments * N * H * W, &pe0, &pe1);
+            if (g_wgrad_split_form == 2) {
+                if (pe0 || pe1) hipExtLaunchKernelGGL(conv3x3_wgrad_split2_kernel, dim3(G), dim3(W2_THREADS), W2_LDS_BYTES, s, pe0, pe1, 0, p);
+                else hipLaunchKernelGGL(conv3x3_wgrad_split2_kernel, dim3(G), dim3(W2_THREADS), W2_LDS_BYTES, s, p);
+            } else {
+                if (pe0 || pe1) hipExtLaunchKernelGGL(conv3x3_wgrad_split_kernel, dim3(G), dim3(NTHREADS), WS_LDS_BYTES, s, pe0, pe1, 0, p);
+                else hipLaunchKernelGGL(conv3x3_wgrad_split_kernel, dim3(G), dim3(NTHREADS), WS_LDS_BYTES, s, p);
+            }
             hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(9 * 64 + 1), dim3(256), 0, s,
                                p.slabs, G, dw, Cout, Cin, co0, ci0, (const float*)p.bslabs, db, (const float*)scale, accumulate);
         }

@@ -23,6 +23,7 @@ constexpr int ISR_VARIANT_TAIL_FINISH = 27;    // tail_s_finish_kernel / tail_se
 constexpr int ISR_VARIANT_FLOW_FILL = 28;      // flow_fill_one_kernel / flow_fill_kernel (sr_frame.hip; the frame pipeline runs it on the render stream)
 constexpr int ISR_VARIANT_FINISH = 29;         // finish_frame_kernel (sr_frame.hip)
 constexpr int ISR_VARIANT_UPS_FRAME = 30;      // ups_frame_kernel (sr_conv_upsp.h): the one-pixel frame of a phase-decomposed upsampling layer
+constexpr int ISR_VARIANT_WGRAD_SPLIT = 32;    // conv3x3_wgrad_split2_kernel / conv3x3_wgrad_split_kernel (sr_conv3x3.hip): the split-operand weight gradient of one 64 x 64 channel block
 constexpr int ISR_VARIANT_SPLIT_UPSP = 31;     // conv3x3_split_upsp_kernel (sr_conv_upsp.h); NOT a "small" kernel: recorded at level 1
 
 // Sets *e0 / *e1 to an event pair (and records the launch) when profiling is on, leaves them untouched otherwise.

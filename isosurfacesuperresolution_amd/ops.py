@@ -298,7 +298,8 @@ VARIANT_NAMES = {6: "conv3x3_small_cout_kernel", 2: "conv3x3_fwd_kernel<1,false>
                  24: "trunk_mt_kernel",
                  # the frame's small kernels (zero algorithmic flops; registered for bench.py's gap accounting)
                  25: "trunk_pack_input_kernel", 26: "assemble_input_kernel", 27: "tail_finish_kernel", 28: "flow_fill_one_kernel",
-                 29: "finish_frame_kernel", 30: "ups_frame_kernel", 31: "conv3x3_split_upsp_kernel"}
+                 29: "finish_frame_kernel", 30: "ups_frame_kernel", 31: "conv3x3_split_upsp_kernel",
+                 32: "conv3x3_wgrad_split_kernel"}
 
 
 def debug_switches():

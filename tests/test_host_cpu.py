@@ -40,6 +40,29 @@ def test_c_abi_exports_every_declared_symbol(libs):
         assert hasattr(sr, n), n
 
 
+def test_product_library_has_no_diagnostics_and_the_diagnostics_build_has_the_same_abi(libs):
+    """the library a deployment ships (lib/libisr_sr.so) exports nothing named isrDebug* -- checked on the dynamic
+    symbol table, not through ctypes -- and the diagnostics build of the same sources (lib/libisr_sr_diag.so) exports every entry point
+    of the public header plus the switches; ``ops`` tells the two apart."""
+    import subprocess
+    from isosurfacesuperresolution_amd import _native, ops
+    product = os.path.join(_native.LIBDIR, "libisr_sr.so")
+    assert os.path.exists(product) and os.path.exists(_native.SR_DIAG_LIB)
+
+    def exported(path):
+        out = subprocess.run(["nm", "-D", "--defined-only", path], capture_output=True, text=True, check=True).stdout
+        return {l.split()[-1] for l in out.splitlines() if " T " in l}
+    prod, diag = exported(product), exported(_native.SR_DIAG_LIB)
+    assert not [n for n in prod if n.startswith("isrDebug")], sorted(n for n in prod if n.startswith("isrDebug"))
+    switches = {n for n in diag if n.startswith("isrDebug")}
+    assert {"isrDebugSetTrunkFault", "isrDebugSetFlowFillFault", "isrDebugSetSplitUpsForm", "isrDebugSplitState"} <= switches
+    assert {n for n in prod if n.startswith("isr")} == {n for n in diag if n.startswith("isr")} - switches      # the same ABI otherwise
+    for n in _declared("isr_sr_kernels.h"):
+        assert n in prod and n in diag, n
+    assert not hasattr(ops._bind(_native.load(product)), "isrDebugSplitState")
+    assert hasattr(ops._bind(_native.load(_native.SR_DIAG_LIB)), "isrDebugSplitState")
+
+
 def test_padding_helpers(libs):
     _, sr = libs
     assert sr.isrConvCinPad(101) == 112 and sr.isrConvCinPad(64) == 64 and sr.isrConvCinPad(6) == 16
