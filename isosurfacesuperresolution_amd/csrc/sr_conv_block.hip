@@ -24,9 +24,9 @@ namespace {
 constexpr int B_THREADS = 256;
 constexpr int R1_H = ST_H + 2, R1_W = ST_W + 2;                              // 10 x 34: the pixels of t the output tile needs
 constexpr int P1_H = ST_H + 4, P1_W = ST_W + 4;                              // 12 x 36: the patch of x conv1 reads for them
-constexpr int P1_PIX = P1_H * P1_W;                                          // 432
+[[maybe_unused]] constexpr int P1_PIX = P1_H * P1_W;                                          // 432
 constexpr int P1_SEG = 464;                                                  // units per (part, group) of the conv1 slot: 432 + the overrun of the last flat block's taps
-constexpr int P1_UNITS = 4 * P1_SEG;                                         // [hi | lo][2 groups][P1_SEG] = 1856 units
+[[maybe_unused]] constexpr int P1_UNITS = 4 * P1_SEG;                                         // [hi | lo][2 groups][P1_SEG] = 1856 units
 constexpr int R1_PIX = R1_H * R1_W;                                          // 340 = SP_PIX: conv2's patch IS the region of t
 constexpr int B_BLOCKS = 3;                                                  // flat blocks of 32 positions per wave: 4 x 3 x 32 = 384 >= 10 x 36
 constexpr int SCR_UNITS = 2 * 8 * R1_PIX;                                    // scratch per workgroup: [hi | lo][8 groups][340] = 5440 units = 87 040 B
