@@ -255,3 +255,77 @@ def test_tile_mode_composite_equals_unsplit_render(oracle, n, splits):
     bad = dict(tiles[0]); bad["origin"] = (4, 0, 0)
     with pytest.raises(ValueError):
         oracle.OracleVolume(bad["data"], tile=bad)
+
+
+def _two_spheres():
+    """Two soft spheres of different size at asymmetric places (iso 0.5 at radius 12 around voxel (20, 24, 40) and radius 7 around
+    (46, 42, 22), (x, y, z)): nothing about the scene is mirror symmetric, so a flipped axis or a transposed matrix in the camera
+    shows."""
+    z, y, x = np.meshgrid(np.arange(64, dtype=np.float32), np.arange(64, dtype=np.float32), np.arange(64, dtype=np.float32), indexing="ij")
+    v = np.zeros((64, 64, 64), np.float32)
+    spheres = [((20.0, 24.0, 40.0), 12.0), ((46.0, 42.0, 22.0), 7.0)]
+    for (cx, cy, cz), rad in spheres:
+        r = np.sqrt((x - cx) ** 2 + (y - cy) ** 2 + (z - cz) ** 2)
+        v = np.maximum(v, np.clip((rad - r) / 4.0 + 0.5, 0.0, 1.0).astype(np.float32))
+    v[v < 1e-3] = 0.0
+    return v, spheres
+
+
+@pytest.mark.parametrize("origin,fov,res", [((1.3, 0.7, -1.1), 40.0, (120, 80)), ((-0.9, 1.5, 1.2), 55.0, (96, 128)), ((0.2, -1.4, 1.6), 30.0, (150, 100))])
+def test_camera_against_an_independent_pinhole_model_on_an_asymmetric_scene(oracle, origin, fov, res):
+    """The product and the oracle share ONE hand-restated camera (OpenVDB's PerspectiveCamera + Mat4::inverse, DESIGN section 2): a
+    mistake in it is invisible to every HIP-vs-oracle test.  Independent check: the same view through a pinhole model written down
+    from scratch in numpy -- eye at `origin` looking at the world origin, up = +y, `fov` = the full HORIZONTAL angle, rays through
+    pixel centres, rows top to bottom -- and closed-form ray / sphere intersections of an asymmetric two-sphere scene.  Hit mask:
+    everything but silhouette pixels agrees; depth (distance along the ray) to a fraction of a voxel on every pixel both call a hit
+    away from the silhouettes; each sphere's image lands where the model puts it (handedness)."""
+    vol, spheres = _two_spheres()
+    ov = oracle.OracleVolume(vol)
+    info = ov.info()
+    W, H = res
+    origin = V.quantize3(origin)
+    img, _ = oracle.render(ov, oracle.make_params(W, H, origin=origin, fov=fov, isovalue=0.5), threads=4)
+    scale, tr = info["scale"], np.array(info["translation"], float)
+    o = np.array(origin, float)
+    f = -o / np.linalg.norm(o)
+    r = np.cross(f, np.array([0.0, 1.0, 0.0])); r /= np.linalg.norm(r)
+    u = np.cross(r, f)
+    sx = math.tan(math.radians(fov / 2)); sy = sx * H / W
+    jj, ii = np.meshgrid(np.arange(W), np.arange(H))
+    d = f[None, None, :] + (((jj + 0.5) / W * 2 - 1) * sx)[..., None] * r + ((1 - (ii + 0.5) / H * 2) * sy)[..., None] * u
+    d /= np.linalg.norm(d, axis=-1, keepdims=True)
+    t_best = np.full((H, W), np.inf)
+    which = np.full((H, W), -1)
+    margin = np.zeros((H, W))                            # how far inside the silhouette (in units of the radius) the ray passes
+    for k, ((cx, cy, cz), rad) in enumerate(spheres):
+        c = np.array([cx, cy, cz]) * scale + tr          # voxel (x, y, z) -> world (CPURenderer.cpp:448-458: uniform scale + translation)
+        R = rad * scale
+        oc = o - c
+        b = (d * oc).sum(-1); disc = b * b - ((oc * oc).sum() - R * R)
+        t = -b - np.sqrt(np.maximum(disc, 0.0))
+        closer = (disc > 0) & (t < t_best)
+        t_best = np.where(closer, t, t_best); which = np.where(closer, k, which)
+        margin = np.where(closer, np.sqrt(np.maximum(disc, 0.0)) / R, margin)
+    model_hit = np.isfinite(t_best)
+    hit = img[..., 3] == 1
+    assert hit.sum() > 200 and (which == 0).sum() > 100 and (which == 1).sum() > 30
+    # masks differ on silhouette pixels only (the sampled field's isosurface is the sphere to a fraction of a voxel)
+    disagree = hit != model_hit
+    assert disagree.mean() < 0.01, disagree.mean()
+    near_edge = np.zeros_like(hit)
+    for dy in (-1, 0, 1):
+        for dx in (-1, 0, 1):
+            near_edge |= np.roll(np.roll(model_hit, dy, 0), dx, 1) != model_hit
+    assert not (disagree & ~near_edge).any()
+    # depth = distance along the ray: within a third of a voxel wherever the ray passes well inside the silhouette
+    solid = hit & model_hit & (margin > 0.35)
+    assert solid.sum() > 100
+    assert np.abs(img[..., 7][solid] - t_best[solid]).max() < 0.34 * scale, np.abs(img[..., 7][solid] - t_best[solid]).max() / scale
+    # handedness: the pixels of each sphere are where the model says (centroids within a pixel), and the two are far apart
+    for k in (0, 1):
+        m = solid & (which == k)
+        cy_o, cx_o = np.argwhere(m).mean(0)
+        assert abs(cy_o - ii[which == k].mean()) < 1.5 and abs(cx_o - jj[which == k].mean()) < 1.5
+    # camera-space normals: unit length, facing the camera
+    n = img[..., 4:7][solid]
+    assert np.allclose(np.linalg.norm(n, axis=-1), 1.0, atol=1e-5) and (n[:, 2] >= 0).all()
