@@ -296,6 +296,7 @@ def test_camera_against_an_independent_pinhole_model_on_an_asymmetric_scene(orac
     d /= np.linalg.norm(d, axis=-1, keepdims=True)
     t_best = np.full((H, W), np.inf)
     which = np.full((H, W), -1)
+    n_world = np.zeros((H, W, 3))                        # the closed-form outward normal at the model's hit point
     margin = np.zeros((H, W))                            # how far inside the silhouette (in units of the radius) the ray passes
     for k, ((cx, cy, cz), rad) in enumerate(spheres):
         c = np.array([cx, cy, cz]) * scale + tr          # voxel (x, y, z) -> world (CPURenderer.cpp:448-458: uniform scale + translation)
@@ -305,6 +306,7 @@ def test_camera_against_an_independent_pinhole_model_on_an_asymmetric_scene(orac
         t = -b - np.sqrt(np.maximum(disc, 0.0))
         closer = (disc > 0) & (t < t_best)
         t_best = np.where(closer, t, t_best); which = np.where(closer, k, which)
+        n_world = np.where(closer[..., None], (o + t[..., None] * d - c) / R, n_world)
         margin = np.where(closer, np.sqrt(np.maximum(disc, 0.0)) / R, margin)
     model_hit = np.isfinite(t_best)
     hit = img[..., 3] == 1
@@ -326,6 +328,10 @@ def test_camera_against_an_independent_pinhole_model_on_an_asymmetric_scene(orac
         m = solid & (which == k)
         cy_o, cx_o = np.argwhere(m).mean(0)
         assert abs(cy_o - ii[which == k].mean()) < 1.5 and abs(cx_o - jj[which == k].mean()) < 1.5
-    # camera-space normals: unit length, facing the camera
+    # camera-space normals: unit length, facing the camera, and equal to the sphere's own normal in the model's camera frame
+    # (right, up, backward), flipped to z >= 0 -- the central-difference gradient of the sampled field is radial to a few 1e-3
     n = img[..., 4:7][solid]
     assert np.allclose(np.linalg.norm(n, axis=-1), 1.0, atol=1e-5) and (n[:, 2] >= 0).all()
+    n_cam = np.stack([(n_world * r).sum(-1), (n_world * u).sum(-1), -(n_world * f).sum(-1)], -1)
+    n_cam = np.where(n_cam[..., 2:3] < 0, -n_cam, n_cam)
+    assert np.abs(n_cam[solid] - n).max() < 0.03, np.abs(n_cam[solid] - n).max()
