@@ -284,7 +284,8 @@ def test_camera_against_an_independent_pinhole_model_on_an_asymmetric_scene(orac
     info = ov.info()
     W, H = res
     origin = V.quantize3(origin)
-    img, _ = oracle.render(ov, oracle.make_params(W, H, origin=origin, fov=fov, isovalue=0.5), threads=4)
+    last = V.quantize3([origin[0] + 0.15, origin[1] - 0.1, origin[2] + 0.2])      # the camera of the frame before (flow reference)
+    img, _ = oracle.render(ov, oracle.make_params(W, H, origin=origin, fov=fov, isovalue=0.5, last_origin=last), threads=4)
     scale, tr = info["scale"], np.array(info["translation"], float)
     o = np.array(origin, float)
     f = -o / np.linalg.norm(o)
@@ -335,3 +336,13 @@ def test_camera_against_an_independent_pinhole_model_on_an_asymmetric_scene(orac
     n_cam = np.stack([(n_world * r).sum(-1), (n_world * u).sum(-1), -(n_world * f).sum(-1)], -1)
     n_cam = np.where(n_cam[..., 2:3] < 0, -n_cam, n_cam)
     assert np.abs(n_cam[solid] - n).max() < 0.03, np.abs(n_cam[solid] - n).max()
+    # flow (IsoVolumeRayTracer.h:538-547: camera-space x, y of the hit point under the previous camera minus under this one, negated):
+    # the model's hit point through the model's two camera frames
+    ol = np.array(last, float)
+    fl = -ol / np.linalg.norm(ol)
+    rl = np.cross(fl, np.array([0.0, 1.0, 0.0])); rl /= np.linalg.norm(rl)
+    ul = np.cross(rl, fl)
+    P = o + np.where(np.isfinite(t_best), t_best, 0.0)[..., None] * d
+    flow_model = np.stack([((P - o) * r).sum(-1) - ((P - ol) * rl).sum(-1), ((P - o) * u).sum(-1) - ((P - ol) * ul).sum(-1)], -1)
+    assert np.abs(flow_model[solid]).max() > 0.02                              # the two cameras do differ
+    assert np.abs(flow_model[solid] - img[..., 8:10][solid]).max() < 6e-3, np.abs(flow_model[solid] - img[..., 8:10][solid]).max()
