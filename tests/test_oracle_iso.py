@@ -346,3 +346,58 @@ def test_camera_against_an_independent_pinhole_model_on_an_asymmetric_scene(orac
     flow_model = np.stack([((P - o) * r).sum(-1) - ((P - ol) * rl).sum(-1), ((P - o) * u).sum(-1) - ((P - ol) * ul).sum(-1)], -1)
     assert np.abs(flow_model[solid]).max() > 0.02                              # the two cameras do differ
     assert np.abs(flow_model[solid] - img[..., 8:10][solid]).max() < 6e-3, np.abs(flow_model[solid] - img[..., 8:10][solid]).max()
+
+
+@pytest.mark.parametrize("origin,last,fov,res", [((0.9, 0.5, -0.8), (1.0, 0.45, -0.7), 40.0, (120, 80)), ((-0.7, 0.9, 0.8), (-0.75, 0.8, 0.9), 50.0, (96, 128))])
+def test_gvdb_semantics_against_an_independent_camera_model_on_an_asymmetric_scene(oracle, origin, last, fov, res):
+    """The CUDA column's restatement (oracle/iso_oracle_gvdb.c) against the same from-scratch pinhole model and closed-form two-sphere scene
+    as above, with GVDB's conventions written down independently: cell-centred samples (voxel i at i + 0.5), world =
+    (index - centre of the brick bounding box) x 0.5 / its longest edge, image half-width tangent tan(fov / 2) / 2, depth = NDC z with
+    near 0.1 / far 5000, OUTWARD view-space normals (right, up, backward; no flip), flow = 0.5 x the difference of the hit point's NDC x, y
+    under this camera and the previous one."""
+    vol, spheres = _two_spheres()
+    ov = oracle.OracleVolume(vol)
+    info = ov.info()
+    W, H = res
+    img = oracle.render_gvdb(ov, oracle.make_params(W, H, origin=origin, fov=fov, isovalue=0.5, last_origin=last), threads=4)
+    bmin, bmax = np.array(info["node_bbox_min"], float), np.array(info["node_bbox_max"], float)
+    scale, centre = 0.5 / (bmax - bmin).max(), (bmin + bmax) / 2
+
+    def frame(eye):
+        eye = np.array(eye, float)
+        fw = -eye / np.linalg.norm(eye)
+        rt = np.cross(fw, np.array([0.0, 1.0, 0.0])); rt /= np.linalg.norm(rt)
+        return eye, fw, rt, np.cross(rt, fw)
+    o, f, r, u = frame(origin)
+    sx = math.tan(math.radians(fov / 2)) / 2; sy = sx * H / W
+    jj, ii = np.meshgrid(np.arange(W), np.arange(H))
+    d = f[None, None, :] + (((jj + 0.5) / W * 2 - 1) * sx)[..., None] * r + ((1 - (ii + 0.5) / H * 2) * sy)[..., None] * u
+    d /= np.linalg.norm(d, axis=-1, keepdims=True)
+    t_best, n_world, margin = np.full((H, W), np.inf), np.zeros((H, W, 3)), np.zeros((H, W))
+    for (cx, cy, cz), rad in spheres:
+        c = (np.array([cx, cy, cz]) + 0.5 - centre) * scale
+        R = rad * scale
+        oc = o - c
+        b = (d * oc).sum(-1); disc = b * b - ((oc * oc).sum() - R * R)
+        t = -b - np.sqrt(np.maximum(disc, 0.0))
+        closer = (disc > 0) & (t < t_best)
+        t_best = np.where(closer, t, t_best)
+        n_world = np.where(closer[..., None], (o + t[..., None] * d - c) / R, n_world)
+        margin = np.where(closer, np.sqrt(np.maximum(disc, 0.0)) / R, margin)
+    model_hit, hit = np.isfinite(t_best), img[..., 3] == 1
+    assert hit.sum() > 500 and (hit != model_hit).mean() < 0.01
+    solid = hit & model_hit & (margin > 0.35)
+    assert solid.sum() > 300
+    P = o + np.where(model_hit, t_best, 1.0)[..., None] * d
+    near, far = 0.1, 5000.0
+    z_eye = ((P - o) * f).sum(-1)
+    ndc_z = (far + near) / (far - near) - 2 * far * near / ((far - near) * z_eye)
+    assert np.abs(ndc_z[solid] - img[..., 7][solid]).max() < 1e-3
+    n_view = np.stack([(n_world * r).sum(-1), (n_world * u).sum(-1), -(n_world * f).sum(-1)], -1)
+    assert np.abs(n_view[solid] - img[..., 4:7][solid]).max() < 0.03
+
+    def ndc_xy(eye, fw, rt, upv):
+        z = ((P - eye) * fw).sum(-1)
+        return np.stack([((P - eye) * rt).sum(-1) / (z * sx), ((P - eye) * upv).sum(-1) / (z * sy)], -1)
+    flow = 0.5 * (ndc_xy(o, f, r, u) - ndc_xy(*frame(last)))
+    assert np.abs(flow[solid]).max() > 0.02 and np.abs(flow[solid] - img[..., 8:10][solid]).max() < 2e-3
