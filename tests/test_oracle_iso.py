@@ -271,21 +271,17 @@ def _two_spheres():
     return v, spheres
 
 
-@pytest.mark.parametrize("origin,fov,res", [((1.3, 0.7, -1.1), 40.0, (120, 80)), ((-0.9, 1.5, 1.2), 55.0, (96, 128)), ((0.2, -1.4, 1.6), 30.0, (150, 100))])
-def test_camera_against_an_independent_pinhole_model_on_an_asymmetric_scene(oracle, origin, fov, res):
-    """The product and the oracle share ONE hand-restated camera (OpenVDB's PerspectiveCamera + Mat4::inverse, DESIGN section 2): a
-    mistake in it is invisible to every HIP-vs-oracle test.  Independent check: the same view through a pinhole model written down
-    from scratch in numpy -- eye at `origin` looking at the world origin, up = +y, `fov` = the full HORIZONTAL angle, rays through
-    pixel centres, rows top to bottom -- and closed-form ray / sphere intersections of an asymmetric two-sphere scene.  Hit mask:
-    everything but silhouette pixels agrees; depth (distance along the ray) to a fraction of a voxel on every pixel both call a hit
-    away from the silhouettes; each sphere's image lands where the model puts it (handedness)."""
-    vol, spheres = _two_spheres()
-    ov = oracle.OracleVolume(vol)
-    info = ov.info()
-    W, H = res
-    origin = V.quantize3(origin)
-    last = V.quantize3([origin[0] + 0.15, origin[1] - 0.1, origin[2] + 0.2])      # the camera of the frame before (flow reference)
-    img, _ = oracle.render(ov, oracle.make_params(W, H, origin=origin, fov=fov, isovalue=0.5, last_origin=last), threads=4)
+PINHOLE_CASES = [((1.3, 0.7, -1.1), 40.0, (120, 80)), ((-0.9, 1.5, 1.2), 55.0, (96, 128)), ((0.2, -1.4, 1.6), 30.0, (150, 100))]
+
+
+def pinhole_last_camera(origin):
+    """The camera of the frame before (flow reference) used by the independent-model tests."""
+    return V.quantize3([origin[0] + 0.15, origin[1] - 0.1, origin[2] + 0.2])
+
+
+def assert_image_matches_pinhole_model(img, info, spheres, origin, last, fov, W, H):
+    """``img``: a [H, W, 12] render of the two-sphere scene with the CPURenderer semantics (the oracle's, or the HIP product's --
+    tests/test_render_gpu.py checks the product DIRECTLY against this model, without the oracle in between)."""
     scale, tr = info["scale"], np.array(info["translation"], float)
     o = np.array(origin, float)
     f = -o / np.linalg.norm(o)
@@ -348,18 +344,30 @@ def test_camera_against_an_independent_pinhole_model_on_an_asymmetric_scene(orac
     assert np.abs(flow_model[solid] - img[..., 8:10][solid]).max() < 6e-3, np.abs(flow_model[solid] - img[..., 8:10][solid]).max()
 
 
-@pytest.mark.parametrize("origin,last,fov,res", [((0.9, 0.5, -0.8), (1.0, 0.45, -0.7), 40.0, (120, 80)), ((-0.7, 0.9, 0.8), (-0.75, 0.8, 0.9), 50.0, (96, 128))])
-def test_gvdb_semantics_against_an_independent_camera_model_on_an_asymmetric_scene(oracle, origin, last, fov, res):
-    """The CUDA column's restatement (oracle/iso_oracle_gvdb.c) against the same from-scratch pinhole model and closed-form two-sphere scene
-    as above, with GVDB's conventions written down independently (SURVEY R1-R7): cell-centred samples (voxel i at i + 0.5), world =
-    (index - centre of the brick bounding box) x 0.5 / its longest edge, image half-width tangent tan(fov / 2) / 2, depth = NDC z with
-    near 0.1 / far 5000, OUTWARD view-space normals (right, up, backward; no flip), flow = 0.5 x the difference of the hit point's NDC x, y
-    under this camera and the previous one."""
+
+
+@pytest.mark.parametrize("origin,fov,res", PINHOLE_CASES)
+def test_camera_against_an_independent_pinhole_model_on_an_asymmetric_scene(oracle, origin, fov, res):
+    """The product and the oracle share ONE hand-restated camera (OpenVDB's PerspectiveCamera + Mat4::inverse, DESIGN section 2): a
+    mistake in it is invisible to every HIP-vs-oracle test.  Independent check: the same view through a pinhole model written down
+    from scratch in numpy -- eye at `origin` looking at the world origin, up = +y, `fov` = the full HORIZONTAL angle, rays through
+    pixel centres, rows top to bottom -- and closed-form ray / sphere intersections of an asymmetric two-sphere scene.  Hit mask:
+    everything but silhouette pixels agrees; depth (distance along the ray) to a fraction of a voxel on every pixel both call a hit
+    away from the silhouettes; each sphere's image lands where the model puts it (handedness)."""
     vol, spheres = _two_spheres()
     ov = oracle.OracleVolume(vol)
-    info = ov.info()
     W, H = res
-    img = oracle.render_gvdb(ov, oracle.make_params(W, H, origin=origin, fov=fov, isovalue=0.5, last_origin=last), threads=4)
+    origin = V.quantize3(origin)
+    last = pinhole_last_camera(origin)
+    img, _ = oracle.render(ov, oracle.make_params(W, H, origin=origin, fov=fov, isovalue=0.5, last_origin=last), threads=4)
+    assert_image_matches_pinhole_model(img, ov.info(), spheres, origin, last, fov, W, H)
+
+
+GVDB_CASES = [((0.9, 0.5, -0.8), (1.0, 0.45, -0.7), 40.0, (120, 80)), ((-0.7, 0.9, 0.8), (-0.75, 0.8, 0.9), 50.0, (96, 128))]
+
+
+def assert_gvdb_image_matches_model(img, info, spheres, origin, last, fov, W, H):
+    """``img``: a [H, W, 12] render of the two-sphere scene with ``semantics=gvdb`` (the restatement's or the HIP product's)."""
     bmin, bmax = np.array(info["node_bbox_min"], float), np.array(info["node_bbox_max"], float)
     scale, centre = 0.5 / (bmax - bmin).max(), (bmin + bmax) / 2
 
@@ -401,3 +409,17 @@ def test_gvdb_semantics_against_an_independent_camera_model_on_an_asymmetric_sce
         return np.stack([((P - eye) * rt).sum(-1) / (z * sx), ((P - eye) * upv).sum(-1) / (z * sy)], -1)
     flow = 0.5 * (ndc_xy(o, f, r, u) - ndc_xy(*frame(last)))
     assert np.abs(flow[solid]).max() > 0.02 and np.abs(flow[solid] - img[..., 8:10][solid]).max() < 2e-3
+
+
+@pytest.mark.parametrize("origin,last,fov,res", GVDB_CASES)
+def test_gvdb_semantics_against_an_independent_camera_model_on_an_asymmetric_scene(oracle, origin, last, fov, res):
+    """The CUDA column's restatement (oracle/iso_oracle_gvdb.c) against the same from-scratch pinhole model and closed-form two-sphere scene
+    as above, with GVDB's conventions written down independently (SURVEY R1-R7): cell-centred samples (voxel i at i + 0.5), world =
+    (index - centre of the brick bounding box) x 0.5 / its longest edge, image half-width tangent tan(fov / 2) / 2, depth = NDC z with
+    near 0.1 / far 5000, OUTWARD view-space normals (right, up, backward; no flip), flow = 0.5 x the difference of the hit point's NDC x, y
+    under this camera and the previous one."""
+    vol, spheres = _two_spheres()
+    ov = oracle.OracleVolume(vol)
+    W, H = res
+    img = oracle.render_gvdb(ov, oracle.make_params(W, H, origin=origin, fov=fov, isovalue=0.5, last_origin=last), threads=4)
+    assert_gvdb_image_matches_model(img, ov.info(), spheres, origin, last, fov, W, H)

@@ -84,6 +84,53 @@ def test_parity_with_oracle(renderer, oracle, case, variant):
         last = origin
 
 
+@pytest.mark.parametrize("variant", [0, 1])
+@pytest.mark.parametrize("case", [0, 1, 2])
+def test_hip_render_against_the_independent_pinhole_model(renderer, case, variant):
+    """The PRODUCT checked without the oracle in between: the HIP render (through the C-ABI) of the asymmetric two-sphere scene
+    against the from-scratch numpy pinhole camera + closed-form ray / sphere intersections of tests/test_oracle_iso.py -- mask off the
+    silhouettes, per-pixel depth, camera-space normals, flow against the previous camera, handedness.  (The product and the oracle
+    share one hand-restated camera; this is the check that does not.)"""
+    from test_oracle_iso import PINHOLE_CASES, _two_spheres, assert_image_matches_pinhole_model, pinhole_last_camera
+    origin, fov, (W, H) = PINHOLE_CASES[case]
+    vol, spheres = _two_spheres()
+    renderer.set_kernel_variant(variant)
+    renderer.load_dense(vol)
+    origin = V.quantize3(origin)
+    last = pinhole_last_camera(origin)
+    _render_gpu(renderer, W, H, last, fov, 0.5)                       # the frame before: makes `last` the flow reference
+    img = _render_gpu(renderer, W, H, origin, fov, 0.5)
+    gi = renderer.volume_info()
+    nz = np.argwhere(vol != 0)
+    lo, hi = nz.min(0)[::-1].astype(float), nz.max(0)[::-1].astype(float)   # active voxel box (x, y, z)
+    scale = 1.0 / (hi - lo).max()                                        # CPURenderer.cpp:448-458: longest edge of the active box -> 1, centred
+    info = {"scale": scale, "translation": list(-(lo + (hi - lo) / 2) * scale)}
+    assert gi["max_value"] == vol.max()
+    assert_image_matches_pinhole_model(img, info, spheres, origin, last, float("%.3f" % fov), W, H)
+    renderer.set_kernel_variant(0)
+
+
+@pytest.mark.parametrize("case", [0, 1])
+def test_hip_gvdb_render_against_the_independent_model(renderer, case):
+    """... and the same for ``semantics=gvdb`` (the CUDA column's arithmetic): the HIP render directly against GVDB's conventions
+    written down independently (tests/test_oracle_iso.py), no restatement in between."""
+    from test_oracle_iso import GVDB_CASES, _two_spheres, assert_gvdb_image_matches_model
+    origin, last, fov, (W, H) = GVDB_CASES[case]
+    vol, spheres = _two_spheres()
+    renderer.set_kernel_variant(0)
+    renderer.load_dense(vol)
+    nz = np.argwhere(vol != 0)
+    lo8, hi8 = (nz.min(0)[::-1] // 8) * 8, (nz.max(0)[::-1] // 8 + 1) * 8        # the box of the occupied 8^3 bricks (x, y, z)
+    info = {"node_bbox_min": [int(v) for v in lo8], "node_bbox_max": [int(v) for v in hi8]}
+    assert renderer.send_command("semantics", "gvdb") == 0
+    try:
+        _render_gpu(renderer, W, H, last, fov, 0.5)                   # the frame before: the flow reference
+        img = _render_gpu(renderer, W, H, origin, fov, 0.5)
+    finally:
+        assert renderer.send_command("semantics", "cpu") == 0
+    assert_gvdb_image_matches_model(img, info, spheres, origin, last, float("%.3f" % fov), W, H)
+
+
 @pytest.mark.parametrize("variant", [0, 2, 4, 5])
 @pytest.mark.parametrize("axis", ["x", "y", "z", "inside"])
 def test_axis_parallel_rays_and_camera_inside(renderer, oracle, variant, axis):
