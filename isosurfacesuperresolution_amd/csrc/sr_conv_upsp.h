@@ -23,6 +23,9 @@
 // NOT bit-identical to interpolate-then-convolve (different roundings: U(x) is never rounded to fp32 here) and is tested at the
 // same distance from an fp64 convolution as the kernels it replaces (tests/test_upsp_gpu.py).
 #pragma once
+#ifndef UP_BIAS_IN_LOOP
+#define UP_BIAS_IN_LOOP 0
+#endif
 #include "sr_split_common.h"
 
 namespace {
@@ -223,8 +226,10 @@ __global__ __launch_bounds__(S_THREADS, 2) void conv3x3_split_upsp_kernel(const 
                 const float4 bq = *reinterpret_cast<const float4*>(biasl + cb * 32 + 8 * gi + 4 * h);
                 bvv[cb][gi][0] = bq.x; bvv[cb][gi][1] = bq.y; bvv[cb][gi][2] = bq.z; bvv[cb][gi][3] = bq.w;
             }
-        __builtin_amdgcn_s_waitcnt(0xC07F);                                  // lgkmcnt(0): the LDS returns have landed
-        __builtin_amdgcn_sched_barrier(0);
+        if (!UP_BIAS_IN_LOOP) {
+            __builtin_amdgcn_s_waitcnt(0xC07F);                              // lgkmcnt(0): the LDS returns have landed
+            __builtin_amdgcn_sched_barrier(0);
+        }
 #pragma unroll
         for (int r = 0; r < 2; ++r) {
             const int ly = oy0 + wave * 2 + r, Y = 2 * ly + py;
@@ -237,7 +242,7 @@ __global__ __launch_bounds__(S_THREADS, 2) void conv3x3_split_upsp_kernel(const 
                     f16x4 th, tl;
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
-                        float v = acc[cb][r][4 * gi + e] * unscale + bvv[cb][gi][e];
+                        float v = acc[cb][r][4 * gi + e] * unscale + (UP_BIAS_IN_LOOP ? biasl[cb * 32 + 8 * gi + 4 * h + e] : bvv[cb][gi][e]);   // (UP_BIAS_IN_LOOP: round-6 investigation, the first version's bias read)
                         if (p.act == ISR_ACT_RELU) v = v > 0.f ? v : 0.f;
                         else if (p.act == ISR_ACT_LEAKY) v = v > 0.f ? v : v * p.slope;
                         _Float16 a, b;
