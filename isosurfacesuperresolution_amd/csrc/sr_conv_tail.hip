@@ -90,6 +90,7 @@ template <int FORM, bool PSIN>
 __global__ __launch_bounds__(S_THREADS, 2) void conv3x3_split_tail_kernel(const TailParams tp)
 {
     constexpr bool FUSED = FORM == 1;
+    constexpr bool SFORM = FORM == 2 || FORM == 4;                           // horizontal tap sums through the wave's slab (4: + the vertical sums of the tile's inner rows)
     const SplitConvParams& p = tp.c;
     extern __shared__ u32x4 patch[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -219,8 +220,8 @@ __global__ __launch_bounds__(S_THREADS, 2) void conv3x3_split_tail_kernel(const 
     const float zunscale = reinterpret_cast<const float*>(tp.wz)[1];
     float* bias_lds = reinterpret_cast<float*>(wbuf + S_WUNITS);
     if (tid < 64) bias_lds[tid] = p.bias ? p.bias[tid] : 0.0f;
-    const rsrc_t zrs = __builtin_amdgcn_make_buffer_rsrc(tp.z, 0, (int)((size_t)(FORM == 2 ? TS_GROUPS : TZ_ROWS) * tp.zPlane * 4), 0x00020000);
-    const rsrc_t rrs = __builtin_amdgcn_make_buffer_rsrc(tp.srec, 0, FORM == 2 ? (int)((size_t)p.H * p.tilesX * TS_REC * 4) : 0, 0x00020000);
+    const rsrc_t zrs = __builtin_amdgcn_make_buffer_rsrc(tp.z, 0, (int)((size_t)(SFORM ? TS_GROUPS : TZ_ROWS) * tp.zPlane * 4), 0x00020000);
+    const rsrc_t rrs = __builtin_amdgcn_make_buffer_rsrc(tp.srec, 0, SFORM ? (int)((size_t)p.H * p.tilesX * TS_REC * 4) : 0, 0x00020000);
     u32x4 zw[4];                                                             // this thread's 4 of the 1024 units of the z weights
 
     Tile cur = decode(jw);
@@ -254,7 +255,7 @@ __global__ __launch_bounds__(S_THREADS, 2) void conv3x3_split_tail_kernel(const 
         }
         if (more) {
             issue_loads(nxt, 0, slot ^ 1);
-            wfetch(0);
+            if (FORM != 4) wfetch(0);                                        // (V form: requested behind the z stage -- 36 registers the epilogue needs, see below)
         }
 #pragma unroll
         for (int i = 0; i < 4; ++i) zw[i] = tp.wz[1 + tid + i * S_THREADS];   // in flight under the last k-step
@@ -269,6 +270,7 @@ __global__ __launch_bounds__(S_THREADS, 2) void conv3x3_split_tail_kernel(const 
         // transposition slab of this wave (8 KB).  With packed-split input the next tile's first k-step is landing in slot ^ 1 by DMA
         // meanwhile: the slabs then live in the two halves of the slot just multiplied and in the front of the weight buffer
         unsigned ymag = 0u;
+        float sreg[2][9];                                                    // V form: S[g = 9 h + k] of this lane's pixel, both rows of the wave
         float* tr = PSIN ? reinterpret_cast<float*>(wave == 0 ? patch + slot * SQ_SLOT : wave == 1 ? patch + S_PART + slot * SQ_SLOT
                                                               : wbuf + (wave - 2) * 512)
                          : reinterpret_cast<float*>(patch) + wave * (64 * 32);
@@ -313,7 +315,7 @@ __global__ __launch_bounds__(S_THREADS, 2) void conv3x3_split_tail_kernel(const 
                         const int m = mb * 32 + (i & 3) + 8 * (i >> 2) + 4 * h;
                         if (m < TZ_ROWS) zt[(m * ST_H + wave * 2 + r) * ST_W + j] = zacc[i] * zunscale;
                     }
-                } else if (FORM == 2) {                                      // ... into this wave's slab [row][pixel -1 .. 32]; rows >= 56 do not exist
+                } else if (SFORM) {                                          // ... into this wave's slab [row][pixel -1 .. 32]; rows >= 56 do not exist
                     const float zs = (cur.ox0 + j < p.W) ? zunscale : 0.0f; // a pixel beyond the image's right edge contributes nothing to its neighbour
 #pragma unroll
                     for (int i = 0; i < 16; ++i)
@@ -324,7 +326,7 @@ __global__ __launch_bounds__(S_THREADS, 2) void conv3x3_split_tail_kernel(const 
                 }
             }
             if (FUSED) continue;
-            if (FORM == 2) {
+            if (SFORM) {
                 if (lane < TZ_ROWS) { tr[lane * TS_STRIDE] = 0.0f; tr[lane * TS_STRIDE + TS_STRIDE - 1] = 0.0f; }      // the pad columns
                 __builtin_amdgcn_s_waitcnt(0xC07F);                          // lgkmcnt(0): same-wave hand-off through LDS
                 // lane (j, h) adds groups g = 9 h + k, k = 0 .. 8: S[g][pixel j] = (z[dx 0][j - 1] + z[dx 1][j]) + z[dx 2][j + 1]
@@ -334,7 +336,8 @@ __global__ __launch_bounds__(S_THREADS, 2) void conv3x3_split_tail_kernel(const 
 #pragma unroll
                 for (int k = 0; k < 9; ++k) {
                     const float sum = (sb[k * TS_STRIDE] + sb[(TS_GROUPS + k) * TS_STRIDE + 1]) + sb[(2 * TS_GROUPS + k) * TS_STRIDE + 2];
-                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, sum), zrs, (int)sv, k * tp.zPlane * 4, 0);
+                    if (FORM == 4) sreg[r][k] = sum;                         // V form: kept for the vertical sums below
+                    else __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, sum), zrs, (int)sv, k * tp.zPlane * 4, 0);
                 }
                 // the addends of the two end pixels (and of the neighbours' end pixels), 6 x 18 floats per (row, tile):
                 //   A z[dx 0] @ 30, B z[dx 1] @ 31, C z[dx 0] @ 31, D z[dx 1] @ 0, E z[dx 2] @ 1, F z[dx 2] @ 0   (pixel of this row)
@@ -364,6 +367,74 @@ __global__ __launch_bounds__(S_THREADS, 2) void conv3x3_split_tail_kernel(const 
             __builtin_amdgcn_s_waitcnt(0xC07F);                              // reads done before the next row overwrites the slab
         }
         isr_range_note(p.absmax, ymag);
+        if (FORM == 4) {
+            // ---- V form: the vertical sums of the tile's rows where all three source rows lie in the tile.
+            // Every wave leaves the S values of its two rows in its (now dead) slab, [row][group][pixel]; after a barrier lane (j, h) takes
+            // the pixel j of tile row 2 wave + h and adds in the finishing kernel's order, ((bias + S[dy 0] @ Y - 1) + S[dy 1] @ Y) + S[dy 2] @ Y + 1:
+            //   rows 1 .. 6: the whole sum -> plane c (the finishing kernel only finishes the pixel);
+            //   row 7:       (bias + S0 @ 6) + S1 @ 7 -> plane c, the finishing kernel adds S2 of the tile below's row 0;
+            //   row 0:       S1 @ 0 -> plane c, S2 @ 1 -> plane 6 + c (row = tile row), the finishing kernel starts from bias + S0 of the tile above's row 7;
+            //   exports for the neighbours: S2 @ 0 and S0 @ 7 -> plane 12 + c, rows 2 ty and 2 ty + 1.
+            // Per pixel the same additions in the same order as the S form: bit-identical, independent of where tile borders fall.  6 + 3 / 8 x 12 plane rows
+            // per image row instead of 18; the first / last pixel of a tile's 32 still come from the end-pixel records (their S needs the neighbour tile).
+            if (more) wfetch(0);                                             // the next tile's first weights travel under the exchange
+            int jv = j, hv = h;                                              // (laundered: hoisted out of the tile loop the ~60 slab addresses below spill)
+            asm volatile("" : "+v"(jv), "+v"(hv));
+            {
+                float* sw = tr + (9 * hv) * 32 + jv;
+#pragma unroll
+                for (int r = 0; r < 2; ++r)
+#pragma unroll
+                    for (int k = 0; k < 9; ++k) sw[(r * TS_GROUPS + k) * 32] = sreg[r][k];
+            }
+            __syncthreads();
+            __builtin_amdgcn_sched_barrier(0);
+            auto slab_of = [&](int w) -> const float* {
+                return PSIN ? reinterpret_cast<const float*>(w == 0 ? patch + slot * SQ_SLOT : w == 1 ? patch + S_PART + slot * SQ_SLOT : wbuf + (w - 2) * 512)
+                            : reinterpret_cast<const float*>(patch) + w * (64 * 32);
+            };
+            // lane (jv, hv): pixel jv, channels 3 hv .. 3 hv + 2, the wave's two rows one after the other -- row index, branches and slab bases are
+            // wave-uniform (a lane-dependent row made every read a four-way select and every wave run all three row kinds)
+            float b3[3];                                                     // the last layer's bias opens the sums
+#pragma unroll
+            for (int c = 0; c < 3; ++c) b3[c] = tp.bias8[3 * hv + c];
+            const int wvu = __builtin_amdgcn_readfirstlane(wave), ty = cur.oy0 / ST_H, X = cur.ox0 + jv;
+#pragma unroll
+            for (int rloc = 0; rloc < 2; ++rloc) {
+                const int rr = wvu * 2 + rloc, Y = cur.oy0 + rr;            // (scalar)
+                const bool live = Y < p.H && X < p.W;
+                const unsigned pv = live ? (unsigned)(Y * p.W + X) * 4u : BAD_OFFSET;
+                const float* own = slab_of(wvu) + (rloc * TS_GROUPS + 3 * hv) * 32 + jv;           // S[g][jv] of row rr at own[g * 32] (g relative to 3 hv)
+                const float* up = (rloc == 1 ? slab_of(wvu) : slab_of(wvu - 1 < 0 ? 0 : wvu - 1) + TS_GROUPS * 32) + (3 * hv) * 32 + jv;     // row rr - 1
+                const float* dn = (rloc == 0 ? slab_of(wvu) + TS_GROUPS * 32 : slab_of(wvu + 1 > 3 ? 3 : wvu + 1)) + (3 * hv) * 32 + jv;    // row rr + 1
+                float vsum[3];
+                if (rr == 0) {
+                    const unsigned e1 = live ? (unsigned)(ty * p.W + X) * 4u : BAD_OFFSET, e2 = live ? (unsigned)(2 * ty * p.W + X) * 4u : BAD_OFFSET;
+#pragma unroll
+                    for (int c = 0; c < 3; ++c) {
+                        vsum[c] = own[(6 + c) * 32];
+                        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, dn[(12 + c) * 32]), zrs, (int)e1, (6 + 3 * hv + c) * tp.zPlane * 4, 0);
+                        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, own[(12 + c) * 32]), zrs, (int)e2, (12 + 3 * hv + c) * tp.zPlane * 4, 0);
+                    }
+                } else if (rr == ST_H - 1) {
+                    const unsigned e2 = live ? (unsigned)((2 * ty + 1) * p.W + X) * 4u : BAD_OFFSET;
+#pragma unroll
+                    for (int c = 0; c < 3; ++c) {
+                        vsum[c] = (b3[c] + up[c * 32]) + own[(6 + c) * 32];
+                        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, own[c * 32]), zrs, (int)e2, (12 + 3 * hv + c) * tp.zPlane * 4, 0);
+                    }
+                } else {
+                    const bool below = Y + 1 < p.H;                          // (a row outside the image is the convolution's zero padding: skipped)
+#pragma unroll
+                    for (int c = 0; c < 3; ++c) {
+                        vsum[c] = (b3[c] + up[c * 32]) + own[(6 + c) * 32];
+                        if (below) vsum[c] += dn[(12 + c) * 32];
+                    }
+                }
+#pragma unroll
+                for (int c = 0; c < 3; ++c) __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, vsum[c]), zrs, (int)pv, (3 * hv + c) * tp.zPlane * 4, 0);
+            }
+        }
         __syncthreads();
         if (FUSED) {
             const float* zt = reinterpret_cast<const float*>(patch);
@@ -504,6 +575,80 @@ __global__ __launch_bounds__(256) void tail_s_finish_kernel(const TailSFinishPar
             }
 #pragma unroll
             for (int c = 0; c < 6; ++c) v[c] += sv[c];
+        }
+    }
+    isr_finish_pixel(p.fin, X, Y, v);
+}
+
+// V form, second launch: as tail_s_finish_kernel, but only the tiles' first and last rows still have additions to make (and the first /
+// last pixel of a tile's 32 come from the end-pixel records, all three rows of them, as before).
+__global__ __launch_bounds__(256) void tail_v_finish_kernel(const TailSFinishParams p)
+{
+    __shared__ float sedge[16][TS_GROUPS + 1];
+    const int H = 4 * p.fin.h, W = 4 * p.fin.w;
+    const int X0 = blockIdx.x * 256, Y = blockIdx.y, tid = threadIdx.x;
+    for (int t = tid; t < 16 * TS_GROUPS; t += 256) {
+        const int ep = t / TS_GROUPS, g = t - ep * TS_GROUPS;
+        const int tile = X0 / ST_W + (ep >> 1), side = ep & 1;
+        const int py = Y + g / 6 - 1, X = tile * ST_W + side * (ST_W - 1);
+        float val = 0.0f;
+        if (tile < p.tilesX && X < W && (unsigned)py < (unsigned)H) {
+            const float* own = p.rec + ((size_t)py * p.tilesX + tile) * TS_REC + g;
+            float z0, z1, z2;
+            if (side == 0) {
+                z0 = tile > 0 ? own[2 * TS_GROUPS - TS_REC] : 0.0f;                             // C of the tile to the left
+                z1 = own[3 * TS_GROUPS]; z2 = own[4 * TS_GROUPS];                               // D, E
+            } else {
+                z0 = own[0]; z1 = own[TS_GROUPS];                                               // A, B
+                z2 = (tile + 1 < p.tilesX && X + 1 < W) ? own[5 * TS_GROUPS + TS_REC] : 0.0f;   // F of the tile to the right
+            }
+            val = (z0 + z1) + z2;
+        }
+        sedge[ep][g] = val;
+    }
+    __syncthreads();
+    const int X = X0 + tid;
+    if (X >= W) return;
+    const int j = X & (ST_W - 1);
+    const bool edge = j == 0 || j == ST_W - 1;
+    const int ep = (tid >> 5) * 2 + (j == ST_W - 1 ? 1 : 0);
+    float v[6];
+    if (edge) {
+#pragma unroll
+        for (int c = 0; c < 6; ++c) v[c] = p.bias8[c];
+#pragma unroll
+        for (int dy = 0; dy < 3; ++dy) {
+            if ((unsigned)(Y + dy - 1) < (unsigned)H) {
+#pragma unroll
+                for (int c = 0; c < 6; ++c) v[c] += sedge[ep][dy * 6 + c];
+            }
+        }
+    } else {
+        const int r = Y & (ST_H - 1), ty = Y / ST_H;
+        const float* vp = p.s + (size_t)Y * W + X;
+        if (r == 0) {
+#pragma unroll
+            for (int c = 0; c < 6; ++c) v[c] = p.bias8[c];
+            if (Y > 0) {
+                const float* e2 = p.s + (size_t)12 * p.zPlane + (size_t)(2 * (ty - 1) + 1) * W + X;     // S[dy 0] of the tile above's last row
+#pragma unroll
+                for (int c = 0; c < 6; ++c) v[c] += e2[(size_t)c * p.zPlane];
+            }
+#pragma unroll
+            for (int c = 0; c < 6; ++c) v[c] += vp[(size_t)c * p.zPlane];                                // S[dy 1] of this row
+            if (Y + 1 < H) {
+                const float* e1 = p.s + (size_t)6 * p.zPlane + (size_t)ty * W + X;                       // S[dy 2] of the row below
+#pragma unroll
+                for (int c = 0; c < 6; ++c) v[c] += e1[(size_t)c * p.zPlane];
+            }
+        } else {
+#pragma unroll
+            for (int c = 0; c < 6; ++c) v[c] = vp[(size_t)c * p.zPlane];
+            if (r == ST_H - 1 && Y + 1 < H) {
+                const float* e2 = p.s + (size_t)12 * p.zPlane + (size_t)(2 * (ty + 1)) * W + X;          // S[dy 2] of the tile below's first row
+#pragma unroll
+                for (int c = 0; c < 6; ++c) v[c] += e2[(size_t)c * p.zPlane];
+            }
         }
     }
     isr_finish_pixel(p.fin, X, Y, v);
@@ -698,6 +843,8 @@ static int tail_launch(const void* xin, int packed, const void* wq6, const float
         (void)hipFuncSetAttribute((const void*)conv3x3_split_tail_kernel<0, true>, hipFuncAttributeMaxDynamicSharedMemorySize, T_LDS_BYTES);
         (void)hipFuncSetAttribute((const void*)conv3x3_split_tail_kernel<2, false>, hipFuncAttributeMaxDynamicSharedMemorySize, T_LDS_BYTES);
         (void)hipFuncSetAttribute((const void*)conv3x3_split_tail_kernel<2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, T_LDS_BYTES);
+        (void)hipFuncSetAttribute((const void*)conv3x3_split_tail_kernel<4, false>, hipFuncAttributeMaxDynamicSharedMemorySize, T_LDS_BYTES);
+        (void)hipFuncSetAttribute((const void*)conv3x3_split_tail_kernel<4, true>, hipFuncAttributeMaxDynamicSharedMemorySize, T_LDS_BYTES);
     }
     const long long ntiles = (long long)p.tilesX * p.tilesY;
     const long long want = ntiles < slots ? ((ntiles + 7) / 8) * 8 : slots;
@@ -721,12 +868,17 @@ static int tail_launch(const void* xin, int packed, const void* wq6, const float
         TAIL_LAUNCH(1, false);
         const long long threads = 2LL * p.tilesY * W + (long long)H * 2 * p.tilesX;
         ISR_LAUNCH_PROFILED(ISR_VARIANT_TAIL_FINISH, tail_seam_finish_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, s, tp);
-    } else if (g_tail_fused == 2) {
-        if (packed) TAIL_LAUNCH(2, true); else TAIL_LAUNCH(2, false);
+    } else if (g_tail_fused == 2 || g_tail_fused == 4) {
         TailSFinishParams fp;
         fp.fin = tp.fin;
         fp.s = tp.z; fp.rec = tp.srec; fp.zPlane = tp.zPlane; fp.tilesX = p.tilesX; fp.bias8 = bias8;
-        ISR_LAUNCH_PROFILED(ISR_VARIANT_TAIL_FINISH, tail_s_finish_kernel, dim3((unsigned)((W + 255) / 256), (unsigned)H), dim3(256), 0, s, fp);
+        if (g_tail_fused == 4) {
+            if (packed) TAIL_LAUNCH(4, true); else TAIL_LAUNCH(4, false);
+            ISR_LAUNCH_PROFILED(ISR_VARIANT_TAIL_FINISH, tail_v_finish_kernel, dim3((unsigned)((W + 255) / 256), (unsigned)H), dim3(256), 0, s, fp);
+        } else {
+            if (packed) TAIL_LAUNCH(2, true); else TAIL_LAUNCH(2, false);
+            ISR_LAUNCH_PROFILED(ISR_VARIANT_TAIL_FINISH, tail_s_finish_kernel, dim3((unsigned)((W + 255) / 256), (unsigned)H), dim3(256), 0, s, fp);
+        }
     } else {
         if (packed) TAIL_LAUNCH(0, true); else TAIL_LAUNCH(0, false);
         TailFinishParams fp;

@@ -223,6 +223,38 @@ def test_s_form_matches_the_54_plane_form_and_fp64(h, w, diag_lib):
     assert torch.isfinite(out[2][0]).all() and torch.isfinite(out[2][1]).all()
 
 
+@pytest.mark.parametrize("h,w", [(2, 8), (6, 8), (23, 37), (30, 52), (67, 120), (135, 240), (270, 480)])
+def test_v_form_equals_the_s_form_bit_for_bit(h, w, diag_lib):
+    """Form 4: the vertical sums of a tile's inner rows are made in the convolution kernel -- 6 planes per
+    row + the rows 0 / 7 exchanges instead of 18 S planes -- per pixel the same additions in the same order as the S form
+    (((bias + S0) + S1) + S2): EQUAL bit for bit, at ragged sizes (H % 8 != 0, W % 32 != 0) and with the packed-split input the frame uses."""
+    import ctypes
+    from isosurfacesuperresolution_amd import ops
+    lib = diag_lib
+    lib.isrDebugSetTailFused.argtypes = [ctypes.c_int]
+    f4, w6, b6, w8, b8, x, sh = _setup(h, w, seed=h * 13 + w)
+    out = {}
+    try:
+        for form in (2, 4, 4):
+            lib.isrDebugSetTailFused(form)
+            with torch.no_grad():
+                raw, rgb = ops.tail_conv_finish(f4, w6, b6, w8, b8, x, sh)
+                packed = None
+                if h >= 4 and ops.packed_supported(f4, w6, False):
+                    ps = ops.pack_split(f4)
+                    packed = ops.tail_conv_finish(ps, w6, b6, w8, b8, x, sh)
+            torch.cuda.synchronize()
+            if form in out:
+                assert torch.equal(out[form][0], raw) and torch.equal(out[form][1], rgb)      # deterministic
+            out[form] = (raw, rgb, packed)
+    finally:
+        lib.isrDebugSetTailFused(2)
+    assert torch.equal(out[4][0], out[2][0]), (out[4][0] - out[2][0]).abs().max().item()
+    assert (out[4][1] - out[2][1]).abs().max().item() <= 1e-6             # (shading inlined into two kernels: contraction may differ)
+    if out[2][2] is not None:
+        assert torch.equal(out[4][2][0], out[2][2][0])
+
+
 def test_s_form_does_not_depend_on_where_tile_borders_fall():
     """The same pixels as part of images cropped at every horizontal offset 0 .. 33 (every position of a pixel relative to the 32-pixel
     tiles: interior, first, last, next to an end) and two vertical offsets: bit for bit equal two pixels inside the crops."""
