@@ -838,13 +838,17 @@ static int tail_launch(const void* xin, int packed, const void* wq6, const float
         (void)hipGetDevice(&dev);
         if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
         slots = 2 * cus;
+#ifdef ISR_DIAG
         (void)hipFuncSetAttribute((const void*)conv3x3_split_tail_kernel<0, false>, hipFuncAttributeMaxDynamicSharedMemorySize, T_LDS_BYTES);
         (void)hipFuncSetAttribute((const void*)conv3x3_split_tail_kernel<1, false>, hipFuncAttributeMaxDynamicSharedMemorySize, T_LDS_BYTES);
         (void)hipFuncSetAttribute((const void*)conv3x3_split_tail_kernel<0, true>, hipFuncAttributeMaxDynamicSharedMemorySize, T_LDS_BYTES);
+#endif
         (void)hipFuncSetAttribute((const void*)conv3x3_split_tail_kernel<2, false>, hipFuncAttributeMaxDynamicSharedMemorySize, T_LDS_BYTES);
         (void)hipFuncSetAttribute((const void*)conv3x3_split_tail_kernel<2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, T_LDS_BYTES);
+#ifdef ISR_DIAG
         (void)hipFuncSetAttribute((const void*)conv3x3_split_tail_kernel<4, false>, hipFuncAttributeMaxDynamicSharedMemorySize, T_LDS_BYTES);
         (void)hipFuncSetAttribute((const void*)conv3x3_split_tail_kernel<4, true>, hipFuncAttributeMaxDynamicSharedMemorySize, T_LDS_BYTES);
+#endif
     }
     const long long ntiles = (long long)p.tilesX * p.tilesY;
     const long long want = ntiles < slots ? ((ntiles + 7) / 8) * 8 : slots;
@@ -864,6 +868,7 @@ static int tail_launch(const void* xin, int packed, const void* wq6, const float
         if (e0 || e1) hipExtLaunchKernelGGL((conv3x3_split_tail_kernel<FORM, PS>), tgrid, tblock, T_LDS_BYTES, s, e0, e1, 0, tp);      \
         else hipLaunchKernelGGL((conv3x3_split_tail_kernel<FORM, PS>), tgrid, tblock, T_LDS_BYTES, s, tp);                             \
     } while (0)
+#ifdef ISR_DIAG     // the forms beside the default (0: 54 planes, 1: finishing inside the kernel, 4: vertical sums inside the kernel; all measured slower) exist in the diagnostics build only
     if (fused) {
         TAIL_LAUNCH(1, false);
         const long long threads = 2LL * p.tilesY * W + (long long)H * 2 * p.tilesX;
@@ -886,6 +891,16 @@ static int tail_launch(const void* xin, int packed, const void* wq6, const float
         fp.z = tp.z; fp.zPlane = tp.zPlane; fp.bias8 = bias8; fp.taps = g_tail_fused == 3 ? 3 : 9;
         ISR_LAUNCH_PROFILED(ISR_VARIANT_TAIL_FINISH, tail_combine_finish_kernel, dim3((W + 255) / 256, H), dim3(256), 0, s, fp);
     }
+#else
+    {
+        (void)fused;
+        TailSFinishParams fp;
+        fp.fin = tp.fin;
+        fp.s = tp.z; fp.rec = tp.srec; fp.zPlane = tp.zPlane; fp.tilesX = p.tilesX; fp.bias8 = bias8;
+        if (packed) TAIL_LAUNCH(2, true); else TAIL_LAUNCH(2, false);
+        ISR_LAUNCH_PROFILED(ISR_VARIANT_TAIL_FINISH, tail_s_finish_kernel, dim3((unsigned)((W + 255) / 256), (unsigned)H), dim3(256), 0, s, fp);
+    }
+#endif
 #undef TAIL_LAUNCH
     return hipGetLastError() == hipSuccess ? 0 : -2;
 }
