@@ -12,7 +12,8 @@ import subprocess
 _PKG = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_PKG, "csrc")
 LIBDIR = os.path.join(_PKG, "lib")
-RENDERER_LIB = os.path.join(LIBDIR, "libGPURendererDirect.so")
+# ISR_RENDERER_LIB: another build of the renderer (A/B measurements of ray-marcher changes on one box)
+RENDERER_LIB = os.environ.get("ISR_RENDERER_LIB") or os.path.join(LIBDIR, "libGPURendererDirect.so")
 # The PRODUCT build of the super-resolution kernels (csrc/sr_diag.h: no isrDebug* export, no ablation switch in a kernel, none of the
 # experimental kernel forms) and the DIAGNOSTICS build of the same sources (`make diag`: what tools/ and the timeout-path / form-parity
 # tests load -- ops.diagnostics_library()).
@@ -31,7 +32,7 @@ def build(force=False, verbose=False):
         cmd.insert(1, "-B")
     out = None if verbose else subprocess.DEVNULL
     subprocess.check_call(cmd, stdout=out)
-    return [RENDERER_LIB, os.path.join(LIBDIR, "libisr_sr.so"), SR_DIAG_LIB]
+    return [os.path.join(LIBDIR, "libGPURendererDirect.so"), os.path.join(LIBDIR, "libisr_sr.so"), SR_DIAG_LIB]
 
 
 def _preload_hip_runtime():

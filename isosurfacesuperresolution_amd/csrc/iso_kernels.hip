@@ -313,9 +313,10 @@ __device__ __forceinline__ void lvl_init(Lvl& d, const Ray& r, double t0)
 template <int DIM>
 __device__ __forceinline__ void lvl_axis(double dir, double inv, int& S, double& D)
 {
-    if (dir == 0.0) { S = 0; D = DBL_MAX; }
-    else if (inv > 0) { S = DIM; D = (double)S * inv; }
-    else { S = -DIM; D = (double)S * inv; }
+    // (+-DIM) * inv with the sign of inv == DIM * |inv| exactly (a product's magnitude does not depend on the signs), so the
+    // delta needs no int->double conversion and no branch: |inv| is a source modifier, DIM == 1 needs no multiply at all
+    S = dir == 0.0 ? 0 : (inv > 0 ? DIM : -DIM);
+    D = dir == 0.0 ? DBL_MAX : (double)DIM * fabs(inv);
 }
 
 __device__ __forceinline__ double lvl_next(const Lvl& d, double t1)
