@@ -19,9 +19,11 @@ namespace {
 // x2 bilinear upsampling
 // ---------------------------------------------------------------------------------------------------------
 // y[p][Y][X] = hy*(hx*x[y0][x0] + lx*x[y0][x1]) + ly*(hx*x[y1][x0] + lx*x[y1][x1])   (ATen's association)
+// V output pixels per thread: 4 where the output rows are whole quads (even w), 2 for an odd w (the rows are whole pairs: W = 2 w)
+template <int V>
 __global__ __launch_bounds__(256) void upsample2x_fwd_kernel(const float* __restrict__ x, float* __restrict__ y, int h, int w, long long quads)
 {
-    const int W = 2 * w, H = 2 * h, QW = W / 4;
+    const int W = 2 * w, H = 2 * h, QW = W / V;
     for (long long q = (long long)blockIdx.x * 256 + threadIdx.x; q < quads; q += (long long)gridDim.x * 256) {
         const int qx = (int)(q % QW);
         const long long r = q / QW;
@@ -32,15 +34,17 @@ __global__ __launch_bounds__(256) void upsample2x_fwd_kernel(const float* __rest
         const float hy = 1.f - ly;
         const float* r0 = x + (plane * h + y0) * w;
         const float* r1 = x + (plane * h + y1) * w;
-        float o[4];
+        float o[V];
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
+        for (int k = 0; k < V; ++k) {
             int x0, x1; float lx;
-            isr_src_index(4 * qx + k, 0.5f, w, x0, x1, lx);
+            isr_src_index(V * qx + k, 0.5f, w, x0, x1, lx);
             const float hx = 1.f - lx;
             o[k] = hy * (hx * r0[x0] + lx * r0[x1]) + ly * (hx * r1[x0] + lx * r1[x1]);
         }
-        *reinterpret_cast<float4*>(y + (plane * H + Y) * W + 4 * qx) = make_float4(o[0], o[1], o[2], o[3]);
+        float* dst = y + (plane * H + Y) * W + V * qx;
+        if constexpr (V == 4) *reinterpret_cast<float4*>(dst) = make_float4(o[0], o[1], o[2], o[3]);
+        else { dst[0] = o[0]; dst[1] = o[1]; }
     }
 }
 
@@ -757,7 +761,14 @@ int isrAdamFlatStep(float* params, const float* grads, float* exp_avg, float* ex
 
 int isrUpsample2xForward(const float* x, float* y, long long planes, int h, int w, void* stream)
 {
-    if (!x || !y || planes <= 0 || h <= 0 || w <= 0 || (w & 1)) return -1;
+    if (!x || !y || planes <= 0 || h <= 0 || w <= 0) return -1;
+    if ((w & 1) || (((uintptr_t)y) & 15)) {                                   // odd width (or a view that is not 16-byte aligned): pairs of output pixels, scalar stores
+        const long long pairs = planes * (2LL * h) * w;
+        long long blocks = (pairs + 255) / 256;
+        if (blocks > 8192) blocks = 8192;
+        hipLaunchKernelGGL(upsample2x_fwd_kernel<2>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, x, y, h, w, pairs);
+        return hipGetLastError() == hipSuccess ? 0 : -2;
+    }
     const long long quads = planes * (2LL * h) * (2 * w / 4);
     if (!(w & 3) && quads < 0x7fffffffLL && !(((uintptr_t)y | (uintptr_t)x) & 15)) {
         const unsigned count = (unsigned)(quads / 4);                         // a thread per four input pixels
@@ -766,7 +777,7 @@ int isrUpsample2xForward(const float* x, float* y, long long planes, int h, int 
     }
     long long blocks = (quads + 255) / 256;
     if (blocks > 8192) blocks = 8192;
-    hipLaunchKernelGGL(upsample2x_fwd_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, x, y, h, w, quads);
+    hipLaunchKernelGGL(upsample2x_fwd_kernel<4>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, x, y, h, w, quads);
     return hipGetLastError() == hipSuccess ? 0 : -2;
 }
 

@@ -10,7 +10,8 @@ import torch.nn.functional as F
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("shape", [(2, 3, 5, 6), (1, 64, 32, 32), (3, 1, 1, 2), (1, 2, 7, 10), (16, 64, 16, 16), (2, 5, 3, 4), (3, 2, 1, 8), (2, 3, 9, 12)])
+@pytest.mark.parametrize("shape", [(2, 3, 5, 6), (1, 64, 32, 32), (3, 1, 1, 2), (1, 2, 7, 10), (16, 64, 16, 16), (2, 5, 3, 4), (3, 2, 1, 8), (2, 3, 9, 12),
+                                   (2, 3, 5, 7), (1, 2, 4, 1), (1, 1, 3, 5), (2, 64, 17, 33)])   # odd widths: the pair-granular launch
 def test_upsample2x_forward_backward_match_torch(shape):
     from isosurfacesuperresolution_amd import ops
     g = torch.Generator().manual_seed(7)
@@ -28,6 +29,13 @@ def test_upsample2x_forward_backward_match_torch(shape):
     x2 = x.detach().clone().requires_grad_(True)
     ops.bilinear_upsample2x(x2).backward(gy)
     assert torch.equal(x2.grad, x.grad)
+
+
+def test_upsample2x_refuses_other_dtypes_on_the_gpu():
+    """No framework fallback on the GPU: fp32 is what the HIP kernel computes, anything else is an error (as ops.conv3x3)."""
+    from isosurfacesuperresolution_amd import ops
+    with pytest.raises(TypeError):
+        ops.bilinear_upsample2x(torch.zeros(1, 1, 4, 4, dtype=torch.float16, device="cuda"))
 
 
 def _opt(losses, ao=0.0):
