@@ -1052,7 +1052,7 @@ int isoSetKernelVariant(int variant)
 }
 
 // Diagnostics, not part of the public header: while a device buffer of 6 * tiles int64 is set, frames are rendered by the
-// instrumented variant-0 kernel, which also writes per-tile clocks and per-ray step counts (tools/raymarch_stats.py).
+// instrumented variant-0 kernel, which also writes per-tile clocks and per-ray step counts (tools/lab/raymarch_stats.py).
 void isoDebugSetStatsBuffer(unsigned long long devicePtr) { g.statsOut = reinterpret_cast<long long*>(devicePtr); }
 
 int isoProfileEnable(int on)

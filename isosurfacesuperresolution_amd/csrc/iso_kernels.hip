@@ -193,7 +193,7 @@ __device__ __forceinline__ bool has_node2(const IsoRenderParams& P, int x, int y
     return P.any_leaf && x == 0 && y == 0 && z == 0;
 }
 
-// Diagnostics (tools/raymarch_stats.py): what one ray did.  The product kernels pass NoTrace, which compiles to nothing.
+// Diagnostics (tools/lab/raymarch_stats.py): what one ray did.  The product kernels pass NoTrace, which compiles to nothing.
 struct NoTrace { __device__ __forceinline__ void sample(int) {} __device__ __forceinline__ void leaf(bool) {} };
 struct Trace {
     int samples = 0, leaves = 0, skipped = 0;
@@ -279,7 +279,7 @@ __device__ bool hits_hierarchy(const IsoRenderParams& P, Ray& ray, double& time)
 // ---- the same traversal as ONE flat per-lane state machine ------------------------------------------------------------
 // hits_hierarchy() nests four loops; a wave runs them in lock step, so every round of the leaf loop lasts as long as the
 // longest voxel march any of its 64 rays does in that round while the rays whose leaf is skipped wait: the heaviest tile of
-// the bench frame costs 1.13 M cycles although its busiest ray, marched alone, costs 0.26 M (tools/raymarch_lone.py).
+// the bench frame costs 1.13 M cycles although its busiest ray, marched alone, costs 0.26 M (tools/lab/raymarch_lone.py).
 // Here every lane carries a state and each iteration of the single loop does at most WALK hierarchy steps and then ONE
 // trilinear sample -- the leaf's first sample, a march sample or a bisection sample, all through the same code -- so a wave
 // lasts about as long as its busiest ray.  Same operations on the same values in the same per-ray order: bit-identical.

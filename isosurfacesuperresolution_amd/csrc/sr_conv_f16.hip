@@ -57,7 +57,7 @@ struct F16ConvParams {
     int Hin, Win;                 // input size: (H, W), or (H / 2, W / 2) for the upsampling variant
     int quads;                    // 1: W, the plane stride of x and its base address allow aligned dwordx4 staging
     ISR_DIAG_MEMBER(int, dbg, 0);                      // diagnostics: 1 skip the MFMAs, 2 skip the staging loads, 4 skip the stores
-    ISR_DIAG_MEMBER(unsigned long long*, stamps, nullptr);   // diagnostics (tools/bench_conv_f16.py): per-workgroup s_memtime stamps, or NULL
+    ISR_DIAG_MEMBER(unsigned long long*, stamps, nullptr);   // diagnostics (tools/lab/bench_conv_f16.py): per-workgroup s_memtime stamps, or NULL
 };
 
 // round to fp16, saturating (activations of this network are O(1) -- depth, normals, ReLU features of unit-gain

@@ -1298,7 +1298,7 @@ int isrConv3x3ForwardSplit(const float* x, const void* wq, const float* bias, co
     // persistent form: two workgroups per CU walk the tile list with the next k-step's loads in flight under the MFMAs.  It pays
     // when a workgroup has SEVERAL tiles to walk; a launch that fits in one round (the 480 x 270 trunk: 510 tiles on 512 slots)
     // has nothing to stream into and runs faster on the one-workgroup-per-tile form with its 32-channel staging passes (half the
-    // barriers): 37.9 vs 42.5 us per layer in a chain of twenty (tools/bench_trunk_algos.py).  g_split_algo = 3 forces the
+    // barriers): 37.9 vs 42.5 us per layer in a chain of twenty (tools/lab/bench_trunk_algos.py).  g_split_algo = 3 forces the
     // persistent form for every size.
     // (A few rounds do not pay either: the 1024 tiles of a 16 x 64 x 128 x 128 training layer take 66-95 us on the persistent form and
     // the step is 0.35 ms shorter with them on the one-workgroup-per-tile form; the 2040 tiles of a 960 x 540 layer of the tiled 4K

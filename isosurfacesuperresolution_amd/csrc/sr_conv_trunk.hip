@@ -41,7 +41,7 @@
 // saved (the weights stay in L2).
 // Every workgroup must be resident at once: the host refuses images of more than #CUs tiles (the per-layer kernels take those).
 //
-// Measured (tools/bench_trunk.py, tools/trunk_timeline.py; 480 x 270, 21 layers): 0.58-0.65 ms against 0.84 for the first form and
+// Measured (tools/lab/bench_trunk.py, tools/lab/trunk_timeline.py; 480 x 270, 21 layers): 0.58-0.65 ms against 0.84 for the first form and
 // 0.83-1.15 for 21 launches.  Per layer ~29 us: MFMA phase 22 (the 108 x 4 MFMAs of a wave take 17 at the 1.6 GHz the chip holds
 // under this load -- 11 with operands read once, i.e. at full clock), epilogue 2.2, drain 1.4, wait 2.5, halo fetch 1.8.
 #include "sr_diag.h"
@@ -871,7 +871,7 @@ Trunk16Layout trunk16_layout(int cin0, int H, int W)
 
 extern "C" {
 
-/* Diagnostics only (tools/bench_trunk.py): bit 0 skip the MFMAs, 1 skip the activation DMA, 2 skip the stores, 3 skip the waits on
+/* Diagnostics only (tools/lab/bench_trunk.py): bit 0 skip the MFMAs, 1 skip the activation DMA, 2 skip the stores, 3 skip the waits on
  * the neighbours, 4 skip the weight DMA, 5 the MFMAs on operands read once per k-step (no LDS traffic).  Results are wrong with any bit set; bench.py refuses to report with a non-zero
  * isrDebugTrunkState(). */
 #ifdef ISR_DIAG

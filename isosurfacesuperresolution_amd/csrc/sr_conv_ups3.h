@@ -3,7 +3,7 @@
 // namespace); the arithmetic -- interpolation, split, products, their order -- is conv3x3_split_kernel<true>'s: bit-identical.
 //
 // Why.  The tile kernel's workgroup spends 70 % of its life outside the MFMA loop (staging 9 + 8 us, epilogue 7 of 35 us at 1080p,
-// tools/ups_timeline.py) and a CU holds two of them: half the time neither is multiplying (matrix pipe busy 44 %,
+// tools/lab/ups_timeline.py) and a CU holds two of them: half the time neither is multiplying (matrix pipe busy 44 %,
 // profiles/r03_pmc_ups.md).  What keeps a third workgroup out is LDS (80 KB each: a 32-channel patch + a k-step of weights) and
 // registers (184).  Here a workgroup holds ONE k-step of the patch (16 channels, 21.8 KB) and ONE tap row of a k-step's weights
 // (3 taps, 12.3 KB): 34 KB and <= 168 registers (3 weight units per thread in flight instead of 9, 3 staging quads), so three
@@ -153,7 +153,7 @@ __global__ __launch_bounds__(S_THREADS, 3) void conv3x3_split_ups3_kernel(const 
     // so quad (kr, kc) blends the copy's rows kr, kr + 1 and columns kc, kc + 1 with the weights 3/4, 1/4 (upper / left pixel of the
     // quad) and 1/4, 3/4 -- exactly what isr_src_index evaluates to there, as compile-time constants: no index arithmetic, no clamps,
     // no validity selects (~100 of the ~230 vector instructions a unit costs; vector instructions are paid at full price beside the
-    // MFMAs, tools/mfma_valu_overlap.hip).  Same operations on the same values in the same order: bit-identical.
+    // MFMAs, tools/lab/mfma_valu_overlap.hip).  Same operations on the same values in the same order: bit-identical.
     const bool interior = oy0 >= 2 && oy0 + ST_H + 2 <= p.H && ox0 >= 2 && ox0 + ST_W + 2 <= p.W;
     auto interpolate = [&]() {
         _Float16* const patch16 = reinterpret_cast<_Float16*>(patch);

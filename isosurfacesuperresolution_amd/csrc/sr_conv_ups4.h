@@ -271,7 +271,7 @@ __global__ __launch_bounds__(U4_THREADS, 4) void conv3x3_split_ups4_kernel(const
             // of the hi and 8 of the lo' unit.  The lane pair (j, 0) / (j, 1) trades halves (v_permlane32_swap: the upper 32 lanes of one
             // register against the lower 32 of another), after which lane (j, 0) holds the whole hi unit and lane (j, 1) the whole lo'
             // unit: ONE 16-byte store per lane and unit pair instead of two 8-byte ones -- the epilogue is store-ISSUE bound
-            // (tools/bench_ups4.py: 88 of 536 us with 32 b64 stores per wave and tile)
+            // (tools/lab/bench_ups4.py: 88 of 536 us with 32 b64 stores per wave and tile)
             const rsrc_t prs = __builtin_amdgcn_make_buffer_rsrc(p.ps, 0, (int)((size_t)2 * 8 * p.psPlane * 16), 0x00020000);
             const unsigned lopart = (unsigned)h * (unsigned)(8 * p.psPlane) * 16u;
 #pragma unroll

@@ -7,7 +7,7 @@
 // three tap rows of MFMAs -- and relies on the other two workgroups of the CU to multiply meanwhile.  Here the patch is double buffered:
 // while the MFMAs of k-step g read slot g & 1, the SAME waves park k-step g + 1's low-resolution region (tap row 0), interpolate, split
 // and pack it into slot (g + 1) & 1 (tap rows 1 and 2) and request k-step g + 2's region (tap row 2): every tap row is one basic block of
-// 36 MFMAs and ~1/3 of a k-step's staging, for the scheduler to interleave (tools/mfma_valu_overlap.hip: up to ~4 vector instructions
+// 36 MFMAs and ~1/3 of a k-step's staging, for the scheduler to interleave (tools/lab/mfma_valu_overlap.hip: up to ~4 vector instructions
 // per MFMA ride along in the same wave).  The weights of a tap row (hi and lo planes; the partner of the scaled x_lo' is made with
 // v_pk_mul_f16 as in the tile kernel) go through registers into the OTHER of two weight slots at the end of the row before: ONE barrier
 // per tap row (ups3: two).  LDS: 2 x 21.8 KB patch slots + 2 x 12.3 KB weight slots + the 7.2 KB fp32 copy = 75.3 KB: two workgroups per

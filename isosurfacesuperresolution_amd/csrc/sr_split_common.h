@@ -136,7 +136,7 @@ __device__ __forceinline__ void split_epilogue_ps(const SplitConvParams& p, f32x
     // The lane pair (j, 0) / (j, 1) holds the two 8-byte halves of the hi unit and of the lo' unit of a pixel's channel group; they trade
     // halves (v_permlane32_swap: the upper 32 lanes of one register against the lower 32 of another), after which lane (j, 0) holds the
     // whole hi unit and lane (j, 1) the whole lo' unit: ONE 16-byte store per lane instead of two 8-byte ones -- the epilogue is
-    // store-ISSUE bound (tools/bench_ups4.py)
+    // store-ISSUE bound (tools/lab/bench_ups4.py)
     const unsigned lopart = (unsigned)h * (unsigned)(groups * p.psPlane) * 16u;
 #pragma unroll
     for (int r = 0; r < 2; ++r) {

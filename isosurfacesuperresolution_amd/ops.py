@@ -385,7 +385,7 @@ def _launch_small(x, weight, bias, residual, act, slope):
 # Channel-plane padding of large activations.  A [64][1080][1920] fp32 tensor has planes of exactly
 # 2025 x 4 KiB; when the 1080p conv reads 64 such planes and writes 64 more (same rows of every plane at the
 # same time) the accesses alias in the memory system and the layer drops from 125 to 105 TFLOP/s
-# (tools/bench_conv_pad.py: any padding >= 16 floats on BOTH tensors cures it, padding one of them does not).
+# (tools/lab/bench_conv_pad.py: any padding >= 16 floats on BOTH tensors cures it, padding one of them does not).
 # Activations the conv kernels allocate themselves therefore get one extra row between channel planes once a
 # plane reaches PLANE_PAD_MIN_BYTES; every consumer in this package takes the strides from the tensor
 # (`_plane_strides`), anything else sees an ordinary strided view.

@@ -135,7 +135,7 @@ class SuperResolutionPipeline:
         self.side_waves = 4 * torch.cuda.get_device_properties(device).multi_processor_count if self._render_stream else 0
         # kernel variant of the render that runs under the network.  None = the foreground variant: since the flat traversal
         # (0.21 ms alone) the plain kernel beside the network gave 400 frames/s in round 2; the capped 128-register kernel (2), which
-        # round 1's 0.45 ms nested-loop kernel needed, gave 384 (tools/side_sweep.sh)
+        # round 1's 0.45 ms nested-loop kernel needed, gave 384 (tools/lab/side_sweep.sh)
         # (round 3) A ray-march wave shares a SIMD's 512 registers with the convolution waves.  Beside the TILE upsampling kernel (two
         # waves of 184) the 124-register one-sample traversal (variant 5) fits where the 168-register default takes the place of one of
         # them: 503-508 against 491-497 frames/s.  Beside the three-workgroups-per-CU upsampling kernel (3 x 168, the default since)
