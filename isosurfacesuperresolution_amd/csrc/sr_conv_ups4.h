@@ -299,7 +299,7 @@ __global__ __launch_bounds__(U4_THREADS, 4) void conv3x3_split_ups4_kernel(const
                         const u32x2 s0 = __builtin_amdgcn_permlane32_swap(uh.x, ul.x, false, false);
                         const u32x2 s1 = __builtin_amdgcn_permlane32_swap(uh.y, ul.y, false, false);
                         const u32x4 unit = {s0.x, s1.x, s0.y, s1.y};        // h = 0: channels 8 g .. + 7 hi; h = 1: the same channels' lo'
-                        __builtin_amdgcn_raw_buffer_store_b128(unit, prs, (int)voff, (cb * 4 + gi) * p.psPlane * 16, 0);
+                        __builtin_amdgcn_raw_buffer_store_b128(unit, prs, (int)(voff == BAD_OFFSET ? BAD_OFFSET : voff + (unsigned)((cb * 4 + gi) * p.psPlane * 16)), 0, 0);   // (soffset 0: sr_split_common.h)
                     }
             }
         } else {

@@ -218,6 +218,9 @@ __global__ __launch_bounds__(S_THREADS, 2) void conv3x3_split_upsp_kernel(const 
         // 16-byte store reads its data registers a little AFTER it issues, the LDS return is not ordered against that, and with two
         // workgroups per CU (a busier memory pipeline) the first dword of the unit -- 8 lanes of one channel -- was overwritten by bias
         // bits before the store had taken it.  The hazard recogniser guards vector-ALU writes behind wide stores, not LDS returns.
+        // (Round 6: the LDS-return reading never reproduced in isolation; what does reproduce is a VECTOR write in the issue slot behind a
+        //  16-byte store whose soffset is an SGPR -- the one case the recogniser does not pad: tools/probes/store_valu_overwrite_probe.hip.
+        //  The stores below carry their plane offset in the vector offset now.)
         float bvv[2][4][4];
 #pragma unroll
         for (int cb = 0; cb < 2; ++cb)
@@ -255,7 +258,7 @@ __global__ __launch_bounds__(S_THREADS, 2) void conv3x3_split_upsp_kernel(const 
                     const u32x2 s0 = __builtin_amdgcn_permlane32_swap(uh.x, ul.x, false, false);
                     const u32x2 s1 = __builtin_amdgcn_permlane32_swap(uh.y, ul.y, false, false);
                     const u32x4 unit = {s0.x, s1.x, s0.y, s1.y};            // h = 0: channels 8 g .. + 7 hi; h = 1: the same channels' lo'
-                    __builtin_amdgcn_raw_buffer_store_b128(unit, prs, (int)((p.dbg & 16) ? BAD_OFFSET : voff), g * p.psPlane * 16, 0);
+                    __builtin_amdgcn_raw_buffer_store_b128(unit, prs, (int)(((p.dbg & 16) || voff == BAD_OFFSET) ? BAD_OFFSET : voff + (unsigned)(g * p.psPlane * 16)), 0, 0);   // (soffset 0: sr_split_common.h)
                 }
             }
         }
@@ -440,7 +443,7 @@ __global__ __launch_bounds__(S_THREADS, 2) void conv3x3_split_upsq_kernel(const 
                     const u32x2 s0 = __builtin_amdgcn_permlane32_swap(uh.x, ul.x, false, false);
                     const u32x2 s1 = __builtin_amdgcn_permlane32_swap(uh.y, ul.y, false, false);
                     const u32x4 unit = {s0.x, s1.x, s0.y, s1.y};
-                    __builtin_amdgcn_raw_buffer_store_b128(unit, prs, (int)((p.dbg & 16) ? BAD_OFFSET : voff), g * p.psPlane * 16, 0);
+                    __builtin_amdgcn_raw_buffer_store_b128(unit, prs, (int)(((p.dbg & 16) || voff == BAD_OFFSET) ? BAD_OFFSET : voff + (unsigned)(g * p.psPlane * 16)), 0, 0);   // (soffset 0: sr_split_common.h)
                 }
             }
         }

@@ -119,8 +119,20 @@ __device__ __forceinline__ f32x16 mfma16(f16x8 a, f16x8 b, f32x16 c) { return __
 // Packed-split epilogue: act(acc 2^-S + bias) of this wave's two rows as (hi, lo') units straight from the D layout -- lane (j, h)
 // holds channels 8 g + 4 h .. + 3 of pixel j for the four groups g of a 32-channel block: 8 bytes of the unit, the lane pair
 // (j, 0), (j, 1) writes the 16, a wave instruction 512 contiguous bytes.  No LDS transposition.
-__device__ __forceinline__ void split_epilogue_ps(const SplitConvParams& p, f32x16 (&acc)[2][2], int oy0, int ox0, int co0, bool second,
-                                                  int wave, int j, int h)
+// The activation as a compile-time constant: with `p.act` tested per value the compiler kept the test -- three scalar compares and
+// taken branches around every one of a wave's 64 output values (round 6, the disassembly of the 1080p layer's epilogue: 148
+// instructions per group of four values).  The epilogues switch ONCE and run straight-line code.
+template <int ACT>
+__device__ __forceinline__ float isr_activate(float v, float slope)
+{
+    if (ACT == ISR_ACT_RELU) return v > 0.f ? v : 0.f;
+    if (ACT == ISR_ACT_LEAKY) return v > 0.f ? v : v * slope;
+    return v;
+}
+
+template <int ACT>
+__device__ __forceinline__ void split_epilogue_ps_act(const SplitConvParams& p, f32x16 (&acc)[2][2], int oy0, int ox0, int co0, bool second,
+                                                      int wave, int j, int h)
 {
     const float unscale = reinterpret_cast<const float*>(p.wq)[1];
     const int groups = p.Cout >> 3;
@@ -150,9 +162,7 @@ __device__ __forceinline__ void split_epilogue_ps(const SplitConvParams& p, f32x
                 f16x4 th, tl;
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
-                    float v = acc[cb][r][4 * gi + e] * unscale + bv[cb][4 * gi + e];
-                    if (p.act == ISR_ACT_RELU) v = v > 0.f ? v : 0.f;
-                    else if (p.act == ISR_ACT_LEAKY) v = v > 0.f ? v : v * p.slope;
+                    const float v = isr_activate<ACT>(acc[cb][r][4 * gi + e] * unscale + bv[cb][4 * gi + e], p.slope);
                     _Float16 a, b;
                     split16x(v, a, b);
                     th[e] = a; tl[e] = b;
@@ -164,11 +174,22 @@ __device__ __forceinline__ void split_epilogue_ps(const SplitConvParams& p, f32x
                 const u32x2 s0 = __builtin_amdgcn_permlane32_swap(uh.x, ul.x, false, false);
                 const u32x2 s1 = __builtin_amdgcn_permlane32_swap(uh.y, ul.y, false, false);
                 const u32x4 unit = {s0.x, s1.x, s0.y, s1.y};                // h = 0: channels 8 g .. + 7 hi; h = 1: the same channels' lo'
-                __builtin_amdgcn_raw_buffer_store_b128(unit, prs, (int)((live && !(p.dbg & 16)) ? voff : BAD_OFFSET), g * p.psPlane * 16, 0);
+                // (the plane offset travels in the VECTOR offset, soffset = 0: behind a 16-byte store with an SGPR soffset the compiler pads
+                //  nothing, and a vector instruction that writes one of its data registers in the next issue slot replaces lanes 12-15 of
+                //  every 16 of that dword in memory -- tools/probes/store_valu_overwrite_probe.hip; with soffset 0 it pads two wait states)
+                __builtin_amdgcn_raw_buffer_store_b128(unit, prs, (int)((live && !(p.dbg & 16)) ? voff + (unsigned)(g * p.psPlane * 16) : BAD_OFFSET), 0, 0);
             }
         }
     }
     isr_range_note(p.absmax, mag);
+}
+
+__device__ __forceinline__ void split_epilogue_ps(const SplitConvParams& p, f32x16 (&acc)[2][2], int oy0, int ox0, int co0, bool second,
+                                                  int wave, int j, int h)
+{
+    if (p.act == ISR_ACT_RELU) split_epilogue_ps_act<ISR_ACT_RELU>(p, acc, oy0, ox0, co0, second, wave, j, h);
+    else if (p.act == ISR_ACT_LEAKY) split_epilogue_ps_act<ISR_ACT_LEAKY>(p, acc, oy0, ox0, co0, second, wave, j, h);
+    else split_epilogue_ps_act<ISR_ACT_NONE>(p, acc, oy0, ox0, co0, second, wave, j, h);
 }
 
 // WIDE_ONLY: the caller guarantees W and both plane strides are multiples of 4 (the per-element path is not compiled in).
