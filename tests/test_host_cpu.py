@@ -63,6 +63,37 @@ def test_product_library_has_no_diagnostics_and_the_diagnostics_build_has_the_sa
     assert hasattr(ops._bind(_native.load(_native.SR_DIAG_LIB)), "isrDebugSplitState")
 
 
+def test_no_sixteen_byte_store_with_an_sgpr_soffset_in_the_built_libraries(libs, tmp_path):
+    """Round 6 (tools/probes/store_valu_overwrite_probe.hip): a 16-byte buffer store reads its data registers during the issue slots behind
+    it; the compiler pads those slots only when the store's soffset is NOT an SGPR, and with an SGPR soffset gfx950 still needs one wait
+    state -- a vector write into a data register there replaces lanes 12-15 of every 16 in memory.  The sources pass soffset = 0 to every
+    16-byte store; this test reads the device code of the built libraries and fails if a > 8-byte store with a register soffset is back."""
+    import re
+    import shutil
+    import subprocess
+    from isosurfacesuperresolution_amd import _native
+    objdump = "/opt/rocm/lib/llvm/bin/llvm-objdump"
+    if not os.path.exists(objdump):
+        pytest.skip("no llvm-objdump in this image")
+    wide = re.compile(r"buffer_store_dwordx[34]\s")
+    register_soffset = re.compile(r"s\[\d+:\d+\],\s*(s\d+|m0|ttmp\d+|vcc_lo|vcc_hi)\b")
+    seen = 0
+    for lib in (os.path.join(_native.LIBDIR, "libGPURendererDirect.so"), os.path.join(_native.LIBDIR, "libisr_sr.so"), _native.SR_DIAG_LIB):
+        work = tmp_path / os.path.basename(lib)
+        work.mkdir()
+        shutil.copy(lib, work)                      # (--offloading writes the bundles next to the file it reads)
+        subprocess.run([objdump, "--offloading", os.path.basename(lib)], cwd=work, capture_output=True, check=True)
+        objects = [f for f in os.listdir(work) if f.endswith("gfx950")]
+        assert objects, "no gfx950 code object in %s" % lib
+        for obj in objects:
+            text = subprocess.run([objdump, "-d", obj], cwd=work, capture_output=True, text=True, check=True).stdout
+            for line in text.splitlines():
+                if wide.search(line):
+                    seen += 1
+                    assert not register_soffset.search(line), "%s: %s" % (os.path.basename(lib), line.strip())
+    assert seen > 50                                # (the epilogues' wide stores were found and looked at)
+
+
 def test_padding_helpers(libs):
     _, sr = libs
     assert sr.isrConvCinPad(101) == 112 and sr.isrConvCinPad(64) == 64 and sr.isrConvCinPad(6) == 16
