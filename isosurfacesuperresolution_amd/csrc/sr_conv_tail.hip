@@ -484,6 +484,7 @@ __global__ __launch_bounds__(S_THREADS, 2) void conv3x3_split_tail_kernel(const 
     }
 }
 
+#ifdef ISR_DIAG      // (form 0's second launch: the diagnostics build only)
 // Second launch: out[c][q] = b[c] + sum over the nine taps, in tap order, of z[t][c][q + d_t]  (taps that fall outside the
 // image are the convolution's zero padding), then the frame's finishing code.  One thread per high-resolution pixel.
 struct TailFinishParams {
@@ -514,6 +515,7 @@ __global__ __launch_bounds__(256) void tail_combine_finish_kernel(const TailFini
     }
     isr_finish_pixel(p.fin, X, Y, v);
 }
+#endif
 
 // S form, second launch: one thread per high-resolution pixel, a block = 256 consecutive pixels of row Y (eight tiles).
 //     out = ((bias + S[dy 0] @ Y - 1) + S[dy 1] @ Y) + S[dy 2] @ Y + 1        (rows outside the image skipped: the convolution's zero padding)
@@ -580,6 +582,7 @@ __global__ __launch_bounds__(256) void tail_s_finish_kernel(const TailSFinishPar
     isr_finish_pixel(p.fin, X, Y, v);
 }
 
+#ifdef ISR_DIAG      // (form 4's second launch: the diagnostics build only)
 // V form, second launch: as tail_s_finish_kernel, but only the tiles' first and last rows still have additions to make (and the first /
 // last pixel of a tile's 32 come from the end-pixel records, all three rows of them, as before).
 __global__ __launch_bounds__(256) void tail_v_finish_kernel(const TailSFinishParams p)
@@ -653,7 +656,9 @@ __global__ __launch_bounds__(256) void tail_v_finish_kernel(const TailSFinishPar
     }
     isr_finish_pixel(p.fin, X, Y, v);
 }
+#endif
 
+#ifdef ISR_DIAG      // (form 1's second launch: the diagnostics build only)
 // Fused form, second launch: the seam pixels (30 % of the image at 8 x 32 tiles) from their records, same order of additions.
 __global__ __launch_bounds__(256) void tail_seam_finish_kernel(const TailParams tp)
 {
@@ -686,6 +691,7 @@ __global__ __launch_bounds__(256) void tail_seam_finish_kernel(const TailParams 
     }
     isr_finish_pixel(tp.fin, X, Y, v);
 }
+#endif
 
 // w8 [6][64][3][3] fp32 -> header + [q][part][h][m] units: element e of (q, h) is y6 channel 32 (q >> 1) + 16 (q & 1) + (e & 3) +
 // 8 (e >> 2) + 4 h, row m = tail_zrow(t, c) holds w8[c][.][t] 2^S (rows >= 54 zero); part 0 = hi, 1 = lo

@@ -1010,13 +1010,17 @@ static int trunk_dataflow_launch(const float* x, bool prepacked, int cin0, long 
     static bool attr = false;
     if (!attr) {
         (void)hipFuncSetAttribute((const void*)trunk_dataflow_kernel<false, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, T16_LDS_BYTES);
-        (void)hipFuncSetAttribute((const void*)trunk_dataflow_kernel<true, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, T16_LDS_BYTES);
         (void)hipFuncSetAttribute((const void*)trunk_dataflow_kernel<false, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, T16_LDS_BYTES);
+#ifdef ISR_DIAG                                                              // (the diagnostics instantiations exist in the diagnostics build only)
+        (void)hipFuncSetAttribute((const void*)trunk_dataflow_kernel<true, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, T16_LDS_BYTES);
         (void)hipFuncSetAttribute((const void*)trunk_dataflow_kernel<true, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, T16_LDS_BYTES);
+#endif
         (void)hipFuncSetAttribute((const void*)trunk_mt_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, T16_LDS_BYTES);
         attr = true;
     }
+#ifdef ISR_DIAG
     const bool diag = p.dbg != 0 || p.stamps != nullptr;
+#endif
     const int npix = H * W;
     if (!prepacked)
         ISR_LAUNCH_PROFILED(ISR_VARIANT_TRUNK_PACK, trunk_pack_input_kernel, dim3((unsigned)((npix + 255) / 256), (unsigned)(lay.groups0 > 8 ? lay.groups0 : 8)), dim3(256), 0, s,
@@ -1034,16 +1038,24 @@ static int trunk_dataflow_launch(const float* x, bool prepacked, int cin0, long 
         else hipLaunchKernelGGL(trunk_mt_kernel, mgrid, block, T16_LDS_BYTES, s, p);
     } else if (g_trunk_rows == 4) {
         const dim3 block4(256);
+#ifdef ISR_DIAG
         if (diag) {
             if (e0 || e1) hipExtLaunchKernelGGL((trunk_dataflow_kernel<true, 4>), grid, block4, T16_LDS_BYTES, s, e0, e1, 0, p);
             else hipLaunchKernelGGL((trunk_dataflow_kernel<true, 4>), grid, block4, T16_LDS_BYTES, s, p);
-        } else if (e0 || e1) hipExtLaunchKernelGGL((trunk_dataflow_kernel<false, 4>), grid, block4, T16_LDS_BYTES, s, e0, e1, 0, p);
+        } else
+#endif
+        if (e0 || e1) hipExtLaunchKernelGGL((trunk_dataflow_kernel<false, 4>), grid, block4, T16_LDS_BYTES, s, e0, e1, 0, p);
         else hipLaunchKernelGGL((trunk_dataflow_kernel<false, 4>), grid, block4, T16_LDS_BYTES, s, p);
-    } else if (diag) {
-        if (e0 || e1) hipExtLaunchKernelGGL((trunk_dataflow_kernel<true, 2>), grid, block, T16_LDS_BYTES, s, e0, e1, 0, p);
-        else hipLaunchKernelGGL((trunk_dataflow_kernel<true, 2>), grid, block, T16_LDS_BYTES, s, p);
-    } else if (e0 || e1) hipExtLaunchKernelGGL((trunk_dataflow_kernel<false, 2>), grid, block, T16_LDS_BYTES, s, e0, e1, 0, p);
-    else hipLaunchKernelGGL((trunk_dataflow_kernel<false, 2>), grid, block, T16_LDS_BYTES, s, p);
+    } else {
+#ifdef ISR_DIAG
+        if (diag) {
+            if (e0 || e1) hipExtLaunchKernelGGL((trunk_dataflow_kernel<true, 2>), grid, block, T16_LDS_BYTES, s, e0, e1, 0, p);
+            else hipLaunchKernelGGL((trunk_dataflow_kernel<true, 2>), grid, block, T16_LDS_BYTES, s, p);
+        } else
+#endif
+        if (e0 || e1) hipExtLaunchKernelGGL((trunk_dataflow_kernel<false, 2>), grid, block, T16_LDS_BYTES, s, e0, e1, 0, p);
+        else hipLaunchKernelGGL((trunk_dataflow_kernel<false, 2>), grid, block, T16_LDS_BYTES, s, p);
+    }
     return hipGetLastError() == hipSuccess ? 0 : -2;
 }
 
