@@ -195,8 +195,9 @@ __device__ __forceinline__ void split_epilogue_ps(const SplitConvParams& p, f32x
 // WIDE_ONLY: the caller guarantees W and both plane strides are multiples of 4 (the per-element path is not compiled in).
 // AUX: cache policy of the output stores (0 plain; 16 = sc1, write-through to memory: the dataflow kernels' hand-off, see
 // sr_conv_trunk.hip).
-template <bool WIDE_ONLY = false, int AUX = 0, bool RES_AHEAD = false>
-__device__ __forceinline__ void split_epilogue(const SplitConvParams& p, f32x16 (&acc)[2][2], u32x4* patch, int n, int oy0, int ox0, int co0,
+// (ACT: the activation as a compile-time constant, see isr_activate; split_epilogue below switches once)
+template <int ACT, bool WIDE_ONLY, int AUX, bool RES_AHEAD>
+__device__ __forceinline__ void split_epilogue_act(const SplitConvParams& p, f32x16 (&acc)[2][2], u32x4* patch, int n, int oy0, int ox0, int co0,
                                                bool second, int lane, int wave, int j, int h)
 {
     const float unscale = reinterpret_cast<const float*>(p.wq)[1];          // 2^-S (header of the prepared weights)
@@ -239,9 +240,7 @@ __device__ __forceinline__ void split_epilogue(const SplitConvParams& p, f32x16 
             for (int cb = 0; cb < 2; ++cb)
 #pragma unroll
                 for (int i = 0; i < 16; ++i) {
-                    float v = acc[cb][r][i] * unscale + bv[cb][i];
-                    if (p.act == ISR_ACT_RELU) v = v > 0.f ? v : 0.f;
-                    else if (p.act == ISR_ACT_LEAKY) v = v > 0.f ? v : v * p.slope;
+                    const float v = isr_activate<ACT>(acc[cb][r][i] * unscale + bv[cb][i], p.slope);
                     tr[(cb * 32 + (i & 3) + 8 * (i >> 2) + 4 * h) * 32 + j] = v;
                 }
             __builtin_amdgcn_s_waitcnt(0xC07F);                              // lgkmcnt(0): same-wave hand-off through LDS
@@ -255,7 +254,7 @@ __device__ __forceinline__ void split_epilogue(const SplitConvParams& p, f32x16 
                 if (p.residual) {
                     if (!RES_AHEAD) rq[r][t] = __builtin_amdgcn_raw_buffer_load_b128(rrs, (int)(ok ? pixoff + (unsigned)co * (unsigned)p.rPlane * 4u : BAD_OFFSET), 0, 0);
                     const float4 rf = __builtin_bit_cast(float4, rq[r][t]);
-                    if (p.act == ISR_ACT_GATE) {
+                    if (ACT == ISR_ACT_GATE) {
                         v.x = rf.x > 0.f ? v.x : 0.f; v.y = rf.y > 0.f ? v.y : 0.f;
                         v.z = rf.z > 0.f ? v.z : 0.f; v.w = rf.w > 0.f ? v.w : 0.f;
                     } else {
@@ -279,13 +278,11 @@ __device__ __forceinline__ void split_epilogue(const SplitConvParams& p, f32x16 
 #pragma unroll
             for (int i = 0; i < 16; ++i) {
                 const int co = co0 + cb * 32 + (i & 3) + 8 * (i >> 2) + 4 * h;
-                float v = acc[cb][r][i] * unscale + bv[cb][i];
-                if (p.act == ISR_ACT_RELU) v = v > 0.f ? v : 0.f;
-                else if (p.act == ISR_ACT_LEAKY) v = v > 0.f ? v : v * p.slope;
+                float v = isr_activate<ACT>(acc[cb][r][i] * unscale + bv[cb][i], p.slope);
                 const bool ok = pix != BAD_OFFSET && co < p.Cout;
                 if (p.residual) {
                     const float rv = buf_load(rrs, ok ? pix + (unsigned)co * (unsigned)p.rPlane * 4u : BAD_OFFSET);
-                    if (p.act == ISR_ACT_GATE) v = rv > 0.f ? v : 0.f; else v += rv;
+                    if (ACT == ISR_ACT_GATE) v = rv > 0.f ? v : 0.f; else v += rv;
                 }
                 if (ok) mag = isr_umax(mag, isr_mag(v));
                 __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), yrs,
@@ -301,6 +298,16 @@ __device__ __forceinline__ void split_epilogue(const SplitConvParams& p, f32x16 
         if (lane == 0) atomicMax(p.slotmax + blockIdx.x * 4 + wave, m);
     }
     isr_range_note(p.absmax, mag);
+}
+
+template <bool WIDE_ONLY = false, int AUX = 0, bool RES_AHEAD = false>
+__device__ __forceinline__ void split_epilogue(const SplitConvParams& p, f32x16 (&acc)[2][2], u32x4* patch, int n, int oy0, int ox0, int co0,
+                                               bool second, int lane, int wave, int j, int h)
+{
+    if (p.act == ISR_ACT_RELU) split_epilogue_act<ISR_ACT_RELU, WIDE_ONLY, AUX, RES_AHEAD>(p, acc, patch, n, oy0, ox0, co0, second, lane, wave, j, h);
+    else if (p.act == ISR_ACT_LEAKY) split_epilogue_act<ISR_ACT_LEAKY, WIDE_ONLY, AUX, RES_AHEAD>(p, acc, patch, n, oy0, ox0, co0, second, lane, wave, j, h);
+    else if (p.act == ISR_ACT_GATE) split_epilogue_act<ISR_ACT_GATE, WIDE_ONLY, AUX, RES_AHEAD>(p, acc, patch, n, oy0, ox0, co0, second, lane, wave, j, h);
+    else split_epilogue_act<ISR_ACT_NONE, WIDE_ONLY, AUX, RES_AHEAD>(p, acc, patch, n, oy0, ox0, co0, second, lane, wave, j, h);
 }
 
 // One k-step of MFMAs: 16 input channels x 9 taps x (2 channel blocks x 2 rows) x 3 products.  wl: this lane's weight
