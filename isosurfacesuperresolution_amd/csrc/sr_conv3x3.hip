@@ -29,6 +29,7 @@
 #include "../../include/isr_sr_kernels.h"
 #include "sr_finish.h"
 #include "sr_profile.h"
+#include "sr_act.h"
 
 // Launch with start/stop events on the dispatch packet when profiling, as a plain launch otherwise (plain launches can be
 // captured into a HIP graph -- train.GraphedTrainStep -- the Ext form cannot be relied upon there).
@@ -369,6 +370,8 @@ __device__ __forceinline__ void conv_epilogue(const ConvParams& p, f32x16 (&acc)
         for (int i = 0; i < 16; ++i)
             bv[m][i] = p.bias[min(co0 + m * 32 + (i & 3) + 8 * (i >> 2) + 4 * kh, p.Cout - 1)];
     const int planeBytes = p.yPlane * 4, rplaneBytes = p.rPlane * 4;
+    isr_with_act(p.act, [&](auto A) {                                       // (one switch, not one per value: sr_act.h)
+    constexpr int ACT = decltype(A)::value;
     if (((p.W | p.yPlane | p.rPlane) & 3) == 0) {
         // Wide path: each wave transposes one output row (64 couts x 32 pixels) through its own 8 KB
         // of the now idle LDS, so that a lane owns 4 consecutive pixels of one channel and the
@@ -382,9 +385,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvParams& p, f32x16 (&acc)
             for (int m = 0; m < MT; ++m)
 #pragma unroll
                 for (int i = 0; i < 16; ++i) {
-                    float v = acc[m][r][i] + bv[m][i];
-                    if (p.act == ISR_ACT_RELU) v = v > 0.f ? v : 0.f;
-                    else if (p.act == ISR_ACT_LEAKY) v = v > 0.f ? v : v * p.slope;
+                    const float v = isr_activate<ACT>(acc[m][r][i] + bv[m][i], p.slope);
                     tr[(m * 32 + (i & 3) + 8 * (i >> 2) + 4 * kh) * 32 + j] = v;
                 }
             // same-wave hand-off: LDS operations of one wave complete in order
@@ -402,7 +403,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvParams& p, f32x16 (&acc)
                     const unsigned roffs = ok ? off + (unsigned)((co0 + co) * rplaneBytes) : BAD_OFFSET;
                     const u32x4 rr = __builtin_amdgcn_raw_buffer_load_b128(rrs, (int)roffs, 0, 0);
                     const float4 rf = __builtin_bit_cast(float4, rr);
-                    if (p.act == ISR_ACT_GATE) {
+                    if (ACT == ISR_ACT_GATE) {
                         v.x = rf.x > 0.f ? v.x : 0.f; v.y = rf.y > 0.f ? v.y : 0.f;
                         v.z = rf.z > 0.f ? v.z : 0.f; v.w = rf.w > 0.f ? v.w : 0.f;
                     } else {
@@ -432,16 +433,15 @@ __device__ __forceinline__ void conv_epilogue(const ConvParams& p, f32x16 (&acc)
 #pragma unroll
             for (int i = 0; i < 16; ++i) {
                 const int soff = (co0 + m * 32 + (i & 3) + 8 * (i >> 2)) * planeBytes;
-                float v = acc[m][r][i] + bv[m][i];
-                if (p.act == ISR_ACT_RELU) v = v > 0.f ? v : 0.f;
-                else if (p.act == ISR_ACT_LEAKY) v = v > 0.f ? v : v * p.slope;
-                if (p.act == ISR_ACT_GATE) v = rv[i] > 0.f ? v : 0.f;
+                float v = isr_activate<ACT>(acc[m][r][i] + bv[m][i], p.slope);
+                if (ACT == ISR_ACT_GATE) v = rv[i] > 0.f ? v : 0.f;
                 else v += rv[i];
                 __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), yrs, (int)pix, soff, 0);
             }
         }
     }
     }
+    });
 }
 
 // ---- forward, two workgroups per CU ------------------------------------------------------------

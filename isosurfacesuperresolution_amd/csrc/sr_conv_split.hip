@@ -699,15 +699,15 @@ __global__ __launch_bounds__(W_THREADS, 1) void conv3x3_split_wide_kernel(const 
                 bv[i] = p.bias ? p.bias[min(cur.co0 + cb * 32 + (i & 3) + 8 * (i >> 2) + 4 * h, p.Cout - 1)] : 0.0f;
             float* tr = reinterpret_cast<float*>(patch + (wave >> 2) * W_PART + slot * W_SLOT) + (wave & 3) * (32 * 32);
             const bool wide = ((p.W | p.yPlane | p.rPlane) & 3) == 0;
+            isr_with_act(p.act, [&](auto A) {                               // (one switch, not one per value: sr_split_common.h)
+            constexpr int ACT = decltype(A)::value;
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int oy = cur.oy0 + 4 * rg + r;
                 if (wide) {
 #pragma unroll
                     for (int i = 0; i < 16; ++i) {
-                        float val = acc[r][i] * unscale + bv[i];
-                        if (p.act == ISR_ACT_RELU) val = val > 0.f ? val : 0.f;
-                        else if (p.act == ISR_ACT_LEAKY) val = val > 0.f ? val : val * p.slope;
+                        float val = isr_activate<ACT>(acc[r][i] * unscale + bv[i], p.slope);
                         tr[((i & 3) + 8 * (i >> 2) + 4 * h) * 32 + j] = val;
                     }
                     __builtin_amdgcn_s_waitcnt(0xC07F);                      // lgkmcnt(0): same-wave hand-off through LDS
@@ -721,7 +721,7 @@ __global__ __launch_bounds__(W_THREADS, 1) void conv3x3_split_wide_kernel(const 
                         if (p.residual) {
                             const u32x4 rr = __builtin_amdgcn_raw_buffer_load_b128(rrs, (int)(ok ? pixoff + (unsigned)co * (unsigned)p.rPlane * 4u : BAD_OFFSET), 0, 0);
                             const float4 rf = __builtin_bit_cast(float4, rr);
-                            if (p.act == ISR_ACT_GATE) {
+                            if (ACT == ISR_ACT_GATE) {
                                 val.x = rf.x > 0.f ? val.x : 0.f; val.y = rf.y > 0.f ? val.y : 0.f;
                                 val.z = rf.z > 0.f ? val.z : 0.f; val.w = rf.w > 0.f ? val.w : 0.f;
                             } else {
@@ -739,13 +739,11 @@ __global__ __launch_bounds__(W_THREADS, 1) void conv3x3_split_wide_kernel(const 
 #pragma unroll
                     for (int i = 0; i < 16; ++i) {
                         const int co = cur.co0 + cb * 32 + (i & 3) + 8 * (i >> 2) + 4 * h;
-                        float val = acc[r][i] * unscale + bv[i];
-                        if (p.act == ISR_ACT_RELU) val = val > 0.f ? val : 0.f;
-                        else if (p.act == ISR_ACT_LEAKY) val = val > 0.f ? val : val * p.slope;
+                        float val = isr_activate<ACT>(acc[r][i] * unscale + bv[i], p.slope);
                         const bool ok = pix != BAD_OFFSET && co < p.Cout;
                         if (p.residual) {
                             const float rv = buf_load(rrs, ok ? pix + (unsigned)co * (unsigned)p.rPlane * 4u : BAD_OFFSET);
-                            if (p.act == ISR_ACT_GATE) val = rv > 0.f ? val : 0.f; else val += rv;
+                            if (ACT == ISR_ACT_GATE) val = rv > 0.f ? val : 0.f; else val += rv;
                         }
                         if (ok) wmag = isr_umax(wmag, isr_mag(val));
                         __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, val), yrs,
@@ -753,6 +751,7 @@ __global__ __launch_bounds__(W_THREADS, 1) void conv3x3_split_wide_kernel(const 
                     }
                 }
             }
+                    });
         }
         isr_range_note(p.absmax, wmag);
         wmag = 0u;
@@ -914,13 +913,13 @@ __global__ __launch_bounds__(S_THREADS, 1) void conv3x3_split_rows2_kernel(const
     float* tr = reinterpret_cast<float*>(patch) + wave * (32 * 32);
     const bool wide = ((p.W | p.yPlane | p.rPlane) & 3) == 0;
     unsigned rmag = 0u;
+    isr_with_act(p.act, [&](auto A) {                                       // (one switch, not one per value: sr_split_common.h)
+    constexpr int ACT = decltype(A)::value;
     if (wide) {
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
             const int c = (i & 3) + 8 * (i >> 2) + 4 * h;
-            float val = acc[i] * unscale + (p.bias ? p.bias[min(co0 + cb * 32 + c, p.Cout - 1)] : 0.0f);
-            if (p.act == ISR_ACT_RELU) val = val > 0.f ? val : 0.f;
-            else if (p.act == ISR_ACT_LEAKY) val = val > 0.f ? val : val * p.slope;
+            const float val = isr_activate<ACT>(acc[i] * unscale + (p.bias ? p.bias[min(co0 + cb * 32 + c, p.Cout - 1)] : 0.0f), p.slope);
             tr[c * 32 + j] = val;
         }
         __builtin_amdgcn_s_waitcnt(0xC07F);                                  // lgkmcnt(0): same-wave hand-off through LDS
@@ -934,7 +933,7 @@ __global__ __launch_bounds__(S_THREADS, 1) void conv3x3_split_rows2_kernel(const
             if (p.residual) {
                 const u32x4 rr = __builtin_amdgcn_raw_buffer_load_b128(rrs, (int)(ok ? pixoff + (unsigned)co * (unsigned)p.rPlane * 4u : BAD_OFFSET), 0, 0);
                 const float4 rf = __builtin_bit_cast(float4, rr);
-                if (p.act == ISR_ACT_GATE) {
+                if (ACT == ISR_ACT_GATE) {
                     val.x = rf.x > 0.f ? val.x : 0.f; val.y = rf.y > 0.f ? val.y : 0.f;
                     val.z = rf.z > 0.f ? val.z : 0.f; val.w = rf.w > 0.f ? val.w : 0.f;
                 } else {
@@ -951,19 +950,18 @@ __global__ __launch_bounds__(S_THREADS, 1) void conv3x3_split_rows2_kernel(const
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
             const int co = co0 + cb * 32 + (i & 3) + 8 * (i >> 2) + 4 * h;
-            float val = acc[i] * unscale + (p.bias ? p.bias[min(co, p.Cout - 1)] : 0.0f);
-            if (p.act == ISR_ACT_RELU) val = val > 0.f ? val : 0.f;
-            else if (p.act == ISR_ACT_LEAKY) val = val > 0.f ? val : val * p.slope;
+            float val = isr_activate<ACT>(acc[i] * unscale + (p.bias ? p.bias[min(co, p.Cout - 1)] : 0.0f), p.slope);
             const bool ok = pix != BAD_OFFSET && co < p.Cout;
             if (p.residual) {
                 const float rv = buf_load(rrs, ok ? pix + (unsigned)co * (unsigned)p.rPlane * 4u : BAD_OFFSET);
-                if (p.act == ISR_ACT_GATE) val = rv > 0.f ? val : 0.f; else val += rv;
+                if (ACT == ISR_ACT_GATE) val = rv > 0.f ? val : 0.f; else val += rv;
             }
             if (ok) rmag = isr_umax(rmag, isr_mag(val));
             __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, val), yrs,
                                                   ok ? (int)(pix + (unsigned)co * (unsigned)p.yPlane * 4u) : (int)BAD_OFFSET, 0, 0);
         }
     }
+    });
     isr_range_note(p.absmax, rmag);
 }
 

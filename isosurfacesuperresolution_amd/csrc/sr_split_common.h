@@ -3,6 +3,7 @@
 // translation unit gets its own copy, nothing is called across translation units (no relocatable device code).
 #pragma once
 #include "sr_diag.h"
+#include "sr_act.h"
 #include <hip/hip_runtime.h>
 #include <hip/hip_ext.h>
 #include <stdint.h>
@@ -119,17 +120,6 @@ __device__ __forceinline__ f32x16 mfma16(f16x8 a, f16x8 b, f32x16 c) { return __
 // Packed-split epilogue: act(acc 2^-S + bias) of this wave's two rows as (hi, lo') units straight from the D layout -- lane (j, h)
 // holds channels 8 g + 4 h .. + 3 of pixel j for the four groups g of a 32-channel block: 8 bytes of the unit, the lane pair
 // (j, 0), (j, 1) writes the 16, a wave instruction 512 contiguous bytes.  No LDS transposition.
-// The activation as a compile-time constant: with `p.act` tested per value the compiler kept the test -- three scalar compares and
-// taken branches around every one of a wave's 64 output values (round 6, the disassembly of the 1080p layer's epilogue: 148
-// instructions per group of four values).  The epilogues switch ONCE and run straight-line code.
-template <int ACT>
-__device__ __forceinline__ float isr_activate(float v, float slope)
-{
-    if (ACT == ISR_ACT_RELU) return v > 0.f ? v : 0.f;
-    if (ACT == ISR_ACT_LEAKY) return v > 0.f ? v : v * slope;
-    return v;
-}
-
 template <int ACT>
 __device__ __forceinline__ void split_epilogue_ps_act(const SplitConvParams& p, f32x16 (&acc)[2][2], int oy0, int ox0, int co0, bool second,
                                                       int wave, int j, int h)
