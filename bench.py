@@ -1063,7 +1063,7 @@ def fast_mode_leg(pipe, origins, Wm, K, overlap, sync):
     return {"value": n / elapsed, "unit": "frames/s", "ms_per_step": elapsed / n * 1e3, "frames": n,
             "dtype": "f16 operands, f32 accumulation and tensors (convolutions with more than 8 output channels)",
             "psnr_rgb_vs_f32_db_first": psnr[0], "psnr_rgb_vs_f32_db_min": min(psnr), "psnr_rgb_vs_f32_db_last": psnr[-1],
-            "note": "separate from `value`: not the 1e-4 parity path; the recurrence feeds its own output back, so the PSNR is that of the whole temporal sequence (random-init weights: rounding differences grow from frame to frame)"}
+            "note": "separate from `value`: not the 1e-4 parity path (and no longer faster than it: the default's dataflow trunk, packed activations and fused tail have no fp16-operand counterpart -- this leg launches the network layer by layer); the recurrence feeds its own output back, so the PSNR is that of the whole temporal sequence (random-init weights: rounding differences grow from frame to frame)"}
 
 
 def raymarch_large_leg(spec, renderer):
